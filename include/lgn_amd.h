@@ -1,0 +1,112 @@
+/*
+ * include/lgn_amd.h -- C ABI of liblgn_amd.so, the MI355X (gfx950) implementation of the LGN
+ * message-passing hot path of zichunhao/lgn-autoencoder.
+ *
+ * The reference has no FFI layer: the path sits behind the Python nn.Module API of
+ * lgn.models.LGNEncoder / LGNDecoder (lgn/models/__init__.py:1-5).  This header is the boundary the
+ * build introduces *below* that API; each entry point names the reference code it replaces.
+ *
+ * Conventions
+ *  - All pointers are DEVICE pointers owned by the caller (PyTorch); the library never allocates,
+ *    frees or retains device memory.  Tensors are contiguous in the reference's planar-complex
+ *    layouts:  scalar irrep (0,0): T[2][B][N][C];  vector irrep (1,1): T[2][B][N][C][4];
+ *    MixReps weight: T[2][C_out][C_in]  (lgn/g_lib/g_vec.py:30-48, g_weight.py:38-40).
+ *  - `stream` is a hipStream_t (0 = default stream).  Calls only enqueue work; no host sync.
+ *  - Return value: 0 success; < 0 argument/shape error detected on the host before any launch;
+ *    > 0 a hipError_t from a launch.  lgn_last_error() gives the message (thread-local).
+ *  - Suffix _f64: IEEE double arithmetic (the reference is fp64-only, lgn/cg_lib/cg_module.py:62-73).
+ *  - Parameter-gradient reductions over the batch are deterministic: kernels write per-workgroup
+ *    partial rows into caller-provided workspaces which lgn_reduce_partials_f64 sums in a fixed order.
+ */
+#ifndef LGN_AMD_H
+#define LGN_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LGN_AMD_ABI_VERSION 1
+
+int lgn_abi_version(void);
+const char* lgn_last_error(void);
+
+/* ---- message-passing level, maxdim = 2 ------------------------------------------------------
+ * Replaces, fused: RadPolyTrig.forward (lgn/nn/position_levels.py:118-209), edge = rad * zonal
+ * (lgn/models/lgn_cg.py:167; zonal functions lgn/cg_lib/zonal_functions.py:123-248),
+ * CGProduct aggregate + power (lgn/cg_lib/cg_ops.py:135-298; LGNNodeLevel.forward
+ * lgn/models/lgn_levels.py:96-121) and CatMixReps (lgn/nn/g_nn.py:260-278).
+ *
+ *  decoder = 0: p = real Cartesian momenta [B][N][4], mask = node mask [B][N] (uint8);
+ *               ra,rb,rc [20]; w0,w1 [2C][20]; b0,b1 [2C]   (Linear feature index 2c+z)
+ *  decoder = 1: p = complex canonical momenta [2][B][N][4], mask ignored (all edges masked:
+ *               lgn/models/lgn_decoder.py:335-340); only the Linear biases b0,b1 [C] are used.
+ *  wm0, wm1: CatMix weights [2][CO][5C] of irreps (0,0) and (1,1); cat order [aggregate, node, power].
+ *  outputs: ag0 [2][B][N][2C], ag1 [2][B][N][2C][4] (the aggregate CG product, kept for backward),
+ *           s_out [2][B][N][CO], v_out [2][B][N][CO][4].
+ */
+int lgn_level_fwd_f64(int B, int N, int C, int CO, int decoder,
+                      const double* s_in, const double* v_in, const double* p, const uint8_t* mask,
+                      const double* ra, const double* rb, const double* rc,
+                      const double* w0, const double* b0, const double* w1, const double* b1,
+                      const double* wm0, const double* wm1,
+                      double* ag0, double* ag1, double* s_out, double* v_out, void* stream);
+
+/* Workspace sizing for lgn_level_bwd_f64: number of partial rows written for the CatMix weights
+ * (row length 4*CO*5C) and for the radial network (row length lgn_level_rad_partial_len). */
+int lgn_level_bwd_partial_rows(int B, int N, int decoder, int* rows_mix, int* rows_rad);
+int lgn_level_rad_partial_len(int C, int decoder);
+
+/* Backward of lgn_level_fwd_f64 (autograd of the same reference functions).  Edges are recomputed.
+ *  in : forward inputs + ag0/ag1 + g_s_out [2][B][N][CO], g_v_out [2][B][N][CO][4]
+ *  out: g_s_in [2][B][N][C], g_v_in [2][B][N][C][4] (overwritten);
+ *       g_p [2][B][N][4] (decoder only; ACCUMULATED into, caller zero-initialises);
+ *       g_ag scratch [B][N][20C]; part_mix [rows_mix][4*CO*5C]; part_rad [rows_rad][rad_partial_len].
+ *  The caller then reduces the partial rows (lgn_reduce_partials_f64) and, for the encoder, converts
+ *  the reduced radial sums into parameter gradients with lgn_radial_finalize_f64.
+ */
+int lgn_level_bwd_f64(int B, int N, int C, int CO, int decoder,
+                      const double* s_in, const double* v_in, const double* p, const uint8_t* mask,
+                      const double* ra, const double* rb, const double* rc,
+                      const double* w0, const double* b0, const double* w1, const double* b1,
+                      const double* wm0, const double* wm1, const double* ag0, const double* ag1,
+                      const double* g_s_out, const double* g_v_out,
+                      double* g_ag, double* g_s_in, double* g_v_in, double* g_p,
+                      double* part_mix, double* part_rad, void* stream);
+
+/* out[n] = (accumulate ? out[n] : 0) + sum_r part[r][n], fixed summation order. */
+int lgn_reduce_partials_f64(const double* part, int rows, int n, double* out, int accumulate, void* stream);
+
+/* Encoder radial network: reduced pair sums (T1|T2|S|dB, see csrc/level_bwd.hip) -> gradients of
+ * RadPolyTrig's a, b, c [20], linear.{0,1}.weight [2C][20] and .bias [2C]
+ * (parameters of lgn/nn/position_levels.py:67-97). */
+int lgn_radial_finalize_f64(const double* tot, int C, const double* ra, const double* rb, const double* rc,
+                            const double* w0, const double* w1,
+                            double* g_a, double* g_b, double* g_c,
+                            double* g_w0, double* g_b0, double* g_w1, double* g_b1, void* stream);
+
+/* ---- CGMLP (lgn/models/lgn_levels.py:191-227) ------------------------------------------------
+ * rows M = B*N, features 2C (index 2c+z) taken from / written to the scalar irrep [2][M][C];
+ * nlin Linear layers (nn.Linear weight [out][in], bias [out]) of hidden width H, LeakyReLU(0.01)
+ * after all but the last.  w / b: host arrays of nlin device pointers. */
+int lgn_cgmlp_fwd_f64(int M, int C, int H, int nlin, const double* const* w, const double* const* b,
+                      const double* s_in, double* s_out, void* stream);
+int lgn_cgmlp_partial_rows(int M);
+/* part [rows][psize], psize = sum_l (out_l*in_l + out_l), layout concat_l (W_l, b_l). */
+int lgn_cgmlp_bwd_f64(int M, int C, int H, int nlin, const double* const* w, const double* const* b,
+                      const double* s_in, const double* g_out, double* g_in, double* part, int psize, void* stream);
+
+/* ---- MixReps (lgn/nn/g_nn.py:95-117, lgn/g_lib/cplx_lib.py:7-25) -------------------------------
+ * y[z][row][o][m] = sum_i W[o][i] x[row][i][m]   complex, d = irrep dimension. */
+int lgn_mixreps_fwd_f64(int rows, int Cin, int Cout, int d, const double* w, const double* x, double* y, void* stream);
+int lgn_mixreps_partial_rows(int rows);
+/* g_x may be NULL (input is data).  part [rows][2*Cout*Cin]. */
+int lgn_mixreps_bwd_f64(int rows, int Cin, int Cout, int d, const double* w, const double* x, const double* g_y,
+                        double* g_x, double* part, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LGN_AMD_H */

@@ -1,0 +1,139 @@
+// lgn-autoencoder_amd/csrc/api.hip -- extern "C" entry points declared in include/lgn_amd.h
+#include "level.hpp"
+#include "../../include/lgn_amd.h"
+
+namespace lgn {
+// level_fwd.hip / level_bwd.hip
+template <typename T> int level_fwd_dispatch(const LevelArgs<T>&, int, hipStream_t);
+template <typename T> int level_bwd_dispatch(const LevelBwdArgs<T>&, int, hipStream_t);
+template <typename T> int reduce_partials(const T*, int, int, T*, int, hipStream_t);
+template <typename T> int rad_finalize(const T*, int, const T*, const T*, const T*, const T*, const T*, T*, T*, T*, T*, T*, T*, T*, hipStream_t);
+void level_bwd_partial_rows(int B, int N, int decoder, int* rows_mix, int* rows_rad);
+
+// mlp.hip
+constexpr int MLP_MAX_LIN = 8;
+template <typename T>
+struct MlpArgs {
+  int M, C, H, nlin;
+  const T* w[MLP_MAX_LIN];
+  const T* b[MLP_MAX_LIN];
+  const T* s_in;
+  T* s_out;
+  const T* g_out;
+  T* g_in;
+  T* part;
+  int psize;
+};
+template <typename T> int mlp_dispatch(const MlpArgs<T>&, bool, hipStream_t);
+
+// mixreps.hip
+template <typename T>
+struct MixArgs {
+  int rows, Cin, Cout, d;
+  const T* w;
+  const T* x;
+  T* y;
+  const T* g_y;
+  T* g_x;
+  T* part;
+};
+template <typename T> int mix_fwd(const MixArgs<T>&, hipStream_t);
+template <typename T> int mix_bwd(const MixArgs<T>&, hipStream_t);
+int mix_partial_rows(int rows);
+}  // namespace lgn
+
+using namespace lgn;
+
+extern "C" {
+
+int lgn_level_fwd_f64(int B, int N, int C, int CO, int decoder, const double* s_in, const double* v_in, const double* p,
+                      const uint8_t* mask, const double* ra, const double* rb, const double* rc, const double* w0,
+                      const double* b0, const double* w1, const double* b1, const double* wm0, const double* wm1,
+                      double* ag0, double* ag1, double* s_out, double* v_out, void* stream) {
+  LGN_CHECK_ARG(s_in && v_in && p && b0 && b1 && wm0 && wm1 && ag0 && ag1 && s_out && v_out, "level_fwd: null pointer");
+  LGN_CHECK_ARG(decoder || (mask && ra && rb && rc && w0 && w1), "level_fwd: encoder needs mask and radial parameters");
+  LevelArgs<double> a{B, N, C, CO, s_in, v_in, p, mask, ra, rb, rc, w0, b0, w1, b1, wm0, wm1, ag0, ag1, s_out, v_out};
+  return level_fwd_dispatch<double>(a, decoder, (hipStream_t)stream);
+}
+
+int lgn_level_bwd_partial_rows(int B, int N, int decoder, int* rows_mix, int* rows_rad) {
+  LGN_CHECK_ARG(B > 0 && N > 0 && rows_mix && rows_rad, "level_bwd_partial_rows: bad arguments");
+  level_bwd_partial_rows(B, N, decoder, rows_mix, rows_rad);
+  return 0;
+}
+
+int lgn_level_rad_partial_len(int C, int decoder) { return rad_partial_size(C, decoder != 0); }
+
+int lgn_level_bwd_f64(int B, int N, int C, int CO, int decoder, const double* s_in, const double* v_in, const double* p,
+                      const uint8_t* mask, const double* ra, const double* rb, const double* rc, const double* w0,
+                      const double* b0, const double* w1, const double* b1, const double* wm0, const double* wm1,
+                      const double* ag0, const double* ag1, const double* g_s_out, const double* g_v_out, double* g_ag,
+                      double* g_s_in, double* g_v_in, double* g_p, double* part_mix, double* part_rad, void* stream) {
+  LGN_CHECK_ARG(s_in && v_in && p && b0 && b1 && wm0 && wm1 && ag0 && ag1 && g_s_out && g_v_out && g_ag && g_s_in &&
+                    g_v_in && part_mix && part_rad, "level_bwd: null pointer");
+  LGN_CHECK_ARG(decoder ? (g_p != nullptr) : (mask && ra && rb && rc && w0 && w1), "level_bwd: missing decoder g_p / encoder radial parameters");
+  LevelBwdArgs<double> a{B, N, C, CO, s_in, v_in, p, mask, ra, rb, rc, w0, b0, w1, b1, wm0, wm1, ag0, ag1,
+                         g_s_out, g_v_out, g_ag, g_s_in, g_v_in, g_p, part_mix, part_rad};
+  return level_bwd_dispatch<double>(a, decoder, (hipStream_t)stream);
+}
+
+int lgn_reduce_partials_f64(const double* part, int rows, int n, double* out, int accumulate, void* stream) {
+  LGN_CHECK_ARG(part && out && rows > 0 && n >= 0, "reduce_partials: bad arguments");
+  return reduce_partials<double>(part, rows, n, out, accumulate, (hipStream_t)stream);
+}
+
+int lgn_radial_finalize_f64(const double* tot, int C, const double* ra, const double* rb, const double* rc, const double* w0,
+                            const double* w1, double* g_a, double* g_b, double* g_c, double* g_w0, double* g_b0,
+                            double* g_w1, double* g_b1, void* stream) {
+  LGN_CHECK_ARG(tot && ra && rb && rc && w0 && w1 && g_a && g_b && g_c && g_w0 && g_b0 && g_w1 && g_b1 && C >= 1 && C <= 8,
+                "radial_finalize: bad arguments");
+  return rad_finalize<double>(tot, C, ra, rb, rc, w0, w1, g_a, g_b, g_c, g_w0, g_b0, g_w1, g_b1, (hipStream_t)stream);
+}
+
+static int fill_mlp(MlpArgs<double>& a, int M, int C, int H, int nlin, const double* const* w, const double* const* b) {
+  LGN_CHECK_ARG(nlin >= 1 && nlin <= MLP_MAX_LIN && w && b, "cgmlp: bad layer list (nlin=%d)", nlin);
+  a.M = M; a.C = C; a.H = H; a.nlin = nlin;
+  for (int l = 0; l < MLP_MAX_LIN; ++l) {
+    a.w[l] = l < nlin ? w[l] : nullptr;
+    a.b[l] = l < nlin ? b[l] : nullptr;
+    if (l < nlin) LGN_CHECK_ARG(w[l] && b[l], "cgmlp: null weight pointer for layer %d", l);
+  }
+  return 0;
+}
+
+int lgn_cgmlp_fwd_f64(int M, int C, int H, int nlin, const double* const* w, const double* const* b, const double* s_in,
+                      double* s_out, void* stream) {
+  MlpArgs<double> a{};
+  if (int rc = fill_mlp(a, M, C, H, nlin, w, b)) return rc;
+  LGN_CHECK_ARG(s_in && s_out, "cgmlp_fwd: null pointer");
+  a.s_in = s_in; a.s_out = s_out;
+  return mlp_dispatch<double>(a, false, (hipStream_t)stream);
+}
+
+int lgn_cgmlp_partial_rows(int M) { return (M + 63) / 64; }
+
+int lgn_cgmlp_bwd_f64(int M, int C, int H, int nlin, const double* const* w, const double* const* b, const double* s_in,
+                      const double* g_out, double* g_in, double* part, int psize, void* stream) {
+  MlpArgs<double> a{};
+  if (int rc = fill_mlp(a, M, C, H, nlin, w, b)) return rc;
+  LGN_CHECK_ARG(s_in && g_out && g_in && part, "cgmlp_bwd: null pointer");
+  a.s_in = s_in; a.g_out = g_out; a.g_in = g_in; a.part = part; a.psize = psize;
+  return mlp_dispatch<double>(a, true, (hipStream_t)stream);
+}
+
+int lgn_mixreps_fwd_f64(int rows, int Cin, int Cout, int d, const double* w, const double* x, double* y, void* stream) {
+  LGN_CHECK_ARG(w && x && y, "mixreps_fwd: null pointer");
+  MixArgs<double> a{rows, Cin, Cout, d, w, x, y, nullptr, nullptr, nullptr};
+  return mix_fwd<double>(a, (hipStream_t)stream);
+}
+
+int lgn_mixreps_partial_rows(int rows) { return mix_partial_rows(rows); }
+
+int lgn_mixreps_bwd_f64(int rows, int Cin, int Cout, int d, const double* w, const double* x, const double* g_y, double* g_x,
+                        double* part, void* stream) {
+  LGN_CHECK_ARG(w && x && g_y && part, "mixreps_bwd: null pointer");
+  MixArgs<double> a{rows, Cin, Cout, d, w, x, nullptr, g_y, g_x, part};
+  return mix_bwd<double>(a, (hipStream_t)stream);
+}
+
+}  // extern "C"

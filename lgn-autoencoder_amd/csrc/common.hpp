@@ -1,0 +1,101 @@
+// lgn-autoencoder_amd/csrc/common.hpp -- shared device/host helpers for the gfx950 kernels.
+//
+// Layout conventions (identical to the reference's planar-complex GVec layout,
+// lgn/g_lib/g_vec.py:30-48, so that level buffers can be handed back to Python as the
+// reference's `nodes_all` without a transpose):
+//   scalar irrep (0,0):  T s[2][B][N][C]
+//   vector irrep (1,1):  T v[2][B][N][C][4]      canonical basis (E, (px-i py)/rt2, pz, (-px-i py)/rt2)
+//   MixReps weight:      T w[2][C_out][C_in]
+// plane 0 = real part, plane 1 = imaginary part.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+namespace lgn {
+
+constexpr int NB = 20;          // 2 * num_basis_fn radial basis functions (position_levels.py:63)
+constexpr int BLOCK = 256;      // threads per workgroup (4 waves of 64)
+
+// ---- error plumbing -------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+#define LGN_CHECK_ARG(cond, ...)                      \
+  do {                                                \
+    if (!(cond)) {                                    \
+      lgn::set_error(__VA_ARGS__);                    \
+      return -1;                                      \
+    }                                                 \
+  } while (0)
+#define LGN_CHECK_LAUNCH()                                              \
+  do {                                                                  \
+    hipError_t e_ = hipGetLastError();                                  \
+    if (e_ != hipSuccess) {                                             \
+      lgn::set_error("HIP launch failed: %s", hipGetErrorString(e_));   \
+      return (int)e_;                                                   \
+    }                                                                   \
+  } while (0)
+
+// ---- tiny complex type living in registers ---------------------------------------------
+template <typename T>
+struct cx {
+  T r, i;
+};
+template <typename T>
+__device__ __forceinline__ cx<T> cmul(cx<T> a, cx<T> b) {
+  return {a.r * b.r - a.i * b.i, a.r * b.i + a.i * b.r};
+}
+// a * conj(b)
+template <typename T>
+__device__ __forceinline__ cx<T> cmulc(cx<T> a, cx<T> b) {
+  return {a.r * b.r + a.i * b.i, a.i * b.r - a.r * b.i};
+}
+template <typename T>
+__device__ __forceinline__ void cfma(cx<T>& acc, cx<T> a, cx<T> b) {
+  acc.r += a.r * b.r - a.i * b.i;
+  acc.i += a.r * b.i + a.i * b.r;
+}
+// acc += a * conj(b)
+template <typename T>
+__device__ __forceinline__ void cfmac(cx<T>& acc, cx<T> a, cx<T> b) {
+  acc.r += a.r * b.r + a.i * b.i;
+  acc.i += a.i * b.r - a.r * b.i;
+}
+
+template <typename T>
+__device__ __forceinline__ T shfl_xor(T v, int m) {
+  return __shfl_xor(v, m, 64);
+}
+
+// Sum over the JS consecutive lanes that share a row (JS power of two <= 64).
+template <int JS, typename T>
+__device__ __forceinline__ T group_sum(T v) {
+#pragma unroll
+  for (int m = 1; m < JS; m <<= 1) v += shfl_xor(v, m);
+  return v;
+}
+
+template <typename T>
+__device__ __forceinline__ T leaky(T x) {
+  return x > T(0) ? x : T(0.01) * x;   // nn.LeakyReLU default slope (generic_levels.py:121-122)
+}
+
+// 1/sqrt(2) used by the Cartesian <-> canonical change of basis (zonal_functions.py:266-283)
+template <typename T>
+__device__ __forceinline__ constexpr T rsqrt2() {
+  return T(0.70710678118654752440084436210484903928);
+}
+
+// signed pseudo-norm of a real Cartesian 4-vector difference, exactly as the reference forms it:
+// norm_sq = 2 E^2 - sum(p^2) + 1e-16 ; norm = norm_sq / sqrt(|norm_sq|)   (zonal_functions.py:142-144,201-218)
+template <typename T>
+__device__ __forceinline__ T signed_norm(T d0, T d1, T d2, T d3, T& nsq_out) {
+  T q0 = d0 * d0, q1 = d1 * d1, q2 = d2 * d2, q3 = d3 * d3;
+  T nsq = (T(2) * q0 - (((q0 + q1) + q2) + q3)) + T(1e-16);
+  nsq_out = nsq;
+  return nsq != T(0) ? nsq / sqrt(fabs(nsq)) : nsq;
+}
+
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+}  // namespace lgn

@@ -1,0 +1,78 @@
+// lgn-autoencoder_amd/csrc/level.hpp -- argument block + LDS carve shared by the maxdim=2 level kernels.
+//
+// One "level" = LGNNodeLevel of the reference (lgn/models/lgn_levels.py:96-121) with its edge
+// network fused in:  edge_ij = RadPolyTrig(|p_i-p_j|) * zonal(p_i-p_j)      (position_levels.py:118-209,
+//                                                                          lgn_cg.py:167)
+//                    ag_i    = sum_j CG(node_j (x) edge_ij)                 (cg_ops.py:135-298, aggregate)
+//                    sq_i    = CG(node_i (x) node_i)                        (cg_ops.py, power)
+//                    out_i   = MixReps([ag_i, node_i, sq_i])                (g_nn.py:260-278)
+// The N x N edge tensors are never written to memory.
+//
+// Closed form at maxdim = 2 (the only non-trivial CG block is
+// (1,1)x(1,1)->(0,0) = 1/2 [e00 + e13 - e22 + e31]):
+//   A1[c][m] = sum_j v_j[c][m] * e0_ij[c]            -> ag(1,1) channel c        pair ((1,1),(0,0))
+//   A2[c][m] = sum_j s_j[c]    * e1_ij[c][m]         -> ag(1,1) channel C+c      pair ((0,0),(1,1))
+//   A3[c]    = sum_j <v_j[c], e1_ij[c]>              -> ag(0,0) channel c        pair ((1,1),(1,1))
+//   A4[c]    = sum_j s_j[c]    * e0_ij[c]            -> ag(0,0) channel C+c      pair ((0,0),(0,0))
+//   e0 = R0 * (1+1i)   (zonal (0,0) is ones on BOTH planes, zonal_functions.py:150-154)
+//   e1[m] = R1 * q[m], q = canonical(p_i - p_j)
+//   <a,b> = 1/2 (a0 b0 + a1 b3 - a2 b2 + a3 b1)       (no conjugation)
+#pragma once
+#include "common.hpp"
+
+namespace lgn {
+
+template <typename T>
+struct LevelArgs {
+  int B, N, C, CO;
+  // node features entering the level
+  const T* s_in;   // [2][B][N][C]
+  const T* v_in;   // [2][B][N][C][4]
+  // positions: encoder real Cartesian [B][N][4]; decoder complex canonical [2][B][N][4]
+  const T* p;
+  const uint8_t* mask;  // encoder [B][N]; decoder: nullptr (all edges are "masked": radial == bias)
+  // radial network.  encoder: ra,rb,rc [20]; w0,w1 [2C][20]; b0,b1 [2C] (feature 2c+z).
+  //                  decoder: b0,b1 [C] only (same real bias on both planes, position_levels.py:184-188)
+  const T *ra, *rb, *rc, *w0, *b0, *w1, *b1;
+  // CatMix weights [2][CO][5C] per irrep
+  const T *wm0, *wm1;
+  // saved aggregate (needed by the backward CatMix-weight gradient) in reference layout
+  T* ag0;    // [2][B][N][2C]
+  T* ag1;    // [2][B][N][2C][4]
+  // level output before the CGMLP
+  T* s_out;  // [2][B][N][CO]
+  T* v_out;  // [2][B][N][CO][4]
+};
+
+template <typename T>
+struct LevelBwdArgs {
+  int B, N, C, CO;
+  const T *s_in, *v_in, *p;
+  const uint8_t* mask;
+  const T *ra, *rb, *rc, *w0, *b0, *w1, *b1;
+  const T *wm0, *wm1;
+  const T *ag0, *ag1;
+  // upstream gradients w.r.t. the level output (pre-MLP scalars, vectors)
+  const T* g_s_out;  // [2][B][N][CO]
+  const T* g_v_out;  // [2][B][N][CO][4]
+  // gradient of the aggregate, scratch [B][N][20C]: per node [A3(2C: c,z)][A4][A1 (C,4,2)][A2]
+  T* g_ag;
+  // outputs
+  T* g_s_in;   // [2][B][N][C]
+  T* g_v_in;   // [2][B][N][C][4]
+  T* g_p;      // decoder only: [2][B][N][4]; accumulated (+=)
+  // per-workgroup partial sums of parameter gradients, reduced by reduce_partials afterwards
+  T* part_mix;   // [nblk_mix][2*2*CO*5C]      wm0 then wm1
+  T* part_rad;   // [nblk_edge][rad_partial_size(C, decoder)]
+};
+
+// Per-node stride (in scalars) of the node tile kept in LDS: [c][ s_r s_i v_r[4] v_i[4] ] + 2 pad.
+__host__ __device__ constexpr int node_stride(int C) { return 10 * C + 2; }
+
+// encoder radial partial layout: T1[4C][20] | T2[4C][20] | S[4C] | dB[4C]
+// decoder: dB0[C] | dB1[C]
+__host__ __device__ constexpr int rad_partial_size(int C, bool dec) {
+  return dec ? 2 * C : (2 * 4 * C * NB + 8 * C);
+}
+
+}  // namespace lgn

@@ -1,0 +1,220 @@
+"""
+ctypes binding of liblgn_amd.so (C ABI: include/lgn_amd.h).
+
+This is the only place the product touches the native library.  There is NO fallback: if the
+library is missing, was built for another ABI version, or a call fails, a RuntimeError is raised.
+PyTorch is used for device memory and streams only (raw ``data_ptr()`` + the current HIP stream).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import torch  # imported before the .so so that the process-wide libamdhip64 is torch's
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_lib", "liblgn_amd.so")
+ABI_VERSION = 1
+
+_lib: Optional[C.CDLL] = None
+
+_vp, _i, _ip = C.c_void_p, C.c_int, C.POINTER(C.c_int)
+
+# name -> argtypes (all return int); mirrors include/lgn_amd.h one to one
+_SIGNATURES = {
+    "lgn_level_fwd_f64": [_i] * 5 + [_vp] * 18,
+    "lgn_level_bwd_partial_rows": [_i, _i, _i, _ip, _ip],
+    "lgn_level_rad_partial_len": [_i, _i],
+    "lgn_level_bwd_f64": [_i] * 5 + [_vp] * 24,
+    "lgn_reduce_partials_f64": [_vp, _i, _i, _vp, _i, _vp],
+    "lgn_radial_finalize_f64": [_vp, _i] + [_vp] * 13,
+    "lgn_cgmlp_fwd_f64": [_i] * 4 + [_vp] * 5,
+    "lgn_cgmlp_partial_rows": [_i],
+    "lgn_cgmlp_bwd_f64": [_i] * 4 + [_vp] * 6 + [_i, _vp],
+    "lgn_mixreps_fwd_f64": [_i] * 4 + [_vp] * 4,
+    "lgn_mixreps_partial_rows": [_i],
+    "lgn_mixreps_bwd_f64": [_i] * 4 + [_vp] * 6,
+}
+EXPORTED_SYMBOLS = ["lgn_abi_version", "lgn_last_error"] + list(_SIGNATURES)
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the native library; raises if it is absent or mismatched."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"liblgn_amd.so not found at {LIB_PATH}. Build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` or `make -C lgn-autoencoder_amd/csrc`. There is no CPU fallback.")
+        l = C.CDLL(LIB_PATH)
+        l.lgn_abi_version.restype = C.c_int
+        l.lgn_last_error.restype = C.c_char_p
+        got = l.lgn_abi_version()
+        if got != ABI_VERSION:
+            raise RuntimeError(f"liblgn_amd.so ABI version {got} != expected {ABI_VERSION}; rebuild the library")
+        for name, argtypes in _SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.argtypes = argtypes
+            fn.restype = C.c_int
+        _lib = l
+    return _lib
+
+
+def last_error() -> str:
+    return lib().lgn_last_error().decode()
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed (code {rc}): {last_error()}")
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t: Optional[torch.Tensor]):
+    """Device pointer of a contiguous CUDA/HIP tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("liblgn_amd.so operates on GPU tensors only (got a CPU tensor); there is no CPU fallback")
+    if not t.is_contiguous():
+        raise RuntimeError("non-contiguous tensor passed to the native library")
+    return t.data_ptr()
+
+
+def f64(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.float64:
+        raise RuntimeError(f"the native path is fp64 (reference precision); got {t.dtype}")
+    return t.contiguous()
+
+
+# ---------------------------------------------------------------------------------------------
+# thin wrappers (shape bookkeeping only)
+# ---------------------------------------------------------------------------------------------
+
+def level_fwd(decoder, s_in, v_in, p, mask, rad, wm0, wm1):
+    """rad = (a, b, c, w0, b0, w1, b1); returns (ag0, ag1, s_out, v_out)."""
+    _, B, N, Cc = s_in.shape
+    CO = wm0.shape[1]
+    dev, dt = s_in.device, s_in.dtype
+    ag0 = torch.empty(2, B, N, 2 * Cc, device=dev, dtype=dt)
+    ag1 = torch.empty(2, B, N, 2 * Cc, 4, device=dev, dtype=dt)
+    s_out = torch.empty(2, B, N, CO, device=dev, dtype=dt)
+    v_out = torch.empty(2, B, N, CO, 4, device=dev, dtype=dt)
+    a, b, c, w0, b0, w1, b1 = rad
+    rc = lib().lgn_level_fwd_f64(B, N, Cc, CO, int(decoder), ptr(s_in), ptr(v_in), ptr(p), ptr(mask),
+                                 ptr(a), ptr(b), ptr(c), ptr(w0), ptr(b0), ptr(w1), ptr(b1), ptr(wm0), ptr(wm1),
+                                 ptr(ag0), ptr(ag1), ptr(s_out), ptr(v_out), stream_ptr())
+    _check(rc, "lgn_level_fwd_f64")
+    return ag0, ag1, s_out, v_out
+
+
+def reduce_partials(part: torch.Tensor, out: torch.Tensor, accumulate: bool = False):
+    rows, n = part.shape
+    _check(lib().lgn_reduce_partials_f64(ptr(part), rows, n, ptr(out), int(accumulate), stream_ptr()),
+           "lgn_reduce_partials_f64")
+    return out
+
+
+def level_bwd(decoder, s_in, v_in, p, mask, rad, wm0, wm1, ag0, ag1, g_s_out, g_v_out, g_p=None):
+    """Returns (g_s_in, g_v_in, g_wm0, g_wm1, rad_grads) where rad_grads is
+    encoder: (g_a, g_b, g_c, g_w0, g_b0, g_w1, g_b1); decoder: (g_b0, g_b1).  g_p is accumulated in place."""
+    _, B, N, Cc = s_in.shape
+    CO = wm0.shape[1]
+    dev, dt = s_in.device, s_in.dtype
+    L = lib()
+    rm, rr = C.c_int(), C.c_int()
+    _check(L.lgn_level_bwd_partial_rows(B, N, int(decoder), C.byref(rm), C.byref(rr)), "lgn_level_bwd_partial_rows")
+    nmix = 4 * CO * 5 * Cc
+    nrad = L.lgn_level_rad_partial_len(Cc, int(decoder))
+    part_mix = torch.empty(rm.value, nmix, device=dev, dtype=dt)
+    part_rad = torch.empty(rr.value, nrad, device=dev, dtype=dt)
+    g_ag = torch.empty(B, N, 20 * Cc, device=dev, dtype=dt)
+    g_s_in = torch.empty_like(s_in)
+    g_v_in = torch.empty_like(v_in)
+    a, b, c, w0, b0, w1, b1 = rad
+    rc = L.lgn_level_bwd_f64(B, N, Cc, CO, int(decoder), ptr(s_in), ptr(v_in), ptr(p), ptr(mask),
+                             ptr(a), ptr(b), ptr(c), ptr(w0), ptr(b0), ptr(w1), ptr(b1), ptr(wm0), ptr(wm1),
+                             ptr(ag0), ptr(ag1), ptr(g_s_out), ptr(g_v_out), ptr(g_ag), ptr(g_s_in), ptr(g_v_in),
+                             ptr(g_p), ptr(part_mix), ptr(part_rad), stream_ptr())
+    _check(rc, "lgn_level_bwd_f64")
+    g_mix = torch.empty(nmix, device=dev, dtype=dt)
+    reduce_partials(part_mix, g_mix)
+    g_wm0 = g_mix[: nmix // 2].view(2, CO, 5 * Cc)
+    g_wm1 = g_mix[nmix // 2:].view(2, CO, 5 * Cc)
+    tot = torch.empty(nrad, device=dev, dtype=dt)
+    reduce_partials(part_rad, tot)
+    if decoder:
+        rad_grads = (tot[:Cc], tot[Cc:])
+    else:
+        g_a, g_b, g_c = (torch.empty_like(x) for x in (a, b, c))
+        g_w0, g_b0, g_w1, g_b1 = (torch.empty_like(x) for x in (w0, b0, w1, b1))
+        _check(L.lgn_radial_finalize_f64(ptr(tot), Cc, ptr(a), ptr(b), ptr(c), ptr(w0), ptr(w1), ptr(g_a), ptr(g_b),
+                                         ptr(g_c), ptr(g_w0), ptr(g_b0), ptr(g_w1), ptr(g_b1), stream_ptr()),
+               "lgn_radial_finalize_f64")
+        rad_grads = (g_a, g_b, g_c, g_w0, g_b0, g_w1, g_b1)
+    return g_s_in, g_v_in, g_wm0, g_wm1, rad_grads
+
+
+def _ptr_array(ts: Sequence[torch.Tensor]):
+    arr = (C.c_void_p * len(ts))()
+    for i, t in enumerate(ts):
+        arr[i] = ptr(t)
+    return arr
+
+
+def cgmlp_fwd(s_in, ws, bs):
+    _, B, N, Cc = s_in.shape
+    H = ws[0].shape[0]
+    s_out = torch.empty_like(s_in)
+    rc = lib().lgn_cgmlp_fwd_f64(B * N, Cc, H, len(ws), _ptr_array(ws), _ptr_array(bs), ptr(s_in), ptr(s_out), stream_ptr())
+    _check(rc, "lgn_cgmlp_fwd_f64")
+    return s_out
+
+
+def cgmlp_bwd(s_in, ws, bs, g_out):
+    """Returns (g_in, [g_w...], [g_b...])."""
+    _, B, N, Cc = s_in.shape
+    H = ws[0].shape[0]
+    L = lib()
+    rows = L.lgn_cgmlp_partial_rows(B * N)
+    psize = sum(w.numel() + b.numel() for w, b in zip(ws, bs))
+    part = torch.empty(rows, psize, device=s_in.device, dtype=s_in.dtype)
+    g_in = torch.empty_like(s_in)
+    rc = L.lgn_cgmlp_bwd_f64(B * N, Cc, H, len(ws), _ptr_array(ws), _ptr_array(bs), ptr(s_in), ptr(g_out), ptr(g_in),
+                             ptr(part), psize, stream_ptr())
+    _check(rc, "lgn_cgmlp_bwd_f64")
+    flat = torch.empty(psize, device=s_in.device, dtype=s_in.dtype)
+    reduce_partials(part, flat)
+    gws, gbs, off = [], [], 0
+    for w, b in zip(ws, bs):
+        gws.append(flat[off: off + w.numel()].view_as(w)); off += w.numel()
+        gbs.append(flat[off: off + b.numel()].view_as(b)); off += b.numel()
+    return g_in, gws, gbs
+
+
+def mixreps_fwd(w, x):
+    """w (2,Co,Ci); x (2,*batch,Ci,d) -> (2,*batch,Co,d)."""
+    Co, Ci = w.shape[1], w.shape[2]
+    d = x.shape[-1]
+    rows = x[0].numel() // (Ci * d)
+    y = torch.empty(x.shape[:-2] + (Co, d), device=x.device, dtype=x.dtype)
+    _check(lib().lgn_mixreps_fwd_f64(rows, Ci, Co, d, ptr(w), ptr(x), ptr(y), stream_ptr()), "lgn_mixreps_fwd_f64")
+    return y
+
+
+def mixreps_bwd(w, x, g_y, need_gx=True):
+    Co, Ci = w.shape[1], w.shape[2]
+    d = x.shape[-1]
+    rows = x[0].numel() // (Ci * d)
+    L = lib()
+    part = torch.empty(L.lgn_mixreps_partial_rows(rows), 2 * Co * Ci, device=x.device, dtype=x.dtype)
+    g_x = torch.empty_like(x) if need_gx else None
+    _check(L.lgn_mixreps_bwd_f64(rows, Ci, Co, d, ptr(w), ptr(x), ptr(g_y), ptr(g_x), ptr(part), stream_ptr()),
+           "lgn_mixreps_bwd_f64")
+    g_w = torch.empty_like(w)
+    reduce_partials(part, g_w.view(-1))
+    return g_x, g_w

@@ -1,0 +1,186 @@
+"""
+Autograd bindings of the native kernels + the small PyTorch glue around them.
+
+Each ``torch.autograd.Function`` forwards to one C-ABI entry point of liblgn_amd.so
+(include/lgn_amd.h) and its hand-written backward; nothing here computes the hot path in PyTorch.
+The glue that stays PyTorch is what SURVEY 8 a-13 lists as IO/pooling glue: input preparation,
+the 4x4 basis changes and the min/max latent pooling (argmin + gather).
+"""
+from math import sqrt
+
+import torch
+
+from . import _native as N
+
+
+# ---------------------------------------------------------------------------------------------
+# native ops
+# ---------------------------------------------------------------------------------------------
+
+class LevelFn(torch.autograd.Function):
+    """Fused LGNNodeLevel + edge network (csrc/level_fwd.hip, csrc/level_bwd.hip)."""
+
+    @staticmethod
+    def forward(ctx, decoder, s_in, v_in, p, mask, ra, rb, rc, w0, b0, w1, b1, wm0, wm1):
+        s_in, v_in, p = N.f64(s_in), N.f64(v_in), N.f64(p)
+        rad = tuple(N.f64(t.detach()) for t in (ra, rb, rc, w0, b0, w1, b1))
+        if decoder:
+            rad = (None, None, None, None, rad[4], None, rad[6])
+        wm0c, wm1c = N.f64(wm0.detach()), N.f64(wm1.detach())
+        ag0, ag1, s_out, v_out = N.level_fwd(decoder, s_in, v_in, p, mask, rad, wm0c, wm1c)
+        ctx.decoder = decoder
+        ctx.mask = mask
+        ctx.rad_full = (ra, rb, rc, w0, b0, w1, b1)
+        ctx.save_for_backward(s_in, v_in, p, wm0c, wm1c, ag0, ag1, *[t for t in rad if t is not None])
+        return s_out, v_out
+
+    @staticmethod
+    def backward(ctx, g_s, g_v):
+        s_in, v_in, p, wm0, wm1, ag0, ag1, *radl = ctx.saved_tensors
+        decoder = ctx.decoder
+        if decoder:
+            rad = (None, None, None, None, radl[0], None, radl[1])
+            g_p = torch.zeros_like(p)
+        else:
+            rad = tuple(radl)
+            g_p = None
+        g_s_in, g_v_in, g_wm0, g_wm1, rg = N.level_bwd(decoder, s_in, v_in, p, ctx.mask, rad, wm0, wm1, ag0, ag1,
+                                                       N.f64(g_s), N.f64(g_v), g_p)
+        ra, rb, rc, w0, b0, w1, b1 = ctx.rad_full
+        if decoder:
+            # the decoder's mask is identically zero: basis and Linear weights get exactly zero gradient
+            # (lgn/models/lgn_decoder.py:335-340, lgn/nn/position_levels.py:144-149)
+            g_rad = (torch.zeros_like(ra), torch.zeros_like(rb), torch.zeros_like(rc), torch.zeros_like(w0),
+                     rg[0].view_as(b0), torch.zeros_like(w1), rg[1].view_as(b1))
+        else:
+            g_rad = (rg[0].view_as(ra), rg[1].view_as(rb), rg[2].view_as(rc), rg[3], rg[4], rg[5], rg[6])
+        return (None, g_s_in, g_v_in, g_p, None) + g_rad + (g_wm0, g_wm1)
+
+
+class CGMLPFn(torch.autograd.Function):
+    """CGMLP on the scalar irrep (csrc/mlp.hip).  args: s_in, w_0, b_0, ..., w_L, b_L."""
+
+    @staticmethod
+    def forward(ctx, s_in, *wb):
+        s_in = N.f64(s_in)
+        ws = [N.f64(t.detach()) for t in wb[0::2]]
+        bs = [N.f64(t.detach()) for t in wb[1::2]]
+        ctx.nl = len(ws)
+        ctx.save_for_backward(s_in, *ws, *bs)
+        return N.cgmlp_fwd(s_in, ws, bs)
+
+    @staticmethod
+    def backward(ctx, g_out):
+        s_in, *rest = ctx.saved_tensors
+        ws, bs = rest[:ctx.nl], rest[ctx.nl:]
+        g_in, gws, gbs = N.cgmlp_bwd(s_in, ws, bs, N.f64(g_out))
+        out = [g_in]
+        for gw, gb in zip(gws, gbs):
+            out += [gw, gb]
+        return tuple(out)
+
+
+class MixFn(torch.autograd.Function):
+    """MixReps: y = W x per irrep (csrc/mixreps.hip)."""
+
+    @staticmethod
+    def forward(ctx, w, x):
+        w, x = N.f64(w.detach()), N.f64(x)
+        ctx.save_for_backward(w, x)
+        ctx.need_gx = x.requires_grad
+        return N.mixreps_fwd(w, x)
+
+    @staticmethod
+    def backward(ctx, g_y):
+        w, x = ctx.saved_tensors
+        g_x, g_w = N.mixreps_bwd(w, x, N.f64(g_y), need_gx=ctx.need_gx)
+        return g_w, g_x
+
+
+# ---------------------------------------------------------------------------------------------
+# PyTorch glue (tiny, O(N) per jet): basis changes and pooling
+# ---------------------------------------------------------------------------------------------
+_H = 1.0 / sqrt(2.0)
+
+
+def normsq4(p):
+    """Minkowski square as the reference forms it: 2 E^2 - sum p^2 (zonal_functions.py:201-218)."""
+    sq = p * p
+    return 2 * sq[..., 0] - sq.sum(dim=-1)
+
+
+def cart_to_canonical_real(p):
+    """real (...,4) -> planar complex canonical (2,...,4)   (p_to_rep, zonal_functions.py:251-289)."""
+    e, px, py, pz = p.unbind(-1)
+    zero = torch.zeros_like(e)
+    re = torch.stack([e, px * _H, pz, -px * _H], -1)
+    im = torch.stack([zero, -py * _H, zero, -py * _H], -1)
+    return torch.stack([re, im], 0)
+
+
+def cart_to_canonical_cplx(p):
+    """complex Cartesian (2,...,4) -> complex canonical (2,...,4)  (p_cplx_to_rep, zonal_functions.py:292-341)."""
+    (er, xr, yr, zr), (ei, xi, yi, zi) = p[0].unbind(-1), p[1].unbind(-1)
+    # c1 = (px - i py)/rt2, c3 = (-px - i py)/rt2
+    re = torch.stack([er, (xr + yi) * _H, zr, (-xr + yi) * _H], -1)
+    im = torch.stack([ei, (xi - yr) * _H, zi, (-xi - yr) * _H], -1)
+    return torch.stack([re, im], 0)
+
+
+def canonical_to_cart(c):
+    """complex canonical (2,...,4) -> complex Cartesian (2,...,4)  (rep_to_p, zonal_functions.py:344-381):
+    E = c0, px = (c1 - c3)/rt2, py = i (c1 + c3)/rt2, pz = c2."""
+    (c0r, c1r, c2r, c3r), (c0i, c1i, c2i, c3i) = c[0].unbind(-1), c[1].unbind(-1)
+    re = torch.stack([c0r, (c1r - c3r) * _H, -(c1i + c3i) * _H, c2r], -1)
+    im = torch.stack([c0i, (c1i - c3i) * _H, (c1r + c3r) * _H, c2i], -1)
+    return torch.stack([re, im], 0)
+
+
+def _msq(f):
+    return f[..., 0] ** 2 - (f[..., 1:] ** 2).sum(-1)
+
+
+def _take_particle(feature, idx):
+    """feature (2,B,N,T,d), idx (2,B,T) -> (2,B,1,T,d): per (plane, jet, channel) pick one particle."""
+    fp = feature.permute(0, 1, 3, 2, 4)
+    ix = idx.unsqueeze(-1).unsqueeze(-1).expand(fp.shape[:3] + (1, fp.shape[-1]))
+    return torch.gather(fp, 3, ix).permute(0, 1, 3, 2, 4)
+
+
+def pool_min(feature):
+    """get_min_features (lgn_encoder.py:540-558): arg-min of the value (d=1) or of E^2-|p|^2 (d=4), taken
+    independently on the re and im planes; padded particles are not excluded."""
+    score = feature[..., 0] if feature.shape[-1] == 1 else _msq(feature)
+    return _take_particle(feature, torch.min(score.detach(), dim=-2).indices)
+
+
+def pool_max(feature):
+    """get_max_features (lgn_encoder.py:561-583): the index is always taken from E^2-|p|^2, which for d=1
+    is the *square* of the value."""
+    return _take_particle(feature, torch.max(_msq(feature).detach(), dim=-2).indices)
+
+
+def aggregate_latent(method, lat):
+    """aggregate() of lgn/models/lgn_encoder.py:419-496 on a dict {(k,n): (2,B,N,T,d)}."""
+    m = method.lower()
+    if m == "sum":
+        return {k: torch.sum(v, dim=-3, keepdim=True).unsqueeze(dim=-3) for k, v in lat.items()}
+    if m in ("mean", "average"):
+        return {k: torch.mean(v, dim=-3, keepdim=True) for k, v in lat.items()}
+    if m == "max":
+        return {k: pool_max(v) for k, v in lat.items()}
+    if m == "min":
+        return {k: pool_min(v) for k, v in lat.items()}
+    if m == "mix":
+        return lat
+    if "+" in m:
+        if "mix" in m:
+            raise NotImplementedError("Adding with mix aggregation not implemented yet.")
+        parts = [aggregate_latent(x, lat) for x in method.split("+")]
+        return {k: sum(p[k] for p in parts) / len(parts) for k in lat}
+    if "&" in method:
+        if "mix" in m:
+            raise NotImplementedError("Concatenating with mix aggregation not implemented yet.")
+        parts = [aggregate_latent(x, lat) for x in method.split("&")]
+        return {k: torch.cat([p[k] for p in parts], dim=3) for k in lat}
+    raise NotImplementedError(f"{method} is not implemented.")

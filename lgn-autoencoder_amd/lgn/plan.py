@@ -1,0 +1,145 @@
+"""
+Static layout of the message-passing levels: which irreps a level carries, in which order, and
+which (source, r1, r2) blocks make up the channel axis of every CatMix input.
+
+The reference never states this layout: it emerges from Python dict / set iteration order
+(lgn/cg_lib/cg_ops.py:179-215, lgn/g_lib/g_torch.py:203-214, lgn/g_lib/parameter_dict_new.py:14-15,
+lgn/models/lgn_levels.py:210,224).  Checkpoints written by the reference are only loadable if the
+same layout is reproduced, so the bookkeeping below replays the same constructions (dict insertion
+order + the ``set`` of parameter keys) and tests/test_host.py pins the outcome to the fixtures.
+"""
+from dataclasses import dataclass, field
+from typing import Dict, List, Sequence, Tuple
+
+Irrep = Tuple[int, int]
+
+
+def param_key_order(keys_in_registration_order: Sequence[Irrep]) -> List[Irrep]:
+    """Order in which a MixReps emits its parts: iteration order of
+    ``set(map(eval, parameter_names))`` (parameter_dict_new.py:14-15, g_torch.py:238-241)."""
+    names = [str(k) for k in keys_in_registration_order]
+    out = []
+    for item in set(map(_parse, names)):
+        out.append(item)
+    return out
+
+
+def _parse(name: str) -> Irrep:
+    a, b = name.strip("() ").split(",")
+    return (int(a), int(b))
+
+
+def product_tau(tau1: Dict[Irrep, int], tau2: Dict[Irrep, int], maxdim: int) -> Dict[Irrep, int]:
+    """cg_product_tau (lgn/cg_lib/cg_ops_tau.py:6-44), including its dict insertion order."""
+    out: Dict[Irrep, int] = {}
+    for (k1, n1), t1 in tau1.items():
+        for (k2, n2), t2 in tau2.items():
+            if max(k1, n1, k2, n2) >= maxdim:
+                continue
+            for k in range(abs(k1 - k2), min(k1 + k2, maxdim - 1) + 1, 2):
+                for n in range(abs(n1 - n2), min(n1 + n2, maxdim - 1) + 1, 2):
+                    out[(k, n)] = out.get((k, n), 0) + t1 * t2
+    return out
+
+
+def cg_tau_out(tau1: Dict[Irrep, int], tau2: Dict[Irrep, int], maxdim: int) -> Dict[Irrep, int]:
+    """CGProduct.tau_out (lgn/cg_lib/cg_ops.py:99-111): channels x number of contributing pairs."""
+    ones1 = {k: int(v > 0) for k, v in tau1.items()}
+    ones2 = {k: int(v > 0) for k, v in tau2.items()}
+    chans = set([t for t in tau1.values() if t > 0] + [t for t in tau2.values() if t > 0])
+    if len(chans) != 1:
+        raise ValueError(f"CG products need the same number of channels in every part, got {tau1} x {tau2}")
+    nchan = chans.pop()
+    return {k: nchan * t for k, t in product_tau(ones1, ones2, maxdim).items()}
+
+
+def cat_tau(taus: Sequence[Dict[Irrep, int]], maxdim: int) -> Dict[Irrep, int]:
+    """CatReps.tau_out (lgn/nn/g_nn.py:150-158)."""
+    out: Dict[Irrep, int] = {}
+    for tau in taus:
+        for key, val in tau.items():
+            if val > 0 and max(key) <= maxdim - 1:
+                out[key] = out.get(key, 0) + val
+    return out
+
+
+@dataclass
+class LevelPlan:
+    channels_in: int
+    channels_out: int
+    node_order: List[Irrep]                 # run-time order of the incoming node GVec
+    tau_in: Dict[Irrep, int]                # bookkeeping dicts (insertion order matters)
+    tau_edge: Dict[Irrep, int]
+    tau_ag: Dict[Irrep, int]
+    tau_sq: Dict[Irrep, int]
+    tau_cat: Dict[Irrep, int]
+    tau_out: Dict[Irrep, int]               # == CatMix parameter registration order
+    out_order: List[Irrep] = field(default_factory=list)   # order of the level's output GVec
+    # per output irrep: channel blocks of the CatMix input, in order: (source, r1, r2)
+    cat_blocks: Dict[Irrep, List[Tuple[str, Irrep, Irrep]]] = field(default_factory=dict)
+
+
+def _product_blocks(order1: Sequence[Irrep], order2: Sequence[Irrep], maxdim: int, tag: str):
+    """Replay the pair loop of cg_product (cg_ops.py:163-215) on key orders only."""
+    maxk1 = max(k for k, _ in order1); maxn1 = max(n for _, n in order1)
+    maxk2 = max(k for k, _ in order2); maxn2 = max(n for _, n in order2)
+    max_dim = min(max(maxk1 + maxk2, maxn1 + maxn2) + 1, maxdim)
+    blocks: Dict[Irrep, List[Tuple[str, Irrep, Irrep]]] = {}
+    for (k1, n1) in order1:
+        for (k2, n2) in order2:
+            if max(k1, n1, k2, n2) > max_dim - 1:
+                continue
+            for k in range(abs(k1 - k2), min(maxdim, k1 + k2 + 1), 2):
+                for n in range(abs(n1 - n2), min(maxdim, n1 + n2 + 1), 2):
+                    blocks.setdefault((k, n), []).append((tag, (k1, n1), (k2, n2)))
+    return blocks
+
+
+def build_level_plans(num_channels: Sequence[int], maxdim: Sequence[int], max_zf: Sequence[int], mlp: bool,
+                      tau_node_in: Dict[Irrep, int], node_order_in: Sequence[Irrep]) -> List[LevelPlan]:
+    """Bookkeeping of LGNCG.__init__ (lgn/models/lgn_cg.py:79-110) + LGNNodeLevel.__init__
+    (lgn/models/lgn_levels.py:52-94) + the run-time key orders."""
+    plans: List[LevelPlan] = []
+    tau = dict(tau_node_in)
+    order = list(node_order_in)
+    for lvl in range(len(num_channels) - 1):
+        md = maxdim[lvl]
+        tau_edge = {(l, l): num_channels[lvl] for l in range(max_zf[lvl] + 1)}
+        tau_sq = cg_tau_out(tau, tau, md)
+        tau_ag = cg_tau_out(tau, tau_edge, md)
+        tau_cat = cat_tau([tau_ag, tau, tau_sq], md)
+        tau_out = {k: num_channels[lvl + 1] for k, v in tau_cat.items() if v}
+        out_order = param_key_order(list(tau_out.keys()))
+        if mlp:   # CGMLP pops (0,0) and re-inserts it last (lgn_levels.py:210,224)
+            out_order = [k for k in out_order if k != (0, 0)] + [(0, 0)]
+        ag = _product_blocks(order, list(tau_edge.keys()), md, "ag")
+        sq = _product_blocks(order, order, md, "sq")
+        cat_blocks = {}
+        for key in tau_cat:
+            blocks = list(ag.get(key, []))
+            if key in order:
+                blocks.append(("node", key, key))
+            blocks += sq.get(key, [])
+            cat_blocks[key] = blocks
+            assert len(blocks) * num_channels[lvl] == tau_cat[key], (key, blocks, tau_cat)
+        plans.append(LevelPlan(num_channels[lvl], num_channels[lvl + 1], list(order), dict(tau), tau_edge, tau_ag,
+                               tau_sq, tau_cat, tau_out, out_order, cat_blocks))
+        tau = dict(tau_out)        # lgn_cg.py:105 hands the CatMix dict (not the GVec order) to the next level
+        order = out_order
+    return plans
+
+
+# the only layout the maxdim=2 fused kernels implement (SURVEY 8 a-3'); asserted at construction time
+MAXDIM2_BLOCKS = {
+    (1, 1): [("ag", (1, 1), (0, 0)), ("ag", (0, 0), (1, 1)), ("node", (1, 1), (1, 1)),
+             ("sq", (1, 1), (0, 0)), ("sq", (0, 0), (1, 1))],
+    (0, 0): [("ag", (1, 1), (1, 1)), ("ag", (0, 0), (0, 0)), ("node", (0, 0), (0, 0)),
+             ("sq", (1, 1), (1, 1)), ("sq", (0, 0), (0, 0))],
+}
+
+
+def check_maxdim2_layout(plan: LevelPlan):
+    got = {k: plan.cat_blocks[k] for k in plan.cat_blocks}
+    if got != MAXDIM2_BLOCKS or plan.node_order != [(1, 1), (0, 0)]:
+        raise RuntimeError(f"unexpected maxdim=2 CatMix layout {got} / node order {plan.node_order}; "
+                           "the fused kernels assume SURVEY 8 a-3'")

@@ -1,0 +1,236 @@
+"""GPU parity tests (run with -m gpu on an MI355X): every native entry point is called through the
+C ABI (ctypes -> liblgn_amd.so) and compared with the oracle on the same seeded inputs, and the full
+networks are compared with the golden vectors captured from the reference.
+Tolerances: fp64 arithmetic, relative to max|ref|; 1e-11 forward, 1e-9 gradients (sums over up to
+B*N*N = 460k terms in a different order than the CPU BLAS)."""
+import pytest
+import torch
+
+import _util as U
+
+pytestmark = pytest.mark.gpu
+
+FWD_TOL = 1e-11
+GRAD_TOL = 1e-9
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the GPU box"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import lgn_oracle
+    return lgn_oracle
+
+
+def _rand_level_params(O, C, CO, decoder, g):
+    cfg = O.NetConfig(num_channels=(C, CO))
+    P = {}
+    torch.manual_seed(int(torch.randint(0, 10000, (1,), generator=g)))
+    O._init_radial(P, cfg, decoder)
+    tau0 = {(0, 0): C, (1, 1): C}
+    plans = O.build_level_plans(cfg, tau0)
+    O._init_levels(P, cfg, plans)
+    # make every parameter O(1) so that all gradient paths are exercised
+    for k in P:
+        if "cat_mix" in k:
+            P[k] = torch.randn(P[k].shape, dtype=torch.float64, generator=g) * 0.3
+    return cfg, plans, P
+
+
+@pytest.mark.parametrize("decoder", [False, True])
+@pytest.mark.parametrize("C,CO,N,B", [(3, 3, 30, 3), (3, 4, 30, 2), (4, 4, 30, 2), (4, 3, 30, 2), (4, 4, 7, 2),
+                                      (2, 5, 33, 2), (4, 4, 70, 1), (1, 1, 1, 1)])
+def test_level_fwd_bwd(dev, O, decoder, C, CO, N, B):
+    from lgn import ops
+    g = torch.Generator().manual_seed(100 * C + 10 * CO + N + int(decoder))
+    cfg, plans, P = _rand_level_params(O, C, CO, decoder, g)
+    P = {k: v.requires_grad_(True) for k, v in P.items()}
+    node = {(1, 1): torch.randn(2, B, N, C, 4, dtype=torch.float64, generator=g).requires_grad_(True),
+            (0, 0): torch.randn(2, B, N, C, 1, dtype=torch.float64, generator=g).requires_grad_(True)}
+    if decoder:
+        p = torch.randn(2, B, N, 4, dtype=torch.float64, generator=g).requires_grad_(True)
+        zonal, norms, _ = O.zonal_rel(p, p, "canonical")
+        mask = None
+        emask = torch.zeros(2, B, N, N, dtype=torch.float64)
+    else:
+        p4, labels = O.synthetic_jets(B, N, seed=N + C, pad=N > 4)
+        p, mask = p4, labels
+        zonal, norms, _ = O.zonal_rel(p, p, "cartesian")
+        em = mask.unsqueeze(1) * mask.unsqueeze(2)
+        emask = em * (norms != 0).byte()
+    rad = O.radial_filters(P, cfg, 0, norms, emask, decoder)
+    edge = {k: O.scalar_times_irrep(rad[k], zonal[k]) for k in rad}
+    out = O.node_level(P, O.get_cg(2), cfg, 0, plans[0], node, edge)
+    cot = {k: torch.randn(v.shape, dtype=torch.float64, generator=g) for k, v in out.items()}
+    sum((out[k] * cot[k]).sum() for k in out).backward()
+
+    # native
+    d = lambda t: t.detach().to(dev).requires_grad_(t.requires_grad)  # noqa: E731
+    s_in = d(node[(0, 0)].squeeze(-1).detach().requires_grad_(True))
+    v_in = d(node[(1, 1)])
+    pd = d(p)
+    pre = "rad_funcs.rad_funcs.0."
+    names = ["a", "b", "c", "linear.0.weight", "linear.0.bias", "linear.1.weight", "linear.1.bias"]
+    radp = [d(P[pre + n]) for n in names]
+    wm0 = d(P["lgn_cg.node_levels.0.cat_mix.mix_reps.weights.(0, 0)"])
+    wm1 = d(P["lgn_cg.node_levels.0.cat_mix.mix_reps.weights.(1, 1)"])
+    s_out, v_out = ops.LevelFn.apply(decoder, s_in, v_in, pd, None if decoder else mask.to(dev), *radp, wm0, wm1)
+    U.assert_close(s_out.unsqueeze(-1), out[(0, 0)], FWD_TOL, "s_out")
+    U.assert_close(v_out, out[(1, 1)], FWD_TOL, "v_out")
+    ((s_out.unsqueeze(-1) * cot[(0, 0)].to(dev)).sum() + (v_out * cot[(1, 1)].to(dev)).sum()).backward()
+    U.assert_close(s_in.grad.unsqueeze(-1), node[(0, 0)].grad, GRAD_TOL, "g_s_in")
+    U.assert_close(v_in.grad, node[(1, 1)].grad, GRAD_TOL, "g_v_in")
+    if decoder:
+        U.assert_close(pd.grad, p.grad, GRAD_TOL, "g_p")
+    for n, t in zip(names, radp):
+        ref = P[pre + n].grad
+        ref = torch.zeros_like(P[pre + n]) if ref is None else ref
+        if ref.abs().max() == 0:
+            assert t.grad is None or t.grad.abs().max() == 0, f"{n} must have exactly zero gradient"
+        else:
+            U.assert_close(t.grad, ref, GRAD_TOL, "g_" + n)
+    U.assert_close(wm0.grad, P["lgn_cg.node_levels.0.cat_mix.mix_reps.weights.(0, 0)"].grad, GRAD_TOL, "g_wm0")
+    U.assert_close(wm1.grad, P["lgn_cg.node_levels.0.cat_mix.mix_reps.weights.(1, 1)"].grad, GRAD_TOL, "g_wm1")
+
+
+@pytest.mark.parametrize("C,B,N", [(3, 2, 30), (4, 3, 30), (4, 1, 150), (2, 1, 5), (6, 1, 40)])
+def test_cgmlp(dev, O, C, B, N):
+    from lgn import ops
+    g = torch.Generator().manual_seed(C * 7 + N)
+    cfg = O.NetConfig(num_channels=(C, C))
+    P = {}
+    torch.manual_seed(C)
+    plans = O.build_level_plans(cfg, {(0, 0): C, (1, 1): C})
+    O._init_levels(P, cfg, plans)
+    P = {k: v.requires_grad_(True) for k, v in P.items() if "mlp" in k}
+    s = torch.randn(2, B, N, C, 1, dtype=torch.float64, generator=g).requires_grad_(True)
+    node = {(1, 1): torch.zeros(2, B, N, C, 4, dtype=torch.float64), (0, 0): s}
+    out = O.cg_mlp(P, cfg, 0, node)[(0, 0)]
+    cot = torch.randn(out.shape, dtype=torch.float64, generator=g)
+    (out * cot).sum().backward()
+
+    sd = s.detach().squeeze(-1).to(dev).requires_grad_(True)
+    flat = []
+    for i in range(7):
+        flat += [P[f"lgn_cg.mlp_levels.0.linear.{i}.weight"].detach().to(dev).requires_grad_(True),
+                 P[f"lgn_cg.mlp_levels.0.linear.{i}.bias"].detach().to(dev).requires_grad_(True)]
+    y = ops.CGMLPFn.apply(sd, *flat)
+    U.assert_close(y.unsqueeze(-1), out, FWD_TOL, "mlp out")
+    (y.unsqueeze(-1) * cot.to(dev)).sum().backward()
+    U.assert_close(sd.grad.unsqueeze(-1), s.grad, GRAD_TOL, "mlp g_in")
+    for i in range(7):
+        U.assert_close(flat[2 * i].grad, P[f"lgn_cg.mlp_levels.0.linear.{i}.weight"].grad, GRAD_TOL, f"g_w{i}")
+        U.assert_close(flat[2 * i + 1].grad, P[f"lgn_cg.mlp_levels.0.linear.{i}.bias"].grad, GRAD_TOL, f"g_b{i}")
+
+
+@pytest.mark.parametrize("rows,Ci,Co,d", [((2, 30), 1, 3, 4), ((2, 30), 4, 8, 4), ((5, 1), 16, 30, 4), ((3, 7), 4, 1, 1),
+                                          ((700,), 3, 2, 4)])
+def test_mixreps(dev, O, rows, Ci, Co, d):
+    from lgn import ops
+    g = torch.Generator().manual_seed(Ci * 31 + Co)
+    w = torch.randn(2, Co, Ci, dtype=torch.float64, generator=g).requires_grad_(True)
+    x = torch.randn((2,) + rows + (Ci, d), dtype=torch.float64, generator=g).requires_grad_(True)
+    y = O.mix_weight_vec(w, x)
+    cot = torch.randn(y.shape, dtype=torch.float64, generator=g)
+    (y * cot).sum().backward()
+    wd, xd = w.detach().to(dev).requires_grad_(True), x.detach().to(dev).requires_grad_(True)
+    yd = ops.MixFn.apply(wd, xd)
+    U.assert_close(yd, y, FWD_TOL, "mix y")
+    (yd * cot.to(dev)).sum().backward()
+    U.assert_close(wd.grad, w.grad, GRAD_TOL, "mix g_w")
+    U.assert_close(xd.grad, x.grad, GRAD_TOL, "mix g_x")
+
+
+def _build(meta, dev):
+    import __graft_entry__ as G
+    enc, dec = G._models(meta["N"], meta["ch_enc"], meta["ch_dec"], dev, seed=meta["seed"])
+    return enc, dec
+
+
+@pytest.mark.parametrize("name", ["g1_e2e_maxdim2.npz", "g3_e2e_n150.npz"])
+def test_end_to_end_vs_reference_golden(dev, O, name):
+    """Full encoder -> decoder -> Chamfer forward/backward against vectors captured from the reference."""
+    z = U.load(name)
+    m = U.meta(z)
+    enc, dec = _build(m, dev)
+    # same seed => same initial weights as the reference; load the fixture weights anyway (checkpoint path)
+    enc.load_state_dict({k: v for k, v in U.params_from(z, "enc").items()})
+    dec.load_state_dict({k: v for k, v in U.params_from(z, "dec").items()})
+    p4 = torch.from_numpy(z["p4"]); labels = torch.from_numpy(z["labels"])
+    batch = {"p4": p4, "labels": labels}
+
+    latent, nodes_all = enc(batch, covariance_test=True)
+    U.assert_rep_close(dict(latent.items()), U.rep_from(z, "latent"), FWD_TOL, "latent")
+    n_enc = len(nodes_all)
+    for i, rep in enumerate(nodes_all):
+        U.assert_rep_close(dict(rep.items()), U.rep_from(z, f"enc_nodes.{i}"), FWD_TOL, f"enc_nodes[{i}]")
+    gen, nodes_all = dec(latent, covariance_test=True, nodes_all=nodes_all)
+    for i, rep in enumerate(nodes_all[n_enc:]):
+        U.assert_rep_close(dict(rep.items()), U.rep_from(z, f"dec_nodes.{i}"), FWD_TOL, f"dec_nodes[{i}]")
+
+    rec = dec(enc(batch))
+    U.assert_close(rec, z["recon"], FWD_TOL, "recon")
+    loss = O.chamfer_loss(rec[0] + rec[1], p4.to(dev))
+    U.assert_close(loss, z["loss_chamfer"], FWD_TOL, "chamfer")
+    loss.backward()
+    for pre, mod in (("enc", enc), ("dec", dec)):
+        for k, p in mod.named_parameters():
+            ref = torch.from_numpy(z[f"grad.{pre}.{k}"])
+            got = p.grad if p.grad is not None else torch.zeros_like(p)
+            if ref.abs().max() == 0:
+                assert got.abs().max() == 0, f"{pre}.{k} must have exactly zero gradient"
+            else:
+                U.assert_close(got, ref, GRAD_TOL, f"grad {pre}.{k}")
+
+
+def test_full_size_batch_properties(dev, O):
+    """BASELINE cfg2 size (bs=512, N=30): jets are independent graphs, so (1) any jet's output inside the big
+    batch equals its output in a batch of its own, (2) permuting the jets permutes the outputs, and
+    (3) parameter gradients of the batch equal the sum of gradients of its two halves (the loss is a sum)."""
+    import __graft_entry__ as G
+    enc, dec = G._models(30, (3, 3, 4, 4), (4, 4, 3, 3), dev, seed=5)
+    p4, labels = O.synthetic_jets(512, 30, seed=9, pad=True)
+    p4d = p4.to(dev)
+
+    def run(idx):
+        for m in (enc, dec):
+            m.zero_grad()
+        rec = dec(enc({"p4": p4[idx], "labels": labels[idx]}))
+        loss = O.chamfer_loss(rec[0] + rec[1], p4d[idx.to(dev)])
+        loss.backward()
+        grads = torch.cat([p.grad.flatten() for m in (enc, dec) for p in m.parameters()])
+        return rec.detach(), loss.detach(), grads
+
+    all_idx = torch.arange(512)
+    rec, loss, grads = run(all_idx)
+    assert torch.isfinite(rec).all() and torch.isfinite(grads).all()
+    sub = torch.tensor([0, 17, 255, 511])
+    rec_s, _, _ = run(sub)
+    assert (rec[:, sub.to(dev)] - rec_s).abs().max().item() <= 1e-13 * rec.abs().max().item()
+    perm = torch.randperm(512, generator=torch.Generator().manual_seed(1))
+    rec_p, loss_p, grads_p = run(perm)
+    assert (rec[:, perm.to(dev)] - rec_p).abs().max().item() <= 1e-13 * rec.abs().max().item()
+    U.assert_close(loss_p, loss, 1e-12, "loss under jet permutation")
+    U.assert_close(grads_p, grads, 1e-9, "grads under jet permutation")
+    _, l1, g1 = run(all_idx[:256])
+    _, l2, g2 = run(all_idx[256:])
+    U.assert_close(l1 + l2, loss, 1e-12, "loss additivity")
+    U.assert_close(g1 + g2, grads, 1e-9, "gradient additivity over jets")
+
+
+def test_bad_arguments_fail_loudly(dev):
+    """Host-side argument checks: negative return code surfaced as RuntimeError, no launch."""
+    from lgn import _native as N
+    s = torch.zeros(2, 1, 4, 9, device=dev, dtype=torch.float64)      # C = 9 unsupported
+    v = torch.zeros(2, 1, 4, 9, 4, device=dev, dtype=torch.float64)
+    p = torch.zeros(2, 1, 4, 4, device=dev, dtype=torch.float64)
+    b = torch.zeros(9, device=dev, dtype=torch.float64)
+    w = torch.zeros(2, 2, 45, device=dev, dtype=torch.float64)
+    with pytest.raises(RuntimeError, match="unsupported"):
+        N.level_fwd(True, s, v, p, None, (None, None, None, None, b, None, b), w, w)
+    with pytest.raises(RuntimeError, match="CPU"):
+        N.mixreps_fwd(torch.zeros(2, 1, 1, dtype=torch.float64), torch.zeros(2, 3, 1, 1, dtype=torch.float64))

@@ -1,0 +1,119 @@
+"""CPU-side tests of the product's host logic (no GPU compute): the C-ABI library loads and exports
+every symbol include/lgn_amd.h declares, CG tables / layout plans / module tree match the reference's
+fixtures, and the product refuses to run without a GPU."""
+import os
+import re
+
+import pytest
+import torch
+
+import _util as U
+
+ROOT = U.ROOT
+
+
+def test_library_exports_every_declared_symbol():
+    from lgn import _native
+    if not os.path.exists(_native.LIB_PATH):
+        import __graft_entry__ as G
+        G.build()
+    lib = _native.lib()
+    header = open(os.path.join(ROOT, "include", "lgn_amd.h")).read()
+    declared = set(re.findall(r"\b(lgn_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    for sym in declared:
+        assert hasattr(lib, sym), f"liblgn_amd.so does not export {sym}"
+    assert set(_native.EXPORTED_SYMBOLS) == declared
+    assert lib.lgn_abi_version() == _native.ABI_VERSION
+
+
+def test_host_side_argument_errors_need_no_gpu():
+    from lgn import _native
+    lib = _native.lib()
+    rc = lib.lgn_level_fwd_f64(1, 1, 1, 1, 0, *([None] * 18))
+    assert rc < 0 and b"null" in lib.lgn_last_error()
+    rc = lib.lgn_reduce_partials_f64(None, 0, 0, None, 0, None)
+    assert rc < 0
+
+
+def test_cg_tables_match_reference_dump():
+    from lgn.cg_lib import CGDict
+    z = U.load("g5_tables.npz")
+    cg = CGDict(maxdim=3)
+    n = 0
+    for (r1, r2), entry in cg.items():
+        for r, mat in entry.items():
+            U.assert_close(mat, z[f"cg.{r1}.{r2}.{r}"], 2e-15, f"cg {r1}x{r2}->{r}")
+            n += 1
+    assert n == len([k for k in z.files if k.startswith("cg.")])
+
+
+def _models(meta):
+    import __graft_entry__ as G
+    return G._models(meta["N"], meta["ch_enc"], meta["ch_dec"], torch.device("cpu"), seed=meta["seed"])
+
+
+def test_module_tree_and_init_match_reference():
+    z = U.load("g1_e2e_maxdim2.npz")
+    enc, dec = _models(U.meta(z))
+    for mod, pre in ((enc, "enc"), (dec, "dec")):
+        ref = U.params_from(z, pre)
+        sd = mod.state_dict()
+        assert list(sd.keys()) == list(ref.keys()), "state_dict keys / order differ from the reference"
+        for k in ref:
+            assert tuple(sd[k].shape) == tuple(ref[k].shape)
+            assert torch.equal(sd[k], ref[k]), f"same seed must give the reference's initial {k}"
+        mod.load_state_dict(ref)
+    assert enc.num_learnable_parameters == 34146 and dec.num_learnable_parameters == 29342
+    assert enc.cg_dict is dec.cg_dict and enc.maxdim == 2
+    assert float(enc.l1_norm() + dec.l1_norm()) == pytest.approx(float(z["l1_norm"]), rel=1e-13)
+
+
+def test_layout_plan_matches_reference_key_orders():
+    from lgn.plan import MAXDIM2_BLOCKS, build_level_plans, param_key_order
+    z = U.load("g1_e2e_maxdim2.npz")
+    enc, dec = _models(U.meta(z))
+    import json
+    for i, plan in enumerate(enc.plans):
+        want = [tuple(k) for k in json.loads(str(z[f"enc_nodes.{i}.__keys__"]))]
+        assert plan.node_order == want
+        assert plan.cat_blocks == MAXDIM2_BLOCKS
+    assert enc.plans[-1].out_order == [tuple(k) for k in json.loads(str(z["enc_nodes.3.__keys__"]))]
+    # maxdim=3 bookkeeping (SURVEY 8 a-3'): node key order and the number of contributing pairs
+    z3 = U.load("g2_e2e_maxdim3.npz")
+    tau0 = {(0, 0): 4, (1, 1): 4}
+    plans = build_level_plans([4, 4, 6, 6], [3, 3, 3], [1, 1, 1], True, tau0, param_key_order(list(tau0)))
+    for i, plan in enumerate(plans):
+        assert plan.node_order == [tuple(k) for k in json.loads(str(z3[f"enc_nodes.{i}.__keys__"]))]
+    assert plans[-1].out_order == [tuple(k) for k in json.loads(str(z3["enc_nodes.3.__keys__"]))]
+    assert [b[1:] for b in plans[1].cat_blocks[(1, 1)] if b[0] == "ag"] == \
+        [((1, 1), (0, 0)), ((2, 0), (1, 1)), ((0, 2), (1, 1)), ((2, 2), (1, 1)), ((0, 0), (1, 1))]
+    assert len([b for b in plans[1].cat_blocks[(2, 2)] if b[0] == "sq"]) == 10
+    for key, ref in U.params_from(z3, "enc").items():
+        mm = re.match(r"lgn_cg\.node_levels\.(\d)\.cat_mix\.mix_reps\.weights\.\((\d), (\d)\)", key)
+        if mm:
+            lvl, k = int(mm.group(1)), (int(mm.group(2)), int(mm.group(3)))
+            assert ref.shape[2] == plans[lvl].tau_cat[k] == len(plans[lvl].cat_blocks[k]) * plans[lvl].channels_in
+
+
+def test_no_cpu_fallback():
+    z = U.load("g1_e2e_maxdim2.npz")
+    enc, dec = _models(U.meta(z))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        enc(torch.from_numpy(z["p4"]))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        dec(U.rep_from(z, "latent"))
+
+
+def test_glue_matches_reference_geometry_and_pooling():
+    """The PyTorch glue around the kernels (basis changes, pooling) against the reference's vectors."""
+    from lgn import ops
+    z = U.load("g4_ops.npz")
+    p = torch.from_numpy(z["geo.p"]); pc = torch.from_numpy(z["geo.pc"])
+    U.assert_close(ops.cart_to_canonical_real(p).unsqueeze(-2), z["geo.p_to_rep"], 1e-15)
+    U.assert_close(ops.cart_to_canonical_cplx(pc), z["geo.p_cplx_to_rep"], 1e-15)
+    U.assert_close(ops.canonical_to_cart(pc), z["geo.rep_to_p"], 1e-15)
+    U.assert_close(ops.normsq4(p), z["geo.normsq4"], 1e-15)
+    lat = U.rep_from(z, "pool.in")
+    for method in ("min", "max", "min&max", "mean", "sum", "min+max"):
+        U.assert_rep_close(ops.aggregate_latent(method, lat), U.rep_from(z, f"pool.{method}"), 1e-15, method)
