@@ -106,7 +106,9 @@ _H = 1.0 / sqrt(2.0)
 def normsq4(p):
     """Minkowski square as the reference forms it: 2 E^2 - sum p^2 (zonal_functions.py:201-218)."""
     sq = p * p
-    return 2 * sq[..., 0] - sq.sum(dim=-1)
+    # explicit left-to-right sum: the order of the reference's CPU reduction (GPU reductions may differ,
+    # and for near-massless particles the cancellation amplifies a 1-ulp difference to ~1e-9)
+    return 2 * sq[..., 0] - (((sq[..., 0] + sq[..., 1]) + sq[..., 2]) + sq[..., 3])
 
 
 def cart_to_canonical_real(p):
@@ -137,7 +139,8 @@ def canonical_to_cart(c):
 
 
 def _msq(f):
-    return f[..., 0] ** 2 - (f[..., 1:] ** 2).sum(-1)
+    """get_msq (lgn_encoder.py:499-505)."""
+    return f[..., 0] ** 2 - torch.norm(f[..., 1:], dim=-1) ** 2
 
 
 def _take_particle(feature, idx):

@@ -202,7 +202,8 @@ def test_full_size_batch_properties(dev, O):
         rec = dec(enc({"p4": p4[idx], "labels": labels[idx]}))
         loss = O.chamfer_loss(rec[0] + rec[1], p4d[idx.to(dev)])
         loss.backward()
-        grads = torch.cat([p.grad.flatten() for m in (enc, dec) for p in m.parameters()])
+        grads = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).flatten()
+                           for m in (enc, dec) for p in m.parameters()])
         return rec.detach(), loss.detach(), grads
 
     all_idx = torch.arange(512)
