@@ -651,13 +651,34 @@ __global__ __launch_bounds__(BLOCK) void level_bwd_rad_dec_kernel(LevelBwdArgs<T
 // =========================================================================================
 // deterministic reduction of per-workgroup partial rows:  out[n] (+)= sum_blk part[blk][n]
 // =========================================================================================
+// 64 columns x 16 row-groups per workgroup: every column is summed by 16 threads (fixed row interleave),
+// then the 16 partial sums are combined in a fixed order through LDS -> bitwise reproducible.
+constexpr int RED_RG = 16;
 template <typename T>
-__global__ void reduce_partials_kernel(const T* part, int nblk, int n, T* out, int accumulate) {
-  const int col = blockIdx.x * blockDim.x + threadIdx.x;
-  if (col >= n) return;
-  T s = T(0);
-  for (int r = 0; r < nblk; ++r) s += part[(size_t)r * n + col];
-  out[col] = accumulate ? out[col] + s : s;
+__global__ __launch_bounds__(64 * RED_RG) void reduce_partials_kernel(const T* __restrict__ part, int nblk, int n, T* out,
+                                                                      int accumulate) {
+  __shared__ T red[RED_RG][64];
+  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + cl;
+  T s0 = T(0), s1 = T(0), s2 = T(0), s3 = T(0);
+  if (col < n) {
+    int r = rg;
+    for (; r + 3 * RED_RG < nblk; r += 4 * RED_RG) {
+      s0 += part[(size_t)r * n + col];
+      s1 += part[(size_t)(r + RED_RG) * n + col];
+      s2 += part[(size_t)(r + 2 * RED_RG) * n + col];
+      s3 += part[(size_t)(r + 3 * RED_RG) * n + col];
+    }
+    for (; r < nblk; r += RED_RG) s0 += part[(size_t)r * n + col];
+  }
+  red[rg][cl] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (rg == 0 && col < n) {
+    T s = T(0);
+#pragma unroll
+    for (int q = 0; q < RED_RG; ++q) s += red[q][cl];
+    out[col] = accumulate ? out[col] + s : s;
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -751,7 +772,7 @@ int level_bwd_dispatch(const LevelBwdArgs<T>& a, int decoder, hipStream_t stream
 template <typename T>
 int reduce_partials(const T* part, int nblk, int n, T* out, int accumulate, hipStream_t stream) {
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(reduce_partials_kernel<T>, dim3(cdiv(n, 64)), dim3(64), 0, stream, part, nblk, n, out, accumulate);
+  hipLaunchKernelGGL(reduce_partials_kernel<T>, dim3(cdiv(n, 64)), dim3(64 * RED_RG), 0, stream, part, nblk, n, out, accumulate);
   LGN_CHECK_LAUNCH();
   return 0;
 }

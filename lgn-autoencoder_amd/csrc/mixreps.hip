@@ -62,23 +62,50 @@ __global__ void mix_bwd_x_kernel(MixArgs<T> a) {
 }
 
 // partial dW[o][i] over a chunk of rows:  sum_rows sum_m g_y[row][o][m] conj(x[row][i][m])
+// Two regimes: many weights (latent_to_graph: C_out = N) -> one thread per weight, serial over the chunk;
+// few weights (input / output mixing over B*N rows) -> all threads split the chunk's (row, m) products of one
+// weight and combine them with wave shuffles + LDS (fixed order -> reproducible).
 template <typename T>
-__global__ void mix_bwd_w_kernel(MixArgs<T> a) {
+__global__ __launch_bounds__(BLOCK) void mix_bwd_w_kernel(MixArgs<T> a) {
+  __shared__ T red[2][BLOCK / 64];
   const int wi = a.Cout * a.Cin;
   const size_t px = (size_t)a.rows * a.Cin * a.d, py = (size_t)a.rows * a.Cout * a.d;
   const int r0 = blockIdx.x * MIX_RCH;
   const int r1 = min(a.rows, r0 + MIX_RCH);
   T* part = a.part + (size_t)blockIdx.x * 2 * wi;
-  for (int e = threadIdx.x; e < wi; e += blockDim.x) {
+  if (wi > 64) {
+    for (int e = threadIdx.x; e < wi; e += blockDim.x) {
+      const int o = e / a.Cin, i = e - o * a.Cin;
+      cx<T> acc = {T(0), T(0)};
+      for (int row = r0; row < r1; ++row)
+        for (int m = 0; m < a.d; ++m) {
+          const size_t ye = ((size_t)row * a.Cout + o) * a.d + m, xe = ((size_t)row * a.Cin + i) * a.d + m;
+          cfmac(acc, cx<T>{a.g_y[ye], a.g_y[py + ye]}, cx<T>{a.x[xe], a.x[px + xe]});
+        }
+      part[e] = acc.r;
+      part[wi + e] = acc.i;
+    }
+    return;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nel = (r1 - r0) * a.d;
+  for (int e = 0; e < wi; ++e) {
     const int o = e / a.Cin, i = e - o * a.Cin;
     cx<T> acc = {T(0), T(0)};
-    for (int row = r0; row < r1; ++row)
-      for (int m = 0; m < a.d; ++m) {
-        const size_t ye = ((size_t)row * a.Cout + o) * a.d + m, xe = ((size_t)row * a.Cin + i) * a.d + m;
-        cfmac(acc, cx<T>{a.g_y[ye], a.g_y[py + ye]}, cx<T>{a.x[xe], a.x[px + xe]});
-      }
-    part[e] = acc.r;
-    part[wi + e] = acc.i;
+    for (int q = threadIdx.x; q < nel; q += BLOCK) {
+      const int row = r0 + q / a.d, m = q % a.d;
+      const size_t ye = ((size_t)row * a.Cout + o) * a.d + m, xe = ((size_t)row * a.Cin + i) * a.d + m;
+      cfmac(acc, cx<T>{a.g_y[ye], a.g_y[py + ye]}, cx<T>{a.x[xe], a.x[px + xe]});
+    }
+    acc.r = group_sum<64>(acc.r);
+    acc.i = group_sum<64>(acc.i);
+    if (lane == 0) { red[0][wave] = acc.r; red[1][wave] = acc.i; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      part[e] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+      part[wi + e] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    }
+    __syncthreads();
   }
 }
 

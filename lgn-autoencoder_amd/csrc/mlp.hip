@@ -256,12 +256,18 @@ static int launch_mlp(const MlpArgs<T>& a, bool backward, hipStream_t stream) {
   return 0;
 }
 
+int mlp_mfma_dispatch(const MlpArgs<double>& a, bool backward, hipStream_t stream);   // mlp_mfma.hip
+
 template <typename T>
 int mlp_dispatch(const MlpArgs<T>& a, bool backward, hipStream_t stream) {
   LGN_CHECK_ARG(a.M > 0 && a.C > 0, "cgmlp: empty input (M=%d C=%d)", a.M, a.C);
   LGN_CHECK_ARG(a.nlin == 7, "cgmlp: only mlp_depth=6 (7 Linear layers) is built, got %d", a.nlin);
   LGN_CHECK_ARG(a.H >= 2 * a.C && a.H <= 96, "cgmlp: hidden width %d unsupported (2C..96)", a.H);
   if (backward) LGN_CHECK_ARG((size_t)a.psize == mlp_param_count(a.C, a.H, a.nlin), "cgmlp: psize mismatch");
+  {  // matrix-core path for H <= 48; the VALU kernels below cover wider MLPs
+    const int rc = mlp_mfma_dispatch(a, backward, stream);
+    if (rc != -2) return rc;
+  }
   const int opt = cdiv(a.H, 4);
   if (opt <= 3) return launch_mlp<T, 3>(a, backward, stream);
   if (opt <= 6) return launch_mlp<T, 6>(a, backward, stream);

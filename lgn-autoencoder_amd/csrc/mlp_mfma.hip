@@ -1,0 +1,322 @@
+// lgn-autoencoder_amd/csrc/mlp_mfma.hip -- CGMLP forward / backward on the fp64 matrix cores.
+//
+// Same operator as csrc/mlp.hip (reference: CGMLP.forward, lgn/models/lgn_levels.py:191-227), for hidden
+// widths H <= 48 (all BASELINE maxdim=2 configs: H = 6 * 2C, C <= 4).  Each Linear is a
+// [rows x Hin] x [Hin x Hout] GEMM executed with v_mfma_f64_16x16x4_f64 (D(16x16) += A(16x4) B(4x16)):
+//   A: lane l holds A[i = l&15][k = l>>4]      B: lane l holds B[k = l>>4][j = l&15]
+//   D: lane l, register r holds D[i = (l>>4) + 4r][j = l&15]          (probed: csrc/probes/mfma_probe.hip)
+// A workgroup owns 64 rows; each of its 4 waves owns a 16-row M-tile and all N-tiles of the layer.
+// Activations stay wave-private: D fragments are written to a padded [row][neuron] LDS tile and read back
+// as A fragments of the next layer (row stride == 2 mod 4 scalars -> conflict-free ds_read_b64).
+// Layer weights are staged row-major [out][in] in LDS (same padded stride), double buffered, the next
+// layer's weights prefetched into registers while the current layer's MFMAs run.
+//
+// Backward (recompute, hidden activations kept in registers in D layout):
+//   g_in  = g_pre W        A = g_pre tile,            B = W[o][k] read "transposed" from the same LDS image
+//   dW    = g_pre^T h_in   A = g_pre tile^T, B = h_in tile, K = the workgroup's 64 rows; the (o,k) output tiles
+//                          are dealt round-robin to the 4 waves, which store them into this workgroup's
+//                          partial row (reduced deterministically by reduce_partials afterwards)
+//   db    = column sums of g_pre (two wave shuffles + a 4-wave LDS reduction)
+#include "common.hpp"
+
+namespace lgn {
+
+constexpr int MLP_MAX_LIN = 8;
+template <typename T>
+struct MlpArgs {
+  int M, C, H, nlin;
+  const T* w[MLP_MAX_LIN];
+  const T* b[MLP_MAX_LIN];
+  const T* s_in;
+  T* s_out;
+  const T* g_out;
+  T* g_in;
+  T* part;
+  int psize;
+};
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+__host__ __device__ constexpr int pad4(int x) { return (x + 3) & ~3; }
+__host__ __device__ constexpr int pad16(int x) { return (x + 15) & ~15; }
+// smallest stride >= x with stride == 2 (mod 4): 16 rows x 2 k's of a ds_read_b64 group hit 32 distinct bank pairs
+__host__ __device__ constexpr int lds_stride(int x) { return x + ((6 - (x & 3)) & 3); }
+
+template <int NT>
+struct Geo {
+  static constexpr int HP = NT * 16;                  // padded hidden width
+  static constexpr int S = lds_stride(HP);            // row stride of weight image and activation tiles
+  static constexpr int NPF = (HP * HP + BLOCK - 1) / BLOCK;   // prefetch registers per thread
+  static constexpr int WSIZE = HP * S;                // one weight image
+  static constexpr int TSIZE = 16 * S;                // one 16-row activation tile
+};
+
+// ---- weight staging ------------------------------------------------------------------------------
+template <int NT>
+__device__ __forceinline__ void prefetch_weights(const double* __restrict__ W, int Hout, int Hin, double (&regs)[Geo<NT>::NPF]) {
+  const int HoP = pad16(Hout), KP = pad16(Hin);      // zero-pad both ways (k padding feeds MFMA zeros)
+#pragma unroll
+  for (int i = 0; i < Geo<NT>::NPF; ++i) {
+    const int e = threadIdx.x + BLOCK * i;
+    const int o = e / KP, k = e - o * KP;
+    regs[i] = (e < HoP * KP && o < Hout && k < Hin) ? W[(size_t)o * Hin + k] : 0.0;
+  }
+}
+template <int NT>
+__device__ __forceinline__ void commit_weights(double* Wl, int Hout, int Hin, const double (&regs)[Geo<NT>::NPF]) {
+  const int HoP = pad16(Hout), KP = pad16(Hin);
+#pragma unroll
+  for (int i = 0; i < Geo<NT>::NPF; ++i) {
+    const int e = threadIdx.x + BLOCK * i;
+    const int o = e / KP, k = e - o * KP;
+    if (e < HoP * KP) Wl[o * Geo<NT>::S + k] = regs[i];
+  }
+}
+
+// ---- one dense layer on a wave's 16-row tile:  acc[t] (D layout) = bias + X W^T ---------------------
+template <int NT>
+__device__ __forceinline__ void dense_tile(const double* Xt, const double* Wl, const double* __restrict__ bias, int Hin,
+                                           int Hout, int lane, v4d (&acc)[NT]) {
+  constexpr int S = Geo<NT>::S;
+  const int c = lane & 15, g = lane >> 4;
+  const int nt = (Hout + 15) >> 4;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const double bv = (t < nt && 16 * t + c < Hout) ? bias[16 * t + c] : 0.0;
+    acc[t] = v4d{bv, bv, bv, bv};
+  }
+  const int ks = pad4(Hin) >> 2;
+  for (int s = 0; s < ks; ++s) {
+    const double a = Xt[c * S + 4 * s + g];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+      if (t < nt) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Wl[(16 * t + c) * S + 4 * s + g], acc[t], 0, 0, 0);
+  }
+}
+
+// D-layout registers -> [row][neuron] tile (all NT tiles; padded neurons carry exact zeros)
+template <int NT>
+__device__ __forceinline__ void store_tile(double* Xt, const v4d (&v)[NT], int lane) {
+  constexpr int S = Geo<NT>::S;
+  const int c = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Xt[(g + 4 * r) * S + 16 * t + c] = v[t][r];
+}
+
+// rows of the scalar irrep [2][M][C] -> wave tile, feature k = 2c + z, zero padded to 16 columns
+template <int NT>
+__device__ __forceinline__ void load_input_tile(const double* __restrict__ s, int M, int C, int row0, double* Xt, int lane) {
+  constexpr int S = Geo<NT>::S;
+  const int D = 2 * C;
+  for (int e = lane; e < 16 * 16; e += 64) {
+    const int r = e >> 4, k = e & 15, row = row0 + r;
+    Xt[r * S + k] = (row < M && k < D) ? s[(size_t)(k & 1) * M * C + (size_t)row * C + (k >> 1)] : 0.0;
+  }
+}
+
+template <int NT, int NH>
+__global__ __launch_bounds__(BLOCK) void mlp_fwd_mfma_kernel(MlpArgs<double> a) {
+  using G = Geo<NT>;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int D = 2 * a.C, H = a.H, M = a.M;
+  const int row0 = blockIdx.x * 64 + wave * 16;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  double* Wl = reinterpret_cast<double*>(smem_raw);          // 2 weight images
+  double* Xt = Wl + 2 * G::WSIZE + wave * G::TSIZE;          // this wave's activation tile
+
+  double regs[G::NPF];
+  prefetch_weights<NT>(a.w[0], H, D, regs);
+  load_input_tile<NT>(a.s_in, M, a.C, row0, Xt, lane);
+  commit_weights<NT>(Wl, H, D, regs);
+  __syncthreads();
+#pragma unroll
+  for (int l = 0; l <= NH; ++l) {
+    const int Hin = l == 0 ? D : H, Hout = l == NH ? D : H;
+    double* Wcur = Wl + (l & 1) * G::WSIZE;
+    if (l < NH) prefetch_weights<NT>(a.w[l + 1], l + 1 == NH ? D : H, H, regs);
+    v4d acc[NT];
+    dense_tile<NT>(Xt, Wcur, a.b[l], Hin, Hout, lane, acc);
+    if (l < NH) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[t][r] = leaky(acc[t][r]);
+      store_tile<NT>(Xt, acc, lane);
+      commit_weights<NT>(Wl + ((l + 1) & 1) * G::WSIZE, l + 1 == NH ? D : H, H, regs);
+      __syncthreads();
+    } else {
+      const int c = lane & 15, g = lane >> 4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = row0 + g + 4 * r;
+        if (c < D && row < M) a.s_out[(size_t)(c & 1) * M * a.C + (size_t)row * a.C + (c >> 1)] = acc[0][r];
+      }
+    }
+  }
+}
+
+template <int NT, int NH>
+__global__ __launch_bounds__(BLOCK) void mlp_bwd_mfma_kernel(MlpArgs<double> a) {
+  using G = Geo<NT>;
+  constexpr int S = G::S;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  const int D = 2 * a.C, H = a.H, M = a.M;
+  const int row0 = blockIdx.x * 64 + wave * 16;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  double* Wl = reinterpret_cast<double*>(smem_raw);          // 2 weight images
+  double* Xall = Wl + 2 * G::WSIZE;                          // 4 waves x layer-input tile
+  double* Gall = Xall + 4 * G::TSIZE;                        // 4 waves x g_pre tile
+  double* X0all = Gall + 4 * G::TSIZE;                       // 4 waves x MLP input tile (16 columns)
+  double* dbw = X0all + 4 * 16 * S;                          // 4 waves x HP column sums
+  double* Xt = Xall + wave * G::TSIZE;
+  double* Gt = Gall + wave * G::TSIZE;
+  double* X0t = X0all + wave * 16 * S;
+  double* part = a.part + (size_t)blockIdx.x * a.psize;
+
+  // ---- forward recompute; h[l] = post-activation of hidden layer l in D layout -----------------------
+  double regs[G::NPF];
+  prefetch_weights<NT>(a.w[0], H, D, regs);
+  load_input_tile<NT>(a.s_in, M, a.C, row0, X0t, lane);
+  for (int e = lane; e < 16 * 16; e += 64) Xt[(e >> 4) * S + (e & 15)] = X0t[(e >> 4) * S + (e & 15)];
+  commit_weights<NT>(Wl, H, D, regs);
+  __syncthreads();
+  v4d h[NH][NT];
+#pragma unroll
+  for (int l = 0; l < NH; ++l) {
+    const int Hin = l == 0 ? D : H;
+    double* Wcur = Wl + (l & 1) * G::WSIZE;
+    // the weights of the next forward layer; after the last hidden layer: the output layer (first backward layer)
+    prefetch_weights<NT>(a.w[l + 1], l + 1 == NH ? D : H, H, regs);
+    dense_tile<NT>(Xt, Wcur, a.b[l], Hin, H, lane, h[l]);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) h[l][t][r] = leaky(h[l][t][r]);
+    if (l + 1 < NH) store_tile<NT>(Xt, h[l], lane);
+    commit_weights<NT>(Wl + ((l + 1) & 1) * G::WSIZE, l + 1 == NH ? D : H, H, regs);
+    __syncthreads();
+  }
+
+  // ---- backward sweep ----------------------------------------------------------------------------
+  v4d gpre[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) gpre[t] = v4d{0, 0, 0, 0};
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = row0 + g + 4 * r;
+    gpre[0][r] = (c < D && row < M) ? a.g_out[(size_t)(c & 1) * M * a.C + (size_t)row * a.C + (c >> 1)] : 0.0;
+  }
+  size_t poff_end = a.psize;
+#pragma unroll
+  for (int l = NH; l >= 0; --l) {
+    const int Hin = l == 0 ? D : H, Hout = l == NH ? D : H;
+    const int nto = (Hout + 15) >> 4, nti = (Hin + 15) >> 4;
+    poff_end -= (size_t)Hout * Hin + Hout;
+    double* pW = part + poff_end;
+    double* pB = pW + (size_t)Hout * Hin;
+    double* Wcur = Wl + (l & 1) * G::WSIZE;                   // image of W_l (staged by the previous iteration)
+    if (l > 0) prefetch_weights<NT>(a.w[l - 1], H, l - 1 == 0 ? D : H, regs);
+
+    // operands of this layer to LDS: g_pre tile and layer-input tile (h[l-1]; the MLP input for l == 0)
+    store_tile<NT>(Gt, gpre, lane);
+    if (l > 0) store_tile<NT>(Xt, h[l > 0 ? l - 1 : 0], lane);
+    // bias gradient: column sums over this wave's 16 rows
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      double v = (gpre[t][0] + gpre[t][1]) + (gpre[t][2] + gpre[t][3]);
+      v += shfl_xor(v, 16);
+      v += shfl_xor(v, 32);
+      if (g == 0) dbw[wave * G::HP + 16 * t + c] = v;
+    }
+    __syncthreads();
+
+    // (a) g_in = g_pre W  (own rows), kept in registers for the next (lower) layer
+    v4d gin[NT];
+#pragma unroll
+    for (int u = 0; u < NT; ++u) gin[u] = v4d{0, 0, 0, 0};
+    {
+      const int ks = pad4(Hout) >> 2;
+      for (int s = 0; s < ks; ++s) {
+        const double av = Gt[c * S + 4 * s + g];
+#pragma unroll
+        for (int u = 0; u < NT; ++u)
+          if (u < nti) gin[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Wcur[(4 * s + g) * S + 16 * u + c], gin[u], 0, 0, 0);
+      }
+    }
+    // (b) dW tiles over the workgroup's 64 rows, dealt round-robin to the waves
+    {
+      const double* Xsrc = l > 0 ? Xall : X0all;
+      const int xts = l > 0 ? G::TSIZE : 16 * S;
+      for (int tile = wave; tile < nto * nti; tile += 4) {
+        const int t = tile / nti, u = tile - t * nti;
+        v4d acc = v4d{0, 0, 0, 0};
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const double av = Gall[w * G::TSIZE + (4 * s + g) * S + 16 * t + c];
+            const double bv = Xsrc[w * xts + (4 * s + g) * S + 16 * u + c];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+          }
+        // D[i = o][j = k]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int o = 16 * t + g + 4 * r, k = 16 * u + c;
+          if (o < Hout && k < Hin) pW[(size_t)o * Hin + k] = acc[r];
+        }
+      }
+      for (int o = tid; o < Hout; o += BLOCK)
+        pB[o] = (dbw[o] + dbw[G::HP + o]) + (dbw[2 * G::HP + o] + dbw[3 * G::HP + o]);
+    }
+    // next layer down
+    if (l > 0) {
+#pragma unroll
+      for (int u = 0; u < NT; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gpre[u][r] = gin[u][r] * (h[l > 0 ? l - 1 : 0][u][r] > 0.0 ? 1.0 : 0.01);
+      __syncthreads();                       // everyone is done with Wcur / the tiles
+      commit_weights<NT>(Wl + ((l - 1) & 1) * G::WSIZE, H, l - 1 == 0 ? D : H, regs);
+      // (the g_pre / input tiles are rewritten at the top of the next iteration, followed by a barrier)
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = row0 + g + 4 * r;
+        if (c < D && row < M) a.g_in[(size_t)(c & 1) * M * a.C + (size_t)row * a.C + (c >> 1)] = gin[0][r];
+      }
+    }
+  }
+}
+
+template <int NT>
+static int launch_mlp_mfma(const MlpArgs<double>& a, bool backward, hipStream_t stream) {
+  using G = Geo<NT>;
+  constexpr int NH = 6;
+  const int nblk = cdiv(a.M, 64);
+  if (!backward) {
+    size_t smem = sizeof(double) * (2 * G::WSIZE + 4 * G::TSIZE);
+    auto kern = mlp_fwd_mfma_kernel<NT, NH>;
+    if (smem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL(kern, dim3(nblk), dim3(BLOCK), smem, stream, a);
+  } else {
+    size_t smem = sizeof(double) * (2 * G::WSIZE + 8 * G::TSIZE + 4 * 16 * G::S + 4 * G::HP);
+    auto kern = mlp_bwd_mfma_kernel<NT, NH>;
+    if (smem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL(kern, dim3(nblk), dim3(BLOCK), smem, stream, a);
+  }
+  LGN_CHECK_LAUNCH();
+  return 0;
+}
+
+// H <= 48, 2C <= 16, 7 Linear layers.  Returns -2 if the shape is outside this kernel's range.
+int mlp_mfma_dispatch(const MlpArgs<double>& a, bool backward, hipStream_t stream) {
+  if (a.nlin != 7 || a.H > 48 || 2 * a.C > 16 || a.H < 2 * a.C) return -2;
+  const int nt = (a.H + 15) / 16;
+  if (nt == 1) return launch_mlp_mfma<1>(a, backward, stream);
+  if (nt == 2) return launch_mlp_mfma<2>(a, backward, stream);
+  return launch_mlp_mfma<3>(a, backward, stream);
+}
+
+}  // namespace lgn
