@@ -135,6 +135,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=BATCH, help="jets per GPU (default: BASELINE cfg2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--harness", choices=["native", "native-nograph", "modular"], default="native",
+                    help="native: one C call per step replayed from a HIP graph (default); modular: nn.Module + autograd path")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -149,9 +151,13 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     import __graft_entry__ as G
-    from lgn.step import TrainStep
+    from lgn.step import NativeTrainStep, TrainStep
     enc, dec = G._models(N_PART, CH_ENC, CH_DEC, dev, seed=0)      # identical replicas on every rank
-    trainer = TrainStep(enc, dec, lr=5e-4, l1_lambda=1e-8)
+    if args.harness == "modular":
+        trainer = TrainStep(enc, dec, lr=5e-4, l1_lambda=1e-8)
+    else:
+        trainer = NativeTrainStep(enc, dec, batch_size=args.batch, lr=5e-4, l1_lambda=1e-8,
+                                  use_graph=args.harness == "native")
     p4, labels = synthetic_jets(args.batch, N_PART, seed=rank)     # per-rank shard, resident in HBM
     batch = {"p4": p4.to(dev), "labels": labels.to(dev)}
 
@@ -189,7 +195,8 @@ def main():
             "config": {"workload": "cfg2: synthetic 30-particle jets, maxdim=2, enc 3-3-4-4 / dec 4-4-3-3, tau-latent 1s/8v, "
                                    "min&max, chamfer + 1e-8 L1, fwd+bwd+Adam, zero-padded Nobj~U{10..30}",
                        "jets_per_gpu": args.batch, "global_batch": args.batch * world, "particles": N_PART,
-                       "parallelism": f"dp{world}" + (" (one RCCL all-reduce of the flat gradient per step)" if world > 1 else "")},
+                       "parallelism": f"dp{world}" + (" (one RCCL all-reduce of the flat gradient per step)" if world > 1 else ""),
+                       "harness": args.harness},
             "roofline": {"bound": "mfma", "pipe": "fp64 vector ALU (same peak as fp64 MFMA on MI355X; the kernel is "
                                                    "FMA-bound, neither HBM- nor matrix-core-bound)",
                          "kernel": dom["kernel"], "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",

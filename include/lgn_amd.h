@@ -106,6 +106,39 @@ int lgn_mixreps_partial_rows(int rows);
 int lgn_mixreps_bwd_f64(int rows, int Cin, int Cout, int d, const double* w, const double* x, const double* g_y,
                         double* g_x, double* part, void* stream);
 
+/* ---- whole training step, maxdim = 2 (utils/train.py:283-343 inner loop) ---------------------------
+ * One call enqueues encoder -> decoder -> get_real('sum') -> Chamfer -> full backward (~80 launches, no host
+ * sync, all buffers caller-owned and static => capturable in a HIP graph).  Parameters of both networks
+ * live in ONE flat buffer `params`; gradients are written into `grads` at the same offsets (the call zero-
+ * fills `grads` first; parameters that cannot receive gradient keep an exact 0).
+ * Offsets (in elements) are given per slot, in this order (L = n_levels, nlin = mlp_nlin):
+ *   encoder: input_func_node (0,0),(1,1) | per level: a,b,c,linear.0.weight,.bias,linear.1.weight,.bias |
+ *            per level: cat_mix (0,0),(1,1) | per level: linear.0.weight,.bias ... linear.{nlin-1} | mix_reps (0,0),(1,1)
+ *   decoder: latent_to_graph (0,0),(1,1) | input_func_node (0,0),(1,1) | radial | cat_mix | mlp | mix_to_output (0,0),(1,1)
+ * Pooling is 'min&max' (lgn/models/lgn_encoder.py:419-583); the decoder consumes 2*tau_v latent vectors.
+ */
+typedef struct lgn_net_desc {
+  int B, N;
+  int n_levels;            /* message-passing levels per network (<= 4) */
+  int enc_channels[5];     /* n_levels + 1 entries */
+  int dec_channels[5];
+  int tau_s, tau_v;        /* encoder latent multiplicities before the min&max concatenation */
+  int mlp_hidden_mul;      /* CGMLP hidden width = mlp_hidden_mul * 2C  (reference: mlp_width) */
+  int mlp_nlin;            /* Linear layers per CGMLP (mlp_depth + 1) */
+} lgn_net_desc;
+
+int lgn_step_param_slots(const lgn_net_desc* d, int decoder);
+long long lgn_step_workspace_doubles(const lgn_net_desc* d);
+/* p4 [B][N][4] real Cartesian (also the Chamfer target), mask [B][N]; recon [2][B][N][4]; loss_part [B]. */
+int lgn_step_fwd_bwd_f64(const lgn_net_desc* d, const double* params, double* grads, long long n_params,
+                         const int64_t* enc_off, const int64_t* dec_off, const double* p4, const uint8_t* mask,
+                         double* workspace, double* recon, double* loss_part, void* stream);
+/* grads += l1_lambda*sign(params) (utils/train.py:484-487); loss_out[0..2] = total, chamfer, sum|w|; optional Adam
+ * (torch.optim.Adam defaults; the step counter lives on the device so that graph replays stay correct). */
+int lgn_step_finalize_f64(double* params, double* grads, long long n_params, const double* loss_part, int n_loss,
+                          double l1_lambda, double* adam_m, double* adam_v, long long* step_dev,
+                          double lr, double beta1, double beta2, double eps, int do_adam, double* loss_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,46 +1,6 @@
 // lgn-autoencoder_amd/csrc/api.hip -- extern "C" entry points declared in include/lgn_amd.h
-#include "level.hpp"
+#include "ops.hpp"
 #include "../../include/lgn_amd.h"
-
-namespace lgn {
-// level_fwd.hip / level_bwd.hip
-template <typename T> int level_fwd_dispatch(const LevelArgs<T>&, int, hipStream_t);
-template <typename T> int level_bwd_dispatch(const LevelBwdArgs<T>&, int, hipStream_t);
-template <typename T> int reduce_partials(const T*, int, int, T*, int, hipStream_t);
-template <typename T> int rad_finalize(const T*, int, const T*, const T*, const T*, const T*, const T*, T*, T*, T*, T*, T*, T*, T*, hipStream_t);
-void level_bwd_partial_rows(int B, int N, int decoder, int* rows_mix, int* rows_rad);
-
-// mlp.hip
-constexpr int MLP_MAX_LIN = 8;
-template <typename T>
-struct MlpArgs {
-  int M, C, H, nlin;
-  const T* w[MLP_MAX_LIN];
-  const T* b[MLP_MAX_LIN];
-  const T* s_in;
-  T* s_out;
-  const T* g_out;
-  T* g_in;
-  T* part;
-  int psize;
-};
-template <typename T> int mlp_dispatch(const MlpArgs<T>&, bool, hipStream_t);
-
-// mixreps.hip
-template <typename T>
-struct MixArgs {
-  int rows, Cin, Cout, d;
-  const T* w;
-  const T* x;
-  T* y;
-  const T* g_y;
-  T* g_x;
-  T* part;
-};
-template <typename T> int mix_fwd(const MixArgs<T>&, hipStream_t);
-template <typename T> int mix_bwd(const MixArgs<T>&, hipStream_t);
-int mix_partial_rows(int rows);
-}  // namespace lgn
 
 using namespace lgn;
 

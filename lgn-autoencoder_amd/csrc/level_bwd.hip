@@ -655,7 +655,7 @@ __global__ __launch_bounds__(BLOCK) void level_bwd_rad_dec_kernel(LevelBwdArgs<T
 // then the 16 partial sums are combined in a fixed order through LDS -> bitwise reproducible.
 constexpr int RED_RG = 16;
 template <typename T>
-__global__ __launch_bounds__(64 * RED_RG) void reduce_partials_kernel(const T* __restrict__ part, int nblk, int n, T* out,
+__global__ __launch_bounds__(64 * RED_RG) void reduce_partials_kernel(const T* __restrict__ part, int nblk, int stride, int n, T* out,
                                                                       int accumulate) {
   __shared__ T red[RED_RG][64];
   const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
@@ -664,12 +664,12 @@ __global__ __launch_bounds__(64 * RED_RG) void reduce_partials_kernel(const T* _
   if (col < n) {
     int r = rg;
     for (; r + 3 * RED_RG < nblk; r += 4 * RED_RG) {
-      s0 += part[(size_t)r * n + col];
-      s1 += part[(size_t)(r + RED_RG) * n + col];
-      s2 += part[(size_t)(r + 2 * RED_RG) * n + col];
-      s3 += part[(size_t)(r + 3 * RED_RG) * n + col];
+      s0 += part[(size_t)r * stride + col];
+      s1 += part[(size_t)(r + RED_RG) * stride + col];
+      s2 += part[(size_t)(r + 2 * RED_RG) * stride + col];
+      s3 += part[(size_t)(r + 3 * RED_RG) * stride + col];
     }
-    for (; r < nblk; r += RED_RG) s0 += part[(size_t)r * n + col];
+    for (; r < nblk; r += RED_RG) s0 += part[(size_t)r * stride + col];
   }
   red[rg][cl] = (s0 + s1) + (s2 + s3);
   __syncthreads();
@@ -772,7 +772,16 @@ int level_bwd_dispatch(const LevelBwdArgs<T>& a, int decoder, hipStream_t stream
 template <typename T>
 int reduce_partials(const T* part, int nblk, int n, T* out, int accumulate, hipStream_t stream) {
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(reduce_partials_kernel<T>, dim3(cdiv(n, 64)), dim3(64 * RED_RG), 0, stream, part, nblk, n, out, accumulate);
+  hipLaunchKernelGGL(reduce_partials_kernel<T>, dim3(cdiv(n, 64)), dim3(64 * RED_RG), 0, stream, part, nblk, n, n, out, accumulate);
+  LGN_CHECK_LAUNCH();
+  return 0;
+}
+
+// columns [col0, col0+n) of rows of length `stride`
+template <typename T>
+int reduce_partials_strided(const T* part, int nblk, int stride, int col0, int n, T* out, hipStream_t stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(reduce_partials_kernel<T>, dim3(cdiv(n, 64)), dim3(64 * RED_RG), 0, stream, part + col0, nblk, stride, n, out, 0);
   LGN_CHECK_LAUNCH();
   return 0;
 }
@@ -788,6 +797,7 @@ int rad_finalize(const T* tot, int C, const T* ra, const T* rb, const T* rc, con
 
 template int level_bwd_dispatch<double>(const LevelBwdArgs<double>&, int, hipStream_t);
 template int reduce_partials<double>(const double*, int, int, double*, int, hipStream_t);
+template int reduce_partials_strided<double>(const double*, int, int, int, int, double*, hipStream_t);
 template int rad_finalize<double>(const double*, int, const double*, const double*, const double*, const double*,
                                   const double*, double*, double*, double*, double*, double*, double*, double*, hipStream_t);
 

@@ -5,20 +5,9 @@
 // with complex W (2,C_out,C_in), planar complex x (2,rows,C_in,d), no conjugation.
 // Used for input_func_node, the encoder's mix_reps, latent_to_graph and mix_to_output (the CatMix
 // of the message-passing levels is fused into level_fwd / level_bwd instead).
-#include "common.hpp"
+#include "ops.hpp"
 
 namespace lgn {
-
-template <typename T>
-struct MixArgs {
-  int rows, Cin, Cout, d;
-  const T* w;     // [2][Cout][Cin]
-  const T* x;     // [2][rows][Cin][d]
-  T* y;           // [2][rows][Cout][d]
-  const T* g_y;   // backward
-  T* g_x;         // [2][rows][Cin][d]  (may be null)
-  T* part;        // [nblk][2*Cout*Cin]
-};
 
 constexpr int MIX_RCH = 128;   // rows per weight-gradient partial
 

@@ -11,30 +11,12 @@
 //   g_in  = g_pre W          (same mapping as the forward)
 //   dW    = g_pre^T h_in     (register-tiled (o,k) outer products over the 64 rows, LDS operands)
 // Per-workgroup weight-gradient partials are reduced afterwards (deterministic, no atomics).
-#include "common.hpp"
+#include "ops.hpp"
 
 namespace lgn {
 
-constexpr int MLP_MAX_LIN = 8;
 constexpr int ROWS = 64;
 constexpr int RPAD = 65;          // padded row stride for the (o,k) outer-product reads
-
-template <typename T>
-struct MlpArgs {
-  int M;        // rows = B*N
-  int C;        // channels; in/out features D = 2C
-  int H;        // hidden width
-  int nlin;     // number of Linear layers = hidden layers + 1
-  const T* w[MLP_MAX_LIN];   // [out][in] row-major (nn.Linear.weight)
-  const T* b[MLP_MAX_LIN];
-  const T* s_in;    // [2][M][C]  scalars before the MLP
-  T* s_out;         // [2][M][C]  scalars after the MLP
-  // backward only
-  const T* g_out;   // [2][M][C]
-  T* g_in;          // [2][M][C]
-  T* part;          // [nblk][psize] partial parameter gradients, layout = concat_l (W_l, b_l)
-  int psize;
-};
 
 __device__ __forceinline__ int uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
 
@@ -255,8 +237,6 @@ static int launch_mlp(const MlpArgs<T>& a, bool backward, hipStream_t stream) {
   LGN_CHECK_LAUNCH();
   return 0;
 }
-
-int mlp_mfma_dispatch(const MlpArgs<double>& a, bool backward, hipStream_t stream);   // mlp_mfma.hip
 
 template <typename T>
 int mlp_dispatch(const MlpArgs<T>& a, bool backward, hipStream_t stream) {

@@ -17,23 +17,9 @@
 //                          are dealt round-robin to the 4 waves, which store them into this workgroup's
 //                          partial row (reduced deterministically by reduce_partials afterwards)
 //   db    = column sums of g_pre (two wave shuffles + a 4-wave LDS reduction)
-#include "common.hpp"
+#include "ops.hpp"
 
 namespace lgn {
-
-constexpr int MLP_MAX_LIN = 8;
-template <typename T>
-struct MlpArgs {
-  int M, C, H, nlin;
-  const T* w[MLP_MAX_LIN];
-  const T* b[MLP_MAX_LIN];
-  const T* s_in;
-  T* s_out;
-  const T* g_out;
-  T* g_in;
-  T* part;
-  int psize;
-};
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 

@@ -1,0 +1,54 @@
+// lgn-autoencoder_amd/csrc/ops.hpp -- argument blocks and host entry points shared between translation units.
+#pragma once
+#include "level.hpp"
+
+namespace lgn {
+
+// ---- level (level_fwd.hip / level_bwd.hip) ---------------------------------------------------------
+template <typename T> int level_fwd_dispatch(const LevelArgs<T>&, int decoder, hipStream_t);
+template <typename T> int level_bwd_dispatch(const LevelBwdArgs<T>&, int decoder, hipStream_t);
+template <typename T> int reduce_partials(const T* part, int rows, int n, T* out, int accumulate, hipStream_t);
+template <typename T> int reduce_partials_strided(const T* part, int rows, int stride, int col0, int n, T* out, hipStream_t);
+template <typename T>
+int rad_finalize(const T* tot, int C, const T* ra, const T* rb, const T* rc, const T* w0, const T* w1, T* g_a, T* g_b, T* g_c,
+                 T* g_w0, T* g_b0, T* g_w1, T* g_b1, hipStream_t);
+void level_bwd_partial_rows(int B, int N, int decoder, int* rows_mix, int* rows_rad);
+
+// ---- CGMLP (mlp.hip / mlp_mfma.hip) ------------------------------------------------------------------
+constexpr int MLP_MAX_LIN = 8;
+template <typename T>
+struct MlpArgs {
+  int M;        // rows = B*N
+  int C;        // channels; in/out features D = 2C (index 2c+z)
+  int H;        // hidden width
+  int nlin;     // number of Linear layers = hidden layers + 1
+  const T* w[MLP_MAX_LIN];   // [out][in] row-major (nn.Linear.weight)
+  const T* b[MLP_MAX_LIN];
+  const T* s_in;    // [2][M][C]  scalars before the MLP
+  T* s_out;         // [2][M][C]  scalars after the MLP
+  // backward only
+  const T* g_out;   // [2][M][C]
+  T* g_in;          // [2][M][C]
+  T* part;          // [nblk][psize] partial parameter gradients, layout = concat_l (W_l, b_l)
+  int psize;
+};
+template <typename T> int mlp_dispatch(const MlpArgs<T>&, bool backward, hipStream_t);
+int mlp_mfma_dispatch(const MlpArgs<double>&, bool backward, hipStream_t);
+inline int mlp_partial_rows(int M) { return (M + 63) / 64; }
+
+// ---- MixReps (mixreps.hip) -----------------------------------------------------------------------------
+template <typename T>
+struct MixArgs {
+  int rows, Cin, Cout, d;
+  const T* w;     // [2][Cout][Cin]
+  const T* x;     // [2][rows][Cin][d]
+  T* y;           // [2][rows][Cout][d]
+  const T* g_y;   // backward
+  T* g_x;         // [2][rows][Cin][d]  (may be null)
+  T* part;        // [nblk][2*Cout*Cin]
+};
+template <typename T> int mix_fwd(const MixArgs<T>&, hipStream_t);
+template <typename T> int mix_bwd(const MixArgs<T>&, hipStream_t);
+int mix_partial_rows(int rows);
+
+}  // namespace lgn

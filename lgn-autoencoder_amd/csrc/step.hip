@@ -1,0 +1,308 @@
+// lgn-autoencoder_amd/csrc/step.hip -- one training step of the LGN autoencoder as a single native call.
+//
+// Counterpart of the inner loop of the reference's utils/train.py:283-343 (encoder -> decoder ->
+// get_real('sum') -> Chamfer -> backward) for the maxdim=2 path: ~80 kernel launches enqueued back to back
+// on the caller's stream, no host synchronisation, every buffer caller-owned and static -> the call can be
+// captured into a HIP graph (the Python harness does so) and replayed.  Parameter gradients are written
+// straight into the caller's flat gradient buffer at the same offsets as the parameters.
+#include <vector>
+
+#include "net.hpp"
+#include "../../include/lgn_amd.h"
+
+namespace lgn {
+namespace {
+
+struct Bump {                       // workspace carving (also used for the size query with base == nullptr)
+  double* base;
+  size_t off = 0;
+  double* take(size_t n) {
+    n = (n + 15) & ~size_t(15);     // 128-byte granules
+    double* p = base ? base + off : nullptr;
+    off += n;
+    return p;
+  }
+};
+
+struct NetBuf {                     // per-network activations kept for the backward pass
+  double *s[5], *v[5], *smix[4], *ag0[4], *ag1[4];
+};
+
+struct Work {
+  NetBuf enc, dec;
+  double *lat_s, *lat_v, *pdec, *g_lat_s, *g_lat_v, *g_p;
+  double *gs[2], *gv[2], *gsmix, *g_ag, *zeros_s;
+  double *part, *tot;
+  int* idx;
+  size_t total;
+};
+
+int mlp_psize(int C, int H, int nlin) {
+  const int D = 2 * C;
+  return nlin == 1 ? D * D + D : (H * D + H) + (nlin - 2) * (H * H + H) + (D * H + D);
+}
+
+Work carve(const lgn_net_desc& d, double* base) {
+  Work w{};
+  Bump b{base};
+  const size_t BN = (size_t)d.B * d.N;
+  const int L = d.n_levels;
+  int cmax = 0;
+  for (int l = 0; l <= L; ++l) cmax = cmax > d.enc_channels[l] ? cmax : d.enc_channels[l], cmax = cmax > d.dec_channels[l] ? cmax : d.dec_channels[l];
+  auto net = [&](NetBuf& n, const int* ch) {
+    for (int l = 0; l <= L; ++l) {
+      n.s[l] = b.take(2 * BN * ch[l]);
+      n.v[l] = b.take(8 * BN * ch[l]);
+    }
+    for (int l = 0; l < L; ++l) {
+      n.smix[l] = b.take(2 * BN * ch[l + 1]);
+      n.ag0[l] = b.take(4 * BN * ch[l]);
+      n.ag1[l] = b.take(16 * BN * ch[l]);
+    }
+  };
+  net(w.enc, d.enc_channels);
+  net(w.dec, d.dec_channels);
+  const int Ts = d.tau_s, Tv = d.tau_v;
+  w.lat_s = b.take((size_t)2 * d.B * 2 * Ts);
+  w.lat_v = b.take((size_t)2 * d.B * 2 * Tv * 4);
+  w.g_lat_s = b.take((size_t)2 * d.B * 2 * Ts);
+  w.g_lat_v = b.take((size_t)2 * d.B * 2 * Tv * 4);
+  w.pdec = b.take(8 * BN);
+  w.g_p = b.take(8 * BN);
+  for (int q = 0; q < 2; ++q) {
+    w.gs[q] = b.take(2 * BN * cmax);
+    w.gv[q] = b.take(8 * BN * cmax);
+  }
+  w.gsmix = b.take(2 * BN * cmax);
+  w.zeros_s = b.take(2 * BN * cmax);
+  w.g_ag = b.take(20 * BN * cmax);
+  w.idx = reinterpret_cast<int*>(b.take(((size_t)d.B * 2 * (Ts + Tv) * 2 + 1) / 2 + 8));
+  // partial rows: the largest producer wins
+  size_t pmax = 0, tmax = 0;
+  for (int dec = 0; dec < 2; ++dec) {
+    const int* ch = dec ? d.dec_channels : d.enc_channels;
+    for (int l = 0; l < L; ++l) {
+      int rm, rr;
+      level_bwd_partial_rows(d.B, d.N, dec, &rm, &rr);
+      const size_t nmix = (size_t)4 * ch[l + 1] * 5 * ch[l], nrad = rad_partial_size(ch[l], dec != 0);
+      pmax = pmax > rm * nmix + rr * nrad ? pmax : rm * nmix + rr * nrad;
+      tmax = tmax > nrad ? tmax : nrad;
+      const size_t pm = (size_t)mlp_partial_rows((int)BN) * mlp_psize(ch[l + 1], d.mlp_hidden_mul * 2 * ch[l + 1], d.mlp_nlin);
+      pmax = pmax > pm ? pmax : pm;
+    }
+  }
+  const size_t pio = (size_t)d.B * (4 * cmax + 2 * (size_t)d.N * 2 * Tv + 2 * (Ts + Tv) * cmax);
+  pmax = pmax > pio ? pmax : pio;
+  w.part = b.take(pmax);
+  w.tot = b.take(tmax + 16);
+  w.total = b.off;
+  return w;
+}
+
+struct Slots {                      // canonical parameter slot order shared with lgn/step.py
+  int L, nlin;
+  int in0(bool dec) const { return dec ? 2 : 0; }
+  int rad(bool dec, int l, int k) const { return in0(dec) + 2 + 7 * l + k; }
+  int mix(bool dec, int l, int k) const { return in0(dec) + 2 + 7 * L + 2 * l + k; }
+  int mlp(bool dec, int l, int k) const { return in0(dec) + 2 + 9 * L + 2 * nlin * l + k; }
+  int out0(bool dec) const { return in0(dec) + 2 + 9 * L + 2 * nlin * L; }
+  int count(bool dec) const { return out0(dec) + 2; }
+};
+
+#define LGN_TRY(expr)            \
+  do {                           \
+    int rc_ = (expr);            \
+    if (rc_ != 0) return rc_;    \
+  } while (0)
+
+// forward of one network's level stack; returns via buffers
+int levels_fwd(const lgn_net_desc& d, bool dec, const int* ch, const double* P, const int64_t* off, NetBuf& n, const double* pos,
+               const uint8_t* mask, hipStream_t st) {
+  const Slots S{d.n_levels, d.mlp_nlin};
+  for (int l = 0; l < d.n_levels; ++l) {
+    auto p = [&](int slot) { return P + off[slot]; };
+    LevelArgs<double> a{d.B, d.N, ch[l], ch[l + 1], n.s[l], n.v[l], pos, mask,
+                        p(S.rad(dec, l, 0)), p(S.rad(dec, l, 1)), p(S.rad(dec, l, 2)), p(S.rad(dec, l, 3)), p(S.rad(dec, l, 4)),
+                        p(S.rad(dec, l, 5)), p(S.rad(dec, l, 6)), p(S.mix(dec, l, 0)), p(S.mix(dec, l, 1)),
+                        n.ag0[l], n.ag1[l], n.smix[l], n.v[l + 1]};
+    LGN_TRY(level_fwd_dispatch<double>(a, dec, st));
+    MlpArgs<double> m{};
+    m.M = d.B * d.N; m.C = ch[l + 1]; m.H = d.mlp_hidden_mul * 2 * ch[l + 1]; m.nlin = d.mlp_nlin;
+    for (int q = 0; q < d.mlp_nlin; ++q) { m.w[q] = p(S.mlp(dec, l, 2 * q)); m.b[q] = p(S.mlp(dec, l, 2 * q + 1)); }
+    m.s_in = n.smix[l]; m.s_out = n.s[l + 1];
+    LGN_TRY(mlp_dispatch<double>(m, false, st));
+  }
+  return 0;
+}
+
+// backward of one network's level stack.  On entry gs[cur]/gv[cur] hold the gradient w.r.t. (s[L], v[L]);
+// has_s_grad says whether gs is non-zero (false for both networks of the autoencoder: the last level's
+// scalars never reach the loss).  On exit gs[cur]/gv[cur] hold the gradient w.r.t. level 0.
+int levels_bwd(const lgn_net_desc& d, bool dec, const int* ch, const double* P, double* G, const int64_t* off, const NetBuf& n,
+               const double* pos, const uint8_t* mask, Work& w, int& cur, bool has_s_grad, hipStream_t st) {
+  const Slots S{d.n_levels, d.mlp_nlin};
+  const int BN = d.B * d.N;
+  for (int l = d.n_levels - 1; l >= 0; --l) {
+    auto p = [&](int slot) { return P + off[slot]; };
+    auto g = [&](int slot) { return G + off[slot]; };
+    const int C = ch[l], CO = ch[l + 1];
+    const double* g_smix = w.zeros_s;
+    if (has_s_grad) {
+      MlpArgs<double> m{};
+      m.M = BN; m.C = CO; m.H = d.mlp_hidden_mul * 2 * CO; m.nlin = d.mlp_nlin;
+      for (int q = 0; q < d.mlp_nlin; ++q) { m.w[q] = p(S.mlp(dec, l, 2 * q)); m.b[q] = p(S.mlp(dec, l, 2 * q + 1)); }
+      m.s_in = n.smix[l]; m.g_out = w.gs[cur]; m.g_in = w.gsmix; m.part = w.part;
+      m.psize = mlp_psize(CO, m.H, m.nlin);
+      LGN_TRY(mlp_dispatch<double>(m, true, st));
+      // the MLP's parameters are contiguous in the flat buffer in (W_0, b_0, W_1, ...) order (checked at plan time)
+      LGN_TRY(reduce_partials<double>(w.part, mlp_partial_rows(BN), m.psize, g(S.mlp(dec, l, 0)), 0, st));
+      g_smix = w.gsmix;
+    }
+    int rm, rr;
+    level_bwd_partial_rows(d.B, d.N, dec, &rm, &rr);
+    const int nmix = 4 * CO * 5 * C, nrad = rad_partial_size(C, dec);
+    double* part_mix = w.part;
+    double* part_rad = w.part + (size_t)rm * nmix;
+    const int nxt = cur ^ 1;
+    LevelBwdArgs<double> a{d.B, d.N, C, CO, n.s[l], n.v[l], pos, mask,
+                           p(S.rad(dec, l, 0)), p(S.rad(dec, l, 1)), p(S.rad(dec, l, 2)), p(S.rad(dec, l, 3)), p(S.rad(dec, l, 4)),
+                           p(S.rad(dec, l, 5)), p(S.rad(dec, l, 6)), p(S.mix(dec, l, 0)), p(S.mix(dec, l, 1)), n.ag0[l], n.ag1[l],
+                           g_smix, w.gv[cur], w.g_ag, w.gs[nxt], w.gv[nxt], dec ? w.g_p : nullptr, part_mix, part_rad};
+    LGN_TRY(level_bwd_dispatch<double>(a, dec, st));
+    // CatMix weights: partial row = [wm0 | wm1]
+    LGN_TRY(reduce_partials_strided<double>(part_mix, rm, nmix, 0, nmix / 2, g(S.mix(dec, l, 0)), st));
+    LGN_TRY(reduce_partials_strided<double>(part_mix, rm, nmix, nmix / 2, nmix / 2, g(S.mix(dec, l, 1)), st));
+    if (dec) {   // only the Linear biases receive gradient (all edges are "masked")
+      LGN_TRY(reduce_partials_strided<double>(part_rad, rr, nrad, 0, C, g(S.rad(dec, l, 4)), st));
+      LGN_TRY(reduce_partials_strided<double>(part_rad, rr, nrad, C, C, g(S.rad(dec, l, 6)), st));
+    } else {
+      LGN_TRY(reduce_partials<double>(part_rad, rr, nrad, w.tot, 0, st));
+      LGN_TRY(rad_finalize<double>(w.tot, C, p(S.rad(dec, l, 0)), p(S.rad(dec, l, 1)), p(S.rad(dec, l, 2)), p(S.rad(dec, l, 3)),
+                                   p(S.rad(dec, l, 5)), g(S.rad(dec, l, 0)), g(S.rad(dec, l, 1)), g(S.rad(dec, l, 2)),
+                                   g(S.rad(dec, l, 3)), g(S.rad(dec, l, 4)), g(S.rad(dec, l, 5)), g(S.rad(dec, l, 6)), st));
+    }
+    cur = nxt;
+    has_s_grad = true;       // the level input scalars do carry gradient
+  }
+  return 0;
+}
+
+int check_desc(const lgn_net_desc* d) {
+  LGN_CHECK_ARG(d, "step: null descriptor");
+  LGN_CHECK_ARG(d->B > 0 && d->N > 0, "step: empty batch (B=%d N=%d)", d->B, d->N);
+  LGN_CHECK_ARG(d->n_levels >= 1 && d->n_levels <= 4, "step: n_levels=%d unsupported (1..4)", d->n_levels);
+  LGN_CHECK_ARG(d->mlp_nlin == 7, "step: mlp_depth must be 6 (7 Linear layers)");
+  LGN_CHECK_ARG(d->tau_s >= 1 && d->tau_v >= 1, "step: latent multiplicities must be positive");
+  for (int l = 0; l <= d->n_levels; ++l)
+    LGN_CHECK_ARG(d->enc_channels[l] >= 1 && d->enc_channels[l] <= 8 && d->dec_channels[l] >= 1 && d->dec_channels[l] <= 8,
+                  "step: channel counts must be in 1..8");
+  return 0;
+}
+
+}  // namespace
+
+}  // namespace lgn
+
+using namespace lgn;
+
+extern "C" {
+
+int lgn_step_param_slots(const lgn_net_desc* d, int decoder) {
+  if (check_desc(d)) return -1;
+  return Slots{d->n_levels, d->mlp_nlin}.count(decoder != 0);
+}
+
+long long lgn_step_workspace_doubles(const lgn_net_desc* d) {
+  if (check_desc(d)) return -1;
+  return (long long)carve(*d, nullptr).total;
+}
+
+int lgn_step_fwd_bwd_f64(const lgn_net_desc* d, const double* params, double* grads, long long n_params, const int64_t* enc_off,
+                         const int64_t* dec_off, const double* p4, const uint8_t* mask, double* workspace, double* recon,
+                         double* loss_part, void* stream) {
+  if (int rc = check_desc(d)) return rc;
+  LGN_CHECK_ARG(params && grads && enc_off && dec_off && p4 && mask && workspace && recon && loss_part && n_params > 0,
+                "step_fwd_bwd: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  Work w = carve(*d, workspace);
+  const Slots S{d->n_levels, d->mlp_nlin};
+  const int L = d->n_levels, B = d->B, N = d->N, Ts = d->tau_s, Tv = d->tau_v;
+  const int* ce = d->enc_channels;
+  const int* cd = d->dec_channels;
+  // MLP parameter blocks must be contiguous (W_0, b_0, W_1, b_1, ...) for the single-reduce path
+  for (int dec = 0; dec < 2; ++dec) {
+    const int64_t* off = dec ? dec_off : enc_off;
+    const int* ch = dec ? cd : ce;
+    for (int l = 0; l < L; ++l) {
+      const int D = 2 * ch[l + 1], H = d->mlp_hidden_mul * D;
+      int64_t expect = off[S.mlp(dec, l, 0)];
+      for (int q = 0; q < d->mlp_nlin; ++q) {
+        const int hin = q == 0 ? D : H, hout = q == d->mlp_nlin - 1 ? D : H;
+        LGN_CHECK_ARG(off[S.mlp(dec, l, 2 * q)] == expect, "step: MLP weights are not contiguous in the flat parameter buffer");
+        expect += (int64_t)hin * hout;
+        LGN_CHECK_ARG(off[S.mlp(dec, l, 2 * q + 1)] == expect, "step: MLP biases are not contiguous in the flat parameter buffer");
+        expect += hout;
+      }
+    }
+  }
+#define HIPOK(e) do { hipError_t e_ = (e); if (e_ != hipSuccess) { set_error("%s: %s", #e, hipGetErrorString(e_)); return (int)e_; } } while (0)
+  HIPOK(hipMemsetAsync(grads, 0, sizeof(double) * (size_t)n_params, st));      // dead parameters keep an exact zero
+  int cmax = 0;
+  for (int l = 0; l <= L; ++l) cmax = cmax > ce[l] ? cmax : ce[l], cmax = cmax > cd[l] ? cmax : cd[l];
+  HIPOK(hipMemsetAsync(w.zeros_s, 0, sizeof(double) * 2 * (size_t)B * N * cmax, st));
+  HIPOK(hipMemsetAsync(w.g_p, 0, sizeof(double) * 8 * (size_t)B * N, st));
+  HIPOK(hipMemsetAsync(w.g_lat_s, 0, sizeof(double) * 2 * (size_t)B * 2 * Ts, st));
+
+  // ---------------- forward ----------------
+  LGN_TRY(enc_input_fwd(B, N, ce[0], p4, params + enc_off[0], params + enc_off[1], w.enc.s[0], w.enc.v[0], st));
+  LGN_TRY(levels_fwd(*d, false, ce, params, enc_off, w.enc, p4, mask, st));
+  LGN_TRY(enc_latent_fwd(B, N, ce[L], Ts, Tv, w.enc.s[L], w.enc.v[L], params + enc_off[S.out0(false)],
+                         params + enc_off[S.out0(false) + 1], w.lat_s, w.lat_v, w.idx, st));
+  LGN_TRY(dec_input_fwd(B, N, cd[0], 2 * Tv, w.lat_v, params + dec_off[1], params + dec_off[2], params + dec_off[3], w.pdec,
+                        w.dec.s[0], w.dec.v[0], st));
+  LGN_TRY(levels_fwd(*d, true, cd, params, dec_off, w.dec, w.pdec, nullptr, st));
+
+  // ---------------- loss + backward ----------------
+  int cur = 0;
+  LGN_TRY(dec_output_loss(B, N, cd[L], w.dec.v[L], params + dec_off[S.out0(true) + 1], p4, 1.0, recon, loss_part, w.gv[cur], w.part, st));
+  LGN_TRY(reduce_partials<double>(w.part, B, 2 * cd[L], grads + dec_off[S.out0(true) + 1], 0, st));
+  LGN_TRY(levels_bwd(*d, true, cd, params, grads, dec_off, w.dec, w.pdec, nullptr, w, cur, /*has_s_grad=*/false, st));
+  {
+    const int C0 = cd[0], Tin = 2 * Tv, row = 4 * C0 + 2 * N * Tin;
+    LGN_TRY(dec_input_bwd(B, N, C0, Tin, w.lat_v, params + dec_off[1], params + dec_off[3], w.pdec, w.g_p, w.gs[cur], w.gv[cur],
+                          w.g_lat_v, w.part, st));
+    LGN_TRY(reduce_partials_strided<double>(w.part, B, row, 0, 2 * C0, grads + dec_off[2], st));
+    LGN_TRY(reduce_partials_strided<double>(w.part, B, row, 2 * C0, 2 * C0, grads + dec_off[3], st));
+    LGN_TRY(reduce_partials_strided<double>(w.part, B, row, 4 * C0, 2 * N * Tin, grads + dec_off[1], st));
+  }
+  {
+    const int CL = ce[L], row = 2 * (Ts + Tv) * CL;
+    cur = 0;
+    LGN_TRY(enc_latent_bwd(B, N, CL, Ts, Tv, w.enc.s[L], w.enc.v[L], params + enc_off[S.out0(false)],
+                           params + enc_off[S.out0(false) + 1], w.g_lat_s, w.g_lat_v, w.idx, w.gs[cur], w.gv[cur], w.part, st));
+    LGN_TRY(reduce_partials_strided<double>(w.part, B, row, 0, 2 * Ts * CL, grads + enc_off[S.out0(false)], st));
+    LGN_TRY(reduce_partials_strided<double>(w.part, B, row, 2 * Ts * CL, 2 * Tv * CL, grads + enc_off[S.out0(false) + 1], st));
+  }
+  LGN_TRY(levels_bwd(*d, false, ce, params, grads, enc_off, w.enc, p4, mask, w, cur, /*has_s_grad=*/false, st));
+  {
+    const int C0 = ce[0];
+    LGN_TRY(enc_input_bwd(B, N, C0, p4, w.gs[cur], w.gv[cur], w.part, st));
+    LGN_TRY(reduce_partials_strided<double>(w.part, B, 4 * C0, 0, 2 * C0, grads + enc_off[0], st));
+    LGN_TRY(reduce_partials_strided<double>(w.part, B, 4 * C0, 2 * C0, 2 * C0, grads + enc_off[1], st));
+  }
+  return 0;
+}
+
+int lgn_step_finalize_f64(double* params, double* grads, long long n_params, const double* loss_part, int n_loss, double l1_lambda,
+                          double* adam_m, double* adam_v, long long* step_dev, double lr, double beta1, double beta2, double eps,
+                          int do_adam, double* loss_out, void* stream) {
+  LGN_CHECK_ARG(params && grads && loss_part && loss_out && n_params > 0 && n_loss > 0, "step_finalize: null pointer");
+  LGN_CHECK_ARG(!do_adam || (adam_m && adam_v && step_dev), "step_finalize: Adam state missing");
+  hipStream_t st = (hipStream_t)stream;
+  LGN_TRY(loss_l1(loss_part, n_loss, params, (long)n_params, l1_lambda, loss_out, reinterpret_cast<long*>(step_dev), do_adam, st));
+  LGN_TRY(l1_adam((long)n_params, params, grads, adam_m, adam_v, l1_lambda, lr, beta1, beta2, eps,
+                  reinterpret_cast<const long*>(step_dev), do_adam, st));
+  return 0;
+}
+
+}  // extern "C"

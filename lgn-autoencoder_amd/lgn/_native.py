@@ -36,7 +36,24 @@ _SIGNATURES = {
     "lgn_mixreps_partial_rows": [_i],
     "lgn_mixreps_bwd_f64": [_i] * 4 + [_vp] * 6,
 }
-EXPORTED_SYMBOLS = ["lgn_abi_version", "lgn_last_error"] + list(_SIGNATURES)
+
+
+class NetDesc(C.Structure):
+    """lgn_net_desc of include/lgn_amd.h."""
+    _fields_ = [("B", C.c_int), ("N", C.c_int), ("n_levels", C.c_int), ("enc_channels", C.c_int * 5),
+                ("dec_channels", C.c_int * 5), ("tau_s", C.c_int), ("tau_v", C.c_int), ("mlp_hidden_mul", C.c_int),
+                ("mlp_nlin", C.c_int)]
+
+
+_dp = C.POINTER(NetDesc)
+_ll = C.c_longlong
+_d = C.c_double
+_SIGNATURES.update({
+    "lgn_step_param_slots": [_dp, _i],
+    "lgn_step_fwd_bwd_f64": [_dp, _vp, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "lgn_step_finalize_f64": [_vp, _vp, _ll, _vp, _i, _d, _vp, _vp, _vp, _d, _d, _d, _d, _i, _vp, _vp],
+})
+EXPORTED_SYMBOLS = ["lgn_abi_version", "lgn_last_error", "lgn_step_workspace_doubles"] + list(_SIGNATURES)
 
 
 def lib() -> C.CDLL:
@@ -57,6 +74,8 @@ def lib() -> C.CDLL:
             fn = getattr(l, name)
             fn.argtypes = argtypes
             fn.restype = C.c_int
+        l.lgn_step_workspace_doubles.argtypes = [_dp]
+        l.lgn_step_workspace_doubles.restype = C.c_longlong
         _lib = l
     return _lib
 

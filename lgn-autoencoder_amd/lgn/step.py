@@ -110,3 +110,153 @@ class TrainStep:
         if self.opt is not None:
             self.opt.step()
         return total, recon
+
+
+# ---------------------------------------------------------------------------------------------------
+# fully native step: one C call for encoder -> decoder -> loss -> backward, captured in a HIP graph
+# ---------------------------------------------------------------------------------------------------
+
+def _slot_tensors(net, decoder: bool):
+    """Parameters of a network in the slot order of include/lgn_amd.h (lgn_step_fwd_bwd_f64)."""
+    out = []
+    if decoder:
+        out += [net.latent_to_graph.weight((0, 0)), net.latent_to_graph.weight((1, 1))]
+    out += [net.input_func_node.weight((0, 0)), net.input_func_node.weight((1, 1))]
+    for rf in net.rad_funcs.rad_funcs:
+        out += rf.flat_params()
+    for lvl in net.lgn_cg.node_levels:
+        out += [lvl.cat_mix.mix_reps.weight((0, 0)), lvl.cat_mix.mix_reps.weight((1, 1))]
+    for mlp in net.lgn_cg.mlp_levels:
+        out += mlp.flat_params()
+    last = net.mix_to_output if decoder else net.mix_reps
+    out += [last.weight((0, 0)), last.weight((1, 1))]
+    return out
+
+
+class NativeTrainStep:
+    """Same step as TrainStep, executed by lgn_step_fwd_bwd_f64 / lgn_step_finalize_f64 (csrc/step.hip):
+    no autograd graph, no PyTorch kernels, every buffer static.  With ``use_graph=True`` the two native calls
+    are captured once into HIP graphs (torch.cuda.CUDAGraph around the ctypes calls -- the kernels are
+    enqueued on the capturing stream) and replayed; the gradient all-reduce sits between the two graphs."""
+
+    def __init__(self, encoder, decoder, batch_size: int, lr: float = 5e-4, l1_lambda: float = 1e-8,
+                 betas=(0.9, 0.999), eps: float = 1e-8, process_group=None, optimizer: bool = True, use_graph: bool = True):
+        import ctypes as C
+        from . import _native as N
+        self.N = N
+        encoder._require_gpu()
+        if encoder.map_to_latent != "min&max" or not encoder.mlp or not decoder.mlp:
+            raise NotImplementedError("the native step implements map_to_latent='min&max' with CGMLP levels")
+        self.encoder, self.decoder = encoder, decoder
+        self.l1_lambda, self.lr, self.betas, self.eps = l1_lambda, lr, betas, eps
+        self.flat = FlatParams(encoder, decoder)
+        self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        self.group = process_group
+        self.optimizer = optimizer
+        dev, dt = self.flat.flat.device, self.flat.flat.dtype
+        L = encoder.num_cg_levels
+        d = N.NetDesc()
+        d.B, d.N, d.n_levels = batch_size, encoder.num_input_particles, L
+        for i, c in enumerate(encoder.num_channels):
+            d.enc_channels[i] = c
+        for i, c in enumerate(decoder.num_channels):
+            d.dec_channels[i] = c
+        d.tau_s, d.tau_v = encoder.tau_latent[(0, 0)], encoder.tau_latent[(1, 1)]
+        d.mlp_hidden_mul, d.mlp_nlin = encoder.mlp_width, encoder.mlp_depth + 1
+        if decoder.tau_latent_vectors != 2 * d.tau_v or decoder.num_output_particles != d.N:
+            raise ValueError("decoder latent size / particle count does not match the encoder (min&max doubles tau)")
+        self.desc = d
+        lib = N.lib()
+        base = self.flat.flat.data_ptr()
+
+        def offsets(net, dec):
+            ts = _slot_tensors(net, dec)
+            want = lib.lgn_step_param_slots(C.byref(d), int(dec))
+            if want < 0:
+                raise RuntimeError(N.last_error())
+            assert len(ts) == want, (len(ts), want)
+            offs = [(t.data_ptr() - base) // 8 for t in ts]
+            assert all(0 <= o < self.flat.flat.numel() for o in offs)
+            return (C.c_int64 * len(offs))(*offs)
+
+        self.enc_off, self.dec_off = offsets(encoder, False), offsets(decoder, True)
+        nws = lib.lgn_step_workspace_doubles(C.byref(d))
+        if nws < 0:
+            raise RuntimeError(N.last_error())
+        self.workspace = torch.empty(nws, device=dev, dtype=dt)
+        self.recon = torch.empty(2, d.B, d.N, 4, device=dev, dtype=dt)
+        self.loss_part = torch.empty(d.B, device=dev, dtype=dt)
+        self.loss_out = torch.zeros(3, device=dev, dtype=dt)
+        self.adam_m = torch.zeros_like(self.flat.flat)
+        self.adam_v = torch.zeros_like(self.flat.flat)
+        self.step_dev = torch.zeros(1, device=dev, dtype=torch.int64)
+        self.p4 = torch.empty(d.B, d.N, 4, device=dev, dtype=dt)
+        self.mask = torch.empty(d.B, d.N, device=dev, dtype=torch.uint8)
+        self.use_graph = use_graph
+        self._g1 = self._g2 = None
+
+    # -- raw native calls on the current stream
+    def _fwd_bwd(self):
+        import ctypes as C
+        N = self.N
+        rc = N.lib().lgn_step_fwd_bwd_f64(C.byref(self.desc), N.ptr(self.flat.flat), N.ptr(self.flat.grad), self.flat.flat.numel(),
+                                          self.enc_off, self.dec_off, N.ptr(self.p4), N.ptr(self.mask), N.ptr(self.workspace),
+                                          N.ptr(self.recon), N.ptr(self.loss_part), N.stream_ptr())
+        N._check(rc, "lgn_step_fwd_bwd_f64")
+
+    def _finalize(self, do_adam: bool):
+        N = self.N
+        rc = N.lib().lgn_step_finalize_f64(N.ptr(self.flat.flat), N.ptr(self.flat.grad), self.flat.flat.numel(), N.ptr(self.loss_part),
+                                           self.loss_part.numel(), float(self.l1_lambda), N.ptr(self.adam_m), N.ptr(self.adam_v),
+                                           N.ptr(self.step_dev), float(self.lr), float(self.betas[0]), float(self.betas[1]),
+                                           float(self.eps), int(do_adam), N.ptr(self.loss_out), N.stream_ptr())
+        N._check(rc, "lgn_step_finalize_f64")
+
+    def _capture(self):
+        # warm up on a side stream (lazy module loads, hipFuncSetAttribute), then capture
+        snap = (self.flat.flat.clone(), self.adam_m.clone(), self.adam_v.clone(), self.step_dev.clone())
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            self._fwd_bwd()
+            self._finalize(False)
+        torch.cuda.current_stream().wait_stream(s)
+        self._g1, self._g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._g1):
+            self._fwd_bwd()
+        with torch.cuda.graph(self._g2, pool=self._g1.pool()):
+            self._finalize(self.optimizer)
+        with torch.no_grad():   # capture does not execute, but restore anyway in case a backend replays eagerly
+            self.flat.flat.copy_(snap[0]); self.adam_m.copy_(snap[1]); self.adam_v.copy_(snap[2]); self.step_dev.copy_(snap[3])
+
+    def load_batch(self, batch: Dict[str, torch.Tensor]):
+        """Stage a batch into the static input buffers (device-to-device copy; labels/masks as in
+        LGNEncoder._prepare_input, lgn/models/lgn_encoder.py:386-398)."""
+        p4 = batch["p4"]
+        self.p4.copy_(p4.to(self.p4.dtype) * self.encoder.scale if self.encoder.scale != 1.0 else p4)
+        for key in ("labels", "masks", "mask"):
+            if key in batch:
+                self.mask.copy_(batch[key].to(torch.uint8))
+                break
+        else:
+            self.mask.copy_((p4[..., 0] != 0).to(torch.uint8))
+
+    def step(self, batch: Optional[Dict[str, torch.Tensor]] = None):
+        """Runs one step on `batch` (or on the already staged static buffers when batch is None).
+        Returns (total loss tensor (device scalar, as the reference logs it), reconstruction (2,B,N,4))."""
+        if batch is not None:
+            self.load_batch(batch)
+        if self.use_graph and self._g1 is None:
+            self._capture()
+        if self.use_graph:
+            self._g1.replay()
+        else:
+            self._fwd_bwd()
+        if self.world > 1:
+            dist.all_reduce(self.flat.grad, op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_reduce(self.loss_part, op=dist.ReduceOp.SUM, group=self.group)
+        if self.use_graph:
+            self._g2.replay()
+        else:
+            self._finalize(self.optimizer)
+        return self.loss_out[0], self.recon
