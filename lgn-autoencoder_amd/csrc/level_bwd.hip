@@ -12,6 +12,7 @@
 // Complex convention: every map is holomorphic (no conjugation in the forward), so for out = f(z) the
 // planar gradient is G_z = G_out * conj(f'(z)).
 #include "level_dev.hpp"
+#include "ops.hpp"
 
 namespace lgn {
 
@@ -776,6 +777,57 @@ int reduce_partials(const T* part, int nblk, int n, T* out, int accumulate, hipS
   LGN_CHECK_LAUNCH();
   return 0;
 }
+
+// several independent column ranges (possibly of different partial buffers) in ONE launch
+template <typename T>
+__global__ __launch_bounds__(64 * RED_RG) void reduce_segments_kernel(RedJob<T> job) {
+  __shared__ T red[RED_RG][64];
+  int k = 0;
+  while (k + 1 < job.nseg && (int)blockIdx.x >= job.tile0[k + 1]) ++k;
+  const RedSeg<T> sg = job.seg[k];
+  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int col = ((int)blockIdx.x - job.tile0[k]) * 64 + cl;
+  T s0 = T(0), s1 = T(0), s2 = T(0), s3 = T(0);
+  if (col < sg.n) {
+    const T* p = sg.part + sg.col0 + col;
+    int r = rg;
+    for (; r + 3 * RED_RG < sg.rows; r += 4 * RED_RG) {
+      s0 += p[(size_t)r * sg.stride];
+      s1 += p[(size_t)(r + RED_RG) * sg.stride];
+      s2 += p[(size_t)(r + 2 * RED_RG) * sg.stride];
+      s3 += p[(size_t)(r + 3 * RED_RG) * sg.stride];
+    }
+    for (; r < sg.rows; r += RED_RG) s0 += p[(size_t)r * sg.stride];
+  }
+  red[rg][cl] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (rg == 0 && col < sg.n) {
+    T s = T(0);
+#pragma unroll
+    for (int q = 0; q < RED_RG; ++q) s += red[q][cl];
+    sg.out[col] = s;
+  }
+}
+
+template <typename T>
+int reduce_segments(RedJob<T>& job, hipStream_t stream) {
+  int tiles = 0, live = 0;
+  RedJob<T> packed{};
+  for (int k = 0; k < job.nseg; ++k) {
+    if (job.seg[k].n <= 0) continue;
+    packed.seg[live] = job.seg[k];
+    packed.tile0[live] = tiles;
+    tiles += cdiv(job.seg[k].n, 64);
+    ++live;
+  }
+  if (!live) return 0;
+  packed.nseg = live;
+  packed.tile0[live] = tiles;
+  hipLaunchKernelGGL(reduce_segments_kernel<T>, dim3(tiles), dim3(64 * RED_RG), 0, stream, packed);
+  LGN_CHECK_LAUNCH();
+  return 0;
+}
+template int reduce_segments<double>(RedJob<double>&, hipStream_t);
 
 // columns [col0, col0+n) of rows of length `stride`
 template <typename T>

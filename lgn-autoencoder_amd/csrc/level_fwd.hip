@@ -8,6 +8,8 @@
 // Thread (il, js) owns output row i = tile*IT + il and visits neighbours j = js, js+JS, ...; the JS
 // partial sums of a row live in adjacent lanes and are combined with wave shuffles.  Node features
 // of the whole jet, positions, mask and all parameters are staged once in LDS.
+#include <stdlib.h>
+
 #include "level_dev.hpp"
 
 namespace lgn {
@@ -211,8 +213,16 @@ static int launch_level_fwd(const LevelArgs<T>& a, hipStream_t stream) {
   return 0;
 }
 
+int level_fwd2_dispatch(const LevelArgs<double>& a, int decoder, hipStream_t stream);   // level_fwd2.hip
+
+static bool use_v1() {
+  static const bool v = [] { const char* e = getenv("LGN_AMD_LEVEL_V1"); return e && e[0] == '1'; }();
+  return v;
+}
+
 template <typename T>
 int level_fwd_dispatch(const LevelArgs<T>& a, int decoder, hipStream_t stream) {
+  if (!use_v1()) return level_fwd2_dispatch(a, decoder, stream);      // matrix-core version (default)
   LGN_CHECK_ARG(a.B > 0 && a.N > 0, "level_fwd: empty batch (B=%d N=%d)", a.B, a.N);
   LGN_CHECK_ARG(a.CO >= 1 && a.CO <= 8, "level_fwd: C_out=%d unsupported (1..8)", a.CO);
   LGN_CHECK_ARG(a.B <= 65535 * 32, "level_fwd: batch too large");

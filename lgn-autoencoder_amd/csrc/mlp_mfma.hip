@@ -38,45 +38,94 @@ struct Geo {
 };
 
 // ---- weight staging ------------------------------------------------------------------------------
-template <int NT>
-__device__ __forceinline__ void prefetch_weights(const double* __restrict__ W, int Hout, int Hin, double (&regs)[Geo<NT>::NPF]) {
-  const int HoP = pad16(Hout), KP = pad16(Hin);      // zero-pad both ways (k padding feeds MFMA zeros)
+// Image of one Linear layer in LDS: W[o][k] at Wl[o*S + k] (zero padded to 16-multiples both ways, k padding feeds
+// the MFMAs zeros) and its bias at Wl[o*S + HP] (S >= HP + 2).  KP = padded input width, a compile-time constant
+// so that the element -> (o,k) split costs a multiply-shift, not an integer division.
+template <int NT, int KP>
+__device__ __forceinline__ void prefetch_weights(const double* __restrict__ W, const double* __restrict__ bias, int Hout,
+                                                 int Hin, double (&regs)[Geo<NT>::NPF], double& breg) {
+  const int HoP = pad16(Hout);
 #pragma unroll
   for (int i = 0; i < Geo<NT>::NPF; ++i) {
     const int e = threadIdx.x + BLOCK * i;
     const int o = e / KP, k = e - o * KP;
     regs[i] = (e < HoP * KP && o < Hout && k < Hin) ? W[(size_t)o * Hin + k] : 0.0;
   }
+  breg = ((int)threadIdx.x < Hout) ? bias[threadIdx.x] : 0.0;
 }
-template <int NT>
-__device__ __forceinline__ void commit_weights(double* Wl, int Hout, int Hin, const double (&regs)[Geo<NT>::NPF]) {
-  const int HoP = pad16(Hout), KP = pad16(Hin);
+template <int NT, int KP>
+__device__ __forceinline__ void commit_weights(double* Wl, int Hout, const double (&regs)[Geo<NT>::NPF], double breg) {
+  const int HoP = pad16(Hout);
 #pragma unroll
   for (int i = 0; i < Geo<NT>::NPF; ++i) {
     const int e = threadIdx.x + BLOCK * i;
     const int o = e / KP, k = e - o * KP;
     if (e < HoP * KP) Wl[o * Geo<NT>::S + k] = regs[i];
   }
+  if ((int)threadIdx.x < Geo<NT>::HP) Wl[threadIdx.x * Geo<NT>::S + Geo<NT>::HP] = breg;
+}
+// layer-kind dispatch: the first Linear has a 16-wide (padded 2C) input, all others a HP-wide one
+template <int NT>
+__device__ __forceinline__ void prefetch_layer(const MlpArgs<double>& a, int l, int NH, int D, int H, double (&regs)[Geo<NT>::NPF],
+                                               double& breg) {
+  if (l == 0) prefetch_weights<NT, 16>(a.w[0], a.b[0], H, D, regs, breg);
+  else prefetch_weights<NT, Geo<NT>::HP>(a.w[l], a.b[l], l == NH ? D : H, H, regs, breg);
+}
+template <int NT>
+__device__ __forceinline__ void commit_layer(double* Wl, int l, int NH, int D, int H, const double (&regs)[Geo<NT>::NPF], double breg) {
+  if (l == 0) commit_weights<NT, 16>(Wl, H, regs, breg);
+  else commit_weights<NT, Geo<NT>::HP>(Wl, l == NH ? D : H, regs, breg);
 }
 
 // ---- one dense layer on a wave's 16-row tile:  acc[t] (D layout) = bias + X W^T ---------------------
 template <int NT>
-__device__ __forceinline__ void dense_tile(const double* Xt, const double* Wl, const double* __restrict__ bias, int Hin,
-                                           int Hout, int lane, v4d (&acc)[NT]) {
+__device__ __forceinline__ void load_bias(const double* Wl, int lane, double (&bv)[NT]) {
+  const int c = lane & 15;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) bv[t] = Wl[(16 * t + c) * Geo<NT>::S + Geo<NT>::HP];     // zero for padded neurons
+}
+
+// NU = number of live N-tiles (compile time: a run-time guard around the MFMA makes hipcc shuttle the accumulators
+// between AGPRs and VGPRs and serialise on every MFMA's latency)
+template <int NT, int NU>
+__device__ __forceinline__ void dense_tile(const double* Xt, const double* Wl, const double (&bv)[NT], int Hin,
+                                           int lane, v4d (&acc)[NT]) {
   constexpr int S = Geo<NT>::S;
   const int c = lane & 15, g = lane >> 4;
-  const int nt = (Hout + 15) >> 4;
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const double bv = (t < nt && 16 * t + c < Hout) ? bias[16 * t + c] : 0.0;
-    acc[t] = v4d{bv, bv, bv, bv};
-  }
+  for (int t = 0; t < NT; ++t) acc[t] = v4d{bv[t], bv[t], bv[t], bv[t]};
   const int ks = pad4(Hin) >> 2;
-  for (int s = 0; s < ks; ++s) {
-    const double a = Xt[c * S + 4 * s + g];
+  const double* xa = Xt + c * S + g;
+  const double* wb = Wl + c * S + g;
+  // software pipelined over k-steps: operands of step s+1 are read while the MFMAs of step s run
+  double a = xa[0], b[NU];
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
-      if (t < nt) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Wl[(16 * t + c) * S + 4 * s + g], acc[t], 0, 0, 0);
+  for (int t = 0; t < NU; ++t) b[t] = wb[16 * t * S];
+  for (int s = 0; s < ks; ++s) {
+    const int sn = s + 1 < ks ? s + 1 : s;
+    const double an = xa[4 * sn];
+    double bn[NU];
+#pragma unroll
+    for (int t = 0; t < NU; ++t) bn[t] = wb[16 * t * S + 4 * sn];
+#pragma unroll
+    for (int t = 0; t < NU; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[t], acc[t], 0, 0, 0);
+    a = an;
+#pragma unroll
+    for (int t = 0; t < NU; ++t) b[t] = bn[t];
+  }
+}
+
+// g_in (D layout) += g_pre W for this wave's rows; NU live input tiles
+template <int NT, int NU>
+__device__ __forceinline__ void gin_tile(const double* Gt, const double* Wcur, int Hout, int lane, v4d (&gin)[NT]) {
+  constexpr int S = Geo<NT>::S;
+  const int c = lane & 15, g = lane >> 4;
+  const int ks = pad4(Hout) >> 2;
+  for (int s = 0; s < ks; ++s) {
+    const double av = Gt[c * S + 4 * s + g];
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+      gin[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Wcur[(4 * s + g) * S + 16 * u + c], gin[u], 0, 0, 0);
   }
 }
 
@@ -112,25 +161,28 @@ __global__ __launch_bounds__(BLOCK) void mlp_fwd_mfma_kernel(MlpArgs<double> a) 
   double* Wl = reinterpret_cast<double*>(smem_raw);          // 2 weight images
   double* Xt = Wl + 2 * G::WSIZE + wave * G::TSIZE;          // this wave's activation tile
 
-  double regs[G::NPF];
-  prefetch_weights<NT>(a.w[0], H, D, regs);
+  double regs[G::NPF], breg;
+  prefetch_layer<NT>(a, 0, NH, D, H, regs, breg);
   load_input_tile<NT>(a.s_in, M, a.C, row0, Xt, lane);
-  commit_weights<NT>(Wl, H, D, regs);
+  commit_layer<NT>(Wl, 0, NH, D, H, regs, breg);
   __syncthreads();
 #pragma unroll
   for (int l = 0; l <= NH; ++l) {
-    const int Hin = l == 0 ? D : H, Hout = l == NH ? D : H;
+    const int Hin = l == 0 ? D : H;
     double* Wcur = Wl + (l & 1) * G::WSIZE;
-    if (l < NH) prefetch_weights<NT>(a.w[l + 1], l + 1 == NH ? D : H, H, regs);
+    double bv[NT];
+    load_bias<NT>(Wcur, lane, bv);
+    if (l < NH) prefetch_layer<NT>(a, l + 1, NH, D, H, regs, breg);
     v4d acc[NT];
-    dense_tile<NT>(Xt, Wcur, a.b[l], Hin, Hout, lane, acc);
+    if (l < NH) dense_tile<NT, NT>(Xt, Wcur, bv, Hin, lane, acc);
+    else dense_tile<NT, 1>(Xt, Wcur, bv, Hin, lane, acc);
     if (l < NH) {
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[t][r] = leaky(acc[t][r]);
       store_tile<NT>(Xt, acc, lane);
-      commit_weights<NT>(Wl + ((l + 1) & 1) * G::WSIZE, l + 1 == NH ? D : H, H, regs);
+      commit_layer<NT>(Wl + ((l + 1) & 1) * G::WSIZE, l + 1, NH, D, H, regs, breg);
       __syncthreads();
     } else {
       const int c = lane & 15, g = lane >> 4;
@@ -163,11 +215,11 @@ __global__ __launch_bounds__(BLOCK) void mlp_bwd_mfma_kernel(MlpArgs<double> a) 
   double* part = a.part + (size_t)blockIdx.x * a.psize;
 
   // ---- forward recompute; h[l] = post-activation of hidden layer l in D layout -----------------------
-  double regs[G::NPF];
-  prefetch_weights<NT>(a.w[0], H, D, regs);
+  double regs[G::NPF], breg;
+  prefetch_layer<NT>(a, 0, NH, D, H, regs, breg);
   load_input_tile<NT>(a.s_in, M, a.C, row0, X0t, lane);
   for (int e = lane; e < 16 * 16; e += 64) Xt[(e >> 4) * S + (e & 15)] = X0t[(e >> 4) * S + (e & 15)];
-  commit_weights<NT>(Wl, H, D, regs);
+  commit_layer<NT>(Wl, 0, NH, D, H, regs, breg);
   __syncthreads();
   v4d h[NH][NT];
 #pragma unroll
@@ -175,14 +227,16 @@ __global__ __launch_bounds__(BLOCK) void mlp_bwd_mfma_kernel(MlpArgs<double> a) 
     const int Hin = l == 0 ? D : H;
     double* Wcur = Wl + (l & 1) * G::WSIZE;
     // the weights of the next forward layer; after the last hidden layer: the output layer (first backward layer)
-    prefetch_weights<NT>(a.w[l + 1], l + 1 == NH ? D : H, H, regs);
-    dense_tile<NT>(Xt, Wcur, a.b[l], Hin, H, lane, h[l]);
+    double bv[NT];
+    load_bias<NT>(Wcur, lane, bv);
+    prefetch_layer<NT>(a, l + 1, NH, D, H, regs, breg);
+    dense_tile<NT, NT>(Xt, Wcur, bv, Hin, lane, h[l]);
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) h[l][t][r] = leaky(h[l][t][r]);
     if (l + 1 < NH) store_tile<NT>(Xt, h[l], lane);
-    commit_weights<NT>(Wl + ((l + 1) & 1) * G::WSIZE, l + 1 == NH ? D : H, H, regs);
+    commit_layer<NT>(Wl + ((l + 1) & 1) * G::WSIZE, l + 1, NH, D, H, regs, breg);
     __syncthreads();
   }
 
@@ -204,7 +258,7 @@ __global__ __launch_bounds__(BLOCK) void mlp_bwd_mfma_kernel(MlpArgs<double> a) 
     double* pW = part + poff_end;
     double* pB = pW + (size_t)Hout * Hin;
     double* Wcur = Wl + (l & 1) * G::WSIZE;                   // image of W_l (staged by the previous iteration)
-    if (l > 0) prefetch_weights<NT>(a.w[l - 1], H, l - 1 == 0 ? D : H, regs);
+    if (l > 0) prefetch_layer<NT>(a, l - 1, NH, D, H, regs, breg);
 
     // operands of this layer to LDS: g_pre tile and layer-input tile (h[l-1]; the MLP input for l == 0)
     store_tile<NT>(Gt, gpre, lane);
@@ -223,15 +277,8 @@ __global__ __launch_bounds__(BLOCK) void mlp_bwd_mfma_kernel(MlpArgs<double> a) 
     v4d gin[NT];
 #pragma unroll
     for (int u = 0; u < NT; ++u) gin[u] = v4d{0, 0, 0, 0};
-    {
-      const int ks = pad4(Hout) >> 2;
-      for (int s = 0; s < ks; ++s) {
-        const double av = Gt[c * S + 4 * s + g];
-#pragma unroll
-        for (int u = 0; u < NT; ++u)
-          if (u < nti) gin[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Wcur[(4 * s + g) * S + 16 * u + c], gin[u], 0, 0, 0);
-      }
-    }
+    if (l == 0) gin_tile<NT, 1>(Gt, Wcur, Hout, lane, gin);      // live input tiles known at compile time
+    else gin_tile<NT, NT>(Gt, Wcur, Hout, lane, gin);
     // (b) dW tiles over the workgroup's 64 rows, dealt round-robin to the waves
     {
       const double* Xsrc = l > 0 ? Xall : X0all;
@@ -264,7 +311,7 @@ __global__ __launch_bounds__(BLOCK) void mlp_bwd_mfma_kernel(MlpArgs<double> a) 
 #pragma unroll
         for (int r = 0; r < 4; ++r) gpre[u][r] = gin[u][r] * (h[l > 0 ? l - 1 : 0][u][r] > 0.0 ? 1.0 : 0.01);
       __syncthreads();                       // everyone is done with Wcur / the tiles
-      commit_weights<NT>(Wl + ((l - 1) & 1) * G::WSIZE, H, l - 1 == 0 ? D : H, regs);
+      commit_layer<NT>(Wl + ((l - 1) & 1) * G::WSIZE, l - 1, NH, D, H, regs, breg);
       // (the g_pre / input tiles are rewritten at the top of the next iteration, followed by a barrier)
     } else {
 #pragma unroll

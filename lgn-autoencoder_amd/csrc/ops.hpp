@@ -9,6 +9,16 @@ template <typename T> int level_fwd_dispatch(const LevelArgs<T>&, int decoder, h
 template <typename T> int level_bwd_dispatch(const LevelBwdArgs<T>&, int decoder, hipStream_t);
 template <typename T> int reduce_partials(const T* part, int rows, int n, T* out, int accumulate, hipStream_t);
 template <typename T> int reduce_partials_strided(const T* part, int rows, int stride, int col0, int n, T* out, hipStream_t);
+// one launch reducing up to 8 column ranges:  seg.out[c] = sum_r seg.part[r*stride + col0 + c]
+constexpr int RED_MAX_SEG = 8;
+template <typename T> struct RedSeg { const T* part; int rows, stride, col0, n; T* out; };
+template <typename T> struct RedJob {
+  int nseg;
+  RedSeg<T> seg[RED_MAX_SEG];
+  int tile0[RED_MAX_SEG + 1];
+  void add(const T* part, int rows, int stride, int col0, int n, T* out) { seg[nseg++] = RedSeg<T>{part, rows, stride, col0, n, out}; }
+};
+template <typename T> int reduce_segments(RedJob<T>& job, hipStream_t);
 template <typename T>
 int rad_finalize(const T* tot, int C, const T* ra, const T* rb, const T* rc, const T* w0, const T* w1, T* g_a, T* g_b, T* g_c,
                  T* g_w0, T* g_b0, T* g_w1, T* g_b1, hipStream_t);

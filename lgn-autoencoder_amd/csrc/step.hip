@@ -169,14 +169,17 @@ int levels_bwd(const lgn_net_desc& d, bool dec, const int* ch, const double* P, 
                            p(S.rad(dec, l, 5)), p(S.rad(dec, l, 6)), p(S.mix(dec, l, 0)), p(S.mix(dec, l, 1)), n.ag0[l], n.ag1[l],
                            g_smix, w.gv[cur], w.g_ag, w.gs[nxt], w.gv[nxt], dec ? w.g_p : nullptr, part_mix, part_rad};
     LGN_TRY(level_bwd_dispatch<double>(a, dec, st));
-    // CatMix weights: partial row = [wm0 | wm1]
-    LGN_TRY(reduce_partials_strided<double>(part_mix, rm, nmix, 0, nmix / 2, g(S.mix(dec, l, 0)), st));
-    LGN_TRY(reduce_partials_strided<double>(part_mix, rm, nmix, nmix / 2, nmix / 2, g(S.mix(dec, l, 1)), st));
+    // one reduction launch per level: CatMix weights (partial row = [wm0 | wm1]) + radial sums
+    RedJob<double> job{};
+    job.add(part_mix, rm, nmix, 0, nmix / 2, g(S.mix(dec, l, 0)));
+    job.add(part_mix, rm, nmix, nmix / 2, nmix / 2, g(S.mix(dec, l, 1)));
     if (dec) {   // only the Linear biases receive gradient (all edges are "masked")
-      LGN_TRY(reduce_partials_strided<double>(part_rad, rr, nrad, 0, C, g(S.rad(dec, l, 4)), st));
-      LGN_TRY(reduce_partials_strided<double>(part_rad, rr, nrad, C, C, g(S.rad(dec, l, 6)), st));
+      job.add(part_rad, rr, nrad, 0, C, g(S.rad(dec, l, 4)));
+      job.add(part_rad, rr, nrad, C, C, g(S.rad(dec, l, 6)));
+      LGN_TRY(reduce_segments<double>(job, st));
     } else {
-      LGN_TRY(reduce_partials<double>(part_rad, rr, nrad, w.tot, 0, st));
+      job.add(part_rad, rr, nrad, 0, nrad, w.tot);
+      LGN_TRY(reduce_segments<double>(job, st));
       LGN_TRY(rad_finalize<double>(w.tot, C, p(S.rad(dec, l, 0)), p(S.rad(dec, l, 1)), p(S.rad(dec, l, 2)), p(S.rad(dec, l, 3)),
                                    p(S.rad(dec, l, 5)), g(S.rad(dec, l, 0)), g(S.rad(dec, l, 1)), g(S.rad(dec, l, 2)),
                                    g(S.rad(dec, l, 3)), g(S.rad(dec, l, 4)), g(S.rad(dec, l, 5)), g(S.rad(dec, l, 6)), st));
@@ -271,24 +274,30 @@ int lgn_step_fwd_bwd_f64(const lgn_net_desc* d, const double* params, double* gr
     const int C0 = cd[0], Tin = 2 * Tv, row = 4 * C0 + 2 * N * Tin;
     LGN_TRY(dec_input_bwd(B, N, C0, Tin, w.lat_v, params + dec_off[1], params + dec_off[3], w.pdec, w.g_p, w.gs[cur], w.gv[cur],
                           w.g_lat_v, w.part, st));
-    LGN_TRY(reduce_partials_strided<double>(w.part, B, row, 0, 2 * C0, grads + dec_off[2], st));
-    LGN_TRY(reduce_partials_strided<double>(w.part, B, row, 2 * C0, 2 * C0, grads + dec_off[3], st));
-    LGN_TRY(reduce_partials_strided<double>(w.part, B, row, 4 * C0, 2 * N * Tin, grads + dec_off[1], st));
+    RedJob<double> job{};
+    job.add(w.part, B, row, 0, 2 * C0, grads + dec_off[2]);
+    job.add(w.part, B, row, 2 * C0, 2 * C0, grads + dec_off[3]);
+    job.add(w.part, B, row, 4 * C0, 2 * N * Tin, grads + dec_off[1]);
+    LGN_TRY(reduce_segments<double>(job, st));
   }
   {
     const int CL = ce[L], row = 2 * (Ts + Tv) * CL;
     cur = 0;
     LGN_TRY(enc_latent_bwd(B, N, CL, Ts, Tv, w.enc.s[L], w.enc.v[L], params + enc_off[S.out0(false)],
                            params + enc_off[S.out0(false) + 1], w.g_lat_s, w.g_lat_v, w.idx, w.gs[cur], w.gv[cur], w.part, st));
-    LGN_TRY(reduce_partials_strided<double>(w.part, B, row, 0, 2 * Ts * CL, grads + enc_off[S.out0(false)], st));
-    LGN_TRY(reduce_partials_strided<double>(w.part, B, row, 2 * Ts * CL, 2 * Tv * CL, grads + enc_off[S.out0(false) + 1], st));
+    RedJob<double> job{};
+    job.add(w.part, B, row, 0, 2 * Ts * CL, grads + enc_off[S.out0(false)]);
+    job.add(w.part, B, row, 2 * Ts * CL, 2 * Tv * CL, grads + enc_off[S.out0(false) + 1]);
+    LGN_TRY(reduce_segments<double>(job, st));
   }
   LGN_TRY(levels_bwd(*d, false, ce, params, grads, enc_off, w.enc, p4, mask, w, cur, /*has_s_grad=*/false, st));
   {
     const int C0 = ce[0];
     LGN_TRY(enc_input_bwd(B, N, C0, p4, w.gs[cur], w.gv[cur], w.part, st));
-    LGN_TRY(reduce_partials_strided<double>(w.part, B, 4 * C0, 0, 2 * C0, grads + enc_off[0], st));
-    LGN_TRY(reduce_partials_strided<double>(w.part, B, 4 * C0, 2 * C0, 2 * C0, grads + enc_off[1], st));
+    RedJob<double> job{};
+    job.add(w.part, B, 4 * C0, 0, 2 * C0, grads + enc_off[0]);
+    job.add(w.part, B, 4 * C0, 2 * C0, 2 * C0, grads + enc_off[1]);
+    LGN_TRY(reduce_segments<double>(job, st));
   }
   return 0;
 }
