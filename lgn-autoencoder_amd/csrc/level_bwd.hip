@@ -11,6 +11,8 @@
 //
 // Complex convention: every map is holomorphic (no conjugation in the forward), so for out = f(z) the
 // planar gradient is G_z = G_out * conj(f'(z)).
+#include <stdlib.h>
+
 #include "level_dev.hpp"
 #include "ops.hpp"
 
@@ -701,6 +703,14 @@ static int ensure_smem(K kern, size_t smem, const char* what) {
   return 0;
 }
 
+int level_bwd_nodes2_dispatch(const LevelBwdArgs<double>& a, int decoder, hipStream_t stream);   // level_bwd2.hip
+int level_bwd_rad2_dispatch(const LevelBwdArgs<double>& a, hipStream_t stream);
+
+static bool use_v1() {
+  static const bool v = [] { const char* e = getenv("LGN_AMD_LEVEL_V1"); return e && e[0] == '1'; }();
+  return v;
+}
+
 int level_bwd_rad_jt(int N) { return N <= 64 ? ((N + 7) / 8) * 8 : 32; }
 
 // number of partial rows the backward launch writes (host side must size the workspace with these)
@@ -709,6 +719,8 @@ void level_bwd_partial_rows(int B, int N, int decoder, int* rows_mix, int* rows_
   *rows_mix = B * tiles;
   if (decoder) {
     *rows_rad = B * tiles;
+  } else if (!use_v1()) {
+    *rows_rad = B;                       // level_bwd_rad2: one partial row per jet
   } else {
     const int JT = level_bwd_rad_jt(N);
     *rows_rad = B * tiles * cdiv(N, JT);
@@ -727,7 +739,9 @@ static int launch_level_bwd(const LevelBwdArgs<T>& a, hipStream_t stream) {
     hipLaunchKernelGGL(kern, dim3(a.B, tiles), dim3(BLOCK), smem, stream, a);
     LGN_CHECK_LAUNCH();
   }
-  {  // 2. j-centric pass
+  if (!use_v1()) {  // 2. j-centric pass, matrix-core version
+    if ((rc = level_bwd_nodes2_dispatch(a, DEC, stream))) return rc;
+  } else {
     constexpr int IS = 8;
     auto kern = level_bwd_nodes_kernel<T, C, IS, DEC>;
     size_t smem = sizeof(T) * (N * GA<C>::SIZE + L::even(N * L::PS) + L::even(L::RAD_SIZE)) + N + 16;
@@ -741,6 +755,8 @@ static int launch_level_bwd(const LevelBwdArgs<T>& a, hipStream_t stream) {
     if ((rc = ensure_smem(kern, smem, "level_bwd_rad_dec"))) return rc;
     hipLaunchKernelGGL(kern, dim3(a.B, tiles), dim3(BLOCK), smem, stream, a);
     LGN_CHECK_LAUNCH();
+  } else if (!use_v1()) {  // 3a, matrix-core version
+    if ((rc = level_bwd_rad2_dispatch(a, stream))) return rc;
   } else {  // 3a
     using S = Stage<C>;
     const int JT = level_bwd_rad_jt(N);

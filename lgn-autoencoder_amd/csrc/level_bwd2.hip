@@ -1,0 +1,488 @@
+// lgn-autoencoder_amd/csrc/level_bwd2.hip -- version 2 of the two N^2 backward passes of the fused level
+// (same mathematics as level_bwd.hip, re-mapped like level_fwd2.hip: a wave owns a group of 4 particles and
+// sweeps the other index in tiles of 4; lane = (pair slot = lane & 15, channel-in-group = lane >> 4); the radial
+// Linear layers run on the fp64 matrix cores).
+//
+//   level_bwd_nodes2   "j-centric": g_node_j += sum_i g_ag_i (x) conj(edge_ij)            (+ decoder d p_j)
+//   level_bwd_rad2     "i-centric", encoder: the four pair-reductions of the radial-network gradient
+//                        T1[r][k] = sum_p G[p][r] on rho_k   T2[r][k] = sum_p G[p][r] on n^2 rho_k^2
+//                        S[r] = sum_p G[p][r] on             dB[r] = sum_p G[p][r]
+//                      are one GEMM  [r x pairs] x [pairs x 42 columns]  executed with v_mfma_f64_16x16x4_f64; the
+//                      two operands are produced pair-per-lane and turned into A/B fragments by a 16x16 transpose
+//                      through a wave-private LDS tile (4 writes + 4 reads per lane for A, 12 + 12 for B).
+#include "level_dev.hpp"
+#include "ops.hpp"
+
+namespace lgn {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+namespace {
+__device__ __forceinline__ double dppq(double v, int xor2) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  if (xor2) {
+    lo = __builtin_amdgcn_mov_dpp(lo, 0x4E, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, 0x4E, 0xF, 0xF, true);
+  } else {
+    lo = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true);
+  }
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double quad_sum(double v) {
+  v += dppq(v, 0);
+  v += dppq(v, 1);
+  return v;
+}
+__device__ __forceinline__ double fast_rcp(double u) {
+  double r = __builtin_amdgcn_rcp(u);
+  double e = __builtin_fma(-u, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-u, r, 1.0);
+  return __builtin_fma(r, e, r);
+}
+template <int C> struct GA2 {
+  static constexpr int A3 = 0, A4 = 2 * C, A1 = 4 * C, A2 = 12 * C, SIZE = 20 * C;
+};
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+}  // namespace
+
+// =========================================================================================================
+// j-centric pass
+// =========================================================================================================
+template <int C, bool DEC>
+__global__ __launch_bounds__(BLOCK) void level_bwd_nodes2_kernel(LevelBwdArgs<double> a) {
+  constexpr int NG = (C + 3) / 4;
+  constexpr int PS = DEC ? 8 : 4;
+  using G = GA2<C>;
+  const int N = a.N, B = a.B;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  double* ga = reinterpret_cast<double*>(smem_raw);          // N * 20C   gradient of the aggregate, all receivers i
+  double* pj = ga + N * G::SIZE;                              // N * PS
+  uint8_t* mk = reinterpret_cast<uint8_t*>(pj + N * PS);      // N
+
+  {
+    const double* src = a.g_ag + (size_t)b * N * G::SIZE;
+    for (int e = tid; e < N * G::SIZE; e += BLOCK) ga[e] = src[e];
+    if (DEC) {
+      const size_t plane_p = (size_t)B * N * 4;
+      const double* p0 = a.p + (size_t)b * N * 4;
+      for (int e = tid; e < N * 4; e += BLOCK) {
+        int j = e >> 2, m = e & 3;
+        pj[j * 8 + m] = p0[e];
+        pj[j * 8 + 4 + m] = p0[plane_p + e];
+      }
+    } else {
+      const double* p0 = a.p + (size_t)b * N * 4;
+      for (int e = tid; e < N * 4; e += BLOCK) pj[e] = p0[e];
+      for (int e = tid; e < N; e += BLOCK) mk[e] = a.mask[(size_t)b * N + e];
+    }
+  }
+  const int pr = lane & 15, cg = lane >> 4;
+  const int tj = pr >> 2, ti = pr & 3;                        // which of the wave's 4 source particles j / slot in the i tile
+  double ak[5], bk[5], ck2[5], wf[NG][5], bias[NG][4];
+  if (!DEC) {
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+      const int k = 4 * s + cg;
+      ak[s] = a.ra[k];
+      bk[s] = a.rb[k];
+      const double c = a.rc[k];
+      ck2[s] = c * c;
+    }
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const int rr = lane & 15, q = rr >> 2, ch = 4 * g + (rr & 3);
+      const double* w = (q >> 1) ? a.w1 : a.w0;
+#pragma unroll
+      for (int s = 0; s < 5; ++s) wf[g][s] = ch < C ? w[(2 * ch + (q & 1)) * NB + 4 * s + cg] : 0.0;
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    const int ch = 4 * g + cg;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const double* bb = (q >> 1) ? a.b1 : a.b0;
+      bias[g][q] = ch < C ? (DEC ? bb[ch] : bb[2 * ch + (q & 1)]) : 0.0;
+    }
+  }
+  __syncthreads();
+
+  const size_t pls = (size_t)B * N * C;
+  const int ngroups = (N + 3) >> 2;
+  for (int rg = wave; rg < ngroups; rg += 4) {
+    const int j = rg * 4 + tj;
+    const bool jok = j < N;
+    const int jj = jok ? j : N - 1;
+    double pme[PS];
+#pragma unroll
+    for (int m = 0; m < PS; ++m) pme[m] = pj[jj * PS + m];
+    const bool mj = DEC ? false : (mk[jj] != 0);
+
+    cx<double> Gs[NG], Gv[NG][4], Gq[4];
+    cx<double> sj[NG], vtj[NG][4];                             // own node features (decoder position gradient)
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      Gs[g] = {0, 0};
+#pragma unroll
+      for (int m = 0; m < 4; ++m) Gv[g][m] = {0, 0};
+      if (DEC) {
+        const int ch = 4 * g + cg;
+        const size_t e = ((size_t)b * N + jj) * C + (ch < C ? ch : 0);
+        sj[g] = {a.s_in[e], a.s_in[pls + e]};
+        cx<double> v[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) v[m] = {a.v_in[e * 4 + m], a.v_in[pls * 4 + e * 4 + m]};
+        metric_perm(v, vtj[g]);
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) Gq[m] = {0, 0};
+
+    for (int i0 = 0; i0 < N; i0 += 4) {
+      const int i = i0 + ti;
+      const bool ok = jok && i < N;
+      const int ii = i < N ? i : N - 1;
+      const double* pii = pj + ii * PS;
+      cx<double> q[4];
+      v4d R[NG];
+      if (DEC) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) q[m] = {pii[m] - pme[m], pii[4 + m] - pme[4 + m]};
+#pragma unroll
+        for (int g = 0; g < NG; ++g) R[g] = v4d{bias[g][0], bias[g][1], bias[g][2], bias[g][3]};
+      } else {
+        const double d0 = pii[0] - pme[0], d1 = pii[1] - pme[1], d2 = pii[2] - pme[2], d3 = pii[3] - pme[3];
+        const double q0 = d0 * d0, q1 = d1 * d1, q2 = d2 * d2, q3 = d3 * d3;
+        const double nsq = (2.0 * q0 - (((q0 + q1) + q2) + q3)) + 1e-16;
+        const double an = fabs(nsq);
+        const bool on = ok && mj && (mk[ii] != 0) && (nsq != 0.0);
+        const double h = rsqrt2<double>();
+        q[0] = {d0, 0.0};
+        q[1] = {d1 * h, -d2 * h};
+        q[2] = {d3, 0.0};
+        q[3] = {-d1 * h, -d2 * h};
+        double beta[5];
+#pragma unroll
+        for (int s = 0; s < 5; ++s) {
+          const double u = (1.0 + ck2[s] * an) + 1e-16;
+          const double bv = __builtin_fma(bk[s], fast_rcp(u), ak[s]);
+          beta[s] = on ? bv : 0.0;
+        }
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          R[g] = v4d{bias[g][0], bias[g][1], bias[g][2], bias[g][3]};
+#pragma unroll
+          for (int s = 0; s < 5; ++s) R[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(wf[g][s], beta[s], R[g], 0, 0, 0);
+        }
+      }
+      if (ok) {
+        const double* gi = ga + ii * G::SIZE;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          const int ch = 4 * g + cg;
+          if (ch < C) {
+            const cx<double> R0 = {R[g][0], R[g][1]}, R1 = {R[g][2], R[g][3]};
+            const cx<double> e0 = {R0.r - R0.i, R0.r + R0.i};
+            cx<double> e1[4], e1t[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) e1[m] = cmul(R1, q[m]);
+            metric_perm(e1, e1t);
+            const cx<double> gA3 = {0.5 * gi[G::A3 + 2 * ch], 0.5 * gi[G::A3 + 2 * ch + 1]};
+            const cx<double> gA4 = {gi[G::A4 + 2 * ch], gi[G::A4 + 2 * ch + 1]};
+            cfmac(Gs[g], gA4, e0);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+              const cx<double> gA1 = {gi[G::A1 + (ch * 4 + m) * 2], gi[G::A1 + (ch * 4 + m) * 2 + 1]};
+              const cx<double> gA2 = {gi[G::A2 + (ch * 4 + m) * 2], gi[G::A2 + (ch * 4 + m) * 2 + 1]};
+              cfmac(Gv[g][m], gA1, e0);
+              cfmac(Gv[g][m], gA3, e1t[m]);
+              cfmac(Gs[g], gA2, e1[m]);
+              if (DEC) {
+                cx<double> ge1 = cmulc(gA2, sj[g]);
+                cfmac(ge1, gA3, vtj[g][m]);
+                cfmac(Gq[m], ge1, R1);
+              }
+            }
+          }
+        }
+      }
+    }
+
+    // combine the 4 i-slots (quad lanes); the ti == 0 lane of each (j, channel) adds into the node gradient
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const int ch = 4 * g + cg;
+      const double sr = quad_sum(Gs[g].r), si = quad_sum(Gs[g].i);
+      const size_t e = ((size_t)b * N + jj) * C + ch;
+      const bool wr = jok && ti == 0 && ch < C;
+      if (wr) {
+        a.g_s_in[e] += sr;
+        a.g_s_in[pls + e] += si;
+      }
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const double vr = quad_sum(Gv[g][m].r), vi = quad_sum(Gv[g][m].i);
+        if (wr) {
+          a.g_v_in[e * 4 + m] += vr;
+          a.g_v_in[pls * 4 + e * 4 + m] += vi;
+        }
+      }
+    }
+    if (DEC) {   // position gradient: also sum over the channel lanes (lane bits 4, 5)
+      const size_t plp = (size_t)B * N * 4;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        double qr = quad_sum(Gq[m].r), qi = quad_sum(Gq[m].i);
+        qr += shfl_xor(qr, 16);  qr += shfl_xor(qr, 32);
+        qi += shfl_xor(qi, 16);  qi += shfl_xor(qi, 32);
+        if (jok && ti == 0 && cg == 0) {
+          a.g_p[((size_t)b * N + jj) * 4 + m] -= qr;
+          a.g_p[plp + ((size_t)b * N + jj) * 4 + m] -= qi;
+        }
+      }
+    }
+  }
+}
+
+// =========================================================================================================
+// i-centric pass, encoder: radial-network gradient sums on the matrix cores
+// =========================================================================================================
+// B-operand columns (3 N-tiles of 16):  [0,16) X1[k=0..15] | [16,32) X2[k=0..15] | 32..35 X1[16..19], 36..39 X2[16..19], 40 on, 41 one
+template <int C>
+__global__ __launch_bounds__(BLOCK) void level_bwd_rad2_kernel(LevelBwdArgs<double> a) {
+  constexpr int NG = (C + 3) / 4;
+  constexpr int NS = node_stride(C);
+  using G = GA2<C>;
+  constexpr int TS = 18;                                   // padded row stride of the 16 x 16 transpose tiles (scalars)
+  const int N = a.N, B = a.B;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  double* nd = reinterpret_cast<double*>(smem_raw);          // N * NS     source node features
+  double* pj = nd + ((N * NS + 1) & ~1);                     // N * 4
+  double* tr = pj + N * 4;                                   // 4 waves * (NG + 3) tiles * 16 * TS
+  double* red = tr;                                          // 4 waves * 64 lanes * NG * 12, aliases the transpose tiles (used after the sweep)
+  uint8_t* mk = reinterpret_cast<uint8_t*>(tr + (4 * (NG + 3) * 16 * TS > 4 * 64 * NG * 12 ? 4 * (NG + 3) * 16 * TS : 4 * 64 * NG * 12));
+
+  load_jet<double, C, false>(a.s_in, a.v_in, a.p, a.mask, B, N, b, nd, pj, mk);
+  const int pr = lane & 15, cg = lane >> 4;
+  const int ti = pr >> 2, tj = pr & 3;
+  double ck2[5];
+#pragma unroll
+  for (int s = 0; s < 5; ++s) {
+    const double c = a.rc[4 * s + cg];
+    ck2[s] = c * c;
+  }
+  __syncthreads();
+
+  double* trw = tr + wave * (NG + 3) * 16 * TS;              // this wave's transpose tiles: NG x G, 3 x X
+  v4d T[NG][3];
+#pragma unroll
+  for (int g = 0; g < NG; ++g)
+#pragma unroll
+    for (int t = 0; t < 3; ++t) T[g][t] = v4d{0, 0, 0, 0};
+
+  const int ngroups = (N + 3) >> 2;
+  for (int rg = wave; rg < ngroups; rg += 4) {
+    const int i = rg * 4 + ti;
+    const bool iok = i < N;
+    const int ii = iok ? i : N - 1;
+    const double pi0 = pj[ii * 4], pi1 = pj[ii * 4 + 1], pi2 = pj[ii * 4 + 2], pi3 = pj[ii * 4 + 3];
+    const bool mi = mk[ii] != 0;
+    // gradient of the aggregate of this lane's receiver i and channel(s): registers for the whole sweep
+    cx<double> rA1[NG][4], rA2[NG][4], rA3[NG], rA4[NG];
+    {
+      const double* gi = a.g_ag + ((size_t)b * N + ii) * G::SIZE;
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        const int ch = 4 * g + cg;
+        const bool live = iok && ch < C;
+        const int cs = ch < C ? ch : 0;
+        rA3[g] = live ? cx<double>{0.5 * gi[G::A3 + 2 * cs], 0.5 * gi[G::A3 + 2 * cs + 1]} : cx<double>{0, 0};
+        rA4[g] = live ? cx<double>{gi[G::A4 + 2 * cs], gi[G::A4 + 2 * cs + 1]} : cx<double>{0, 0};
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          rA1[g][m] = live ? cx<double>{gi[G::A1 + (cs * 4 + m) * 2], gi[G::A1 + (cs * 4 + m) * 2 + 1]} : cx<double>{0, 0};
+          rA2[g][m] = live ? cx<double>{gi[G::A2 + (cs * 4 + m) * 2], gi[G::A2 + (cs * 4 + m) * 2 + 1]} : cx<double>{0, 0};
+        }
+      }
+    }
+    for (int j0 = 0; j0 < N; j0 += 4) {
+      const int j = j0 + tj;
+      const bool ok = iok && j < N;
+      const int jj = j < N ? j : N - 1;
+      const double* pjj = pj + jj * 4;
+      const double d0 = pi0 - pjj[0], d1 = pi1 - pjj[1], d2 = pi2 - pjj[2], d3 = pi3 - pjj[3];
+      const double q0 = d0 * d0, q1 = d1 * d1, q2 = d2 * d2, q3 = d3 * d3;
+      const double nsq = (2.0 * q0 - (((q0 + q1) + q2) + q3)) + 1e-16;
+      const double an = fabs(nsq);
+      const bool on = ok && mi && (mk[jj] != 0) && (nsq != 0.0);
+      const double h = rsqrt2<double>();
+      cx<double> q[4];
+      q[0] = {d0, 0.0};
+      q[1] = {d1 * h, -d2 * h};
+      q[2] = {d3, 0.0};
+      q[3] = {-d1 * h, -d2 * h};
+
+      // ---- B operand source: this lane's pair (row pr), columns k = 4s + cg ----------------------------
+      double* xb = trw + NG * 16 * TS;                         // three 16 x 16 tiles [pair][col]
+#pragma unroll
+      for (int s = 0; s < 5; ++s) {
+        const double rho = on ? fast_rcp((1.0 + ck2[s] * an) + 1e-16) : 0.0;
+        const double x2 = an * rho * rho;
+        if (s < 4) {
+          xb[pr * TS + 4 * s + cg] = rho;                      // tile 0: X1[k], k = 4s + cg < 16
+          xb[16 * TS + pr * TS + 4 * s + cg] = x2;             // tile 1: X2[k]
+        } else {
+          xb[32 * TS + pr * TS + cg] = rho;                    // tile 2: cols 0..3 X1[16 + cg]
+          xb[32 * TS + pr * TS + 4 + cg] = x2;                 //         cols 4..7 X2[16 + cg]
+        }
+      }
+      // cols 8 (on), 9 (one), 10..15 zero: each of the 4 channel lanes of a pair fills two of them
+      xb[32 * TS + pr * TS + 8 + 2 * cg] = cg == 0 ? (on ? 1.0 : 0.0) : 0.0;
+      xb[32 * TS + pr * TS + 9 + 2 * cg] = cg == 0 ? (ok ? 1.0 : 0.0) : 0.0;
+
+      // ---- A operand source: dL/d rad of this lane's pair and channel -------------------------------------
+      const double* njp = nd + jj * NS;
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        const int ch = 4 * g + cg;
+        double G0r = 0, G0i = 0, G1r = 0, G1i = 0;
+        if (ok && ch < C) {
+          const cx<double> s = {njp[ch * 10], njp[ch * 10 + 1]};
+          cx<double> v[4], vt[4];
+#pragma unroll
+          for (int m = 0; m < 4; ++m) v[m] = {njp[ch * 10 + 2 + m], njp[ch * 10 + 6 + m]};
+          metric_perm(v, vt);
+          cx<double> ge0 = cmulc(rA4[g], s);
+          cx<double> gR1 = {0, 0};
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            cfmac(ge0, rA1[g][m], v[m]);
+            cx<double> ge1 = cmulc(rA2[g][m], s);
+            cfmac(ge1, rA3[g], vt[m]);
+            cfmac(gR1, ge1, q[m]);
+          }
+          G0r = ge0.r + ge0.i;  G0i = ge0.i - ge0.r;          // e0 = R0 (1+i)  ->  G_R0 = G_e0 (1-i)
+          G1r = gR1.r;  G1i = gR1.i;
+        }
+        double* ta = trw + g * 16 * TS;                       // [pair][r' = cg + 4q]
+        ta[pr * TS + cg] = G0r;
+        ta[pr * TS + 4 + cg] = G0i;
+        ta[pr * TS + 8 + cg] = G1r;
+        ta[pr * TS + 12 + cg] = G1i;
+      }
+      wave_sync();
+      // ---- T[r'][col] += sum_pairs G[pair][r'] X[pair][col] : A[i = r' = lane&15][k = pair], B[k = pair][j = col] ----
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int prow = 4 * s + cg;                          // pair index held by this lane for k-step s
+        double bv[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) bv[t] = xb[t * 16 * TS + prow * TS + pr];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          const double av = trw[g * 16 * TS + prow * TS + pr];
+#pragma unroll
+          for (int t = 0; t < 3; ++t) T[g][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[t], T[g][t], 0, 0, 0);
+        }
+      }
+      wave_sync();
+    }
+  }
+
+  // ---- cross-wave reduction; D layout: lane holds T[r' = (lane>>4) + 4q][col = lane & 15] -----------------
+  __syncthreads();                                           // every wave is done with its transpose tiles (aliased by red)
+  {
+    double* mine = red + (size_t)(wave * 64 + lane) * NG * 12;
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) mine[(g * 3 + t) * 4 + q] = T[g][t][q];
+  }
+  __syncthreads();
+  if (wave == 0) {
+    constexpr int R = 4 * C;
+    double* part = a.part_rad + (size_t)blockIdx.x * rad_partial_size(C, false);
+    const int col = lane & 15;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const int ch = 4 * g + cg;
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int e = (g * 3 + t) * 4 + q;
+          const double v = (red[(size_t)(0 * 64 + lane) * NG * 12 + e] + red[(size_t)(1 * 64 + lane) * NG * 12 + e]) +
+                           (red[(size_t)(2 * 64 + lane) * NG * 12 + e] + red[(size_t)(3 * 64 + lane) * NG * 12 + e]);
+          if (ch >= C) continue;
+          const int r = (q >> 1) * 2 * C + 2 * ch + (q & 1);       // row of the partial layout: lin*2C + 2c + z
+          if (t == 0) part[r * NB + col] = v;                      // T1[r][k = col]
+          else if (t == 1) part[R * NB + r * NB + col] = v;        // T2[r][k = col]
+          else {
+            if (col < 4) part[r * NB + 16 + col] = v;
+            else if (col < 8) part[R * NB + r * NB + 16 + (col - 4)] = v;
+            else if (col == 8) part[2 * R * NB + r] = v;           // S
+            else if (col == 9) part[2 * R * NB + R + r] = v;       // dB
+          }
+        }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+template <int C, bool DEC>
+static int launch_nodes2(const LevelBwdArgs<double>& a, hipStream_t stream) {
+  constexpr int PS = DEC ? 8 : 4;
+  const size_t smem = sizeof(double) * ((size_t)a.N * 20 * C + (size_t)a.N * PS) + a.N + 16;
+  LGN_CHECK_ARG(smem <= 160 * 1024, "level_bwd_nodes: N=%d C=%d needs %zu B of LDS", a.N, a.C, smem);
+  auto kern = level_bwd_nodes2_kernel<C, DEC>;
+  if (smem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipLaunchKernelGGL(kern, dim3(a.B), dim3(BLOCK), smem, stream, a);
+  LGN_CHECK_LAUNCH();
+  return 0;
+}
+
+template <int C>
+static int launch_rad2(const LevelBwdArgs<double>& a, hipStream_t stream) {
+  constexpr int NG = (C + 3) / 4;
+  const size_t smem = sizeof(double) * ((((size_t)a.N * node_stride(C) + 1) & ~size_t(1)) + (size_t)a.N * 4 +
+                                        (4 * (NG + 3) * 16 * 18 > 4 * 64 * NG * 12 ? 4 * (NG + 3) * 16 * 18 : 4 * 64 * NG * 12)) + a.N + 16;
+  LGN_CHECK_ARG(smem <= 160 * 1024, "level_bwd_rad: N=%d C=%d needs %zu B of LDS", a.N, a.C, smem);
+  auto kern = level_bwd_rad2_kernel<C>;
+  if (smem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipLaunchKernelGGL(kern, dim3(a.B), dim3(BLOCK), smem, stream, a);
+  LGN_CHECK_LAUNCH();
+  return 0;
+}
+
+int level_bwd_nodes2_dispatch(const LevelBwdArgs<double>& a, int decoder, hipStream_t stream) {
+#define LGN_CASE(CC) case CC: return decoder ? launch_nodes2<CC, true>(a, stream) : launch_nodes2<CC, false>(a, stream);
+  switch (a.C) {
+    LGN_CASE(1) LGN_CASE(2) LGN_CASE(3) LGN_CASE(4) LGN_CASE(5) LGN_CASE(6) LGN_CASE(7) LGN_CASE(8)
+    default: set_error("level_bwd: C_in=%d unsupported (1..8)", a.C); return -1;
+  }
+#undef LGN_CASE
+}
+
+// encoder only; writes ONE partial row per jet (rows_rad == B)
+int level_bwd_rad2_dispatch(const LevelBwdArgs<double>& a, hipStream_t stream) {
+#define LGN_CASE(CC) case CC: return launch_rad2<CC>(a, stream);
+  switch (a.C) {
+    LGN_CASE(1) LGN_CASE(2) LGN_CASE(3) LGN_CASE(4) LGN_CASE(5) LGN_CASE(6) LGN_CASE(7) LGN_CASE(8)
+    default: set_error("level_bwd: C_in=%d unsupported (1..8)", a.C); return -1;
+  }
+#undef LGN_CASE
+}
+
+}  // namespace lgn
