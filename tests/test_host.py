@@ -117,3 +117,21 @@ def test_glue_matches_reference_geometry_and_pooling():
     lat = U.rep_from(z, "pool.in")
     for method in ("min", "max", "min&max", "mean", "sum", "min+max"):
         U.assert_rep_close(ops.aggregate_latent(method, lat), U.rep_from(z, f"pool.{method}"), 1e-15, method)
+
+
+def test_lorentz_D_matches_reference_matrices():
+    """Representation matrices used by the equivariance harness vs the reference's LorentzD (3 rotations, 3 boosts)."""
+    from lgn.cg_lib import CGDict
+    from lgn.models.autotest import lorentz_D, cartesian_lorentz
+    z = U.load("g5_tables.npz")
+    cg = CGDict(maxdim=3)
+    for i in range(6):
+        ang = [complex(a[0], a[1]) for a in z[f"lorentzD.{i}.angles"]]
+        for k in range(3):
+            for n in range(3):
+                U.assert_close(lorentz_D((k, n), *ang, cg), z[f"lorentzD.{i}.({k}, {n})"], 1e-13, f"D{i} ({k},{n})")
+    # a boost along z with rapidity 2 in Cartesian coordinates; metric preserved
+    R = cartesian_lorentz(lorentz_D((1, 1), 0, 0, 2.0j, cg))
+    eta = torch.diag(torch.tensor([1.0, -1, -1, -1], dtype=torch.float64))
+    U.assert_close(R @ eta @ R.t(), eta, 1e-13, "R eta R^T")
+    assert R[0, 0].item() == pytest.approx(3.7621956910836314, rel=1e-13)
