@@ -106,6 +106,43 @@ int lgn_mixreps_partial_rows(int rows);
 int lgn_mixreps_bwd_f64(int rows, int Cin, int Cout, int d, const double* w, const double* x, const double* g_y,
                         double* g_x, double* part, void* stream);
 
+/* ---- arbitrary irreps (maxdim = 3): table-driven level --------------------------------------------------
+ * Same operator as lgn_level_fwd/bwd for node features carrying any set of irreps with k, n < maxdim, packed as
+ * X [2][B][N][C][Q] (Q = sum of irrep dimensions, irreps in the level's GVec order).  Split in two stages:
+ *  (1) "moments" (O(N^2), no CG tables):  U[b][i][c][q][0] = sum_j X_j[c][q] e0_ij[c],  U[..][1+m] = sum_j X_j[c][q] e1_ij[c][m]
+ *      -- the neighbour sum of the Kronecker products of lgn/cg_lib/cg_ops.py:281-297 before the CG matrix is applied;
+ *  (2) per node: sparse CG contraction of U (aggregate) and of X (x) X (power), concatenation with X, CatMix
+ *      (cg_ops.py:195-215, lgn/nn/g_nn.py:160-190,260-278), driven by the CSR tables of lgn_local_tables.
+ * U / gU layout: [B][N][C][Q][5][2] (re, im innermost).  Radial parameters as for lgn_level_fwd_f64. */
+int lgn_moments_fwd_f64(int B, int N, int C, int Q, int decoder, const double* X, const double* p, const uint8_t* mask,
+                        const double* ra, const double* rb, const double* rc, const double* w0, const double* b0,
+                        const double* w1, const double* b1, double* U, void* stream);
+/* gX [2][B][N][C][Q] and g_p (decoder) are ACCUMULATED into; part_rad [B][lgn_level_rad_partial_len(C, decoder)]. */
+int lgn_moments_bwd_f64(int B, int N, int C, int Q, int decoder, const double* X, const double* p, const uint8_t* mask,
+                        const double* ra, const double* rb, const double* rc, const double* w0, const double* b0,
+                        const double* w1, const double* b1, const double* gU, double* gX, double* g_p,
+                        double* part_rad, void* stream);
+
+typedef struct lgn_local_tables {
+  int n_rows, n_out, n_w;          /* concatenated rows (irrep, block, m); output irreps; complex CatMix weights */
+  const int *row_ptr, *t_type, *t_a, *t_b;      /* CSR terms per row: type 0: U[a = q*5+k], 1: X[a], 2: X[a]*X[b] */
+  const double* t_coef;
+  const int *out_dim, *out_nblk, *out_row0, *out_q0, *out_w0;   /* per output irrep */
+  const int *u_ptr, *u_row;                     /* transposed lists for the backward */
+  const double* u_coef;
+  const int *x_ptr, *x_row, *x_other;
+  const double* x_coef;
+} lgn_local_tables;
+
+/* X [2][nodes][C][Q], U [nodes][C][Q][5][2], wcat = CatMix weights of all irreps ([2][CO][nblk*C] each, at out_w0),
+ * out [2][nodes][CO][Qout]. */
+int lgn_local_fwd_f64(int nodes, int C, int CO, int Q, int Qout, const lgn_local_tables* t, const double* X, const double* U,
+                      const double* wcat, double* out, void* stream);
+int lgn_local_partial_rows(int nodes);
+/* gU, gX overwritten; part [lgn_local_partial_rows][2*n_w] (layout like wcat). */
+int lgn_local_bwd_f64(int nodes, int C, int CO, int Q, int Qout, const lgn_local_tables* t, const double* X, const double* U,
+                      const double* wcat, const double* g_out, double* gU, double* gX, double* part, void* stream);
+
 /* ---- whole training step, maxdim = 2 (utils/train.py:283-343 inner loop) ---------------------------
  * One call enqueues encoder -> decoder -> get_real('sum') -> Chamfer -> full backward (~80 launches, no host
  * sync, all buffers caller-owned and static => capturable in a HIP graph).  Parameters of both networks

@@ -96,4 +96,64 @@ int lgn_mixreps_bwd_f64(int rows, int Cin, int Cout, int d, const double* w, con
   return mix_bwd<double>(a, (hipStream_t)stream);
 }
 
+static GenArgs gen_args(int B, int N, int C, int Q, const double* X, const double* p, const uint8_t* mask, const double* ra,
+                        const double* rb, const double* rc, const double* w0, const double* b0, const double* w1, const double* b1) {
+  GenArgs a{};
+  a.B = B; a.N = N; a.C = C; a.Q = Q; a.X = X; a.p = p; a.mask = mask;
+  a.ra = ra; a.rb = rb; a.rc = rc; a.w0 = w0; a.b0 = b0; a.w1 = w1; a.b1 = b1;
+  return a;
+}
+
+int lgn_moments_fwd_f64(int B, int N, int C, int Q, int decoder, const double* X, const double* p, const uint8_t* mask,
+                        const double* ra, const double* rb, const double* rc, const double* w0, const double* b0,
+                        const double* w1, const double* b1, double* U, void* stream) {
+  LGN_CHECK_ARG(X && p && b0 && b1 && U, "moments_fwd: null pointer");
+  LGN_CHECK_ARG(decoder || (mask && ra && rb && rc && w0 && w1), "moments_fwd: encoder needs mask and radial parameters");
+  GenArgs a = gen_args(B, N, C, Q, X, p, mask, ra, rb, rc, w0, b0, w1, b1);
+  a.U = U;
+  return moments_dispatch(a, decoder, 0, (hipStream_t)stream);
+}
+
+int lgn_moments_bwd_f64(int B, int N, int C, int Q, int decoder, const double* X, const double* p, const uint8_t* mask,
+                        const double* ra, const double* rb, const double* rc, const double* w0, const double* b0,
+                        const double* w1, const double* b1, const double* gU, double* gX, double* g_p, double* part_rad,
+                        void* stream) {
+  LGN_CHECK_ARG(X && p && b0 && b1 && gU && gX && part_rad, "moments_bwd: null pointer");
+  LGN_CHECK_ARG(decoder ? (g_p != nullptr) : (mask && ra && rb && rc && w0 && w1), "moments_bwd: missing decoder g_p / encoder radial parameters");
+  GenArgs a = gen_args(B, N, C, Q, X, p, mask, ra, rb, rc, w0, b0, w1, b1);
+  a.gU = gU; a.gX = gX; a.g_p = g_p; a.part_rad = part_rad;
+  if (int rc2 = moments_dispatch(a, decoder, 1, (hipStream_t)stream)) return rc2;
+  return moments_dispatch(a, decoder, 2, (hipStream_t)stream);
+}
+
+static int local_args(LocalArgs& a, int nodes, int C, int CO, int Q, int Qout, const lgn_local_tables* t) {
+  LGN_CHECK_ARG(t && t->row_ptr && t->t_type && t->t_a && t->t_b && t->t_coef && t->out_dim && t->out_nblk && t->out_row0 &&
+                    t->out_q0 && t->out_w0 && t->u_ptr && t->u_row && t->u_coef && t->x_ptr && t->x_row && t->x_other && t->x_coef,
+                "local: incomplete tables");
+  a.nodes = nodes; a.C = C; a.CO = CO; a.Q = Q; a.Qout = Qout;
+  a.t = LocalTables{t->n_rows, t->n_out, t->n_w, t->row_ptr, t->t_type, t->t_a, t->t_b, t->t_coef, t->out_dim, t->out_nblk,
+                    t->out_row0, t->out_q0, t->out_w0, t->u_ptr, t->u_row, t->u_coef, t->x_ptr, t->x_row, t->x_other, t->x_coef};
+  return 0;
+}
+
+int lgn_local_fwd_f64(int nodes, int C, int CO, int Q, int Qout, const lgn_local_tables* t, const double* X, const double* U,
+                      const double* wcat, double* out, void* stream) {
+  LocalArgs a{};
+  if (int rc = local_args(a, nodes, C, CO, Q, Qout, t)) return rc;
+  LGN_CHECK_ARG(X && U && wcat && out, "local_fwd: null pointer");
+  a.X = X; a.U = U; a.wcat = wcat; a.out = out;
+  return local_fwd(a, (hipStream_t)stream);
+}
+
+int lgn_local_partial_rows(int nodes) { return local_partial_rows(nodes); }
+
+int lgn_local_bwd_f64(int nodes, int C, int CO, int Q, int Qout, const lgn_local_tables* t, const double* X, const double* U,
+                      const double* wcat, const double* g_out, double* gU, double* gX, double* part, void* stream) {
+  LocalArgs a{};
+  if (int rc = local_args(a, nodes, C, CO, Q, Qout, t)) return rc;
+  LGN_CHECK_ARG(X && U && wcat && g_out && gU && gX && part, "local_bwd: null pointer");
+  a.X = X; a.U = U; a.wcat = wcat; a.g_out = g_out; a.gU = gU; a.gX = gX; a.part = part;
+  return local_bwd(a, (hipStream_t)stream);
+}
+
 }  // extern "C"

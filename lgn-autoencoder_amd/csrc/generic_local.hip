@@ -1,0 +1,209 @@
+// lgn-autoencoder_amd/csrc/generic_local.hip -- per-node part of a message-passing level for arbitrary irreps:
+// Clebsch-Gordan contraction of the neighbour moments (aggregate) and of node (x) node (power), concatenation
+// with the node features and the complex CatMix -- forward and backward.
+//
+// Reference: cg_product (lgn/cg_lib/cg_ops.py:177-218: CG matrix applied after the neighbour sum, outputs of all
+// contributing irrep pairs concatenated on the channel axis), CatReps/CatMixReps (lgn/nn/g_nn.py:160-190,260-278).
+// The CG tables are sparse (5 726 non-zeros of 38 416 at maxdim 3); the host (lgn/plan.py) flattens
+// "which products feed which concatenated row" into CSR term lists, so the device code is table driven:
+//   cat[row][c] = sum_terms coef * { U[c][q][k] | X[c][q] | X[c][q1] X[c][q2] }       row = (out irrep, block, m)
+//   out[o][q0_l + m] = sum_{block, c} W_l[o][block*C + c] cat[row(l, block, m)][c]
+#include "ops.hpp"
+
+namespace lgn {
+
+namespace {
+constexpr int NODES_PER_WG = 8;
+constexpr int MAXW = 16;      // CatMix weights accumulated per thread in the backward (n_w <= MAXW * BLOCK)
+
+__device__ __forceinline__ cx<double> ldU(const double* U, int node, int c, int C, int Q, int a) {
+  const double* u = U + (((size_t)node * C + c) * Q) * 10 + 2 * a;      // a = q*5 + k
+  return {u[0], u[1]};
+}
+__device__ __forceinline__ cx<double> ldX(const double* X, size_t plane, int node, int c, int C, int Q, int q) {
+  const size_t e = ((size_t)node * C + c) * Q + q;
+  return {X[e], X[plane + e]};
+}
+
+__device__ __forceinline__ void build_cat(const LocalArgs& a, int node, double* cat) {
+  const int C = a.C, Q = a.Q;
+  const size_t plane = (size_t)a.nodes * C * Q;
+  for (int e = threadIdx.x; e < a.t.n_rows * C; e += BLOCK) {
+    const int row = e / C, c = e - row * C;
+    cx<double> acc = {0, 0};
+    for (int t = a.t.row_ptr[row]; t < a.t.row_ptr[row + 1]; ++t) {
+      const int ty = a.t.t_type[t];
+      const double coef = a.t.t_coef[t];
+      cx<double> v;
+      if (ty == 0) v = ldU(a.U, node, c, C, Q, a.t.t_a[t]);
+      else if (ty == 1) v = ldX(a.X, plane, node, c, C, Q, a.t.t_a[t]);
+      else v = cmul(ldX(a.X, plane, node, c, C, Q, a.t.t_a[t]), ldX(a.X, plane, node, c, C, Q, a.t.t_b[t]));
+      acc.r += coef * v.r;
+      acc.i += coef * v.i;
+    }
+    cat[2 * e] = acc.r;
+    cat[2 * e + 1] = acc.i;
+  }
+}
+
+__device__ __forceinline__ int irrep_of(const LocalTables& t, int q) {
+  int l = 0;
+  while (l + 1 < t.n_out && q >= t.out_q0[l + 1]) ++l;
+  return l;
+}
+}  // namespace
+
+__global__ __launch_bounds__(BLOCK) void local_fwd_kernel(LocalArgs a) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  double* cat = reinterpret_cast<double*>(smem_raw);          // n_rows * C * 2
+  const int C = a.C, CO = a.CO, Qo = a.Qout;
+  const size_t plo = (size_t)a.nodes * CO * Qo;
+  for (int nl = 0; nl < NODES_PER_WG; ++nl) {
+    const int node = blockIdx.x * NODES_PER_WG + nl;
+    if (node >= a.nodes) break;
+    build_cat(a, node, cat);
+    __syncthreads();
+    for (int e = threadIdx.x; e < CO * Qo; e += BLOCK) {
+      const int o = e / Qo, q = e - o * Qo;
+      const int l = irrep_of(a.t, q), m = q - a.t.out_q0[l], d = a.t.out_dim[l], nb = a.t.out_nblk[l];
+      const int K = nb * C;
+      const double* wr = a.wcat + a.t.out_w0[l] + (size_t)o * K;
+      const double* wi = wr + (size_t)CO * K;
+      cx<double> acc = {0, 0};
+      for (int blk = 0; blk < nb; ++blk) {
+        const double* cr = cat + (size_t)(a.t.out_row0[l] + blk * d + m) * C * 2;
+        for (int c = 0; c < C; ++c) cfma(acc, cx<double>{wr[blk * C + c], wi[blk * C + c]}, cx<double>{cr[2 * c], cr[2 * c + 1]});
+      }
+      const size_t oe = ((size_t)node * CO + o) * Qo + q;
+      a.out[oe] = acc.r;
+      a.out[plo + oe] = acc.i;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(BLOCK) void local_bwd_kernel(LocalArgs a) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int C = a.C, CO = a.CO, Q = a.Q, Qo = a.Qout;
+  double* cat = reinterpret_cast<double*>(smem_raw);          // n_rows * C * 2
+  double* gcat = cat + (size_t)a.t.n_rows * C * 2;            // n_rows * C * 2
+  double* go = gcat + (size_t)a.t.n_rows * C * 2;             // CO * Qo * 2
+  const size_t plo = (size_t)a.nodes * CO * Qo, plx = (size_t)a.nodes * C * Q;
+  cx<double> dw[MAXW];
+#pragma unroll
+  for (int k = 0; k < MAXW; ++k) dw[k] = {0, 0};
+
+  for (int nl = 0; nl < NODES_PER_WG; ++nl) {
+    const int node = blockIdx.x * NODES_PER_WG + nl;
+    if (node >= a.nodes) break;
+    build_cat(a, node, cat);
+    for (int e = threadIdx.x; e < CO * Qo; e += BLOCK) {
+      const size_t oe = (size_t)node * CO * Qo + e;
+      go[2 * e] = a.g_out[oe];
+      go[2 * e + 1] = a.g_out[plo + oe];
+    }
+    __syncthreads();
+    // gradient of the concatenated rows
+    for (int e = threadIdx.x; e < a.t.n_rows * C; e += BLOCK) {
+      const int row = e / C, c = e - row * C;
+      int l = 0;
+      while (l + 1 < a.t.n_out && row >= a.t.out_row0[l + 1]) ++l;
+      const int d = a.t.out_dim[l], rel = row - a.t.out_row0[l], blk = rel / d, m = rel - blk * d;
+      const int K = a.t.out_nblk[l] * C, q = a.t.out_q0[l] + m;
+      cx<double> acc = {0, 0};
+      for (int o = 0; o < CO; ++o) {
+        const double* wr = a.wcat + a.t.out_w0[l] + (size_t)o * K;
+        const double* wi = wr + (size_t)CO * K;
+        cfmac(acc, cx<double>{go[2 * (o * Qo + q)], go[2 * (o * Qo + q) + 1]}, cx<double>{wr[blk * C + c], wi[blk * C + c]});
+      }
+      gcat[2 * e] = acc.r;
+      gcat[2 * e + 1] = acc.i;
+    }
+    // CatMix weight gradient, accumulated over this workgroup's nodes:  dW_l[o][k] += sum_m g_out[o][q0+m] conj(cat[row][c])
+#pragma unroll
+    for (int k = 0; k < MAXW; ++k) {
+      const int w = threadIdx.x + k * BLOCK;
+      if (w < a.t.n_w) {
+        int l = 0, base = 0;
+        // weights are ordered irrep by irrep: CO * nblk_l * C complex each
+        while (l + 1 < a.t.n_out && w >= base + CO * a.t.out_nblk[l] * C) { base += CO * a.t.out_nblk[l] * C; ++l; }
+        const int K = a.t.out_nblk[l] * C, rel = w - base, o = rel / K, kc = rel - o * K, blk = kc / C, c = kc - blk * C;
+        const int d = a.t.out_dim[l];
+        for (int m = 0; m < d; ++m) {
+          const int row = a.t.out_row0[l] + blk * d + m, q = a.t.out_q0[l] + m;
+          cfmac(dw[k], cx<double>{go[2 * (o * Qo + q)], go[2 * (o * Qo + q) + 1]}, cx<double>{cat[2 * (row * C + c)], cat[2 * (row * C + c) + 1]});
+        }
+      }
+    }
+    __syncthreads();
+    // gradient of the moments
+    for (int e = threadIdx.x; e < C * Q * 5; e += BLOCK) {
+      const int c = e / (Q * 5), uq = e - c * Q * 5;
+      cx<double> acc = {0, 0};
+      for (int t = a.t.u_ptr[uq]; t < a.t.u_ptr[uq + 1]; ++t) {
+        const double coef = a.t.u_coef[t];
+        const int row = a.t.u_row[t];
+        acc.r += coef * gcat[2 * (row * C + c)];
+        acc.i += coef * gcat[2 * (row * C + c) + 1];
+      }
+      double* gu = a.gU + (((size_t)node * C + c) * Q) * 10 + 2 * uq;
+      gu[0] = acc.r;
+      gu[1] = acc.i;
+    }
+    // gradient of the node features (direct block + power terms); the N^2 backward adds the aggregate part later
+    for (int e = threadIdx.x; e < C * Q; e += BLOCK) {
+      const int c = e / Q, q = e - c * Q;
+      cx<double> acc = {0, 0};
+      for (int t = a.t.x_ptr[q]; t < a.t.x_ptr[q + 1]; ++t) {
+        const double coef = a.t.x_coef[t];
+        const int row = a.t.x_row[t], other = a.t.x_other[t];
+        cx<double> g = {coef * gcat[2 * (row * C + c)], coef * gcat[2 * (row * C + c) + 1]};
+        if (other >= 0) g = cmulc(g, ldX(a.X, plx, node, c, C, Q, other));
+        acc.r += g.r;
+        acc.i += g.i;
+      }
+      const size_t xe = ((size_t)node * C + c) * Q + q;
+      a.gX[xe] = acc.r;
+      a.gX[plx + xe] = acc.i;
+    }
+    __syncthreads();
+  }
+  // partial row of this workgroup, layout like wcat: per irrep [2][CO][K]
+  double* part = a.part + (size_t)blockIdx.x * 2 * a.t.n_w;
+#pragma unroll
+  for (int k = 0; k < MAXW; ++k) {
+    const int w = threadIdx.x + k * BLOCK;
+    if (w < a.t.n_w) {
+      int l = 0, base = 0;
+      while (l + 1 < a.t.n_out && w >= base + CO * a.t.out_nblk[l] * C) { base += CO * a.t.out_nblk[l] * C; ++l; }
+      const int sz = CO * a.t.out_nblk[l] * C, rel = w - base;
+      part[2 * base + rel] = dw[k].r;            // plane 0 of irrep l
+      part[2 * base + sz + rel] = dw[k].i;       // plane 1
+    }
+  }
+}
+
+int local_partial_rows(int nodes) { return cdiv(nodes, NODES_PER_WG); }
+
+int local_fwd(const LocalArgs& a, hipStream_t st) {
+  LGN_CHECK_ARG(a.nodes > 0 && a.C >= 1 && a.CO >= 1, "local_fwd: empty input");
+  const size_t smem = sizeof(double) * (size_t)a.t.n_rows * a.C * 2;
+  LGN_CHECK_ARG(smem <= 160 * 1024, "local_fwd: %zu B of LDS needed", smem);
+  if (smem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(local_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipLaunchKernelGGL(local_fwd_kernel, dim3(local_partial_rows(a.nodes)), dim3(BLOCK), smem, st, a);
+  LGN_CHECK_LAUNCH();
+  return 0;
+}
+
+int local_bwd(const LocalArgs& a, hipStream_t st) {
+  LGN_CHECK_ARG(a.nodes > 0 && a.C >= 1 && a.CO >= 1, "local_bwd: empty input");
+  LGN_CHECK_ARG(a.t.n_w <= MAXW * BLOCK, "local_bwd: %d CatMix weights exceed the per-workgroup accumulator budget", a.t.n_w);
+  const size_t smem = sizeof(double) * ((size_t)a.t.n_rows * a.C * 4 + (size_t)a.CO * a.Qout * 2);
+  LGN_CHECK_ARG(smem <= 160 * 1024, "local_bwd: %zu B of LDS needed", smem);
+  if (smem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(local_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipLaunchKernelGGL(local_bwd_kernel, dim3(local_partial_rows(a.nodes)), dim3(BLOCK), smem, st, a);
+  LGN_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // namespace lgn

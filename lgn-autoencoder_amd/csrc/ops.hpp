@@ -61,4 +61,46 @@ template <typename T> int mix_fwd(const MixArgs<T>&, hipStream_t);
 template <typename T> int mix_bwd(const MixArgs<T>&, hipStream_t);
 int mix_partial_rows(int rows);
 
+// ---- generic irreps (generic_moments.hip / generic_local.hip) -----------------------------------------------
+struct GenArgs {
+  int B, N, C, Q;
+  const double* X;          // packed node features [2][B][N][C][Q]
+  const double* p;          // encoder [B][N][4] real; decoder [2][B][N][4] complex canonical
+  const uint8_t* mask;
+  const double *ra, *rb, *rc, *w0, *b0, *w1, *b1;
+  double* U;                // moments [B][N][C][Q][5][2]
+  const double* gU;
+  double* gX;               // [2][B][N][C][Q], accumulated into
+  double* g_p;              // decoder, accumulated into
+  double* part_rad;         // [B][rad_partial_size]
+};
+int moments_dispatch(const GenArgs& a, int decoder, int which, hipStream_t st);
+
+// sparse description of (aggregate CG, power CG, concatenation) of one level, see lgn/plan.py:build_local_tables
+struct LocalTables {
+  int n_rows, n_out, n_w;                 // cat rows (irrep, block, m); output irreps; total complex CatMix weights
+  const int *row_ptr, *t_type, *t_a, *t_b;
+  const double* t_coef;
+  const int *out_dim, *out_nblk, *out_row0, *out_q0, *out_w0;
+  const int *u_ptr, *u_row;
+  const double* u_coef;
+  const int *x_ptr, *x_row, *x_other;
+  const double* x_coef;
+};
+struct LocalArgs {
+  int nodes, C, CO, Q, Qout;
+  LocalTables t;
+  const double* X;          // [2][nodes][C][Q]
+  const double* U;          // [nodes][C][Q][5][2]
+  const double* wcat;       // concatenated CatMix weights, irrep l at t.out_w0[l]: [2][CO][nblk_l*C]
+  double* out;              // [2][nodes][CO][Qout]
+  const double* g_out;
+  double* gU;               // [nodes][C][Q][5][2]
+  double* gX;               // [2][nodes][C][Q]  (overwritten)
+  double* part;             // [nblk][2*n_w]  layout per irrep like wcat
+};
+int local_fwd(const LocalArgs& a, hipStream_t st);
+int local_bwd(const LocalArgs& a, hipStream_t st);
+int local_partial_rows(int nodes);
+
 }  // namespace lgn

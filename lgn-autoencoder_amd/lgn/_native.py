@@ -45,10 +45,23 @@ class NetDesc(C.Structure):
                 ("mlp_nlin", C.c_int)]
 
 
+class LocalTables(C.Structure):
+    """lgn_local_tables of include/lgn_amd.h (device pointers)."""
+    _fields_ = [("n_rows", C.c_int), ("n_out", C.c_int), ("n_w", C.c_int)] + [
+        (name, C.c_void_p) for name in ("row_ptr", "t_type", "t_a", "t_b", "t_coef", "out_dim", "out_nblk", "out_row0", "out_q0",
+                                        "out_w0", "u_ptr", "u_row", "u_coef", "x_ptr", "x_row", "x_other", "x_coef")]
+
+
 _dp = C.POINTER(NetDesc)
+_tp = C.POINTER(LocalTables)
 _ll = C.c_longlong
 _d = C.c_double
 _SIGNATURES.update({
+    "lgn_moments_fwd_f64": [_i] * 5 + [_vp] * 12,
+    "lgn_moments_bwd_f64": [_i] * 5 + [_vp] * 15,
+    "lgn_local_fwd_f64": [_i] * 5 + [_tp] + [_vp] * 5,
+    "lgn_local_partial_rows": [_i],
+    "lgn_local_bwd_f64": [_i] * 5 + [_tp] + [_vp] * 8,
     "lgn_step_param_slots": [_dp, _i],
     "lgn_step_fwd_bwd_f64": [_dp, _vp, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "lgn_step_finalize_f64": [_vp, _vp, _ll, _vp, _i, _d, _vp, _vp, _vp, _d, _d, _d, _d, _i, _vp, _vp],
@@ -237,3 +250,79 @@ def mixreps_bwd(w, x, g_y, need_gx=True):
     g_w = torch.empty_like(w)
     reduce_partials(part, g_w.view(-1))
     return g_x, g_w
+
+
+# ---------------------------------------------------------------------------------------------
+# generic (any maxdim) level
+# ---------------------------------------------------------------------------------------------
+
+class DeviceTables:
+    """Device copy of the CSR tables built by lgn.plan.build_local_tables."""
+
+    def __init__(self, tab: dict, device):
+        self.meta = tab
+        self.tensors = {}
+        st = LocalTables()
+        st.n_rows, st.n_out, st.n_w = tab["n_rows"], tab["n_out"], tab["n_w"]
+        for name, vals in tab["ints"].items():
+            t = torch.tensor(vals if len(vals) else [0], dtype=torch.int32, device=device)
+            self.tensors[name] = t
+            setattr(st, name, t.data_ptr())
+        for name, vals in tab["dbls"].items():
+            t = torch.tensor(vals if len(vals) else [0.0], dtype=torch.float64, device=device)
+            self.tensors[name] = t
+            setattr(st, name, t.data_ptr())
+        self.struct = st
+
+
+def moments_fwd(decoder, X, p, mask, rad):
+    _, B, N, Cc, Q = X.shape
+    U = torch.empty(B, N, Cc, Q, 5, 2, device=X.device, dtype=X.dtype)
+    a, b, c, w0, b0, w1, b1 = rad
+    _check(lib().lgn_moments_fwd_f64(B, N, Cc, Q, int(decoder), ptr(X), ptr(p), ptr(mask), ptr(a), ptr(b), ptr(c), ptr(w0),
+                                     ptr(b0), ptr(w1), ptr(b1), ptr(U), stream_ptr()), "lgn_moments_fwd_f64")
+    return U
+
+
+def moments_bwd(decoder, X, p, mask, rad, gU, gX, g_p):
+    """gX (and g_p for the decoder) are accumulated in place; returns the radial gradients like level_bwd."""
+    _, B, N, Cc, Q = X.shape
+    L = lib()
+    nrad = L.lgn_level_rad_partial_len(Cc, int(decoder))
+    part = torch.empty(B, nrad, device=X.device, dtype=X.dtype)
+    a, b, c, w0, b0, w1, b1 = rad
+    _check(L.lgn_moments_bwd_f64(B, N, Cc, Q, int(decoder), ptr(X), ptr(p), ptr(mask), ptr(a), ptr(b), ptr(c), ptr(w0), ptr(b0),
+                                 ptr(w1), ptr(b1), ptr(gU), ptr(gX), ptr(g_p), ptr(part), stream_ptr()), "lgn_moments_bwd_f64")
+    tot = torch.empty(nrad, device=X.device, dtype=X.dtype)
+    reduce_partials(part, tot)
+    if decoder:
+        return (tot[:Cc], tot[Cc:])
+    g_a, g_b, g_c = (torch.empty_like(x) for x in (a, b, c))
+    g_w0, g_b0, g_w1, g_b1 = (torch.empty_like(x) for x in (w0, b0, w1, b1))
+    _check(L.lgn_radial_finalize_f64(ptr(tot), Cc, ptr(a), ptr(b), ptr(c), ptr(w0), ptr(w1), ptr(g_a), ptr(g_b), ptr(g_c),
+                                     ptr(g_w0), ptr(g_b0), ptr(g_w1), ptr(g_b1), stream_ptr()), "lgn_radial_finalize_f64")
+    return (g_a, g_b, g_c, g_w0, g_b0, g_w1, g_b1)
+
+
+def local_fwd(tables: DeviceTables, CO, X, U, wcat):
+    _, B, N, Cc, Q = X.shape
+    Qo = tables.meta["Qout"]
+    out = torch.empty(2, B, N, CO, Qo, device=X.device, dtype=X.dtype)
+    _check(lib().lgn_local_fwd_f64(B * N, Cc, CO, Q, Qo, C.byref(tables.struct), ptr(X), ptr(U), ptr(wcat), ptr(out), stream_ptr()),
+           "lgn_local_fwd_f64")
+    return out
+
+
+def local_bwd(tables: DeviceTables, CO, X, U, wcat, g_out):
+    _, B, N, Cc, Q = X.shape
+    Qo = tables.meta["Qout"]
+    L = lib()
+    rows = L.lgn_local_partial_rows(B * N)
+    part = torch.empty(rows, wcat.numel(), device=X.device, dtype=X.dtype)
+    gU = torch.empty(B, N, Cc, Q, 5, 2, device=X.device, dtype=X.dtype)
+    gX = torch.empty_like(X)
+    _check(L.lgn_local_bwd_f64(B * N, Cc, CO, Q, Qo, C.byref(tables.struct), ptr(X), ptr(U), ptr(wcat), ptr(g_out), ptr(gU), ptr(gX),
+                               ptr(part), stream_ptr()), "lgn_local_bwd_f64")
+    g_w = torch.empty_like(wcat)
+    reduce_partials(part, g_w)
+    return gU, gX, g_w

@@ -71,22 +71,57 @@ class CGModule(nn.Module):
                 f"this module was created on '{self._device}'. There is no CPU fallback.")
 
 
-def run_levels(lgn_cg, rad_funcs, plans: List[LevelPlan], decoder: bool, s, v, p, mask):
-    """LGNCG.forward (lgn/models/lgn_cg.py:124-180) at maxdim = 2: per level one fused native level call
-    (edge network + CG aggregate + CG power + CatMix) followed by the native CGMLP on the scalars.
-    s (2,B,N,C), v (2,B,N,C,4).  Returns the list of (s, v) after every level (input first)."""
-    feats = [(s, v)]
-    for lvl, plan in enumerate(plans):
+def _is_fused_layout(plan: LevelPlan, maxdim: int) -> bool:
+    if maxdim != 2:
+        return False
+    try:
         check_maxdim2_layout(plan)
+        return True
+    except RuntimeError:
+        return False
+
+
+def run_levels(module, decoder: bool, feats, p, mask):
+    """LGNCG.forward (lgn/models/lgn_cg.py:124-180): per level one native level call (edge network + CG aggregate +
+    CG power + CatMix) followed by the native CGMLP on the scalars.  ``feats`` = {irrep: (2,B,N,C,d)} in the
+    level's GVec order.  Levels whose layout is the maxdim=2 one use the fused closed-form kernels
+    (csrc/level_*.hip); any other irrep content goes through the table-driven generic kernels
+    (csrc/generic_*.hip).  Returns the list of feature dicts after every level (input first)."""
+    lgn_cg, rad_funcs, plans = module.lgn_cg, module.rad_funcs, module.plans
+    out = [feats]
+    for lvl, plan in enumerate(plans):
         mix = lgn_cg.node_levels[lvl].cat_mix.mix_reps
-        s, v = ops.LevelFn.apply(decoder, s, v, p, mask, *rad_funcs.rad_funcs[lvl].flat_params(),
-                                 mix.weight((0, 0)), mix.weight((1, 1)))
+        radp = rad_funcs.rad_funcs[lvl].flat_params()
+        if _is_fused_layout(plan, module.level_maxdim[lvl]):
+            s, v = ops.LevelFn.apply(decoder, feats[(0, 0)].squeeze(-1), feats[(1, 1)], p, mask, *radp,
+                                     mix.weight((0, 0)), mix.weight((1, 1)))
+            new = {(0, 0): s.unsqueeze(-1), (1, 1): v}
+        else:
+            tables = module.level_tables(lvl)
+            X = torch.cat([feats[r] for r in plan.node_order], dim=-1).contiguous()
+            wmix = [mix.weight(r) for r in tables.meta["out_irreps"]]
+            Y = ops.GenericLevelFn.apply(decoder, tables, plan.channels_out, X, p, mask, *radp, *wmix)
+            parts = torch.split(Y, [(r[0] + 1) * (r[1] + 1) for r in tables.meta["out_irreps"]], dim=-1)
+            new = dict(zip(tables.meta["out_irreps"], parts))
         if lgn_cg.mlp:
-            s = ops.CGMLPFn.apply(s, *lgn_cg.mlp_levels[lvl].flat_params())
-        feats.append((s, v))
-    return feats
+            s = ops.CGMLPFn.apply(new[(0, 0)].squeeze(-1).contiguous(), *lgn_cg.mlp_levels[lvl].flat_params())
+            new[(0, 0)] = s.unsqueeze(-1)
+        feats = {r: new[r] for r in plan.out_order}
+        out.append(feats)
+    return out
 
 
-def as_gvec(s, v, order):
-    parts = {(0, 0): s.unsqueeze(-1), (1, 1): v}
-    return GVec({k: parts[k] for k in order})
+class LevelTablesMixin:
+    """Lazily built device tables of the generic levels (one per level, cached)."""
+
+    def level_tables(self, lvl: int):
+        from .. import _native as N
+        from ..plan import build_local_tables
+        cache = self.__dict__.setdefault("_level_tables", {})
+        if lvl not in cache:
+            cache[lvl] = N.DeviceTables(build_local_tables(self.plans[lvl], self.cg_dict), self.device)
+        return cache[lvl]
+
+
+def as_gvec(feats, order):
+    return GVec({k: feats[k] for k in order})

@@ -9,10 +9,10 @@ from .. import ops
 from ..g_lib import GTau, GVec
 from ..nn import LGNCG, MixReps, RadialFilters
 from ..plan import build_level_plans
-from .common import CGModule, adapt_var_list, as_gvec, run_levels
+from .common import CGModule, LevelTablesMixin, adapt_var_list, as_gvec, run_levels
 
 
-class LGNDecoder(CGModule):
+class LGNDecoder(CGModule, LevelTablesMixin):
     def __init__(self, tau_latent_scalars: int, tau_latent_vectors: int, num_output_particles: int,
                  tau_output_scalars: int, tau_output_vectors: int, maxdim, num_basis_fn: int, num_channels: List[int],
                  max_zf, weight_init, level_gain, activation: str = "leakyrelu", mlp: bool = True,
@@ -24,9 +24,9 @@ class LGNDecoder(CGModule):
         max_zf = adapt_var_list(max_zf, num_cg_levels)
         super().__init__(maxdim=max(maxdim + max_zf), device=device, dtype=dtype, cg_dict=cg_dict)
         logging.info(f"Initializing decoder with device: {self.device} and dtype: {self.dtype}")
-        if num_cg_levels < 1 or any(m != 2 for m in maxdim) or any(z != 1 for z in max_zf):
+        if num_cg_levels < 1 or any(m not in (2, 3) for m in maxdim) or any(z != 1 for z in max_zf):
             raise NotImplementedError(
-                f"this build implements the fused maxdim=2 / max_zf=1 path; got maxdim={maxdim}, max_zf={max_zf}")
+                f"this build implements maxdim 2 (fused kernels) and 3 (table-driven kernels) with max_zf=1; got maxdim={maxdim}, max_zf={max_zf}")
         misc = {"device": self.device, "dtype": self.dtype}
 
         self.input_basis = "canonical"
@@ -36,6 +36,7 @@ class LGNDecoder(CGModule):
         self.num_cg_levels = num_cg_levels
         self.num_basis_fn = num_basis_fn
         self.max_zf = max_zf
+        self.level_maxdim = maxdim
         self.num_channels = num_channels
         self.mlp, self.mlp_depth, self.mlp_width = mlp, mlp_depth, mlp_width
         self.activation = activation
@@ -83,15 +84,17 @@ class LGNDecoder(CGModule):
         s = ops.MixFn.apply(self.input_func_node.weight((0, 0)), s0).squeeze(-1)
         v = ops.MixFn.apply(self.input_func_node.weight((1, 1)), v0)
 
-        feats = run_levels(self.lgn_cg, self.rad_funcs, self.plans, True, s, v, node_ps, None)
+        order0 = self.input_func_node.out_order
+        f0 = {(0, 0): s.unsqueeze(-1), (1, 1): v}
+        feats = run_levels(self, True, {r: f0[r] for r in order0}, node_ps, None)
 
-        s, v = feats[-1]
-        gen_v = ops.MixFn.apply(self.mix_to_output.weight((1, 1)), v)                           # (2,B,N,1,4)
+        last = feats[-1]
+        gen_v = ops.MixFn.apply(self.mix_to_output.weight((1, 1)), last[(1, 1)].contiguous())      # (2,B,N,1,4)
         if not covariance_test:
             return ops.canonical_to_cart(gen_v).squeeze(-2)
-        gen = GVec({(0, 0): ops.MixFn.apply(self.mix_to_output.weight((0, 0)), s.unsqueeze(-1)), (1, 1): gen_v})
-        orders = [self.input_func_node.out_order] + [p.out_order for p in self.plans]
-        for (s_, v_), o in zip(feats, orders):
-            nodes_all.append(as_gvec(s_, v_, o))
+        gen = GVec({(0, 0): ops.MixFn.apply(self.mix_to_output.weight((0, 0)), last[(0, 0)].contiguous()), (1, 1): gen_v})
+        orders = [order0] + [p.out_order for p in self.plans]
+        for f, o in zip(feats, orders):
+            nodes_all.append(as_gvec(f, o))
         nodes_all.append(gen)
         return gen, nodes_all

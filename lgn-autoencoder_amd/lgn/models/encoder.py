@@ -10,10 +10,10 @@ from .. import ops
 from ..g_lib import GTau, GVec
 from ..nn import LGNCG, MixReps, RadialFilters
 from ..plan import build_level_plans
-from .common import CGModule, adapt_var_list, as_gvec, run_levels
+from .common import CGModule, LevelTablesMixin, adapt_var_list, as_gvec, run_levels
 
 
-class LGNEncoder(CGModule):
+class LGNEncoder(CGModule, LevelTablesMixin):
     def __init__(self, num_input_particles: int, tau_input_scalars: int, tau_input_vectors: int,
                  tau_latent_scalars: int, tau_latent_vectors: int, maxdim, num_basis_fn: int, num_channels: List[int],
                  max_zf, weight_init, level_gain, activation: str = "leakyrelu", mlp: bool = True,
@@ -27,9 +27,9 @@ class LGNEncoder(CGModule):
         logging.info(f"Initializing encoder with device: {self.device} and dtype: {self.dtype}")
         if jet_features:
             raise NotImplementedError("jet_features=True is outside the accelerated path (SURVEY section 8)")
-        if num_cg_levels < 1 or any(m != 2 for m in maxdim) or any(z != 1 for z in max_zf):
+        if num_cg_levels < 1 or any(m not in (2, 3) for m in maxdim) or any(z != 1 for z in max_zf):
             raise NotImplementedError(
-                f"this build implements the fused maxdim=2 / max_zf=1 path; got maxdim={maxdim}, max_zf={max_zf}")
+                f"this build implements maxdim 2 (fused kernels) and 3 (table-driven kernels) with max_zf=1; got maxdim={maxdim}, max_zf={max_zf}")
         if tau_input_scalars != 1 or tau_input_vectors != 1:
             raise NotImplementedError("the encoder input is one scalar (mass) and one vector (p4) per particle")
         misc = {"device": self.device, "dtype": self.dtype}
@@ -39,6 +39,7 @@ class LGNEncoder(CGModule):
         self.num_cg_levels = num_cg_levels
         self.num_basis_fn = num_basis_fn
         self.max_zf = max_zf
+        self.level_maxdim = maxdim
         self.num_channels = num_channels
         self.jet_features = jet_features
         self.map_to_latent = map_to_latent
@@ -85,16 +86,19 @@ class LGNEncoder(CGModule):
         s = ops.MixFn.apply(self.input_func_node.weight((0, 0)), s0).squeeze(-1)
         v = ops.MixFn.apply(self.input_func_node.weight((1, 1)), v0)
 
-        feats = run_levels(self.lgn_cg, self.rad_funcs, self.plans, False, s, v, node_ps, node_mask)
+        order0 = self.input_func_node.out_order
+        f0 = {(0, 0): s.unsqueeze(-1), (1, 1): v}
+        feats = run_levels(self, False, {r: f0[r] for r in order0}, node_ps, node_mask)
 
-        s, v = feats[-1]
-        lat = {(0, 0): ops.MixFn.apply(self.mix_reps.weight((0, 0)), s.unsqueeze(-1)),
-               (1, 1): ops.canonical_to_cart(ops.MixFn.apply(self.mix_reps.weight((1, 1)), v))}
+        # mix_reps acts on every irrep of the last level; only (0,0) and (1,1) are kept (lgn_encoder.py:322-325)
+        last = feats[-1]
+        lat = {(0, 0): ops.MixFn.apply(self.mix_reps.weight((0, 0)), last[(0, 0)].contiguous()),
+               (1, 1): ops.canonical_to_cart(ops.MixFn.apply(self.mix_reps.weight((1, 1)), last[(1, 1)].contiguous()))}
         latent = GVec(ops.aggregate_latent(self.map_to_latent, lat))
         if not covariance_test:
             return latent
-        orders = [self.input_func_node.out_order] + [p.out_order for p in self.plans]
-        return latent, [as_gvec(s_, v_, o) for (s_, v_), o in zip(feats, orders)]
+        orders = [order0] + [p.out_order for p in self.plans]
+        return latent, [as_gvec(f, o) for f, o in zip(feats, orders)]
 
     def _prepare_input(self, data):
         """lgn_encoder.py:338-412 (without the jet-feature node)."""

@@ -33,13 +33,17 @@ class MixReps(nn.Module):
             raise NotImplementedError(f"weight_init can only be 'randn' or 'rand'; other choices are not implemented yet ({weight_init})!")
         self.tau_in, self.tau_out = GTau(tau_in), GTau(tau_out)
         self.real, self.weight_init = real, weight_init
-        self.weights = nn.ParameterDict()
-        for key in tau_out:
+        drawn = {}
+        for key in tau_out:                                    # RNG consumption order = tau_out order (g_weight.py:95-109)
             shape = (2, tau_out[key], tau_in[key])
             w = (torch.randn if weight_init == "randn" else torch.rand)(shape, dtype=dtype)   # CPU RNG, then moved
             g = gain / max(shape) / (10 ** key[0] if key[0] == key[1] else 1)
-            self.weights[str(key)] = nn.Parameter((w * g).to(device))
-        self.out_order: List[Irrep] = param_key_order(list(tau_out.keys()))
+            drawn[key] = (w * g).to(device)
+        # registration order = sorted keys: ParameterDict.update() sorts a plain dict (g_weight.py:76-80)
+        self.weights = nn.ParameterDict()
+        for key in sorted(drawn):
+            self.weights[str(key)] = nn.Parameter(drawn[key])
+        self.out_order: List[Irrep] = param_key_order(sorted(drawn))
 
     def weight(self, key: Irrep) -> torch.Tensor:
         return self.weights[str(key)]

@@ -187,3 +187,48 @@ def aggregate_latent(method, lat):
         parts = [aggregate_latent(x, lat) for x in method.split("&")]
         return {k: torch.cat([p[k] for p in parts], dim=3) for k in lat}
     raise NotImplementedError(f"{method} is not implemented.")
+
+
+class GenericLevelFn(torch.autograd.Function):
+    """LGNNodeLevel + edge network for arbitrary irreps (csrc/generic_moments.hip, csrc/generic_local.hip).
+    args: decoder, tables (N.DeviceTables), CO, X packed (2,B,N,C,Q), p, mask, 7 radial params, then the CatMix
+    weights of the output irreps in ``tables.meta['out_irreps']`` order.  Returns the packed output (2,B,N,CO,Qout)."""
+
+    @staticmethod
+    def forward(ctx, decoder, tables, CO, X, p, mask, ra, rb, rc, w0, b0, w1, b1, *wmix):
+        X, p = N.f64(X), N.f64(p)
+        rad = tuple(N.f64(t.detach()) for t in (ra, rb, rc, w0, b0, w1, b1))
+        if decoder:
+            rad = (None, None, None, None, rad[4], None, rad[6])
+        wcat = torch.cat([N.f64(w.detach()).reshape(-1) for w in wmix])
+        U = N.moments_fwd(decoder, X, p, mask, rad)
+        out = N.local_fwd(tables, CO, X, U, wcat)
+        ctx.decoder, ctx.tables, ctx.CO, ctx.mask = decoder, tables, CO, mask
+        ctx.rad_full = (ra, rb, rc, w0, b0, w1, b1)
+        ctx.wshapes = [w.shape for w in wmix]
+        ctx.save_for_backward(X, p, U, wcat, *[t for t in rad if t is not None])
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        X, p, U, wcat, *radl = ctx.saved_tensors
+        decoder = ctx.decoder
+        if decoder:
+            rad = (None, None, None, None, radl[0], None, radl[1])
+            g_p = torch.zeros_like(p)
+        else:
+            rad, g_p = tuple(radl), None
+        gU, gX, g_w = N.local_bwd(ctx.tables, ctx.CO, X, U, wcat, N.f64(g_out))
+        rg = N.moments_bwd(decoder, X, p, ctx.mask, rad, gU, gX, g_p)
+        ra, rb, rc, w0, b0, w1, b1 = ctx.rad_full
+        if decoder:
+            g_rad = (torch.zeros_like(ra), torch.zeros_like(rb), torch.zeros_like(rc), torch.zeros_like(w0),
+                     rg[0].view_as(b0), torch.zeros_like(w1), rg[1].view_as(b1))
+        else:
+            g_rad = (rg[0].view_as(ra), rg[1].view_as(rb), rg[2].view_as(rc), rg[3], rg[4], rg[5], rg[6])
+        g_ws, off = [], 0
+        for shp in ctx.wshapes:
+            n = shp.numel()
+            g_ws.append(g_w[off:off + n].view(shp))
+            off += n
+        return (None, None, None, gX, g_p, None) + g_rad + tuple(g_ws)

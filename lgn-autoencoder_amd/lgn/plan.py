@@ -109,7 +109,7 @@ def build_level_plans(num_channels: Sequence[int], maxdim: Sequence[int], max_zf
         tau_ag = cg_tau_out(tau, tau_edge, md)
         tau_cat = cat_tau([tau_ag, tau, tau_sq], md)
         tau_out = {k: num_channels[lvl + 1] for k, v in tau_cat.items() if v}
-        out_order = param_key_order(list(tau_out.keys()))
+        out_order = param_key_order(sorted(tau_out.keys()))   # ParameterDict registers a plain dict in sorted key order
         if mlp:   # CGMLP pops (0,0) and re-inserts it last (lgn_levels.py:210,224)
             out_order = [k for k in out_order if k != (0, 0)] + [(0, 0)]
         ag = _product_blocks(order, list(tau_edge.keys()), md, "ag")
@@ -143,3 +143,88 @@ def check_maxdim2_layout(plan: LevelPlan):
     if got != MAXDIM2_BLOCKS or plan.node_order != [(1, 1), (0, 0)]:
         raise RuntimeError(f"unexpected maxdim=2 CatMix layout {got} / node order {plan.node_order}; "
                            "the fused kernels assume SURVEY 8 a-3'")
+
+
+# ---------------------------------------------------------------------------------------------------
+# sparse tables of the generic (any maxdim) level: which products feed which concatenated row
+# ---------------------------------------------------------------------------------------------------
+def irrep_dim(r: Irrep) -> int:
+    return (r[0] + 1) * (r[1] + 1)
+
+
+def build_local_tables(plan: LevelPlan, cg_dict, tol: float = 1e-14):
+    """Flatten (aggregate CG, power CG, concatenation) of one level into CSR term lists for
+    csrc/generic_local.hip (struct lgn_local_tables of include/lgn_amd.h).
+
+    Packed input components: irreps in ``plan.node_order``; packed output components: ``plan.out_order``.
+    Row (l, block, m) of the concatenated CatMix input of output irrep l is a sparse combination of
+      type 0: moments U[q][k]   (k = 0: edge irrep (0,0); k = 1 + m2: edge irrep (1,1))   -- aggregate blocks
+      type 1: node component X[q]                                                             -- node block
+      type 2: products X[q1] X[q2]                                                            -- power blocks
+    with the Clebsch-Gordan coefficient as weight (reference: the CG matmul of cg_ops.py:195-204 applied to the
+    Kronecker index m1*d2 + m2 of cg_ops.py:281-288)."""
+    import numpy as np
+    qoff, q = {}, 0
+    for r in plan.node_order:
+        qoff[r] = q
+        q += irrep_dim(r)
+    Q = q
+    out_irreps = list(plan.out_order)
+    row_ptr, t_type, t_a, t_b, t_coef = [0], [], [], [], []
+    out_dim, out_nblk, out_row0, out_q0, out_w0 = [], [], [], [], []
+    qo, wbase, nrows = 0, 0, 0
+    C, CO = plan.channels_in, plan.channels_out
+    for L in out_irreps:
+        d = irrep_dim(L)
+        blocks = plan.cat_blocks[L]
+        out_dim.append(d); out_nblk.append(len(blocks)); out_row0.append(nrows); out_q0.append(qo); out_w0.append(2 * wbase)
+        qo += d
+        wbase += CO * len(blocks) * C
+        for (src, r1, r2) in blocks:
+            d1, d2 = irrep_dim(r1), irrep_dim(r2)
+            if src != "node":
+                cgm = cg_dict[(r1, r2)][L].detach().cpu().numpy().astype(np.float64).reshape(d, d1, d2)
+            for m in range(d):
+                if src == "node":
+                    t_type.append(1); t_a.append(qoff[L] + m); t_b.append(0); t_coef.append(1.0)
+                else:
+                    for m1 in range(d1):
+                        for m2 in range(d2):
+                            cf = float(cgm[m, m1, m2])
+                            if abs(cf) <= tol:
+                                continue
+                            if src == "ag":
+                                k = 0 if r2 == (0, 0) else 1 + m2
+                                t_type.append(0); t_a.append((qoff[r1] + m1) * 5 + k); t_b.append(0)
+                            else:
+                                t_type.append(2); t_a.append(qoff[r1] + m1); t_b.append(qoff[r2] + m2)
+                            t_coef.append(cf)
+                row_ptr.append(len(t_type))
+                nrows += 1
+    # transposed lists
+    u_lists = [[] for _ in range(Q * 5)]
+    x_lists = [[] for _ in range(Q)]
+    for row in range(nrows):
+        for t in range(row_ptr[row], row_ptr[row + 1]):
+            if t_type[t] == 0:
+                u_lists[t_a[t]].append((row, t_coef[t]))
+            elif t_type[t] == 1:
+                x_lists[t_a[t]].append((row, -1, t_coef[t]))
+            else:
+                x_lists[t_a[t]].append((row, t_b[t], t_coef[t]))
+                x_lists[t_b[t]].append((row, t_a[t], t_coef[t]))
+    u_ptr, u_row, u_coef = [0], [], []
+    for lst in u_lists:
+        for (row, cf) in lst:
+            u_row.append(row); u_coef.append(cf)
+        u_ptr.append(len(u_row))
+    x_ptr, x_row, x_other, x_coef = [0], [], [], []
+    for lst in x_lists:
+        for (row, other, cf) in lst:
+            x_row.append(row); x_other.append(other); x_coef.append(cf)
+        x_ptr.append(len(x_row))
+    ints = dict(row_ptr=row_ptr, t_type=t_type, t_a=t_a, t_b=t_b, out_dim=out_dim, out_nblk=out_nblk, out_row0=out_row0,
+                out_q0=out_q0, out_w0=out_w0, u_ptr=u_ptr, u_row=u_row, x_ptr=x_ptr, x_row=x_row, x_other=x_other)
+    dbls = dict(t_coef=t_coef, u_coef=u_coef, x_coef=x_coef)
+    return dict(Q=Q, Qout=qo, n_rows=nrows, n_out=len(out_irreps), n_w=wbase, ints=ints, dbls=dbls,
+                in_irreps=list(plan.node_order), out_irreps=out_irreps)

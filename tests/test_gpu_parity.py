@@ -147,11 +147,78 @@ def test_mixreps(dev, O, rows, Ci, Co, d):
 
 def _build(meta, dev):
     import __graft_entry__ as G
-    enc, dec = G._models(meta["N"], meta["ch_enc"], meta["ch_dec"], dev, seed=meta["seed"])
+    enc, dec = G._models(meta["N"], meta["ch_enc"], meta["ch_dec"], dev, seed=meta["seed"], maxdim=meta["maxdim"])
     return enc, dec
 
 
-@pytest.mark.parametrize("name", ["g1_e2e_maxdim2.npz", "g3_e2e_n150.npz"])
+@pytest.mark.parametrize("decoder", [False, True])
+@pytest.mark.parametrize("maxdim,full,C,CO,N,B", [(3, True, 4, 6, 30, 2), (3, False, 4, 4, 30, 2), (3, True, 6, 4, 13, 1),
+                                                  (2, False, 3, 4, 30, 2), (3, True, 2, 3, 5, 1)])
+def test_generic_level_fwd_bwd(dev, O, decoder, maxdim, full, C, CO, N, B):
+    """Table-driven level (moments + sparse CG + CatMix) for arbitrary irreps vs the oracle's cg_product /
+    CatMixReps, forward and all gradients.  `full`: the node carries all five maxdim=3 irreps."""
+    from lgn import ops, _native as Nn
+    from lgn.cg_lib import CGDict
+    from lgn.plan import build_level_plans, build_local_tables, param_key_order
+    g = torch.Generator().manual_seed(1000 * maxdim + 10 * C + CO + N + int(decoder) + int(full))
+    node_order = [(1, 1), (2, 0), (0, 2), (2, 2), (0, 0)] if full else [(1, 1), (0, 0)]
+    cfg = O.NetConfig(num_channels=(C, CO), maxdim=maxdim)
+    tau_in = {k: C for k in ([(0, 0), (0, 2), (1, 1), (2, 0), (2, 2)] if full else [(0, 0), (1, 1)])}
+    plan_o = O.build_level_plans(cfg, tau_in)[0]
+    plan = build_level_plans([C, CO], [maxdim], [1], True, tau_in, node_order)[0]
+    P = {}
+    torch.manual_seed(int(torch.randint(0, 10000, (1,), generator=g)))
+    O._init_radial(P, cfg, decoder)
+    for k, n_in in plan_o.tau_cat.items():
+        P[f"lgn_cg.node_levels.0.cat_mix.mix_reps.weights.{k}"] = torch.randn(2, CO, n_in, dtype=torch.float64, generator=g) * 0.3
+    P = {k: v.requires_grad_(True) for k, v in P.items()}
+    node = {r: torch.randn(2, B, N, C, (r[0] + 1) * (r[1] + 1), dtype=torch.float64, generator=g).requires_grad_(True)
+            for r in node_order}
+    if decoder:
+        p = torch.randn(2, B, N, 4, dtype=torch.float64, generator=g).requires_grad_(True)
+        zonal, norms, _ = O.zonal_rel(p, p, "canonical")
+        mask, emask = None, torch.zeros(2, B, N, N, dtype=torch.float64)
+    else:
+        p, mask = O.synthetic_jets(B, N, seed=N + C, pad=N > 4)
+        zonal, norms, _ = O.zonal_rel(p, p, "cartesian")
+        emask = (mask.unsqueeze(1) * mask.unsqueeze(2)) * (norms != 0).byte()
+    rad = O.radial_filters(P, cfg, 0, norms, emask, decoder)
+    edge = {k: O.scalar_times_irrep(rad[k], zonal[k]) for k in rad}
+    out = O.node_level(P, O.get_cg(maxdim), cfg, 0, plan_o, node, edge)
+    cot = {k: torch.randn(v.shape, dtype=torch.float64, generator=g) for k, v in out.items()}
+    sum((out[k] * cot[k]).sum() for k in out).backward()
+
+    d = lambda t: t.detach().to(dev).requires_grad_(t.requires_grad)  # noqa: E731
+    tables = Nn.DeviceTables(build_local_tables(plan, CGDict(maxdim=maxdim)), dev)
+    assert set(tables.meta["out_irreps"]) == set(out.keys())
+    feats = {r: d(node[r]) for r in node_order}
+    X = torch.cat([feats[r] for r in node_order], dim=-1)
+    pd = d(p)
+    pre = "rad_funcs.rad_funcs.0."
+    names = ["a", "b", "c", "linear.0.weight", "linear.0.bias", "linear.1.weight", "linear.1.bias"]
+    radp = [d(P[pre + n]) for n in names]
+    wmix = [d(P[f"lgn_cg.node_levels.0.cat_mix.mix_reps.weights.{r}"]) for r in tables.meta["out_irreps"]]
+    Y = ops.GenericLevelFn.apply(decoder, tables, CO, X, pd, None if decoder else mask.to(dev), *radp, *wmix)
+    parts = dict(zip(tables.meta["out_irreps"], torch.split(Y, [(r[0] + 1) * (r[1] + 1) for r in tables.meta["out_irreps"]], dim=-1)))
+    for r in out:
+        U.assert_close(parts[r], out[r], FWD_TOL, f"out {r}")
+    sum((parts[r] * cot[r].to(dev)).sum() for r in out).backward()
+    for r in node_order:
+        U.assert_close(feats[r].grad, node[r].grad, GRAD_TOL, f"g_node {r}")
+    if decoder:
+        U.assert_close(pd.grad, p.grad, GRAD_TOL, "g_p")
+    for n, t in zip(names, radp):
+        ref = P[pre + n].grad
+        ref = torch.zeros_like(P[pre + n]) if ref is None else ref
+        if ref.abs().max() == 0:
+            assert t.grad is None or t.grad.abs().max() == 0, f"{n} must have exactly zero gradient"
+        else:
+            U.assert_close(t.grad, ref, GRAD_TOL, "g_" + n)
+    for r, w in zip(tables.meta["out_irreps"], wmix):
+        U.assert_close(w.grad, P[f"lgn_cg.node_levels.0.cat_mix.mix_reps.weights.{r}"].grad, GRAD_TOL, f"g_wmix {r}")
+
+
+@pytest.mark.parametrize("name", ["g1_e2e_maxdim2.npz", "g3_e2e_n150.npz", "g2_e2e_maxdim3.npz"])
 def test_end_to_end_vs_reference_golden(dev, O, name):
     """Full encoder -> decoder -> Chamfer forward/backward against vectors captured from the reference."""
     z = U.load(name)
