@@ -547,6 +547,44 @@ __global__ void rad_finalize_kernel(const T* tot, int C, const T* ra, const T* r
   }
 }
 
+__global__ void rad_finalize_batch_kernel(RadFinJob job) {
+  const RadFinJob::Item it = job.it[blockIdx.x];
+  const int C = it.C, R = 4 * C, F = 2 * C;
+  const double* T1 = it.tot;
+  const double* T2 = it.tot + R * NB;
+  const double* S = it.tot + 2 * R * NB;
+  const double* dB = S + R;
+  for (int e = threadIdx.x; e < R * NB; e += blockDim.x) {
+    int r = e / NB, k = e - r * NB;
+    int lin = r / F, f = r - lin * F;
+    (lin ? it.g_w1 : it.g_w0)[f * NB + k] = it.rb[k] * T1[e] + it.ra[k] * S[r];
+  }
+  for (int r = threadIdx.x; r < R; r += blockDim.x) {
+    int lin = r / F, f = r - lin * F;
+    (lin ? it.g_b1 : it.g_b0)[f] = dB[r];
+  }
+  for (int k = threadIdx.x; k < NB; k += blockDim.x) {
+    double da = 0, db = 0, dc = 0;
+    for (int r = 0; r < R; ++r) {
+      int lin = r / F, f = r - lin * F;
+      double w = (lin ? it.w1 : it.w0)[f * NB + k];
+      da += w * S[r];
+      db += w * T1[r * NB + k];
+      dc += w * T2[r * NB + k];
+    }
+    it.g_a[k] = da;
+    it.g_b[k] = db;
+    it.g_c[k] = -2.0 * it.rb[k] * it.rc[k] * dc;
+  }
+}
+
+int rad_finalize_batch(const RadFinJob& job, hipStream_t stream) {
+  if (job.n <= 0) return 0;
+  hipLaunchKernelGGL(rad_finalize_batch_kernel, dim3(job.n), dim3(256), 0, stream, job);
+  LGN_CHECK_LAUNCH();
+  return 0;
+}
+
 // =========================================================================================
 // 3b. i-centric pass, decoder: radial bias gradients + position gradient of the receiving node.
 //   R0[c] = b0[c] (1+i), R1[c] = b1[c] (1+i)  ->  d b0[c] = Re G_R0 + Im G_R0 (same for b1)

@@ -476,8 +476,16 @@ __global__ __launch_bounds__(BLOCK) void dec_output_loss_kernel(int B, int N, in
 __global__ __launch_bounds__(1024) void loss_l1_kernel(const double* __restrict__ loss_part, int nB, const double* __restrict__ w,
                                                       long n, double lambda, double* loss_out, long* step_dev, int bump) {
   __shared__ double red[2][16];
-  double a = 0, l = 0;
-  for (long i = threadIdx.x; i < n; i += 1024) a += fabs(w[i]);
+  double a = 0, l = 0, a1 = 0, a2 = 0, a3 = 0;
+  long i = threadIdx.x;
+  for (; i + 3 * 1024 < n; i += 4 * 1024) {      // four independent streams: the loads overlap
+    a += fabs(w[i]);
+    a1 += fabs(w[i + 1024]);
+    a2 += fabs(w[i + 2 * 1024]);
+    a3 += fabs(w[i + 3 * 1024]);
+  }
+  for (; i < n; i += 1024) a += fabs(w[i]);
+  a = (a + a1) + (a2 + a3);
   for (int i = threadIdx.x; i < nB; i += 1024) l += loss_part[i];
   a = group_sum<64>(a);
   l = group_sum<64>(l);

@@ -10,7 +10,7 @@ template <typename T> int level_bwd_dispatch(const LevelBwdArgs<T>&, int decoder
 template <typename T> int reduce_partials(const T* part, int rows, int n, T* out, int accumulate, hipStream_t);
 template <typename T> int reduce_partials_strided(const T* part, int rows, int stride, int col0, int n, T* out, hipStream_t);
 // one launch reducing up to 8 column ranges:  seg.out[c] = sum_r seg.part[r*stride + col0 + c]
-constexpr int RED_MAX_SEG = 8;
+constexpr int RED_MAX_SEG = 24;
 template <typename T> struct RedSeg { const T* part; int rows, stride, col0, n; T* out; };
 template <typename T> struct RedJob {
   int nseg;
@@ -22,6 +22,12 @@ template <typename T> int reduce_segments(RedJob<T>& job, hipStream_t);
 template <typename T>
 int rad_finalize(const T* tot, int C, const T* ra, const T* rb, const T* rc, const T* w0, const T* w1, T* g_a, T* g_b, T* g_c,
                  T* g_w0, T* g_b0, T* g_w1, T* g_b1, hipStream_t);
+// several levels in one launch (one workgroup per level)
+struct RadFinJob {
+  int n;
+  struct Item { const double* tot; int C; const double *ra, *rb, *rc, *w0, *w1; double *g_a, *g_b, *g_c, *g_w0, *g_b0, *g_w1, *g_b1; } it[4];
+};
+int rad_finalize_batch(const RadFinJob& job, hipStream_t);
 void level_bwd_partial_rows(int B, int N, int decoder, int* rows_mix, int* rows_rad);
 
 // ---- CGMLP (mlp.hip / mlp_mfma.hip) ------------------------------------------------------------------

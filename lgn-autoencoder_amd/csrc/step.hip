@@ -32,9 +32,37 @@ struct Work {
   NetBuf enc, dec;
   double *lat_s, *lat_v, *pdec, *g_lat_s, *g_lat_v, *g_p;
   double *gs[2], *gv[2], *gsmix, *g_ag, *zeros_s;
-  double *part, *tot;
+  double *parts;               // bump region: every producer of partial rows gets its own slice (reduced at the end)
+  size_t parts_size;
+  double* tot[2][4];           // reduced radial sums per (network, level)
   int* idx;
   size_t total;
+  size_t zero_doubles;         // zeros_s | g_p | g_lat_s are contiguous: one memset
+};
+
+// deferred reductions: producers register their column ranges, one or two launches at the end reduce everything
+struct Deferred {
+  std::vector<RedSeg<double>> segs;
+  double* parts;
+  size_t off = 0, cap = 0;
+  double* take(size_t n) {
+    n = (n + 15) & ~size_t(15);
+    double* p = parts + off;
+    off += n;
+    return p;
+  }
+  void add(const double* part, int rows, int stride, int col0, int n, double* out) {
+    if (n > 0) segs.push_back(RedSeg<double>{part, rows, stride, col0, n, out});
+  }
+  int flush(hipStream_t st) {
+    for (size_t i = 0; i < segs.size(); i += RED_MAX_SEG) {
+      RedJob<double> job{};
+      for (size_t k = i; k < segs.size() && k < i + RED_MAX_SEG; ++k) job.seg[job.nseg++] = segs[k];
+      if (int rc = reduce_segments<double>(job, st)) return rc;
+    }
+    segs.clear();
+    return 0;
+  }
 };
 
 int mlp_psize(int C, int H, int nlin) {
@@ -65,36 +93,38 @@ Work carve(const lgn_net_desc& d, double* base) {
   const int Ts = d.tau_s, Tv = d.tau_v;
   w.lat_s = b.take((size_t)2 * d.B * 2 * Ts);
   w.lat_v = b.take((size_t)2 * d.B * 2 * Tv * 4);
-  w.g_lat_s = b.take((size_t)2 * d.B * 2 * Ts);
   w.g_lat_v = b.take((size_t)2 * d.B * 2 * Tv * 4);
   w.pdec = b.take(8 * BN);
-  w.g_p = b.take(8 * BN);
   for (int q = 0; q < 2; ++q) {
     w.gs[q] = b.take(2 * BN * cmax);
     w.gv[q] = b.take(8 * BN * cmax);
   }
   w.gsmix = b.take(2 * BN * cmax);
-  w.zeros_s = b.take(2 * BN * cmax);
   w.g_ag = b.take(20 * BN * cmax);
+  {  // contiguous zero-initialised region
+    const size_t z0 = b.off;
+    w.zeros_s = b.take(2 * BN * cmax);
+    w.g_p = b.take(8 * BN);
+    w.g_lat_s = b.take((size_t)2 * d.B * 2 * d.tau_s);
+    w.zero_doubles = b.off - z0;
+  }
   w.idx = reinterpret_cast<int*>(b.take(((size_t)d.B * 2 * (Ts + Tv) * 2 + 1) / 2 + 8));
-  // partial rows: the largest producer wins
-  size_t pmax = 0, tmax = 0;
+  // partial rows: every producer keeps its own slice until the deferred reduction at the end of the step
+  size_t psum = 0;
   for (int dec = 0; dec < 2; ++dec) {
     const int* ch = dec ? d.dec_channels : d.enc_channels;
     for (int l = 0; l < L; ++l) {
       int rm, rr;
       level_bwd_partial_rows(d.B, d.N, dec, &rm, &rr);
       const size_t nmix = (size_t)4 * ch[l + 1] * 5 * ch[l], nrad = rad_partial_size(ch[l], dec != 0);
-      pmax = pmax > rm * nmix + rr * nrad ? pmax : rm * nmix + rr * nrad;
-      tmax = tmax > nrad ? tmax : nrad;
-      const size_t pm = (size_t)mlp_partial_rows((int)BN) * mlp_psize(ch[l + 1], d.mlp_hidden_mul * 2 * ch[l + 1], d.mlp_nlin);
-      pmax = pmax > pm ? pmax : pm;
+      psum += ((rm * nmix + 15) & ~size_t(15)) + ((rr * nrad + 15) & ~size_t(15));
+      psum += ((size_t)mlp_partial_rows((int)BN) * mlp_psize(ch[l + 1], d.mlp_hidden_mul * 2 * ch[l + 1], d.mlp_nlin) + 15) & ~size_t(15);
+      w.tot[dec][l] = b.take(nrad + 16);
     }
   }
-  const size_t pio = (size_t)d.B * (4 * cmax + 2 * (size_t)d.N * 2 * Tv + 2 * (Ts + Tv) * cmax);
-  pmax = pmax > pio ? pmax : pio;
-  w.part = b.take(pmax);
-  w.tot = b.take(tmax + 16);
+  psum += 4 * (((size_t)d.B * (4 * cmax + 2 * (size_t)d.N * 2 * Tv + 2 * (Ts + Tv) * cmax) + 15) & ~size_t(15));
+  w.parts = b.take(psum);
+  w.parts_size = psum;
   w.total = b.off;
   return w;
 }
@@ -139,7 +169,8 @@ int levels_fwd(const lgn_net_desc& d, bool dec, const int* ch, const double* P, 
 // has_s_grad says whether gs is non-zero (false for both networks of the autoencoder: the last level's
 // scalars never reach the loss).  On exit gs[cur]/gv[cur] hold the gradient w.r.t. level 0.
 int levels_bwd(const lgn_net_desc& d, bool dec, const int* ch, const double* P, double* G, const int64_t* off, const NetBuf& n,
-               const double* pos, const uint8_t* mask, Work& w, int& cur, bool has_s_grad, hipStream_t st) {
+               const double* pos, const uint8_t* mask, Work& w, Deferred& dq, RadFinJob& fin, int& cur, bool has_s_grad,
+               hipStream_t st) {
   const Slots S{d.n_levels, d.mlp_nlin};
   const int BN = d.B * d.N;
   for (int l = d.n_levels - 1; l >= 0; --l) {
@@ -151,38 +182,37 @@ int levels_bwd(const lgn_net_desc& d, bool dec, const int* ch, const double* P, 
       MlpArgs<double> m{};
       m.M = BN; m.C = CO; m.H = d.mlp_hidden_mul * 2 * CO; m.nlin = d.mlp_nlin;
       for (int q = 0; q < d.mlp_nlin; ++q) { m.w[q] = p(S.mlp(dec, l, 2 * q)); m.b[q] = p(S.mlp(dec, l, 2 * q + 1)); }
-      m.s_in = n.smix[l]; m.g_out = w.gs[cur]; m.g_in = w.gsmix; m.part = w.part;
+      m.s_in = n.smix[l]; m.g_out = w.gs[cur]; m.g_in = w.gsmix;
       m.psize = mlp_psize(CO, m.H, m.nlin);
+      m.part = dq.take((size_t)mlp_partial_rows(BN) * m.psize);
       LGN_TRY(mlp_dispatch<double>(m, true, st));
       // the MLP's parameters are contiguous in the flat buffer in (W_0, b_0, W_1, ...) order (checked at plan time)
-      LGN_TRY(reduce_partials<double>(w.part, mlp_partial_rows(BN), m.psize, g(S.mlp(dec, l, 0)), 0, st));
+      dq.add(m.part, mlp_partial_rows(BN), m.psize, 0, m.psize, g(S.mlp(dec, l, 0)));
       g_smix = w.gsmix;
     }
     int rm, rr;
     level_bwd_partial_rows(d.B, d.N, dec, &rm, &rr);
     const int nmix = 4 * CO * 5 * C, nrad = rad_partial_size(C, dec);
-    double* part_mix = w.part;
-    double* part_rad = w.part + (size_t)rm * nmix;
+    double* part_mix = dq.take((size_t)rm * nmix);
+    double* part_rad = dq.take((size_t)rr * nrad);
     const int nxt = cur ^ 1;
     LevelBwdArgs<double> a{d.B, d.N, C, CO, n.s[l], n.v[l], pos, mask,
                            p(S.rad(dec, l, 0)), p(S.rad(dec, l, 1)), p(S.rad(dec, l, 2)), p(S.rad(dec, l, 3)), p(S.rad(dec, l, 4)),
                            p(S.rad(dec, l, 5)), p(S.rad(dec, l, 6)), p(S.mix(dec, l, 0)), p(S.mix(dec, l, 1)), n.ag0[l], n.ag1[l],
                            g_smix, w.gv[cur], w.g_ag, w.gs[nxt], w.gv[nxt], dec ? w.g_p : nullptr, part_mix, part_rad};
     LGN_TRY(level_bwd_dispatch<double>(a, dec, st));
-    // one reduction launch per level: CatMix weights (partial row = [wm0 | wm1]) + radial sums
-    RedJob<double> job{};
-    job.add(part_mix, rm, nmix, 0, nmix / 2, g(S.mix(dec, l, 0)));
-    job.add(part_mix, rm, nmix, nmix / 2, nmix / 2, g(S.mix(dec, l, 1)));
+    // deferred reductions: CatMix weights (partial row = [wm0 | wm1]) + radial sums
+    dq.add(part_mix, rm, nmix, 0, nmix / 2, g(S.mix(dec, l, 0)));
+    dq.add(part_mix, rm, nmix, nmix / 2, nmix / 2, g(S.mix(dec, l, 1)));
     if (dec) {   // only the Linear biases receive gradient (all edges are "masked")
-      job.add(part_rad, rr, nrad, 0, C, g(S.rad(dec, l, 4)));
-      job.add(part_rad, rr, nrad, C, C, g(S.rad(dec, l, 6)));
-      LGN_TRY(reduce_segments<double>(job, st));
+      dq.add(part_rad, rr, nrad, 0, C, g(S.rad(dec, l, 4)));
+      dq.add(part_rad, rr, nrad, C, C, g(S.rad(dec, l, 6)));
     } else {
-      job.add(part_rad, rr, nrad, 0, nrad, w.tot);
-      LGN_TRY(reduce_segments<double>(job, st));
-      LGN_TRY(rad_finalize<double>(w.tot, C, p(S.rad(dec, l, 0)), p(S.rad(dec, l, 1)), p(S.rad(dec, l, 2)), p(S.rad(dec, l, 3)),
-                                   p(S.rad(dec, l, 5)), g(S.rad(dec, l, 0)), g(S.rad(dec, l, 1)), g(S.rad(dec, l, 2)),
-                                   g(S.rad(dec, l, 3)), g(S.rad(dec, l, 4)), g(S.rad(dec, l, 5)), g(S.rad(dec, l, 6)), st));
+      double* tot = w.tot[0][l];
+      dq.add(part_rad, rr, nrad, 0, nrad, tot);
+      fin.it[fin.n++] = RadFinJob::Item{tot, C, p(S.rad(dec, l, 0)), p(S.rad(dec, l, 1)), p(S.rad(dec, l, 2)), p(S.rad(dec, l, 3)),
+                                        p(S.rad(dec, l, 5)), g(S.rad(dec, l, 0)), g(S.rad(dec, l, 1)), g(S.rad(dec, l, 2)),
+                                        g(S.rad(dec, l, 3)), g(S.rad(dec, l, 4)), g(S.rad(dec, l, 5)), g(S.rad(dec, l, 6))};
     }
     cur = nxt;
     has_s_grad = true;       // the level input scalars do carry gradient
@@ -250,11 +280,11 @@ int lgn_step_fwd_bwd_f64(const lgn_net_desc* d, const double* params, double* gr
   }
 #define HIPOK(e) do { hipError_t e_ = (e); if (e_ != hipSuccess) { set_error("%s: %s", #e, hipGetErrorString(e_)); return (int)e_; } } while (0)
   HIPOK(hipMemsetAsync(grads, 0, sizeof(double) * (size_t)n_params, st));      // dead parameters keep an exact zero
-  int cmax = 0;
-  for (int l = 0; l <= L; ++l) cmax = cmax > ce[l] ? cmax : ce[l], cmax = cmax > cd[l] ? cmax : cd[l];
-  HIPOK(hipMemsetAsync(w.zeros_s, 0, sizeof(double) * 2 * (size_t)B * N * cmax, st));
-  HIPOK(hipMemsetAsync(w.g_p, 0, sizeof(double) * 8 * (size_t)B * N, st));
-  HIPOK(hipMemsetAsync(w.g_lat_s, 0, sizeof(double) * 2 * (size_t)B * 2 * Ts, st));
+  HIPOK(hipMemsetAsync(w.zeros_s, 0, sizeof(double) * w.zero_doubles, st));      // zeros_s | g_p | g_lat_s
+  Deferred dq;
+  dq.parts = w.parts;
+  dq.cap = w.parts_size;
+  RadFinJob fin{};
 
   // ---------------- forward ----------------
   LGN_TRY(enc_input_fwd(B, N, ce[0], p4, params + enc_off[0], params + enc_off[1], w.enc.s[0], w.enc.v[0], st));
@@ -267,38 +297,41 @@ int lgn_step_fwd_bwd_f64(const lgn_net_desc* d, const double* params, double* gr
 
   // ---------------- loss + backward ----------------
   int cur = 0;
-  LGN_TRY(dec_output_loss(B, N, cd[L], w.dec.v[L], params + dec_off[S.out0(true) + 1], p4, 1.0, recon, loss_part, w.gv[cur], w.part, st));
-  LGN_TRY(reduce_partials<double>(w.part, B, 2 * cd[L], grads + dec_off[S.out0(true) + 1], 0, st));
-  LGN_TRY(levels_bwd(*d, true, cd, params, grads, dec_off, w.dec, w.pdec, nullptr, w, cur, /*has_s_grad=*/false, st));
+  {
+    double* part = dq.take((size_t)B * 2 * cd[L]);
+    LGN_TRY(dec_output_loss(B, N, cd[L], w.dec.v[L], params + dec_off[S.out0(true) + 1], p4, 1.0, recon, loss_part, w.gv[cur], part, st));
+    dq.add(part, B, 2 * cd[L], 0, 2 * cd[L], grads + dec_off[S.out0(true) + 1]);
+  }
+  LGN_TRY(levels_bwd(*d, true, cd, params, grads, dec_off, w.dec, w.pdec, nullptr, w, dq, fin, cur, /*has_s_grad=*/false, st));
   {
     const int C0 = cd[0], Tin = 2 * Tv, row = 4 * C0 + 2 * N * Tin;
+    double* part = dq.take((size_t)B * row);
     LGN_TRY(dec_input_bwd(B, N, C0, Tin, w.lat_v, params + dec_off[1], params + dec_off[3], w.pdec, w.g_p, w.gs[cur], w.gv[cur],
-                          w.g_lat_v, w.part, st));
-    RedJob<double> job{};
-    job.add(w.part, B, row, 0, 2 * C0, grads + dec_off[2]);
-    job.add(w.part, B, row, 2 * C0, 2 * C0, grads + dec_off[3]);
-    job.add(w.part, B, row, 4 * C0, 2 * N * Tin, grads + dec_off[1]);
-    LGN_TRY(reduce_segments<double>(job, st));
+                          w.g_lat_v, part, st));
+    dq.add(part, B, row, 0, 2 * C0, grads + dec_off[2]);
+    dq.add(part, B, row, 2 * C0, 2 * C0, grads + dec_off[3]);
+    dq.add(part, B, row, 4 * C0, 2 * N * Tin, grads + dec_off[1]);
   }
   {
     const int CL = ce[L], row = 2 * (Ts + Tv) * CL;
     cur = 0;
+    double* part = dq.take((size_t)B * row);
     LGN_TRY(enc_latent_bwd(B, N, CL, Ts, Tv, w.enc.s[L], w.enc.v[L], params + enc_off[S.out0(false)],
-                           params + enc_off[S.out0(false) + 1], w.g_lat_s, w.g_lat_v, w.idx, w.gs[cur], w.gv[cur], w.part, st));
-    RedJob<double> job{};
-    job.add(w.part, B, row, 0, 2 * Ts * CL, grads + enc_off[S.out0(false)]);
-    job.add(w.part, B, row, 2 * Ts * CL, 2 * Tv * CL, grads + enc_off[S.out0(false) + 1]);
-    LGN_TRY(reduce_segments<double>(job, st));
+                           params + enc_off[S.out0(false) + 1], w.g_lat_s, w.g_lat_v, w.idx, w.gs[cur], w.gv[cur], part, st));
+    dq.add(part, B, row, 0, 2 * Ts * CL, grads + enc_off[S.out0(false)]);
+    dq.add(part, B, row, 2 * Ts * CL, 2 * Tv * CL, grads + enc_off[S.out0(false) + 1]);
   }
-  LGN_TRY(levels_bwd(*d, false, ce, params, grads, enc_off, w.enc, p4, mask, w, cur, /*has_s_grad=*/false, st));
+  LGN_TRY(levels_bwd(*d, false, ce, params, grads, enc_off, w.enc, p4, mask, w, dq, fin, cur, /*has_s_grad=*/false, st));
   {
     const int C0 = ce[0];
-    LGN_TRY(enc_input_bwd(B, N, C0, p4, w.gs[cur], w.gv[cur], w.part, st));
-    RedJob<double> job{};
-    job.add(w.part, B, 4 * C0, 0, 2 * C0, grads + enc_off[0]);
-    job.add(w.part, B, 4 * C0, 2 * C0, 2 * C0, grads + enc_off[1]);
-    LGN_TRY(reduce_segments<double>(job, st));
+    double* part = dq.take((size_t)B * 4 * C0);
+    LGN_TRY(enc_input_bwd(B, N, C0, p4, w.gs[cur], w.gv[cur], part, st));
+    dq.add(part, B, 4 * C0, 0, 2 * C0, grads + enc_off[0]);
+    dq.add(part, B, 4 * C0, 2 * C0, 2 * C0, grads + enc_off[1]);
   }
+  LGN_CHECK_ARG(dq.off <= dq.cap, "step: partial-row workspace overflow (%zu > %zu)", dq.off, dq.cap);
+  LGN_TRY(dq.flush(st));                       // every batch reduction of the step, in one or two launches
+  LGN_TRY(rad_finalize_batch(fin, st));
   return 0;
 }
 
