@@ -744,9 +744,16 @@ static int ensure_smem(K kern, size_t smem, const char* what) {
 int level_bwd_nodes2_dispatch(const LevelBwdArgs<double>& a, int decoder, hipStream_t stream);   // level_bwd2.hip
 int level_bwd_rad2_dispatch(const LevelBwdArgs<double>& a, hipStream_t stream);
 
+int level_bwd3_dispatch(const LevelBwdArgs<double>& a, int decoder, hipStream_t stream);         // level_bwd3.hip
+bool level_bwd3_fits(int N);
+
 static bool use_v1() {
   static const bool v = [] { const char* e = getenv("LGN_AMD_LEVEL_V1"); return e && e[0] == '1'; }();
   return v;
+}
+static bool use_v3(int N) {   // single-kernel backward (default when the jet fits in LDS); LGN_AMD_LEVEL_V2=1 forces the 3-kernel form
+  static const bool off = [] { const char* e = getenv("LGN_AMD_LEVEL_V2"); return e && e[0] == '1'; }();
+  return !off && !use_v1() && level_bwd3_fits(N);
 }
 
 int level_bwd_rad_jt(int N) { return N <= 64 ? ((N + 7) / 8) * 8 : 32; }
@@ -754,6 +761,11 @@ int level_bwd_rad_jt(int N) { return N <= 64 ? ((N + 7) / 8) * 8 : 32; }
 // number of partial rows the backward launch writes (host side must size the workspace with these)
 void level_bwd_partial_rows(int B, int N, int decoder, int* rows_mix, int* rows_rad) {
   const int tiles = cdiv(N, 32);
+  if (use_v3(N)) {                       // level_bwd3: one partial row per jet for both
+    *rows_mix = B;
+    *rows_rad = B;
+    return;
+  }
   *rows_mix = B * tiles;
   if (decoder) {
     *rows_rad = B * tiles;
@@ -770,6 +782,7 @@ static int launch_level_bwd(const LevelBwdArgs<T>& a, hipStream_t stream) {
   using L = Carve<C, DEC>;
   const int N = a.N, CO = a.CO, tiles = cdiv(N, 32);
   int rc;
+  if (use_v3(N)) return level_bwd3_dispatch(a, DEC, stream);
   {  // 1. CatMix / power
     auto kern = level_bwd_mix_kernel<T, C>;
     size_t smem = sizeof(T) * (4 * CO * 5 * C + 32 * (5 * C * 10) + 32 * CO * 10);

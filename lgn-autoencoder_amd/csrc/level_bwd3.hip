@@ -1,0 +1,562 @@
+// lgn-autoencoder_amd/csrc/level_bwd3.hip -- the whole backward of a fused maxdim=2 level in ONE kernel per jet
+// (N <= 40): CatMix/power backward, the j-centric pass (node gradients), and the radial-parameter pass share one
+// staging of the jet and ONE sweep over the particle pairs; the gradient of the aggregate never leaves LDS and the
+// node gradient is written once.  Same mathematics as level_bwd.hip / level_bwd2.hip (reference: autograd through
+// lgn/nn/position_levels.py:118-209, lgn/models/lgn_cg.py:167, lgn/cg_lib/cg_ops.py:135-298, lgn/nn/g_nn.py:260-278).
+//
+//   phase 1  thread = (node, channel): g_cat = W^H g_out -> g_ag (LDS), direct + power terms of the node gradient (LDS);
+//            thread = (out channel, cat slot): CatMix weight gradient over the jet's nodes -> partial row
+//   phase 2  wave = 4 source particles j, tiles of 4 receivers i, lane = (pair, channel in group), radial Linear on the
+//            matrix cores.  Per pair: (a) g_node_j += g_ag_i (x) conj(edge_ij); (b) encoder: dL/d rad of the pair ->
+//            16x16 LDS transposes -> T1|T2|S|dB GEMM on the matrix cores; decoder: bias sums and d p_j
+//   phase 3  decoder only: i-centric sweep for d p_i
+#include "level_dev.hpp"
+#include "ops.hpp"
+
+namespace lgn {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+namespace {
+__device__ __forceinline__ double dppq(double v, int xor2) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  if (xor2) {
+    lo = __builtin_amdgcn_mov_dpp(lo, 0x4E, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, 0x4E, 0xF, 0xF, true);
+  } else {
+    lo = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true);
+  }
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double quad_sum(double v) {
+  v += dppq(v, 0);
+  v += dppq(v, 1);
+  return v;
+}
+__device__ __forceinline__ double fast_rcp(double u) {
+  double r = __builtin_amdgcn_rcp(u);
+  double e = __builtin_fma(-u, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-u, r, 1.0);
+  return __builtin_fma(r, e, r);
+}
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+template <int C> struct GA3 {
+  static constexpr int A3 = 0, A4 = 2 * C, A1 = 4 * C, A2 = 12 * C, SIZE = 20 * C;
+};
+constexpr int TS = 18;
+}  // namespace
+
+template <int C, bool DEC>
+struct Bwd3 {
+  static constexpr int NG = (C + 3) / 4;
+  static constexpr int NS = node_stride(C);
+  static constexpr int PS = DEC ? 8 : 4;
+  static constexpr int TRSZ = DEC ? 4 * 64 : (4 * (NG + 3) * 16 * TS > 4 * 64 * NG * 12 ? 4 * (NG + 3) * 16 * TS : 4 * 64 * NG * 12);
+  // phase-1 scratch (upstream gradient tile + CatMix weights) and phase-2 scratch (transpose tiles) share one region
+  __host__ __device__ static size_t scratch(int N, int CO) {
+    const size_t p1 = (size_t)N * 10 * CO + 4 * CO * 5 * C;
+    return p1 > (size_t)TRSZ ? p1 : (size_t)TRSZ;
+  }
+  static size_t smem(int N, int CO) {
+    return sizeof(double) * ((((size_t)N * NS + 1) & ~size_t(1)) + (size_t)N * 20 * C + (size_t)N * 10 * C + (size_t)N * PS +
+                             scratch(N, CO)) + N + 16;
+  }
+};
+
+template <int C, bool DEC>
+__global__ __launch_bounds__(BLOCK) void level_bwd3_kernel(LevelBwdArgs<double> a) {
+  using F = Bwd3<C, DEC>;
+  using G = GA3<C>;
+  constexpr int NG = F::NG, NS = F::NS, PS = F::PS, K = 5 * C;
+  const int N = a.N, B = a.B, CO = a.CO;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  double* nd = reinterpret_cast<double*>(smem_raw);            // N * NS      node features entering the level
+  double* ga = nd + ((N * NS + 1) & ~1);                       // N * 20C     gradient of the aggregate
+  double* gd = ga + N * G::SIZE;                               // N * 10C     direct + power part of the node gradient [n][c][s2|v8]
+  double* pj = gd + N * 10 * C;                                // N * PS
+  double* tr = pj + N * PS;                                    // phase 2: transpose tiles / reduction scratch ...
+  double* go = tr;                                             // ... phase 1: N * 10CO upstream gradient [n][o][s2|v8]
+  double* wm = go + N * 10 * CO;                               //              4 * CO * K CatMix weights
+  uint8_t* mk = reinterpret_cast<uint8_t*>(tr + F::scratch(N, CO));
+
+  // ---------------- staging ----------------------------------------------------------------------------
+  load_jet<double, C, DEC>(a.s_in, a.v_in, a.p, a.mask, B, N, b, nd, pj, mk);
+  for (int e = tid; e < 2 * CO * K; e += BLOCK) {
+    wm[e] = a.wm0[e];
+    wm[2 * CO * K + e] = a.wm1[e];
+  }
+  {
+    const size_t plo = (size_t)B * N * CO;
+    for (int e = tid; e < N * CO; e += BLOCK) {
+      const size_t idx = (size_t)b * N * CO + e;
+      double* g = go + e * 10;
+      g[0] = a.g_s_out[idx];
+      g[1] = a.g_s_out[plo + idx];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        g[2 + m] = a.g_v_out[idx * 4 + m];
+        g[6 + m] = a.g_v_out[plo * 4 + idx * 4 + m];
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---------------- phase 1a: per (node, channel) CatMix^H, power backward ---------------------------------
+  for (int e = tid; e < N * C; e += BLOCK) {
+    const int n = e / C, c = e - n * C;
+    const double* ni = nd + n * NS + c * 10;
+    const cx<double> s = {ni[0], ni[1]};
+    cx<double> v[4], vt[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) v[m] = {ni[2 + m], ni[6 + m]};
+    metric_perm(v, vt);
+    cx<double> gx0[5], gx1[5][4];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+      const int k = q * C + c;
+      cx<double> acc0 = {0, 0}, acc1[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+      for (int o = 0; o < CO; ++o) {
+        const double* g = go + (n * CO + o) * 10;
+        const cx<double> w0 = {wm[(0 * CO + o) * K + k], wm[(1 * CO + o) * K + k]};
+        const cx<double> w1 = {wm[2 * CO * K + (0 * CO + o) * K + k], wm[2 * CO * K + (1 * CO + o) * K + k]};
+        cfmac(acc0, cx<double>{g[0], g[1]}, w0);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) cfmac(acc1[m], cx<double>{g[2 + m], g[6 + m]}, w1);
+      }
+      gx0[q] = acc0;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) gx1[q][m] = acc1[m];
+    }
+    double* gan = ga + n * G::SIZE;
+    gan[G::A3 + 2 * c] = gx0[0].r;  gan[G::A3 + 2 * c + 1] = gx0[0].i;
+    gan[G::A4 + 2 * c] = gx0[1].r;  gan[G::A4 + 2 * c + 1] = gx0[1].i;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      gan[G::A1 + (c * 4 + m) * 2] = gx1[0][m].r;  gan[G::A1 + (c * 4 + m) * 2 + 1] = gx1[0][m].i;
+      gan[G::A2 + (c * 4 + m) * 2] = gx1[1][m].r;  gan[G::A2 + (c * 4 + m) * 2 + 1] = gx1[1][m].i;
+    }
+    // node block + power blocks: sq(0,0) = [<v,v>, s^2], sq(1,1) = [v s, s v]
+    cx<double> gs = gx0[2];
+    cfmac(gs, cx<double>{2.0 * gx0[4].r, 2.0 * gx0[4].i}, s);
+    double* gdn = gd + (n * C + c) * 10;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const cx<double> gvs = {gx1[3][m].r + gx1[4][m].r, gx1[3][m].i + gx1[4][m].i};
+      cfmac(gs, gvs, v[m]);
+      cx<double> gv = gx1[2][m];
+      cfmac(gv, gvs, s);
+      cfmac(gv, gx0[3], vt[m]);
+      gdn[2 + m] = gv.r;
+      gdn[6 + m] = gv.i;
+    }
+    gdn[0] = gs.r;
+    gdn[1] = gs.i;
+  }
+  // ---------------- phase 1b: CatMix weight gradient over the jet's nodes -> this jet's partial row --------
+  {
+    double* part = a.part_mix + (size_t)b * (4 * CO * K);
+    const size_t pa = (size_t)B * N * 2 * C;
+    for (int e = tid; e < CO * K; e += BLOCK) {
+      const int o = e / K, k = e - o * K, q = k / C, c = k - q * C;
+      cx<double> d0 = {0, 0}, d1 = {0, 0};
+      for (int n = 0; n < N; ++n) {
+        const double* g = go + (n * CO + o) * 10;
+        const double* ni = nd + n * NS + c * 10;
+        const cx<double> s = {ni[0], ni[1]};
+        cx<double> v[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) v[m] = {ni[2 + m], ni[6 + m]};
+        cx<double> x0, x1[4];
+        if (q < 2) {                                  // aggregate blocks, saved by the forward
+          const size_t ea = ((size_t)b * N + n) * 2 * C + q * C + c;
+          x0 = {a.ag0[ea], a.ag0[pa + ea]};
+#pragma unroll
+          for (int m = 0; m < 4; ++m) x1[m] = {a.ag1[ea * 4 + m], a.ag1[(pa + ea) * 4 + m]};
+        } else if (q == 2) {                          // node block
+          x0 = s;
+#pragma unroll
+          for (int m = 0; m < 4; ++m) x1[m] = v[m];
+        } else {                                      // power blocks: (0,0): <v,v> | s^2 ; (1,1): v s | s v
+          if (q == 3) { x0 = bil2(v, v); x0.r *= 0.5; x0.i *= 0.5; } else x0 = cmul(s, s);
+#pragma unroll
+          for (int m = 0; m < 4; ++m) x1[m] = cmul(v[m], s);
+        }
+        cfmac(d0, cx<double>{g[0], g[1]}, x0);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) cfmac(d1, cx<double>{g[2 + m], g[6 + m]}, x1[m]);
+      }
+      part[(0 * CO + o) * K + k] = d0.r;
+      part[(1 * CO + o) * K + k] = d0.i;
+      part[2 * CO * K + (0 * CO + o) * K + k] = d1.r;
+      part[2 * CO * K + (1 * CO + o) * K + k] = d1.i;
+    }
+  }
+
+  // ---------------- per-lane constants of the pair sweep --------------------------------------------------------
+  const int pr = lane & 15, cg = lane >> 4;
+  const int tj = pr >> 2, ti = pr & 3;                  // which of the wave's 4 source particles j / slot in the i tile
+  double ak[5], bk[5], ck2[5], wf[NG][5], bias[NG][4];
+  if (!DEC) {
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+      const int k = 4 * s + cg;
+      ak[s] = a.ra[k];
+      bk[s] = a.rb[k];
+      const double c = a.rc[k];
+      ck2[s] = c * c;
+    }
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const int rr = lane & 15, q = rr >> 2, ch = 4 * g + (rr & 3);
+      const double* w = (q >> 1) ? a.w1 : a.w0;
+#pragma unroll
+      for (int s = 0; s < 5; ++s) wf[g][s] = ch < C ? w[(2 * ch + (q & 1)) * NB + 4 * s + cg] : 0.0;
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    const int ch = 4 * g + cg;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const double* bb = (q >> 1) ? a.b1 : a.b0;
+      bias[g][q] = ch < C ? (DEC ? bb[ch] : bb[2 * ch + (q & 1)]) : 0.0;
+    }
+  }
+  __syncthreads();                                      // g_ag / gd of the whole jet are in LDS; phase-1 scratch is dead
+
+  // ---------------- phase 2: one sweep over the ordered pairs (i, j), j-centric ------------------------------------
+  double* trw = tr + wave * (NG + 3) * 16 * TS;         // encoder: transpose tiles of this wave
+  v4d T[NG][3];
+  double dB0[NG], dB1[NG];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    dB0[g] = dB1[g] = 0.0;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) T[g][t] = v4d{0, 0, 0, 0};
+  }
+  const size_t pls = (size_t)B * N * C;
+  const int ngroups = (N + 3) >> 2;
+  for (int rg = wave; rg < ngroups; rg += 4) {
+    const int j = rg * 4 + tj;
+    const bool jok = j < N;
+    const int jj = jok ? j : N - 1;
+    double pme[PS];
+#pragma unroll
+    for (int m = 0; m < PS; ++m) pme[m] = pj[jj * PS + m];
+    const bool mj = DEC ? false : (mk[jj] != 0);
+    cx<double> Gs[NG], Gv[NG][4], Gq[4];
+    cx<double> sj[NG], vj[NG][4], vtj[NG][4];            // own (source) node features
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      Gs[g] = {0, 0};
+#pragma unroll
+      for (int m = 0; m < 4; ++m) Gv[g][m] = {0, 0};
+      const int ch = 4 * g + cg, cs = ch < C ? ch : 0;
+      const double* nj = nd + jj * NS + cs * 10;
+      sj[g] = {nj[0], nj[1]};
+#pragma unroll
+      for (int m = 0; m < 4; ++m) vj[g][m] = {nj[2 + m], nj[6 + m]};
+      metric_perm(vj[g], vtj[g]);
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) Gq[m] = {0, 0};
+
+    for (int i0 = 0; i0 < N; i0 += 4) {
+      const int i = i0 + ti;
+      const bool ok = jok && i < N;
+      const int ii = i < N ? i : N - 1;
+      const double* pii = pj + ii * PS;
+      cx<double> q[4];
+      v4d R[NG];
+      double rho[5], an = 0.0;
+      bool on = false;
+      if (DEC) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) q[m] = {pii[m] - pme[m], pii[4 + m] - pme[4 + m]};
+#pragma unroll
+        for (int g = 0; g < NG; ++g) R[g] = v4d{bias[g][0], bias[g][1], bias[g][2], bias[g][3]};
+      } else {
+        const double d0 = pii[0] - pme[0], d1 = pii[1] - pme[1], d2 = pii[2] - pme[2], d3 = pii[3] - pme[3];
+        const double q0 = d0 * d0, q1 = d1 * d1, q2 = d2 * d2, q3 = d3 * d3;
+        const double nsq = (2.0 * q0 - (((q0 + q1) + q2) + q3)) + 1e-16;
+        an = fabs(nsq);
+        on = ok && mj && (mk[ii] != 0) && (nsq != 0.0);
+        const double h = rsqrt2<double>();
+        q[0] = {d0, 0.0};
+        q[1] = {d1 * h, -d2 * h};
+        q[2] = {d3, 0.0};
+        q[3] = {-d1 * h, -d2 * h};
+        double beta[5];
+#pragma unroll
+        for (int s = 0; s < 5; ++s) {
+          const double r = fast_rcp((1.0 + ck2[s] * an) + 1e-16);
+          rho[s] = on ? r : 0.0;
+          beta[s] = on ? __builtin_fma(bk[s], r, ak[s]) : 0.0;
+        }
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          R[g] = v4d{bias[g][0], bias[g][1], bias[g][2], bias[g][3]};
+#pragma unroll
+          for (int s = 0; s < 5; ++s) R[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(wf[g][s], beta[s], R[g], 0, 0, 0);
+        }
+        // B-operand source of the radial GEMM: this lane's pair (row pr), columns k = 4s + cg
+        double* xb = trw + NG * 16 * TS;
+#pragma unroll
+        for (int s = 0; s < 5; ++s) {
+          const double x2 = an * rho[s] * rho[s];
+          if (s < 4) {
+            xb[pr * TS + 4 * s + cg] = rho[s];
+            xb[16 * TS + pr * TS + 4 * s + cg] = x2;
+          } else {
+            xb[32 * TS + pr * TS + cg] = rho[s];
+            xb[32 * TS + pr * TS + 4 + cg] = x2;
+          }
+        }
+        xb[32 * TS + pr * TS + 8 + 2 * cg] = cg == 0 ? (on ? 1.0 : 0.0) : 0.0;
+        xb[32 * TS + pr * TS + 9 + 2 * cg] = cg == 0 ? (ok ? 1.0 : 0.0) : 0.0;
+      }
+      const double* gi = ga + ii * G::SIZE;
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        const int ch = 4 * g + cg;
+        double G0r = 0, G0i = 0, G1r = 0, G1i = 0;
+        if (ok && ch < C) {
+          const cx<double> R0 = {R[g][0], R[g][1]}, R1 = {R[g][2], R[g][3]};
+          const cx<double> e0 = {R0.r - R0.i, R0.r + R0.i};
+          cx<double> e1[4], e1t[4];
+#pragma unroll
+          for (int m = 0; m < 4; ++m) e1[m] = cmul(R1, q[m]);
+          metric_perm(e1, e1t);
+          const cx<double> gA3 = {0.5 * gi[G::A3 + 2 * ch], 0.5 * gi[G::A3 + 2 * ch + 1]};
+          const cx<double> gA4 = {gi[G::A4 + 2 * ch], gi[G::A4 + 2 * ch + 1]};
+          cfmac(Gs[g], gA4, e0);
+          cx<double> ge0 = cmulc(gA4, sj[g]);
+          cx<double> gR1 = {0, 0};
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            const cx<double> gA1 = {gi[G::A1 + (ch * 4 + m) * 2], gi[G::A1 + (ch * 4 + m) * 2 + 1]};
+            const cx<double> gA2 = {gi[G::A2 + (ch * 4 + m) * 2], gi[G::A2 + (ch * 4 + m) * 2 + 1]};
+            // (a) gradient w.r.t. the source node j
+            cfmac(Gv[g][m], gA1, e0);
+            cfmac(Gv[g][m], gA3, e1t[m]);
+            cfmac(Gs[g], gA2, e1[m]);
+            // (b) gradient w.r.t. the edge of this pair
+            cfmac(ge0, gA1, vj[g][m]);
+            cx<double> ge1 = cmulc(gA2, sj[g]);
+            cfmac(ge1, gA3, vtj[g][m]);
+            cfmac(gR1, ge1, q[m]);
+            if (DEC) cfmac(Gq[m], ge1, R1);
+          }
+          G0r = ge0.r + ge0.i;  G0i = ge0.i - ge0.r;        // e0 = R0 (1+i)  ->  G_R0 = G_e0 (1-i)
+          G1r = gR1.r;  G1i = gR1.i;
+        }
+        if (DEC) {
+          dB0[g] += G0r + G0i;                              // R0 = b0 (1+i): d b0 = Re G_R0 + Im G_R0
+          dB1[g] += G1r + G1i;
+        } else {
+          double* ta = trw + g * 16 * TS;                   // [pair][r' = cg + 4q]
+          ta[pr * TS + cg] = G0r;
+          ta[pr * TS + 4 + cg] = G0i;
+          ta[pr * TS + 8 + cg] = G1r;
+          ta[pr * TS + 12 + cg] = G1i;
+        }
+      }
+      if (!DEC) {
+        wave_sync();
+        const double* xb = trw + NG * 16 * TS;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const int prow = 4 * s + cg;
+          double bv[3];
+#pragma unroll
+          for (int t = 0; t < 3; ++t) bv[t] = xb[t * 16 * TS + prow * TS + pr];
+#pragma unroll
+          for (int g = 0; g < NG; ++g) {
+            const double av = trw[g * 16 * TS + prow * TS + pr];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) T[g][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[t], T[g][t], 0, 0, 0);
+          }
+        }
+        wave_sync();
+      }
+    }
+
+    // node gradient of the wave's 4 particles: neighbour part (quad sum over the i slots) + direct part, written once
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const int ch = 4 * g + cg;
+      const double sr = quad_sum(Gs[g].r), si = quad_sum(Gs[g].i);
+      const bool wr = jok && ti == 0 && ch < C;
+      const size_t e = ((size_t)b * N + jj) * C + (ch < C ? ch : 0);
+      const double* gdn = gd + (jj * C + (ch < C ? ch : 0)) * 10;
+      if (wr) {
+        a.g_s_in[e] = gdn[0] + sr;
+        a.g_s_in[pls + e] = gdn[1] + si;
+      }
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const double vr = quad_sum(Gv[g][m].r), vi = quad_sum(Gv[g][m].i);
+        if (wr) {
+          a.g_v_in[e * 4 + m] = gdn[2 + m] + vr;
+          a.g_v_in[pls * 4 + e * 4 + m] = gdn[6 + m] + vi;
+        }
+      }
+    }
+    if (DEC) {
+      const size_t plp = (size_t)B * N * 4;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        double qr = quad_sum(Gq[m].r), qi = quad_sum(Gq[m].i);
+        qr += shfl_xor(qr, 16);  qr += shfl_xor(qr, 32);
+        qi += shfl_xor(qi, 16);  qi += shfl_xor(qi, 32);
+        if (jok && ti == 0 && cg == 0) {
+          a.g_p[((size_t)b * N + jj) * 4 + m] -= qr;
+          a.g_p[plp + ((size_t)b * N + jj) * 4 + m] -= qi;
+        }
+      }
+    }
+  }
+
+  // ---------------- phase 3 (decoder): i-centric sweep for d p_i = sum_j G_q(i, j) ---------------------------------
+  if (DEC) {
+    const int ti2 = pr >> 2, tj2 = pr & 3;
+    const size_t plp = (size_t)B * N * 4;
+    for (int rg = wave; rg < ngroups; rg += 4) {
+      const int i = rg * 4 + ti2;
+      const bool iok = i < N;
+      const int ii = iok ? i : N - 1;
+      const double* gi = ga + ii * G::SIZE;
+      cx<double> Gq[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+      for (int j0 = 0; j0 < N; j0 += 4) {
+        const int j = j0 + tj2;
+        if (iok && j < N) {
+#pragma unroll
+          for (int g = 0; g < NG; ++g) {
+            const int ch = 4 * g + cg;
+            if (ch < C) {
+              const double* nj = nd + j * NS + ch * 10;
+              const cx<double> s = {nj[0], nj[1]};
+              cx<double> v[4], vt[4];
+#pragma unroll
+              for (int m = 0; m < 4; ++m) v[m] = {nj[2 + m], nj[6 + m]};
+              metric_perm(v, vt);
+              const cx<double> R1 = {bias[g][2], bias[g][3]};
+              const cx<double> gA3 = {0.5 * gi[G::A3 + 2 * ch], 0.5 * gi[G::A3 + 2 * ch + 1]};
+#pragma unroll
+              for (int m = 0; m < 4; ++m) {
+                const cx<double> gA2 = {gi[G::A2 + (ch * 4 + m) * 2], gi[G::A2 + (ch * 4 + m) * 2 + 1]};
+                cx<double> ge1 = cmulc(gA2, s);
+                cfmac(ge1, gA3, vt[m]);
+                cfmac(Gq[m], ge1, R1);
+              }
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        double qr = quad_sum(Gq[m].r), qi = quad_sum(Gq[m].i);
+        qr += shfl_xor(qr, 16);  qr += shfl_xor(qr, 32);
+        qi += shfl_xor(qi, 16);  qi += shfl_xor(qi, 32);
+        if (iok && tj2 == 0 && cg == 0) {
+          a.g_p[((size_t)b * N + i) * 4 + m] += qr;
+          a.g_p[plp + ((size_t)b * N + i) * 4 + m] += qi;
+        }
+      }
+    }
+  }
+
+  // ---------------- radial partial row of this jet ------------------------------------------------------------
+  __syncthreads();
+  double* part = a.part_rad + (size_t)blockIdx.x * rad_partial_size(C, DEC);
+  if (DEC) {
+    double* red = tr;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      double x0 = dB0[g], x1 = dB1[g];
+      for (int m = 1; m < 16; m <<= 1) { x0 += shfl_xor(x0, m); x1 += shfl_xor(x1, m); }
+      if (pr == 0) {
+        red[(wave * NG + g) * 8 + cg] = x0;
+        red[(wave * NG + g) * 8 + 4 + cg] = x1;
+      }
+    }
+    __syncthreads();
+    if (tid < 2 * C) {
+      const int lin = tid / C, ch = tid - lin * C, g = ch >> 2, c4 = ch & 3;
+      double s = 0;
+      for (int w = 0; w < 4; ++w) s += red[(w * NG + g) * 8 + lin * 4 + c4];
+      part[tid] = s;
+    }
+  } else {
+    double* red = tr;
+    {
+      double* mine = red + (size_t)(wave * 64 + lane) * NG * 12;
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) mine[(g * 3 + t) * 4 + q] = T[g][t][q];
+    }
+    __syncthreads();
+    if (wave == 0) {
+      constexpr int R = 4 * C;
+      const int col = lane & 15;
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        const int ch = 4 * g + cg;
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int e = (g * 3 + t) * 4 + q;
+            const double v = (red[(size_t)(0 * 64 + lane) * NG * 12 + e] + red[(size_t)(1 * 64 + lane) * NG * 12 + e]) +
+                             (red[(size_t)(2 * 64 + lane) * NG * 12 + e] + red[(size_t)(3 * 64 + lane) * NG * 12 + e]);
+            if (ch >= C) continue;
+            const int r = (q >> 1) * 2 * C + 2 * ch + (q & 1);
+            if (t == 0) part[r * NB + col] = v;
+            else if (t == 1) part[R * NB + r * NB + col] = v;
+            else {
+              if (col < 4) part[r * NB + 16 + col] = v;
+              else if (col < 8) part[R * NB + r * NB + 16 + (col - 4)] = v;
+              else if (col == 8) part[2 * R * NB + r] = v;
+              else if (col == 9) part[2 * R * NB + R + r] = v;
+            }
+          }
+      }
+    }
+  }
+}
+
+bool level_bwd3_fits(int N) { return N <= 40; }
+
+template <int C, bool DEC>
+static int launch_bwd3(const LevelBwdArgs<double>& a, hipStream_t stream) {
+  const size_t smem = Bwd3<C, DEC>::smem(a.N, a.CO);
+  LGN_CHECK_ARG(smem <= 160 * 1024, "level_bwd: N=%d C=%d needs %zu B of LDS", a.N, a.C, smem);
+  auto kern = level_bwd3_kernel<C, DEC>;
+  if (smem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipLaunchKernelGGL(kern, dim3(a.B), dim3(BLOCK), smem, stream, a);
+  LGN_CHECK_LAUNCH();
+  return 0;
+}
+
+// whole level backward in one launch; one CatMix partial row and one radial partial row per jet
+int level_bwd3_dispatch(const LevelBwdArgs<double>& a, int decoder, hipStream_t stream) {
+#define LGN_CASE(CC) case CC: return decoder ? launch_bwd3<CC, true>(a, stream) : launch_bwd3<CC, false>(a, stream);
+  switch (a.C) {
+    LGN_CASE(1) LGN_CASE(2) LGN_CASE(3) LGN_CASE(4) LGN_CASE(5) LGN_CASE(6) LGN_CASE(7) LGN_CASE(8)
+    default: set_error("level_bwd: C_in=%d unsupported (1..8)", a.C); return -1;
+  }
+#undef LGN_CASE
+}
+
+}  // namespace lgn
