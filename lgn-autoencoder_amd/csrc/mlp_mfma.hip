@@ -85,34 +85,40 @@ __device__ __forceinline__ void load_bias(const double* Wl, int lane, double (&b
   for (int t = 0; t < NT; ++t) bv[t] = Wl[(16 * t + c) * Geo<NT>::S + Geo<NT>::HP];     // zero for padded neurons
 }
 
-// NU = number of live N-tiles (compile time: a run-time guard around the MFMA makes hipcc shuttle the accumulators
-// between AGPRs and VGPRs and serialise on every MFMA's latency)
-template <int NT, int NU>
+// NU = number of live N-tiles, KS = number of k-steps (both compile time: a run-time guard around the MFMA makes hipcc
+// shuttle the accumulators between register classes, and a fully unrolled k-loop lets it schedule the LDS operand
+// reads of later steps under the MFMAs of earlier ones without loop-carried copies).  KS == 0: run-time k-loop.
+template <int NT, int NU, int KS>
 __device__ __forceinline__ void dense_tile(const double* Xt, const double* Wl, const double (&bv)[NT], int Hin,
                                            int lane, v4d (&acc)[NT]) {
   constexpr int S = Geo<NT>::S;
   const int c = lane & 15, g = lane >> 4;
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = v4d{bv[t], bv[t], bv[t], bv[t]};
-  const int ks = pad4(Hin) >> 2;
   const double* xa = Xt + c * S + g;
   const double* wb = Wl + c * S + g;
-  // software pipelined over k-steps: operands of step s+1 are read while the MFMAs of step s run
-  double a = xa[0], b[NU];
+  if (KS > 0) {
 #pragma unroll
-  for (int t = 0; t < NU; ++t) b[t] = wb[16 * t * S];
-  for (int s = 0; s < ks; ++s) {
-    const int sn = s + 1 < ks ? s + 1 : s;
-    const double an = xa[4 * sn];
-    double bn[NU];
+    for (int s = 0; s < KS; ++s) {
+      const double a = xa[4 * s];
 #pragma unroll
-    for (int t = 0; t < NU; ++t) bn[t] = wb[16 * t * S + 4 * sn];
+      for (int t = 0; t < NU; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, wb[16 * t * S + 4 * s], acc[t], 0, 0, 0);
+    }
+  } else {
+    const int ks = pad4(Hin) >> 2;
+    for (int s = 0; s < ks; ++s) {
+      const double a = xa[4 * s];
 #pragma unroll
-    for (int t = 0; t < NU; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[t], acc[t], 0, 0, 0);
-    a = an;
-#pragma unroll
-    for (int t = 0; t < NU; ++t) b[t] = bn[t];
+      for (int t = 0; t < NU; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, wb[16 * t * S + 4 * s], acc[t], 0, 0, 0);
+    }
   }
+}
+// layer-kind dispatch of the k-step count: first layer K = 2C <= 16 (run time), hidden layers K = H = 4*KSH
+template <int NT, int NU, int KSH>
+__device__ __forceinline__ void dense_hidden(const double* Xt, const double* Wl, const double (&bv)[NT], int Hin, int lane,
+                                             v4d (&acc)[NT], bool first) {
+  if (first) dense_tile<NT, NU, 0>(Xt, Wl, bv, Hin, lane, acc);
+  else dense_tile<NT, NU, KSH>(Xt, Wl, bv, Hin, lane, acc);
 }
 
 // g_in (D layout) += g_pre W for this wave's rows; NU live input tiles
@@ -151,7 +157,7 @@ __device__ __forceinline__ void load_input_tile(const double* __restrict__ s, in
   }
 }
 
-template <int NT, int NH>
+template <int NT, int NH, int KSH>
 __global__ __launch_bounds__(BLOCK) void mlp_fwd_mfma_kernel(MlpArgs<double> a) {
   using G = Geo<NT>;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -174,8 +180,8 @@ __global__ __launch_bounds__(BLOCK) void mlp_fwd_mfma_kernel(MlpArgs<double> a) 
     load_bias<NT>(Wcur, lane, bv);
     if (l < NH) prefetch_layer<NT>(a, l + 1, NH, D, H, regs, breg);
     v4d acc[NT];
-    if (l < NH) dense_tile<NT, NT>(Xt, Wcur, bv, Hin, lane, acc);
-    else dense_tile<NT, 1>(Xt, Wcur, bv, Hin, lane, acc);
+    if (l < NH) dense_hidden<NT, NT, KSH>(Xt, Wcur, bv, Hin, lane, acc, l == 0);
+    else dense_tile<NT, 1, KSH>(Xt, Wcur, bv, Hin, lane, acc);
     if (l < NH) {
 #pragma unroll
       for (int t = 0; t < NT; ++t)
@@ -195,7 +201,7 @@ __global__ __launch_bounds__(BLOCK) void mlp_fwd_mfma_kernel(MlpArgs<double> a) 
   }
 }
 
-template <int NT, int NH>
+template <int NT, int NH, int KSH>
 __global__ __launch_bounds__(BLOCK) void mlp_bwd_mfma_kernel(MlpArgs<double> a) {
   using G = Geo<NT>;
   constexpr int S = G::S;
@@ -230,7 +236,7 @@ __global__ __launch_bounds__(BLOCK) void mlp_bwd_mfma_kernel(MlpArgs<double> a) 
     double bv[NT];
     load_bias<NT>(Wcur, lane, bv);
     prefetch_layer<NT>(a, l + 1, NH, D, H, regs, breg);
-    dense_tile<NT, NT>(Xt, Wcur, bv, Hin, lane, h[l]);
+    dense_hidden<NT, NT, KSH>(Xt, Wcur, bv, Hin, lane, h[l], l == 0);
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -323,19 +329,19 @@ __global__ __launch_bounds__(BLOCK) void mlp_bwd_mfma_kernel(MlpArgs<double> a) 
   }
 }
 
-template <int NT>
+template <int NT, int KSH>
 static int launch_mlp_mfma(const MlpArgs<double>& a, bool backward, hipStream_t stream) {
   using G = Geo<NT>;
   constexpr int NH = 6;
   const int nblk = cdiv(a.M, 64);
   if (!backward) {
     size_t smem = sizeof(double) * (2 * G::WSIZE + 4 * G::TSIZE);
-    auto kern = mlp_fwd_mfma_kernel<NT, NH>;
+    auto kern = mlp_fwd_mfma_kernel<NT, NH, KSH>;
     if (smem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     hipLaunchKernelGGL(kern, dim3(nblk), dim3(BLOCK), smem, stream, a);
   } else {
     size_t smem = sizeof(double) * (2 * G::WSIZE + 8 * G::TSIZE + 4 * 16 * G::S + 4 * G::HP);
-    auto kern = mlp_bwd_mfma_kernel<NT, NH>;
+    auto kern = mlp_bwd_mfma_kernel<NT, NH, KSH>;
     if (smem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     hipLaunchKernelGGL(kern, dim3(nblk), dim3(BLOCK), smem, stream, a);
   }
@@ -347,9 +353,14 @@ static int launch_mlp_mfma(const MlpArgs<double>& a, bool backward, hipStream_t 
 int mlp_mfma_dispatch(const MlpArgs<double>& a, bool backward, hipStream_t stream) {
   if (a.nlin != 7 || a.H > 48 || 2 * a.C > 16 || a.H < 2 * a.C) return -2;
   const int nt = (a.H + 15) / 16;
-  if (nt == 1) return launch_mlp_mfma<1>(a, backward, stream);
-  if (nt == 2) return launch_mlp_mfma<2>(a, backward, stream);
-  return launch_mlp_mfma<3>(a, backward, stream);
+  // fully unrolled k-loops for the widths of the reference configs (H = 6 * 2C); anything else keeps the run-time loop
+  if (a.H == 48) return launch_mlp_mfma<3, 12>(a, backward, stream);
+  if (a.H == 36) return launch_mlp_mfma<3, 9>(a, backward, stream);
+  if (a.H == 24) return launch_mlp_mfma<2, 6>(a, backward, stream);
+  if (a.H == 12) return launch_mlp_mfma<1, 3>(a, backward, stream);
+  if (nt == 1) return launch_mlp_mfma<1, 0>(a, backward, stream);
+  if (nt == 2) return launch_mlp_mfma<2, 0>(a, backward, stream);
+  return launch_mlp_mfma<3, 0>(a, backward, stream);
 }
 
 }  // namespace lgn
