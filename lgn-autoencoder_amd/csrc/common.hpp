@@ -77,7 +77,7 @@ __device__ __forceinline__ T group_sum(T v) {
 
 template <typename T>
 __device__ __forceinline__ T leaky(T x) {
-  return x > T(0) ? x : T(0.01) * x;   // nn.LeakyReLU default slope (generic_levels.py:121-122)
+  return fmax(x, T(0.01) * x);         // == x > 0 ? x : 0.01 x; nn.LeakyReLU default slope (generic_levels.py:121-122)
 }
 
 // 1/sqrt(2) used by the Cartesian <-> canonical change of basis (zonal_functions.py:266-283)

@@ -5,18 +5,24 @@
 // [rows x Hin] x [Hin x Hout] GEMM executed with v_mfma_f64_16x16x4_f64 (D(16x16) += A(16x4) B(4x16)):
 //   A: lane l holds A[i = l&15][k = l>>4]      B: lane l holds B[k = l>>4][j = l&15]
 //   D: lane l, register r holds D[i = (l>>4) + 4r][j = l&15]          (probed: csrc/probes/mfma_probe.hip)
-// A workgroup owns 64 rows; each of its 4 waves owns a 16-row M-tile and all N-tiles of the layer.
-// Activations stay wave-private: D fragments are written to a padded [row][neuron] LDS tile and read back
-// as A fragments of the next layer (row stride == 2 mod 4 scalars -> conflict-free ds_read_b64).
-// Layer weights are staged row-major [out][in] in LDS (same padded stride), double buffered, the next
-// layer's weights prefetched into registers while the current layer's MFMAs run.
 //
-// Backward (recompute, hidden activations kept in registers in D layout):
+// Work split: a workgroup owns 64 rows = 4 M-tiles of 16 rows and runs 4 * NT waves (NT = ceil(H/16) N-tiles);
+// wave (mt, nt) owns ONE 16x16 output tile of every layer.  B*N rows give only ~one M-tile per SIMD of the
+// chip, so splitting N over waves is what puts several waves on a SIMD: a layer is 12 dependent MFMAs per wave,
+// and the other waves' MFMAs fill the gaps left by its LDS reads, LeakyReLU and stores.  It also keeps the
+// backward's register footprint small (one tile of each hidden activation instead of NT).
+//
+// LDS: activations as padded [row][neuron] tiles per M-tile (row stride == 2 mod 4 scalars -> conflict-free
+// ds_read_b64 of A fragments), ping-ponged between layers so that one barrier per layer suffices; layer weights
+// row-major [out][in] with the same stride (bias in column HP), double buffered, the next layer's weights
+// prefetched into registers while the current layer's MFMAs run.
+//
+// Backward (recompute; the hidden activations of the wave's own tile stay in registers in D layout):
 //   g_in  = g_pre W        A = g_pre tile,            B = W[o][k] read "transposed" from the same LDS image
-//   dW    = g_pre^T h_in   A = g_pre tile^T, B = h_in tile, K = the workgroup's 64 rows; the (o,k) output tiles
-//                          are dealt round-robin to the 4 waves, which store them into this workgroup's
-//                          partial row (reduced deterministically by reduce_partials afterwards)
-//   db    = column sums of g_pre (two wave shuffles + a 4-wave LDS reduction)
+//   dW    = g_pre^T h_in   A = g_pre tile^T, B = h_in tile, K = the workgroup's 64 rows; output tile (o-tile, k-tile)
+//                          number w is computed by wave w and stored into this workgroup's partial row
+//                          (reduced deterministically by reduce_partials afterwards)
+//   db    = column sums of g_pre (two wave shuffles + a sum over the 4 M-tiles through LDS)
 #include "ops.hpp"
 
 namespace lgn {
@@ -24,7 +30,6 @@ namespace lgn {
 typedef double v4d __attribute__((ext_vector_type(4)));
 
 __host__ __device__ constexpr int pad4(int x) { return (x + 3) & ~3; }
-__host__ __device__ constexpr int pad16(int x) { return (x + 15) & ~15; }
 // smallest stride >= x with stride == 2 (mod 4): 16 rows x 2 k's of a ds_read_b64 group hit 32 distinct bank pairs
 __host__ __device__ constexpr int lds_stride(int x) { return x + ((6 - (x & 3)) & 3); }
 
@@ -32,298 +37,273 @@ template <int NT>
 struct Geo {
   static constexpr int HP = NT * 16;                  // padded hidden width
   static constexpr int S = lds_stride(HP);            // row stride of weight image and activation tiles
-  static constexpr int NPF = (HP * HP + BLOCK - 1) / BLOCK;   // prefetch registers per thread
+  static constexpr int S0 = 18;                       // row stride of the 16-column MLP input tiles
   static constexpr int WSIZE = HP * S;                // one weight image
   static constexpr int TSIZE = 16 * S;                // one 16-row activation tile
+  static constexpr int T0SIZE = 16 * S0;              // one 16-row input tile
+  static constexpr int THREADS = 256 * NT;            // 4 M-tiles x NT N-tiles waves
+  static constexpr size_t fwd_doubles() { return 2 * WSIZE + 8 * TSIZE + 4 * T0SIZE; }
+  static constexpr size_t bwd_doubles() { return 2 * WSIZE + 16 * TSIZE + 4 * T0SIZE + 8 * HP; }
 };
 
 // ---- weight staging ------------------------------------------------------------------------------
-// Image of one Linear layer in LDS: W[o][k] at Wl[o*S + k] (zero padded to 16-multiples both ways, k padding feeds
-// the MFMAs zeros) and its bias at Wl[o*S + HP] (S >= HP + 2).  KP = padded input width, a compile-time constant
-// so that the element -> (o,k) split costs a multiply-shift, not an integer division.
-template <int NT, int KP>
-__device__ __forceinline__ void prefetch_weights(const double* __restrict__ W, const double* __restrict__ bias, int Hout,
-                                                 int Hin, double (&regs)[Geo<NT>::NPF], double& breg) {
-  const int HoP = pad16(Hout);
+// Image of one Linear layer in LDS: W[o][k] at Wl[o*S + k] (zero padded to 16-multiples both ways; the k padding
+// feeds the MFMAs zeros, padded neurons produce exact zeros) and its bias at Wl[o*S + HP] (S >= HP + 2).
+// Hidden / output layers (HP input columns): thread tid stages column k = tid % HP of rows tid / HP + 16 i, so every
+// address is a thread-constant base plus a compile-time (LDS) or wave-uniform (global) multiple of i.
+template <int NT>
+__device__ __forceinline__ void prefetch_hidden(const double* __restrict__ W, const double* __restrict__ bias, int Hout,
+                                                int Hin, double (&regs)[NT], double& breg) {
+  constexpr int HP = Geo<NT>::HP;
+  const int o0 = (int)threadIdx.x / HP, k = (int)threadIdx.x - o0 * HP;
+  const double* src = W + (o0 * Hin + k);
 #pragma unroll
-  for (int i = 0; i < Geo<NT>::NPF; ++i) {
-    const int e = threadIdx.x + BLOCK * i;
-    const int o = e / KP, k = e - o * KP;
-    regs[i] = (e < HoP * KP && o < Hout && k < Hin) ? W[(size_t)o * Hin + k] : 0.0;
-  }
+  for (int i = 0; i < NT; ++i) regs[i] = (k < Hin && o0 + 16 * i < Hout) ? src[16 * i * Hin] : 0.0;
   breg = ((int)threadIdx.x < Hout) ? bias[threadIdx.x] : 0.0;
 }
-template <int NT, int KP>
-__device__ __forceinline__ void commit_weights(double* Wl, int Hout, const double (&regs)[Geo<NT>::NPF], double breg) {
-  const int HoP = pad16(Hout);
+template <int NT>
+__device__ __forceinline__ void commit_hidden(double* Wl, const double (&regs)[NT], double breg) {
+  constexpr int HP = Geo<NT>::HP, S = Geo<NT>::S;
+  const int o0 = (int)threadIdx.x / HP, k = (int)threadIdx.x - o0 * HP;
+  double* dst = Wl + (o0 * S + k);
 #pragma unroll
-  for (int i = 0; i < Geo<NT>::NPF; ++i) {
-    const int e = threadIdx.x + BLOCK * i;
-    const int o = e / KP, k = e - o * KP;
-    if (e < HoP * KP) Wl[o * Geo<NT>::S + k] = regs[i];
+  for (int i = 0; i < NT; ++i) dst[16 * i * S] = regs[i];
+  if ((int)threadIdx.x < HP) Wl[threadIdx.x * S + HP] = breg;
+}
+// First layer (2C <= 16 input columns): one element per thread, o = tid / 16 < HP.
+template <int NT>
+__device__ __forceinline__ void prefetch_first(const double* __restrict__ W, const double* __restrict__ bias, int Hout,
+                                               int Hin, double& reg, double& breg) {
+  const int o = (int)threadIdx.x >> 4, k = (int)threadIdx.x & 15;
+  reg = (o < Hout && k < Hin) ? W[o * Hin + k] : 0.0;
+  breg = ((int)threadIdx.x < Hout) ? bias[threadIdx.x] : 0.0;
+}
+template <int NT>
+__device__ __forceinline__ void commit_first(double* Wl, double reg, double breg) {
+  constexpr int HP = Geo<NT>::HP, S = Geo<NT>::S;
+  Wl[((int)threadIdx.x >> 4) * S + ((int)threadIdx.x & 15)] = reg;
+  if ((int)threadIdx.x < HP) Wl[threadIdx.x * S + HP] = breg;
+}
+
+// rows of the scalar irrep [2][M][C] -> the workgroup's 4 input tiles, feature k = 2c + z, zero padded to 16 columns
+template <int NT>
+__device__ __forceinline__ void load_input_tiles(const double* __restrict__ s, int M, int C, int wg_row0, double* X0) {
+  const int D = 2 * C;
+  for (int e = threadIdx.x; e < 64 * 16; e += Geo<NT>::THREADS) {
+    const int r = e >> 4, k = e & 15, row = wg_row0 + r;
+    X0[(r >> 4) * Geo<NT>::T0SIZE + (r & 15) * Geo<NT>::S0 + k] =
+        (row < M && k < D) ? s[(size_t)(k & 1) * M * C + (size_t)row * C + (k >> 1)] : 0.0;
   }
-  if ((int)threadIdx.x < Geo<NT>::HP) Wl[threadIdx.x * Geo<NT>::S + Geo<NT>::HP] = breg;
-}
-// layer-kind dispatch: the first Linear has a 16-wide (padded 2C) input, all others a HP-wide one
-template <int NT>
-__device__ __forceinline__ void prefetch_layer(const MlpArgs<double>& a, int l, int NH, int D, int H, double (&regs)[Geo<NT>::NPF],
-                                               double& breg) {
-  if (l == 0) prefetch_weights<NT, 16>(a.w[0], a.b[0], H, D, regs, breg);
-  else prefetch_weights<NT, Geo<NT>::HP>(a.w[l], a.b[l], l == NH ? D : H, H, regs, breg);
-}
-template <int NT>
-__device__ __forceinline__ void commit_layer(double* Wl, int l, int NH, int D, int H, const double (&regs)[Geo<NT>::NPF], double breg) {
-  if (l == 0) commit_weights<NT, 16>(Wl, H, regs, breg);
-  else commit_weights<NT, Geo<NT>::HP>(Wl, l == NH ? D : H, regs, breg);
 }
 
-// ---- one dense layer on a wave's 16-row tile:  acc[t] (D layout) = bias + X W^T ---------------------
-template <int NT>
-__device__ __forceinline__ void load_bias(const double* Wl, int lane, double (&bv)[NT]) {
-  const int c = lane & 15;
-#pragma unroll
-  for (int t = 0; t < NT; ++t) bv[t] = Wl[(16 * t + c) * Geo<NT>::S + Geo<NT>::HP];     // zero for padded neurons
-}
-
-// NU = number of live N-tiles, KS = number of k-steps (both compile time: a run-time guard around the MFMA makes hipcc
-// shuttle the accumulators between register classes, and a fully unrolled k-loop lets it schedule the LDS operand
-// reads of later steps under the MFMAs of earlier ones without loop-carried copies).  KS == 0: run-time k-loop.
-template <int NT, int NU, int KS>
-__device__ __forceinline__ void dense_tile(const double* Xt, const double* Wl, const double (&bv)[NT], int Hin,
-                                           int lane, v4d (&acc)[NT]) {
-  constexpr int S = Geo<NT>::S;
-  const int c = lane & 15, g = lane >> 4;
-#pragma unroll
-  for (int t = 0; t < NT; ++t) acc[t] = v4d{bv[t], bv[t], bv[t], bv[t]};
-  const double* xa = Xt + c * S + g;
-  const double* wb = Wl + c * S + g;
+// acc (D layout) += X[16 x 4KS] W^T for one output tile.  xa -> A fragment base (row c, column g), wb -> B fragment base
+// (W row 16 nt + c, column g); KS compile-time k-steps, or the run-time count ks when KS == 0.
+template <int KS>
+__device__ __forceinline__ void mma_rowmajor(const double* xa, const double* wb, int ks, v4d& acc) {
   if (KS > 0) {
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const double a = xa[4 * s];
-#pragma unroll
-      for (int t = 0; t < NU; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, wb[16 * t * S + 4 * s], acc[t], 0, 0, 0);
-    }
+    for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[4 * s], wb[4 * s], acc, 0, 0, 0);
   } else {
-    const int ks = pad4(Hin) >> 2;
-    for (int s = 0; s < ks; ++s) {
-      const double a = xa[4 * s];
-#pragma unroll
-      for (int t = 0; t < NU; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, wb[16 * t * S + 4 * s], acc[t], 0, 0, 0);
-    }
+    for (int s = 0; s < ks; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[4 * s], wb[4 * s], acc, 0, 0, 0);
   }
 }
-// layer-kind dispatch of the k-step count: first layer K = 2C <= 16 (run time), hidden layers K = H = 4*KSH
-template <int NT, int NU, int KSH>
-__device__ __forceinline__ void dense_hidden(const double* Xt, const double* Wl, const double (&bv)[NT], int Hin, int lane,
-                                             v4d (&acc)[NT], bool first) {
-  if (first) dense_tile<NT, NU, 0>(Xt, Wl, bv, Hin, lane, acc);
-  else dense_tile<NT, NU, KSH>(Xt, Wl, bv, Hin, lane, acc);
-}
-
-// g_in (D layout) += g_pre W for this wave's rows; NU live input tiles
-template <int NT, int NU>
-__device__ __forceinline__ void gin_tile(const double* Gt, const double* Wcur, int Hout, int lane, v4d (&gin)[NT]) {
-  constexpr int S = Geo<NT>::S;
-  const int c = lane & 15, g = lane >> 4;
-  const int ks = pad4(Hout) >> 2;
-  for (int s = 0; s < ks; ++s) {
-    const double av = Gt[c * S + 4 * s + g];
+// acc += G[16 x 4KS] W for one input tile: ga -> A fragment base of the g_pre tile, wb -> W image at (row g, column 16u + c)
+template <int KS, int S>
+__device__ __forceinline__ void mma_transposed(const double* ga, const double* wb, int ks, v4d& acc) {
+  if (KS > 0) {
 #pragma unroll
-    for (int u = 0; u < NU; ++u)
-      gin[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Wcur[(4 * s + g) * S + 16 * u + c], gin[u], 0, 0, 0);
+    for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ga[4 * s], wb[4 * s * S], acc, 0, 0, 0);
+  } else {
+    for (int s = 0; s < ks; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ga[4 * s], wb[4 * s * S], acc, 0, 0, 0);
   }
 }
 
-// D-layout registers -> [row][neuron] tile (all NT tiles; padded neurons carry exact zeros)
-template <int NT>
-__device__ __forceinline__ void store_tile(double* Xt, const v4d (&v)[NT], int lane) {
-  constexpr int S = Geo<NT>::S;
-  const int c = lane & 15, g = lane >> 4;
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) Xt[(g + 4 * r) * S + 16 * t + c] = v[t][r];
-}
-
-// rows of the scalar irrep [2][M][C] -> wave tile, feature k = 2c + z, zero padded to 16 columns
-template <int NT>
-__device__ __forceinline__ void load_input_tile(const double* __restrict__ s, int M, int C, int row0, double* Xt, int lane) {
-  constexpr int S = Geo<NT>::S;
-  const int D = 2 * C;
-  for (int e = lane; e < 16 * 16; e += 64) {
-    const int r = e >> 4, k = e & 15, row = row0 + r;
-    Xt[r * S + k] = (row < M && k < D) ? s[(size_t)(k & 1) * M * C + (size_t)row * C + (k >> 1)] : 0.0;
-  }
-}
-
-template <int NT, int NH, int KSH>
-__global__ __launch_bounds__(BLOCK) void mlp_fwd_mfma_kernel(MlpArgs<double> a) {
-  using G = Geo<NT>;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int D = 2 * a.C, H = a.H, M = a.M;
-  const int row0 = blockIdx.x * 64 + wave * 16;
-  extern __shared__ __align__(16) unsigned char smem_raw[];
-  double* Wl = reinterpret_cast<double*>(smem_raw);          // 2 weight images
-  double* Xt = Wl + 2 * G::WSIZE + wave * G::TSIZE;          // this wave's activation tile
-
-  double regs[G::NPF], breg;
-  prefetch_layer<NT>(a, 0, NH, D, H, regs, breg);
-  load_input_tile<NT>(a.s_in, M, a.C, row0, Xt, lane);
-  commit_layer<NT>(Wl, 0, NH, D, H, regs, breg);
-  __syncthreads();
-#pragma unroll
-  for (int l = 0; l <= NH; ++l) {
-    const int Hin = l == 0 ? D : H;
-    double* Wcur = Wl + (l & 1) * G::WSIZE;
-    double bv[NT];
-    load_bias<NT>(Wcur, lane, bv);
-    if (l < NH) prefetch_layer<NT>(a, l + 1, NH, D, H, regs, breg);
-    v4d acc[NT];
-    if (l < NH) dense_hidden<NT, NT, KSH>(Xt, Wcur, bv, Hin, lane, acc, l == 0);
-    else dense_tile<NT, 1, KSH>(Xt, Wcur, bv, Hin, lane, acc);
-    if (l < NH) {
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[t][r] = leaky(acc[t][r]);
-      store_tile<NT>(Xt, acc, lane);
-      commit_layer<NT>(Wl + ((l + 1) & 1) * G::WSIZE, l + 1, NH, D, H, regs, breg);
-      __syncthreads();
-    } else {
-      const int c = lane & 15, g = lane >> 4;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = row0 + g + 4 * r;
-        if (c < D && row < M) a.s_out[(size_t)(c & 1) * M * a.C + (size_t)row * a.C + (c >> 1)] = acc[0][r];
-      }
-    }
-  }
-}
-
-template <int NT, int NH, int KSH>
-__global__ __launch_bounds__(BLOCK) void mlp_bwd_mfma_kernel(MlpArgs<double> a) {
+// One forward layer for this wave's tile (shared by the forward kernel and the backward's recompute).
+//   l == 0 reads the input tiles (K = 16), hidden layers the activation buffer of parity l&1; writes LeakyReLU(pre)
+//   into the buffer of parity (l+1)&1 when `store`.
+template <int NT, int KSH>
+__device__ __forceinline__ v4d forward_layer(int l, const double* Wcur, const double* X0, double* Xb, int mt, int nt, int lane,
+                                             int ksh, bool store) {
   using G = Geo<NT>;
   constexpr int S = G::S;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, g = lane >> 4;
+  const double bias = Wcur[(16 * nt + c) * S + G::HP];
+  v4d acc = v4d{bias, bias, bias, bias};
+  const double* wb = Wcur + (16 * nt + c) * S + g;
+  if (l == 0) mma_rowmajor<4>(X0 + mt * G::T0SIZE + c * G::S0 + g, wb, 4, acc);
+  else mma_rowmajor<KSH>(Xb + ((l & 1) * 4 + mt) * G::TSIZE + c * S + g, wb, ksh, acc);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc[r] = leaky(acc[r]);
+  if (store) {
+    double* Xn = Xb + (((l + 1) & 1) * 4 + mt) * G::TSIZE + g * S + 16 * nt + c;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Xn[4 * r * S] = acc[r];
+  }
+  return acc;
+}
+
+template <int NT, int NH, int KSH>
+__global__ __launch_bounds__(256 * NT) void mlp_fwd_mfma_kernel(MlpArgs<double> a) {
+  using G = Geo<NT>;
+  constexpr int S = G::S;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int mt = wave & 3, nt = wave >> 2;
   const int D = 2 * a.C, H = a.H, M = a.M;
-  const int row0 = blockIdx.x * 64 + wave * 16;
+  const int ksh = pad4(H) >> 2;
   extern __shared__ __align__(16) unsigned char smem_raw[];
   double* Wl = reinterpret_cast<double*>(smem_raw);          // 2 weight images
-  double* Xall = Wl + 2 * G::WSIZE;                          // 4 waves x layer-input tile
-  double* Gall = Xall + 4 * G::TSIZE;                        // 4 waves x g_pre tile
-  double* X0all = Gall + 4 * G::TSIZE;                       // 4 waves x MLP input tile (16 columns)
-  double* dbw = X0all + 4 * 16 * S;                          // 4 waves x HP column sums
-  double* Xt = Xall + wave * G::TSIZE;
-  double* Gt = Gall + wave * G::TSIZE;
-  double* X0t = X0all + wave * 16 * S;
-  double* part = a.part + (size_t)blockIdx.x * a.psize;
+  double* Xb = Wl + 2 * G::WSIZE;                            // 2 x 4 activation tiles
+  double* X0 = Xb + 8 * G::TSIZE;                            // 4 input tiles
 
-  // ---- forward recompute; h[l] = post-activation of hidden layer l in D layout -----------------------
-  double regs[G::NPF], breg;
-  prefetch_layer<NT>(a, 0, NH, D, H, regs, breg);
-  load_input_tile<NT>(a.s_in, M, a.C, row0, X0t, lane);
-  for (int e = lane; e < 16 * 16; e += 64) Xt[(e >> 4) * S + (e & 15)] = X0t[(e >> 4) * S + (e & 15)];
-  commit_layer<NT>(Wl, 0, NH, D, H, regs, breg);
+  double regs[NT], breg;
+  prefetch_first<NT>(a.w[0], a.b[0], H, D, regs[0], breg);
+  load_input_tiles<NT>(a.s_in, M, a.C, blockIdx.x * 64, X0);
+  commit_first<NT>(Wl, regs[0], breg);
   __syncthreads();
-  v4d h[NH][NT];
 #pragma unroll
   for (int l = 0; l < NH; ++l) {
-    const int Hin = l == 0 ? D : H;
-    double* Wcur = Wl + (l & 1) * G::WSIZE;
+    const double* Wcur = Wl + (l & 1) * G::WSIZE;
+    prefetch_hidden<NT>(a.w[l + 1], a.b[l + 1], l + 1 == NH ? D : H, H, regs, breg);
+    forward_layer<NT, KSH>(l, Wcur, X0, Xb, mt, nt, lane, ksh, true);
+    commit_hidden<NT>(Wl + ((l + 1) & 1) * G::WSIZE, regs, breg);
+    __syncthreads();
+  }
+  if (nt == 0) {                                             // output layer: one N-tile (2C <= 16 neurons), no activation
+    const int c = lane & 15, g = lane >> 4;
+    const double* Wcur = Wl + (NH & 1) * G::WSIZE;
+    const double bias = Wcur[c * S + G::HP];
+    v4d acc = v4d{bias, bias, bias, bias};
+    mma_rowmajor<KSH>(Xb + ((NH & 1) * 4 + mt) * G::TSIZE + c * S + g, Wcur + c * S + g, ksh, acc);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = blockIdx.x * 64 + mt * 16 + g + 4 * r;
+      if (c < D && row < M) a.s_out[(size_t)(c & 1) * M * a.C + (size_t)row * a.C + (c >> 1)] = acc[r];
+    }
+  }
+}
+
+template <int NT, int NH, int KSH>
+__global__ __launch_bounds__(256 * NT) void mlp_bwd_mfma_kernel(MlpArgs<double> a) {
+  using G = Geo<NT>;
+  constexpr int S = G::S, HP = G::HP;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int mt = wave & 3, nt = wave >> 2;
+  const int c = lane & 15, g = lane >> 4;
+  const int D = 2 * a.C, H = a.H, M = a.M;
+  const int ksh = pad4(H) >> 2;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  double* Wl = reinterpret_cast<double*>(smem_raw);          // 2 weight images
+  double* Xb = Wl + 2 * G::WSIZE;                            // 2 x 4 layer-input tiles
+  double* Gb = Xb + 8 * G::TSIZE;                            // 2 x 4 g_pre tiles
+  double* X0 = Gb + 8 * G::TSIZE;                            // 4 MLP input tiles
+  double* dbw = X0 + 4 * G::T0SIZE;                          // 2 x 4 x HP column sums
+  double* part = a.part + (size_t)blockIdx.x * a.psize;
+
+  // ---- forward recompute; h[l] = post-activation of hidden layer l, this wave's tile, D layout ---------
+  double regs[NT], breg;
+  prefetch_first<NT>(a.w[0], a.b[0], H, D, regs[0], breg);
+  load_input_tiles<NT>(a.s_in, M, a.C, blockIdx.x * 64, X0);
+  commit_first<NT>(Wl, regs[0], breg);
+  __syncthreads();
+  v4d h[NH];
+#pragma unroll
+  for (int l = 0; l < NH; ++l) {
+    const double* Wcur = Wl + (l & 1) * G::WSIZE;
     // the weights of the next forward layer; after the last hidden layer: the output layer (first backward layer)
-    double bv[NT];
-    load_bias<NT>(Wcur, lane, bv);
-    prefetch_layer<NT>(a, l + 1, NH, D, H, regs, breg);
-    dense_hidden<NT, NT, KSH>(Xt, Wcur, bv, Hin, lane, h[l], l == 0);
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) h[l][t][r] = leaky(h[l][t][r]);
-    if (l + 1 < NH) store_tile<NT>(Xt, h[l], lane);
-    commit_layer<NT>(Wl + ((l + 1) & 1) * G::WSIZE, l + 1, NH, D, H, regs, breg);
+    prefetch_hidden<NT>(a.w[l + 1], a.b[l + 1], l + 1 == NH ? D : H, H, regs, breg);
+    h[l] = forward_layer<NT, KSH>(l, Wcur, X0, Xb, mt, nt, lane, ksh, l + 1 < NH);
+    commit_hidden<NT>(Wl + ((l + 1) & 1) * G::WSIZE, regs, breg);
     __syncthreads();
   }
 
-  // ---- backward sweep ----------------------------------------------------------------------------
-  v4d gpre[NT];
+  // ---- backward sweep; tile buffers of parity q alternate per layer -> one barrier per layer ------------
+  v4d gpre = v4d{0, 0, 0, 0};
+  if (nt == 0) {
 #pragma unroll
-  for (int t = 0; t < NT; ++t) gpre[t] = v4d{0, 0, 0, 0};
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int row = row0 + g + 4 * r;
-    gpre[0][r] = (c < D && row < M) ? a.g_out[(size_t)(c & 1) * M * a.C + (size_t)row * a.C + (c >> 1)] : 0.0;
+    for (int r = 0; r < 4; ++r) {
+      const int row = blockIdx.x * 64 + mt * 16 + g + 4 * r;
+      gpre[r] = (c < D && row < M) ? a.g_out[(size_t)(c & 1) * M * a.C + (size_t)row * a.C + (c >> 1)] : 0.0;
+    }
   }
-  size_t poff_end = a.psize;
+  int poff_end = a.psize;
 #pragma unroll
   for (int l = NH; l >= 0; --l) {
     const int Hin = l == 0 ? D : H, Hout = l == NH ? D : H;
-    const int nto = (Hout + 15) >> 4, nti = (Hin + 15) >> 4;
-    poff_end -= (size_t)Hout * Hin + Hout;
+    const int q = (NH - l) & 1;
+    poff_end -= Hout * Hin + Hout;
     double* pW = part + poff_end;
-    double* pB = pW + (size_t)Hout * Hin;
-    double* Wcur = Wl + (l & 1) * G::WSIZE;                   // image of W_l (staged by the previous iteration)
-    if (l > 0) prefetch_layer<NT>(a, l - 1, NH, D, H, regs, breg);
+    double* pB = pW + Hout * Hin;
+    const double* Wcur = Wl + (l & 1) * G::WSIZE;            // image of W_l (staged by the previous iteration)
+    if (l == 1) prefetch_first<NT>(a.w[0], a.b[0], H, D, regs[0], breg);
+    else if (l > 1) prefetch_hidden<NT>(a.w[l - 1], a.b[l - 1], H, H, regs, breg);
 
-    // operands of this layer to LDS: g_pre tile and layer-input tile (h[l-1]; the MLP input for l == 0)
-    store_tile<NT>(Gt, gpre, lane);
-    if (l > 0) store_tile<NT>(Xt, h[l > 0 ? l - 1 : 0], lane);
-    // bias gradient: column sums over this wave's 16 rows
+    // operands of this layer to LDS: g_pre tile and layer-input tile (h[l-1]; the MLP input tiles serve l == 0)
+    double* Gq = Gb + q * 4 * G::TSIZE;
+    double* Xq = Xb + q * 4 * G::TSIZE;
+    {
+      double* gt = Gq + mt * G::TSIZE + g * S + 16 * nt + c;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      double v = (gpre[t][0] + gpre[t][1]) + (gpre[t][2] + gpre[t][3]);
+      for (int r = 0; r < 4; ++r) gt[4 * r * S] = gpre[r];
+      if (l > 0) {
+        double* xt = Xq + mt * G::TSIZE + g * S + 16 * nt + c;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xt[4 * r * S] = h[l > 0 ? l - 1 : 0][r];
+      }
+      // bias gradient: column sums over this tile's 16 rows
+      double v = (gpre[0] + gpre[1]) + (gpre[2] + gpre[3]);
       v += shfl_xor(v, 16);
       v += shfl_xor(v, 32);
-      if (g == 0) dbw[wave * G::HP + 16 * t + c] = v;
+      if (g == 0) dbw[(q * 4 + mt) * HP + 16 * nt + c] = v;
     }
     __syncthreads();
 
-    // (a) g_in = g_pre W  (own rows), kept in registers for the next (lower) layer
-    v4d gin[NT];
-#pragma unroll
-    for (int u = 0; u < NT; ++u) gin[u] = v4d{0, 0, 0, 0};
-    if (l == 0) gin_tile<NT, 1>(Gt, Wcur, Hout, lane, gin);      // live input tiles known at compile time
-    else gin_tile<NT, NT>(Gt, Wcur, Hout, lane, gin);
-    // (b) dW tiles over the workgroup's 64 rows, dealt round-robin to the waves
+    // (a) g_in tile (mt, nt) = g_pre W; the first layer has a single (16-column) input tile
+    v4d gin = v4d{0, 0, 0, 0};
+    if (l > 0 || nt == 0) {
+      const double* ga = Gq + mt * G::TSIZE + c * S + g;
+      const double* wb = Wcur + g * S + 16 * nt + c;
+      if (l == NH) mma_transposed<4, S>(ga, wb, 4, gin);     // K = 2C <= 16 output neurons
+      else mma_transposed<KSH, S>(ga, wb, ksh, gin);
+    }
+    // (b) dW tile number `wave` over the workgroup's 64 rows, two accumulation chains (row blocks {0,1}, {2,3})
     {
-      const double* Xsrc = l > 0 ? Xall : X0all;
-      const int xts = l > 0 ? G::TSIZE : 16 * S;
-      for (int tile = wave; tile < nto * nti; tile += 4) {
-        const int t = tile / nti, u = tile - t * nti;
-        v4d acc = v4d{0, 0, 0, 0};
+      const int nti = l == 0 ? 1 : NT, ntiles = (l == NH ? 1 : NT) * nti;
+      if (wave < ntiles) {
+        const int t = wave / nti, u = wave - t * nti;
+        const double* ga = Gq + g * S + 16 * t + c;
+        const double* xb = l == 0 ? X0 + g * G::S0 + c : Xq + g * S + 16 * u + c;
+        const int xts = l == 0 ? G::T0SIZE : G::TSIZE, xss = l == 0 ? G::S0 : S;
+        v4d acc0 = v4d{0, 0, 0, 0}, acc1 = v4d{0, 0, 0, 0};
 #pragma unroll
-        for (int w = 0; w < 4; ++w)
+        for (int w = 0; w < 2; ++w)
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
-            const double av = Gall[w * G::TSIZE + (4 * s + g) * S + 16 * t + c];
-            const double bv = Xsrc[w * xts + (4 * s + g) * S + 16 * u + c];
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ga[w * G::TSIZE + 4 * s * S], xb[w * xts + 4 * s * xss], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ga[(w + 2) * G::TSIZE + 4 * s * S], xb[(w + 2) * xts + 4 * s * xss], acc1, 0,
+                                                        0, 0);
           }
-        // D[i = o][j = k]
+        const int k = 16 * u + c;                            // D[i = o][j = k]
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int o = 16 * t + g + 4 * r, k = 16 * u + c;
-          if (o < Hout && k < Hin) pW[(size_t)o * Hin + k] = acc[r];
+          const int o = 16 * t + g + 4 * r;
+          if (o < Hout && k < Hin) pW[o * Hin + k] = acc0[r] + acc1[r];
         }
       }
-      for (int o = tid; o < Hout; o += BLOCK)
-        pB[o] = (dbw[o] + dbw[G::HP + o]) + (dbw[2 * G::HP + o] + dbw[3 * G::HP + o]);
+      const double* dq = dbw + q * 4 * HP;
+      if (tid < Hout) pB[tid] = (dq[tid] + dq[HP + tid]) + (dq[2 * HP + tid] + dq[3 * HP + tid]);
     }
     // next layer down
     if (l > 0) {
 #pragma unroll
-      for (int u = 0; u < NT; ++u)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) gpre[u][r] = gin[u][r] * (h[l > 0 ? l - 1 : 0][u][r] > 0.0 ? 1.0 : 0.01);
-      __syncthreads();                       // everyone is done with Wcur / the tiles
-      commit_layer<NT>(Wl + ((l - 1) & 1) * G::WSIZE, l - 1, NH, D, H, regs, breg);
-      // (the g_pre / input tiles are rewritten at the top of the next iteration, followed by a barrier)
-    } else {
+      for (int r = 0; r < 4; ++r) gpre[r] = gin[r] * (h[l > 0 ? l - 1 : 0][r] > 0.0 ? 1.0 : 0.01);
+      // W_{l-1} goes into the image buffer last read two layers up; every wave is past that layer's barrier
+      if (l == 1) commit_first<NT>(Wl, regs[0], breg);
+      else commit_hidden<NT>(Wl + ((l - 1) & 1) * G::WSIZE, regs, breg);
+    } else if (nt == 0) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = row0 + g + 4 * r;
-        if (c < D && row < M) a.g_in[(size_t)(c & 1) * M * a.C + (size_t)row * a.C + (c >> 1)] = gin[0][r];
+        const int row = blockIdx.x * 64 + mt * 16 + g + 4 * r;
+        if (c < D && row < M) a.g_in[(size_t)(c & 1) * M * a.C + (size_t)row * a.C + (c >> 1)] = gin[r];
       }
     }
   }
@@ -334,17 +314,11 @@ static int launch_mlp_mfma(const MlpArgs<double>& a, bool backward, hipStream_t 
   using G = Geo<NT>;
   constexpr int NH = 6;
   const int nblk = cdiv(a.M, 64);
-  if (!backward) {
-    size_t smem = sizeof(double) * (2 * G::WSIZE + 4 * G::TSIZE);
-    auto kern = mlp_fwd_mfma_kernel<NT, NH, KSH>;
-    if (smem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL(kern, dim3(nblk), dim3(BLOCK), smem, stream, a);
-  } else {
-    size_t smem = sizeof(double) * (2 * G::WSIZE + 8 * G::TSIZE + 4 * 16 * G::S + 4 * G::HP);
-    auto kern = mlp_bwd_mfma_kernel<NT, NH, KSH>;
-    if (smem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL(kern, dim3(nblk), dim3(BLOCK), smem, stream, a);
-  }
+  const size_t smem = sizeof(double) * (backward ? G::bwd_doubles() : G::fwd_doubles());
+  static_assert(sizeof(double) * G::bwd_doubles() <= 160 * 1024, "LDS budget");
+  auto kern = backward ? mlp_bwd_mfma_kernel<NT, NH, KSH> : mlp_fwd_mfma_kernel<NT, NH, KSH>;
+  if (smem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipLaunchKernelGGL(kern, dim3(nblk), dim3(G::THREADS), smem, stream, a);
   LGN_CHECK_LAUNCH();
   return 0;
 }
