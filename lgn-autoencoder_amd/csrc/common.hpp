@@ -75,6 +75,19 @@ __device__ __forceinline__ T group_sum(T v) {
   return v;
 }
 
+// Phase stamps (debug builds only: `make stamps` -> liblgn_amd_stamps.so, read by tools/kbench.py with KB_STAMPS=1).
+// Thread 0 of workgroup 0 records s_memtime at each STAMP(i); compiled out of the shipped library.
+#ifdef LGN_STAMPS
+#define LGN_STAMP_DECL static __device__ long long g_stamps[64];
+#define STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_stamps[i] = clock64(); } while (0)
+#define LGN_STAMP_READER(name) \
+  extern "C" int name(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(long long) * 64); }
+#else
+#define LGN_STAMP_DECL
+#define STAMP(i) do { } while (0)
+#define LGN_STAMP_READER(name)
+#endif
+
 template <typename T>
 __device__ __forceinline__ T leaky(T x) {
   return fmax(x, T(0.01) * x);         // == x > 0 ? x : 0.01 x; nn.LeakyReLU default slope (generic_levels.py:121-122)

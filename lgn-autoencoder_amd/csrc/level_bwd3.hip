@@ -50,7 +50,9 @@ template <int C> struct GA3 {
   static constexpr int A3 = 0, A4 = 2 * C, A1 = 4 * C, A2 = 12 * C, SIZE = 20 * C;
 };
 constexpr int TS = 18;
+LGN_STAMP_DECL
 }  // namespace
+LGN_STAMP_READER(lgn_debug_stamps_bwd3)
 
 template <int C, bool DEC>
 struct Bwd3 {
@@ -59,8 +61,16 @@ struct Bwd3 {
   static constexpr int PS = DEC ? 8 : 4;
   static constexpr int TRSZ = DEC ? 4 * 64 : (4 * (NG + 3) * 16 * TS > 4 * 64 * NG * 12 ? 4 * (NG + 3) * 16 * TS : 4 * 64 * NG * 12);
   // phase-1 scratch (upstream gradient tile + CatMix weights) and phase-2 scratch (transpose tiles) share one region
+  // phase 1: upstream gradient tile | CatMix weights | aggregate saved by the forward; then (aliased, after a barrier)
+  // the per-part partial sums of the CatMix weight gradient
+  __host__ __device__ static int mix_parts(int CO) {
+    const int ok = CO * 5 * C;
+    return ok >= BLOCK ? 1 : (BLOCK / ok < 8 ? BLOCK / ok : 8);
+  }
   __host__ __device__ static size_t scratch(int N, int CO) {
-    const size_t p1 = (size_t)N * 10 * CO + 4 * CO * 5 * C;
+    size_t p1 = (size_t)N * 10 * CO + 4 * CO * 5 * C + (size_t)N * 20 * C;
+    const size_t red = (size_t)mix_parts(CO) * CO * 5 * C * 4;
+    if (red > p1) p1 = red;
     return p1 > (size_t)TRSZ ? p1 : (size_t)TRSZ;
   }
   static size_t smem(int N, int CO) {
@@ -85,9 +95,11 @@ __global__ __launch_bounds__(BLOCK) void level_bwd3_kernel(LevelBwdArgs<double> 
   double* tr = pj + N * PS;                                    // phase 2: transpose tiles / reduction scratch ...
   double* go = tr;                                             // ... phase 1: N * 10CO upstream gradient [n][o][s2|v8]
   double* wm = go + N * 10 * CO;                               //              4 * CO * K CatMix weights
+  double* agl = wm + 4 * CO * K;                               //              N * 2C * 10 aggregate [n][q*C+c][s2|v8]
   uint8_t* mk = reinterpret_cast<uint8_t*>(tr + F::scratch(N, CO));
 
   // ---------------- staging ----------------------------------------------------------------------------
+  STAMP(0);
   load_jet<double, C, DEC>(a.s_in, a.v_in, a.p, a.mask, B, N, b, nd, pj, mk);
   for (int e = tid; e < 2 * CO * K; e += BLOCK) {
     wm[e] = a.wm0[e];
@@ -106,8 +118,21 @@ __global__ __launch_bounds__(BLOCK) void level_bwd3_kernel(LevelBwdArgs<double> 
         g[6 + m] = a.g_v_out[plo * 4 + idx * 4 + m];
       }
     }
+    const size_t pa = (size_t)B * N * 2 * C;
+    for (int e = tid; e < N * 2 * C; e += BLOCK) {
+      const size_t ea = (size_t)b * N * 2 * C + e;
+      double* x = agl + e * 10;
+      x[0] = a.ag0[ea];
+      x[1] = a.ag0[pa + ea];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        x[2 + m] = a.ag1[ea * 4 + m];
+        x[6 + m] = a.ag1[(pa + ea) * 4 + m];
+      }
+    }
   }
   __syncthreads();
+  STAMP(1);
 
   // ---------------- phase 1a: per (node, channel) CatMix^H, power backward ---------------------------------
   for (int e = tid; e < N * C; e += BLOCK) {
@@ -160,46 +185,83 @@ __global__ __launch_bounds__(BLOCK) void level_bwd3_kernel(LevelBwdArgs<double> 
     gdn[0] = gs.r;
     gdn[1] = gs.i;
   }
+  STAMP(2);
   // ---------------- phase 1b: CatMix weight gradient over the jet's nodes -> this jet's partial row --------
+  // item = (node part, out channel o, cat slot k); the parts' sums meet in LDS (fixed order -> deterministic)
   {
     double* part = a.part_mix + (size_t)b * (4 * CO * K);
-    const size_t pa = (size_t)B * N * 2 * C;
-    for (int e = tid; e < CO * K; e += BLOCK) {
-      const int o = e / K, k = e - o * K, q = k / C, c = k - q * C;
+    const int OK = CO * K, npart = F::mix_parts(CO), nper = (N + npart - 1) / npart;
+    double acc[2][4];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {                    // OK <= 2 * BLOCK (checked by the dispatcher)
+      const int item = tid + it * BLOCK;
       cx<double> d0 = {0, 0}, d1 = {0, 0};
-      for (int n = 0; n < N; ++n) {
-        const double* g = go + (n * CO + o) * 10;
-        const double* ni = nd + n * NS + c * 10;
-        const cx<double> s = {ni[0], ni[1]};
-        cx<double> v[4];
+      if (item < OK * npart) {
+        const int pi = item / OK, e = item - pi * OK;
+        const int o = e / K, k = e - o * K, q = k / C, c = k - q * C;
+        const int n1 = min(N, (pi + 1) * nper);
+        for (int n = pi * nper; n < n1; ++n) {
+          const double* g = go + (n * CO + o) * 10;
+          cx<double> x0, x1[4];
+          if (q < 2) {                                  // aggregate blocks, saved by the forward
+            const double* x = agl + (n * 2 * C + k) * 10;
+            x0 = {x[0], x[1]};
 #pragma unroll
-        for (int m = 0; m < 4; ++m) v[m] = {ni[2 + m], ni[6 + m]};
-        cx<double> x0, x1[4];
-        if (q < 2) {                                  // aggregate blocks, saved by the forward
-          const size_t ea = ((size_t)b * N + n) * 2 * C + q * C + c;
-          x0 = {a.ag0[ea], a.ag0[pa + ea]};
+            for (int m = 0; m < 4; ++m) x1[m] = {x[2 + m], x[6 + m]};
+          } else {
+            const double* ni = nd + n * NS + c * 10;
+            const cx<double> s = {ni[0], ni[1]};
+            cx<double> v[4];
 #pragma unroll
-          for (int m = 0; m < 4; ++m) x1[m] = {a.ag1[ea * 4 + m], a.ag1[(pa + ea) * 4 + m]};
-        } else if (q == 2) {                          // node block
-          x0 = s;
+            for (int m = 0; m < 4; ++m) v[m] = {ni[2 + m], ni[6 + m]};
+            if (q == 2) {                               // node block
+              x0 = s;
 #pragma unroll
-          for (int m = 0; m < 4; ++m) x1[m] = v[m];
-        } else {                                      // power blocks: (0,0): <v,v> | s^2 ; (1,1): v s | s v
-          if (q == 3) { x0 = bil2(v, v); x0.r *= 0.5; x0.i *= 0.5; } else x0 = cmul(s, s);
+              for (int m = 0; m < 4; ++m) x1[m] = v[m];
+            } else {                                    // power blocks: (0,0): <v,v> | s^2 ; (1,1): v s | s v
+              if (q == 3) { x0 = bil2(v, v); x0.r *= 0.5; x0.i *= 0.5; } else x0 = cmul(s, s);
 #pragma unroll
-          for (int m = 0; m < 4; ++m) x1[m] = cmul(v[m], s);
+              for (int m = 0; m < 4; ++m) x1[m] = cmul(v[m], s);
+            }
+          }
+          cfmac(d0, cx<double>{g[0], g[1]}, x0);
+#pragma unroll
+          for (int m = 0; m < 4; ++m) cfmac(d1, cx<double>{g[2 + m], g[6 + m]}, x1[m]);
         }
-        cfmac(d0, cx<double>{g[0], g[1]}, x0);
-#pragma unroll
-        for (int m = 0; m < 4; ++m) cfmac(d1, cx<double>{g[2 + m], g[6 + m]}, x1[m]);
       }
-      part[(0 * CO + o) * K + k] = d0.r;
-      part[(1 * CO + o) * K + k] = d0.i;
-      part[2 * CO * K + (0 * CO + o) * K + k] = d1.r;
-      part[2 * CO * K + (1 * CO + o) * K + k] = d1.i;
+      acc[it][0] = d0.r;  acc[it][1] = d0.i;  acc[it][2] = d1.r;  acc[it][3] = d1.i;
+    }
+    if (npart > 1) {                                    // OK * npart <= BLOCK: one item per thread
+      __syncthreads();                                  // every read of go / wm / agl is done: reuse the region
+      double* red = tr;
+      if (tid < OK * npart) {
+#pragma unroll
+        for (int x = 0; x < 4; ++x) red[tid * 4 + x] = acc[0][x];
+      }
+      __syncthreads();
+      if (tid < OK) {
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          double v = red[tid * 4 + x];
+          for (int pi = 1; pi < npart; ++pi) v += red[(pi * OK + tid) * 4 + x];
+          acc[0][x] = v;
+        }
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int e = tid + it * BLOCK;
+      if (e < OK && (npart == 1 || it == 0)) {
+        const int o = e / K, k = e - o * K;
+        part[(0 * CO + o) * K + k] = acc[it][0];
+        part[(1 * CO + o) * K + k] = acc[it][1];
+        part[2 * CO * K + (0 * CO + o) * K + k] = acc[it][2];
+        part[2 * CO * K + (1 * CO + o) * K + k] = acc[it][3];
+      }
     }
   }
 
+  STAMP(3);
   // ---------------- per-lane constants of the pair sweep --------------------------------------------------------
   const int pr = lane & 15, cg = lane >> 4;
   const int tj = pr >> 2, ti = pr & 3;                  // which of the wave's 4 source particles j / slot in the i tile
@@ -230,7 +292,9 @@ __global__ __launch_bounds__(BLOCK) void level_bwd3_kernel(LevelBwdArgs<double> 
       bias[g][q] = ch < C ? (DEC ? bb[ch] : bb[2 * ch + (q & 1)]) : 0.0;
     }
   }
+  STAMP(4);
   __syncthreads();                                      // g_ag / gd of the whole jet are in LDS; phase-1 scratch is dead
+  STAMP(5);
 
   // ---------------- phase 2: one sweep over the ordered pairs (i, j), j-centric ------------------------------------
   double* trw = tr + wave * (NG + 3) * 16 * TS;         // encoder: transpose tiles of this wave
@@ -270,6 +334,7 @@ __global__ __launch_bounds__(BLOCK) void level_bwd3_kernel(LevelBwdArgs<double> 
     for (int m = 0; m < 4; ++m) Gq[m] = {0, 0};
 
     for (int i0 = 0; i0 < N; i0 += 4) {
+      if (rg == 0 && i0 < 32) STAMP(16 + (i0 >> 2) * 4);
       const int i = i0 + ti;
       const bool ok = jok && i < N;
       const int ii = i < N ? i : N - 1;
@@ -323,6 +388,7 @@ __global__ __launch_bounds__(BLOCK) void level_bwd3_kernel(LevelBwdArgs<double> 
         xb[32 * TS + pr * TS + 8 + 2 * cg] = cg == 0 ? (on ? 1.0 : 0.0) : 0.0;
         xb[32 * TS + pr * TS + 9 + 2 * cg] = cg == 0 ? (ok ? 1.0 : 0.0) : 0.0;
       }
+      if (rg == 0 && i0 < 32) STAMP(17 + (i0 >> 2) * 4);
       const double* gi = ga + ii * G::SIZE;
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
@@ -369,6 +435,7 @@ __global__ __launch_bounds__(BLOCK) void level_bwd3_kernel(LevelBwdArgs<double> 
           ta[pr * TS + 12 + cg] = G1i;
         }
       }
+      if (rg == 0 && i0 < 32) STAMP(18 + (i0 >> 2) * 4);
       if (!DEC) {
         wave_sync();
         const double* xb = trw + NG * 16 * TS;
@@ -389,6 +456,7 @@ __global__ __launch_bounds__(BLOCK) void level_bwd3_kernel(LevelBwdArgs<double> 
       }
     }
 
+    if (rg == 0) STAMP(6);
     // node gradient of the wave's 4 particles: neighbour part (quad sum over the i slots) + direct part, written once
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
@@ -425,6 +493,7 @@ __global__ __launch_bounds__(BLOCK) void level_bwd3_kernel(LevelBwdArgs<double> 
     }
   }
 
+  STAMP(7);
   // ---------------- phase 3 (decoder): i-centric sweep for d p_i = sum_j G_q(i, j) ---------------------------------
   if (DEC) {
     const int ti2 = pr >> 2, tj2 = pr & 3;
@@ -475,7 +544,9 @@ __global__ __launch_bounds__(BLOCK) void level_bwd3_kernel(LevelBwdArgs<double> 
   }
 
   // ---------------- radial partial row of this jet ------------------------------------------------------------
+  STAMP(8);
   __syncthreads();
+  STAMP(9);
   double* part = a.part_rad + (size_t)blockIdx.x * rad_partial_size(C, DEC);
   if (DEC) {
     double* red = tr;
@@ -534,6 +605,7 @@ __global__ __launch_bounds__(BLOCK) void level_bwd3_kernel(LevelBwdArgs<double> 
       }
     }
   }
+  STAMP(10);
 }
 
 bool level_bwd3_fits(int N) { return N <= 40; }
@@ -542,6 +614,7 @@ template <int C, bool DEC>
 static int launch_bwd3(const LevelBwdArgs<double>& a, hipStream_t stream) {
   const size_t smem = Bwd3<C, DEC>::smem(a.N, a.CO);
   LGN_CHECK_ARG(smem <= 160 * 1024, "level_bwd: N=%d C=%d needs %zu B of LDS", a.N, a.C, smem);
+  LGN_CHECK_ARG(a.CO * 5 * C <= 2 * BLOCK, "level_bwd: C_in=%d C_out=%d unsupported", C, a.CO);
   auto kern = level_bwd3_kernel<C, DEC>;
   if (smem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   hipLaunchKernelGGL(kern, dim3(a.B), dim3(BLOCK), smem, stream, a);

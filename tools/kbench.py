@@ -14,6 +14,9 @@ from lgn import _native as Nn  # noqa: E402
 
 
 def main():
+    stamps = os.environ.get("KB_STAMPS")          # name of a stamp reader of the debug build, e.g. lgn_debug_stamps_bwd3
+    if stamps:
+        Nn.LIB_PATH = Nn.LIB_PATH.replace("liblgn_amd.so", "liblgn_amd_stamps.so")
     what = sys.argv[1] if len(sys.argv) > 1 else "level_fwd_enc"
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
     B = int(os.environ.get("KB_BATCH", "512"))
@@ -67,6 +70,16 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     print(f"{what}: B={B} N={N} C={C}->{CO}  {e0.elapsed_time(e1) * 1e3 / reps:.1f} us per call")
+    if stamps:
+        import ctypes
+        buf = (ctypes.c_longlong * 64)()
+        rc = getattr(Nn.lib(), stamps)(buf)
+        st = list(buf)
+        print(f"stamps ({stamps}, rc={rc}), s_memtime ticks relative to stamp 0:")
+        prev = st[0]
+        for i in range(1, 64):
+            if st[i] > st[0]:
+                print(f"  {i:3d}  t={st[i] - st[0]:8d}")
 
 
 if __name__ == "__main__":
