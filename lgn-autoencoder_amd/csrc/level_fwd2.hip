@@ -14,14 +14,16 @@
 //  * a wave owns a "row group" of 4 receiving particles i and sweeps the neighbours in tiles of 4 (16 pairs per
 //    tile); the lane's accumulators (20 reals per channel group) stay in registers across the sweep and are
 //    combined across the 4 lanes of a quad (the 4 neighbours of a tile) with two DPP quad permutes.
-//  * CatMix is done by the same wave right after each row group from a wave-private LDS staging buffer,
-//    so there is no workgroup barrier after the prologue.
+//  * the aggregate of the whole jet is collected in LDS; after one barrier all 256 threads write it out (it is saved
+//    for the backward) and run CatMix over the items (row, out channel, component).
 #include "level_dev.hpp"
 #include "ops.hpp"
 
 namespace lgn {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
+LGN_STAMP_DECL
+LGN_STAMP_READER(lgn_debug_stamps_fwd2)
 
 __device__ __forceinline__ double dpp_quad(double v, int ctrl_is_xor2) {
   // quad_perm [1,0,3,2] = 0xB1 (xor 1), [2,3,0,1] = 0x4E (xor 2)
@@ -60,7 +62,7 @@ struct Fwd2 {
 };
 
 template <int C, bool DEC>
-__global__ __launch_bounds__(BLOCK) void level_fwd2_kernel(LevelArgs<double> a) {
+__global__ __launch_bounds__(BLOCK) void level_fwd2_kernel(LevelArgs<double> a, int chunk) {
   using F = Fwd2<C, DEC>;
   constexpr int NG = F::NG;
   const int N = a.N, B = a.B, CO = a.CO;
@@ -70,9 +72,10 @@ __global__ __launch_bounds__(BLOCK) void level_fwd2_kernel(LevelArgs<double> a) 
   double* nd = reinterpret_cast<double*>(smem_raw);                   // N * NS
   double* pj = nd + ((N * F::NS + 1) & ~1);                           // N * PS
   double* wm = pj + N * F::PS;                                        // 4 * CO * 5C
-  double* agw = wm + 4 * CO * 5 * C;                                  // 4 waves * 4 rows * AGS
-  uint8_t* mk = reinterpret_cast<uint8_t*>(agw + 4 * 4 * F::AGS);     // N
+  double* agl = wm + 4 * CO * 5 * C;                                  // chunk rows * AGS: aggregate of a chunk of rows
+  uint8_t* mk = reinterpret_cast<uint8_t*>(agl + chunk * F::AGS);     // N
 
+  STAMP(0);
   load_jet<double, C, DEC>(a.s_in, a.v_in, a.p, a.mask, B, N, b, nd, pj, mk);
   for (int e = tid; e < 2 * CO * 5 * C; e += BLOCK) {
     wm[e] = a.wm0[e];
@@ -112,10 +115,12 @@ __global__ __launch_bounds__(BLOCK) void level_fwd2_kernel(LevelArgs<double> a) 
     }
   }
   __syncthreads();
+  STAMP(1);
 
-  double* stage = agw + wave * 4 * F::AGS;
-  const int ngroups = (N + 3) >> 2;
-  for (int rg = wave; rg < ngroups; rg += 4) {
+  // rows are processed in chunks of `chunk` (a multiple of 16; the whole jet when it fits the LDS budget)
+  for (int c0 = 0; c0 < N; c0 += chunk) {
+  const int c1 = min(N, c0 + chunk);
+  for (int rg = (c0 >> 2) + wave; rg * 4 < c1; rg += 4) {
     const int i0 = rg * 4;
     const int i = i0 + ti;
     const bool iok = i < N;
@@ -134,6 +139,7 @@ __global__ __launch_bounds__(BLOCK) void level_fwd2_kernel(LevelArgs<double> a) 
       for (int m = 0; m < 4; ++m) { A1[g][m] = {0, 0}; A2[g][m] = {0, 0}; }
     }
 
+    STAMP(2 + ((rg >> 2) & 3) * 4);
     for (int j0 = 0; j0 < N; j0 += 4) {
       const int j = j0 + tj;
       const bool ok = iok && j < N;
@@ -197,6 +203,7 @@ __global__ __launch_bounds__(BLOCK) void level_fwd2_kernel(LevelArgs<double> a) 
       }
     }
 
+    STAMP(3 + ((rg >> 2) & 3) * 4);
     // ---- combine the 4 neighbour slots of a tile (quad lanes), stage + store the aggregate -----------------
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
@@ -209,8 +216,7 @@ __global__ __launch_bounds__(BLOCK) void level_fwd2_kernel(LevelArgs<double> a) 
       }
     }
     if (tj == 0) {
-      double* st = stage + ti * F::AGS;
-      const size_t pl0 = (size_t)B * N * 2 * C;
+      double* st = agl + (i0 + ti - c0) * F::AGS;        // rows >= N of the last group land in the padding
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
         const int ch = 4 * g + cg;
@@ -222,91 +228,132 @@ __global__ __launch_bounds__(BLOCK) void level_fwd2_kernel(LevelArgs<double> a) 
             st[F::A1 + (ch * 4 + m) * 2] = A1[g][m].r;  st[F::A1 + (ch * 4 + m) * 2 + 1] = A1[g][m].i;
             st[F::A2 + (ch * 4 + m) * 2] = A2[g][m].r;  st[F::A2 + (ch * 4 + m) * 2 + 1] = A2[g][m].i;
           }
-          if (iok) {
-            double* g0 = a.ag0 + ((size_t)b * N + i) * 2 * C;
-            double* g1 = a.ag1 + ((size_t)b * N + i) * 2 * C * 4;
-            g0[ch] = A3[g].r;  g0[pl0 + ch] = A3[g].i;
-            g0[C + ch] = A4[g].r;  g0[pl0 + C + ch] = A4[g].i;
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-              g1[ch * 4 + m] = A1[g][m].r;  g1[pl0 * 4 + ch * 4 + m] = A1[g][m].i;
-              g1[(C + ch) * 4 + m] = A2[g][m].r;  g1[pl0 * 4 + (C + ch) * 4 + m] = A2[g][m].i;
-            }
-          }
         }
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    STAMP(4 + ((rg >> 2) & 3) * 4);
+  }
+  __syncthreads();
+  STAMP(20);
 
-    // ---- power + CatMix for the 4 rows: item = (row, out channel, component m; m == 4 is the scalar) --------
-    // Cat order per irrep: [aggregate (2C), node (C), power (2C)]; power (0,0) = [<v,v>, s*s], (1,1) = [v*s, s*v]
-    {
-      const int K = 5 * C;
-      const size_t plo = (size_t)B * N * CO;
-      for (int it = lane; it < 20 * CO; it += 64) {
-        const int rl = it / (5 * CO), rem = it - rl * 5 * CO, o = rem / 5, m = rem - o * 5;
-        const int r = i0 + rl;
-        if (r >= N) continue;
-        const double* st = stage + rl * F::AGS;
+  // ---- aggregate -> global (saved for the backward): ag0 [2][B][N][2C], ag1 [2][B][N][2C][4] -----------------------
+  {
+    const size_t pl0 = (size_t)B * N * 2 * C;
+    for (int e = tid; e < (c1 - c0) * 2 * C; e += BLOCK) {        // e = n * 2C + (blk * C + ch), blk 0: A3, 1: A4
+      const int n = e / (2 * C), r = e - n * 2 * C, blk = r / C, ch = r - blk * C;
+      const double* st = agl + n * F::AGS + (blk ? F::A4 : F::A3) + 2 * ch;
+      const size_t ge = ((size_t)b * N + c0) * 2 * C + e;
+      a.ag0[ge] = st[0];
+      a.ag0[pl0 + ge] = st[1];
+    }
+    for (int e = tid; e < (c1 - c0) * 2 * C * 4; e += BLOCK) {    // e = (n * 2C + blk * C + ch) * 4 + m, blk 0: A1, 1: A2
+      const int n = e / (8 * C), r = e - n * 8 * C, blk = r / (4 * C), cm = r - blk * 4 * C;
+      const double* st = agl + n * F::AGS + (blk ? F::A2 : F::A1) + 2 * cm;
+      const size_t ge = ((size_t)b * N + c0) * 8 * C + e;
+      a.ag1[ge] = st[0];
+      a.ag1[pl0 * 4 + ge] = st[1];
+    }
+  }
+  STAMP(21);
+
+  // ---- power + CatMix.  A lane owns one row's scalar (wave 0) or one (row, component m) of the vectors (waves 1-3):
+  // it builds that item's cat vector x[k] once in registers and runs all out channels over it; the weights are
+  // wave-uniform reads.  Cat order per irrep: [aggregate (2C), node (C), power (2C)]; power (0,0) = [<v,v>, s*s],
+  // (1,1) = [v*s, s*v]
+  {
+    constexpr int K = 5 * C;
+    const int nr = c1 - c0;
+    const size_t plo = (size_t)B * N * CO;
+    if (wave == 0) {
+      for (int rl = lane; rl < nr; rl += 64) {
+        const int r = c0 + rl;
+        const double* st = agl + rl * F::AGS;
         const double* ni = nd + r * F::NS;
-        cx<double> acc = {0, 0};
-        if (m == 4) {
+        cx<double> x[K];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          const cx<double> sc = {ni[c * 10], ni[c * 10 + 1]};
+          cx<double> v[4];
+#pragma unroll
+          for (int mm = 0; mm < 4; ++mm) v[mm] = {ni[c * 10 + 2 + mm], ni[c * 10 + 6 + mm]};
+          cx<double> vv = bil2(v, v);
+          vv.r *= 0.5;  vv.i *= 0.5;
+          x[c] = {st[F::A3 + 2 * c], st[F::A3 + 2 * c + 1]};
+          x[C + c] = {st[F::A4 + 2 * c], st[F::A4 + 2 * c + 1]};
+          x[2 * C + c] = sc;
+          x[3 * C + c] = vv;
+          x[4 * C + c] = cmul(sc, sc);
+        }
+#pragma unroll 2
+        for (int o = 0; o < CO; ++o) {
           const double* wr = wm + (0 * CO + o) * K;
           const double* wi = wm + (1 * CO + o) * K;
+          cx<double> acc = {0, 0};
 #pragma unroll
-          for (int c = 0; c < C; ++c) {
-            const cx<double> s = {ni[c * 10], ni[c * 10 + 1]};
-            cx<double> v[4];
-#pragma unroll
-            for (int mm = 0; mm < 4; ++mm) v[mm] = {ni[c * 10 + 2 + mm], ni[c * 10 + 6 + mm]};
-            cx<double> vv = bil2(v, v);
-            vv.r *= 0.5;  vv.i *= 0.5;
-            cfma(acc, cx<double>{wr[c], wi[c]}, cx<double>{st[F::A3 + 2 * c], st[F::A3 + 2 * c + 1]});
-            cfma(acc, cx<double>{wr[C + c], wi[C + c]}, cx<double>{st[F::A4 + 2 * c], st[F::A4 + 2 * c + 1]});
-            cfma(acc, cx<double>{wr[2 * C + c], wi[2 * C + c]}, s);
-            cfma(acc, cx<double>{wr[3 * C + c], wi[3 * C + c]}, vv);
-            cfma(acc, cx<double>{wr[4 * C + c], wi[4 * C + c]}, cmul(s, s));
-          }
+          for (int k = 0; k < K; ++k) cfma(acc, cx<double>{wr[k], wi[k]}, x[k]);
           const size_t e = ((size_t)b * N + r) * CO + o;
           a.s_out[e] = acc.r;
           a.s_out[plo + e] = acc.i;
-        } else {
+        }
+      }
+    } else {
+      for (int it = lane + 64 * (wave - 1); it < nr * 4; it += 192) {
+        const int rl = it >> 2, m = it & 3, r = c0 + rl;
+        const double* st = agl + rl * F::AGS;
+        const double* ni = nd + r * F::NS;
+        cx<double> x[K];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          const cx<double> sc = {ni[c * 10], ni[c * 10 + 1]};
+          const cx<double> v = {ni[c * 10 + 2 + m], ni[c * 10 + 6 + m]};
+          x[c] = {st[F::A1 + (c * 4 + m) * 2], st[F::A1 + (c * 4 + m) * 2 + 1]};
+          x[C + c] = {st[F::A2 + (c * 4 + m) * 2], st[F::A2 + (c * 4 + m) * 2 + 1]};
+          x[2 * C + c] = v;
+          x[3 * C + c] = x[4 * C + c] = cmul(v, sc);
+        }
+#pragma unroll 2
+        for (int o = 0; o < CO; ++o) {
           const double* wr = wm + 2 * CO * K + (0 * CO + o) * K;
           const double* wi = wm + 2 * CO * K + (1 * CO + o) * K;
+          cx<double> acc = {0, 0};
 #pragma unroll
-          for (int c = 0; c < C; ++c) {
-            const cx<double> s = {ni[c * 10], ni[c * 10 + 1]};
-            const cx<double> v = {ni[c * 10 + 2 + m], ni[c * 10 + 6 + m]};
-            cfma(acc, cx<double>{wr[c], wi[c]}, cx<double>{st[F::A1 + (c * 4 + m) * 2], st[F::A1 + (c * 4 + m) * 2 + 1]});
-            cfma(acc, cx<double>{wr[C + c], wi[C + c]}, cx<double>{st[F::A2 + (c * 4 + m) * 2], st[F::A2 + (c * 4 + m) * 2 + 1]});
-            cfma(acc, cx<double>{wr[2 * C + c], wi[2 * C + c]}, v);
-            cfma(acc, cx<double>{wr[3 * C + c] + wr[4 * C + c], wi[3 * C + c] + wi[4 * C + c]}, cmul(v, s));
-          }
+          for (int k = 0; k < K; ++k) cfma(acc, cx<double>{wr[k], wi[k]}, x[k]);
           const size_t e = ((size_t)b * N + r) * CO + o;
           a.v_out[e * 4 + m] = acc.r;
           a.v_out[plo * 4 + e * 4 + m] = acc.i;
         }
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();       // staging buffer is reused by the next row group
   }
+  STAMP(22);
+  if (c1 < N) __syncthreads();                           // the chunk's aggregate rows are reused
+  }
+  STAMP(40);
 }
 
 template <int C, bool DEC>
 static int launch_level_fwd2(const LevelArgs<double>& a, hipStream_t stream) {
   using F = Fwd2<C, DEC>;
-  const size_t smem = sizeof(double) * (((size_t)a.N * F::NS + 1 & ~size_t(1)) + (size_t)a.N * F::PS + 4 * a.CO * 5 * C + 16 * F::AGS) +
-                      a.N + 16;
+  // aggregate rows kept in LDS: the whole jet if that still leaves room for two workgroups per CU (or nothing does),
+  // else as many 16-row slabs as fit next to the node data
+  const size_t fixed = sizeof(double) * (((size_t)a.N * F::NS + 1 & ~size_t(1)) + (size_t)a.N * F::PS + 4 * a.CO * 5 * C) + a.N + 16;
+  const size_t row = sizeof(double) * F::AGS, budget2 = 78 * 1024, budget1 = 160 * 1024;
+  const int full = (a.N + 15) & ~15;
+  int chunk = full;
+  if (fixed + full * row > budget2) {
+    const size_t room = fixed + 16 * row <= budget2 ? budget2 - fixed : (fixed < budget1 ? budget1 - fixed : 0);
+    chunk = (int)(room / row) & ~15;
+    if (chunk > full) chunk = full;
+    if (chunk < 16) chunk = 16;
+  }
+  const size_t smem = fixed + chunk * row;
   LGN_CHECK_ARG(smem <= 160 * 1024, "level_fwd: N=%d C=%d needs %zu B of LDS (> 160 KiB)", a.N, a.C, smem);
   auto kern = level_fwd2_kernel<C, DEC>;
   if (smem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
   }
-  hipLaunchKernelGGL(kern, dim3(a.B), dim3(BLOCK), smem, stream, a);
+  hipLaunchKernelGGL(kern, dim3(a.B), dim3(BLOCK), smem, stream, a, chunk);
   LGN_CHECK_LAUNCH();
   return 0;
 }
