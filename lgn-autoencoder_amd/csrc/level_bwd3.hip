@@ -63,13 +63,10 @@ struct Bwd3 {
   // phase-1 scratch (upstream gradient tile + CatMix weights) and phase-2 scratch (transpose tiles) share one region
   // phase 1: upstream gradient tile | CatMix weights | aggregate saved by the forward; then (aliased, after a barrier)
   // the per-part partial sums of the CatMix weight gradient
-  __host__ __device__ static int mix_parts(int CO) {
-    const int ok = CO * 5 * C;
-    return ok >= BLOCK ? 1 : (BLOCK / ok < 8 ? BLOCK / ok : 8);
-  }
+  static constexpr int MIXP = BLOCK / (5 * C) < 16 ? BLOCK / (5 * C) : 16;   // node parts of the CatMix weight gradient
   __host__ __device__ static size_t scratch(int N, int CO) {
     size_t p1 = (size_t)N * 10 * CO + 4 * CO * 5 * C + (size_t)N * 20 * C;
-    const size_t red = (size_t)mix_parts(CO) * CO * 5 * C * 4;
+    const size_t red = (size_t)MIXP * CO * 5 * C * 4;
     if (red > p1) p1 = red;
     return p1 > (size_t)TRSZ ? p1 : (size_t)TRSZ;
   }
@@ -135,129 +132,156 @@ __global__ __launch_bounds__(BLOCK) void level_bwd3_kernel(LevelBwdArgs<double> 
   STAMP(1);
 
   // ---------------- phase 1a: per (node, channel) CatMix^H, power backward ---------------------------------
-  for (int e = tid; e < N * C; e += BLOCK) {
-    const int n = e / C, c = e - n * C;
-    const double* ni = nd + n * NS + c * 10;
-    const cx<double> s = {ni[0], ni[1]};
-    cx<double> v[4], vt[4];
+  // waves 0,1: aggregate blocks (cat slots q = 0,1) -> g_ag;  waves 2,3: node + power blocks (q = 2,3,4) -> direct part
+  {
+    const int half = tid >> 7;
+    for (int e = tid & 127; e < N * C; e += 128) {
+      const int n = e / C, c = e - n * C;
+      const double* w0r = wm + c;                          // [z][o][k]: + (z * CO + o) * K + q * C
+      const double* w1r = wm + 2 * CO * K + c;
+      if (half == 0) {
+        cx<double> gx0[2] = {{0, 0}, {0, 0}}, gx1[2][4] = {{{0, 0}, {0, 0}, {0, 0}, {0, 0}}, {{0, 0}, {0, 0}, {0, 0}, {0, 0}}};
+        for (int o = 0; o < CO; ++o) {
+          const double* g = go + (n * CO + o) * 10;
+          const cx<double> gs = {g[0], g[1]};
+          cx<double> gv[4];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) v[m] = {ni[2 + m], ni[6 + m]};
-    metric_perm(v, vt);
-    cx<double> gx0[5], gx1[5][4];
+          for (int m = 0; m < 4; ++m) gv[m] = {g[2 + m], g[6 + m]};
 #pragma unroll
-    for (int q = 0; q < 5; ++q) {
-      const int k = q * C + c;
-      cx<double> acc0 = {0, 0}, acc1[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
-      for (int o = 0; o < CO; ++o) {
-        const double* g = go + (n * CO + o) * 10;
-        const cx<double> w0 = {wm[(0 * CO + o) * K + k], wm[(1 * CO + o) * K + k]};
-        const cx<double> w1 = {wm[2 * CO * K + (0 * CO + o) * K + k], wm[2 * CO * K + (1 * CO + o) * K + k]};
-        cfmac(acc0, cx<double>{g[0], g[1]}, w0);
+          for (int q = 0; q < 2; ++q) {
+            const cx<double> w0 = {w0r[(0 * CO + o) * K + q * C], w0r[(1 * CO + o) * K + q * C]};
+            const cx<double> w1 = {w1r[(0 * CO + o) * K + q * C], w1r[(1 * CO + o) * K + q * C]};
+            cfmac(gx0[q], gs, w0);
 #pragma unroll
-        for (int m = 0; m < 4; ++m) cfmac(acc1[m], cx<double>{g[2 + m], g[6 + m]}, w1);
+            for (int m = 0; m < 4; ++m) cfmac(gx1[q][m], gv[m], w1);
+          }
+        }
+        double* gan = ga + n * G::SIZE;
+        gan[G::A3 + 2 * c] = gx0[0].r;  gan[G::A3 + 2 * c + 1] = gx0[0].i;
+        gan[G::A4 + 2 * c] = gx0[1].r;  gan[G::A4 + 2 * c + 1] = gx0[1].i;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          gan[G::A1 + (c * 4 + m) * 2] = gx1[0][m].r;  gan[G::A1 + (c * 4 + m) * 2 + 1] = gx1[0][m].i;
+          gan[G::A2 + (c * 4 + m) * 2] = gx1[1][m].r;  gan[G::A2 + (c * 4 + m) * 2 + 1] = gx1[1][m].i;
+        }
+      } else {
+        // a2/a3/a4: scalar slots q = 2,3,4;  b2: vector slot q = 2;  b34: vector slots 3 and 4 (both multiply v s)
+        cx<double> a2 = {0, 0}, a3 = {0, 0}, a4 = {0, 0};
+        cx<double> b2[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}}, b34[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+        for (int o = 0; o < CO; ++o) {
+          const double* g = go + (n * CO + o) * 10;
+          const cx<double> gs = {g[0], g[1]};
+          const double* wr0 = w0r + (0 * CO + o) * K;
+          const double* wi0 = w0r + (1 * CO + o) * K;
+          const double* wr1 = w1r + (0 * CO + o) * K;
+          const double* wi1 = w1r + (1 * CO + o) * K;
+          cfmac(a2, gs, cx<double>{wr0[2 * C], wi0[2 * C]});
+          cfmac(a3, gs, cx<double>{wr0[3 * C], wi0[3 * C]});
+          cfmac(a4, gs, cx<double>{wr0[4 * C], wi0[4 * C]});
+          const cx<double> w2 = {wr1[2 * C], wi1[2 * C]};
+          const cx<double> w34 = {wr1[3 * C] + wr1[4 * C], wi1[3 * C] + wi1[4 * C]};
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            const cx<double> gv = {g[2 + m], g[6 + m]};
+            cfmac(b2[m], gv, w2);
+            cfmac(b34[m], gv, w34);
+          }
+        }
+        const double* ni = nd + n * NS + c * 10;
+        const cx<double> s = {ni[0], ni[1]};
+        cx<double> v[4], vt[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) v[m] = {ni[2 + m], ni[6 + m]};
+        metric_perm(v, vt);
+        // node block + power blocks: sq(0,0) = [<v,v>, s^2], sq(1,1) = [v s, s v]
+        cx<double> gs = a2;
+        cfmac(gs, cx<double>{2.0 * a4.r, 2.0 * a4.i}, s);
+        double* gdn = gd + (n * C + c) * 10;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          cfmac(gs, b34[m], v[m]);
+          cx<double> gv = b2[m];
+          cfmac(gv, b34[m], s);
+          cfmac(gv, a3, vt[m]);
+          gdn[2 + m] = gv.r;
+          gdn[6 + m] = gv.i;
+        }
+        gdn[0] = gs.r;
+        gdn[1] = gs.i;
       }
-      gx0[q] = acc0;
-#pragma unroll
-      for (int m = 0; m < 4; ++m) gx1[q][m] = acc1[m];
     }
-    double* gan = ga + n * G::SIZE;
-    gan[G::A3 + 2 * c] = gx0[0].r;  gan[G::A3 + 2 * c + 1] = gx0[0].i;
-    gan[G::A4 + 2 * c] = gx0[1].r;  gan[G::A4 + 2 * c + 1] = gx0[1].i;
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      gan[G::A1 + (c * 4 + m) * 2] = gx1[0][m].r;  gan[G::A1 + (c * 4 + m) * 2 + 1] = gx1[0][m].i;
-      gan[G::A2 + (c * 4 + m) * 2] = gx1[1][m].r;  gan[G::A2 + (c * 4 + m) * 2 + 1] = gx1[1][m].i;
-    }
-    // node block + power blocks: sq(0,0) = [<v,v>, s^2], sq(1,1) = [v s, s v]
-    cx<double> gs = gx0[2];
-    cfmac(gs, cx<double>{2.0 * gx0[4].r, 2.0 * gx0[4].i}, s);
-    double* gdn = gd + (n * C + c) * 10;
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      const cx<double> gvs = {gx1[3][m].r + gx1[4][m].r, gx1[3][m].i + gx1[4][m].i};
-      cfmac(gs, gvs, v[m]);
-      cx<double> gv = gx1[2][m];
-      cfmac(gv, gvs, s);
-      cfmac(gv, gx0[3], vt[m]);
-      gdn[2 + m] = gv.r;
-      gdn[6 + m] = gv.i;
-    }
-    gdn[0] = gs.r;
-    gdn[1] = gs.i;
   }
   STAMP(2);
   // ---------------- phase 1b: CatMix weight gradient over the jet's nodes -> this jet's partial row --------
-  // item = (node part, out channel o, cat slot k); the parts' sums meet in LDS (fixed order -> deterministic)
+  // lane = (node part, cat slot k): builds the slot's cat entry x of each of its nodes once and updates all out
+  // channels; the parts' sums meet in LDS in a fixed order (deterministic)
   {
     double* part = a.part_mix + (size_t)b * (4 * CO * K);
-    const int OK = CO * K, npart = F::mix_parts(CO), nper = (N + npart - 1) / npart;
-    double acc[2][4];
+    constexpr int NPART = F::MIXP;
+    const int OK = CO * K, nper = (N + NPART - 1) / NPART;
+    const int pi = tid / K, k = tid - pi * K;
+    cx<double> d0[8], d1[8];
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {                    // OK <= 2 * BLOCK (checked by the dispatcher)
-      const int item = tid + it * BLOCK;
-      cx<double> d0 = {0, 0}, d1 = {0, 0};
-      if (item < OK * npart) {
-        const int pi = item / OK, e = item - pi * OK;
-        const int o = e / K, k = e - o * K, q = k / C, c = k - q * C;
-        const int n1 = min(N, (pi + 1) * nper);
-        for (int n = pi * nper; n < n1; ++n) {
-          const double* g = go + (n * CO + o) * 10;
-          cx<double> x0, x1[4];
-          if (q < 2) {                                  // aggregate blocks, saved by the forward
-            const double* x = agl + (n * 2 * C + k) * 10;
-            x0 = {x[0], x[1]};
+    for (int o = 0; o < 8; ++o) d0[o] = d1[o] = {0, 0};
+    if (pi < NPART) {
+      const int q = k / C, c = k - q * C;
+      const int n1 = min(N, (pi + 1) * nper);
+      for (int n = pi * nper; n < n1; ++n) {
+        cx<double> x0, x1[4];
+        if (q < 2) {                                  // aggregate blocks, saved by the forward
+          const double* x = agl + (n * 2 * C + k) * 10;
+          x0 = {x[0], x[1]};
 #pragma unroll
-            for (int m = 0; m < 4; ++m) x1[m] = {x[2 + m], x[6 + m]};
-          } else {
-            const double* ni = nd + n * NS + c * 10;
-            const cx<double> s = {ni[0], ni[1]};
-            cx<double> v[4];
+          for (int m = 0; m < 4; ++m) x1[m] = {x[2 + m], x[6 + m]};
+        } else {
+          const double* ni = nd + n * NS + c * 10;
+          const cx<double> s = {ni[0], ni[1]};
+          cx<double> v[4];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) v[m] = {ni[2 + m], ni[6 + m]};
-            if (q == 2) {                               // node block
-              x0 = s;
+          for (int m = 0; m < 4; ++m) v[m] = {ni[2 + m], ni[6 + m]};
+          if (q == 2) {                               // node block
+            x0 = s;
 #pragma unroll
-              for (int m = 0; m < 4; ++m) x1[m] = v[m];
-            } else {                                    // power blocks: (0,0): <v,v> | s^2 ; (1,1): v s | s v
-              if (q == 3) { x0 = bil2(v, v); x0.r *= 0.5; x0.i *= 0.5; } else x0 = cmul(s, s);
+            for (int m = 0; m < 4; ++m) x1[m] = v[m];
+          } else {                                    // power blocks: (0,0): <v,v> | s^2 ; (1,1): v s | s v
+            if (q == 3) { x0 = bil2(v, v); x0.r *= 0.5; x0.i *= 0.5; } else x0 = cmul(s, s);
 #pragma unroll
-              for (int m = 0; m < 4; ++m) x1[m] = cmul(v[m], s);
-            }
+            for (int m = 0; m < 4; ++m) x1[m] = cmul(v[m], s);
           }
-          cfmac(d0, cx<double>{g[0], g[1]}, x0);
-#pragma unroll
-          for (int m = 0; m < 4; ++m) cfmac(d1, cx<double>{g[2 + m], g[6 + m]}, x1[m]);
         }
-      }
-      acc[it][0] = d0.r;  acc[it][1] = d0.i;  acc[it][2] = d1.r;  acc[it][3] = d1.i;
-    }
-    if (npart > 1) {                                    // OK * npart <= BLOCK: one item per thread
-      __syncthreads();                                  // every read of go / wm / agl is done: reuse the region
-      double* red = tr;
-      if (tid < OK * npart) {
 #pragma unroll
-        for (int x = 0; x < 4; ++x) red[tid * 4 + x] = acc[0][x];
-      }
-      __syncthreads();
-      if (tid < OK) {
+        for (int o = 0; o < 8; ++o)
+          if (o < CO) {
+            const double* g = go + (n * CO + o) * 10;
+            cfmac(d0[o], cx<double>{g[0], g[1]}, x0);
 #pragma unroll
-        for (int x = 0; x < 4; ++x) {
-          double v = red[tid * 4 + x];
-          for (int pi = 1; pi < npart; ++pi) v += red[(pi * OK + tid) * 4 + x];
-          acc[0][x] = v;
-        }
+            for (int m = 0; m < 4; ++m) cfmac(d1[o], cx<double>{g[2 + m], g[6 + m]}, x1[m]);
+          }
       }
     }
+    __syncthreads();                                  // every read of go / wm / agl is done: reuse the region
+    double* red = tr;
+    if (pi < NPART) {
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const int e = tid + it * BLOCK;
-      if (e < OK && (npart == 1 || it == 0)) {
-        const int o = e / K, k = e - o * K;
-        part[(0 * CO + o) * K + k] = acc[it][0];
-        part[(1 * CO + o) * K + k] = acc[it][1];
-        part[2 * CO * K + (0 * CO + o) * K + k] = acc[it][2];
-        part[2 * CO * K + (1 * CO + o) * K + k] = acc[it][3];
-      }
+      for (int o = 0; o < 8; ++o)
+        if (o < CO) {
+          double* r4 = red + ((pi * CO + o) * K + k) * 4;
+          r4[0] = d0[o].r;  r4[1] = d0[o].i;  r4[2] = d1[o].r;  r4[3] = d1[o].i;
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < OK; e += BLOCK) {
+      double v[4];
+#pragma unroll
+      for (int x = 0; x < 4; ++x) v[x] = red[e * 4 + x];
+      for (int pp = 1; pp < NPART; ++pp)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) v[x] += red[(pp * OK + e) * 4 + x];
+      const int o = e / K, kk = e - o * K;
+      part[(0 * CO + o) * K + kk] = v[0];
+      part[(1 * CO + o) * K + kk] = v[1];
+      part[2 * CO * K + (0 * CO + o) * K + kk] = v[2];
+      part[2 * CO * K + (1 * CO + o) * K + kk] = v[3];
     }
   }
 
@@ -614,7 +638,7 @@ template <int C, bool DEC>
 static int launch_bwd3(const LevelBwdArgs<double>& a, hipStream_t stream) {
   const size_t smem = Bwd3<C, DEC>::smem(a.N, a.CO);
   LGN_CHECK_ARG(smem <= 160 * 1024, "level_bwd: N=%d C=%d needs %zu B of LDS", a.N, a.C, smem);
-  LGN_CHECK_ARG(a.CO * 5 * C <= 2 * BLOCK, "level_bwd: C_in=%d C_out=%d unsupported", C, a.CO);
+  LGN_CHECK_ARG(a.CO <= 8, "level_bwd: C_out=%d unsupported (1..8)", a.CO);
   auto kern = level_bwd3_kernel<C, DEC>;
   if (smem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   hipLaunchKernelGGL(kern, dim3(a.B), dim3(BLOCK), smem, stream, a);
