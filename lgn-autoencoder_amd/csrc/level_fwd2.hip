@@ -61,7 +61,12 @@ struct Fwd2 {
   static constexpr int A3 = 0, A4 = 2 * C, A1 = 4 * C, A2 = 12 * C;
 };
 
-template <int C, bool DEC>
+// SEP (decoder only): the decoder's edge mask is identically zero, so its radial functions are the Linear biases --
+// per-channel constants R0, R1 (position_levels.py:184-188) -- and the aggregate over j separates into jet-level sums:
+//   A1_i = e0 sum_j v_j            A2_i = R1 (p_i sum_j s_j - sum_j s_j p_j)
+//   A4_i = e0 sum_j s_j            A3_i = R1 (<sum_j v_j, p_i> - sum_j <v_j, p_j>) / 2
+// O(N C) instead of O(N^2 C) work per jet, same values up to summation order.  SEP = false keeps the pair sweep.
+template <int C, bool DEC, bool SEP>
 __global__ __launch_bounds__(BLOCK) void level_fwd2_kernel(LevelArgs<double> a, int chunk) {
   using F = Fwd2<C, DEC>;
   constexpr int NG = F::NG;
@@ -73,7 +78,8 @@ __global__ __launch_bounds__(BLOCK) void level_fwd2_kernel(LevelArgs<double> a, 
   double* pj = nd + ((N * F::NS + 1) & ~1);                           // N * PS
   double* wm = pj + N * F::PS;                                        // 4 * CO * 5C
   double* agl = wm + 4 * CO * 5 * C;                                  // chunk rows * AGS: aggregate of a chunk of rows
-  uint8_t* mk = reinterpret_cast<uint8_t*>(agl + chunk * F::AGS);     // N
+  double* sums = agl + chunk * F::AGS;                                // 20 C: jet-level sums of the separable form
+  uint8_t* mk = reinterpret_cast<uint8_t*>(sums + 20 * C);            // N
 
   STAMP(0);
   load_jet<double, C, DEC>(a.s_in, a.v_in, a.p, a.mask, B, N, b, nd, pj, mk);
@@ -117,9 +123,80 @@ __global__ __launch_bounds__(BLOCK) void level_fwd2_kernel(LevelArgs<double> a, 
   __syncthreads();
   STAMP(1);
 
+  if constexpr (DEC && SEP) {
+    // jet-level sums per channel: S | VS[4] | SP[4] | VP.  Stage 1: thread = (node, channel) writes its 10 complex
+    // terms into the (still unused) aggregate rows; stage 2: thread = (channel, term) adds them up in node order
+    double total = 0.0;
+    for (int nb = 0; nb < N; nb += chunk) {
+      const int rows = min(chunk, N - nb);
+      for (int e = tid; e < rows * C; e += BLOCK) {
+        const int rl = e / C, c = e - rl * C, n = nb + rl;
+        const double* ni = nd + n * F::NS + c * 10;
+        const double* pn = pj + n * 8;
+        const cx<double> sn = {ni[0], ni[1]};
+        cx<double> v[4], pc[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          v[m] = {ni[2 + m], ni[6 + m]};
+          pc[m] = {pn[m], pn[4 + m]};
+        }
+        double* t = agl + e * 20;
+        t[0] = sn.r;  t[1] = sn.i;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          t[2 + 2 * m] = v[m].r;  t[3 + 2 * m] = v[m].i;
+          const cx<double> sp = cmul(sn, pc[m]);
+          t[10 + 2 * m] = sp.r;  t[11 + 2 * m] = sp.i;
+        }
+        const cx<double> vp = bil2(v, pc);
+        t[18] = vp.r;  t[19] = vp.i;
+      }
+      __syncthreads();
+      if (tid < 20 * C) {
+        const int c = tid / 20, k = tid - c * 20;
+        for (int rl = 0; rl < rows; ++rl) total += agl[(rl * C + c) * 20 + k];
+      }
+      __syncthreads();
+    }
+    if (tid < 20 * C) sums[tid] = total;
+    __syncthreads();
+  }
+
   // rows are processed in chunks of `chunk` (a multiple of 16; the whole jet when it fits the LDS budget)
   for (int c0 = 0; c0 < N; c0 += chunk) {
   const int c1 = min(N, c0 + chunk);
+  if constexpr (DEC && SEP) {
+    for (int e = tid; e < (c1 - c0) * C; e += BLOCK) {
+      const int rl = e / C, c = e - rl * C, n = c0 + rl;
+      const double* sm = sums + c * 20;
+      const double* pn = pj + n * 8;
+      const cx<double> R0 = {a.b0[c], a.b0[c]}, R1 = {a.b1[c], a.b1[c]};
+      const cx<double> e0 = {R0.r - R0.i, R0.r + R0.i};
+      const cx<double> S = {sm[0], sm[1]};
+      cx<double> VS[4], pc[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        VS[m] = {sm[2 + 2 * m], sm[3 + 2 * m]};
+        pc[m] = {pn[m], pn[4 + m]};
+      }
+      double* st = agl + rl * F::AGS;
+      const cx<double> a4 = cmul(S, e0);
+      cx<double> t = bil2(VS, pc);
+      t.r -= sm[18];  t.i -= sm[19];
+      cx<double> a3 = cmul(R1, t);
+      st[F::A3 + 2 * c] = 0.5 * a3.r;  st[F::A3 + 2 * c + 1] = 0.5 * a3.i;
+      st[F::A4 + 2 * c] = a4.r;        st[F::A4 + 2 * c + 1] = a4.i;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const cx<double> a1 = cmul(VS[m], e0);
+        cx<double> u = cmul(pc[m], S);
+        u.r -= sm[10 + 2 * m];  u.i -= sm[11 + 2 * m];
+        const cx<double> a2 = cmul(R1, u);
+        st[F::A1 + (c * 4 + m) * 2] = a1.r;  st[F::A1 + (c * 4 + m) * 2 + 1] = a1.i;
+        st[F::A2 + (c * 4 + m) * 2] = a2.r;  st[F::A2 + (c * 4 + m) * 2 + 1] = a2.i;
+      }
+    }
+  } else
   for (int rg = (c0 >> 2) + wave; rg * 4 < c1; rg += 4) {
     const int i0 = rg * 4;
     const int i = i0 + ti;
@@ -331,12 +408,12 @@ __global__ __launch_bounds__(BLOCK) void level_fwd2_kernel(LevelArgs<double> a, 
   STAMP(40);
 }
 
-template <int C, bool DEC>
+template <int C, bool DEC, bool SEP>
 static int launch_level_fwd2(const LevelArgs<double>& a, hipStream_t stream) {
   using F = Fwd2<C, DEC>;
   // aggregate rows kept in LDS: the whole jet if that still leaves room for two workgroups per CU (or nothing does),
   // else as many 16-row slabs as fit next to the node data
-  const size_t fixed = sizeof(double) * (((size_t)a.N * F::NS + 1 & ~size_t(1)) + (size_t)a.N * F::PS + 4 * a.CO * 5 * C) + a.N + 16;
+  const size_t fixed = sizeof(double) * (((size_t)a.N * F::NS + 1 & ~size_t(1)) + (size_t)a.N * F::PS + 4 * a.CO * 5 * C + 20 * C) + a.N + 16;
   const size_t row = sizeof(double) * F::AGS, budget2 = 78 * 1024, budget1 = 160 * 1024;
   const int full = (a.N + 15) & ~15;
   int chunk = full;
@@ -348,7 +425,7 @@ static int launch_level_fwd2(const LevelArgs<double>& a, hipStream_t stream) {
   }
   const size_t smem = fixed + chunk * row;
   LGN_CHECK_ARG(smem <= 160 * 1024, "level_fwd: N=%d C=%d needs %zu B of LDS (> 160 KiB)", a.N, a.C, smem);
-  auto kern = level_fwd2_kernel<C, DEC>;
+  auto kern = level_fwd2_kernel<C, DEC, SEP>;
   if (smem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
@@ -361,9 +438,12 @@ static int launch_level_fwd2(const LevelArgs<double>& a, hipStream_t stream) {
 int level_fwd2_dispatch(const LevelArgs<double>& a, int decoder, hipStream_t stream) {
   LGN_CHECK_ARG(a.B > 0 && a.N > 0, "level_fwd: empty batch (B=%d N=%d)", a.B, a.N);
   LGN_CHECK_ARG(a.CO >= 1 && a.CO <= 8, "level_fwd: C_out=%d unsupported (1..8)", a.CO);
-#define LGN_CASE(CC)                                                              \
-  case CC:                                                                        \
-    return decoder ? launch_level_fwd2<CC, true>(a, stream) : launch_level_fwd2<CC, false>(a, stream);
+  // LGN_AMD_DEC_PAIRWISE=1 keeps the decoder on the O(N^2) pair sweep (cross-check of the separable form)
+  static const bool pairwise = [] { const char* e = getenv("LGN_AMD_DEC_PAIRWISE"); return e && e[0] == '1'; }();
+#define LGN_CASE(CC)                                                                                         \
+  case CC:                                                                                                   \
+    if (!decoder) return launch_level_fwd2<CC, false, false>(a, stream);                                     \
+    return pairwise ? launch_level_fwd2<CC, true, false>(a, stream) : launch_level_fwd2<CC, true, true>(a, stream);
   switch (a.C) {
     LGN_CASE(1) LGN_CASE(2) LGN_CASE(3) LGN_CASE(4) LGN_CASE(5) LGN_CASE(6) LGN_CASE(7) LGN_CASE(8)
     default:
