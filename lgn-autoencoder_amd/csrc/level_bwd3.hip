@@ -70,13 +70,19 @@ struct Bwd3 {
     if (red > p1) p1 = red;
     return p1 > (size_t)TRSZ ? p1 : (size_t)TRSZ;
   }
+  static constexpr int SEPSZ = DEC ? 50 * C : 0;        // jet-level sums of the separable decoder form
   static size_t smem(int N, int CO) {
     return sizeof(double) * ((((size_t)N * NS + 1) & ~size_t(1)) + (size_t)N * 20 * C + (size_t)N * 10 * C + (size_t)N * PS +
-                             scratch(N, CO)) + N + 16;
+                             scratch(N, CO) + SEPSZ) + N + 16;
   }
 };
 
-template <int C, bool DEC>
+// SEP (decoder only): with the decoder's all-zero edge mask the radial weights are the per-channel constants R0, R1, so
+// every sum over pairs separates into jet-level sums (see level_fwd2.hip); the pair sweep (phases 2, 3) is replaced by
+//   stage 1   per (node, channel): the node's terms of S, VS, SP, VP (forward) and of the sums of g_ag (backward)
+//   stage 2   per (channel, term): sum over the nodes in node order
+//   outputs   node gradient, position gradient and bias gradients from O(N C) closed forms.
+template <int C, bool DEC, bool SEP>
 __global__ __launch_bounds__(BLOCK) void level_bwd3_kernel(LevelBwdArgs<double> a) {
   using F = Bwd3<C, DEC>;
   using G = GA3<C>;
@@ -93,7 +99,8 @@ __global__ __launch_bounds__(BLOCK) void level_bwd3_kernel(LevelBwdArgs<double> 
   double* go = tr;                                             // ... phase 1: N * 10CO upstream gradient [n][o][s2|v8]
   double* wm = go + N * 10 * CO;                               //              4 * CO * K CatMix weights
   double* agl = wm + 4 * CO * K;                               //              N * 2C * 10 aggregate [n][q*C+c][s2|v8]
-  uint8_t* mk = reinterpret_cast<uint8_t*>(tr + F::scratch(N, CO));
+  double* sm = tr + F::scratch(N, CO);                         // decoder: 50 C jet-level sums
+  uint8_t* mk = reinterpret_cast<uint8_t*>(sm + F::SEPSZ);
 
   // ---------------- staging ----------------------------------------------------------------------------
   STAMP(0);
@@ -283,6 +290,168 @@ __global__ __launch_bounds__(BLOCK) void level_bwd3_kernel(LevelBwdArgs<double> 
       part[2 * CO * K + (0 * CO + o) * K + kk] = v[2];
       part[2 * CO * K + (1 * CO + o) * K + kk] = v[3];
     }
+  }
+
+  if constexpr (DEC && SEP) {
+    __syncthreads();                                    // g_ag / gd are complete; the phase-1 scratch is dead
+    // ---- jet-level sums, three rounds of <= 20 reals per (node, channel) through the scratch region -----------
+    //   sm[c*50 + ..]: S 0 | VS[m] 2+2m | SP[m] 10+2m | VP 18 | SG4 20 | SG3 22 | SG1[m] 24+2m | SG2[m] 32+2m | GP2 40 | GP3[m] 42+2m
+    //   (g_A3 enters with its factor 1/2 everywhere)
+#pragma unroll
+    for (int round = 0; round < 3; ++round) {
+      const int nv = round == 2 ? 10 : 20;
+      for (int e = tid; e < N * C; e += BLOCK) {
+        const int n = e / C, c = e - n * C;
+        const double* ni = nd + n * NS + c * 10;
+        const double* pn = pj + n * 8;
+        const double* gi = ga + n * G::SIZE;
+        double* t = tr + e * 20;
+        cx<double> pc[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) pc[m] = {pn[m], pn[4 + m]};
+        if (round == 0) {
+          const cx<double> sn = {ni[0], ni[1]};
+          cx<double> v[4];
+#pragma unroll
+          for (int m = 0; m < 4; ++m) v[m] = {ni[2 + m], ni[6 + m]};
+          t[0] = sn.r;  t[1] = sn.i;
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            t[2 + 2 * m] = v[m].r;  t[3 + 2 * m] = v[m].i;
+            const cx<double> sp = cmul(sn, pc[m]);
+            t[10 + 2 * m] = sp.r;  t[11 + 2 * m] = sp.i;
+          }
+          const cx<double> vp = bil2(v, pc);
+          t[18] = vp.r;  t[19] = vp.i;
+        } else if (round == 1) {
+          t[0] = gi[G::A4 + 2 * c];        t[1] = gi[G::A4 + 2 * c + 1];
+          t[2] = 0.5 * gi[G::A3 + 2 * c];  t[3] = 0.5 * gi[G::A3 + 2 * c + 1];
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            t[4 + 2 * m] = gi[G::A1 + (c * 4 + m) * 2];   t[5 + 2 * m] = gi[G::A1 + (c * 4 + m) * 2 + 1];
+            t[12 + 2 * m] = gi[G::A2 + (c * 4 + m) * 2];  t[13 + 2 * m] = gi[G::A2 + (c * 4 + m) * 2 + 1];
+          }
+        } else {
+          const cx<double> g3 = {0.5 * gi[G::A3 + 2 * c], 0.5 * gi[G::A3 + 2 * c + 1]};
+          cx<double> gp2 = {0, 0};
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            cfmac(gp2, cx<double>{gi[G::A2 + (c * 4 + m) * 2], gi[G::A2 + (c * 4 + m) * 2 + 1]}, pc[m]);
+            const cx<double> gp3 = cmulc(g3, pc[m]);
+            t[2 + 2 * m] = gp3.r;  t[3 + 2 * m] = gp3.i;
+          }
+          t[0] = gp2.r;  t[1] = gp2.i;
+        }
+      }
+      __syncthreads();
+      if (tid < nv * C) {
+        const int c = tid / nv, k = tid - c * nv;
+        double total = 0.0;
+        for (int n = 0; n < N; ++n) total += tr[(n * C + c) * 20 + k];
+        sm[c * 50 + round * 20 + k] = total;
+      }
+      __syncthreads();
+    }
+
+    // ---- node gradient: neighbour part from the sums + direct part, written once --------------------------------
+    const size_t pls = (size_t)B * N * C;
+    for (int e = tid; e < N * C; e += BLOCK) {
+      const int n = e / C, c = e - n * C;
+      const double* q = sm + c * 50;
+      const double* pn = pj + n * 8;
+      const double* gdn = gd + e * 10;
+      const cx<double> R0 = {a.b0[c], a.b0[c]}, R1 = {a.b1[c], a.b1[c]};
+      const cx<double> e0 = {R0.r - R0.i, R0.r + R0.i};
+      cx<double> pc[4], pt[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) pc[m] = {pn[m], pn[4 + m]};
+      metric_perm(pc, pt);
+      const cx<double> SG4 = {q[20], q[21]}, SG3 = {q[22], q[23]}, GP2 = {q[40], q[41]};
+      cx<double> GP3[4], GPT3[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) GP3[m] = {q[42 + 2 * m], q[43 + 2 * m]};
+      metric_perm(GP3, GPT3);
+      // Gs = conj(e0) SG4 + conj(R1) (GP2 - sum_m SG2[m] conj(p[m]))
+      cx<double> u = GP2;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const cx<double> t = cmulc(cx<double>{q[32 + 2 * m], q[33 + 2 * m]}, pc[m]);
+        u.r -= t.r;  u.i -= t.i;
+      }
+      cx<double> gs = cmulc(SG4, e0);
+      cfmac(gs, u, R1);
+      const size_t ge = ((size_t)b * N + n) * C + c;
+      a.g_s_in[ge] = gdn[0] + gs.r;
+      a.g_s_in[pls + ge] = gdn[1] + gs.i;
+      // Gv[m] = conj(e0) SG1[m] + conj(R1) (GPT3[m] - SG3 conj(pt[m]))
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        cx<double> w = GPT3[m];
+        const cx<double> t = cmulc(SG3, pt[m]);
+        w.r -= t.r;  w.i -= t.i;
+        cx<double> gv = cmulc(cx<double>{q[24 + 2 * m], q[25 + 2 * m]}, e0);
+        cfmac(gv, w, R1);
+        a.g_v_in[ge * 4 + m] = gdn[2 + m] + gv.r;
+        a.g_v_in[pls * 4 + ge * 4 + m] = gdn[6 + m] + gv.i;
+      }
+    }
+    // ---- position gradient: d p_n[m] += sum_c conj(R1) [ gA2_n[m] conj(S) + gA3_n conj(VSt[m]) - SG2[m] conj(s_n) - SG3 conj(vt_n[m]) ]
+    {
+      const size_t plp = (size_t)B * N * 4;
+      for (int e = tid; e < N * 4; e += BLOCK) {
+        const int n = e >> 2, m = e & 3;
+        const int mp = m == 1 ? 3 : (m == 3 ? 1 : m);      // metric_perm index; component 2 changes sign
+        const double sg = m == 2 ? -1.0 : 1.0;
+        const double* gi = ga + n * G::SIZE;
+        cx<double> acc = {0, 0};
+        for (int c = 0; c < C; ++c) {
+          const double* q = sm + c * 50;
+          const double* ni = nd + n * NS + c * 10;
+          const cx<double> R1 = {a.b1[c], a.b1[c]};
+          const cx<double> S = {q[0], q[1]}, SG3 = {q[22], q[23]};
+          const cx<double> VSt = {sg * q[2 + 2 * mp], sg * q[3 + 2 * mp]};
+          const cx<double> vt = {sg * ni[2 + mp], sg * ni[6 + mp]};
+          const cx<double> g2 = {gi[G::A2 + (c * 4 + m) * 2], gi[G::A2 + (c * 4 + m) * 2 + 1]};
+          const cx<double> g3 = {0.5 * gi[G::A3 + 2 * c], 0.5 * gi[G::A3 + 2 * c + 1]};
+          cx<double> t = cmulc(g2, S);
+          cfmac(t, g3, VSt);
+          const cx<double> t2 = cmulc(cx<double>{q[32 + 2 * m], q[33 + 2 * m]}, cx<double>{ni[0], ni[1]});
+          t.r -= t2.r;  t.i -= t2.i;
+          const cx<double> t3 = cmulc(SG3, vt);
+          t.r -= t3.r;  t.i -= t3.i;
+          cfmac(acc, t, R1);
+        }
+        a.g_p[((size_t)b * N + n) * 4 + m] += acc.r;
+        a.g_p[plp + ((size_t)b * N + n) * 4 + m] += acc.i;
+      }
+    }
+    // ---- bias gradients of this jet ----------------------------------------------------------------------------
+    if (tid < 2 * C) {
+      const int lin = tid / C, c = tid - lin * C;
+      const double* q = sm + c * 50;
+      const cx<double> S = {q[0], q[1]};
+      double* part = a.part_rad + (size_t)blockIdx.x * rad_partial_size(C, true);
+      if (lin == 0) {
+        cx<double> E0 = cmulc(cx<double>{q[20], q[21]}, S);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) cfmac(E0, cx<double>{q[24 + 2 * m], q[25 + 2 * m]}, cx<double>{q[2 + 2 * m], q[3 + 2 * m]});
+        part[tid] = (E0.r + E0.i) + (E0.i - E0.r);          // R0 = b0 (1+i): d b0 = Re G_R0 + Im G_R0, G_R0 = G_e0 (1-i)
+      } else {
+        cx<double> VS[4], VSt[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) VS[m] = {q[2 + 2 * m], q[3 + 2 * m]};
+        metric_perm(VS, VSt);
+        cx<double> E1 = cmulc(cx<double>{q[40], q[41]}, S);
+        cx<double> neg = cmulc(cx<double>{q[22], q[23]}, cx<double>{q[18], q[19]});
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          cfmac(neg, cx<double>{q[32 + 2 * m], q[33 + 2 * m]}, cx<double>{q[10 + 2 * m], q[11 + 2 * m]});
+          cfmac(E1, cx<double>{q[42 + 2 * m], q[43 + 2 * m]}, VSt[m]);
+        }
+        part[tid] = (E1.r - neg.r) + (E1.i - neg.i);
+      }
+    }
+    return;
   }
 
   STAMP(3);
@@ -634,12 +803,12 @@ __global__ __launch_bounds__(BLOCK) void level_bwd3_kernel(LevelBwdArgs<double> 
 
 bool level_bwd3_fits(int N) { return N <= 40; }
 
-template <int C, bool DEC>
+template <int C, bool DEC, bool SEP>
 static int launch_bwd3(const LevelBwdArgs<double>& a, hipStream_t stream) {
   const size_t smem = Bwd3<C, DEC>::smem(a.N, a.CO);
   LGN_CHECK_ARG(smem <= 160 * 1024, "level_bwd: N=%d C=%d needs %zu B of LDS", a.N, a.C, smem);
   LGN_CHECK_ARG(a.CO <= 8, "level_bwd: C_out=%d unsupported (1..8)", a.CO);
-  auto kern = level_bwd3_kernel<C, DEC>;
+  auto kern = level_bwd3_kernel<C, DEC, SEP>;
   if (smem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   hipLaunchKernelGGL(kern, dim3(a.B), dim3(BLOCK), smem, stream, a);
   LGN_CHECK_LAUNCH();
@@ -648,7 +817,13 @@ static int launch_bwd3(const LevelBwdArgs<double>& a, hipStream_t stream) {
 
 // whole level backward in one launch; one CatMix partial row and one radial partial row per jet
 int level_bwd3_dispatch(const LevelBwdArgs<double>& a, int decoder, hipStream_t stream) {
-#define LGN_CASE(CC) case CC: return decoder ? launch_bwd3<CC, true>(a, stream) : launch_bwd3<CC, false>(a, stream);
+  // LGN_AMD_DEC_PAIRWISE=1 keeps the decoder on the O(N^2) pair sweep (cross-check of the separable form)
+  const char* pw_env = getenv("LGN_AMD_DEC_PAIRWISE");      // read per call: tests flip it
+  const bool pairwise = pw_env && pw_env[0] == '1';
+#define LGN_CASE(CC)                                                                \
+  case CC:                                                                          \
+    if (!decoder) return launch_bwd3<CC, false, false>(a, stream);                  \
+    return pairwise ? launch_bwd3<CC, true, false>(a, stream) : launch_bwd3<CC, true, true>(a, stream);
   switch (a.C) {
     LGN_CASE(1) LGN_CASE(2) LGN_CASE(3) LGN_CASE(4) LGN_CASE(5) LGN_CASE(6) LGN_CASE(7) LGN_CASE(8)
     default: set_error("level_bwd: C_in=%d unsupported (1..8)", a.C); return -1;

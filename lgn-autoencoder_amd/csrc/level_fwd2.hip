@@ -439,7 +439,8 @@ int level_fwd2_dispatch(const LevelArgs<double>& a, int decoder, hipStream_t str
   LGN_CHECK_ARG(a.B > 0 && a.N > 0, "level_fwd: empty batch (B=%d N=%d)", a.B, a.N);
   LGN_CHECK_ARG(a.CO >= 1 && a.CO <= 8, "level_fwd: C_out=%d unsupported (1..8)", a.CO);
   // LGN_AMD_DEC_PAIRWISE=1 keeps the decoder on the O(N^2) pair sweep (cross-check of the separable form)
-  static const bool pairwise = [] { const char* e = getenv("LGN_AMD_DEC_PAIRWISE"); return e && e[0] == '1'; }();
+  const char* pw_env = getenv("LGN_AMD_DEC_PAIRWISE");      // read per call: tests flip it
+  const bool pairwise = pw_env && pw_env[0] == '1';
 #define LGN_CASE(CC)                                                                                         \
   case CC:                                                                                                   \
     if (!decoder) return launch_level_fwd2<CC, false, false>(a, stream);                                     \

@@ -45,6 +45,18 @@ def _rand_level_params(O, C, CO, decoder, g):
 @pytest.mark.parametrize("C,CO,N,B", [(3, 3, 30, 3), (3, 4, 30, 2), (4, 4, 30, 2), (4, 3, 30, 2), (4, 4, 7, 2),
                                       (2, 5, 33, 2), (4, 4, 70, 1), (1, 1, 1, 1)])
 def test_level_fwd_bwd(dev, O, decoder, C, CO, N, B):
+    _level_case(dev, O, decoder, C, CO, N, B)
+
+
+@pytest.mark.parametrize("C,CO,N,B", [(4, 4, 30, 2), (3, 4, 30, 2), (4, 3, 7, 1)])
+def test_level_decoder_pair_sweep(dev, O, monkeypatch, C, CO, N, B):
+    """The decoder levels normally run the separable O(N C) form (edge mask == 0 -> constant radial weights);
+    LGN_AMD_DEC_PAIRWISE=1 keeps the O(N^2) pair sweep of the reference's formulation.  Both must match the oracle."""
+    monkeypatch.setenv("LGN_AMD_DEC_PAIRWISE", "1")
+    _level_case(dev, O, True, C, CO, N, B)
+
+
+def _level_case(dev, O, decoder, C, CO, N, B):
     from lgn import ops
     g = torch.Generator().manual_seed(100 * C + 10 * CO + N + int(decoder))
     cfg, plans, P = _rand_level_params(O, C, CO, decoder, g)
