@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LGN_AMD_ABI_VERSION 1
+#define LGN_AMD_ABI_VERSION 2
 
 int lgn_abi_version(void);
 const char* lgn_last_error(void);
@@ -171,7 +171,9 @@ int lgn_step_fwd_bwd_f64(const lgn_net_desc* d, const double* params, double* gr
                          const int64_t* enc_off, const int64_t* dec_off, const double* p4, const uint8_t* mask,
                          double* workspace, double* recon, double* loss_part, void* stream);
 /* grads += l1_lambda*sign(params) (utils/train.py:484-487); loss_out[0..2] = total, chamfer, sum|w|; optional Adam
- * (torch.optim.Adam defaults; the step counter lives on the device so that graph replays stay correct). */
+ * (torch.optim.Adam defaults; the step counter lives on the device so that graph replays stay correct).
+ * loss_out must hold 3 + LGN_FINALIZE_SCRATCH doubles: the results, then scratch for the per-workgroup |w| partials. */
+#define LGN_FINALIZE_SCRATCH 2048
 int lgn_step_finalize_f64(double* params, double* grads, long long n_params, const double* loss_part, int n_loss,
                           double l1_lambda, double* adam_m, double* adam_v, long long* step_dev,
                           double lr, double beta1, double beta2, double eps, int do_adam, double* loss_out, void* stream);

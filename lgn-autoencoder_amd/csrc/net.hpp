@@ -1,6 +1,7 @@
 // lgn-autoencoder_amd/csrc/net.hpp -- host launchers of net_kernels.hip (the O(N)-per-jet network ends).
 #pragma once
 #include "ops.hpp"
+#include "../../include/lgn_amd.h"
 
 namespace lgn {
 int enc_input_fwd(int B, int N, int C, const double* p4, const double* w0, const double* w1, double* s, double* v, hipStream_t);
@@ -17,8 +18,6 @@ int dec_input_bwd(int B, int N, int C, int Tin, const double* lat_v, const doubl
                   double* part /*[B][4C + 2 N Tin]*/, hipStream_t);
 int dec_output_loss(int B, int N, int C, const double* v, const double* wo1, const double* target, double loss_scale, double* recon,
                     double* loss_part /*[B]*/, double* g_v, double* part /*[B][2C]*/, hipStream_t);
-int loss_l1(const double* loss_part, int nB, const double* w, long n, double lambda, double* loss_out, long* step_dev, int bump,
-            hipStream_t);
-int l1_adam(long n, double* w, double* g, double* m, double* v, double lambda, double lr, double beta1, double beta2, double eps,
-            const long* step_dev, int do_adam, hipStream_t);
+int finalize_step(double* w, double* g, long n, const double* loss_part, int nB, double lambda, double* m, double* v, long* step_dev,
+                  double lr, double beta1, double beta2, double eps, int do_adam, double* loss_out, hipStream_t st);
 }  // namespace lgn

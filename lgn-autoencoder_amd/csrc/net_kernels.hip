@@ -90,31 +90,36 @@ __global__ void enc_input_fwd_kernel(int B, int N, int C, const double* __restri
   }
 }
 
-// partial rows [nblk][4C]: dW00 (re[C], im[C]) then dW11 (re[C], im[C]).  One workgroup per jet.
+// partial rows [nblk][4C]: dW00 (re[C], im[C]) then dW11 (re[C], im[C]).  One workgroup per jet:
+// thread = (node, channel) writes its four terms to LDS, thread = (term, channel) adds them up in node order.
 __global__ __launch_bounds__(BLOCK) void enc_input_bwd_kernel(int B, int N, int C, const double* __restrict__ p4,
                                                              const double* __restrict__ g_s, const double* __restrict__ g_v,
                                                              double* part) {
-  __shared__ double red[4];
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  double* tmp = reinterpret_cast<double*>(smem_raw);    // [N*C][4]
   const int b = blockIdx.x;
   const size_t pl = (size_t)B * N * C;
-  for (int c = 0; c < C; ++c) {
-    cx<double> d0 = {0, 0}, d1 = {0, 0};
-    for (int n = threadIdx.x; n < N; n += BLOCK) {
-      const double* p = p4 + ((size_t)b * N + n) * 4;
-      const double mass = sqrt(fabs(minkowski_sq_ref(p)));
-      cx<double> q[4];
-      canon_real(p, q);
-      const size_t e = ((size_t)b * N + n) * C + c;
-      d0.r += g_s[e] * mass;
-      d0.i += g_s[pl + e] * mass;
+  for (int i = threadIdx.x; i < N * C; i += BLOCK) {
+    const int n = i / C;
+    const double* p = p4 + ((size_t)b * N + n) * 4;
+    const double mass = sqrt(fabs(minkowski_sq_ref(p)));
+    cx<double> q[4];
+    canon_real(p, q);
+    const size_t e = (size_t)b * N * C + i;
+    cx<double> d1 = {0, 0};
 #pragma unroll
-      for (int m = 0; m < 4; ++m) cfmac(d1, cx<double>{g_v[e * 4 + m], g_v[pl * 4 + e * 4 + m]}, q[m]);
-    }
-    double a0 = block_sum(d0.r, red), a1 = block_sum(d0.i, red), a2 = block_sum(d1.r, red), a3 = block_sum(d1.i, red);
-    if (threadIdx.x == 0) {
-      double* row = part + (size_t)b * 4 * C;
-      row[c] = a0; row[C + c] = a1; row[2 * C + c] = a2; row[3 * C + c] = a3;
-    }
+    for (int m = 0; m < 4; ++m) cfmac(d1, cx<double>{g_v[e * 4 + m], g_v[pl * 4 + e * 4 + m]}, q[m]);
+    tmp[i * 4 + 0] = g_s[e] * mass;
+    tmp[i * 4 + 1] = g_s[pl + e] * mass;
+    tmp[i * 4 + 2] = d1.r;
+    tmp[i * 4 + 3] = d1.i;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < 4 * C) {
+    const int k = threadIdx.x / C, c = threadIdx.x - k * C;
+    double acc = 0.0;
+    for (int n = 0; n < N; ++n) acc += tmp[(n * C + c) * 4 + k];
+    part[(size_t)b * 4 * C + k * C + c] = acc;
   }
 }
 
@@ -189,18 +194,36 @@ __global__ __launch_bounds__(BLOCK) void enc_latent_fwd_kernel(int B, int N, int
 }
 
 // backward: scatter the latent gradient to the selected particles, undo rep_to_p and the MixReps.
-// part row per jet: dWl0 [2][Ts][C] then dWl1 [2][Tv][C]
+// part row per jet: dWl0 [2][Ts][C] then dWl1 [2][Tv][C].  The jet's node features and the mixing weights are staged
+// in LDS once; the weight gradient runs over (channel pair, node part) items whose parts meet in LDS in a fixed order.
+constexpr int LAT_PARTS = 4;
 __global__ __launch_bounds__(BLOCK) void enc_latent_bwd_kernel(int B, int N, int C, int Ts, int Tv,
                                                               const double* __restrict__ s, const double* __restrict__ v,
                                                               const double* __restrict__ wl0, const double* __restrict__ wl1,
                                                               const double* __restrict__ g_lat_s, const double* __restrict__ g_lat_v,
                                                               const int* __restrict__ idx, double* g_s, double* g_v, double* part) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
-  double* gy = reinterpret_cast<double*>(smem_raw);     // same layout as y in the forward; vectors become canonical grads
   const int b = blockIdx.x, TT = Ts + Tv;
   const int YS = 2 * Ts + 8 * Tv;
+  double* gy = reinterpret_cast<double*>(smem_raw);     // [N][YS] same layout as y in the forward; vectors become canonical grads
+  double* sv = gy + N * YS;                             // [N][C][10]: s re, im, v re[4], im[4]
+  double* w0l = sv + N * C * 10;                        // [2][Ts][C]
+  double* w1l = w0l + 2 * Ts * C;                       // [2][Tv][C]
+  double* red = w1l + 2 * Tv * C;                       // [LAT_PARTS][TT*C][2]
   const size_t pl = (size_t)B * N * C;
   for (int e = threadIdx.x; e < N * YS; e += BLOCK) gy[e] = 0.0;
+  for (int e = threadIdx.x; e < N * C; e += BLOCK) {
+    const size_t base = (size_t)b * N * C + e;
+    sv[e * 10] = s[base];
+    sv[e * 10 + 1] = s[pl + base];
+  }
+  for (int e = threadIdx.x; e < N * C * 4; e += BLOCK) {
+    const size_t base = (size_t)b * N * C * 4 + e;
+    sv[(e >> 2) * 10 + 2 + (e & 3)] = v[base];
+    sv[(e >> 2) * 10 + 6 + (e & 3)] = v[pl * 4 + base];
+  }
+  for (int e = threadIdx.x; e < 2 * Ts * C; e += BLOCK) w0l[e] = wl0[e];
+  for (int e = threadIdx.x; e < 2 * Tv * C; e += BLOCK) w1l[e] = wl1[e];
   __syncthreads();
   for (int e = threadIdx.x; e < 2 * TT; e += BLOCK) {    // (plane, channel) owners: no write conflicts
     const int z = e / TT, t = e - z * TT;
@@ -230,9 +253,9 @@ __global__ __launch_bounds__(BLOCK) void enc_latent_bwd_kernel(int B, int N, int
     const size_t base = ((size_t)b * N + n) * C + c;
     cx<double> as = {0, 0}, av[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
     for (int t = 0; t < Ts; ++t)
-      cfmac(as, cx<double>{gy[n * YS + 2 * t], gy[n * YS + 2 * t + 1]}, cx<double>{wl0[t * C + c], wl0[Ts * C + t * C + c]});
+      cfmac(as, cx<double>{gy[n * YS + 2 * t], gy[n * YS + 2 * t + 1]}, cx<double>{w0l[t * C + c], w0l[Ts * C + t * C + c]});
     for (int t = 0; t < Tv; ++t) {
-      const cx<double> w = {wl1[t * C + c], wl1[Tv * C + t * C + c]};
+      const cx<double> w = {w1l[t * C + c], w1l[Tv * C + t * C + c]};
       const double* o = gy + n * YS + 2 * Ts + 8 * t;
 #pragma unroll
       for (int m = 0; m < 4; ++m) cfmac(av[m], cx<double>{o[m], o[4 + m]}, w);
@@ -242,27 +265,39 @@ __global__ __launch_bounds__(BLOCK) void enc_latent_bwd_kernel(int B, int N, int
 #pragma unroll
     for (int m = 0; m < 4; ++m) { g_v[base * 4 + m] = av[m].r; g_v[pl * 4 + base * 4 + m] = av[m].i; }
   }
-  double* row = part + (size_t)b * 2 * TT * C;
-  for (int e = threadIdx.x; e < TT * C; e += BLOCK) {    // weight gradients of this jet
-    const int t = e / C, c = e - t * C;
+  // weight gradients of this jet: item = (node part, latent channel t, node channel c)
+  const int nper = (N + LAT_PARTS - 1) / LAT_PARTS;
+  for (int e = threadIdx.x; e < LAT_PARTS * TT * C; e += BLOCK) {
+    const int pi = e / (TT * C), r = e - pi * TT * C, t = r / C, c = r - t * C;
+    const int n1 = min(N, (pi + 1) * nper);
     cx<double> acc = {0, 0};
     if (t < Ts) {
-      for (int n = 0; n < N; ++n) {
-        const size_t base = ((size_t)b * N + n) * C + c;
-        cfmac(acc, cx<double>{gy[n * YS + 2 * t], gy[n * YS + 2 * t + 1]}, cx<double>{s[base], s[pl + base]});
-      }
-      row[t * C + c] = acc.r;
-      row[Ts * C + t * C + c] = acc.i;
+      for (int n = pi * nper; n < n1; ++n)
+        cfmac(acc, cx<double>{gy[n * YS + 2 * t], gy[n * YS + 2 * t + 1]}, cx<double>{sv[(n * C + c) * 10], sv[(n * C + c) * 10 + 1]});
     } else {
       const int tv = t - Ts;
-      for (int n = 0; n < N; ++n) {
-        const size_t base = ((size_t)b * N + n) * C + c;
+      for (int n = pi * nper; n < n1; ++n) {
         const double* o = gy + n * YS + 2 * Ts + 8 * tv;
+        const double* x = sv + (n * C + c) * 10;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) cfmac(acc, cx<double>{o[m], o[4 + m]}, cx<double>{v[base * 4 + m], v[(pl + base) * 4 + m]});
+        for (int m = 0; m < 4; ++m) cfmac(acc, cx<double>{o[m], o[4 + m]}, cx<double>{x[2 + m], x[6 + m]});
       }
-      row[2 * Ts * C + tv * C + c] = acc.r;
-      row[2 * Ts * C + Tv * C + tv * C + c] = acc.i;
+    }
+    red[e * 2] = acc.r;
+    red[e * 2 + 1] = acc.i;
+  }
+  __syncthreads();
+  double* row = part + (size_t)b * 2 * TT * C;
+  for (int e = threadIdx.x; e < TT * C; e += BLOCK) {
+    const int t = e / C, c = e - t * C;
+    double ar = red[e * 2], ai = red[e * 2 + 1];
+    for (int pi = 1; pi < LAT_PARTS; ++pi) { ar += red[(pi * TT * C + e) * 2]; ai += red[(pi * TT * C + e) * 2 + 1]; }
+    if (t < Ts) {
+      row[t * C + c] = ar;
+      row[Ts * C + t * C + c] = ai;
+    } else {
+      row[2 * Ts * C + (t - Ts) * C + c] = ar;
+      row[2 * Ts * C + Tv * C + (t - Ts) * C + c] = ai;
     }
   }
 }
@@ -306,38 +341,68 @@ __global__ __launch_bounds__(BLOCK) void dec_input_fwd_kernel(int B, int N, int 
 
 // backward.  g_p holds the gradient w.r.t. pdec accumulated by the levels.  part row per jet:
 //   dW00 [2][C] | dW11 [2][C] | dWg1 [2][N][Tin]
+// Every global operand is read once up front; the reductions over the particles run on LDS data.
 __global__ __launch_bounds__(BLOCK) void dec_input_bwd_kernel(int B, int N, int C, int Tin, const double* __restrict__ lat_v,
                                                              const double* __restrict__ wg1, const double* __restrict__ w1,
                                                              const double* __restrict__ pdec, const double* __restrict__ g_p,
                                                              const double* __restrict__ g_s0, const double* __restrict__ g_v0,
                                                              double* g_lat_v, double* part) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
-  double* gcart = reinterpret_cast<double*>(smem_raw);   // [N][8]
-  __shared__ double red[4];
+  double* gcan = reinterpret_cast<double*>(smem_raw);    // [N][8] gradient w.r.t. the canonical momenta
+  double* gcart = gcan + N * 8;                          // [N][8] gradient w.r.t. the complex Cartesian momenta
+  double* tmp = gcart + N * 8;                           // [N*C][4] input-mixing terms
+  double* wgl = tmp + N * C * 4;                         // [2][N][Tin]
+  double* latl = wgl + 2 * N * Tin;                      // [Tin][8]
   const int b = blockIdx.x;
   const size_t plp = (size_t)B * N * 4, pl = (size_t)B * N * C;
   double* row = part + (size_t)b * (4 * C + 2 * N * Tin);
-  for (int n = threadIdx.x; n < N; n += BLOCK) {
+  for (int e = threadIdx.x; e < 2 * N * Tin; e += BLOCK) wgl[e] = wg1[e];
+  for (int e = threadIdx.x; e < Tin * 4; e += BLOCK) {
+    latl[(e >> 2) * 8 + (e & 3)] = lat_v[(size_t)b * Tin * 4 + e];
+    latl[(e >> 2) * 8 + 4 + (e & 3)] = lat_v[((size_t)B + b) * Tin * 4 + e];
+  }
+  for (int e = threadIdx.x; e < N * 4; e += BLOCK) {     // (n, m): G_pc[m] = g_p + sum_c g_v0[c][m] conj(W11[c])
+    const int n = e >> 2, m = e & 3;
     const size_t node = (size_t)b * N + n;
+    cx<double> g = {g_p[node * 4 + m], g_p[plp + node * 4 + m]};
+    for (int c = 0; c < C; ++c) {
+      const size_t x = (node * C + c) * 4 + m;
+      cfmac(g, cx<double>{g_v0[x], g_v0[pl * 4 + x]}, cx<double>{w1[c], w1[C + c]});
+    }
+    gcan[n * 8 + m] = g.r;
+    gcan[n * 8 + 4 + m] = g.i;
+  }
+  for (int i = threadIdx.x; i < N * C; i += BLOCK) {     // (n, c): terms of dW00, dW11
+    const int n = i / C;
+    const size_t node = (size_t)b * N + n, e = (size_t)b * N * C + i;
+    cx<double> d0 = {0, 0}, d1 = {0, 0};
+    cfmac(d0, cx<double>{g_s0[e], g_s0[pl + e]}, cx<double>{1.0, 1.0});
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+      cfmac(d1, cx<double>{g_v0[e * 4 + m], g_v0[pl * 4 + e * 4 + m]}, cx<double>{pdec[node * 4 + m], pdec[plp + node * 4 + m]});
+    tmp[i * 4 + 0] = d0.r;  tmp[i * 4 + 1] = d0.i;  tmp[i * 4 + 2] = d1.r;  tmp[i * 4 + 3] = d1.i;
+  }
+  __syncthreads();
+  for (int n = threadIdx.x; n < N; n += BLOCK) {
     cx<double> g[4], gc[4];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) g[m] = {g_p[node * 4 + m], g_p[plp + node * 4 + m]};
-    for (int c = 0; c < C; ++c) {
-      const cx<double> w = {w1[c], w1[C + c]};
-      const size_t e = node * C + c;
-#pragma unroll
-      for (int m = 0; m < 4; ++m) cfmac(g[m], cx<double>{g_v0[e * 4 + m], g_v0[pl * 4 + e * 4 + m]}, w);
-    }
+    for (int m = 0; m < 4; ++m) g[m] = {gcan[n * 8 + m], gcan[n * 8 + 4 + m]};
     canon_cplx_bwd(g, gc);
 #pragma unroll
     for (int m = 0; m < 4; ++m) { gcart[n * 8 + m] = gc[m].r; gcart[n * 8 + 4 + m] = gc[m].i; }
+  }
+  if ((int)threadIdx.x >= 64 && (int)threadIdx.x < 64 + 4 * C) {   // input mixing weights (a wave that is idle above)
+    const int k = (threadIdx.x - 64) / C, c = (threadIdx.x - 64) - k * C;
+    double acc = 0.0;
+    for (int n = 0; n < N; ++n) acc += tmp[(n * C + c) * 4 + k];
+    row[k * C + c] = acc;
   }
   __syncthreads();
   for (int e = threadIdx.x; e < Tin * 4; e += BLOCK) {    // g_lat_v[t][m] = sum_n G_cart[n][m] conj(Wg1[n][t])
     const int t = e >> 2, m = e & 3;
     cx<double> acc = {0, 0};
     for (int n = 0; n < N; ++n)
-      cfmac(acc, cx<double>{gcart[n * 8 + m], gcart[n * 8 + 4 + m]}, cx<double>{wg1[n * Tin + t], wg1[N * Tin + n * Tin + t]});
+      cfmac(acc, cx<double>{gcart[n * 8 + m], gcart[n * 8 + 4 + m]}, cx<double>{wgl[n * Tin + t], wgl[N * Tin + n * Tin + t]});
     g_lat_v[((size_t)b * Tin + t) * 4 + m] = acc.r;
     g_lat_v[(((size_t)B + b) * Tin + t) * 4 + m] = acc.i;
   }
@@ -346,22 +411,9 @@ __global__ __launch_bounds__(BLOCK) void dec_input_bwd_kernel(int B, int N, int 
     cx<double> acc = {0, 0};
 #pragma unroll
     for (int m = 0; m < 4; ++m)
-      cfmac(acc, cx<double>{gcart[n * 8 + m], gcart[n * 8 + 4 + m]},
-            cx<double>{lat_v[((size_t)b * Tin + t) * 4 + m], lat_v[(((size_t)B + b) * Tin + t) * 4 + m]});
+      cfmac(acc, cx<double>{gcart[n * 8 + m], gcart[n * 8 + 4 + m]}, cx<double>{latl[t * 8 + m], latl[t * 8 + 4 + m]});
     row[4 * C + e] = acc.r;
     row[4 * C + N * Tin + e] = acc.i;
-  }
-  for (int c = 0; c < C; ++c) {                           // input mixing weights
-    cx<double> d0 = {0, 0}, d1 = {0, 0};
-    for (int n = threadIdx.x; n < N; n += BLOCK) {
-      const size_t node = (size_t)b * N + n, e = node * C + c;
-      cfmac(d0, cx<double>{g_s0[e], g_s0[pl + e]}, cx<double>{1.0, 1.0});
-#pragma unroll
-      for (int m = 0; m < 4; ++m)
-        cfmac(d1, cx<double>{g_v0[e * 4 + m], g_v0[pl * 4 + e * 4 + m]}, cx<double>{pdec[node * 4 + m], pdec[plp + node * 4 + m]});
-    }
-    double a0 = block_sum(d0.r, red), a1 = block_sum(d0.i, red), a2 = block_sum(d1.r, red), a3 = block_sum(d1.i, red);
-    if (threadIdx.x == 0) { row[c] = a0; row[C + c] = a1; row[2 * C + c] = a2; row[3 * C + c] = a3; }
   }
 }
 
@@ -453,65 +505,52 @@ __global__ __launch_bounds__(BLOCK) void dec_output_loss_kernel(int B, int N, in
       g_v[pl * 4 + base * 4 + m] = r.i;
     }
   }
-  for (int c = 0; c < C; ++c) {
-    cx<double> d = {0, 0};
-    for (int n = threadIdx.x; n < N; n += BLOCK) {
-      cx<double> g[4], gc[4];
+  // dWo1[c] = sum_n sum_m G_yc[n][m] conj(v[n][c][m]): (n, c) terms to LDS (the distance scratch is dead), then 2C sums
+  __syncthreads();
+  double* tmp = x;                                        // [N*C][2] over x | tg (8N doubles >= 2NC for C <= 4) ...
+  double* tmpbig = reinterpret_cast<double*>(carg + N);   // ... or the spill region for wider outputs
+  if (2 * C > 8) tmp = tmpbig;
+  for (int e = threadIdx.x; e < N * C; e += BLOCK) {
+    const int n = e / C;
+    cx<double> g[4], gc[4], d = {0, 0};
 #pragma unroll
-      for (int m = 0; m < 4; ++m) g[m] = {gx[n * 4 + m], gx[n * 4 + m]};
-      cart_from_canon_bwd(g, gc);
-      const size_t base = ((size_t)b * N + n) * C + c;
+    for (int m = 0; m < 4; ++m) g[m] = {gx[n * 4 + m], gx[n * 4 + m]};
+    cart_from_canon_bwd(g, gc);
+    const size_t base = (size_t)b * N * C + e;
 #pragma unroll
-      for (int m = 0; m < 4; ++m) cfmac(d, gc[m], cx<double>{v[base * 4 + m], v[pl * 4 + base * 4 + m]});
-    }
-    double a0 = block_sum(d.r, red), a1 = block_sum(d.i, red);
-    if (threadIdx.x == 0) { part[(size_t)b * 2 * C + c] = a0; part[(size_t)b * 2 * C + C + c] = a1; }
+    for (int m = 0; m < 4; ++m) cfmac(d, gc[m], cx<double>{v[base * 4 + m], v[pl * 4 + base * 4 + m]});
+    tmp[e * 2] = d.r;
+    tmp[e * 2 + 1] = d.i;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < 2 * C) {
+    const int k = threadIdx.x / C, c = threadIdx.x - k * C;
+    double acc = 0.0;
+    for (int n = 0; n < N; ++n) acc += tmp[(n * C + c) * 2 + k];
+    part[(size_t)b * 2 * C + k * C + c] = acc;
   }
 }
 
 // ============================================================================================
 // L1 regularisation + loss assembly, Adam
 // ============================================================================================
-// loss_out[0] = chamfer + lambda * sum|w|, loss_out[1] = chamfer, loss_out[2] = sum|w|.  One workgroup.
-__global__ __launch_bounds__(1024) void loss_l1_kernel(const double* __restrict__ loss_part, int nB, const double* __restrict__ w,
-                                                      long n, double lambda, double* loss_out, long* step_dev, int bump) {
-  __shared__ double red[2][16];
-  double a = 0, l = 0, a1 = 0, a2 = 0, a3 = 0;
-  long i = threadIdx.x;
-  for (; i + 3 * 1024 < n; i += 4 * 1024) {      // four independent streams: the loads overlap
-    a += fabs(w[i]);
-    a1 += fabs(w[i + 1024]);
-    a2 += fabs(w[i + 2 * 1024]);
-    a3 += fabs(w[i + 3 * 1024]);
-  }
-  for (; i < n; i += 1024) a += fabs(w[i]);
-  a = (a + a1) + (a2 + a3);
-  for (int i = threadIdx.x; i < nB; i += 1024) l += loss_part[i];
-  a = group_sum<64>(a);
-  l = group_sum<64>(l);
-  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = l; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double sa = 0, sl = 0;
-    for (int q = 0; q < 16; ++q) { sa += red[0][q]; sl += red[1][q]; }
-    loss_out[0] = sl + lambda * sa;
-    loss_out[1] = sl;
-    loss_out[2] = sa;
-    if (bump) *step_dev += 1;          // optimiser step counter lives on the device (graph replays stay correct)
-  }
-}
-
-// g += lambda * sign(w); Adam update (torch.optim.Adam defaults: no weight decay, no amsgrad)
-__global__ void l1_adam_kernel(long n, double* w, double* g, double* m, double* v, double lambda, double lr, double beta1,
-                               double beta2, double eps, const long* step_dev, int do_adam) {
+// g += lambda * sign(w); Adam update (torch.optim.Adam defaults: no weight decay, no amsgrad).  The same pass adds up
+// |w| of the weights BEFORE the update (the L1 term of this step's loss) into one partial per workgroup.
+// The optimiser step counter lives on the device (graph replays stay correct): this step is number *step_dev + 1.
+__global__ __launch_bounds__(BLOCK) void l1_adam_kernel(long n, double* w, double* g, double* m, double* v, double lambda, double lr,
+                                                       double beta1, double beta2, double eps, const long* step_dev, int do_adam,
+                                                       double* l1_part) {
+  __shared__ double red[4];
   double bc1 = 1.0, bc2_sqrt = 1.0;
   if (do_adam) {
-    const double t = (double)*step_dev;
+    const double t = (double)(*step_dev + 1);
     bc1 = 1.0 - pow(beta1, t);
     bc2_sqrt = sqrt(1.0 - pow(beta2, t));
   }
+  double l1 = 0.0;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const double wi = w[i];
+    l1 += fabs(wi);
     const double gi = g[i] + lambda * ((wi > 0.0) - (wi < 0.0));
     g[i] = gi;
     if (do_adam) {
@@ -522,6 +561,25 @@ __global__ void l1_adam_kernel(long n, double* w, double* g, double* m, double* 
       const double denom = sqrt(vi) / bc2_sqrt + eps;
       w[i] = wi - (lr / bc1) * (mi / denom);
     }
+  }
+  l1 = block_sum(l1, red);
+  if (threadIdx.x == 0) l1_part[blockIdx.x] = l1;
+}
+
+// loss_out[0] = chamfer + lambda * sum|w|, loss_out[1] = chamfer, loss_out[2] = sum|w|; bumps the step counter.
+__global__ __launch_bounds__(BLOCK) void loss_final_kernel(const double* __restrict__ loss_part, int nB, const double* __restrict__ l1_part,
+                                                          int nblk, double lambda, double* loss_out, long* step_dev, int bump) {
+  __shared__ double red[4];
+  double a = 0, l = 0;
+  for (int i = threadIdx.x; i < nblk; i += BLOCK) a += l1_part[i];
+  for (int i = threadIdx.x; i < nB; i += BLOCK) l += loss_part[i];
+  a = block_sum(a, red);
+  l = block_sum(l, red);
+  if (threadIdx.x == 0) {
+    loss_out[0] = l + lambda * a;
+    loss_out[1] = l;
+    loss_out[2] = a;
+    if (bump) *step_dev += 1;
   }
 }
 
@@ -539,7 +597,7 @@ int enc_input_fwd(int B, int N, int C, const double* p4, const double* w0, const
   return 0;
 }
 int enc_input_bwd(int B, int N, int C, const double* p4, const double* g_s, const double* g_v, double* part, hipStream_t st) {
-  hipLaunchKernelGGL(enc_input_bwd_kernel, dim3(B), dim3(BLOCK), 0, st, B, N, C, p4, g_s, g_v, part);
+  hipLaunchKernelGGL(enc_input_bwd_kernel, dim3(B), dim3(BLOCK), sizeof(double) * N * C * 4, st, B, N, C, p4, g_s, g_v, part);
   LGN_CHECK_LAUNCH();
   return 0;
 }
@@ -556,7 +614,7 @@ int enc_latent_fwd(int B, int N, int C, int Ts, int Tv, const double* s, const d
 int enc_latent_bwd(int B, int N, int C, int Ts, int Tv, const double* s, const double* v, const double* wl0, const double* wl1,
                    const double* g_lat_s, const double* g_lat_v, const int* idx, double* g_s, double* g_v, double* part,
                    hipStream_t st) {
-  const size_t smem = latent_smem(N, Ts, Tv);
+  const size_t smem = latent_smem(N, Ts, Tv) + sizeof(double) * ((size_t)N * C * 10 + 2 * (Ts + Tv) * C + LAT_PARTS * (Ts + Tv) * C * 2);
   LGN_CHECK_ARG(smem <= 160 * 1024, "enc_latent_bwd: needs %zu B of LDS", smem);
   if (smem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(enc_latent_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   hipLaunchKernelGGL(enc_latent_bwd_kernel, dim3(B), dim3(BLOCK), smem, st, B, N, C, Ts, Tv, s, v, wl0, wl1, g_lat_s, g_lat_v, idx,
@@ -572,29 +630,32 @@ int dec_input_fwd(int B, int N, int C, int Tin, const double* lat_v, const doubl
 }
 int dec_input_bwd(int B, int N, int C, int Tin, const double* lat_v, const double* wg1, const double* w1, const double* pdec,
                   const double* g_p, const double* g_s0, const double* g_v0, double* g_lat_v, double* part, hipStream_t st) {
-  hipLaunchKernelGGL(dec_input_bwd_kernel, dim3(B), dim3(BLOCK), sizeof(double) * N * 8, st, B, N, C, Tin, lat_v, wg1, w1, pdec, g_p,
+  const size_t smem = sizeof(double) * ((size_t)N * 16 + (size_t)N * C * 4 + 2 * (size_t)N * Tin + (size_t)Tin * 8);
+  LGN_CHECK_ARG(smem <= 160 * 1024, "dec_input_bwd: needs %zu B of LDS", smem);
+  if (smem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_input_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipLaunchKernelGGL(dec_input_bwd_kernel, dim3(B), dim3(BLOCK), smem, st, B, N, C, Tin, lat_v, wg1, w1, pdec, g_p,
                      g_s0, g_v0, g_lat_v, part);
   LGN_CHECK_LAUNCH();
   return 0;
 }
 int dec_output_loss(int B, int N, int C, const double* v, const double* wo1, const double* target, double loss_scale, double* recon,
                     double* loss_part, double* g_v, double* part, hipStream_t st) {
-  const size_t smem = sizeof(double) * (size_t)N * 14 + sizeof(int) * (size_t)N * 2;
+  const size_t smem = sizeof(double) * (size_t)N * 14 + sizeof(int) * (size_t)N * 2 + 16 + (2 * C > 8 ? sizeof(double) * (size_t)N * C * 2 : 0);
   hipLaunchKernelGGL(dec_output_loss_kernel, dim3(B), dim3(BLOCK), smem, st, B, N, C, v, wo1, target, loss_scale, recon, loss_part,
                      g_v, part);
   LGN_CHECK_LAUNCH();
   return 0;
 }
-int loss_l1(const double* loss_part, int nB, const double* w, long n, double lambda, double* loss_out, long* step_dev, int bump,
-            hipStream_t st) {
-  hipLaunchKernelGGL(loss_l1_kernel, dim3(1), dim3(1024), 0, st, loss_part, nB, w, n, lambda, loss_out, step_dev, bump);
+// loss_out: 3 results followed by LGN_FINALIZE_SCRATCH doubles of scratch (per-workgroup |w| partials)
+int finalize_step(double* w, double* g, long n, const double* loss_part, int nB, double lambda, double* m, double* v, long* step_dev,
+                  double lr, double beta1, double beta2, double eps, int do_adam, double* loss_out, hipStream_t st) {
+  int nblk = grid_for((size_t)n);
+  if (nblk > LGN_FINALIZE_SCRATCH) nblk = LGN_FINALIZE_SCRATCH;
+  double* l1_part = loss_out + 3;
+  hipLaunchKernelGGL(l1_adam_kernel, dim3(nblk), dim3(BLOCK), 0, st, n, w, g, m, v, lambda, lr, beta1, beta2, eps, step_dev, do_adam,
+                     l1_part);
   LGN_CHECK_LAUNCH();
-  return 0;
-}
-int l1_adam(long n, double* w, double* g, double* m, double* v, double lambda, double lr, double beta1, double beta2, double eps,
-            const long* step_dev, int do_adam, hipStream_t st) {
-  hipLaunchKernelGGL(l1_adam_kernel, dim3(grid_for((size_t)n)), dim3(BLOCK), 0, st, n, w, g, m, v, lambda, lr, beta1, beta2, eps,
-                     step_dev, do_adam);
+  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(BLOCK), 0, st, loss_part, nB, l1_part, nblk, lambda, loss_out, step_dev, do_adam);
   LGN_CHECK_LAUNCH();
   return 0;
 }

@@ -341,9 +341,8 @@ int lgn_step_finalize_f64(double* params, double* grads, long long n_params, con
   LGN_CHECK_ARG(params && grads && loss_part && loss_out && n_params > 0 && n_loss > 0, "step_finalize: null pointer");
   LGN_CHECK_ARG(!do_adam || (adam_m && adam_v && step_dev), "step_finalize: Adam state missing");
   hipStream_t st = (hipStream_t)stream;
-  LGN_TRY(loss_l1(loss_part, n_loss, params, (long)n_params, l1_lambda, loss_out, reinterpret_cast<long*>(step_dev), do_adam, st));
-  LGN_TRY(l1_adam((long)n_params, params, grads, adam_m, adam_v, l1_lambda, lr, beta1, beta2, eps,
-                  reinterpret_cast<const long*>(step_dev), do_adam, st));
+  LGN_TRY(finalize_step(params, grads, (long)n_params, loss_part, n_loss, l1_lambda, adam_m, adam_v, reinterpret_cast<long*>(step_dev),
+                        lr, beta1, beta2, eps, do_adam, loss_out, st));
   return 0;
 }
 

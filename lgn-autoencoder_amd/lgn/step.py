@@ -186,7 +186,8 @@ class NativeTrainStep:
         self.workspace = torch.empty(nws, device=dev, dtype=dt)
         self.recon = torch.empty(2, d.B, d.N, 4, device=dev, dtype=dt)
         self.loss_part = torch.empty(d.B, device=dev, dtype=dt)
-        self.loss_out = torch.zeros(3, device=dev, dtype=dt)
+        self._loss_buf = torch.zeros(3 + N.FINALIZE_SCRATCH, device=dev, dtype=dt)   # results | scratch
+        self.loss_out = self._loss_buf[:3]
         self.adam_m = torch.zeros_like(self.flat.flat)
         self.adam_v = torch.zeros_like(self.flat.flat)
         self.step_dev = torch.zeros(1, device=dev, dtype=torch.int64)
@@ -209,7 +210,7 @@ class NativeTrainStep:
         rc = N.lib().lgn_step_finalize_f64(N.ptr(self.flat.flat), N.ptr(self.flat.grad), self.flat.flat.numel(), N.ptr(self.loss_part),
                                            self.loss_part.numel(), float(self.l1_lambda), N.ptr(self.adam_m), N.ptr(self.adam_v),
                                            N.ptr(self.step_dev), float(self.lr), float(self.betas[0]), float(self.betas[1]),
-                                           float(self.eps), int(do_adam), N.ptr(self.loss_out), N.stream_ptr())
+                                           float(self.eps), int(do_adam), N.ptr(self._loss_buf), N.stream_ptr())
         N._check(rc, "lgn_step_finalize_f64")
 
     def _capture(self):
