@@ -224,6 +224,7 @@ __global__ __launch_bounds__(BLOCK) void level_fwd2_kernel(LevelArgs<double> a, 
       const double* pjj = pj + jj * F::PS;
       cx<double> q[4];
       v4d R[NG];
+      double qd0 = 0.0, qd3 = 0.0, qa = 0.0, qb = 0.0;       // encoder: q = [d0, a - ib, d3, -a - ib] (real momenta)
       if (DEC) {
 #pragma unroll
         for (int m = 0; m < 4; ++m) q[m] = {pi[m] - pjj[m], pi[4 + m] - pjj[4 + m]};
@@ -240,6 +241,7 @@ __global__ __launch_bounds__(BLOCK) void level_fwd2_kernel(LevelArgs<double> a, 
         q[1] = {d1 * h, -d2 * h};
         q[2] = {d3, 0.0};
         q[3] = {-d1 * h, -d2 * h};
+        qd0 = d0;  qd3 = d3;  qa = d1 * h;  qb = d2 * h;
         double beta[5];
 #pragma unroll
         for (int s = 0; s < 5; ++s) {
@@ -263,18 +265,38 @@ __global__ __launch_bounds__(BLOCK) void level_fwd2_kernel(LevelArgs<double> a, 
             const cx<double> R0 = {R[g][0], R[g][1]}, R1 = {R[g][2], R[g][3]};
             const cx<double> e0 = {R0.r - R0.i, R0.r + R0.i};
             const cx<double> sj = {nj[ch * 10], nj[ch * 10 + 1]};
-            cx<double> vj[4], e1[4];
+            cx<double> vj[4];
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
               vj[m] = {nj[ch * 10 + 2 + m], nj[ch * 10 + 6 + m]};
-              e1[m] = cmul(R1, q[m]);
               cfma(A1[g][m], vj[m], e0);
-              cfma(A2[g][m], sj, e1[m]);
             }
             cfma(A4[g], sj, e0);
-            const cx<double> t = bil2(vj, e1);
-            A3[g].r += t.r;
-            A3[g].i += t.i;
+            if (!DEC) {
+              // e1[m] = R1 q[m] with real momenta q = [d0, a - ib, d3, -a - ib]:
+              //   A2[m] += (s_j R1) q[m],   A3 += R1 <v_j, q>,  <v_j, q> = v0 d0 - v2 d3 + a (v3 - v1) - ib (v1 + v3)
+              const cx<double> T = cmul(sj, R1);
+              A2[g][0].r = __builtin_fma(T.r, qd0, A2[g][0].r);  A2[g][0].i = __builtin_fma(T.i, qd0, A2[g][0].i);
+              A2[g][2].r = __builtin_fma(T.r, qd3, A2[g][2].r);  A2[g][2].i = __builtin_fma(T.i, qd3, A2[g][2].i);
+              const double aTr = qa * T.r, aTi = qa * T.i, bTr = qb * T.r, bTi = qb * T.i;
+              A2[g][1].r += aTr + bTi;  A2[g][1].i += aTi - bTr;       // T ( a - ib)
+              A2[g][3].r += bTi - aTr;  A2[g][3].i -= aTi + bTr;       // T (-a - ib)
+              const cx<double> dv = {vj[3].r - vj[1].r, vj[3].i - vj[1].i}, sv = {vj[1].r + vj[3].r, vj[1].i + vj[3].i};
+              cx<double> V;
+              V.r = __builtin_fma(vj[0].r, qd0, __builtin_fma(-vj[2].r, qd3, __builtin_fma(qa, dv.r, qb * sv.i)));
+              V.i = __builtin_fma(vj[0].i, qd0, __builtin_fma(-vj[2].i, qd3, __builtin_fma(qa, dv.i, -qb * sv.r)));
+              cfma(A3[g], R1, V);
+            } else {
+              cx<double> e1[4];
+#pragma unroll
+              for (int m = 0; m < 4; ++m) {
+                e1[m] = cmul(R1, q[m]);
+                cfma(A2[g][m], sj, e1[m]);
+              }
+              const cx<double> t = bil2(vj, e1);
+              A3[g].r += t.r;
+              A3[g].i += t.i;
+            }
           }
         }
       }
