@@ -217,31 +217,34 @@ __global__ __launch_bounds__(BLOCK) void level_fwd2_kernel(LevelArgs<double> a, 
     }
 
     STAMP(2 + ((rg >> 2) & 3) * 4);
-    for (int j0 = 0; j0 < N; j0 += 4) {
-      const int j = j0 + tj;
-      const bool ok = iok && j < N;
-      const int jj = j < N ? j : N - 1;
-      const double* pjj = pj + jj * F::PS;
-      cx<double> q[4];
+    // One tile = this row group x 4 neighbours (16 pairs).  prep(): geometry, basis functions and the radial Linear
+    // (matrix cores) of a tile; agg(): the CG aggregate of a tile.  The loop is software pipelined over two tile
+    // buffers: the MFMAs of tile t+1 are in flight while the VALU works through the aggregate of tile t.
+    struct Tile {
+      cx<double> q[4];                  // decoder: complex canonical difference
+      double qd0, qd3, qa, qb;          // encoder: q = [d0, a - ib, d3, -a - ib] (real momenta)
       v4d R[NG];
-      double qd0 = 0.0, qd3 = 0.0, qa = 0.0, qb = 0.0;       // encoder: q = [d0, a - ib, d3, -a - ib] (real momenta)
+      int jj;
+      bool ok;
+    };
+    auto prep = [&](int j0, Tile& T) {
+      const int j = j0 + tj;
+      T.ok = iok && j < N;
+      T.jj = j < N ? j : N - 1;
+      const double* pjj = pj + T.jj * F::PS;
       if (DEC) {
 #pragma unroll
-        for (int m = 0; m < 4; ++m) q[m] = {pi[m] - pjj[m], pi[4 + m] - pjj[4 + m]};
+        for (int m = 0; m < 4; ++m) T.q[m] = {pi[m] - pjj[m], pi[4 + m] - pjj[4 + m]};
 #pragma unroll
-        for (int g = 0; g < NG; ++g) R[g] = v4d{bias[g][0], bias[g][1], bias[g][2], bias[g][3]};
+        for (int g = 0; g < NG; ++g) T.R[g] = v4d{bias[g][0], bias[g][1], bias[g][2], bias[g][3]};
       } else {
         const double d0 = pi[0] - pjj[0], d1 = pi[1] - pjj[1], d2 = pi[2] - pjj[2], d3 = pi[3] - pjj[3];
         const double q0 = d0 * d0, q1 = d1 * d1, q2 = d2 * d2, q3 = d3 * d3;
         const double nsq = (2.0 * q0 - (((q0 + q1) + q2) + q3)) + 1e-16;       // zonal_functions.py:142,201-218
         const double an = fabs(nsq);                                            // (c * norm)^2 == c^2 |norm_sq|
-        const bool on = ok && mi && (mk[jj] != 0) && (nsq != 0.0);
+        const bool on = T.ok && mi && (mk[T.jj] != 0) && (nsq != 0.0);
         const double h = rsqrt2<double>();
-        q[0] = {d0, 0.0};
-        q[1] = {d1 * h, -d2 * h};
-        q[2] = {d3, 0.0};
-        q[3] = {-d1 * h, -d2 * h};
-        qd0 = d0;  qd3 = d3;  qa = d1 * h;  qb = d2 * h;
+        T.qd0 = d0;  T.qd3 = d3;  T.qa = d1 * h;  T.qb = d2 * h;
         double beta[5];
 #pragma unroll
         for (int s = 0; s < 5; ++s) {
@@ -251,18 +254,20 @@ __global__ __launch_bounds__(BLOCK) void level_fwd2_kernel(LevelArgs<double> a, 
         }
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-          R[g] = v4d{bias[g][0], bias[g][1], bias[g][2], bias[g][3]};
+          T.R[g] = v4d{bias[g][0], bias[g][1], bias[g][2], bias[g][3]};
 #pragma unroll
-          for (int s = 0; s < 5; ++s) R[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(wf[g][s], beta[s], R[g], 0, 0, 0);
+          for (int s = 0; s < 5; ++s) T.R[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(wf[g][s], beta[s], T.R[g], 0, 0, 0);
         }
       }
-      if (ok) {
-        const double* nj = nd + jj * F::NS;
+    };
+    auto agg = [&](const Tile& T) {
+      if (T.ok) {
+        const double* nj = nd + T.jj * F::NS;
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
           const int ch = 4 * g + cg;
           if (ch < C) {
-            const cx<double> R0 = {R[g][0], R[g][1]}, R1 = {R[g][2], R[g][3]};
+            const cx<double> R0 = {T.R[g][0], T.R[g][1]}, R1 = {T.R[g][2], T.R[g][3]};
             const cx<double> e0 = {R0.r - R0.i, R0.r + R0.i};
             const cx<double> sj = {nj[ch * 10], nj[ch * 10 + 1]};
             cx<double> vj[4];
@@ -275,10 +280,11 @@ __global__ __launch_bounds__(BLOCK) void level_fwd2_kernel(LevelArgs<double> a, 
             if (!DEC) {
               // e1[m] = R1 q[m] with real momenta q = [d0, a - ib, d3, -a - ib]:
               //   A2[m] += (s_j R1) q[m],   A3 += R1 <v_j, q>,  <v_j, q> = v0 d0 - v2 d3 + a (v3 - v1) - ib (v1 + v3)
-              const cx<double> T = cmul(sj, R1);
-              A2[g][0].r = __builtin_fma(T.r, qd0, A2[g][0].r);  A2[g][0].i = __builtin_fma(T.i, qd0, A2[g][0].i);
-              A2[g][2].r = __builtin_fma(T.r, qd3, A2[g][2].r);  A2[g][2].i = __builtin_fma(T.i, qd3, A2[g][2].i);
-              const double aTr = qa * T.r, aTi = qa * T.i, bTr = qb * T.r, bTi = qb * T.i;
+              const double qd0 = T.qd0, qd3 = T.qd3, qa = T.qa, qb = T.qb;
+              const cx<double> Tm = cmul(sj, R1);
+              A2[g][0].r = __builtin_fma(Tm.r, qd0, A2[g][0].r);  A2[g][0].i = __builtin_fma(Tm.i, qd0, A2[g][0].i);
+              A2[g][2].r = __builtin_fma(Tm.r, qd3, A2[g][2].r);  A2[g][2].i = __builtin_fma(Tm.i, qd3, A2[g][2].i);
+              const double aTr = qa * Tm.r, aTi = qa * Tm.i, bTr = qb * Tm.r, bTi = qb * Tm.i;
               A2[g][1].r += aTr + bTi;  A2[g][1].i += aTi - bTr;       // T ( a - ib)
               A2[g][3].r += bTi - aTr;  A2[g][3].i -= aTi + bTr;       // T (-a - ib)
               const cx<double> dv = {vj[3].r - vj[1].r, vj[3].i - vj[1].i}, sv = {vj[1].r + vj[3].r, vj[1].i + vj[3].i};
@@ -290,7 +296,7 @@ __global__ __launch_bounds__(BLOCK) void level_fwd2_kernel(LevelArgs<double> a, 
               cx<double> e1[4];
 #pragma unroll
               for (int m = 0; m < 4; ++m) {
-                e1[m] = cmul(R1, q[m]);
+                e1[m] = cmul(R1, T.q[m]);
                 cfma(A2[g][m], sj, e1[m]);
               }
               const cx<double> t = bil2(vj, e1);
@@ -299,6 +305,21 @@ __global__ __launch_bounds__(BLOCK) void level_fwd2_kernel(LevelArgs<double> a, 
             }
           }
         }
+      }
+    };
+    {
+      Tile ta, tb;
+      prep(0, ta);
+      int j0 = 0;
+      while (true) {
+        if (j0 + 4 < N) prep(j0 + 4, tb);
+        agg(ta);
+        j0 += 4;
+        if (j0 >= N) break;
+        if (j0 + 4 < N) prep(j0 + 4, ta);
+        agg(tb);
+        j0 += 4;
+        if (j0 >= N) break;
       }
     }
 
