@@ -294,6 +294,15 @@ __global__ __launch_bounds__(BLOCK) void level_bwd3_kernel(LevelBwdArgs<double> 
 
   if constexpr (DEC && SEP) {
     __syncthreads();                                    // g_ag / gd are complete; the phase-1 scratch is dead
+    // centre the momenta on the jet mean (only differences enter; see level_fwd2.hip)
+    if (tid < 8) {
+      double mean = 0.0;
+      for (int n = 0; n < N; ++n) mean += pj[n * 8 + tid];
+      sm[tid] = mean / N;
+    }
+    __syncthreads();
+    for (int e = tid; e < N * 8; e += BLOCK) pj[e] -= sm[e & 7];
+    __syncthreads();
     // ---- jet-level sums, three rounds of <= 20 reals per (node, channel) through the scratch region -----------
     //   sm[c*50 + ..]: S 0 | VS[m] 2+2m | SP[m] 10+2m | VP 18 | SG4 20 | SG3 22 | SG1[m] 24+2m | SG2[m] 32+2m | GP2 40 | GP3[m] 42+2m
     //   (g_A3 enters with its factor 1/2 everywhere)

@@ -124,6 +124,16 @@ __global__ __launch_bounds__(BLOCK) void level_fwd2_kernel(LevelArgs<double> a, 
   STAMP(1);
 
   if constexpr (DEC && SEP) {
+    // Only differences p_i - p_j enter: centre the momenta on the jet mean first, so that the separated sums
+    // p_i S - SP do not cancel digits the pair sweep would keep (boosted jets: |p| >> |p_i - p_j|).
+    if (tid < 8) {
+      double mean = 0.0;
+      for (int n = 0; n < N; ++n) mean += pj[n * 8 + tid];
+      sums[tid] = mean / N;
+    }
+    __syncthreads();
+    for (int e = tid; e < N * 8; e += BLOCK) pj[e] -= sums[e & 7];
+    __syncthreads();
     // jet-level sums per channel: S | VS[4] | SP[4] | VP.  Stage 1: thread = (node, channel) writes its 10 complex
     // terms into the (still unused) aggregate rows; stage 2: thread = (channel, term) adds them up in node order
     double total = 0.0;

@@ -51,12 +51,16 @@ def test_equivariance_harness_native_vs_cpu_path():
     ref = lgn_tests(None, oe, od, [{"p4": p4.clone(), "labels": labels.clone()}], unit="TeV")
     assert not check_equivariance(ref), "the CPU path itself violates the thresholds (harness bug?)"
 
-    # "equivariance error unchanged": same order of magnitude as the reference CPU path at every angle / boost
+    # "equivariance error unchanged": same order of magnitude as the reference CPU path at every angle / boost.
+    # The deviation is rounding noise that grows like eps * gamma^2 (CPU path: 1.5e-15..2.6e-15 gamma^2 at gamma >= 1e3)
+    # and scatters by an order of magnitude from one gamma to the next, so a point passes if it is within 20x of the
+    # CPU value at the same point OR under the smooth envelope 1e-13 + 1e-14 gamma^2.
     floor = 1e-13
-    for key in ("rot_dev_output", "boost_dev_output"):
-        for a, b in zip(res[key], ref[key]):
+    for key, xs in (("rot_dev_output", [1.0] * len(res["rot_dev_output"])), ("boost_dev_output", res["gammas"])):
+        for a, b, gam in zip(res[key], ref[key], xs):
             for irrep in a:
-                assert a[irrep] <= 20 * max(b[irrep], floor), f"{key} {irrep}: native {a[irrep]:.2e} vs cpu {b[irrep]:.2e}"
+                bound = max(20 * max(b[irrep], floor), floor + 1e-14 * float(gam) ** 2)
+                assert a[irrep] <= bound, f"{key} {irrep} gamma={float(gam):.4g}: native {a[irrep]:.2e} vs cpu {b[irrep]:.2e}"
     # internal features of every layer, rotations
     for per_angle in res["rot_dev_internal"]:
         for layer in per_angle:
