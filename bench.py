@@ -13,8 +13,8 @@ utils/train.py:280-343.  fp64 throughout (the reference's precision).
         bench.py --gpus N --steps K --warmup W
 
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
-  roofline     -- dominant kernel (the fused level forward of the widest encoder level), timed live with
-                  events on the launch stream, priced with SURVEY 8(d)'s algorithmic flop count
+  roofline     -- dominant kernel (the fused level BACKWARD of the widest encoder level; its forward twin is reported
+                  next to it), timed live with events on the launch stream, priced with SURVEY 8(d)'s algorithmic flops
   cpu_baseline -- the oracle (CPU restatement of the reference, materialised like the reference) timed on
                   this box's host cores on a bounded sample of the same workload (rank 0, N=1 only)
 """
@@ -63,34 +63,64 @@ def level_fwd_flops(N, C, CO, decoder):
 
 
 def time_dominant_kernel(enc, batch, reps=20):
-    """Average duration of the widest encoder level's fused forward kernel, measured with events on the
-    stream it is launched on (torch's current stream)."""
+    """Average duration of the dominant kernel -- the fused BACKWARD of the widest encoder level, the largest single
+    launch of the step (profiles/) -- and of the matching fused forward, measured with events on the stream they are
+    launched on (torch's current stream).  Both go through the C ABI with preallocated buffers; for N <= 40 the
+    backward is ONE kernel (level_bwd3_kernel), its partial-row reductions are separate launches and not timed here."""
+    import ctypes as C
     from lgn import _native as Nn
     lvl = max(range(enc.num_cg_levels), key=lambda l: enc.num_channels[l] * enc.num_channels[l + 1])
-    C, CO = enc.num_channels[lvl], enc.num_channels[lvl + 1]
+    Cc, CO = enc.num_channels[lvl], enc.num_channels[lvl + 1]
     dev = enc.device
     B, N = batch["p4"].shape[:2]
     g = torch.Generator(device="cpu").manual_seed(1)
-    s = torch.randn(2, B, N, C, dtype=torch.float64, generator=g).to(dev)
-    v = torch.randn(2, B, N, C, 4, dtype=torch.float64, generator=g).to(dev)
+    s = torch.randn(2, B, N, Cc, dtype=torch.float64, generator=g).to(dev)
+    v = torch.randn(2, B, N, Cc, 4, dtype=torch.float64, generator=g).to(dev)
     rad = tuple(t.detach().contiguous() for t in enc.rad_funcs.rad_funcs[lvl].flat_params())
     mix = enc.lgn_cg.node_levels[lvl].cat_mix.mix_reps
     wm0, wm1 = mix.weight((0, 0)).detach().contiguous(), mix.weight((1, 1)).detach().contiguous()
     p = batch["p4"].to(dev).contiguous()
     mask = batch["labels"].to(dev).contiguous()
-    for _ in range(3):
-        Nn.level_fwd(False, s, v, p, mask, rad, wm0, wm1)
-    torch.cuda.synchronize()
-    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    start.record()
-    for _ in range(reps):
-        Nn.level_fwd(False, s, v, p, mask, rad, wm0, wm1)
-    stop.record()
-    torch.cuda.synchronize()
-    # the loop also allocates 4 output tensors per call from torch's caching allocator (no device sync)
-    us = start.elapsed_time(stop) * 1e3 / reps
-    flops = B * level_fwd_flops(N, C, CO, False)
-    return {"kernel": f"level_fwd_kernel<double,{C},8,false>", "level": lvl, "us": us, "flops": flops}
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        start.record()
+        for _ in range(reps):
+            fn()
+        stop.record()
+        torch.cuda.synchronize()
+        return start.elapsed_time(stop) * 1e3 / reps
+
+    # forward (the loop also allocates 4 output tensors per call from torch's caching allocator: no device sync)
+    us_fwd = timed(lambda: Nn.level_fwd(False, s, v, p, mask, rad, wm0, wm1))
+    ag0, ag1, so, vo = Nn.level_fwd(False, s, v, p, mask, rad, wm0, wm1)
+    gs = torch.randn(so.shape, dtype=torch.float64, generator=g).to(dev)
+    gv = torch.randn(vo.shape, dtype=torch.float64, generator=g).to(dev)
+    L = Nn.lib()
+    rm, rr = C.c_int(), C.c_int()
+    Nn._check(L.lgn_level_bwd_partial_rows(B, N, 0, C.byref(rm), C.byref(rr)), "lgn_level_bwd_partial_rows")
+    part_mix = torch.empty(rm.value, 4 * CO * 5 * Cc, device=dev, dtype=torch.float64)
+    part_rad = torch.empty(rr.value, L.lgn_level_rad_partial_len(Cc, 0), device=dev, dtype=torch.float64)
+    g_ag = torch.empty(B, N, 20 * Cc, device=dev, dtype=torch.float64)
+    g_s_in, g_v_in = torch.empty_like(s), torch.empty_like(v)
+    a, b, c, w0, b0, w1, b1 = rad
+    P = Nn.ptr
+
+    def bwd():
+        rc = L.lgn_level_bwd_f64(B, N, Cc, CO, 0, P(s), P(v), P(p), P(mask), P(a), P(b), P(c), P(w0), P(b0), P(w1), P(b1),
+                                 P(wm0), P(wm1), P(ag0), P(ag1), P(gs), P(gv), P(g_ag), P(g_s_in), P(g_v_in), P(None),
+                                 P(part_mix), P(part_rad), Nn.stream_ptr())
+        Nn._check(rc, "lgn_level_bwd_f64")
+
+    us_bwd = timed(bwd)
+    fwd_flops = B * level_fwd_flops(N, Cc, CO, False)
+    single = N <= 40
+    return {"kernel": f"level_bwd3_kernel<{Cc}, false, false>" if single else "level_bwd (nodes2 + rad2 + mix kernels)",
+            "level": lvl, "us": us_bwd, "flops": 2 * fwd_flops,          # SURVEY 8(d): backward = 2 x forward
+            "forward": {"kernel": f"level_fwd2_kernel<{Cc}, false, false>", "us": us_fwd, "flops": fwd_flops}}
 
 
 def cpu_baseline(seconds_budget=25.0):
@@ -201,7 +231,13 @@ def main():
                                                    "FMA-bound, neither HBM- nor matrix-core-bound)",
                          "kernel": dom["kernel"], "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_VECTOR_PEAK_TFLOPS, "traffic": None,
-                         "us_per_launch": dom["us"], "algorithmic_flops_per_launch": dom["flops"]},
+                         "us_per_launch": dom["us"], "algorithmic_flops_per_launch": dom["flops"],
+                         "forward_kernel": {"kernel": dom["forward"]["kernel"], "us_per_launch": dom["forward"]["us"],
+                                            "algorithmic_flops_per_launch": dom["forward"]["flops"],
+                                            "achieved": dom["forward"]["flops"] / (dom["forward"]["us"] * 1e-6) / 1e12,
+                                            "frac": dom["forward"]["flops"] / (dom["forward"]["us"] * 1e-6) / 1e12 / FP64_VECTOR_PEAK_TFLOPS},
+                         "note": "the decoder levels run the separable O(N C) form (SURVEY a-14: an algorithmic change, "
+                                 "not counted as roofline gain); this kernel is an encoder level and is unaffected"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
