@@ -68,9 +68,14 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
 // ============================================================================================
 // encoder input
 // ============================================================================================
+// z1/z2: two buffers the step wants zeroed before anything later in the stream touches them (the flat gradient buffer and
+// the zero-initialised workspace block); folded into this first kernel instead of two memset launches.
 __global__ void enc_input_fwd_kernel(int B, int N, int C, const double* __restrict__ p4, const double* __restrict__ w0,
-                                     const double* __restrict__ w1, double* s, double* v) {
+                                     const double* __restrict__ w1, double* s, double* v, double* z1, size_t n1, double* z2,
+                                     size_t n2) {
   const size_t total = (size_t)B * N * C, pl = total;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n1; e += (size_t)gridDim.x * blockDim.x) z1[e] = 0.0;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n2; e += (size_t)gridDim.x * blockDim.x) z2[e] = 0.0;
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
     const int c = e % C;
     const size_t node = e / C;
@@ -127,11 +132,10 @@ __global__ __launch_bounds__(BLOCK) void enc_input_bwd_kernel(int B, int N, int 
 // encoder latent: MixReps -> Cartesian -> min&max pooling
 //   lat_s [2][B][2Ts]  (min block, max block), lat_v [2][B][2Tv][4], idx [B][2][Ts+Tv][2] (plane, channel, min/max)
 // ============================================================================================
-__global__ __launch_bounds__(BLOCK) void enc_latent_fwd_kernel(int B, int N, int C, int Ts, int Tv,
+__device__ __forceinline__ void enc_latent_fwd_body(int B, int N, int C, int Ts, int Tv,
                                                               const double* __restrict__ s, const double* __restrict__ v,
                                                               const double* __restrict__ wl0, const double* __restrict__ wl1,
-                                                              double* lat_s, double* lat_v, int* idx) {
-  extern __shared__ __align__(16) unsigned char smem_raw[];
+                                                              double* lat_s, double* lat_v, int* idx, unsigned char* smem_raw) {
   double* y = reinterpret_cast<double*>(smem_raw);      // [n][t] : scalars 2 (re,im), vectors 8 (cart re[4], im[4])
   const int b = blockIdx.x, TT = Ts + Tv;
   const int YS = 2 * Ts + 8 * Tv;                       // per-node stride
@@ -192,17 +196,23 @@ __global__ __launch_bounds__(BLOCK) void enc_latent_fwd_kernel(int B, int N, int
     }
   }
 }
+__global__ __launch_bounds__(BLOCK) void enc_latent_fwd_kernel(int B, int N, int C, int Ts, int Tv,
+                                                              const double* __restrict__ s, const double* __restrict__ v,
+                                                              const double* __restrict__ wl0, const double* __restrict__ wl1,
+                                                              double* lat_s, double* lat_v, int* idx) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  enc_latent_fwd_body(B, N, C, Ts, Tv, s, v, wl0, wl1, lat_s, lat_v, idx, smem_raw);
+}
 
 // backward: scatter the latent gradient to the selected particles, undo rep_to_p and the MixReps.
 // part row per jet: dWl0 [2][Ts][C] then dWl1 [2][Tv][C].  The jet's node features and the mixing weights are staged
 // in LDS once; the weight gradient runs over (channel pair, node part) items whose parts meet in LDS in a fixed order.
 constexpr int LAT_PARTS = 4;
-__global__ __launch_bounds__(BLOCK) void enc_latent_bwd_kernel(int B, int N, int C, int Ts, int Tv,
+__device__ __forceinline__ void enc_latent_bwd_body(int B, int N, int C, int Ts, int Tv,
                                                               const double* __restrict__ s, const double* __restrict__ v,
                                                               const double* __restrict__ wl0, const double* __restrict__ wl1,
                                                               const double* __restrict__ g_lat_s, const double* __restrict__ g_lat_v,
-                                                              const int* __restrict__ idx, double* g_s, double* g_v, double* part) {
-  extern __shared__ __align__(16) unsigned char smem_raw[];
+                                                              const int* __restrict__ idx, double* g_s, double* g_v, double* part, unsigned char* smem_raw) {
   const int b = blockIdx.x, TT = Ts + Tv;
   const int YS = 2 * Ts + 8 * Tv;
   double* gy = reinterpret_cast<double*>(smem_raw);     // [N][YS] same layout as y in the forward; vectors become canonical grads
@@ -301,14 +311,22 @@ __global__ __launch_bounds__(BLOCK) void enc_latent_bwd_kernel(int B, int N, int
     }
   }
 }
+__global__ __launch_bounds__(BLOCK) void enc_latent_bwd_kernel(int B, int N, int C, int Ts, int Tv,
+                                                              const double* __restrict__ s, const double* __restrict__ v,
+                                                              const double* __restrict__ wl0, const double* __restrict__ wl1,
+                                                              const double* __restrict__ g_lat_s, const double* __restrict__ g_lat_v,
+                                                              const int* __restrict__ idx, double* g_s, double* g_v, double* part) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  enc_latent_bwd_body(B, N, C, Ts, Tv, s, v, wl0, wl1, g_lat_s, g_lat_v, idx, g_s, g_v, part, smem_raw);
+}
 
 // ============================================================================================
 // decoder input: latent vectors -> particles (latent_to_graph) -> canonical momenta -> input_func_node
 //   pdec [2][B][N][4]; s0 [2][B][N][C] = W00[c] (1+1i); v0 [2][B][N][C][4] = W11[c] pc[n]
 // ============================================================================================
-__global__ __launch_bounds__(BLOCK) void dec_input_fwd_kernel(int B, int N, int C, int Tin, const double* __restrict__ lat_v,
+__device__ __forceinline__ void dec_input_fwd_body(int B, int N, int C, int Tin, const double* __restrict__ lat_v,
                                                              const double* __restrict__ wg1, const double* __restrict__ w0,
-                                                             const double* __restrict__ w1, double* pdec, double* s0, double* v0) {
+                                                             const double* __restrict__ w1, double* pdec, double* s0, double* v0, unsigned char* smem_raw) {
   const int b = blockIdx.x;
   const size_t plp = (size_t)B * N * 4, pl = (size_t)B * N * C;
   for (int n = threadIdx.x; n < N; n += BLOCK) {
@@ -338,16 +356,21 @@ __global__ __launch_bounds__(BLOCK) void dec_input_fwd_kernel(int B, int N, int 
     }
   }
 }
+__global__ __launch_bounds__(BLOCK) void dec_input_fwd_kernel(int B, int N, int C, int Tin, const double* __restrict__ lat_v,
+                                                             const double* __restrict__ wg1, const double* __restrict__ w0,
+                                                             const double* __restrict__ w1, double* pdec, double* s0, double* v0) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  dec_input_fwd_body(B, N, C, Tin, lat_v, wg1, w0, w1, pdec, s0, v0, smem_raw);
+}
 
 // backward.  g_p holds the gradient w.r.t. pdec accumulated by the levels.  part row per jet:
 //   dW00 [2][C] | dW11 [2][C] | dWg1 [2][N][Tin]
 // Every global operand is read once up front; the reductions over the particles run on LDS data.
-__global__ __launch_bounds__(BLOCK) void dec_input_bwd_kernel(int B, int N, int C, int Tin, const double* __restrict__ lat_v,
+__device__ __forceinline__ void dec_input_bwd_body(int B, int N, int C, int Tin, const double* __restrict__ lat_v,
                                                              const double* __restrict__ wg1, const double* __restrict__ w1,
                                                              const double* __restrict__ pdec, const double* __restrict__ g_p,
                                                              const double* __restrict__ g_s0, const double* __restrict__ g_v0,
-                                                             double* g_lat_v, double* part) {
-  extern __shared__ __align__(16) unsigned char smem_raw[];
+                                                             double* g_lat_v, double* part, unsigned char* smem_raw) {
   double* gcan = reinterpret_cast<double*>(smem_raw);    // [N][8] gradient w.r.t. the canonical momenta
   double* gcart = gcan + N * 8;                          // [N][8] gradient w.r.t. the complex Cartesian momenta
   double* tmp = gcart + N * 8;                           // [N*C][4] input-mixing terms
@@ -415,6 +438,39 @@ __global__ __launch_bounds__(BLOCK) void dec_input_bwd_kernel(int B, int N, int 
     row[4 * C + e] = acc.r;
     row[4 * C + N * Tin + e] = acc.i;
   }
+}
+__global__ __launch_bounds__(BLOCK) void dec_input_bwd_kernel(int B, int N, int C, int Tin, const double* __restrict__ lat_v,
+                                                             const double* __restrict__ wg1, const double* __restrict__ w1,
+                                                             const double* __restrict__ pdec, const double* __restrict__ g_p,
+                                                             const double* __restrict__ g_s0, const double* __restrict__ g_v0,
+                                                             double* g_lat_v, double* part) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  dec_input_bwd_body(B, N, C, Tin, lat_v, wg1, w1, pdec, g_p, g_s0, g_v0, g_lat_v, part, smem_raw);
+}
+
+// ============================================================================================
+// encoder -> decoder junction, one launch per direction: the decoder input of a jet needs only that jet's latent
+// vectors (and vice versa for the gradients), so the two per-jet kernels run back to back in the same workgroup.
+// ============================================================================================
+__global__ __launch_bounds__(BLOCK) void junction_fwd_kernel(int B, int N, int CL, int Ts, int Tv, const double* s, const double* v,
+                                                            const double* wl0, const double* wl1, double* lat_s, double* lat_v,
+                                                            int* idx, int C0, const double* wg1, const double* w0, const double* w1,
+                                                            double* pdec, double* s0, double* v0) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  enc_latent_fwd_body(B, N, CL, Ts, Tv, s, v, wl0, wl1, lat_s, lat_v, idx, smem_raw);
+  __syncthreads();                                       // this jet's lat_v (global) is visible to the whole workgroup
+  dec_input_fwd_body(B, N, C0, 2 * Tv, lat_v, wg1, w0, w1, pdec, s0, v0, smem_raw);
+}
+__global__ __launch_bounds__(BLOCK) void junction_bwd_kernel(int B, int N, int C0, int Tin, const double* lat_v, const double* wg1,
+                                                            const double* w1, const double* pdec, const double* g_p,
+                                                            const double* g_s0, const double* g_v0, double* g_lat_v, double* part_dec,
+                                                            int CL, int Ts, int Tv, const double* s, const double* v,
+                                                            const double* wl0, const double* wl1, const double* g_lat_s,
+                                                            const int* idx, double* g_s, double* g_v, double* part_enc) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  dec_input_bwd_body(B, N, C0, Tin, lat_v, wg1, w1, pdec, g_p, g_s0, g_v0, g_lat_v, part_dec, smem_raw);
+  __syncthreads();                                       // this jet's g_lat_v is visible; the LDS scratch is free again
+  enc_latent_bwd_body(B, N, CL, Ts, Tv, s, v, wl0, wl1, g_lat_s, g_lat_v, idx, g_s, g_v, part_enc, smem_raw);
 }
 
 // ============================================================================================
@@ -591,8 +647,10 @@ static int grid_for(size_t total) {
   return (int)(g < 2048 ? (g ? g : 1) : 2048);
 }
 
-int enc_input_fwd(int B, int N, int C, const double* p4, const double* w0, const double* w1, double* s, double* v, hipStream_t st) {
-  hipLaunchKernelGGL(enc_input_fwd_kernel, dim3(grid_for((size_t)B * N * C)), dim3(BLOCK), 0, st, B, N, C, p4, w0, w1, s, v);
+int enc_input_fwd(int B, int N, int C, const double* p4, const double* w0, const double* w1, double* s, double* v, hipStream_t st,
+                  double* z1, size_t n1, double* z2, size_t n2) {
+  hipLaunchKernelGGL(enc_input_fwd_kernel, dim3(grid_for((size_t)B * N * C)), dim3(BLOCK), 0, st, B, N, C, p4, w0, w1, s, v, z1, n1,
+                     z2, n2);
   LGN_CHECK_LAUNCH();
   return 0;
 }
@@ -646,6 +704,36 @@ int dec_output_loss(int B, int N, int C, const double* v, const double* wo1, con
   LGN_CHECK_LAUNCH();
   return 0;
 }
+static size_t latent_bwd_smem(int N, int C, int Ts, int Tv) {
+  return latent_smem(N, Ts, Tv) + sizeof(double) * ((size_t)N * C * 10 + 2 * (Ts + Tv) * C + LAT_PARTS * (Ts + Tv) * C * 2);
+}
+static size_t dec_input_bwd_smem(int N, int C, int Tin) {
+  return sizeof(double) * ((size_t)N * 16 + (size_t)N * C * 4 + 2 * (size_t)N * Tin + (size_t)Tin * 8);
+}
+int junction_fwd(int B, int N, int CL, int Ts, int Tv, const double* s, const double* v, const double* wl0, const double* wl1,
+                 double* lat_s, double* lat_v, int* idx, int C0, const double* wg1, const double* w0, const double* w1, double* pdec,
+                 double* s0, double* v0, hipStream_t st) {
+  const size_t smem = latent_smem(N, Ts, Tv);
+  LGN_CHECK_ARG(smem <= 160 * 1024, "junction_fwd: N=%d tau=(%d,%d) needs %zu B of LDS", N, Ts, Tv, smem);
+  if (smem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(junction_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipLaunchKernelGGL(junction_fwd_kernel, dim3(B), dim3(BLOCK), smem, st, B, N, CL, Ts, Tv, s, v, wl0, wl1, lat_s, lat_v, idx, C0, wg1,
+                     w0, w1, pdec, s0, v0);
+  LGN_CHECK_LAUNCH();
+  return 0;
+}
+int junction_bwd(int B, int N, int C0, int Tin, const double* lat_v, const double* wg1, const double* w1, const double* pdec,
+                 const double* g_p, const double* g_s0, const double* g_v0, double* g_lat_v, double* part_dec, int CL, int Ts, int Tv,
+                 const double* s, const double* v, const double* wl0, const double* wl1, const double* g_lat_s, const int* idx,
+                 double* g_s, double* g_v, double* part_enc, hipStream_t st) {
+  const size_t a = dec_input_bwd_smem(N, C0, Tin), b = latent_bwd_smem(N, CL, Ts, Tv), smem = a > b ? a : b;
+  LGN_CHECK_ARG(smem <= 160 * 1024, "junction_bwd: needs %zu B of LDS", smem);
+  if (smem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(junction_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipLaunchKernelGGL(junction_bwd_kernel, dim3(B), dim3(BLOCK), smem, st, B, N, C0, Tin, lat_v, wg1, w1, pdec, g_p, g_s0, g_v0, g_lat_v,
+                     part_dec, CL, Ts, Tv, s, v, wl0, wl1, g_lat_s, idx, g_s, g_v, part_enc);
+  LGN_CHECK_LAUNCH();
+  return 0;
+}
+
 // loss_out: 3 results followed by LGN_FINALIZE_SCRATCH doubles of scratch (per-workgroup |w| partials)
 int finalize_step(double* w, double* g, long n, const double* loss_part, int nB, double lambda, double* m, double* v, long* step_dev,
                   double lr, double beta1, double beta2, double eps, int do_adam, double* loss_out, hipStream_t st) {

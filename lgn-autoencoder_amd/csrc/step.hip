@@ -279,20 +279,19 @@ int lgn_step_fwd_bwd_f64(const lgn_net_desc* d, const double* params, double* gr
     }
   }
 #define HIPOK(e) do { hipError_t e_ = (e); if (e_ != hipSuccess) { set_error("%s: %s", #e, hipGetErrorString(e_)); return (int)e_; } } while (0)
-  HIPOK(hipMemsetAsync(grads, 0, sizeof(double) * (size_t)n_params, st));      // dead parameters keep an exact zero
-  HIPOK(hipMemsetAsync(w.zeros_s, 0, sizeof(double) * w.zero_doubles, st));      // zeros_s | g_p | g_lat_s
   Deferred dq;
   dq.parts = w.parts;
   dq.cap = w.parts_size;
   RadFinJob fin{};
 
   // ---------------- forward ----------------
-  LGN_TRY(enc_input_fwd(B, N, ce[0], p4, params + enc_off[0], params + enc_off[1], w.enc.s[0], w.enc.v[0], st));
+  // the first kernel also zeroes the gradient buffer (dead parameters keep an exact zero) and zeros_s | g_p | g_lat_s
+  LGN_TRY(enc_input_fwd(B, N, ce[0], p4, params + enc_off[0], params + enc_off[1], w.enc.s[0], w.enc.v[0], st, grads,
+                        (size_t)n_params, w.zeros_s, w.zero_doubles));
   LGN_TRY(levels_fwd(*d, false, ce, params, enc_off, w.enc, p4, mask, st));
-  LGN_TRY(enc_latent_fwd(B, N, ce[L], Ts, Tv, w.enc.s[L], w.enc.v[L], params + enc_off[S.out0(false)],
-                         params + enc_off[S.out0(false) + 1], w.lat_s, w.lat_v, w.idx, st));
-  LGN_TRY(dec_input_fwd(B, N, cd[0], 2 * Tv, w.lat_v, params + dec_off[1], params + dec_off[2], params + dec_off[3], w.pdec,
-                        w.dec.s[0], w.dec.v[0], st));
+  LGN_TRY(junction_fwd(B, N, ce[L], Ts, Tv, w.enc.s[L], w.enc.v[L], params + enc_off[S.out0(false)],
+                       params + enc_off[S.out0(false) + 1], w.lat_s, w.lat_v, w.idx, cd[0], params + dec_off[1], params + dec_off[2],
+                       params + dec_off[3], w.pdec, w.dec.s[0], w.dec.v[0], st));
   LGN_TRY(levels_fwd(*d, true, cd, params, dec_off, w.dec, w.pdec, nullptr, st));
 
   // ---------------- loss + backward ----------------
@@ -305,21 +304,21 @@ int lgn_step_fwd_bwd_f64(const lgn_net_desc* d, const double* params, double* gr
   LGN_TRY(levels_bwd(*d, true, cd, params, grads, dec_off, w.dec, w.pdec, nullptr, w, dq, fin, cur, /*has_s_grad=*/false, st));
   {
     const int C0 = cd[0], Tin = 2 * Tv, row = 4 * C0 + 2 * N * Tin;
+    const int CL = ce[L], rowe = 2 * (Ts + Tv) * CL;
     double* part = dq.take((size_t)B * row);
-    LGN_TRY(dec_input_bwd(B, N, C0, Tin, w.lat_v, params + dec_off[1], params + dec_off[3], w.pdec, w.g_p, w.gs[cur], w.gv[cur],
-                          w.g_lat_v, part, st));
+    double* parte = dq.take((size_t)B * rowe);
+    // reads the gradient w.r.t. the decoder's level-0 features, writes the one w.r.t. the encoder's last level into the
+    // other buffer pair (jets do not occupy the same slices when the two channel counts differ)
+    const int rd = cur, wr = cur ^ 1;
+    cur = wr;
+    LGN_TRY(junction_bwd(B, N, C0, Tin, w.lat_v, params + dec_off[1], params + dec_off[3], w.pdec, w.g_p, w.gs[rd], w.gv[rd], w.g_lat_v, part,
+                         CL, Ts, Tv, w.enc.s[L], w.enc.v[L], params + enc_off[S.out0(false)], params + enc_off[S.out0(false) + 1],
+                         w.g_lat_s, w.idx, w.gs[wr], w.gv[wr], parte, st));
     dq.add(part, B, row, 0, 2 * C0, grads + dec_off[2]);
     dq.add(part, B, row, 2 * C0, 2 * C0, grads + dec_off[3]);
     dq.add(part, B, row, 4 * C0, 2 * N * Tin, grads + dec_off[1]);
-  }
-  {
-    const int CL = ce[L], row = 2 * (Ts + Tv) * CL;
-    cur = 0;
-    double* part = dq.take((size_t)B * row);
-    LGN_TRY(enc_latent_bwd(B, N, CL, Ts, Tv, w.enc.s[L], w.enc.v[L], params + enc_off[S.out0(false)],
-                           params + enc_off[S.out0(false) + 1], w.g_lat_s, w.g_lat_v, w.idx, w.gs[cur], w.gv[cur], part, st));
-    dq.add(part, B, row, 0, 2 * Ts * CL, grads + enc_off[S.out0(false)]);
-    dq.add(part, B, row, 2 * Ts * CL, 2 * Tv * CL, grads + enc_off[S.out0(false) + 1]);
+    dq.add(parte, B, rowe, 0, 2 * Ts * CL, grads + enc_off[S.out0(false)]);
+    dq.add(parte, B, rowe, 2 * Ts * CL, 2 * Tv * CL, grads + enc_off[S.out0(false) + 1]);
   }
   LGN_TRY(levels_bwd(*d, false, ce, params, grads, enc_off, w.enc, p4, mask, w, dq, fin, cur, /*has_s_grad=*/false, st));
   {

@@ -50,13 +50,17 @@ def normalize_p4(p4: torch.Tensor) -> torch.Tensor:
 class FlatParams:
     """Re-homes the parameters (and gradients) of several modules into two flat buffers."""
 
-    def __init__(self, *modules):
+    def __init__(self, *modules, grad_tail: int = 0):
+        """grad_tail: extra scalars allocated right behind the gradients (``self.grad_buf`` = gradients | tail) so that
+        a caller can all-reduce gradients and per-jet loss terms with ONE collective."""
         params = [p for m in modules for p in m.parameters()]
         assert params, "no parameters"
         dev, dt = params[0].device, params[0].dtype
         total = sum(p.numel() for p in params)
         self.flat = torch.empty(total, device=dev, dtype=dt)
-        self.grad = torch.zeros(total, device=dev, dtype=dt)
+        self.grad_buf = torch.zeros(total + grad_tail, device=dev, dtype=dt)
+        self.grad = self.grad_buf[:total]
+        self.tail = self.grad_buf[total:]
         off = 0
         with torch.no_grad():
             for p in params:
@@ -149,7 +153,7 @@ class NativeTrainStep:
             raise NotImplementedError("the native step implements map_to_latent='min&max' with CGMLP levels")
         self.encoder, self.decoder = encoder, decoder
         self.l1_lambda, self.lr, self.betas, self.eps = l1_lambda, lr, betas, eps
-        self.flat = FlatParams(encoder, decoder)
+        self.flat = FlatParams(encoder, decoder, grad_tail=batch_size)   # gradients | per-jet Chamfer terms
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         self.group = process_group
         self.optimizer = optimizer
@@ -185,7 +189,7 @@ class NativeTrainStep:
             raise RuntimeError(N.last_error())
         self.workspace = torch.empty(nws, device=dev, dtype=dt)
         self.recon = torch.empty(2, d.B, d.N, 4, device=dev, dtype=dt)
-        self.loss_part = torch.empty(d.B, device=dev, dtype=dt)
+        self.loss_part = self.flat.tail
         self._loss_buf = torch.zeros(3 + N.FINALIZE_SCRATCH, device=dev, dtype=dt)   # results | scratch
         self.loss_out = self._loss_buf[:3]
         self.adam_m = torch.zeros_like(self.flat.flat)
@@ -253,9 +257,8 @@ class NativeTrainStep:
             self._g1.replay()
         else:
             self._fwd_bwd()
-        if self.world > 1:
-            dist.all_reduce(self.flat.grad, op=dist.ReduceOp.SUM, group=self.group)
-            dist.all_reduce(self.loss_part, op=dist.ReduceOp.SUM, group=self.group)
+        if self.world > 1:      # ONE collective per step: gradients and the per-jet loss terms share a buffer
+            dist.all_reduce(self.flat.grad_buf, op=dist.ReduceOp.SUM, group=self.group)
         if self.use_graph:
             self._g2.replay()
         else:
