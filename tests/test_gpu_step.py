@@ -1,5 +1,7 @@
 """GPU test of the training-step harness (lgn/step.py) on the native modules: one full step on the golden
 configuration must reproduce the reference's total loss and gradients (Chamfer + 1e-8 L1)."""
+import os
+
 import pytest
 import torch
 
@@ -98,3 +100,35 @@ def test_native_step_full_size_properties():
     U.assert_close(ra, rb, 1e-12, "recon")
     U.assert_close(a.flat.grad, b.flat.grad, 1e-9, "flat gradient")
     assert torch.isfinite(a.flat.grad).all()
+
+
+def test_native_step_two_ranks_match_single_process(tmp_path):
+    dev = torch.device("cuda:0")
+    """2 ranks x 8 jets (one all-reduce of gradients | loss terms between the two captured graphs) must reproduce the
+    single-process 16-jet step: the loss is a SUM over jets, gradients are summed, the L1 term is added once."""
+    import socket
+    import subprocess
+    import sys as _sys
+    import bench
+    import __graft_entry__ as G
+    from lgn.step import NativeTrainStep
+    per_rank, world, steps = 8, 2, 3
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_dist_native_worker.py")
+    procs = [subprocess.Popen([_sys.executable, worker, str(r), str(world), str(port), str(tmp_path), str(per_rank), str(steps)],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    outs = [p.communicate(timeout=600)[0].decode(errors="replace") for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r} failed:\n{o[-3000:]}"
+    enc, dec = G._models(bench.N_PART, bench.CH_ENC, bench.CH_DEC, dev, seed=0)
+    ref = NativeTrainStep(enc, dec, batch_size=per_rank * world, lr=5e-4, l1_lambda=1e-8, use_graph=True)
+    p4, labels = bench.synthetic_jets(per_rank * world, bench.N_PART, seed=5)
+    batch = {"p4": p4.to(dev), "labels": labels.to(dev)}
+    ref_losses = [float(ref.step(batch)[0]) for _ in range(steps)]
+    for r in range(world):
+        z = torch.load(os.path.join(str(tmp_path), f"rank{r}.pt"))
+        U.assert_close(z["params"].to(dev), ref.flat.flat.detach(), 1e-9, f"rank {r} parameters after {steps} steps")
+        for a, b in zip(z["losses"], ref_losses):
+            assert abs(a - b) <= 1e-10 * max(1.0, abs(b)), (z["losses"], ref_losses)
