@@ -214,6 +214,12 @@ def main():
     if rank == 0:
         dom = time_dominant_kernel(enc, batch)
         achieved = dom["flops"] / (dom["us"] * 1e-6) / 1e12
+        traffic = None          # HBM bytes per launch of the dominant kernel, from the PMC passes recorded under profiles/
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_v8_traffic.json")) as fh:
+                traffic = json.load(fh).get(dom["kernel"], {}).get("hbm_bytes_per_launch")
+        except OSError:
+            pass
         out = {
             "metric": "jets/sec fwd+bwd, 30-particle maxdim=2 bs=512",
             "value": args.batch * world * args.steps / elapsed,
@@ -230,7 +236,9 @@ def main():
             "roofline": {"bound": "mfma", "pipe": "fp64 vector ALU (same peak as fp64 MFMA on MI355X; the kernel is "
                                                    "FMA-bound, neither HBM- nor matrix-core-bound)",
                          "kernel": dom["kernel"], "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_VECTOR_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic,
+                         "traffic_note": "bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction), separate rocprofv3 "
+                                         "--pmc passes recorded in profiles/r01_v8_traffic.json; 0.5 TB/s, HBM is not the bound",
                          "us_per_launch": dom["us"], "algorithmic_flops_per_launch": dom["flops"],
                          "forward_kernel": {"kernel": dom["forward"]["kernel"], "us_per_launch": dom["forward"]["us"],
                                             "algorithmic_flops_per_launch": dom["forward"]["flops"],

@@ -266,7 +266,9 @@ __global__ __launch_bounds__(BLOCK) void level_bwd3_kernel(LevelBwdArgs<double> 
           }
       }
     }
+    STAMP(48);
     __syncthreads();                                  // every read of go / wm / agl is done: reuse the region
+    STAMP(49);
     double* red = tr;
     if (pi < NPART) {
 #pragma unroll
@@ -276,7 +278,9 @@ __global__ __launch_bounds__(BLOCK) void level_bwd3_kernel(LevelBwdArgs<double> 
           r4[0] = d0[o].r;  r4[1] = d0[o].i;  r4[2] = d1[o].r;  r4[3] = d1[o].i;
         }
     }
+    STAMP(50);
     __syncthreads();
+    STAMP(51);
     for (int e = tid; e < OK; e += BLOCK) {
       double v[4];
 #pragma unroll
