@@ -226,11 +226,17 @@ class NativeTrainStep:
             self._fwd_bwd()
             self._finalize(False)
         torch.cuda.current_stream().wait_stream(s)
-        self._g1, self._g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._g1):
-            self._fwd_bwd()
-        with torch.cuda.graph(self._g2, pool=self._g1.pool()):
-            self._finalize(self.optimizer)
+        self._g1, self._g2 = torch.cuda.CUDAGraph(), None
+        if self.world > 1:            # the gradient all-reduce sits between the two graphs
+            self._g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._g1):
+                self._fwd_bwd()
+            with torch.cuda.graph(self._g2, pool=self._g1.pool()):
+                self._finalize(self.optimizer)
+        else:                         # single process: the whole step is ONE graph launch
+            with torch.cuda.graph(self._g1):
+                self._fwd_bwd()
+                self._finalize(self.optimizer)
         with torch.no_grad():   # capture does not execute, but restore anyway in case a backend replays eagerly
             self.flat.flat.copy_(snap[0]); self.adam_m.copy_(snap[1]); self.adam_v.copy_(snap[2]); self.step_dev.copy_(snap[3])
 
@@ -260,7 +266,8 @@ class NativeTrainStep:
         if self.world > 1:      # ONE collective per step: gradients and the per-jet loss terms share a buffer
             dist.all_reduce(self.flat.grad_buf, op=dist.ReduceOp.SUM, group=self.group)
         if self.use_graph:
-            self._g2.replay()
+            if self._g2 is not None:
+                self._g2.replay()
         else:
             self._finalize(self.optimizer)
         return self.loss_out[0], self.recon
