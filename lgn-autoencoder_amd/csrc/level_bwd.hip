@@ -14,6 +14,7 @@
 #include <stdlib.h>
 
 #include "level_dev.hpp"
+#include <type_traits>
 #include "ops.hpp"
 
 namespace lgn {
@@ -745,6 +746,11 @@ int level_bwd_nodes2_dispatch(const LevelBwdArgs<double>& a, int decoder, hipStr
 int level_bwd_rad2_dispatch(const LevelBwdArgs<double>& a, hipStream_t stream);
 
 int level_bwd3_dispatch(const LevelBwdArgs<double>& a, int decoder, hipStream_t stream);         // level_bwd3.hip
+int level_bwd_dec_sep_dispatch(const LevelBwdArgs<double>& a, hipStream_t stream);               // level_bwd_dec_sep.hip
+static bool dec_pairwise() {   // LGN_AMD_DEC_PAIRWISE=1 keeps the decoder on the O(N^2) pair sweeps (read per call: tests flip it)
+  const char* e = getenv("LGN_AMD_DEC_PAIRWISE");
+  return e && e[0] == '1';
+}
 bool level_bwd3_fits(int N);
 
 static bool use_v1() {
@@ -767,7 +773,9 @@ void level_bwd_partial_rows(int B, int N, int decoder, int* rows_mix, int* rows_
     return;
   }
   *rows_mix = B * tiles;
-  if (decoder) {
+  if (decoder && !use_v1() && !dec_pairwise()) {
+    *rows_rad = B;                       // separable decoder backward: one partial row per jet
+  } else if (decoder) {
     *rows_rad = B * tiles;
   } else if (!use_v1()) {
     *rows_rad = B;                       // level_bwd_rad2: one partial row per jet
@@ -789,6 +797,9 @@ static int launch_level_bwd(const LevelBwdArgs<T>& a, hipStream_t stream) {
     if ((rc = ensure_smem(kern, smem, "level_bwd_mix"))) return rc;
     hipLaunchKernelGGL(kern, dim3(a.B, tiles), dim3(BLOCK), smem, stream, a);
     LGN_CHECK_LAUNCH();
+  }
+  if constexpr (DEC && std::is_same<T, double>::value) {
+    if (!use_v1() && !dec_pairwise()) return level_bwd_dec_sep_dispatch(a, stream);   // 2+3. from jet-level sums, O(N C)
   }
   if (!use_v1()) {  // 2. j-centric pass, matrix-core version
     if ((rc = level_bwd_nodes2_dispatch(a, DEC, stream))) return rc;

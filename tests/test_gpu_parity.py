@@ -48,7 +48,7 @@ def test_level_fwd_bwd(dev, O, decoder, C, CO, N, B):
     _level_case(dev, O, decoder, C, CO, N, B)
 
 
-@pytest.mark.parametrize("C,CO,N,B", [(4, 4, 30, 2), (3, 4, 30, 2), (4, 3, 7, 1)])
+@pytest.mark.parametrize("C,CO,N,B", [(4, 4, 30, 2), (3, 4, 30, 2), (4, 3, 7, 1), (4, 4, 70, 1)])
 def test_level_decoder_pair_sweep(dev, O, monkeypatch, C, CO, N, B):
     """The decoder levels normally run the separable O(N C) form (edge mask == 0 -> constant radial weights);
     LGN_AMD_DEC_PAIRWISE=1 keeps the O(N^2) pair sweep of the reference's formulation.  Both must match the oracle."""
