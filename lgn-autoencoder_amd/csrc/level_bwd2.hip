@@ -153,6 +153,7 @@ __global__ __launch_bounds__(BLOCK) void level_bwd_nodes2_kernel(LevelBwdArgs<do
       const double* pii = pj + ii * PS;
       cx<double> q[4];
       v4d R[NG];
+      double qd0 = 0.0, qd3 = 0.0, qa = 0.0, qb = 0.0;       // encoder: q = [d0, a - ib, d3, -a - ib]
       if (DEC) {
 #pragma unroll
         for (int m = 0; m < 4; ++m) q[m] = {pii[m] - pme[m], pii[4 + m] - pme[4 + m]};
@@ -169,6 +170,7 @@ __global__ __launch_bounds__(BLOCK) void level_bwd_nodes2_kernel(LevelBwdArgs<do
         q[1] = {d1 * h, -d2 * h};
         q[2] = {d3, 0.0};
         q[3] = {-d1 * h, -d2 * h};
+        qd0 = d0;  qd3 = d3;  qa = d1 * h;  qb = d2 * h;
         double beta[5];
 #pragma unroll
         for (int s = 0; s < 5; ++s) {
@@ -191,22 +193,42 @@ __global__ __launch_bounds__(BLOCK) void level_bwd_nodes2_kernel(LevelBwdArgs<do
           if (ch < C) {
             const cx<double> R0 = {R[g][0], R[g][1]}, R1 = {R[g][2], R[g][3]};
             const cx<double> e0 = {R0.r - R0.i, R0.r + R0.i};
-            cx<double> e1[4], e1t[4];
-#pragma unroll
-            for (int m = 0; m < 4; ++m) e1[m] = cmul(R1, q[m]);
-            metric_perm(e1, e1t);
             const cx<double> gA3 = {0.5 * gi[G::A3 + 2 * ch], 0.5 * gi[G::A3 + 2 * ch + 1]};
             const cx<double> gA4 = {gi[G::A4 + 2 * ch], gi[G::A4 + 2 * ch + 1]};
-            cfmac(Gs[g], gA4, e0);
+            cx<double> gA1[4], gA2[4];
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
-              const cx<double> gA1 = {gi[G::A1 + (ch * 4 + m) * 2], gi[G::A1 + (ch * 4 + m) * 2 + 1]};
-              const cx<double> gA2 = {gi[G::A2 + (ch * 4 + m) * 2], gi[G::A2 + (ch * 4 + m) * 2 + 1]};
-              cfmac(Gv[g][m], gA1, e0);
-              cfmac(Gv[g][m], gA3, e1t[m]);
-              cfmac(Gs[g], gA2, e1[m]);
-              if (DEC) {
-                cx<double> ge1 = cmulc(gA2, sj[g]);
+              gA1[m] = {gi[G::A1 + (ch * 4 + m) * 2], gi[G::A1 + (ch * 4 + m) * 2 + 1]};
+              gA2[m] = {gi[G::A2 + (ch * 4 + m) * 2], gi[G::A2 + (ch * 4 + m) * 2 + 1]};
+            }
+            cfmac(Gs[g], gA4, e0);
+            if (!DEC) {
+              // the edge e1[m] = R1 q[m] enters through P2 = sum_m gA2[m] conj(q[m]) and Z = gA3 conj(R1) only; with real
+              // momenta q = [d0, a - ib, d3, -a - ib] (level_bwd3.hip)
+              const cx<double> dg = {gA2[1].r - gA2[3].r, gA2[1].i - gA2[3].i}, sg = {gA2[1].r + gA2[3].r, gA2[1].i + gA2[3].i};
+              cx<double> P2;
+              P2.r = __builtin_fma(gA2[0].r, qd0, __builtin_fma(gA2[2].r, qd3, __builtin_fma(qa, dg.r, -qb * sg.i)));
+              P2.i = __builtin_fma(gA2[0].i, qd0, __builtin_fma(gA2[2].i, qd3, __builtin_fma(qa, dg.i, qb * sg.r)));
+              cfmac(Gs[g], P2, R1);
+              const cx<double> Z = cmulc(gA3, R1);
+#pragma unroll
+              for (int m = 0; m < 4; ++m) cfmac(Gv[g][m], gA1[m], e0);
+              Gv[g][0].r = __builtin_fma(Z.r, qd0, Gv[g][0].r);   Gv[g][0].i = __builtin_fma(Z.i, qd0, Gv[g][0].i);
+              Gv[g][2].r = __builtin_fma(-Z.r, qd3, Gv[g][2].r);  Gv[g][2].i = __builtin_fma(-Z.i, qd3, Gv[g][2].i);
+              const double aZr = qa * Z.r, aZi = qa * Z.i, bZr = qb * Z.r, bZi = qb * Z.i;
+              Gv[g][1].r -= aZr + bZi;  Gv[g][1].i += bZr - aZi;   // Z (-a + ib)
+              Gv[g][3].r += aZr - bZi;  Gv[g][3].i += aZi + bZr;   // Z ( a + ib)
+            } else {
+              cx<double> e1[4], e1t[4];
+#pragma unroll
+              for (int m = 0; m < 4; ++m) e1[m] = cmul(R1, q[m]);
+              metric_perm(e1, e1t);
+#pragma unroll
+              for (int m = 0; m < 4; ++m) {
+                cfmac(Gv[g][m], gA1[m], e0);
+                cfmac(Gv[g][m], gA3, e1t[m]);
+                cfmac(Gs[g], gA2[m], e1[m]);
+                cx<double> ge1 = cmulc(gA2[m], sj[g]);
                 cfmac(ge1, gA3, vtj[g][m]);
                 cfmac(Gq[m], ge1, R1);
               }
@@ -299,6 +321,7 @@ __global__ __launch_bounds__(BLOCK) void level_bwd_rad2_kernel(LevelBwdArgs<doub
     const bool mi = mk[ii] != 0;
     // gradient of the aggregate of this lane's receiver i and channel(s): registers for the whole sweep
     cx<double> rA1[NG][4], rA2[NG][4], rA3[NG], rA4[NG];
+    cx<double> dA2[NG], sA2[NG];                             // gA2[1] - gA2[3], gA2[1] + gA2[3]
     {
       const double* gi = a.g_ag + ((size_t)b * N + ii) * G::SIZE;
 #pragma unroll
@@ -313,6 +336,8 @@ __global__ __launch_bounds__(BLOCK) void level_bwd_rad2_kernel(LevelBwdArgs<doub
           rA1[g][m] = live ? cx<double>{gi[G::A1 + (cs * 4 + m) * 2], gi[G::A1 + (cs * 4 + m) * 2 + 1]} : cx<double>{0, 0};
           rA2[g][m] = live ? cx<double>{gi[G::A2 + (cs * 4 + m) * 2], gi[G::A2 + (cs * 4 + m) * 2 + 1]} : cx<double>{0, 0};
         }
+        dA2[g] = {rA2[g][1].r - rA2[g][3].r, rA2[g][1].i - rA2[g][3].i};
+        sA2[g] = {rA2[g][1].r + rA2[g][3].r, rA2[g][1].i + rA2[g][3].i};
       }
     }
     for (int j0 = 0; j0 < N; j0 += 4) {
@@ -358,19 +383,23 @@ __global__ __launch_bounds__(BLOCK) void level_bwd_rad2_kernel(LevelBwdArgs<doub
         double G0r = 0, G0i = 0, G1r = 0, G1i = 0;
         if (ok && ch < C) {
           const cx<double> s = {njp[ch * 10], njp[ch * 10 + 1]};
-          cx<double> v[4], vt[4];
+          cx<double> v[4];
 #pragma unroll
           for (int m = 0; m < 4; ++m) v[m] = {njp[ch * 10 + 2 + m], njp[ch * 10 + 6 + m]};
-          metric_perm(v, vt);
           cx<double> ge0 = cmulc(rA4[g], s);
-          cx<double> gR1 = {0, 0};
 #pragma unroll
-          for (int m = 0; m < 4; ++m) {
-            cfmac(ge0, rA1[g][m], v[m]);
-            cx<double> ge1 = cmulc(rA2[g][m], s);
-            cfmac(ge1, rA3[g], vt[m]);
-            cfmac(gR1, ge1, q[m]);
-          }
+          for (int m = 0; m < 4; ++m) cfmac(ge0, rA1[g][m], v[m]);
+          // G_R1 = sum_m ge1[m] conj(q[m]) = conj(s_j) P2 + gA3 conj(V), P2 = sum_m gA2[m] conj(q[m]), V = <v_j, q>, with the
+          // real-momentum structure q = [d0, a - ib, d3, -a - ib] (level_bwd3.hip)
+          const double qa = d1 * h, qb = d2 * h;
+          cx<double> P2, V;
+          P2.r = __builtin_fma(rA2[g][0].r, d0, __builtin_fma(rA2[g][2].r, d3, __builtin_fma(qa, dA2[g].r, -qb * sA2[g].i)));
+          P2.i = __builtin_fma(rA2[g][0].i, d0, __builtin_fma(rA2[g][2].i, d3, __builtin_fma(qa, dA2[g].i, qb * sA2[g].r)));
+          const cx<double> dv = {v[3].r - v[1].r, v[3].i - v[1].i}, sv = {v[1].r + v[3].r, v[1].i + v[3].i};
+          V.r = __builtin_fma(v[0].r, d0, __builtin_fma(-v[2].r, d3, __builtin_fma(qa, dv.r, qb * sv.i)));
+          V.i = __builtin_fma(v[0].i, d0, __builtin_fma(-v[2].i, d3, __builtin_fma(qa, dv.i, -qb * sv.r)));
+          cx<double> gR1 = cmulc(P2, s);
+          cfmac(gR1, rA3[g], V);
           G0r = ge0.r + ge0.i;  G0i = ge0.i - ge0.r;          // e0 = R0 (1+i)  ->  G_R0 = G_e0 (1-i)
           G1r = gR1.r;  G1i = gR1.i;
         }
