@@ -55,12 +55,13 @@ __device__ __forceinline__ void wave_sync() {
 // j-centric pass
 // =========================================================================================================
 template <int C, bool DEC>
-__global__ __launch_bounds__(BLOCK) void level_bwd_nodes2_kernel(LevelBwdArgs<double> a) {
+__global__ __launch_bounds__(2 * BLOCK) void level_bwd_nodes2_kernel(LevelBwdArgs<double> a) {
   constexpr int NG = (C + 3) / 4;
   constexpr int PS = DEC ? 8 : 4;
   using G = GA2<C>;
   const int N = a.N, B = a.B;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nthr = blockDim.x, nw = nthr >> 6;            // 4 or 8 waves: 8 when the batch alone cannot fill the SIMDs
 
   extern __shared__ __align__(16) unsigned char smem_raw[];
   double* ga = reinterpret_cast<double*>(smem_raw);          // N * 20C   gradient of the aggregate, all receivers i
@@ -69,19 +70,19 @@ __global__ __launch_bounds__(BLOCK) void level_bwd_nodes2_kernel(LevelBwdArgs<do
 
   {
     const double* src = a.g_ag + (size_t)b * N * G::SIZE;
-    for (int e = tid; e < N * G::SIZE; e += BLOCK) ga[e] = src[e];
+    for (int e = tid; e < N * G::SIZE; e += nthr) ga[e] = src[e];
     if (DEC) {
       const size_t plane_p = (size_t)B * N * 4;
       const double* p0 = a.p + (size_t)b * N * 4;
-      for (int e = tid; e < N * 4; e += BLOCK) {
+      for (int e = tid; e < N * 4; e += nthr) {
         int j = e >> 2, m = e & 3;
         pj[j * 8 + m] = p0[e];
         pj[j * 8 + 4 + m] = p0[plane_p + e];
       }
     } else {
       const double* p0 = a.p + (size_t)b * N * 4;
-      for (int e = tid; e < N * 4; e += BLOCK) pj[e] = p0[e];
-      for (int e = tid; e < N; e += BLOCK) mk[e] = a.mask[(size_t)b * N + e];
+      for (int e = tid; e < N * 4; e += nthr) pj[e] = p0[e];
+      for (int e = tid; e < N; e += nthr) mk[e] = a.mask[(size_t)b * N + e];
     }
   }
   const int pr = lane & 15, cg = lane >> 4;
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(BLOCK) void level_bwd_nodes2_kernel(LevelBwdArgs<do
 
   const size_t pls = (size_t)B * N * C;
   const int ngroups = (N + 3) >> 2;
-  for (int rg = wave; rg < ngroups; rg += 4) {
+  for (int rg = wave; rg < ngroups; rg += nw) {
     const int j = rg * 4 + tj;
     const bool jok = j < N;
     const int jj = jok ? j : N - 1;
@@ -279,20 +280,21 @@ __global__ __launch_bounds__(BLOCK) void level_bwd_nodes2_kernel(LevelBwdArgs<do
 // =========================================================================================================
 // B-operand columns (3 N-tiles of 16):  [0,16) X1[k=0..15] | [16,32) X2[k=0..15] | 32..35 X1[16..19], 36..39 X2[16..19], 40 on, 41 one
 template <int C>
-__global__ __launch_bounds__(BLOCK) void level_bwd_rad2_kernel(LevelBwdArgs<double> a) {
+__global__ __launch_bounds__(2 * BLOCK) void level_bwd_rad2_kernel(LevelBwdArgs<double> a) {
   constexpr int NG = (C + 3) / 4;
   constexpr int NS = node_stride(C);
   using G = GA2<C>;
   constexpr int TS = 18;                                   // padded row stride of the 16 x 16 transpose tiles (scalars)
   const int N = a.N, B = a.B;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nw = blockDim.x >> 6;                            // 4 or 8 waves
 
   extern __shared__ __align__(16) unsigned char smem_raw[];
   double* nd = reinterpret_cast<double*>(smem_raw);          // N * NS     source node features
   double* pj = nd + ((N * NS + 1) & ~1);                     // N * 4
   double* tr = pj + N * 4;                                   // 4 waves * (NG + 3) tiles * 16 * TS
   double* red = tr;                                          // 4 waves * 64 lanes * NG * 12, aliases the transpose tiles (used after the sweep)
-  uint8_t* mk = reinterpret_cast<uint8_t*>(tr + (4 * (NG + 3) * 16 * TS > 4 * 64 * NG * 12 ? 4 * (NG + 3) * 16 * TS : 4 * 64 * NG * 12));
+  uint8_t* mk = reinterpret_cast<uint8_t*>(tr + nw * ((NG + 3) * 16 * TS > 64 * NG * 12 ? (NG + 3) * 16 * TS : 64 * NG * 12));
 
   load_jet<double, C, false>(a.s_in, a.v_in, a.p, a.mask, B, N, b, nd, pj, mk);
   const int pr = lane & 15, cg = lane >> 4;
@@ -313,7 +315,7 @@ __global__ __launch_bounds__(BLOCK) void level_bwd_rad2_kernel(LevelBwdArgs<doub
     for (int t = 0; t < 3; ++t) T[g][t] = v4d{0, 0, 0, 0};
 
   const int ngroups = (N + 3) >> 2;
-  for (int rg = wave; rg < ngroups; rg += 4) {
+  for (int rg = wave; rg < ngroups; rg += nw) {
     const int i = rg * 4 + ti;
     const bool iok = i < N;
     const int ii = iok ? i : N - 1;
@@ -452,8 +454,11 @@ __global__ __launch_bounds__(BLOCK) void level_bwd_rad2_kernel(LevelBwdArgs<doub
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int e = (g * 3 + t) * 4 + q;
-          const double v = (red[(size_t)(0 * 64 + lane) * NG * 12 + e] + red[(size_t)(1 * 64 + lane) * NG * 12 + e]) +
-                           (red[(size_t)(2 * 64 + lane) * NG * 12 + e] + red[(size_t)(3 * 64 + lane) * NG * 12 + e]);
+          double v = (red[(size_t)(0 * 64 + lane) * NG * 12 + e] + red[(size_t)(1 * 64 + lane) * NG * 12 + e]) +
+                     (red[(size_t)(2 * 64 + lane) * NG * 12 + e] + red[(size_t)(3 * 64 + lane) * NG * 12 + e]);
+          if (nw == 8)
+            v += (red[(size_t)(4 * 64 + lane) * NG * 12 + e] + red[(size_t)(5 * 64 + lane) * NG * 12 + e]) +
+                 (red[(size_t)(6 * 64 + lane) * NG * 12 + e] + red[(size_t)(7 * 64 + lane) * NG * 12 + e]);
           if (ch >= C) continue;
           const int r = (q >> 1) * 2 * C + 2 * ch + (q & 1);       // row of the partial layout: lin*2C + 2c + z
           if (t == 0) part[r * NB + col] = v;                      // T1[r][k = col]
@@ -470,6 +475,10 @@ __global__ __launch_bounds__(BLOCK) void level_bwd_rad2_kernel(LevelBwdArgs<doub
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// One workgroup per jet with 4 waves leaves a SIMD with a single wave when the batch has no more jets than the chip has
+// CUs (cfg4: 256 jets of 150 particles = 38 row groups each): run 8 waves per jet then.
+static int sweep_wave_factor(int B, int N) { return (B <= 320 && N >= 64) ? 2 : 1; }
+
 template <int C, bool DEC>
 static int launch_nodes2(const LevelBwdArgs<double>& a, hipStream_t stream) {
   constexpr int PS = DEC ? 8 : 4;
@@ -477,7 +486,7 @@ static int launch_nodes2(const LevelBwdArgs<double>& a, hipStream_t stream) {
   LGN_CHECK_ARG(smem <= 160 * 1024, "level_bwd_nodes: N=%d C=%d needs %zu B of LDS", a.N, a.C, smem);
   auto kern = level_bwd_nodes2_kernel<C, DEC>;
   if (smem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  hipLaunchKernelGGL(kern, dim3(a.B), dim3(BLOCK), smem, stream, a);
+  hipLaunchKernelGGL(kern, dim3(a.B), dim3(BLOCK * sweep_wave_factor(a.B, a.N)), smem, stream, a);
   LGN_CHECK_LAUNCH();
   return 0;
 }
@@ -485,12 +494,17 @@ static int launch_nodes2(const LevelBwdArgs<double>& a, hipStream_t stream) {
 template <int C>
 static int launch_rad2(const LevelBwdArgs<double>& a, hipStream_t stream) {
   constexpr int NG = (C + 3) / 4;
-  const size_t smem = sizeof(double) * ((((size_t)a.N * node_stride(C) + 1) & ~size_t(1)) + (size_t)a.N * 4 +
-                                        (4 * (NG + 3) * 16 * 18 > 4 * 64 * NG * 12 ? 4 * (NG + 3) * 16 * 18 : 4 * 64 * NG * 12)) + a.N + 16;
+  auto bytes = [&](int nw) {
+    return sizeof(double) * ((((size_t)a.N * node_stride(C) + 1) & ~size_t(1)) + (size_t)a.N * 4 +
+                             (size_t)nw * ((NG + 3) * 16 * 18 > 64 * NG * 12 ? (NG + 3) * 16 * 18 : 64 * NG * 12)) + a.N + 16;
+  };
+  int f = sweep_wave_factor(a.B, a.N);
+  if (f == 2 && bytes(8) > 160 * 1024) f = 1;
+  const size_t smem = bytes(4 * f);
   LGN_CHECK_ARG(smem <= 160 * 1024, "level_bwd_rad: N=%d C=%d needs %zu B of LDS", a.N, a.C, smem);
   auto kern = level_bwd_rad2_kernel<C>;
   if (smem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  hipLaunchKernelGGL(kern, dim3(a.B), dim3(BLOCK), smem, stream, a);
+  hipLaunchKernelGGL(kern, dim3(a.B), dim3(BLOCK * f), smem, stream, a);
   LGN_CHECK_LAUNCH();
   return 0;
 }
