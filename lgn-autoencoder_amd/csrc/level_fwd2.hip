@@ -67,11 +67,12 @@ struct Fwd2 {
 //   A4_i = e0 sum_j s_j            A3_i = R1 (<sum_j v_j, p_i> - sum_j <v_j, p_j>) / 2
 // O(N C) instead of O(N^2 C) work per jet, same values up to summation order.  SEP = false keeps the pair sweep.
 template <int C, bool DEC, bool SEP>
-__global__ __launch_bounds__(BLOCK) void level_fwd2_kernel(LevelArgs<double> a, int chunk) {
+__global__ __launch_bounds__(2 * BLOCK) void level_fwd2_kernel(LevelArgs<double> a, int chunk) {
   using F = Fwd2<C, DEC>;
   constexpr int NG = F::NG;
   const int N = a.N, B = a.B, CO = a.CO;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nthr = blockDim.x, nw = nthr >> 6;            // 4 waves, or 8 when the batch alone cannot fill the SIMDs
 
   extern __shared__ __align__(16) unsigned char smem_raw[];
   double* nd = reinterpret_cast<double*>(smem_raw);                   // N * NS
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(BLOCK) void level_fwd2_kernel(LevelArgs<double> a, 
 
   STAMP(0);
   load_jet<double, C, DEC>(a.s_in, a.v_in, a.p, a.mask, B, N, b, nd, pj, mk);
-  for (int e = tid; e < 2 * CO * 5 * C; e += BLOCK) {
+  for (int e = tid; e < 2 * CO * 5 * C; e += nthr) {
     wm[e] = a.wm0[e];
     wm[2 * CO * 5 * C + e] = a.wm1[e];
   }
@@ -132,14 +133,14 @@ __global__ __launch_bounds__(BLOCK) void level_fwd2_kernel(LevelArgs<double> a, 
       sums[tid] = mean / N;
     }
     __syncthreads();
-    for (int e = tid; e < N * 8; e += BLOCK) pj[e] -= sums[e & 7];
+    for (int e = tid; e < N * 8; e += nthr) pj[e] -= sums[e & 7];
     __syncthreads();
     // jet-level sums per channel: S | VS[4] | SP[4] | VP.  Stage 1: thread = (node, channel) writes its 10 complex
     // terms into the (still unused) aggregate rows; stage 2: thread = (channel, term) adds them up in node order
     double total = 0.0;
     for (int nb = 0; nb < N; nb += chunk) {
       const int rows = min(chunk, N - nb);
-      for (int e = tid; e < rows * C; e += BLOCK) {
+      for (int e = tid; e < rows * C; e += nthr) {
         const int rl = e / C, c = e - rl * C, n = nb + rl;
         const double* ni = nd + n * F::NS + c * 10;
         const double* pn = pj + n * 8;
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(BLOCK) void level_fwd2_kernel(LevelArgs<double> a, 
   for (int c0 = 0; c0 < N; c0 += chunk) {
   const int c1 = min(N, c0 + chunk);
   if constexpr (DEC && SEP) {
-    for (int e = tid; e < (c1 - c0) * C; e += BLOCK) {
+    for (int e = tid; e < (c1 - c0) * C; e += nthr) {
       const int rl = e / C, c = e - rl * C, n = c0 + rl;
       const double* sm = sums + c * 20;
       const double* pn = pj + n * 8;
@@ -207,7 +208,7 @@ __global__ __launch_bounds__(BLOCK) void level_fwd2_kernel(LevelArgs<double> a, 
       }
     }
   } else
-  for (int rg = (c0 >> 2) + wave; rg * 4 < c1; rg += 4) {
+  for (int rg = (c0 >> 2) + wave; rg * 4 < c1; rg += nw) {
     const int i0 = rg * 4;
     const int i = i0 + ti;
     const bool iok = i < N;
@@ -369,14 +370,14 @@ __global__ __launch_bounds__(BLOCK) void level_fwd2_kernel(LevelArgs<double> a, 
   // ---- aggregate -> global (saved for the backward): ag0 [2][B][N][2C], ag1 [2][B][N][2C][4] -----------------------
   {
     const size_t pl0 = (size_t)B * N * 2 * C;
-    for (int e = tid; e < (c1 - c0) * 2 * C; e += BLOCK) {        // e = n * 2C + (blk * C + ch), blk 0: A3, 1: A4
+    for (int e = tid; e < (c1 - c0) * 2 * C; e += nthr) {        // e = n * 2C + (blk * C + ch), blk 0: A3, 1: A4
       const int n = e / (2 * C), r = e - n * 2 * C, blk = r / C, ch = r - blk * C;
       const double* st = agl + n * F::AGS + (blk ? F::A4 : F::A3) + 2 * ch;
       const size_t ge = ((size_t)b * N + c0) * 2 * C + e;
       a.ag0[ge] = st[0];
       a.ag0[pl0 + ge] = st[1];
     }
-    for (int e = tid; e < (c1 - c0) * 2 * C * 4; e += BLOCK) {    // e = (n * 2C + blk * C + ch) * 4 + m, blk 0: A1, 1: A2
+    for (int e = tid; e < (c1 - c0) * 2 * C * 4; e += nthr) {    // e = (n * 2C + blk * C + ch) * 4 + m, blk 0: A1, 1: A2
       const int n = e / (8 * C), r = e - n * 8 * C, blk = r / (4 * C), cm = r - blk * 4 * C;
       const double* st = agl + n * F::AGS + (blk ? F::A2 : F::A1) + 2 * cm;
       const size_t ge = ((size_t)b * N + c0) * 8 * C + e;
@@ -427,7 +428,7 @@ __global__ __launch_bounds__(BLOCK) void level_fwd2_kernel(LevelArgs<double> a, 
         }
       }
     } else {
-      for (int it = lane + 64 * (wave - 1); it < nr * 4; it += 192) {
+      for (int it = lane + 64 * (wave - 1); it < nr * 4; it += 64 * (nw - 1)) {
         const int rl = it >> 2, m = it & 3, r = c0 + rl;
         const double* st = agl + rl * F::AGS;
         const double* ni = nd + r * F::NS;
@@ -467,7 +468,9 @@ static int launch_level_fwd2(const LevelArgs<double>& a, hipStream_t stream) {
   // aggregate rows kept in LDS: the whole jet if that still leaves room for two workgroups per CU (or nothing does),
   // else as many 16-row slabs as fit next to the node data
   const size_t fixed = sizeof(double) * (((size_t)a.N * F::NS + 1 & ~size_t(1)) + (size_t)a.N * F::PS + 4 * a.CO * 5 * C + 20 * C) + a.N + 16;
-  const size_t row = sizeof(double) * F::AGS, budget2 = 78 * 1024, budget1 = 160 * 1024;
+  // (a batch with no more jets than CUs runs one 8-wave workgroup per CU anyway: it takes the whole LDS)
+  const bool wide = a.B <= 320 && a.N >= 64;
+  const size_t row = sizeof(double) * F::AGS, budget1 = 160 * 1024, budget2 = wide ? budget1 : 78 * 1024;
   const int full = (a.N + 15) & ~15;
   int chunk = full;
   if (fixed + full * row > budget2) {
@@ -483,7 +486,9 @@ static int launch_level_fwd2(const LevelArgs<double>& a, hipStream_t stream) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
   }
-  hipLaunchKernelGGL(kern, dim3(a.B), dim3(BLOCK), smem, stream, a, chunk);
+  // 8 waves per jet when the batch has no more jets than the chip has CUs and the jet has enough row groups (cfg4)
+  const int nthreads = wide ? 2 * BLOCK : BLOCK;
+  hipLaunchKernelGGL(kern, dim3(a.B), dim3(nthreads), smem, stream, a, chunk);
   LGN_CHECK_LAUNCH();
   return 0;
 }
