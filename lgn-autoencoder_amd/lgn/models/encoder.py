@@ -60,8 +60,8 @@ class LGNEncoder(CGModule, LevelTablesMixin):
         self.tau_dict["cg_layers"] = self.tau_cg_levels_node.copy()
 
         tau_last = dict(self.plans[-1].tau_out)
-        if map_to_latent.lower() == "mix":
-            raise NotImplementedError("map_to_latent='mix' is not part of the accelerated path yet")
+        if map_to_latent.lower() == "mix":     # learned mixing over the particle axis as well (lgn_encoder.py:226-232)
+            tau_last = {w: int(v * num_input_particles) for w, v in tau_last.items()}
         self.tau_output = {w: 1 for w in tau_last}
         self.tau_output[(0, 0)] = tau_latent_scalars
         self.tau_output[(1, 1)] = tau_latent_vectors
@@ -92,6 +92,8 @@ class LGNEncoder(CGModule, LevelTablesMixin):
 
         # mix_reps acts on every irrep of the last level; only (0,0) and (1,1) are kept (lgn_encoder.py:322-325)
         last = feats[-1]
+        if self.map_to_latent.lower() == "mix":    # (2,B,N,C,d) -> (2,B,1,N*C,d)  (lgn_encoder.py:313-319)
+            last = {k: v.reshape(2, v.shape[1], 1, -1, v.shape[-1]) for k, v in last.items()}
         lat = {(0, 0): ops.MixFn.apply(self.mix_reps.weight((0, 0)), last[(0, 0)].contiguous()),
                (1, 1): ops.canonical_to_cart(ops.MixFn.apply(self.mix_reps.weight((1, 1)), last[(1, 1)].contiguous()))}
         latent = GVec(ops.aggregate_latent(self.map_to_latent, lat))

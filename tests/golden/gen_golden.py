@@ -17,6 +17,10 @@ Fixtures
   g3_e2e_n150.npz     end-to-end, B=1 N=150 maxdim=2
   g4_ops.npz          per-op vectors (cg_product, radial filters, geometry, pooling, chamfer ...)
   g5_tables.npz       CGDict(maxdim=3) coefficient tables (dense) + LorentzD matrices
+  g6_e2e_mix.npz      end-to-end, B=3 N=12 maxdim=2 ch 2233/3322, map_to_latent='mix' (learned mixing over particles)
+  g7_e2e_meanmax.npz  end-to-end, B=3 N=12, map_to_latent=mean+max
+
+`python gen_golden.py g6 g7` regenerates only the named fixtures.
 """
 import json
 import os
@@ -68,24 +72,25 @@ def jets(B, N, seed, pad_rows=()):
     return p4, labels
 
 
-def build(N, maxdim, ch_enc, ch_dec, seed):
+def build(N, maxdim, ch_enc, ch_dec, seed, map_to_latent="min&max"):
     torch.manual_seed(seed)
     common = dict(maxdim=[maxdim], max_zf=[1], weight_init="randn", level_gain=[1.0], num_basis_fn=10,
                   activation="leakyrelu", mlp=True, mlp_depth=6, mlp_width=6, device=CPU, dtype=F64)
-    enc = LGNEncoder(num_input_particles=N, tau_input_scalars=1, tau_input_vectors=1, map_to_latent="min&max",
+    enc = LGNEncoder(num_input_particles=N, tau_input_scalars=1, tau_input_vectors=1, map_to_latent=map_to_latent,
                      tau_latent_scalars=1, tau_latent_vectors=8, num_channels=list(ch_enc), scale=1.0,
                      jet_features=False, **common)
-    dec = LGNDecoder(tau_latent_scalars=2, tau_latent_vectors=16, num_output_particles=N, tau_output_scalars=1,
+    mult = len(map_to_latent.split("&"))          # '&' concatenates the pooled features (utils/initialize.py:118-120)
+    dec = LGNDecoder(tau_latent_scalars=1 * mult, tau_latent_vectors=8 * mult, num_output_particles=N, tau_output_scalars=1,
                      tau_output_vectors=1, num_channels=list(ch_dec), cg_dict=enc.cg_dict, **common)
     return enc, dec
 
 
-def e2e(name, B, N, maxdim, ch_enc, ch_dec, seed, pad_rows=()):
-    enc, dec = build(N, maxdim, ch_enc, ch_dec, seed)
+def e2e(name, B, N, maxdim, ch_enc, ch_dec, seed, pad_rows=(), map_to_latent="min&max"):
+    enc, dec = build(N, maxdim, ch_enc, ch_dec, seed, map_to_latent)
     p4, labels = jets(B, N, seed + 100, pad_rows)
     store = {"p4": npy(p4), "labels": npy(labels),
              "meta": np.array(json.dumps(dict(B=B, N=N, maxdim=maxdim, ch_enc=list(ch_enc), ch_dec=list(ch_dec),
-                                              seed=seed, l1_lambda=1e-8)))}
+                                              seed=seed, l1_lambda=1e-8, map_to_latent=map_to_latent)))}
     for k, v in enc.state_dict().items():
         store["enc." + k] = npy(v)
     for k, v in dec.state_dict().items():
@@ -232,8 +237,19 @@ def tables():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    e2e("g1_e2e_maxdim2.npz", 4, 30, 2, (3, 3, 4, 4), (4, 4, 3, 3), seed=0, pad_rows=((1, 17), (3, 25)))
-    e2e("g2_e2e_maxdim3.npz", 2, 30, 3, (4, 4, 6, 6), (6, 6, 4, 4), seed=1, pad_rows=((1, 21),))
-    e2e("g3_e2e_n150.npz", 1, 150, 2, (3, 3, 4, 4), (4, 4, 3, 3), seed=2, pad_rows=((0, 131),))
-    ops()
-    tables()
+    only = set(sys.argv[1:])
+    want = lambda tag: not only or tag in only          # noqa: E731
+    if want("g1"):
+        e2e("g1_e2e_maxdim2.npz", 4, 30, 2, (3, 3, 4, 4), (4, 4, 3, 3), seed=0, pad_rows=((1, 17), (3, 25)))
+    if want("g2"):
+        e2e("g2_e2e_maxdim3.npz", 2, 30, 3, (4, 4, 6, 6), (6, 6, 4, 4), seed=1, pad_rows=((1, 21),))
+    if want("g3"):
+        e2e("g3_e2e_n150.npz", 1, 150, 2, (3, 3, 4, 4), (4, 4, 3, 3), seed=2, pad_rows=((0, 131),))
+    if want("g4"):
+        ops()
+    if want("g5"):
+        tables()
+    if want("g6"):
+        e2e("g6_e2e_mix.npz", 3, 12, 2, (2, 2, 3, 3), (3, 3, 2, 2), seed=3, pad_rows=((1, 8),), map_to_latent="mix")
+    if want("g7"):
+        e2e("g7_e2e_meanmax.npz", 3, 12, 2, (2, 2, 3, 3), (3, 3, 2, 2), seed=4, pad_rows=((2, 9),), map_to_latent="mean+max")

@@ -159,7 +159,8 @@ def test_mixreps(dev, O, rows, Ci, Co, d):
 
 def _build(meta, dev):
     import __graft_entry__ as G
-    enc, dec = G._models(meta["N"], meta["ch_enc"], meta["ch_dec"], dev, seed=meta["seed"], maxdim=meta["maxdim"])
+    enc, dec = G._models(meta["N"], meta["ch_enc"], meta["ch_dec"], dev, seed=meta["seed"], maxdim=meta["maxdim"],
+                         map_to_latent=meta.get("map_to_latent", "min&max"))
     return enc, dec
 
 
@@ -230,7 +231,8 @@ def test_generic_level_fwd_bwd(dev, O, decoder, maxdim, full, C, CO, N, B):
         U.assert_close(w.grad, P[f"lgn_cg.node_levels.0.cat_mix.mix_reps.weights.{r}"].grad, GRAD_TOL, f"g_wmix {r}")
 
 
-@pytest.mark.parametrize("name", ["g1_e2e_maxdim2.npz", "g3_e2e_n150.npz", "g2_e2e_maxdim3.npz"])
+@pytest.mark.parametrize("name", ["g1_e2e_maxdim2.npz", "g3_e2e_n150.npz", "g2_e2e_maxdim3.npz", "g6_e2e_mix.npz",
+                                  "g7_e2e_meanmax.npz"])
 def test_end_to_end_vs_reference_golden(dev, O, name):
     """Full encoder -> decoder -> Chamfer forward/backward against vectors captured from the reference."""
     z = U.load(name)

@@ -10,12 +10,13 @@ TOL = 1e-12
 
 
 def _cfgs(m):
-    common = dict(num_particles=m["N"], maxdim=m["maxdim"])
+    common = dict(num_particles=m["N"], maxdim=m["maxdim"], map_to_latent=m.get("map_to_latent", "min&max"))
     return (O.NetConfig(num_channels=tuple(m["ch_enc"]), **common),
             O.NetConfig(num_channels=tuple(m["ch_dec"]), **common))
 
 
-@pytest.mark.parametrize("name", ["g1_e2e_maxdim2.npz", "g2_e2e_maxdim3.npz", "g3_e2e_n150.npz"])
+@pytest.mark.parametrize("name", ["g1_e2e_maxdim2.npz", "g2_e2e_maxdim3.npz", "g3_e2e_n150.npz", "g6_e2e_mix.npz",
+                                  "g7_e2e_meanmax.npz"])
 def test_end_to_end_forward_backward(name):
     z = U.load(name)
     m = U.meta(z)
