@@ -245,8 +245,13 @@ int mlp_dispatch(const MlpArgs<T>& a, bool backward, hipStream_t stream) {
   LGN_CHECK_ARG(a.H >= 2 * a.C && a.H <= 96, "cgmlp: hidden width %d unsupported (2C..96)", a.H);
   if (backward) LGN_CHECK_ARG((size_t)a.psize == mlp_param_count(a.C, a.H, a.nlin), "cgmlp: psize mismatch");
   {  // matrix-core path for H <= 48; the VALU kernels below cover wider MLPs
-    const int rc = mlp_mfma_dispatch(a, backward, stream);
+    int rc = mlp_mfma_dispatch(a, backward, stream);
     if (rc != -2) return rc;
+    static const bool valu_only = [] { const char* e = getenv("LGN_AMD_MLP_VALU"); return e && e[0] == '1'; }();
+    if (!valu_only) {
+      rc = mlp_mfma_wide_dispatch(a, backward, stream);
+      if (rc != -2) return rc;
+    }
   }
   const int opt = cdiv(a.H, 4);
   if (opt <= 3) return launch_mlp<T, 3>(a, backward, stream);

@@ -50,6 +50,7 @@ struct MlpArgs {
 };
 template <typename T> int mlp_dispatch(const MlpArgs<T>&, bool backward, hipStream_t);
 int mlp_mfma_dispatch(const MlpArgs<double>&, bool backward, hipStream_t);
+int mlp_mfma_wide_dispatch(const MlpArgs<double>&, bool backward, hipStream_t);   // 48 < H <= 96 (mlp_mfma_wide.hip)
 inline int mlp_partial_rows(int M) { return (M + 63) / 64; }
 
 // ---- MixReps (mixreps.hip) -----------------------------------------------------------------------------
