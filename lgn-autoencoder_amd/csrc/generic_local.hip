@@ -16,30 +16,58 @@ namespace {
 constexpr int NODES_PER_WG = 8;
 constexpr int MAXW = 16;      // CatMix weights accumulated per thread in the backward (n_w <= MAXW * BLOCK)
 
-__device__ __forceinline__ cx<double> ldU(const double* U, int node, int c, int C, int Q, int a) {
-  const double* u = U + (((size_t)node * C + c) * Q) * 10 + 2 * a;      // a = q*5 + k
-  return {u[0], u[1]};
-}
-__device__ __forceinline__ cx<double> ldX(const double* X, size_t plane, int node, int c, int C, int Q, int q) {
-  const size_t e = ((size_t)node * C + c) * Q + q;
-  return {X[e], X[plane + e]};
+// node data -> LDS: Ul [C][Q][5][2] (as in global), Xl [C*Q][2] (re, im interleaved); coalesced reads, then the table
+// walks below hit LDS instead of scattered global addresses
+__device__ __forceinline__ void stage_node(const LocalArgs& a, int node, double* Ul, double* Xl) {
+  const int CQ = a.C * a.Q;
+  const size_t plane = (size_t)a.nodes * CQ;
+  const double* u = a.U + (size_t)node * CQ * 10;
+  for (int e = threadIdx.x; e < CQ * 10; e += BLOCK) Ul[e] = u[e];
+  for (int e = threadIdx.x; e < CQ; e += BLOCK) {
+    Xl[2 * e] = a.X[(size_t)node * CQ + e];
+    Xl[2 * e + 1] = a.X[plane + (size_t)node * CQ + e];
+  }
 }
 
-__device__ __forceinline__ void build_cat(const LocalArgs& a, int node, double* cat) {
-  const int C = a.C, Q = a.Q;
-  const size_t plane = (size_t)a.nodes * C * Q;
-  for (int e = threadIdx.x; e < a.t.n_rows * C; e += BLOCK) {
+// cat[row][c] = sum_terms coef * value.  A row's terms are fetched four at a time (clamped index, zero coefficient past
+// the end, loads of all three operand kinds issued unconditionally) so that the round trips of a walk overlap; the terms
+// are still added in list order.
+__device__ __forceinline__ void build_cat(const LocalTables& t, int C, int Q, const double* Ul, const double* Xl, double* cat) {
+  for (int e = threadIdx.x; e < t.n_rows * C; e += BLOCK) {
     const int row = e / C, c = e - row * C;
+    const int beg = t.row_ptr[row], end = t.row_ptr[row + 1];
+    const double* ub = Ul + (c * Q) * 10;
+    const double* xb = Xl + 2 * (c * Q);
     cx<double> acc = {0, 0};
-    for (int t = a.t.row_ptr[row]; t < a.t.row_ptr[row + 1]; ++t) {
-      const int ty = a.t.t_type[t];
-      const double coef = a.t.t_coef[t];
-      cx<double> v;
-      if (ty == 0) v = ldU(a.U, node, c, C, Q, a.t.t_a[t]);
-      else if (ty == 1) v = ldX(a.X, plane, node, c, C, Q, a.t.t_a[t]);
-      else v = cmul(ldX(a.X, plane, node, c, C, Q, a.t.t_a[t]), ldX(a.X, plane, node, c, C, Q, a.t.t_b[t]));
-      acc.r += coef * v.r;
-      acc.i += coef * v.i;
+    for (int k = beg; k < end; k += 4) {
+      int ty[4], ia[4], ib[4];
+      double cf[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int kk = min(k + j, end - 1);
+        ty[j] = t.t_type[kk];
+        ia[j] = t.t_a[kk];
+        ib[j] = t.t_b[kk];
+        cf[j] = k + j < end ? t.t_coef[kk] : 0.0;
+      }
+      cx<double> u[4], x[4], y[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const double* up = ub + 2 * (ty[j] == 0 ? ia[j] : 0);       // type 0: U[a = q*5 + k']
+        const double* xp = xb + 2 * (ty[j] == 0 ? 0 : ia[j]);       // type 1, 2: X[a]
+        const double* yp = xb + 2 * (ty[j] == 2 ? ib[j] : 0);       // type 2: X[a] * X[b]
+        u[j] = {up[0], up[1]};
+        x[j] = {xp[0], xp[1]};
+        y[j] = {yp[0], yp[1]};
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const cx<double> xy = cmul(x[j], y[j]);
+        cx<double> v = ty[j] == 0 ? u[j] : x[j];
+        if (ty[j] == 2) v = xy;
+        acc.r += cf[j] * v.r;
+        acc.i += cf[j] * v.i;
+      }
     }
     cat[2 * e] = acc.r;
     cat[2 * e + 1] = acc.i;
@@ -57,11 +85,15 @@ __global__ __launch_bounds__(BLOCK) void local_fwd_kernel(LocalArgs a) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   double* cat = reinterpret_cast<double*>(smem_raw);          // n_rows * C * 2
   const int C = a.C, CO = a.CO, Qo = a.Qout;
+  double* Ul = cat + (size_t)a.t.n_rows * C * 2;              // C * Q * 10
+  double* Xl = Ul + (size_t)C * a.Q * 10;                     // C * Q * 2
   const size_t plo = (size_t)a.nodes * CO * Qo;
   for (int nl = 0; nl < NODES_PER_WG; ++nl) {
     const int node = blockIdx.x * NODES_PER_WG + nl;
     if (node >= a.nodes) break;
-    build_cat(a, node, cat);
+    stage_node(a, node, Ul, Xl);
+    __syncthreads();
+    build_cat(a.t, C, a.Q, Ul, Xl, cat);
     __syncthreads();
     for (int e = threadIdx.x; e < CO * Qo; e += BLOCK) {
       const int o = e / Qo, q = e - o * Qo;
@@ -69,16 +101,22 @@ __global__ __launch_bounds__(BLOCK) void local_fwd_kernel(LocalArgs a) {
       const int K = nb * C;
       const double* wr = a.wcat + a.t.out_w0[l] + (size_t)o * K;
       const double* wi = wr + (size_t)CO * K;
-      cx<double> acc = {0, 0};
+      cx<double> acc0 = {0, 0}, acc1 = {0, 0};               // two chains: the sum over (block, channel) is latency bound
+      const int row0 = a.t.out_row0[l];
       for (int blk = 0; blk < nb; ++blk) {
-        const double* cr = cat + (size_t)(a.t.out_row0[l] + blk * d + m) * C * 2;
-        for (int c = 0; c < C; ++c) cfma(acc, cx<double>{wr[blk * C + c], wi[blk * C + c]}, cx<double>{cr[2 * c], cr[2 * c + 1]});
+        const double* cr = cat + (size_t)(row0 + blk * d + m) * C * 2;
+        int c = 0;
+        for (; c + 1 < C; c += 2) {
+          cfma(acc0, cx<double>{wr[blk * C + c], wi[blk * C + c]}, cx<double>{cr[2 * c], cr[2 * c + 1]});
+          cfma(acc1, cx<double>{wr[blk * C + c + 1], wi[blk * C + c + 1]}, cx<double>{cr[2 * c + 2], cr[2 * c + 3]});
+        }
+        if (c < C) cfma(acc0, cx<double>{wr[blk * C + c], wi[blk * C + c]}, cx<double>{cr[2 * c], cr[2 * c + 1]});
       }
       const size_t oe = ((size_t)node * CO + o) * Qo + q;
-      a.out[oe] = acc.r;
-      a.out[plo + oe] = acc.i;
+      a.out[oe] = acc0.r + acc1.r;
+      a.out[plo + oe] = acc0.i + acc1.i;
     }
-    __syncthreads();
+    // (the next node's staging touches Ul / Xl only; cat is rewritten after the barrier that follows it)
   }
 }
 
@@ -88,6 +126,8 @@ __global__ __launch_bounds__(BLOCK) void local_bwd_kernel(LocalArgs a) {
   double* cat = reinterpret_cast<double*>(smem_raw);          // n_rows * C * 2
   double* gcat = cat + (size_t)a.t.n_rows * C * 2;            // n_rows * C * 2
   double* go = gcat + (size_t)a.t.n_rows * C * 2;             // CO * Qo * 2
+  double* Ul = go + (size_t)CO * Qo * 2;                      // C * Q * 10
+  double* Xl = Ul + (size_t)C * Q * 10;                       // C * Q * 2
   const size_t plo = (size_t)a.nodes * CO * Qo, plx = (size_t)a.nodes * C * Q;
   cx<double> dw[MAXW];
 #pragma unroll
@@ -96,12 +136,14 @@ __global__ __launch_bounds__(BLOCK) void local_bwd_kernel(LocalArgs a) {
   for (int nl = 0; nl < NODES_PER_WG; ++nl) {
     const int node = blockIdx.x * NODES_PER_WG + nl;
     if (node >= a.nodes) break;
-    build_cat(a, node, cat);
+    stage_node(a, node, Ul, Xl);
     for (int e = threadIdx.x; e < CO * Qo; e += BLOCK) {
       const size_t oe = (size_t)node * CO * Qo + e;
       go[2 * e] = a.g_out[oe];
       go[2 * e + 1] = a.g_out[plo + oe];
     }
+    __syncthreads();
+    build_cat(a.t, C, Q, Ul, Xl, cat);
     __syncthreads();
     // gradient of the concatenated rows
     for (int e = threadIdx.x; e < a.t.n_rows * C; e += BLOCK) {
@@ -158,7 +200,7 @@ __global__ __launch_bounds__(BLOCK) void local_bwd_kernel(LocalArgs a) {
         const double coef = a.t.x_coef[t];
         const int row = a.t.x_row[t], other = a.t.x_other[t];
         cx<double> g = {coef * gcat[2 * (row * C + c)], coef * gcat[2 * (row * C + c) + 1]};
-        if (other >= 0) g = cmulc(g, ldX(a.X, plx, node, c, C, Q, other));
+        if (other >= 0) g = cmulc(g, cx<double>{Xl[2 * (c * Q + other)], Xl[2 * (c * Q + other) + 1]});
         acc.r += g.r;
         acc.i += g.i;
       }
@@ -187,7 +229,7 @@ int local_partial_rows(int nodes) { return cdiv(nodes, NODES_PER_WG); }
 
 int local_fwd(const LocalArgs& a, hipStream_t st) {
   LGN_CHECK_ARG(a.nodes > 0 && a.C >= 1 && a.CO >= 1, "local_fwd: empty input");
-  const size_t smem = sizeof(double) * (size_t)a.t.n_rows * a.C * 2;
+  const size_t smem = sizeof(double) * ((size_t)a.t.n_rows * a.C * 2 + (size_t)a.C * a.Q * 12);
   LGN_CHECK_ARG(smem <= 160 * 1024, "local_fwd: %zu B of LDS needed", smem);
   if (smem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(local_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   hipLaunchKernelGGL(local_fwd_kernel, dim3(local_partial_rows(a.nodes)), dim3(BLOCK), smem, st, a);
@@ -198,7 +240,7 @@ int local_fwd(const LocalArgs& a, hipStream_t st) {
 int local_bwd(const LocalArgs& a, hipStream_t st) {
   LGN_CHECK_ARG(a.nodes > 0 && a.C >= 1 && a.CO >= 1, "local_bwd: empty input");
   LGN_CHECK_ARG(a.t.n_w <= MAXW * BLOCK, "local_bwd: %d CatMix weights exceed the per-workgroup accumulator budget", a.t.n_w);
-  const size_t smem = sizeof(double) * ((size_t)a.t.n_rows * a.C * 4 + (size_t)a.CO * a.Qout * 2);
+  const size_t smem = sizeof(double) * ((size_t)a.t.n_rows * a.C * 4 + (size_t)a.CO * a.Qout * 2 + (size_t)a.C * a.Q * 12);
   LGN_CHECK_ARG(smem <= 160 * 1024, "local_bwd: %zu B of LDS needed", smem);
   if (smem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(local_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   hipLaunchKernelGGL(local_bwd_kernel, dim3(local_partial_rows(a.nodes)), dim3(BLOCK), smem, st, a);
