@@ -13,6 +13,7 @@
 namespace lgn {
 
 namespace {
+LGN_STAMP_DECL
 constexpr int NODES_PER_WG = 8;
 constexpr int MAXW = 16;      // CatMix weights accumulated per thread in the backward (n_w <= MAXW * BLOCK)
 
@@ -80,6 +81,7 @@ __device__ __forceinline__ int irrep_of(const LocalTables& t, int q) {
   return l;
 }
 }  // namespace
+LGN_STAMP_READER(lgn_debug_stamps_local)
 
 __global__ __launch_bounds__(BLOCK) void local_fwd_kernel(LocalArgs a) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -128,6 +130,23 @@ __global__ __launch_bounds__(BLOCK) void local_bwd_kernel(LocalArgs a) {
   double* go = gcat + (size_t)a.t.n_rows * C * 2;             // CO * Qo * 2
   double* Ul = go + (size_t)CO * Qo * 2;                      // C * Q * 10
   double* Xl = Ul + (size_t)C * Q * 10;                       // C * Q * 2
+  int* winfo = reinterpret_cast<int*>(Xl + (size_t)C * Q * 2);  // n_w packed (first cat row, q0, d, o, c) of every CatMix weight
+  for (int w = threadIdx.x; w < a.t.n_w; w += BLOCK) {        // decoded once per workgroup, not once per node
+    int l = 0, base = 0;
+    while (l + 1 < a.t.n_out && w >= base + CO * a.t.out_nblk[l] * C) { base += CO * a.t.out_nblk[l] * C; ++l; }
+    const int K = a.t.out_nblk[l] * C, rel = w - base, o = rel / K, kc = rel - o * K, blk = kc / C, c = kc - blk * C;
+    const int d = a.t.out_dim[l];
+    winfo[w] = (a.t.out_row0[l] + blk * d) | (a.t.out_q0[l] << 10) | (d << 16) | (o << 20) | (c << 24);
+  }
+  int* rinfo = winfo + a.t.n_w;                              // per cat row: q | K << 8, and the offset of W_l[0][blk * C]
+  int* rwoff = rinfo + a.t.n_rows;
+  for (int row = threadIdx.x; row < a.t.n_rows; row += BLOCK) {
+    int l = 0;
+    while (l + 1 < a.t.n_out && row >= a.t.out_row0[l + 1]) ++l;
+    const int d = a.t.out_dim[l], rel = row - a.t.out_row0[l], blk = rel / d, m = rel - blk * d;
+    rinfo[row] = (a.t.out_q0[l] + m) | ((a.t.out_nblk[l] * C) << 8);
+    rwoff[row] = a.t.out_w0[l] + blk * C;
+  }
   const size_t plo = (size_t)a.nodes * CO * Qo, plx = (size_t)a.nodes * C * Q;
   cx<double> dw[MAXW];
 #pragma unroll
@@ -136,6 +155,7 @@ __global__ __launch_bounds__(BLOCK) void local_bwd_kernel(LocalArgs a) {
   for (int nl = 0; nl < NODES_PER_WG; ++nl) {
     const int node = blockIdx.x * NODES_PER_WG + nl;
     if (node >= a.nodes) break;
+    if (nl == 0) STAMP(0);
     stage_node(a, node, Ul, Xl);
     for (int e = threadIdx.x; e < CO * Qo; e += BLOCK) {
       const size_t oe = (size_t)node * CO * Qo + e;
@@ -143,73 +163,126 @@ __global__ __launch_bounds__(BLOCK) void local_bwd_kernel(LocalArgs a) {
       go[2 * e + 1] = a.g_out[plo + oe];
     }
     __syncthreads();
+    if (nl == 0) STAMP(1);
     build_cat(a.t, C, Q, Ul, Xl, cat);
     __syncthreads();
+    if (nl == 0) STAMP(2);
     // gradient of the concatenated rows
     for (int e = threadIdx.x; e < a.t.n_rows * C; e += BLOCK) {
       const int row = e / C, c = e - row * C;
-      int l = 0;
-      while (l + 1 < a.t.n_out && row >= a.t.out_row0[l + 1]) ++l;
-      const int d = a.t.out_dim[l], rel = row - a.t.out_row0[l], blk = rel / d, m = rel - blk * d;
-      const int K = a.t.out_nblk[l] * C, q = a.t.out_q0[l] + m;
-      cx<double> acc = {0, 0};
-      for (int o = 0; o < CO; ++o) {
-        const double* wr = a.wcat + a.t.out_w0[l] + (size_t)o * K;
+      const int q = rinfo[row] & 255, K = rinfo[row] >> 8;
+      cx<double> acc = {0, 0}, acc1 = {0, 0};
+      const double* wbase = a.wcat + rwoff[row] + c;
+      int o = 0;
+      for (; o + 1 < CO; o += 2) {                       // two chains: the weights come from global memory (L1)
+        const double* wr = wbase + (size_t)o * K;
         const double* wi = wr + (size_t)CO * K;
-        cfmac(acc, cx<double>{go[2 * (o * Qo + q)], go[2 * (o * Qo + q) + 1]}, cx<double>{wr[blk * C + c], wi[blk * C + c]});
+        cfmac(acc, cx<double>{go[2 * (o * Qo + q)], go[2 * (o * Qo + q) + 1]}, cx<double>{wr[0], wi[0]});
+        cfmac(acc1, cx<double>{go[2 * ((o + 1) * Qo + q)], go[2 * ((o + 1) * Qo + q) + 1]}, cx<double>{wr[K], wi[K]});
       }
+      if (o < CO) {
+        const double* wr = wbase + (size_t)o * K;
+        const double* wi = wr + (size_t)CO * K;
+        cfmac(acc, cx<double>{go[2 * (o * Qo + q)], go[2 * (o * Qo + q) + 1]}, cx<double>{wr[0], wi[0]});
+      }
+      acc.r += acc1.r;
+      acc.i += acc1.i;
       gcat[2 * e] = acc.r;
       gcat[2 * e + 1] = acc.i;
     }
+    if (nl == 0) STAMP(3);
     // CatMix weight gradient, accumulated over this workgroup's nodes:  dW_l[o][k] += sum_m g_out[o][q0+m] conj(cat[row][c])
 #pragma unroll
     for (int k = 0; k < MAXW; ++k) {
       const int w = threadIdx.x + k * BLOCK;
       if (w < a.t.n_w) {
-        int l = 0, base = 0;
-        // weights are ordered irrep by irrep: CO * nblk_l * C complex each
-        while (l + 1 < a.t.n_out && w >= base + CO * a.t.out_nblk[l] * C) { base += CO * a.t.out_nblk[l] * C; ++l; }
-        const int K = a.t.out_nblk[l] * C, rel = w - base, o = rel / K, kc = rel - o * K, blk = kc / C, c = kc - blk * C;
-        const int d = a.t.out_dim[l];
-        for (int m = 0; m < d; ++m) {
-          const int row = a.t.out_row0[l] + blk * d + m, q = a.t.out_q0[l] + m;
-          cfmac(dw[k], cx<double>{go[2 * (o * Qo + q)], go[2 * (o * Qo + q) + 1]}, cx<double>{cat[2 * (row * C + c)], cat[2 * (row * C + c) + 1]});
-        }
+        const int info = winfo[w];
+        const int row = info & 1023, q0 = (info >> 10) & 63, d = (info >> 16) & 15, o = (info >> 20) & 15, c = info >> 24;
+        for (int m = 0; m < d; ++m)
+          cfmac(dw[k], cx<double>{go[2 * (o * Qo + q0 + m)], go[2 * (o * Qo + q0 + m) + 1]},
+                cx<double>{cat[2 * ((row + m) * C + c)], cat[2 * ((row + m) * C + c) + 1]});
       }
     }
+    if (nl == 0) STAMP(4);
     __syncthreads();
+    if (nl == 0) STAMP(5);
     // gradient of the moments
     for (int e = threadIdx.x; e < C * Q * 5; e += BLOCK) {
       const int c = e / (Q * 5), uq = e - c * Q * 5;
       cx<double> acc = {0, 0};
-      for (int t = a.t.u_ptr[uq]; t < a.t.u_ptr[uq + 1]; ++t) {
-        const double coef = a.t.u_coef[t];
-        const int row = a.t.u_row[t];
-        acc.r += coef * gcat[2 * (row * C + c)];
-        acc.i += coef * gcat[2 * (row * C + c) + 1];
+      const int ub0 = a.t.u_ptr[uq], ue0 = a.t.u_ptr[uq + 1];
+      for (int t = ub0; t < ue0; t += 4) {               // four terms in flight, added in list order
+        double cf[4];
+        cx<double> gv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int tt = min(t + j, ue0 - 1);
+          cf[j] = t + j < ue0 ? a.t.u_coef[tt] : 0.0;
+          const double* gp = gcat + 2 * (a.t.u_row[tt] * C + c);
+          gv[j] = {gp[0], gp[1]};
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc.r += cf[j] * gv[j].r;
+          acc.i += cf[j] * gv[j].i;
+        }
       }
       double* gu = a.gU + (((size_t)node * C + c) * Q) * 10 + 2 * uq;
       gu[0] = acc.r;
       gu[1] = acc.i;
     }
+    if (nl == 0) STAMP(6);
     // gradient of the node features (direct block + power terms); the N^2 backward adds the aggregate part later
-    for (int e = threadIdx.x; e < C * Q; e += BLOCK) {
-      const int c = e / Q, q = e - c * Q;
+    // a component's term list is long (every product it enters): 8 lanes share one (channel, component), each walks
+    // every 8th group of four terms, and the partial sums meet by lane shuffles
+    for (int e8 = threadIdx.x; e8 < ((C * Q * 8 + 63) & ~63); e8 += BLOCK) {
+      const int e = e8 >> 3, sub = e8 & 7;
+      const bool live = e < C * Q;
+      const int c = live ? e / Q : 0, q = live ? e - c * Q : 0;
       cx<double> acc = {0, 0};
-      for (int t = a.t.x_ptr[q]; t < a.t.x_ptr[q + 1]; ++t) {
-        const double coef = a.t.x_coef[t];
-        const int row = a.t.x_row[t], other = a.t.x_other[t];
-        cx<double> g = {coef * gcat[2 * (row * C + c)], coef * gcat[2 * (row * C + c) + 1]};
-        if (other >= 0) g = cmulc(g, cx<double>{Xl[2 * (c * Q + other)], Xl[2 * (c * Q + other) + 1]});
-        acc.r += g.r;
-        acc.i += g.i;
+      const int xb0 = a.t.x_ptr[q], xe0 = live ? a.t.x_ptr[q + 1] : xb0;
+      for (int t = xb0 + 4 * sub; t < xe0; t += 32) {     // four terms in flight
+        double cf[4];
+        int oth[4];
+        cx<double> gv[4], xo[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int tt = min(t + j, xe0 - 1);
+          cf[j] = t + j < xe0 ? a.t.x_coef[tt] : 0.0;
+          oth[j] = a.t.x_other[tt];
+          const double* gp = gcat + 2 * (a.t.x_row[tt] * C + c);
+          gv[j] = {gp[0], gp[1]};
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const double* xp = Xl + 2 * (c * Q + (oth[j] >= 0 ? oth[j] : 0));
+          xo[j] = {xp[0], xp[1]};
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          cx<double> g = {cf[j] * gv[j].r, cf[j] * gv[j].i};
+          const cx<double> gx = cmulc(g, xo[j]);
+          if (oth[j] >= 0) g = gx;
+          acc.r += g.r;
+          acc.i += g.i;
+        }
       }
-      const size_t xe = ((size_t)node * C + c) * Q + q;
-      a.gX[xe] = acc.r;
-      a.gX[plx + xe] = acc.i;
+#pragma unroll
+      for (int m = 1; m < 8; m <<= 1) {
+        acc.r += shfl_xor(acc.r, m);
+        acc.i += shfl_xor(acc.i, m);
+      }
+      if (live && sub == 0) {
+        const size_t xe = ((size_t)node * C + c) * Q + q;
+        a.gX[xe] = acc.r;
+        a.gX[plx + xe] = acc.i;
+      }
     }
+    if (nl == 0) STAMP(7);
     __syncthreads();
+    if (nl == 0) STAMP(8);
   }
+  STAMP(9);
   // partial row of this workgroup, layout like wcat: per irrep [2][CO][K]
   double* part = a.part + (size_t)blockIdx.x * 2 * a.t.n_w;
 #pragma unroll
@@ -240,7 +313,8 @@ int local_fwd(const LocalArgs& a, hipStream_t st) {
 int local_bwd(const LocalArgs& a, hipStream_t st) {
   LGN_CHECK_ARG(a.nodes > 0 && a.C >= 1 && a.CO >= 1, "local_bwd: empty input");
   LGN_CHECK_ARG(a.t.n_w <= MAXW * BLOCK, "local_bwd: %d CatMix weights exceed the per-workgroup accumulator budget", a.t.n_w);
-  const size_t smem = sizeof(double) * ((size_t)a.t.n_rows * a.C * 4 + (size_t)a.CO * a.Qout * 2 + (size_t)a.C * a.Q * 12);
+  const size_t smem = sizeof(double) * ((size_t)a.t.n_rows * a.C * 4 + (size_t)a.CO * a.Qout * 2 + (size_t)a.C * a.Q * 12) +
+                      sizeof(int) * ((size_t)a.t.n_w + 2 * (size_t)a.t.n_rows);
   LGN_CHECK_ARG(smem <= 160 * 1024, "local_bwd: %zu B of LDS needed", smem);
   if (smem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(local_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   hipLaunchKernelGGL(local_bwd_kernel, dim3(local_partial_rows(a.nodes)), dim3(BLOCK), smem, st, a);
