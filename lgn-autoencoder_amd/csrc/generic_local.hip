@@ -30,6 +30,33 @@ __device__ __forceinline__ void stage_node(const LocalArgs& a, int node, double*
   }
 }
 
+// The next node's data is fetched into registers while the current node is processed (the loads' latency would otherwise
+// sit at the head of every node's chain of barrier-separated phases) and moved to LDS once the current node is done with it.
+constexpr int PF_U = 7;               // C * Q * 10 <= PF_U * BLOCK, C * Q <= BLOCK, CO * Qout <= BLOCK (checked at launch)
+struct NodePrefetch {
+  double u[PF_U], x0, x1, g0, g1;
+};
+__device__ __forceinline__ void prefetch_node(const LocalArgs& a, int node, bool with_g, NodePrefetch& P) {
+  const int CQ = a.C * a.Q, COQ = a.CO * a.Qout, tid = threadIdx.x;
+  const double* u = a.U + (size_t)node * CQ * 10;
+#pragma unroll
+  for (int i = 0; i < PF_U; ++i) P.u[i] = tid + i * BLOCK < CQ * 10 ? u[tid + i * BLOCK] : 0.0;
+  P.x0 = tid < CQ ? a.X[(size_t)node * CQ + tid] : 0.0;
+  P.x1 = tid < CQ ? a.X[(size_t)a.nodes * CQ + (size_t)node * CQ + tid] : 0.0;
+  if (with_g) {
+    P.g0 = tid < COQ ? a.g_out[(size_t)node * COQ + tid] : 0.0;
+    P.g1 = tid < COQ ? a.g_out[(size_t)a.nodes * COQ + (size_t)node * COQ + tid] : 0.0;
+  }
+}
+__device__ __forceinline__ void commit_node(const LocalArgs& a, const NodePrefetch& P, double* Ul, double* Xl, double* go) {
+  const int CQ = a.C * a.Q, COQ = a.CO * a.Qout, tid = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < PF_U; ++i)
+    if (tid + i * BLOCK < CQ * 10) Ul[tid + i * BLOCK] = P.u[i];
+  if (tid < CQ) { Xl[2 * tid] = P.x0;  Xl[2 * tid + 1] = P.x1; }
+  if (go && tid < COQ) { go[2 * tid] = P.g0;  go[2 * tid + 1] = P.g1; }
+}
+
 // cat[row][c] = sum_terms coef * value.  A row's terms are fetched four at a time (clamped index, zero coefficient past
 // the end, loads of all three operand kinds issued unconditionally) so that the round trips of a walk overlap; the terms
 // are still added in list order.
@@ -90,13 +117,17 @@ __global__ __launch_bounds__(BLOCK) void local_fwd_kernel(LocalArgs a) {
   double* Ul = cat + (size_t)a.t.n_rows * C * 2;              // C * Q * 10
   double* Xl = Ul + (size_t)C * a.Q * 10;                     // C * Q * 2
   const size_t plo = (size_t)a.nodes * CO * Qo;
+  NodePrefetch P;
+  if ((int)blockIdx.x * NODES_PER_WG < a.nodes) stage_node(a, blockIdx.x * NODES_PER_WG, Ul, Xl);
+  __syncthreads();
   for (int nl = 0; nl < NODES_PER_WG; ++nl) {
     const int node = blockIdx.x * NODES_PER_WG + nl;
     if (node >= a.nodes) break;
-    stage_node(a, node, Ul, Xl);
-    __syncthreads();
+    const bool more = nl + 1 < NODES_PER_WG && node + 1 < a.nodes;
+    if (more) prefetch_node(a, node + 1, false, P);
     build_cat(a.t, C, a.Q, Ul, Xl, cat);
     __syncthreads();
+    if (more) commit_node(a, P, Ul, Xl, nullptr);          // Ul / Xl are free once the cat rows exist
     for (int e = threadIdx.x; e < CO * Qo; e += BLOCK) {
       const int o = e / Qo, q = e - o * Qo;
       const int l = irrep_of(a.t, q), m = q - a.t.out_q0[l], d = a.t.out_dim[l], nb = a.t.out_nblk[l];
@@ -118,7 +149,7 @@ __global__ __launch_bounds__(BLOCK) void local_fwd_kernel(LocalArgs a) {
       a.out[oe] = acc0.r + acc1.r;
       a.out[plo + oe] = acc0.i + acc1.i;
     }
-    // (the next node's staging touches Ul / Xl only; cat is rewritten after the barrier that follows it)
+    __syncthreads();                                       // cat is rewritten by the next node; its Ul / Xl are in place
   }
 }
 
@@ -147,22 +178,23 @@ __global__ __launch_bounds__(BLOCK) void local_bwd_kernel(LocalArgs a) {
     rinfo[row] = (a.t.out_q0[l] + m) | ((a.t.out_nblk[l] * C) << 8);
     rwoff[row] = a.t.out_w0[l] + blk * C;
   }
-  const size_t plo = (size_t)a.nodes * CO * Qo, plx = (size_t)a.nodes * C * Q;
+  const size_t plx = (size_t)a.nodes * C * Q;
   cx<double> dw[MAXW];
 #pragma unroll
   for (int k = 0; k < MAXW; ++k) dw[k] = {0, 0};
+  NodePrefetch P;
 
   for (int nl = 0; nl < NODES_PER_WG; ++nl) {
     const int node = blockIdx.x * NODES_PER_WG + nl;
     if (node >= a.nodes) break;
     if (nl == 0) STAMP(0);
-    stage_node(a, node, Ul, Xl);
-    for (int e = threadIdx.x; e < CO * Qo; e += BLOCK) {
-      const size_t oe = (size_t)node * CO * Qo + e;
-      go[2 * e] = a.g_out[oe];
-      go[2 * e + 1] = a.g_out[plo + oe];
+    const bool more = nl + 1 < NODES_PER_WG && node + 1 < a.nodes;
+    if (nl == 0) {
+      prefetch_node(a, node, true, P);
+      commit_node(a, P, Ul, Xl, go);
+      __syncthreads();
     }
-    __syncthreads();
+    if (more) prefetch_node(a, node + 1, true, P);
     if (nl == 0) STAMP(1);
     build_cat(a.t, C, Q, Ul, Xl, cat);
     __syncthreads();
@@ -279,6 +311,8 @@ __global__ __launch_bounds__(BLOCK) void local_bwd_kernel(LocalArgs a) {
       }
     }
     if (nl == 0) STAMP(7);
+    __syncthreads();                                       // every read of Ul / Xl / go / cat / gcat of this node is done
+    if (more) commit_node(a, P, Ul, Xl, go);
     __syncthreads();
     if (nl == 0) STAMP(8);
   }
@@ -302,6 +336,7 @@ int local_partial_rows(int nodes) { return cdiv(nodes, NODES_PER_WG); }
 
 int local_fwd(const LocalArgs& a, hipStream_t st) {
   LGN_CHECK_ARG(a.nodes > 0 && a.C >= 1 && a.CO >= 1, "local_fwd: empty input");
+  LGN_CHECK_ARG(a.C * a.Q <= BLOCK && a.C * a.Q * 10 <= PF_U * BLOCK && a.CO * a.Qout <= BLOCK, "local_fwd: C*Q=%d too large", a.C * a.Q);
   const size_t smem = sizeof(double) * ((size_t)a.t.n_rows * a.C * 2 + (size_t)a.C * a.Q * 12);
   LGN_CHECK_ARG(smem <= 160 * 1024, "local_fwd: %zu B of LDS needed", smem);
   if (smem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(local_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -312,6 +347,7 @@ int local_fwd(const LocalArgs& a, hipStream_t st) {
 
 int local_bwd(const LocalArgs& a, hipStream_t st) {
   LGN_CHECK_ARG(a.nodes > 0 && a.C >= 1 && a.CO >= 1, "local_bwd: empty input");
+  LGN_CHECK_ARG(a.C * a.Q <= BLOCK && a.C * a.Q * 10 <= PF_U * BLOCK && a.CO * a.Qout <= BLOCK, "local_bwd: C*Q=%d too large", a.C * a.Q);
   LGN_CHECK_ARG(a.t.n_w <= MAXW * BLOCK, "local_bwd: %d CatMix weights exceed the per-workgroup accumulator budget", a.t.n_w);
   const size_t smem = sizeof(double) * ((size_t)a.t.n_rows * a.C * 4 + (size_t)a.CO * a.Qout * 2 + (size_t)a.C * a.Q * 12) +
                       sizeof(int) * ((size_t)a.t.n_w + 2 * (size_t)a.t.n_rows);
