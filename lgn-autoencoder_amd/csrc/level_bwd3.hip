@@ -297,12 +297,18 @@ __global__ __launch_bounds__(BLOCK) void level_bwd3_kernel(LevelBwdArgs<double> 
   }
 
   if constexpr (DEC && SEP) {
+    STAMP(3);
     __syncthreads();                                    // g_ag / gd are complete; the phase-1 scratch is dead
+    STAMP(4);
     // centre the momenta on the jet mean (only differences enter; see level_fwd2.hip)
-    if (tid < 8) {
+    if (tid < 64) {                                       // lane = (node part, component): 8 x 8, parts meet by shuffles
+      const int k = tid & 7, part = tid >> 3;
       double mean = 0.0;
-      for (int n = 0; n < N; ++n) mean += pj[n * 8 + tid];
-      sm[tid] = mean / N;
+      for (int n = part; n < N; n += 8) mean += pj[n * 8 + k];
+      mean += shfl_xor(mean, 8);
+      mean += shfl_xor(mean, 16);
+      mean += shfl_xor(mean, 32);
+      if (part == 0) sm[k] = mean / N;
     }
     __syncthreads();
     for (int e = tid; e < N * 8; e += BLOCK) pj[e] -= sm[e & 7];
@@ -360,12 +366,14 @@ __global__ __launch_bounds__(BLOCK) void level_bwd3_kernel(LevelBwdArgs<double> 
       if (tid < nv * C) {
         const int c = tid / nv, k = tid - c * nv;
         double total = 0.0;
+#pragma unroll 8
         for (int n = 0; n < N; ++n) total += tr[(n * C + c) * 20 + k];
         sm[c * 50 + round * 20 + k] = total;
       }
       __syncthreads();
     }
 
+    STAMP(5);
     // ---- node gradient: neighbour part from the sums + direct part, written once --------------------------------
     const size_t pls = (size_t)B * N * C;
     for (int e = tid; e < N * C; e += BLOCK) {
@@ -408,6 +416,7 @@ __global__ __launch_bounds__(BLOCK) void level_bwd3_kernel(LevelBwdArgs<double> 
         a.g_v_in[pls * 4 + ge * 4 + m] = gdn[6 + m] + gv.i;
       }
     }
+    STAMP(6);
     // ---- position gradient: d p_n[m] += sum_c conj(R1) [ gA2_n[m] conj(S) + gA3_n conj(VSt[m]) - SG2[m] conj(s_n) - SG3 conj(vt_n[m]) ]
     {
       const size_t plp = (size_t)B * N * 4;
@@ -464,6 +473,7 @@ __global__ __launch_bounds__(BLOCK) void level_bwd3_kernel(LevelBwdArgs<double> 
         part[tid] = (E1.r - neg.r) + (E1.i - neg.i);
       }
     }
+    STAMP(7);
     return;
   }
 

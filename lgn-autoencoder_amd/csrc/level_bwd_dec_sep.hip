@@ -33,10 +33,14 @@ __global__ __launch_bounds__(BLOCK) void level_bwd_dec_sep_kernel(LevelBwdArgs<d
     pj[(e >> 2) * 8 + 4 + (e & 3)] = a.p[plp + (size_t)b * N * 4 + e];
   }
   __syncthreads();
-  if (tid < 8) {                                        // centre on the jet mean: only differences p_i - p_j enter
+  if (tid < 64) {                                       // centre on the jet mean (only differences p_i - p_j enter):
+    const int k = tid & 7, part = tid >> 3;             // lane = (node part, component), parts meet by shuffles
     double mean = 0.0;
-    for (int n = 0; n < N; ++n) mean += pj[n * 8 + tid];
-    sm[tid] = mean / N;
+    for (int n = part; n < N; n += 8) mean += pj[n * 8 + k];
+    mean += shfl_xor(mean, 8);
+    mean += shfl_xor(mean, 16);
+    mean += shfl_xor(mean, 32);
+    if (part == 0) sm[k] = mean / N;
   }
   __syncthreads();
   for (int e = tid; e < N * 8; e += BLOCK) pj[e] -= sm[e & 7];
@@ -95,6 +99,7 @@ __global__ __launch_bounds__(BLOCK) void level_bwd_dec_sep_kernel(LevelBwdArgs<d
       __syncthreads();
       if (tid < nv * C) {
         const int c = tid / nv, k = tid - c * nv;
+#pragma unroll 8
         for (int rl = 0; rl < rows; ++rl) total += tr[(rl * C + c) * 20 + k];
       }
       __syncthreads();

@@ -127,10 +127,14 @@ __global__ __launch_bounds__(2 * BLOCK) void level_fwd2_kernel(LevelArgs<double>
   if constexpr (DEC && SEP) {
     // Only differences p_i - p_j enter: centre the momenta on the jet mean first, so that the separated sums
     // p_i S - SP do not cancel digits the pair sweep would keep (boosted jets: |p| >> |p_i - p_j|).
-    if (tid < 8) {
+    if (tid < 64) {                                       // lane = (node part, component): 8 x 8, parts meet by shuffles
+      const int k = tid & 7, part = tid >> 3;
       double mean = 0.0;
-      for (int n = 0; n < N; ++n) mean += pj[n * 8 + tid];
-      sums[tid] = mean / N;
+      for (int n = part; n < N; n += 8) mean += pj[n * 8 + k];
+      mean += shfl_xor(mean, 8);
+      mean += shfl_xor(mean, 16);
+      mean += shfl_xor(mean, 32);
+      if (part == 0) sums[k] = mean / N;
     }
     __syncthreads();
     for (int e = tid; e < N * 8; e += nthr) pj[e] -= sums[e & 7];
@@ -165,6 +169,7 @@ __global__ __launch_bounds__(2 * BLOCK) void level_fwd2_kernel(LevelArgs<double>
       __syncthreads();
       if (tid < 20 * C) {
         const int c = tid / 20, k = tid - c * 20;
+#pragma unroll 8
         for (int rl = 0; rl < rows; ++rl) total += agl[(rl * C + c) * 20 + k];
       }
       __syncthreads();
