@@ -329,13 +329,22 @@ __device__ __forceinline__ void dec_input_fwd_body(int B, int N, int C, int Tin,
                                                              const double* __restrict__ w1, double* pdec, double* s0, double* v0, unsigned char* smem_raw) {
   const int b = blockIdx.x;
   const size_t plp = (size_t)B * N * 4, pl = (size_t)B * N * C;
+  // the latent vectors of the jet and latent_to_graph's weights go to LDS first: the sum over the latent channels below
+  // would otherwise be a chain of Tin dependent global round trips per particle
+  double* wgl = reinterpret_cast<double*>(smem_raw);     // [2][N][Tin]
+  double* latl = wgl + 2 * N * Tin;                      // [Tin][8]
+  for (int e = threadIdx.x; e < 2 * N * Tin; e += BLOCK) wgl[e] = wg1[e];
+  for (int e = threadIdx.x; e < Tin * 4; e += BLOCK) {
+    latl[(e >> 2) * 8 + (e & 3)] = lat_v[(size_t)b * Tin * 4 + e];
+    latl[(e >> 2) * 8 + 4 + (e & 3)] = lat_v[((size_t)B + b) * Tin * 4 + e];
+  }
+  __syncthreads();
   for (int n = threadIdx.x; n < N; n += BLOCK) {
     cx<double> cart[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}}, pc[4];
     for (int t = 0; t < Tin; ++t) {
-      const cx<double> w = {wg1[n * Tin + t], wg1[N * Tin + n * Tin + t]};
+      const cx<double> w = {wgl[n * Tin + t], wgl[N * Tin + n * Tin + t]};
 #pragma unroll
-      for (int m = 0; m < 4; ++m)
-        cfma(cart[m], w, cx<double>{lat_v[((size_t)b * Tin + t) * 4 + m], lat_v[(((size_t)B + b) * Tin + t) * 4 + m]});
+      for (int m = 0; m < 4; ++m) cfma(cart[m], w, cx<double>{latl[t * 8 + m], latl[t * 8 + 4 + m]});
     }
     canon_cplx(cart, pc);
     const size_t node = (size_t)b * N + n;
@@ -682,7 +691,9 @@ int enc_latent_bwd(int B, int N, int C, int Ts, int Tv, const double* s, const d
 }
 int dec_input_fwd(int B, int N, int C, int Tin, const double* lat_v, const double* wg1, const double* w0, const double* w1,
                   double* pdec, double* s0, double* v0, hipStream_t st) {
-  hipLaunchKernelGGL(dec_input_fwd_kernel, dim3(B), dim3(BLOCK), 0, st, B, N, C, Tin, lat_v, wg1, w0, w1, pdec, s0, v0);
+  const size_t smem = sizeof(double) * (2 * (size_t)N * Tin + (size_t)Tin * 8);
+  LGN_CHECK_ARG(smem <= 64 * 1024, "dec_input_fwd: needs %zu B of LDS", smem);
+  hipLaunchKernelGGL(dec_input_fwd_kernel, dim3(B), dim3(BLOCK), smem, st, B, N, C, Tin, lat_v, wg1, w0, w1, pdec, s0, v0);
   LGN_CHECK_LAUNCH();
   return 0;
 }
@@ -713,7 +724,8 @@ static size_t dec_input_bwd_smem(int N, int C, int Tin) {
 int junction_fwd(int B, int N, int CL, int Ts, int Tv, const double* s, const double* v, const double* wl0, const double* wl1,
                  double* lat_s, double* lat_v, int* idx, int C0, const double* wg1, const double* w0, const double* w1, double* pdec,
                  double* s0, double* v0, hipStream_t st) {
-  const size_t smem = latent_smem(N, Ts, Tv);
+  const size_t s2 = sizeof(double) * (2 * (size_t)N * 2 * Tv + (size_t)2 * Tv * 8);   // dec_input_fwd part (Tin = 2 Tv)
+  const size_t smem = latent_smem(N, Ts, Tv) > s2 ? latent_smem(N, Ts, Tv) : s2;
   LGN_CHECK_ARG(smem <= 160 * 1024, "junction_fwd: N=%d tau=(%d,%d) needs %zu B of LDS", N, Ts, Tv, smem);
   if (smem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(junction_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   hipLaunchKernelGGL(junction_fwd_kernel, dim3(B), dim3(BLOCK), smem, st, B, N, CL, Ts, Tv, s, v, wl0, wl1, lat_s, lat_v, idx, C0, wg1,
