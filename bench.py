@@ -161,8 +161,8 @@ def cpu_baseline(seconds_budget=25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=BATCH, help="jets per GPU (default: BASELINE cfg2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--harness", choices=["native", "native-nograph", "modular"], default="native",
