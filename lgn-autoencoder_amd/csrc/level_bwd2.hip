@@ -55,7 +55,7 @@ __device__ __forceinline__ void wave_sync() {
 // j-centric pass
 // =========================================================================================================
 template <int C, bool DEC>
-__global__ __launch_bounds__(2 * BLOCK) void level_bwd_nodes2_kernel(LevelBwdArgs<double> a) {
+__global__ __launch_bounds__(3 * BLOCK) void level_bwd_nodes2_kernel(LevelBwdArgs<double> a) {
   constexpr int NG = (C + 3) / 4;
   constexpr int PS = DEC ? 8 : 4;
   using G = GA2<C>;
@@ -486,7 +486,8 @@ static int launch_nodes2(const LevelBwdArgs<double>& a, hipStream_t stream) {
   LGN_CHECK_ARG(smem <= 160 * 1024, "level_bwd_nodes: N=%d C=%d needs %zu B of LDS", a.N, a.C, smem);
   auto kern = level_bwd_nodes2_kernel<C, DEC>;
   if (smem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  hipLaunchKernelGGL(kern, dim3(a.B), dim3(BLOCK * sweep_wave_factor(a.B, a.N)), smem, stream, a);
+  // (no per-wave LDS here and <= 168 VGPRs: 12 waves per jet when the batch leaves SIMDs idle)
+  hipLaunchKernelGGL(kern, dim3(a.B), dim3(BLOCK * (sweep_wave_factor(a.B, a.N) == 2 ? 3 : 1)), smem, stream, a);
   LGN_CHECK_LAUNCH();
   return 0;
 }
