@@ -125,6 +125,8 @@ int lgn_moments_bwd_f64(int B, int N, int C, int Q, int decoder, const double* X
 
 typedef struct lgn_local_tables {
   int n_rows, n_out, n_w;          /* concatenated rows (irrep, block, m); output irreps; complex CatMix weights */
+  int n_terms, n_u, n_x;           /* lengths of the three CSR term lists (= row_ptr[n_rows], u_ptr[5 Q], x_ptr[Q]); the backward keeps
+                                      the U list in LDS and the host sizes it from n_u */
   const int *row_ptr, *t_type, *t_a, *t_b;      /* CSR terms per row: type 0: U[a = q*5+k], 1: X[a], 2: X[a]*X[b] */
   const double* t_coef;
   const int *out_dim, *out_nblk, *out_row0, *out_q0, *out_w0;   /* per output irrep */

@@ -178,6 +178,12 @@ __global__ __launch_bounds__(BLOCK) void local_bwd_kernel(LocalArgs a) {
     rinfo[row] = (a.t.out_q0[l] + m) | ((a.t.out_nblk[l] * C) << 8);
     rwoff[row] = a.t.out_w0[l] + blk * C;
   }
+  // the transposed U lists (which cat rows a moment feeds) are walked by 5 C Q items per node: LDS copies
+  int* uptr = rwoff + a.t.n_rows;                            // 5 Q + 1
+  int* urow = uptr + (5 * Q + 1);                            // n_u
+  double* ucoef = reinterpret_cast<double*>(urow + a.n_u + ((5 * Q + 1 + a.n_u + a.t.n_w + 2 * a.t.n_rows) & 1));   // 8-byte aligned
+  for (int e = threadIdx.x; e < 5 * Q + 1; e += BLOCK) uptr[e] = a.t.u_ptr[e];
+  for (int e = threadIdx.x; e < a.n_u; e += BLOCK) { urow[e] = a.t.u_row[e];  ucoef[e] = a.t.u_coef[e]; }
   const size_t plx = (size_t)a.nodes * C * Q;
   cx<double> dw[MAXW];
 #pragma unroll
@@ -242,15 +248,15 @@ __global__ __launch_bounds__(BLOCK) void local_bwd_kernel(LocalArgs a) {
     for (int e = threadIdx.x; e < C * Q * 5; e += BLOCK) {
       const int c = e / (Q * 5), uq = e - c * Q * 5;
       cx<double> acc = {0, 0};
-      const int ub0 = a.t.u_ptr[uq], ue0 = a.t.u_ptr[uq + 1];
+      const int ub0 = uptr[uq], ue0 = uptr[uq + 1];
       for (int t = ub0; t < ue0; t += 4) {               // four terms in flight, added in list order
         double cf[4];
         cx<double> gv[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int tt = min(t + j, ue0 - 1);
-          cf[j] = t + j < ue0 ? a.t.u_coef[tt] : 0.0;
-          const double* gp = gcat + 2 * (a.t.u_row[tt] * C + c);
+          cf[j] = t + j < ue0 ? ucoef[tt] : 0.0;
+          const double* gp = gcat + 2 * (urow[tt] * C + c);
           gv[j] = {gp[0], gp[1]};
         }
 #pragma unroll
@@ -350,7 +356,8 @@ int local_bwd(const LocalArgs& a, hipStream_t st) {
   LGN_CHECK_ARG(a.C * a.Q <= BLOCK && a.C * a.Q * 10 <= PF_U * BLOCK && a.CO * a.Qout <= BLOCK, "local_bwd: C*Q=%d too large", a.C * a.Q);
   LGN_CHECK_ARG(a.t.n_w <= MAXW * BLOCK, "local_bwd: %d CatMix weights exceed the per-workgroup accumulator budget", a.t.n_w);
   const size_t smem = sizeof(double) * ((size_t)a.t.n_rows * a.C * 4 + (size_t)a.CO * a.Qout * 2 + (size_t)a.C * a.Q * 12) +
-                      sizeof(int) * ((size_t)a.t.n_w + 2 * (size_t)a.t.n_rows);
+                      sizeof(int) * ((size_t)a.t.n_w + 2 * (size_t)a.t.n_rows + 5 * (size_t)a.Q + 2 + (size_t)a.n_u) +
+                      sizeof(double) * (size_t)a.n_u;
   LGN_CHECK_ARG(smem <= 160 * 1024, "local_bwd: %zu B of LDS needed", smem);
   if (smem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(local_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   hipLaunchKernelGGL(local_bwd_kernel, dim3(local_partial_rows(a.nodes)), dim3(BLOCK), smem, st, a);

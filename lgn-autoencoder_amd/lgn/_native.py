@@ -48,7 +48,8 @@ class NetDesc(C.Structure):
 
 class LocalTables(C.Structure):
     """lgn_local_tables of include/lgn_amd.h (device pointers)."""
-    _fields_ = [("n_rows", C.c_int), ("n_out", C.c_int), ("n_w", C.c_int)] + [
+    _fields_ = [("n_rows", C.c_int), ("n_out", C.c_int), ("n_w", C.c_int), ("n_terms", C.c_int), ("n_u", C.c_int),
+                ("n_x", C.c_int)] + [
         (name, C.c_void_p) for name in ("row_ptr", "t_type", "t_a", "t_b", "t_coef", "out_dim", "out_nblk", "out_row0", "out_q0",
                                         "out_w0", "u_ptr", "u_row", "u_coef", "x_ptr", "x_row", "x_other", "x_coef")]
 
@@ -265,6 +266,7 @@ class DeviceTables:
         self.tensors = {}
         st = LocalTables()
         st.n_rows, st.n_out, st.n_w = tab["n_rows"], tab["n_out"], tab["n_w"]
+        st.n_terms, st.n_u, st.n_x = len(tab["ints"]["t_type"]), len(tab["ints"]["u_row"]), len(tab["ints"]["x_row"])
         for name, vals in tab["ints"].items():
             t = torch.tensor(vals if len(vals) else [0], dtype=torch.int32, device=device)
             self.tensors[name] = t
