@@ -147,4 +147,6 @@ class CGDict:
         return self._maxdim is not None
 
 
-__all__ = ["CGDict", "lorentz_cg", "su2_cg"]
+from .zonal_functions import p_to_rep, p_cplx_to_rep, rep_to_p, normsq, normsq4, repdot  # noqa: E402  (cg_lib/__init__.py:13-23)
+
+__all__ = ["CGDict", "lorentz_cg", "su2_cg", "p_to_rep", "p_cplx_to_rep", "rep_to_p", "normsq", "normsq4", "repdot"]
