@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LGN_AMD_ABI_VERSION 2
+#define LGN_AMD_ABI_VERSION 3   /* bump on ANY struct or signature change (lgn/_native.py: ABI_VERSION) */
 
 int lgn_abi_version(void);
 const char* lgn_last_error(void);
@@ -164,14 +164,19 @@ typedef struct lgn_net_desc {
   int tau_s, tau_v;        /* encoder latent multiplicities before the min&max concatenation */
   int mlp_hidden_mul;      /* CGMLP hidden width = mlp_hidden_mul * 2C  (reference: mlp_width) */
   int mlp_nlin;            /* Linear layers per CGMLP (mlp_depth + 1) */
+  int tau_v_in;            /* decoder: latent vectors it consumes; 0 = 2 * tau_v (the 'min&max' concatenation) */
 } lgn_net_desc;
 
 int lgn_step_param_slots(const lgn_net_desc* d, int decoder);
 long long lgn_step_workspace_doubles(const lgn_net_desc* d);
-/* p4 [B][N][4] real Cartesian (also the Chamfer target), mask [B][N]; recon [2][B][N][4]; loss_part [B]. */
+/* p4 [B][N][4] real Cartesian encoder input (already multiplied by the encoder's `scale`, lgn_encoder.py:376);
+ * target [B][N][4] the UNscaled batch the reconstruction is compared with (utils/train.py:285-292; may alias p4 when
+ * scale == 1); mask [B][N]; recon [2][B][N][4]; loss_part [B].  workspace_doubles = capacity of `workspace`: the call
+ * fails before enqueuing anything if the current configuration needs more (lgn_step_workspace_doubles). */
 int lgn_step_fwd_bwd_f64(const lgn_net_desc* d, const double* params, double* grads, long long n_params,
-                         const int64_t* enc_off, const int64_t* dec_off, const double* p4, const uint8_t* mask,
-                         double* workspace, double* recon, double* loss_part, void* stream);
+                         const int64_t* enc_off, const int64_t* dec_off, const double* p4, const double* target,
+                         const uint8_t* mask, double* workspace, long long workspace_doubles, double* recon,
+                         double* loss_part, void* stream);
 /* grads += l1_lambda*sign(params) (utils/train.py:484-487); loss_out[0..2] = total, chamfer, sum|w|; optional Adam
  * (torch.optim.Adam defaults; the step counter lives on the device so that graph replays stay correct).
  * loss_out must hold 3 + LGN_FINALIZE_SCRATCH doubles: the results, then scratch for the per-workgroup |w| partials. */
@@ -179,6 +184,29 @@ int lgn_step_fwd_bwd_f64(const lgn_net_desc* d, const double* params, double* gr
 int lgn_step_finalize_f64(double* params, double* grads, long long n_params, const double* loss_part, int n_loss,
                           double l1_lambda, double* adam_m, double* adam_v, long long* step_dev,
                           double lr, double beta1, double beta2, double eps, int do_adam, double* loss_out, void* stream);
+
+/* ---- one network at a time, maxdim = 2: what LGNEncoder.forward / LGNDecoder.forward (lgn/models/lgn_encoder.py:255-336,
+ * lgn_decoder.py:218-303) and autograd's backward of them become under the module API.  Same parameter-slot layout as
+ * above, but `params` / `grads` / `off` refer to ONE network's flat parameter block.  *_fwd writes the activations the
+ * backward needs into `act` (lgn_net_workspace_doubles(d, decoder, 0) doubles, owned by the caller between the two
+ * calls); *_bwd zero-fills `grads`, then writes every parameter gradient (dead parameters keep an exact 0) and uses
+ * `scratch` (lgn_net_workspace_doubles(d, decoder, 1) doubles).
+ *   encoder: p4 [B][N][4] (already scaled), mask [B][N] -> lat_s [2][B][2 tau_s], lat_v [2][B][2 tau_v][4] Cartesian
+ *            ('min&max' pooling); g_lat_s may be NULL (no gradient on the latent scalars: the last level's scalar
+ *            branch is then skipped, like autograd would).
+ *   decoder: lat_v [2][B][Tin][4] (Tin = tau_v_in, or 2 tau_v when 0) -> recon [2][B][N][4] complex Cartesian;
+ *            backward from g_recon [2][B][N][4] to g_lat_v (the latent scalars never reach the output). */
+long long lgn_net_workspace_doubles(const lgn_net_desc* d, int decoder, int which);
+int lgn_encoder_fwd_f64(const lgn_net_desc* d, const double* params, const int64_t* off, const double* p4, const uint8_t* mask,
+                        double* act, long long act_doubles, double* lat_s, double* lat_v, void* stream);
+int lgn_encoder_bwd_f64(const lgn_net_desc* d, const double* params, double* grads, long long n_params, const int64_t* off,
+                        const double* p4, const uint8_t* mask, const double* act, long long act_doubles,
+                        const double* g_lat_s, const double* g_lat_v, double* scratch, long long scratch_doubles, void* stream);
+int lgn_decoder_fwd_f64(const lgn_net_desc* d, const double* params, const int64_t* off, const double* lat_v, double* act,
+                        long long act_doubles, double* recon, void* stream);
+int lgn_decoder_bwd_f64(const lgn_net_desc* d, const double* params, double* grads, long long n_params, const int64_t* off,
+                        const double* lat_v, const double* act, long long act_doubles, const double* g_recon, double* g_lat_v,
+                        double* scratch, long long scratch_doubles, void* stream);
 
 #ifdef __cplusplus
 }

@@ -6,8 +6,10 @@
 //
 //   1. level_bwd_mix     per node: CatMix^T -> grad of aggregate (g_ag), direct + power-term grads of the
 //                        node features, and CatMix weight gradient partials.
-//   2. level_bwd_nodes   "j-centric" pass: g_node_j += sum_i g_ag_i (x) conj(edge_ij)   (+ decoder dp_j)
-//   3. level_bwd_rad_*   "i-centric" pass: radial-network parameter gradients (+ decoder dp_i)
+//   2. level_bwd_nodes2  "j-centric" pass: g_node_j += sum_i g_ag_i (x) conj(edge_ij)   (+ decoder dp_j)   [level_bwd2.hip]
+//   3. level_bwd_rad2 / level_bwd_rad_dec   "i-centric" pass: radial-network parameter gradients (+ decoder dp_i)
+// This three-launch form serves N > 40 (and LGN_AMD_LEVEL_V2=1); smaller jets take the one-kernel level_bwd3.hip, the
+// separable decoder level_bwd_dec_sep.hip.
 //
 // Complex convention: every map is holomorphic (no conjugation in the forward), so for out = f(z) the
 // planar gradient is G_z = G_out * conj(f'(z)).
@@ -178,340 +180,11 @@ __global__ __launch_bounds__(BLOCK) void level_bwd_mix_kernel(LevelBwdArgs<T> a)
 }
 
 // =========================================================================================
-// 2. j-centric pass: gradient w.r.t. the node features that were *sources* of messages
-//    G_v[j][c][m] += sum_i gA1[i][c][m] conj(e0_ij[c]) + 1/2 gA3[i][c] conj(tilde(e1_ij[c])[m])
-//    G_s[j][c]    += sum_i sum_m gA2[i][c][m] conj(e1_ij[c][m]) + gA4[i][c] conj(e0_ij[c])
-//    decoder:  g_p[j] -= sum_i G_q_ij,   G_q_ij[m] = sum_c G_e1_ij[c][m] conj(R1[c])
+// 2. / 3a.  The j-centric pass (gradient w.r.t. the source nodes) and the encoder's i-centric radial-gradient pass
+//    live in level_bwd2.hip (matrix-core kernels).  The radial pair sums they produce,
+//      T1[r][k] = sum_p G on rho_k    T2[r][k] = sum_p G on n^2 rho_k^2    S[r] = sum_p G on    dB[r] = sum_p G,
+//    are turned into parameter gradients by rad_finalize below.
 // =========================================================================================
-template <typename T, int C, int IS, bool DEC>
-__global__ __launch_bounds__(BLOCK) void level_bwd_nodes_kernel(LevelBwdArgs<T> a) {
-  using L = Carve<C, DEC>;
-  constexpr int JT = BLOCK / IS;
-  constexpr int R = L::R;
-  const int N = a.N, B = a.B;
-  const int b = blockIdx.x, tile = blockIdx.y, tid = threadIdx.x;
-
-  extern __shared__ __align__(16) unsigned char smem_raw[];
-  T* sm = reinterpret_cast<T*>(smem_raw);
-  T* ga = sm;                                    // N * 20C
-  T* pj = ga + N * GA<C>::SIZE;                  // N * PS
-  T* rp = pj + L::even(N * L::PS);               // RAD_SIZE
-  uint8_t* mk = reinterpret_cast<uint8_t*>(rp + L::even(L::RAD_SIZE));
-
-  {
-    const T* src = a.g_ag + (size_t)b * N * GA<C>::SIZE;
-    for (int e = tid; e < N * GA<C>::SIZE; e += BLOCK) ga[e] = src[e];
-    if (DEC) {
-      const size_t plane_p = (size_t)B * N * 4;
-      const T* p0 = a.p + (size_t)b * N * 4;
-      for (int e = tid; e < N * 4; e += BLOCK) {
-        int j = e >> 2, m = e & 3;
-        pj[j * 8 + m] = p0[e];
-        pj[j * 8 + 4 + m] = p0[plane_p + e];
-      }
-    } else {
-      const T* p0 = a.p + (size_t)b * N * 4;
-      for (int e = tid; e < N * 4; e += BLOCK) pj[e] = p0[e];
-      for (int e = tid; e < N; e += BLOCK) mk[e] = a.mask[(size_t)b * N + e];
-    }
-    load_radial<T, C, DEC>(a.ra, a.rb, a.rc, a.w0, a.b0, a.w1, a.b1, rp);
-  }
-  __syncthreads();
-
-  const int jl = tid / IS, is = tid % IS;
-  const int j = tile * JT + jl;
-  const bool ok = j < N;
-  const int jj = ok ? j : 0;
-  T pme[L::PS];
-#pragma unroll
-  for (int m = 0; m < L::PS; ++m) pme[m] = pj[jj * L::PS + m];
-  const bool mj = DEC ? false : (mk[jj] != 0);
-
-  cx<T> Gs[C], Gv[C][4], Gq[4];
-#pragma unroll
-  for (int c = 0; c < C; ++c) {
-    Gs[c] = {T(0), T(0)};
-#pragma unroll
-    for (int m = 0; m < 4; ++m) Gv[c][m] = {T(0), T(0)};
-  }
-#pragma unroll
-  for (int m = 0; m < 4; ++m) Gq[m] = {T(0), T(0)};
-
-  // own node features (decoder position gradient only)
-  cx<T> sj[C], vtj[C][4];
-  if (DEC) {
-    const size_t pls = (size_t)B * N * C;
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-      const size_t e = ((size_t)b * N + jj) * C + c;
-      sj[c] = {a.s_in[e], a.s_in[pls + e]};
-      cx<T> v[4];
-#pragma unroll
-      for (int m = 0; m < 4; ++m) v[m] = {a.v_in[e * 4 + m], a.v_in[pls * 4 + e * 4 + m]};
-      metric_perm(v, vtj[c]);
-    }
-  }
-
-  if (ok) {
-    for (int i = is; i < N; i += IS) {
-      // ordered pair (i, j): q = canonical(p_i - p_j)
-      PairGeom<T, DEC> g = pair_geom<T, DEC>(pj + i * L::PS, pme, DEC ? false : (mk[i] != 0), mj);
-      T rad[R];
-      radial_eval<T, C, DEC>(rp, g.nrm, g.on, rad);
-      const T* gi = ga + i * GA<C>::SIZE;
-#pragma unroll
-      for (int c = 0; c < C; ++c) {
-        cx<T> R0 = {rad[2 * c], rad[2 * c + 1]};
-        cx<T> R1 = {rad[2 * C + 2 * c], rad[2 * C + 2 * c + 1]};
-        cx<T> e0 = {R0.r - R0.i, R0.r + R0.i};
-        cx<T> e1[4], e1t[4];
-#pragma unroll
-        for (int m = 0; m < 4; ++m) e1[m] = cmul(R1, g.q[m]);
-        metric_perm(e1, e1t);
-        cx<T> gA3 = {T(0.5) * gi[GA<C>::A3 + 2 * c], T(0.5) * gi[GA<C>::A3 + 2 * c + 1]};
-        cx<T> gA4 = {gi[GA<C>::A4 + 2 * c], gi[GA<C>::A4 + 2 * c + 1]};
-        cfmac(Gs[c], gA4, e0);
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          cx<T> gA1 = {gi[GA<C>::A1 + (c * 4 + m) * 2], gi[GA<C>::A1 + (c * 4 + m) * 2 + 1]};
-          cx<T> gA2 = {gi[GA<C>::A2 + (c * 4 + m) * 2], gi[GA<C>::A2 + (c * 4 + m) * 2 + 1]};
-          cfmac(Gv[c][m], gA1, e0);
-          cfmac(Gv[c][m], gA3, e1t[m]);
-          cfmac(Gs[c], gA2, e1[m]);
-          if (DEC) {
-            cx<T> ge1 = cmulc(gA2, sj[c]);
-            cfmac(ge1, gA3, vtj[c][m]);
-            cfmac(Gq[m], ge1, R1);
-          }
-        }
-      }
-    }
-  }
-
-  const size_t pls = (size_t)B * N * C;
-#pragma unroll
-  for (int c = 0; c < C; ++c) {
-    T sr = group_sum<IS>(Gs[c].r), si = group_sum<IS>(Gs[c].i);
-    const size_t e = ((size_t)b * N + jj) * C + c;
-    if (ok && is == 0) {
-      a.g_s_in[e] += sr;
-      a.g_s_in[pls + e] += si;
-    }
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      T vr = group_sum<IS>(Gv[c][m].r), vi = group_sum<IS>(Gv[c][m].i);
-      if (ok && is == 0) {
-        a.g_v_in[e * 4 + m] += vr;
-        a.g_v_in[pls * 4 + e * 4 + m] += vi;
-      }
-    }
-  }
-  if (DEC) {
-    const size_t plp = (size_t)B * N * 4;
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      T qr = group_sum<IS>(Gq[m].r), qi = group_sum<IS>(Gq[m].i);
-      if (ok && is == 0) {
-        a.g_p[((size_t)b * N + jj) * 4 + m] -= qr;
-        a.g_p[plp + ((size_t)b * N + jj) * 4 + m] -= qi;
-      }
-    }
-  }
-}
-
-// =========================================================================================
-// 3a. i-centric pass, encoder: radial-network parameter gradient partials.
-//   rad[r] = sum_k W[r][k] beta_k + bias[r],  beta_k = on * (b_k rho_k + a_k),  rho_k = 1/(1 + (c_k n)^2 + 1e-16)
-//   With G[p][r] = dL/drad[r] of pair p, everything follows from four pair-reductions
-//     T1[r][k] = sum_p G on rho_k      T2[r][k] = sum_p G on n^2 rho_k^2     S[r] = sum_p G on     dB[r] = sum_p G
-//   (finalised by rad_finalize_kernel).  G is produced lane-per-pair, staged in LDS, and reduced by a
-//   register-tiled outer-product accumulation (lane = (r, k-group)).
-// =========================================================================================
-template <int C> struct Stage {
-  static constexpr int R = 4 * C;
-  static constexpr int X = NB + 2;               // rho_k (masked), n^2, on
-  static constexpr int STRIDE = ((R + X) | 1);   // odd stride (in scalars) spreads lanes over banks
-  static constexpr int RPL = (R + 15) / 16;      // radial rows per consumer lane
-};
-
-template <typename T, int C>
-__global__ __launch_bounds__(BLOCK) void level_bwd_rad_enc_kernel(LevelBwdArgs<T> a, int JT) {
-  using L = Carve<C, false>;
-  using S = Stage<C>;
-  constexpr int JS = 8, IT = BLOCK / JS;
-  constexpr int R = S::R;
-  const int N = a.N, B = a.B;
-  const int b = blockIdx.x, it = blockIdx.y, jt = blockIdx.z, tid = threadIdx.x;
-  const int j0 = jt * JT;
-  const int nj = min(JT, N - j0);
-
-  extern __shared__ __align__(16) unsigned char smem_raw[];
-  T* sm = reinterpret_cast<T*>(smem_raw);
-  T* nd = sm;                                     // JT * NS
-  T* pjt = nd + L::even(JT * L::NS);              // JT * 4
-  T* pit = pjt + JT * 4;                          // IT * 4
-  T* gat = pit + IT * 4;                          // IT * 20C
-  T* rc = gat + IT * GA<C>::SIZE;                 // NB (c_k)
-  T* stg = rc + NB;                               // BLOCK * STRIDE
-  T* red = stg + BLOCK * S::STRIDE;               // 4 waves * 64 lanes * (RPL*10 + 2)
-  uint8_t* mkj = reinterpret_cast<uint8_t*>(red + 4 * 64 * (S::RPL * 10 + 2));
-  uint8_t* mki = mkj + JT;
-
-  {
-    const size_t pls = (size_t)B * N * C;
-    for (int e = tid; e < nj * C; e += BLOCK) {
-      int jl = e / C, c = e - jl * C;
-      size_t src = ((size_t)b * N + j0 + jl) * C + c;
-      nd[jl * L::NS + c * 10 + 0] = a.s_in[src];
-      nd[jl * L::NS + c * 10 + 1] = a.s_in[pls + src];
-      for (int m = 0; m < 4; ++m) {
-        nd[jl * L::NS + c * 10 + 2 + m] = a.v_in[src * 4 + m];
-        nd[jl * L::NS + c * 10 + 6 + m] = a.v_in[pls * 4 + src * 4 + m];
-      }
-    }
-    for (int e = tid; e < nj * 4; e += BLOCK) pjt[e] = a.p[((size_t)b * N + j0) * 4 + e];
-    for (int e = tid; e < nj; e += BLOCK) mkj[e] = a.mask[(size_t)b * N + j0 + e];
-    for (int e = tid; e < IT; e += BLOCK) {
-      int i = it * IT + e;
-      mki[e] = i < N ? a.mask[(size_t)b * N + i] : 0;
-      for (int m = 0; m < 4; ++m) pit[e * 4 + m] = i < N ? a.p[((size_t)b * N + i) * 4 + m] : T(0);
-    }
-    for (int e = tid; e < IT * GA<C>::SIZE; e += BLOCK) {
-      int il = e / GA<C>::SIZE, i = it * IT + il;
-      gat[e] = i < N ? a.g_ag[((size_t)b * N + it * IT) * GA<C>::SIZE + e] : T(0);
-    }
-    for (int e = tid; e < NB; e += BLOCK) rc[e] = a.rc[e];
-  }
-  __syncthreads();
-
-  const int il = tid / JS, js = tid % JS;
-  const int i = it * IT + il;
-  const bool row_ok = i < N;
-  const T pi[4] = {pit[il * 4], pit[il * 4 + 1], pit[il * 4 + 2], pit[il * 4 + 3]};
-  const bool mi = mki[il] != 0;
-  const T* gi = gat + il * GA<C>::SIZE;
-
-  // consumer role of this lane in the outer-product accumulation
-  const int lane = tid & 63, wave = tid >> 6;
-  const int xg = lane & 3, rg = lane >> 2;
-  T acc1[S::RPL][5], acc2[S::RPL][5], accx[S::RPL];
-#pragma unroll
-  for (int t = 0; t < S::RPL; ++t) {
-    accx[t] = T(0);
-#pragma unroll
-    for (int q = 0; q < 5; ++q) acc1[t][q] = acc2[t][q] = T(0);
-  }
-
-  const int iters = (JT + JS - 1) / JS;
-  for (int t = 0; t < iters; ++t) {
-    const int jl = js + JS * t;
-    T* my = stg + tid * S::STRIDE;
-    if (row_ok && jl < nj) {
-      PairGeom<T, false> g = pair_geom<T, false>(pi, pjt + jl * 4, mi, mkj[jl] != 0);
-      const T n2 = g.nrm * g.nrm;
-      for (int k = 0; k < NB; ++k) {
-        T tt = rc[k] * g.nrm;
-        T u = (T(1) + tt * tt) + T(1e-16);
-        my[R + k] = g.on ? T(1) / u : T(0);
-      }
-      my[R + NB] = n2;
-      my[R + NB + 1] = g.on ? T(1) : T(0);
-      const T* njp = nd + jl * L::NS;
-#pragma unroll
-      for (int c = 0; c < C; ++c) {
-        cx<T> s = {njp[c * 10], njp[c * 10 + 1]};
-        cx<T> v[4], vt[4];
-#pragma unroll
-        for (int m = 0; m < 4; ++m) v[m] = {njp[c * 10 + 2 + m], njp[c * 10 + 6 + m]};
-        metric_perm(v, vt);
-        cx<T> gA3 = {T(0.5) * gi[GA<C>::A3 + 2 * c], T(0.5) * gi[GA<C>::A3 + 2 * c + 1]};
-        cx<T> gA4 = {gi[GA<C>::A4 + 2 * c], gi[GA<C>::A4 + 2 * c + 1]};
-        cx<T> ge0 = cmulc(gA4, s);
-        cx<T> gR1 = {T(0), T(0)};
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          cx<T> gA1 = {gi[GA<C>::A1 + (c * 4 + m) * 2], gi[GA<C>::A1 + (c * 4 + m) * 2 + 1]};
-          cx<T> gA2 = {gi[GA<C>::A2 + (c * 4 + m) * 2], gi[GA<C>::A2 + (c * 4 + m) * 2 + 1]};
-          cfmac(ge0, gA1, v[m]);
-          cx<T> ge1 = cmulc(gA2, s);
-          cfmac(ge1, gA3, vt[m]);
-          cfmac(gR1, ge1, g.q[m]);
-        }
-        // e0 = R0 (1 + i)  ->  G_R0 = G_e0 (1 - i)
-        my[2 * c] = ge0.r + ge0.i;
-        my[2 * c + 1] = ge0.i - ge0.r;
-        my[2 * C + 2 * c] = gR1.r;
-        my[2 * C + 2 * c + 1] = gR1.i;
-      }
-    } else {
-      for (int e = 0; e < R + S::X; ++e) my[e] = T(0);
-    }
-    __syncthreads();
-    // each wave reduces the 64 pairs it just staged
-    const T* base = stg + (wave * 64) * S::STRIDE;
-    for (int p = 0; p < 64; ++p) {
-      const T* row = base + p * S::STRIDE;
-      T rho[5];
-#pragma unroll
-      for (int q = 0; q < 5; ++q) rho[q] = row[R + xg * 5 + q];
-      const T n2 = row[R + NB];
-      const T extra = xg == 0 ? row[R + NB + 1] : (xg == 1 ? T(1) : T(0));
-#pragma unroll
-      for (int tt = 0; tt < S::RPL; ++tt) {
-        const int r = rg + 16 * tt;
-        const T G = r < R ? row[r] : T(0);
-        accx[tt] += G * extra;
-#pragma unroll
-        for (int q = 0; q < 5; ++q) {
-          T gr = G * rho[q];
-          acc1[tt][q] += gr;
-          acc2[tt][q] += gr * (n2 * rho[q]);
-        }
-      }
-    }
-    __syncthreads();
-  }
-
-  // cross-wave reduction and partial-row write
-  constexpr int PER = S::RPL * 10 + 2;
-  {
-    T* mine = red + (wave * 64 + lane) * PER;
-#pragma unroll
-    for (int tt = 0; tt < S::RPL; ++tt) {
-#pragma unroll
-      for (int q = 0; q < 5; ++q) {
-        mine[tt * 10 + q] = acc1[tt][q];
-        mine[tt * 10 + 5 + q] = acc2[tt][q];
-      }
-    }
-    mine[S::RPL * 10] = accx[0];
-    mine[S::RPL * 10 + 1] = S::RPL > 1 ? accx[S::RPL - 1] : T(0);
-  }
-  __syncthreads();
-  if (wave == 0) {
-    const size_t blk = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    T* part = a.part_rad + blk * rad_partial_size(C, false);
-    T tot[PER];
-#pragma unroll
-    for (int e = 0; e < PER; ++e)
-      tot[e] = red[(0 * 64 + lane) * PER + e] + red[(1 * 64 + lane) * PER + e] + red[(2 * 64 + lane) * PER + e] +
-               red[(3 * 64 + lane) * PER + e];
-#pragma unroll
-    for (int tt = 0; tt < S::RPL; ++tt) {
-      const int r = rg + 16 * tt;
-      if (r < R) {
-#pragma unroll
-        for (int q = 0; q < 5; ++q) {
-          part[r * NB + xg * 5 + q] = tot[tt * 10 + q];
-          part[R * NB + r * NB + xg * 5 + q] = tot[tt * 10 + 5 + q];
-        }
-        const T ex = tt == 0 ? tot[S::RPL * 10] : tot[S::RPL * 10 + 1];
-        if (xg == 0) part[2 * R * NB + r] = ex;          // S
-        if (xg == 1) part[2 * R * NB + R + r] = ex;      // dB
-      }
-    }
-  }
-}
 
 // Turn the reduced pair-sums into parameter gradients (one tiny workgroup).
 //   tot: T1[R][20] | T2[R][20] | S[R] | dB[R]
@@ -753,16 +426,10 @@ static bool dec_pairwise() {   // LGN_AMD_DEC_PAIRWISE=1 keeps the decoder on th
 }
 bool level_bwd3_fits(int N);
 
-static bool use_v1() {
-  static const bool v = [] { const char* e = getenv("LGN_AMD_LEVEL_V1"); return e && e[0] == '1'; }();
-  return v;
+static bool use_v3(int N) {   // single-kernel backward (default when the jet fits in LDS); LGN_AMD_LEVEL_V2=1 forces the 3-kernel
+  const char* e = getenv("LGN_AMD_LEVEL_V2");   // form also for small N (read per call: the parity tests flip it)
+  return !(e && e[0] == '1') && level_bwd3_fits(N);
 }
-static bool use_v3(int N) {   // single-kernel backward (default when the jet fits in LDS); LGN_AMD_LEVEL_V2=1 forces the 3-kernel form
-  static const bool off = [] { const char* e = getenv("LGN_AMD_LEVEL_V2"); return e && e[0] == '1'; }();
-  return !off && !use_v1() && level_bwd3_fits(N);
-}
-
-int level_bwd_rad_jt(int N) { return N <= 64 ? ((N + 7) / 8) * 8 : 32; }
 
 // number of partial rows the backward launch writes (host side must size the workspace with these)
 void level_bwd_partial_rows(int B, int N, int decoder, int* rows_mix, int* rows_rad) {
@@ -773,15 +440,10 @@ void level_bwd_partial_rows(int B, int N, int decoder, int* rows_mix, int* rows_
     return;
   }
   *rows_mix = B * tiles;
-  if (decoder && !use_v1() && !dec_pairwise()) {
-    *rows_rad = B;                       // separable decoder backward: one partial row per jet
-  } else if (decoder) {
-    *rows_rad = B * tiles;
-  } else if (!use_v1()) {
-    *rows_rad = B;                       // level_bwd_rad2: one partial row per jet
+  if (decoder && dec_pairwise()) {
+    *rows_rad = B * tiles;               // level_bwd_rad_dec: one partial row per 32-node tile
   } else {
-    const int JT = level_bwd_rad_jt(N);
-    *rows_rad = B * tiles * cdiv(N, JT);
+    *rows_rad = B;                       // separable decoder backward / level_bwd_rad2: one partial row per jet
   }
 }
 
@@ -799,35 +461,17 @@ static int launch_level_bwd(const LevelBwdArgs<T>& a, hipStream_t stream) {
     LGN_CHECK_LAUNCH();
   }
   if constexpr (DEC && std::is_same<T, double>::value) {
-    if (!use_v1() && !dec_pairwise()) return level_bwd_dec_sep_dispatch(a, stream);   // 2+3. from jet-level sums, O(N C)
+    if (!dec_pairwise()) return level_bwd_dec_sep_dispatch(a, stream);   // 2+3. from jet-level sums, O(N C)
   }
-  if (!use_v1()) {  // 2. j-centric pass, matrix-core version
-    if ((rc = level_bwd_nodes2_dispatch(a, DEC, stream))) return rc;
-  } else {
-    constexpr int IS = 8;
-    auto kern = level_bwd_nodes_kernel<T, C, IS, DEC>;
-    size_t smem = sizeof(T) * (N * GA<C>::SIZE + L::even(N * L::PS) + L::even(L::RAD_SIZE)) + N + 16;
-    if ((rc = ensure_smem(kern, smem, "level_bwd_nodes"))) return rc;
-    hipLaunchKernelGGL(kern, dim3(a.B, cdiv(N, BLOCK / IS)), dim3(BLOCK), smem, stream, a);
-    LGN_CHECK_LAUNCH();
-  }
+  if ((rc = level_bwd_nodes2_dispatch(a, DEC, stream))) return rc;        // 2. j-centric pass
   if (DEC) {  // 3b
     auto kern = level_bwd_rad_dec_kernel<T, C>;
     size_t smem = sizeof(T) * (L::even(N * L::NS) + N * 8 + 32 * GA<C>::SIZE + L::even(2 * C) + (BLOCK / 64) * 2 * C);
     if ((rc = ensure_smem(kern, smem, "level_bwd_rad_dec"))) return rc;
     hipLaunchKernelGGL(kern, dim3(a.B, tiles), dim3(BLOCK), smem, stream, a);
     LGN_CHECK_LAUNCH();
-  } else if (!use_v1()) {  // 3a, matrix-core version
+  } else {    // 3a
     if ((rc = level_bwd_rad2_dispatch(a, stream))) return rc;
-  } else {  // 3a
-    using S = Stage<C>;
-    const int JT = level_bwd_rad_jt(N);
-    auto kern = level_bwd_rad_enc_kernel<T, C>;
-    size_t smem = sizeof(T) * (L::even(JT * L::NS) + JT * 4 + 32 * 4 + 32 * GA<C>::SIZE + NB + BLOCK * S::STRIDE +
-                               4 * 64 * (S::RPL * 10 + 2)) + JT + 32 + 16;
-    if ((rc = ensure_smem(kern, smem, "level_bwd_rad_enc"))) return rc;
-    hipLaunchKernelGGL(kern, dim3(a.B, tiles, cdiv(N, JT)), dim3(BLOCK), smem, stream, a, JT);
-    LGN_CHECK_LAUNCH();
   }
   return 0;
 }

@@ -498,7 +498,8 @@ static int launch_level_fwd2(const LevelArgs<double>& a, hipStream_t stream) {
   return 0;
 }
 
-int level_fwd2_dispatch(const LevelArgs<double>& a, int decoder, hipStream_t stream) {
+template <>
+int level_fwd_dispatch<double>(const LevelArgs<double>& a, int decoder, hipStream_t stream) {
   LGN_CHECK_ARG(a.B > 0 && a.N > 0, "level_fwd: empty batch (B=%d N=%d)", a.B, a.N);
   LGN_CHECK_ARG(a.CO >= 1 && a.CO <= 8, "level_fwd: C_out=%d unsupported (1..8)", a.CO);
   // LGN_AMD_DEC_PAIRWISE=1 keeps the decoder on the O(N^2) pair sweep (cross-check of the separable form)

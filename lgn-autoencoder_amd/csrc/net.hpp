@@ -28,6 +28,9 @@ int dec_input_bwd(int B, int N, int C, int Tin, const double* lat_v, const doubl
                   double* part /*[B][4C + 2 N Tin]*/, hipStream_t);
 int dec_output_loss(int B, int N, int C, const double* v, const double* wo1, const double* target, double loss_scale, double* recon,
                     double* loss_part /*[B]*/, double* g_v, double* part /*[B][2C]*/, hipStream_t);
+// decoder output without the loss (module API): recon [2][B][N][4]; backward from g_recon, part [B][2C]
+int dec_output_fwd(int B, int N, int C, const double* v, const double* wo1, double* recon, hipStream_t);
+int dec_output_bwd(int B, int N, int C, const double* v, const double* wo1, const double* g_recon, double* g_v, double* part, hipStream_t);
 int finalize_step(double* w, double* g, long n, const double* loss_part, int nB, double lambda, double* m, double* v, long* step_dev,
                   double lr, double beta1, double beta2, double eps, int do_adam, double* loss_out, hipStream_t st);
 }  // namespace lgn

@@ -597,6 +597,73 @@ __global__ __launch_bounds__(BLOCK) void dec_output_loss_kernel(int B, int N, in
 }
 
 // ============================================================================================
+// decoder output alone (module API: the loss is the caller's): mix_to_output on the (1,1) irrep + rep_to_p
+// (lgn_decoder.py:286-295) and its backward from an arbitrary upstream gradient g_recon [2][B][N][4].
+// ============================================================================================
+__global__ __launch_bounds__(BLOCK) void dec_output_fwd_kernel(int B, int N, int C, const double* __restrict__ v,
+                                                              const double* __restrict__ wo1, double* recon) {
+  const size_t plp = (size_t)B * N * 4, pl = (size_t)B * N * C;
+  for (size_t node = (size_t)blockIdx.x * BLOCK + threadIdx.x; node < (size_t)B * N; node += (size_t)gridDim.x * BLOCK) {
+    cx<double> yc[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}}, pc[4];
+    for (int c = 0; c < C; ++c) {
+      const cx<double> w = {wo1[c], wo1[C + c]};
+      const size_t e = node * C + c;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) cfma(yc[m], w, cx<double>{v[e * 4 + m], v[pl * 4 + e * 4 + m]});
+    }
+    cart_from_canon(yc, pc);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      recon[node * 4 + m] = pc[m].r;
+      recon[plp + node * 4 + m] = pc[m].i;
+    }
+  }
+}
+// one workgroup per jet; g_v [2][B][N][C][4]; part row per jet: dWo1 [2][C]
+__global__ __launch_bounds__(BLOCK) void dec_output_bwd_kernel(int B, int N, int C, const double* __restrict__ v,
+                                                              const double* __restrict__ wo1, const double* __restrict__ g_recon,
+                                                              double* g_v, double* part) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  double* gc_l = reinterpret_cast<double*>(smem_raw);    // [N][8] gradient w.r.t. the canonical output (re[4] | im[4])
+  double* tmp = gc_l + (size_t)N * 8;                    // [N*C][2]
+  const int b = blockIdx.x;
+  const size_t plp = (size_t)B * N * 4, pl = (size_t)B * N * C;
+  for (int n = threadIdx.x; n < N; n += BLOCK) {
+    const size_t node = (size_t)b * N + n;
+    cx<double> g[4], gc[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) g[m] = {g_recon[node * 4 + m], g_recon[plp + node * 4 + m]};
+    cart_from_canon_bwd(g, gc);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) { gc_l[n * 8 + m] = gc[m].r; gc_l[n * 8 + 4 + m] = gc[m].i; }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < N * C; e += BLOCK) {
+    const int n = e / C, c = e - n * C;
+    const cx<double> w = {wo1[c], wo1[C + c]};
+    const size_t base = (size_t)b * N * C + e;
+    cx<double> d = {0, 0};
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const cx<double> gc = {gc_l[n * 8 + m], gc_l[n * 8 + 4 + m]};
+      cx<double> r = cmulc(gc, w);
+      g_v[base * 4 + m] = r.r;
+      g_v[pl * 4 + base * 4 + m] = r.i;
+      cfmac(d, gc, cx<double>{v[base * 4 + m], v[pl * 4 + base * 4 + m]});
+    }
+    tmp[e * 2] = d.r;
+    tmp[e * 2 + 1] = d.i;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < 2 * C) {
+    const int k = threadIdx.x / C, c = threadIdx.x - k * C;
+    double acc = 0.0;
+    for (int n = 0; n < N; ++n) acc += tmp[(n * C + c) * 2 + k];
+    part[(size_t)b * 2 * C + k * C + c] = acc;
+  }
+}
+
+// ============================================================================================
 // L1 regularisation + loss assembly, Adam
 // ============================================================================================
 // g += lambda * sign(w); Adam update (torch.optim.Adam defaults: no weight decay, no amsgrad).  The same pass adds up
@@ -712,6 +779,20 @@ int dec_output_loss(int B, int N, int C, const double* v, const double* wo1, con
   const size_t smem = sizeof(double) * (size_t)N * 14 + sizeof(int) * (size_t)N * 2 + 16 + (2 * C > 8 ? sizeof(double) * (size_t)N * C * 2 : 0);
   hipLaunchKernelGGL(dec_output_loss_kernel, dim3(B), dim3(BLOCK), smem, st, B, N, C, v, wo1, target, loss_scale, recon, loss_part,
                      g_v, part);
+  LGN_CHECK_LAUNCH();
+  return 0;
+}
+int dec_output_fwd(int B, int N, int C, const double* v, const double* wo1, double* recon, hipStream_t st) {
+  hipLaunchKernelGGL(dec_output_fwd_kernel, dim3(grid_for((size_t)B * N)), dim3(BLOCK), 0, st, B, N, C, v, wo1, recon);
+  LGN_CHECK_LAUNCH();
+  return 0;
+}
+int dec_output_bwd(int B, int N, int C, const double* v, const double* wo1, const double* g_recon, double* g_v, double* part,
+                   hipStream_t st) {
+  const size_t smem = sizeof(double) * ((size_t)N * 8 + (size_t)N * C * 2);
+  LGN_CHECK_ARG(smem <= 160 * 1024, "dec_output_bwd: needs %zu B of LDS", smem);
+  if (smem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_output_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipLaunchKernelGGL(dec_output_bwd_kernel, dim3(B), dim3(BLOCK), smem, st, B, N, C, v, wo1, g_recon, g_v, part);
   LGN_CHECK_LAUNCH();
   return 0;
 }

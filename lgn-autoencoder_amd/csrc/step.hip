@@ -139,6 +139,7 @@ struct Slots {                      // canonical parameter slot order shared wit
   int count(bool dec) const { return out0(dec) + 2; }
 };
 
+#define HIPOK(e) do { hipError_t e_ = (e); if (e_ != hipSuccess) { set_error("%s: %s", #e, hipGetErrorString(e_)); return (int)e_; } } while (0)
 #define LGN_TRY(expr)            \
   do {                           \
     int rc_ = (expr);            \
@@ -225,7 +226,7 @@ int check_desc(const lgn_net_desc* d) {
   LGN_CHECK_ARG(d->B > 0 && d->N > 0, "step: empty batch (B=%d N=%d)", d->B, d->N);
   LGN_CHECK_ARG(d->n_levels >= 1 && d->n_levels <= 4, "step: n_levels=%d unsupported (1..4)", d->n_levels);
   LGN_CHECK_ARG(d->mlp_nlin == 7, "step: mlp_depth must be 6 (7 Linear layers)");
-  LGN_CHECK_ARG(d->tau_s >= 1 && d->tau_v >= 1, "step: latent multiplicities must be positive");
+  LGN_CHECK_ARG(d->tau_s >= 1 && d->tau_v >= 1 && d->tau_v_in >= 0, "step: latent multiplicities must be positive");
   for (int l = 0; l <= d->n_levels; ++l)
     LGN_CHECK_ARG(d->enc_channels[l] >= 1 && d->enc_channels[l] <= 8 && d->dec_channels[l] >= 1 && d->dec_channels[l] <= 8,
                   "step: channel counts must be in 1..8");
@@ -251,13 +252,17 @@ long long lgn_step_workspace_doubles(const lgn_net_desc* d) {
 }
 
 int lgn_step_fwd_bwd_f64(const lgn_net_desc* d, const double* params, double* grads, long long n_params, const int64_t* enc_off,
-                         const int64_t* dec_off, const double* p4, const uint8_t* mask, double* workspace, double* recon,
-                         double* loss_part, void* stream) {
+                         const int64_t* dec_off, const double* p4, const double* target, const uint8_t* mask, double* workspace,
+                         long long workspace_doubles, double* recon, double* loss_part, void* stream) {
   if (int rc = check_desc(d)) return rc;
-  LGN_CHECK_ARG(params && grads && enc_off && dec_off && p4 && mask && workspace && recon && loss_part && n_params > 0,
+  LGN_CHECK_ARG(params && grads && enc_off && dec_off && p4 && target && mask && workspace && recon && loss_part && n_params > 0,
                 "step_fwd_bwd: null pointer");
   hipStream_t st = (hipStream_t)stream;
   Work w = carve(*d, workspace);
+  // the layout depends on run-time switches (LGN_AMD_DEC_PAIRWISE / LGN_AMD_LEVEL_V2 change the partial-row counts):
+  // refuse before anything is enqueued if the caller sized the workspace under different settings
+  LGN_CHECK_ARG((long long)w.total <= workspace_doubles, "step: workspace holds %lld doubles, this configuration needs %zu",
+                workspace_doubles, w.total);
   const Slots S{d->n_levels, d->mlp_nlin};
   const int L = d->n_levels, B = d->B, N = d->N, Ts = d->tau_s, Tv = d->tau_v;
   const int* ce = d->enc_channels;
@@ -278,7 +283,6 @@ int lgn_step_fwd_bwd_f64(const lgn_net_desc* d, const double* params, double* gr
       }
     }
   }
-#define HIPOK(e) do { hipError_t e_ = (e); if (e_ != hipSuccess) { set_error("%s: %s", #e, hipGetErrorString(e_)); return (int)e_; } } while (0)
   Deferred dq;
   dq.parts = w.parts;
   dq.cap = w.parts_size;
@@ -298,7 +302,7 @@ int lgn_step_fwd_bwd_f64(const lgn_net_desc* d, const double* params, double* gr
   int cur = 0;
   {
     double* part = dq.take((size_t)B * 2 * cd[L]);
-    LGN_TRY(dec_output_loss(B, N, cd[L], w.dec.v[L], params + dec_off[S.out0(true) + 1], p4, 1.0, recon, loss_part, w.gv[cur], part, st));
+    LGN_TRY(dec_output_loss(B, N, cd[L], w.dec.v[L], params + dec_off[S.out0(true) + 1], target, 1.0, recon, loss_part, w.gv[cur], part, st));
     dq.add(part, B, 2 * cd[L], 0, 2 * cd[L], grads + dec_off[S.out0(true) + 1]);
   }
   LGN_TRY(levels_bwd(*d, true, cd, params, grads, dec_off, w.dec, w.pdec, nullptr, w, dq, fin, cur, /*has_s_grad=*/false, st));
@@ -342,6 +346,232 @@ int lgn_step_finalize_f64(double* params, double* grads, long long n_params, con
   hipStream_t st = (hipStream_t)stream;
   LGN_TRY(finalize_step(params, grads, (long)n_params, loss_part, n_loss, l1_lambda, adam_m, adam_v, reinterpret_cast<long*>(step_dev),
                         lr, beta1, beta2, eps, do_adam, loss_out, st));
+  return 0;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------
+// one network at a time (module API: LGNEncoder.forward / LGNDecoder.forward and their autograd backward)
+// ---------------------------------------------------------------------------------------------------------
+namespace lgn {
+namespace {
+
+struct NetAct {                     // written by *_fwd, read by *_bwd
+  NetBuf n;
+  double* pdec;                     // decoder: complex canonical positions [2][B][N][4]
+  int* idx;                         // encoder: pooling indices
+  size_t total;
+};
+NetAct carve_act(const lgn_net_desc& d, bool dec, double* base) {
+  NetAct a{};
+  Bump b{base};
+  const size_t BN = (size_t)d.B * d.N;
+  const int* ch = dec ? d.dec_channels : d.enc_channels;
+  for (int l = 0; l <= d.n_levels; ++l) {
+    a.n.s[l] = b.take(2 * BN * ch[l]);
+    a.n.v[l] = b.take(8 * BN * ch[l]);
+  }
+  for (int l = 0; l < d.n_levels; ++l) {
+    a.n.smix[l] = b.take(2 * BN * ch[l + 1]);
+    a.n.ag0[l] = b.take(4 * BN * ch[l]);
+    a.n.ag1[l] = b.take(16 * BN * ch[l]);
+  }
+  if (dec) a.pdec = b.take(8 * BN);
+  else a.idx = reinterpret_cast<int*>(b.take(((size_t)d.B * 2 * (d.tau_s + d.tau_v) * 2 + 1) / 2 + 8));
+  a.total = b.off;
+  return a;
+}
+
+struct NetScratch {                 // backward only
+  Work w;                           // gs, gv, gsmix, g_ag, zeros_s, g_p, g_lat_s (zero block), tot, parts
+  size_t total;
+};
+NetScratch carve_scratch(const lgn_net_desc& d, bool dec, double* base) {
+  NetScratch s{};
+  Work& w = s.w;
+  Bump b{base};
+  const size_t BN = (size_t)d.B * d.N;
+  const int L = d.n_levels, Ts = d.tau_s, Tv = d.tau_v;
+  const int* ch = dec ? d.dec_channels : d.enc_channels;
+  int cmax = 0;
+  for (int l = 0; l <= L; ++l) cmax = cmax > ch[l] ? cmax : ch[l];
+  for (int q = 0; q < 2; ++q) {
+    w.gs[q] = b.take(2 * BN * cmax);
+    w.gv[q] = b.take(8 * BN * cmax);
+  }
+  w.gsmix = b.take(2 * BN * cmax);
+  w.g_ag = b.take(20 * BN * cmax);
+  {
+    const size_t z0 = b.off;
+    w.zeros_s = b.take(2 * BN * cmax);
+    w.g_p = b.take(dec ? 8 * BN : 0);
+    w.g_lat_s = b.take(dec ? 0 : (size_t)2 * d.B * 2 * Ts);
+    w.zero_doubles = b.off - z0;
+  }
+  size_t psum = 0;
+  for (int l = 0; l < L; ++l) {
+    int rm, rr;
+    level_bwd_partial_rows(d.B, d.N, dec, &rm, &rr);
+    const size_t nmix = (size_t)4 * ch[l + 1] * 5 * ch[l], nrad = rad_partial_size(ch[l], dec);
+    psum += ((rm * nmix + 15) & ~size_t(15)) + ((rr * nrad + 15) & ~size_t(15));
+    psum += ((size_t)mlp_partial_rows((int)BN) * mlp_psize(ch[l + 1], d.mlp_hidden_mul * 2 * ch[l + 1], d.mlp_nlin) + 15) & ~size_t(15);
+    w.tot[dec ? 1 : 0][l] = b.take(nrad + 16);
+  }
+  // input / output ends: decoder  B x (2 C_L) + B x (4 C_0 + 2 N Tin);  encoder  B x 2 (Ts + Tv) C_L + B x 4 C_0
+  const int Tin = d.tau_v_in > 0 ? d.tau_v_in : 2 * Tv;
+  if (dec) psum += (((size_t)d.B * 2 * ch[L] + 15) & ~size_t(15)) + (((size_t)d.B * (4 * ch[0] + 2 * (size_t)d.N * Tin) + 15) & ~size_t(15));
+  else psum += (((size_t)d.B * 2 * (Ts + Tv) * ch[L] + 15) & ~size_t(15)) + (((size_t)d.B * 4 * ch[0] + 15) & ~size_t(15));
+  w.parts = b.take(psum);
+  w.parts_size = psum;
+  s.total = b.off;
+  return s;
+}
+
+int check_mlp_contiguous(const lgn_net_desc& d, bool dec, const int64_t* off) {
+  const Slots S{d.n_levels, d.mlp_nlin};
+  const int* ch = dec ? d.dec_channels : d.enc_channels;
+  for (int l = 0; l < d.n_levels; ++l) {
+    const int D = 2 * ch[l + 1], H = d.mlp_hidden_mul * D;
+    int64_t expect = off[S.mlp(dec, l, 0)];
+    for (int q = 0; q < d.mlp_nlin; ++q) {
+      const int hin = q == 0 ? D : H, hout = q == d.mlp_nlin - 1 ? D : H;
+      LGN_CHECK_ARG(off[S.mlp(dec, l, 2 * q)] == expect, "MLP weights are not contiguous in the flat parameter buffer");
+      expect += (int64_t)hin * hout;
+      LGN_CHECK_ARG(off[S.mlp(dec, l, 2 * q + 1)] == expect, "MLP biases are not contiguous in the flat parameter buffer");
+      expect += hout;
+    }
+  }
+  return 0;
+}
+
+}  // namespace
+}  // namespace lgn
+
+extern "C" {
+
+long long lgn_net_workspace_doubles(const lgn_net_desc* d, int decoder, int which) {
+  if (check_desc(d)) return -1;
+  return which == 0 ? (long long)carve_act(*d, decoder != 0, nullptr).total : (long long)carve_scratch(*d, decoder != 0, nullptr).total;
+}
+
+int lgn_encoder_fwd_f64(const lgn_net_desc* d, const double* params, const int64_t* off, const double* p4, const uint8_t* mask,
+                        double* act, long long act_doubles, double* lat_s, double* lat_v, void* stream) {
+  if (int rc = check_desc(d)) return rc;
+  LGN_CHECK_ARG(params && off && p4 && mask && act && lat_s && lat_v, "encoder_fwd: null pointer");
+  NetAct a = carve_act(*d, false, act);
+  LGN_CHECK_ARG((long long)a.total <= act_doubles, "encoder_fwd: activation buffer holds %lld doubles, needs %zu", act_doubles, a.total);
+  hipStream_t st = (hipStream_t)stream;
+  const Slots S{d->n_levels, d->mlp_nlin};
+  const int L = d->n_levels;
+  const int* ce = d->enc_channels;
+  LGN_TRY(enc_input_fwd(d->B, d->N, ce[0], p4, params + off[0], params + off[1], a.n.s[0], a.n.v[0], st));
+  LGN_TRY(levels_fwd(*d, false, ce, params, off, a.n, p4, mask, st));
+  LGN_TRY(enc_latent_fwd(d->B, d->N, ce[L], d->tau_s, d->tau_v, a.n.s[L], a.n.v[L], params + off[S.out0(false)],
+                         params + off[S.out0(false) + 1], lat_s, lat_v, a.idx, st));
+  return 0;
+}
+
+int lgn_encoder_bwd_f64(const lgn_net_desc* d, const double* params, double* grads, long long n_params, const int64_t* off,
+                        const double* p4, const uint8_t* mask, const double* act, long long act_doubles, const double* g_lat_s,
+                        const double* g_lat_v, double* scratch, long long scratch_doubles, void* stream) {
+  if (int rc = check_desc(d)) return rc;
+  LGN_CHECK_ARG(params && grads && off && p4 && mask && act && g_lat_v && scratch && n_params > 0, "encoder_bwd: null pointer");
+  NetAct a = carve_act(*d, false, const_cast<double*>(act));
+  NetScratch sc = carve_scratch(*d, false, scratch);
+  LGN_CHECK_ARG((long long)a.total <= act_doubles && (long long)sc.total <= scratch_doubles,
+                "encoder_bwd: buffers hold %lld / %lld doubles, need %zu / %zu", act_doubles, scratch_doubles, a.total, sc.total);
+  if (int rc = check_mlp_contiguous(*d, false, off)) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  Work& w = sc.w;
+  const Slots S{d->n_levels, d->mlp_nlin};
+  const int L = d->n_levels, B = d->B, N = d->N, Ts = d->tau_s, Tv = d->tau_v;
+  const int* ce = d->enc_channels;
+  HIPOK(hipMemsetAsync(grads, 0, sizeof(double) * (size_t)n_params, st));
+  HIPOK(hipMemsetAsync(w.zeros_s, 0, sizeof(double) * w.zero_doubles, st));
+  Deferred dq;
+  dq.parts = w.parts;
+  dq.cap = w.parts_size;
+  RadFinJob fin{};
+  int cur = 0;
+  {
+    const int CL = ce[L], rowe = 2 * (Ts + Tv) * CL;
+    double* parte = dq.take((size_t)B * rowe);
+    LGN_TRY(enc_latent_bwd(B, N, CL, Ts, Tv, a.n.s[L], a.n.v[L], params + off[S.out0(false)], params + off[S.out0(false) + 1],
+                           g_lat_s ? g_lat_s : w.g_lat_s, g_lat_v, a.idx, w.gs[cur], w.gv[cur], parte, st));
+    dq.add(parte, B, rowe, 0, 2 * Ts * CL, grads + off[S.out0(false)]);
+    dq.add(parte, B, rowe, 2 * Ts * CL, 2 * Tv * CL, grads + off[S.out0(false) + 1]);
+  }
+  // without an upstream gradient on the latent scalars the last level's scalars (and its CGMLP) receive none
+  LGN_TRY(levels_bwd(*d, false, ce, params, grads, off, a.n, p4, mask, w, dq, fin, cur, /*has_s_grad=*/g_lat_s != nullptr, st));
+  {
+    const int C0 = ce[0];
+    double* part = dq.take((size_t)B * 4 * C0);
+    LGN_TRY(enc_input_bwd(B, N, C0, p4, w.gs[cur], w.gv[cur], part, st));
+    dq.add(part, B, 4 * C0, 0, 2 * C0, grads + off[0]);
+    dq.add(part, B, 4 * C0, 2 * C0, 2 * C0, grads + off[1]);
+  }
+  LGN_CHECK_ARG(dq.off <= dq.cap, "encoder_bwd: partial-row workspace overflow (%zu > %zu)", dq.off, dq.cap);
+  LGN_TRY(dq.flush(st));
+  LGN_TRY(rad_finalize_batch(fin, st));
+  return 0;
+}
+
+int lgn_decoder_fwd_f64(const lgn_net_desc* d, const double* params, const int64_t* off, const double* lat_v, double* act,
+                        long long act_doubles, double* recon, void* stream) {
+  if (int rc = check_desc(d)) return rc;
+  LGN_CHECK_ARG(params && off && lat_v && act && recon, "decoder_fwd: null pointer");
+  NetAct a = carve_act(*d, true, act);
+  LGN_CHECK_ARG((long long)a.total <= act_doubles, "decoder_fwd: activation buffer holds %lld doubles, needs %zu", act_doubles, a.total);
+  hipStream_t st = (hipStream_t)stream;
+  const Slots S{d->n_levels, d->mlp_nlin};
+  const int L = d->n_levels, Tin = d->tau_v_in > 0 ? d->tau_v_in : 2 * d->tau_v;
+  const int* cd = d->dec_channels;
+  LGN_TRY(dec_input_fwd(d->B, d->N, cd[0], Tin, lat_v, params + off[1], params + off[2], params + off[3], a.pdec, a.n.s[0], a.n.v[0], st));
+  LGN_TRY(levels_fwd(*d, true, cd, params, off, a.n, a.pdec, nullptr, st));
+  LGN_TRY(dec_output_fwd(d->B, d->N, cd[L], a.n.v[L], params + off[S.out0(true) + 1], recon, st));
+  return 0;
+}
+
+int lgn_decoder_bwd_f64(const lgn_net_desc* d, const double* params, double* grads, long long n_params, const int64_t* off,
+                        const double* lat_v, const double* act, long long act_doubles, const double* g_recon, double* g_lat_v,
+                        double* scratch, long long scratch_doubles, void* stream) {
+  if (int rc = check_desc(d)) return rc;
+  LGN_CHECK_ARG(params && grads && off && lat_v && act && g_recon && g_lat_v && scratch && n_params > 0, "decoder_bwd: null pointer");
+  NetAct a = carve_act(*d, true, const_cast<double*>(act));
+  NetScratch sc = carve_scratch(*d, true, scratch);
+  LGN_CHECK_ARG((long long)a.total <= act_doubles && (long long)sc.total <= scratch_doubles,
+                "decoder_bwd: buffers hold %lld / %lld doubles, need %zu / %zu", act_doubles, scratch_doubles, a.total, sc.total);
+  if (int rc = check_mlp_contiguous(*d, true, off)) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  Work& w = sc.w;
+  const Slots S{d->n_levels, d->mlp_nlin};
+  const int L = d->n_levels, B = d->B, N = d->N, Tin = d->tau_v_in > 0 ? d->tau_v_in : 2 * d->tau_v;
+  const int* cd = d->dec_channels;
+  HIPOK(hipMemsetAsync(grads, 0, sizeof(double) * (size_t)n_params, st));
+  HIPOK(hipMemsetAsync(w.zeros_s, 0, sizeof(double) * w.zero_doubles, st));
+  Deferred dq;
+  dq.parts = w.parts;
+  dq.cap = w.parts_size;
+  RadFinJob fin{};
+  int cur = 0;
+  {
+    double* part = dq.take((size_t)B * 2 * cd[L]);
+    LGN_TRY(dec_output_bwd(B, N, cd[L], a.n.v[L], params + off[S.out0(true) + 1], g_recon, w.gv[cur], part, st));
+    dq.add(part, B, 2 * cd[L], 0, 2 * cd[L], grads + off[S.out0(true) + 1]);
+  }
+  LGN_TRY(levels_bwd(*d, true, cd, params, grads, off, a.n, a.pdec, nullptr, w, dq, fin, cur, /*has_s_grad=*/false, st));
+  {
+    const int C0 = cd[0], row = 4 * C0 + 2 * N * Tin;
+    double* part = dq.take((size_t)B * row);
+    LGN_TRY(dec_input_bwd(B, N, C0, Tin, lat_v, params + off[1], params + off[3], a.pdec, w.g_p, w.gs[cur], w.gv[cur], g_lat_v, part, st));
+    dq.add(part, B, row, 0, 2 * C0, grads + off[2]);
+    dq.add(part, B, row, 2 * C0, 2 * C0, grads + off[3]);
+    dq.add(part, B, row, 4 * C0, 2 * N * Tin, grads + off[1]);
+  }
+  LGN_CHECK_ARG(dq.off <= dq.cap, "decoder_bwd: partial-row workspace overflow (%zu > %zu)", dq.off, dq.cap);
+  LGN_TRY(dq.flush(st));
+  LGN_TRY(rad_finalize_batch(fin, st));
   return 0;
 }
 

@@ -15,7 +15,7 @@ import torch  # imported before the .so so that the process-wide libamdhip64 is 
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_lib", "liblgn_amd.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 FINALIZE_SCRATCH = 2048      # include/lgn_amd.h: LGN_FINALIZE_SCRATCH
 
 _lib: Optional[C.CDLL] = None
@@ -43,7 +43,7 @@ class NetDesc(C.Structure):
     """lgn_net_desc of include/lgn_amd.h."""
     _fields_ = [("B", C.c_int), ("N", C.c_int), ("n_levels", C.c_int), ("enc_channels", C.c_int * 5),
                 ("dec_channels", C.c_int * 5), ("tau_s", C.c_int), ("tau_v", C.c_int), ("mlp_hidden_mul", C.c_int),
-                ("mlp_nlin", C.c_int)]
+                ("mlp_nlin", C.c_int), ("tau_v_in", C.c_int)]
 
 
 class LocalTables(C.Structure):
@@ -65,10 +65,14 @@ _SIGNATURES.update({
     "lgn_local_partial_rows": [_i],
     "lgn_local_bwd_f64": [_i] * 5 + [_tp] + [_vp] * 8,
     "lgn_step_param_slots": [_dp, _i],
-    "lgn_step_fwd_bwd_f64": [_dp, _vp, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "lgn_step_fwd_bwd_f64": [_dp, _vp, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _vp, _vp],
+    "lgn_encoder_fwd_f64": [_dp, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _vp, _vp],
+    "lgn_encoder_bwd_f64": [_dp, _vp, _vp, _ll, _vp, _vp, _vp, _vp, _ll, _vp, _vp, _vp, _ll, _vp],
+    "lgn_decoder_fwd_f64": [_dp, _vp, _vp, _vp, _vp, _ll, _vp, _vp],
+    "lgn_decoder_bwd_f64": [_dp, _vp, _vp, _ll, _vp, _vp, _vp, _ll, _vp, _vp, _vp, _ll, _vp],
     "lgn_step_finalize_f64": [_vp, _vp, _ll, _vp, _i, _d, _vp, _vp, _vp, _d, _d, _d, _d, _i, _vp, _vp],
 })
-EXPORTED_SYMBOLS = ["lgn_abi_version", "lgn_last_error", "lgn_step_workspace_doubles"] + list(_SIGNATURES)
+EXPORTED_SYMBOLS = ["lgn_abi_version", "lgn_last_error", "lgn_step_workspace_doubles", "lgn_net_workspace_doubles"] + list(_SIGNATURES)
 
 
 def lib() -> C.CDLL:
@@ -91,6 +95,8 @@ def lib() -> C.CDLL:
             fn.restype = C.c_int
         l.lgn_step_workspace_doubles.argtypes = [_dp]
         l.lgn_step_workspace_doubles.restype = C.c_longlong
+        l.lgn_net_workspace_doubles.argtypes = [_dp, _i, _i]
+        l.lgn_net_workspace_doubles.restype = C.c_longlong
         _lib = l
     return _lib
 

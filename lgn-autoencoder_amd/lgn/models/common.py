@@ -24,7 +24,19 @@ def adapt_var_list(var, num_cg_levels):
 
 
 class CGModule(nn.Module):
-    """Device / dtype / cg_dict plumbing of the reference's CGModule (lgn/cg_lib/cg_module.py:7-210)."""
+    """Device / dtype / cg_dict plumbing of the reference's CGModule (lgn/cg_lib/cg_module.py:7-210), plus the
+    MI355X-first parameter storage of the two networks:
+
+    **one flat fp64 block per network.**  The sub-modules are constructed exactly like the reference's (same shapes,
+    names, init rules and RNG order), then ``_flatten_parameters`` moves every tensor into ONE ``nn.Parameter``
+    (``flat_params``) and leaves plain views of it in the sub-modules.  Consequences:
+      * ``parameters()`` is a single leaf: an optimiser step is one element-wise pass, ``l1_norm()`` two kernels,
+        autograd accumulates one gradient, data parallelism all-reduces one buffer, and the native kernels address
+        every weight as ``flat + offset`` (include/lgn_amd.h: parameter slots);
+      * ``state_dict()`` / ``load_state_dict()`` keep the reference's keys and order (checkpoints are interchangeable,
+        utils/train.py:114-129,376-385): they enumerate the named views, not the flat block;
+      * per-name access: ``named_parameter_views()`` and ``named_grads()``.
+    """
 
     def __init__(self, maxdim, device=None, dtype=None, cg_dict=None):
         super().__init__()
@@ -58,17 +70,116 @@ class CGModule(nn.Module):
     def cg_dict(self):
         return self._cg_dict
 
+    # ---- flat parameter block -------------------------------------------------------------------------
+    def _flatten_parameters(self):
+        named = list(self.named_parameters())            # registration order == the reference's state_dict order
+        self._p_names = [n for n, _ in named]
+        self._p_shapes = [tuple(p.shape) for _, p in named]
+        self._p_sizes = [p.numel() for _, p in named]
+        self._p_offsets = [0]
+        for n in self._p_sizes:
+            self._p_offsets.append(self._p_offsets[-1] + n)
+        flat = torch.cat([p.detach().reshape(-1) for _, p in named]).contiguous()
+        self._p_slots = []
+        for name, _ in named:
+            path, _, attr = name.rpartition(".")
+            owner = self.get_submodule(path) if path else self
+            del owner._parameters[attr]
+            self._p_slots.append((owner, attr))
+        self.flat_params = nn.Parameter(flat)
+        self._rebind_views()
+
+    def _rebind_views(self):
+        """(Re)create the plain views the sub-modules and the native calls read; called whenever ``flat_params``
+        moved (``.to()``, a trainer re-homing it into a joint buffer, deepcopy)."""
+        base = self.flat_params.detach()
+        self._p_views = [base[o:o + n].view(s) for o, n, s in zip(self._p_offsets, self._p_sizes, self._p_shapes)]
+        self._views_ptr = base.data_ptr()
+        self._device = base.device
+        self._bind(self._p_views)
+        self.__dict__.pop("_native_cache", None)
+
+    def _bind(self, tensors):
+        for (owner, attr), t in zip(self._p_slots, tensors):
+            owner.__dict__[attr] = t
+
+    def _check_views(self):
+        if self._views_ptr != self.flat_params.data_ptr():
+            self._rebind_views()
+
+    def _tracked_views(self):
+        """Views of ``flat_params`` that autograd follows (module/autograd path): ONE split node + metadata-only views,
+        so the backward assembles the flat gradient with a single concatenation."""
+        parts = torch.split_with_sizes(self.flat_params, self._p_sizes)
+        return [p.view(s) for p, s in zip(parts, self._p_shapes)]
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        if "flat_params" in self._parameters:
+            self._rebind_views()
+        return out
+
+    def __deepcopy__(self, memo):
+        import copy
+        cls = self.__class__
+        new = cls.__new__(cls)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            new.__dict__[k] = copy.deepcopy(v, memo)
+        if "flat_params" in new._parameters:
+            new._rebind_views()
+        return new
+
+    def named_parameter_views(self):
+        """(reference parameter name, view of the flat block) in state_dict order."""
+        self._check_views()
+        return list(zip(self._p_names, self._p_views))
+
+    def named_grads(self):
+        """(reference parameter name, view of ``flat_params.grad`` or None) in state_dict order."""
+        g = self.flat_params.grad
+        if g is None:
+            return [(n, None) for n in self._p_names]
+        return [(n, g[o:o + k].view(s)) for n, o, k, s in zip(self._p_names, self._p_offsets, self._p_sizes, self._p_shapes)]
+
+    def state_dict(self, *args, destination=None, prefix="", keep_vars=False):
+        from collections import OrderedDict
+        out = destination if destination is not None else OrderedDict()
+        for name, view in self.named_parameter_views():
+            out[prefix + name] = view if keep_vars else view.detach()
+        return out
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        from torch.nn.modules.module import _IncompatibleKeys
+        views = dict(self.named_parameter_views())
+        missing = [k for k in views if k not in state_dict]
+        unexpected = [k for k in state_dict if k not in views]
+        errors = []
+        for k, v in views.items():
+            if k in state_dict and tuple(state_dict[k].shape) != tuple(v.shape):
+                errors.append(f"size mismatch for {k}: copying a param with shape {tuple(state_dict[k].shape)} from checkpoint, "
+                              f"the shape in current model is {tuple(v.shape)}.")
+        if strict and (missing or unexpected):
+            errors.insert(0, f"Missing key(s) in state_dict: {missing}. Unexpected key(s) in state_dict: {unexpected}.")
+        if errors:
+            raise RuntimeError(f"Error(s) in loading state_dict for {self.__class__.__name__}:\n\t" + "\n\t".join(errors))
+        with torch.no_grad():
+            for k, v in views.items():
+                if k in state_dict:
+                    v.copy_(state_dict[k])
+        return _IncompatibleKeys(missing, unexpected)
+
     def l1_norm(self) -> torch.Tensor:
-        return sum(p.abs().sum() for p in self.parameters())
+        return self.flat_params.abs().sum()
 
     def l2_norm(self) -> torch.Tensor:
-        return sum(torch.pow(p, 2).sum() for p in self.parameters())
+        return torch.pow(self.flat_params, 2).sum()
 
     def _require_gpu(self):
-        if self._device.type != "cuda":
+        if self.flat_params.device.type != "cuda":
             raise RuntimeError(
                 "lgn (MI355X build): the LGN hot path runs only in the HIP kernels of liblgn_amd.so on a GPU device; "
-                f"this module was created on '{self._device}'. There is no CPU fallback.")
+                f"this module lives on '{self.flat_params.device}'. There is no CPU fallback.")
 
 
 def _is_fused_layout(plan: LevelPlan, maxdim: int) -> bool:

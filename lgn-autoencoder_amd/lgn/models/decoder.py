@@ -60,6 +60,8 @@ class LGNDecoder(CGModule, LevelTablesMixin):
         self.tau_dict["output"] = self.tau_output
         self.mix_to_output = MixReps(tau_last, self.tau_output, **misc)
         self.__num_param = sum(p.nelement() for p in self.parameters() if p.requires_grad)
+        self.use_fused = True      # False: force the per-operator module/autograd path (cross-checks, tests)
+        self._flatten_parameters()
 
     @property
     def num_learnable_parameters(self) -> int:
@@ -67,9 +69,36 @@ class LGNDecoder(CGModule, LevelTablesMixin):
 
     def forward(self, latent_features, covariance_test: bool = False, nodes_all: List[GVec] = None):
         self._require_gpu()
+        self._check_views()
         if covariance_test and nodes_all is None:
             raise ValueError("covariance_test is set to True, but the full node features from the encoder is not passed in!")
         lat_v = latent_features[(1, 1)].to(device=self.device, dtype=self.dtype)               # (2,B,1,T,4)
+        if not covariance_test and self.use_fused and self._fused_ok():
+            # the whole decoder is one native call (and one more for its backward): csrc/step.hip lgn_decoder_fwd/bwd_f64
+            return ops.DecoderFn.apply(self, lat_v, self.flat_params)
+        self._bind(self._tracked_views())
+        try:
+            return self._forward_modular(lat_v, covariance_test, nodes_all)
+        finally:
+            self._bind(self._p_views)
+
+    def _fused_ok(self) -> bool:
+        ok = self.__dict__.get("_fused")
+        if ok is None:
+            from ..plan import check_maxdim2_layout
+            ok = (bool(self.mlp) and self.mlp_depth == 6 and self.num_basis_fn == 10 and 1 <= self.num_cg_levels <= 4
+                  and all(m == 2 for m in self.level_maxdim) and all(1 <= c <= 8 for c in self.num_channels)
+                  and self.mlp_width * 2 * max(self.num_channels[1:]) <= 96)
+            if ok:
+                try:
+                    for plan in self.plans:
+                        check_maxdim2_layout(plan)
+                except RuntimeError:
+                    ok = False
+            self.__dict__["_fused"] = ok
+        return ok
+
+    def _forward_modular(self, lat_v, covariance_test, nodes_all):
         B = lat_v.shape[1]
         N = self.num_output_particles
 

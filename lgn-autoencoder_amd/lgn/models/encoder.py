@@ -69,6 +69,8 @@ class LGNEncoder(CGModule, LevelTablesMixin):
         self.mix_reps = MixReps(tau_last, self.tau_output, **misc)
         self.tau_latent = self.tau_output
         self.__num_param = sum(p.nelement() for p in self.parameters() if p.requires_grad)
+        self.use_fused = True      # False: force the per-operator module/autograd path (cross-checks, tests)
+        self._flatten_parameters()
 
     @property
     def num_learnable_parameters(self) -> int:
@@ -77,8 +79,37 @@ class LGNEncoder(CGModule, LevelTablesMixin):
     def forward(self, data: Union[Dict[str, torch.Tensor], torch.Tensor, np.ndarray], covariance_test: bool = False
                 ) -> Union[GVec, Tuple[GVec, List[GVec]]]:
         self._require_gpu()
+        self._check_views()
         node_ps, node_mask = self._prepare_input(data)
+        if not covariance_test and self.use_fused and self._fused_ok():
+            # the whole encoder is one native call (and one more for its backward): csrc/step.hip lgn_encoder_fwd/bwd_f64
+            lat_s, lat_v = ops.EncoderFn.apply(self, node_ps, node_mask, self.flat_params)
+            return GVec({(0, 0): lat_s, (1, 1): lat_v})
+        # module / autograd path: one native call per operator (all irreps, every map_to_latent, internal features)
+        self._bind(self._tracked_views())
+        try:
+            return self._forward_modular(node_ps, node_mask, covariance_test)
+        finally:
+            self._bind(self._p_views)
 
+    def _fused_ok(self) -> bool:
+        ok = self.__dict__.get("_fused")
+        if ok is None:
+            from ..plan import check_maxdim2_layout
+            ok = (self.map_to_latent == "min&max" and bool(self.mlp) and self.mlp_depth == 6 and self.num_basis_fn == 10
+                  and 1 <= self.num_cg_levels <= 4 and all(m == 2 for m in self.level_maxdim)
+                  and all(1 <= c <= 8 for c in self.num_channels)
+                  and self.mlp_width * 2 * max(self.num_channels[1:]) <= 96)
+            if ok:
+                try:
+                    for plan in self.plans:
+                        check_maxdim2_layout(plan)
+                except RuntimeError:
+                    ok = False
+            self.__dict__["_fused"] = ok
+        return ok
+
+    def _forward_modular(self, node_ps, node_mask, covariance_test):
         # input features: (0,0) = (sqrt|p^2|, 0), (1,1) = canonical(p)   (lgn_encoder.py:287-293,376)
         mass = ops.normsq4(node_ps).abs().sqrt()
         s0 = torch.stack([mass, torch.zeros_like(mass)], 0).unsqueeze(-1).unsqueeze(-1)      # (2,B,N,1,1)

@@ -232,3 +232,142 @@ class GenericLevelFn(torch.autograd.Function):
             g_ws.append(g_w[off:off + n].view(shp))
             off += n
         return (None, None, None, gX, g_p, None) + g_rad + tuple(g_ws)
+
+
+# ---------------------------------------------------------------------------------------------
+# whole networks: one native call per direction (csrc/step.hip: lgn_encoder_* / lgn_decoder_*)
+# ---------------------------------------------------------------------------------------------
+
+def slot_tensors(net, decoder: bool):
+    """Parameter views of a network in the slot order of include/lgn_amd.h (lgn_step_fwd_bwd_f64)."""
+    out = []
+    if decoder:
+        out += [net.latent_to_graph.weight((0, 0)), net.latent_to_graph.weight((1, 1))]
+    out += [net.input_func_node.weight((0, 0)), net.input_func_node.weight((1, 1))]
+    for rf in net.rad_funcs.rad_funcs:
+        out += rf.flat_params()
+    for lvl in net.lgn_cg.node_levels:
+        out += [lvl.cat_mix.mix_reps.weight((0, 0)), lvl.cat_mix.mix_reps.weight((1, 1))]
+    for mlp in net.lgn_cg.mlp_levels:
+        out += mlp.flat_params()
+    last = net.mix_to_output if decoder else net.mix_reps
+    out += [last.weight((0, 0)), last.weight((1, 1))]
+    return out
+
+
+class NetHandle:
+    """Descriptor + slot offsets + workspace sizes of one network for one batch size (cached on the module)."""
+
+    def __init__(self, net, decoder: bool, B: int):
+        import ctypes as C
+        d = N.NetDesc()
+        d.B, d.n_levels = B, net.num_cg_levels
+        ch = d.dec_channels if decoder else d.enc_channels
+        for i, c in enumerate(net.num_channels):
+            ch[i] = c
+        other = d.enc_channels if decoder else d.dec_channels
+        for i in range(len(net.num_channels)):
+            other[i] = 1
+        if decoder:
+            d.N = net.num_output_particles
+            d.tau_s, d.tau_v, d.tau_v_in = 1, 1, net.tau_latent_vectors
+        else:
+            d.N = net.num_input_particles
+            d.tau_s, d.tau_v, d.tau_v_in = net.tau_latent[(0, 0)], net.tau_latent[(1, 1)], 0
+        d.mlp_hidden_mul, d.mlp_nlin = net.mlp_width, net.mlp_depth + 1
+        lib = N.lib()
+        slots = slot_tensors(net, decoder)
+        want = lib.lgn_step_param_slots(C.byref(d), int(decoder))
+        if want < 0:
+            raise RuntimeError(N.last_error())
+        assert len(slots) == want, (len(slots), want)
+        base = net.flat_params.data_ptr()
+        offs = [(t.data_ptr() - base) // 8 for t in slots]
+        assert all(0 <= o < net.flat_params.numel() for o in offs)
+        self.desc, self.ref = d, C.byref(d)
+        self.off = (C.c_int64 * len(offs))(*offs)
+        self.n_act = lib.lgn_net_workspace_doubles(self.ref, int(decoder), 0)
+        self.n_scratch = lib.lgn_net_workspace_doubles(self.ref, int(decoder), 1)
+        if self.n_act < 0 or self.n_scratch < 0:
+            raise RuntimeError(N.last_error())
+        self.n_params = net.flat_params.numel()
+
+
+def net_handle(net, decoder: bool, B: int) -> NetHandle:
+    net._check_views()
+    cache = net.__dict__.setdefault("_native_cache", {})
+    h = cache.get(B)
+    if h is None:
+        h = cache[B] = NetHandle(net, decoder, B)
+    return h
+
+
+class EncoderFn(torch.autograd.Function):
+    """LGNEncoder.forward (lgn/models/lgn_encoder.py:255-336; 'min&max' pooling) as ONE native call, and the backward
+    autograd would run through it as one more.  args: net, p4 (B,N,4) already scaled, mask (B,N) uint8, flat_params."""
+
+    @staticmethod
+    def forward(ctx, net, p4, mask, flat):
+        B = p4.shape[0]
+        h = net_handle(net, False, B)
+        dev, dt = flat.device, flat.dtype
+        Ts, Tv = h.desc.tau_s, h.desc.tau_v
+        act = torch.empty(h.n_act, device=dev, dtype=dt)
+        lat_s = torch.empty(2, B, 1, 2 * Ts, 1, device=dev, dtype=dt)
+        lat_v = torch.empty(2, B, 1, 2 * Tv, 4, device=dev, dtype=dt)
+        flat_d = flat.detach()
+        rc = N.lib().lgn_encoder_fwd_f64(h.ref, N.ptr(flat_d), h.off, N.ptr(p4), N.ptr(mask), N.ptr(act), h.n_act,
+                                         N.ptr(lat_s), N.ptr(lat_v), N.stream_ptr())
+        N._check(rc, "lgn_encoder_fwd_f64")
+        ctx.h = h
+        ctx.save_for_backward(p4, mask, flat, act)
+        ctx.set_materialize_grads(False)
+        return lat_s, lat_v
+
+    @staticmethod
+    def backward(ctx, g_s, g_v):
+        p4, mask, flat, act = ctx.saved_tensors
+        h = ctx.h
+        grads = torch.empty_like(flat)
+        if g_v is None:
+            if g_s is None:
+                return None, None, None, grads.zero_()
+            g_v = torch.zeros(2, h.desc.B, 1, 2 * h.desc.tau_v, 4, device=flat.device, dtype=flat.dtype)
+        scratch = torch.empty(h.n_scratch, device=flat.device, dtype=flat.dtype)
+        rc = N.lib().lgn_encoder_bwd_f64(h.ref, N.ptr(flat.detach()), N.ptr(grads), h.n_params, h.off, N.ptr(p4), N.ptr(mask),
+                                         N.ptr(act), h.n_act, N.ptr(None if g_s is None else N.f64(g_s)), N.ptr(N.f64(g_v)),
+                                         N.ptr(scratch), h.n_scratch, N.stream_ptr())
+        N._check(rc, "lgn_encoder_bwd_f64")
+        return None, None, None, grads
+
+
+class DecoderFn(torch.autograd.Function):
+    """LGNDecoder.forward (lgn/models/lgn_decoder.py:218-303) as one native call per direction.
+    args: net, latent vectors (2,B,1,T,4), flat_params -> reconstruction (2,B,N,4)."""
+
+    @staticmethod
+    def forward(ctx, net, lat_v, flat):
+        lat_v = N.f64(lat_v)
+        B = lat_v.shape[1]
+        h = net_handle(net, True, B)
+        dev, dt = flat.device, flat.dtype
+        act = torch.empty(h.n_act, device=dev, dtype=dt)
+        recon = torch.empty(2, B, h.desc.N, 4, device=dev, dtype=dt)
+        rc = N.lib().lgn_decoder_fwd_f64(h.ref, N.ptr(flat.detach()), h.off, N.ptr(lat_v), N.ptr(act), h.n_act, N.ptr(recon),
+                                         N.stream_ptr())
+        N._check(rc, "lgn_decoder_fwd_f64")
+        ctx.h = h
+        ctx.save_for_backward(lat_v, flat, act)
+        return recon
+
+    @staticmethod
+    def backward(ctx, g_recon):
+        lat_v, flat, act = ctx.saved_tensors
+        h = ctx.h
+        grads = torch.empty_like(flat)
+        g_lat = torch.empty_like(lat_v)
+        scratch = torch.empty(h.n_scratch, device=flat.device, dtype=flat.dtype)
+        rc = N.lib().lgn_decoder_bwd_f64(h.ref, N.ptr(flat.detach()), N.ptr(grads), h.n_params, h.off, N.ptr(lat_v), N.ptr(act),
+                                         h.n_act, N.ptr(N.f64(g_recon)), N.ptr(g_lat), N.ptr(scratch), h.n_scratch, N.stream_ptr())
+        N._check(rc, "lgn_decoder_bwd_f64")
+        return None, g_lat, grads

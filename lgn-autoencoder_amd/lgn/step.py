@@ -70,6 +70,9 @@ class FlatParams:
                 p.grad = self.grad[off:off + n].view(p.shape)
                 off += n
         self.params = params
+        for m in modules:                       # the networks keep plain views of their flat block: refresh them
+            if hasattr(m, "_rebind_views"):
+                m._rebind_views()
 
     def zero_grad(self):
         self.grad.zero_()
@@ -120,21 +123,7 @@ class TrainStep:
 # fully native step: one C call for encoder -> decoder -> loss -> backward, captured in a HIP graph
 # ---------------------------------------------------------------------------------------------------
 
-def _slot_tensors(net, decoder: bool):
-    """Parameters of a network in the slot order of include/lgn_amd.h (lgn_step_fwd_bwd_f64)."""
-    out = []
-    if decoder:
-        out += [net.latent_to_graph.weight((0, 0)), net.latent_to_graph.weight((1, 1))]
-    out += [net.input_func_node.weight((0, 0)), net.input_func_node.weight((1, 1))]
-    for rf in net.rad_funcs.rad_funcs:
-        out += rf.flat_params()
-    for lvl in net.lgn_cg.node_levels:
-        out += [lvl.cat_mix.mix_reps.weight((0, 0)), lvl.cat_mix.mix_reps.weight((1, 1))]
-    for mlp in net.lgn_cg.mlp_levels:
-        out += mlp.flat_params()
-    last = net.mix_to_output if decoder else net.mix_reps
-    out += [last.weight((0, 0)), last.weight((1, 1))]
-    return out
+from .ops import slot_tensors as _slot_tensors  # noqa: E402  (parameter slots of include/lgn_amd.h)
 
 
 class NativeTrainStep:
@@ -144,18 +133,27 @@ class NativeTrainStep:
     enqueued on the capturing stream) and replayed; the gradient all-reduce sits between the two graphs."""
 
     def __init__(self, encoder, decoder, batch_size: int, lr: float = 5e-4, l1_lambda: float = 1e-8,
-                 betas=(0.9, 0.999), eps: float = 1e-8, process_group=None, optimizer: bool = True, use_graph: bool = True):
+                 betas=(0.9, 0.999), eps: float = 1e-8, process_group=None, optimizer: bool = True, use_graph: bool = True,
+                 force_collective: bool = False):
         import ctypes as C
         from . import _native as N
         self.N = N
+        if not (encoder._fused_ok() and decoder._fused_ok()):
+            # lgn_step_fwd_bwd_f64 is the maxdim = 2 closed form: [2][CO][5C] CatMix weights, 20 radial basis functions,
+            # 7-layer CGMLPs.  Anything else would be read with the wrong layout -> refuse instead of computing garbage.
+            raise NotImplementedError(
+                "the native step implements maxdim=2 networks with map_to_latent='min&max', CGMLP levels (mlp_depth=6), "
+                f"num_basis_fn=10 and <= 8 channels; got encoder maxdim={encoder.level_maxdim} map_to_latent="
+                f"{encoder.map_to_latent!r} mlp={encoder.mlp}, decoder maxdim={decoder.level_maxdim} mlp={decoder.mlp}")
         encoder._require_gpu()
-        if encoder.map_to_latent != "min&max" or not encoder.mlp or not decoder.mlp:
-            raise NotImplementedError("the native step implements map_to_latent='min&max' with CGMLP levels")
         self.encoder, self.decoder = encoder, decoder
         self.l1_lambda, self.lr, self.betas, self.eps = l1_lambda, lr, betas, eps
         self.flat = FlatParams(encoder, decoder, grad_tail=batch_size)   # gradients | per-jet Chamfer terms
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         self.group = process_group
+        # force_collective: take the two-graph + all-reduce branch even with one rank (exercises the capture boundaries and
+        # the RCCL call on the flat buffer on a single GPU; a 1-rank SUM leaves the buffer unchanged)
+        self.collective = self.world > 1 or force_collective
         self.optimizer = optimizer
         dev, dt = self.flat.flat.device, self.flat.flat.dtype
         L = encoder.num_cg_levels
@@ -179,6 +177,12 @@ class NativeTrainStep:
             if want < 0:
                 raise RuntimeError(N.last_error())
             assert len(ts) == want, (len(ts), want)
+            ch = net.num_channels
+            for l in range(L):                   # sizes the kernels assume for the per-level slots
+                mix0 = ts[(2 if dec else 0) + 2 + 7 * L + 2 * l]
+                assert mix0.numel() == 2 * ch[l + 1] * 5 * ch[l], "CatMix weight is not [2][CO][5C]: not a maxdim=2 level"
+                ra = ts[(2 if dec else 0) + 2 + 7 * l]
+                assert ra.numel() == 20, "radial network must have 2 * num_basis_fn = 20 basis functions"
             offs = [(t.data_ptr() - base) // 8 for t in ts]
             assert all(0 <= o < self.flat.flat.numel() for o in offs)
             return (C.c_int64 * len(offs))(*offs)
@@ -195,7 +199,9 @@ class NativeTrainStep:
         self.adam_m = torch.zeros_like(self.flat.flat)
         self.adam_v = torch.zeros_like(self.flat.flat)
         self.step_dev = torch.zeros(1, device=dev, dtype=torch.int64)
-        self.p4 = torch.empty(d.B, d.N, 4, device=dev, dtype=dt)
+        self.p4 = torch.empty(d.B, d.N, 4, device=dev, dtype=dt)           # encoder input (p4 * scale)
+        # Chamfer target = the UNscaled batch (utils/train.py:285-292); aliases the input when scale == 1
+        self.target = self.p4 if encoder.scale == 1.0 else torch.empty_like(self.p4)
         self.mask = torch.empty(d.B, d.N, device=dev, dtype=torch.uint8)
         self.use_graph = use_graph
         self._g1 = self._g2 = None
@@ -205,8 +211,9 @@ class NativeTrainStep:
         import ctypes as C
         N = self.N
         rc = N.lib().lgn_step_fwd_bwd_f64(C.byref(self.desc), N.ptr(self.flat.flat), N.ptr(self.flat.grad), self.flat.flat.numel(),
-                                          self.enc_off, self.dec_off, N.ptr(self.p4), N.ptr(self.mask), N.ptr(self.workspace),
-                                          N.ptr(self.recon), N.ptr(self.loss_part), N.stream_ptr())
+                                          self.enc_off, self.dec_off, N.ptr(self.p4), N.ptr(self.target), N.ptr(self.mask),
+                                          N.ptr(self.workspace), self.workspace.numel(), N.ptr(self.recon), N.ptr(self.loss_part),
+                                          N.stream_ptr())
         N._check(rc, "lgn_step_fwd_bwd_f64")
 
     def _finalize(self, do_adam: bool):
@@ -227,7 +234,7 @@ class NativeTrainStep:
             self._finalize(False)
         torch.cuda.current_stream().wait_stream(s)
         self._g1, self._g2 = torch.cuda.CUDAGraph(), None
-        if self.world > 1:            # the gradient all-reduce sits between the two graphs
+        if self.collective:           # the gradient all-reduce sits between the two graphs
             self._g2 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._g1):
                 self._fwd_bwd()
@@ -244,9 +251,18 @@ class NativeTrainStep:
         """Stage a batch into the static input buffers (device-to-device copy; labels/masks as in
         LGNEncoder._prepare_input, lgn/models/lgn_encoder.py:386-398)."""
         p4 = batch["p4"]
-        self.p4.copy_(p4.to(self.p4.dtype) * self.encoder.scale if self.encoder.scale != 1.0 else p4)
+        if tuple(p4.shape) != tuple(self.p4.shape):
+            raise ValueError(f"NativeTrainStep was built for batches of shape {tuple(self.p4.shape)}, got {tuple(p4.shape)} "
+                             "(static buffers / captured graph: pad or drop the last short batch)")
+        if self.target is not self.p4:
+            self.target.copy_(p4)
+            torch.mul(self.target, self.encoder.scale, out=self.p4)
+        else:
+            self.p4.copy_(p4)
         for key in ("labels", "masks", "mask"):
             if key in batch:
+                if tuple(batch[key].shape) != tuple(self.mask.shape):
+                    raise ValueError(f"mask shape {tuple(batch[key].shape)} != {tuple(self.mask.shape)}")
                 self.mask.copy_(batch[key].to(torch.uint8))
                 break
         else:
@@ -263,7 +279,7 @@ class NativeTrainStep:
             self._g1.replay()
         else:
             self._fwd_bwd()
-        if self.world > 1:      # ONE collective per step: gradients and the per-jet loss terms share a buffer
+        if self.collective:     # ONE collective per step: gradients and the per-jet loss terms share a buffer
             dist.all_reduce(self.flat.grad_buf, op=dist.ReduceOp.SUM, group=self.group)
         if self.use_graph:
             if self._g2 is not None:

@@ -43,9 +43,79 @@ def _rand_level_params(O, C, CO, decoder, g):
 
 @pytest.mark.parametrize("decoder", [False, True])
 @pytest.mark.parametrize("C,CO,N,B", [(3, 3, 30, 3), (3, 4, 30, 2), (4, 4, 30, 2), (4, 3, 30, 2), (4, 4, 7, 2),
-                                      (2, 5, 33, 2), (4, 4, 70, 1), (1, 1, 1, 1)])
+                                      (2, 5, 33, 2), (4, 4, 70, 1), (1, 1, 1, 1),
+                                      (4, 4, 48, 2), (3, 4, 50, 1), (4, 3, 41, 2), (2, 2, 63, 1)])   # 40 < N < 64
 def test_level_fwd_bwd(dev, O, decoder, C, CO, N, B):
+    """N <= 40: one-kernel backward (level_bwd3); 40 < N < 64: three-kernel backward (mix + nodes2 + rad2, four waves per
+    jet) resp. mix + separable decoder backward; N >= 64 with a small batch: the 8-wave 'wide' sweeps."""
     _level_case(dev, O, decoder, C, CO, N, B)
+
+
+@pytest.mark.parametrize("decoder", [False, True])
+@pytest.mark.parametrize("C,CO,N,B", [(4, 4, 30, 2), (3, 4, 30, 3), (4, 3, 7, 1), (2, 5, 33, 2)])
+def test_level_three_kernel_backward_small_jets(dev, O, monkeypatch, decoder, C, CO, N, B):
+    """LGN_AMD_LEVEL_V2=1 (read per call) forces the three-kernel backward of large jets onto small ones."""
+    monkeypatch.setenv("LGN_AMD_LEVEL_V2", "1")
+    _level_case(dev, O, decoder, C, CO, N, B)
+
+
+@pytest.mark.parametrize("decoder", [False, True])
+def test_level_large_batch_of_large_jets_matches_single_jet(dev, O, decoder):
+    """N >= 64 with B > 320 takes the non-'wide' launch shapes (4-wave sweeps, chunked forward under the 78 KB budget);
+    the oracle cannot hold such a batch, so the property used is batch independence: jets 0, 137 and 329 of a B = 330,
+    N = 70 batch must equal the same jets computed in batches of their own (B = 1: the 'wide' path, which the oracle
+    pins in test_level_fwd_bwd), forward and input/position gradients; parameter gradients must be the sum over jets
+    (checked on a B = 322 batch made of two copies of a 161-jet batch: exactly twice its gradients)."""
+    from lgn import _native as Nn
+    C, CO, N, B = 4, 4, 70, 330
+    g = torch.Generator().manual_seed(7 + int(decoder))
+    cfg, plans, P = _rand_level_params(O, C, CO, decoder, g)
+    pre = "rad_funcs.rad_funcs.0."
+    names = ["a", "b", "c", "linear.0.weight", "linear.0.bias", "linear.1.weight", "linear.1.bias"]
+    rad = tuple(P[pre + n].to(dev).contiguous() for n in names)
+    if decoder:
+        rad = (None, None, None, None, rad[4], None, rad[6])
+    wm0 = P["lgn_cg.node_levels.0.cat_mix.mix_reps.weights.(0, 0)"].to(dev).contiguous()
+    wm1 = P["lgn_cg.node_levels.0.cat_mix.mix_reps.weights.(1, 1)"].to(dev).contiguous()
+
+    def run(s, v, p, mask, gs, gv):
+        ag0, ag1, so, vo = Nn.level_fwd(decoder, s, v, p, mask, rad, wm0, wm1)
+        g_p = torch.zeros_like(p) if decoder else None
+        g_s, g_v, g_w0, g_w1, rg = Nn.level_bwd(decoder, s, v, p, mask, rad, wm0, wm1, ag0, ag1, gs, gv, g_p)
+        return so, vo, g_s, g_v, g_p, g_w0, g_w1, rg
+
+    def batch(Bn, seed):
+        gg = torch.Generator().manual_seed(seed)
+        s = torch.randn(2, Bn, N, C, dtype=torch.float64, generator=gg).to(dev)
+        v = torch.randn(2, Bn, N, C, 4, dtype=torch.float64, generator=gg).to(dev)
+        gs = torch.randn(2, Bn, N, CO, dtype=torch.float64, generator=gg).to(dev)
+        gv = torch.randn(2, Bn, N, CO, 4, dtype=torch.float64, generator=gg).to(dev)
+        if decoder:
+            p, mask = torch.randn(2, Bn, N, 4, dtype=torch.float64, generator=gg).to(dev), None
+        else:
+            p4, labels = O.synthetic_jets(Bn, N, seed=seed, pad=True)
+            p, mask = p4.to(dev), labels.to(dev)
+        return s, v, p, mask, gs, gv
+
+    s, v, p, mask, gs, gv = batch(B, 3)
+    big = run(s, v, p, mask, gs, gv)
+    for k in (0, 137, 329):
+        sl = slice(k, k + 1)
+        one = run(s[:, sl].contiguous(), v[:, sl].contiguous(), (p[:, sl] if decoder else p[sl]).contiguous(),
+                  None if decoder else mask[sl].contiguous(), gs[:, sl].contiguous(), gv[:, sl].contiguous())
+        for i, what in enumerate(("s_out", "v_out", "g_s_in", "g_v_in")):
+            U.assert_close(big[i][:, sl], one[i], 1e-12, f"jet {k} {what}")
+        if decoder:
+            U.assert_close(big[4][:, sl], one[4], 1e-12, f"jet {k} g_p")
+    half = batch(161, 5)
+    bdim = (1, 1, 1 if decoder else 0, 0, 1, 1)            # batch axis of (s, v, p, mask, gs, gv)
+    dbl = tuple(None if t is None else torch.cat([t, t], ax).contiguous() for t, ax in zip(half, bdim))
+    r1, r2 = run(*half), run(*dbl)
+    U.assert_close(r2[5], 2 * r1[5], 1e-11, "g_wm0 additivity")
+    U.assert_close(r2[6], 2 * r1[6], 1e-11, "g_wm1 additivity")
+    for a, b in zip(r2[7], r1[7]):
+        if b.abs().max() > 0:
+            U.assert_close(a, 2 * b, 1e-10, "radial gradient additivity")
 
 
 @pytest.mark.parametrize("C,CO,N,B", [(4, 4, 30, 2), (3, 4, 30, 2), (4, 3, 7, 1), (4, 4, 70, 1)])
@@ -233,11 +303,15 @@ def test_generic_level_fwd_bwd(dev, O, decoder, maxdim, full, C, CO, N, B):
 
 @pytest.mark.parametrize("name", ["g1_e2e_maxdim2.npz", "g3_e2e_n150.npz", "g2_e2e_maxdim3.npz", "g6_e2e_mix.npz",
                                   "g7_e2e_meanmax.npz"])
-def test_end_to_end_vs_reference_golden(dev, O, name):
-    """Full encoder -> decoder -> Chamfer forward/backward against vectors captured from the reference."""
+@pytest.mark.parametrize("fused", [True, False])
+def test_end_to_end_vs_reference_golden(dev, O, name, fused):
+    """Full encoder -> decoder -> Chamfer forward/backward against vectors captured from the reference, through the
+    module API: ``fused`` = one native call per network and direction (lgn_encoder_* / lgn_decoder_*, taken when the
+    configuration allows it), else one native call per operator under autograd."""
     z = U.load(name)
     m = U.meta(z)
     enc, dec = _build(m, dev)
+    enc.use_fused = dec.use_fused = fused
     # same seed => same initial weights as the reference; load the fixture weights anyway (checkpoint path)
     enc.load_state_dict({k: v for k, v in U.params_from(z, "enc").items()})
     dec.load_state_dict({k: v for k, v in U.params_from(z, "dec").items()})
@@ -259,9 +333,9 @@ def test_end_to_end_vs_reference_golden(dev, O, name):
     U.assert_close(loss, z["loss_chamfer"], FWD_TOL, "chamfer")
     loss.backward()
     for pre, mod in (("enc", enc), ("dec", dec)):
-        for k, p in mod.named_parameters():
+        assert [n for n, _ in mod.named_parameters()] == ["flat_params"]
+        for k, got in mod.named_grads():
             ref = torch.from_numpy(z[f"grad.{pre}.{k}"])
-            got = p.grad if p.grad is not None else torch.zeros_like(p)
             if ref.abs().max() == 0:
                 assert got.abs().max() == 0, f"{pre}.{k} must have exactly zero gradient"
             else:

@@ -25,9 +25,9 @@ def test_train_step_matches_reference_golden():
     lam = m["l1_lambda"]
     for pre, mod in (("enc", enc), ("dec", dec)):
         sd = U.params_from(z, pre)
-        for k, p in mod.named_parameters():
+        for k, g in mod.named_grads():
             ref = torch.from_numpy(z[f"grad.{pre}.{k}"]) + lam * torch.sign(sd[k])
-            U.assert_close(p.grad, ref, 1e-9, f"grad {pre}.{k}")
+            U.assert_close(g, ref, 1e-9, f"grad {pre}.{k}")
     # a second call starts from zeroed gradients (flat buffer), same result
     total2, _ = step.forward_backward(batch)
     assert float(total2) == float(total)
@@ -60,11 +60,11 @@ def test_native_step_matches_reference_golden(name, use_graph):
     lam = m["l1_lambda"]
     for pre, mod in (("enc", enc), ("dec", dec)):
         sd = U.params_from(z, pre)
-        for k, p in mod.named_parameters():
+        for k, g in mod.named_grads():
             ref = torch.from_numpy(z[f"grad.{pre}.{k}"]) + lam * torch.sign(sd[k])
-            U.assert_close(p.grad, ref, 1e-9, f"grad {pre}.{k}")
+            U.assert_close(g, ref, 1e-9, f"grad {pre}.{k}")
             if z[f"grad.{pre}.{k}"].max() == 0 and z[f"grad.{pre}.{k}"].min() == 0:
-                assert torch.equal(p.grad.cpu(), lam * torch.sign(sd[k])), f"{pre}.{k}: dead parameter must get exactly the L1 term"
+                assert torch.equal(g.cpu(), lam * torch.sign(sd[k])), f"{pre}.{k}: dead parameter must get exactly the L1 term"
 
 
 def test_native_adam_matches_torch_adam_and_modular_path():
@@ -132,3 +132,77 @@ def test_native_step_two_ranks_match_single_process(tmp_path):
         U.assert_close(z["params"].to(dev), ref.flat.flat.detach(), 1e-9, f"rank {r} parameters after {steps} steps")
         for a, b in zip(z["losses"], ref_losses):
             assert abs(a - b) <= 1e-10 * max(1.0, abs(b)), (z["losses"], ref_losses)
+
+
+def test_native_step_scaled_input_uses_unscaled_target():
+    """--scale != 1 (lgn_encoder.py:376): only the encoder input is scaled, the reconstruction is compared with the
+    UNscaled batch (utils/train.py:285-292).  Native step vs the module/autograd harness on the same weights."""
+    import __graft_entry__ as G
+    from lgn.step import NativeTrainStep, TrainStep
+    z, m, _, _, batch = _golden_setup()
+    dev = torch.device("cuda:0")
+    nets = []
+    for _ in range(2):
+        enc, dec = G._models(m["N"], m["ch_enc"], m["ch_dec"], dev, seed=m["seed"])
+        enc.scale = 0.5
+        nets.append((enc, dec))
+    a = NativeTrainStep(*nets[0], batch_size=m["B"], optimizer=False, use_graph=True)
+    b = TrainStep(*nets[1], optimizer=False)
+    for _ in range(2):
+        la, ra = a.step(batch)
+    lb, rb = b.forward_backward(batch)
+    U.assert_close(la, lb, 1e-11, "loss (scale = 0.5)")
+    U.assert_close(ra, rb, 1e-11, "recon (scale = 0.5)")
+    U.assert_close(a.flat.grad, b.flat.grad, 1e-9, "gradients (scale = 0.5)")
+    assert abs(float(la) - float(z["loss_total"])) > 1e-6 * abs(float(z["loss_total"])), "scale must change the loss"
+    with pytest.raises(ValueError, match="static buffers"):
+        a.load_batch({"p4": batch["p4"][:1]})
+
+
+def test_native_step_rccl_collective_branch_single_rank():
+    """RCCL on the one GPU of the box: an `nccl` process group of world size 1 with ``force_collective=True`` runs the
+    two-graph + all_reduce(grad_buf) branch that data-parallel runs take; it must equal the one-graph step bit for bit
+    (a 1-rank SUM is the identity), over several optimiser steps."""
+    import socket
+    import torch.distributed as dist
+    from lgn.step import NativeTrainStep
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        z, m, enc, dec, batch = _golden_setup()
+        _, _, enc2, dec2, _ = _golden_setup()
+        a = NativeTrainStep(enc, dec, batch_size=m["B"], lr=5e-4, l1_lambda=1e-8, use_graph=True, force_collective=True)
+        b = NativeTrainStep(enc2, dec2, batch_size=m["B"], lr=5e-4, l1_lambda=1e-8, use_graph=True)
+        assert a._g2 is None and a.collective and not b.collective
+        for it in range(3):
+            la, _ = a.step(batch)
+            lb, _ = b.step(batch)
+            assert float(la) == float(lb), f"step {it}: {float(la)!r} vs {float(lb)!r}"
+        assert a._g2 is not None and b._g2 is None
+        assert torch.equal(a.flat.flat, b.flat.flat) and torch.equal(a.flat.grad_buf, b.flat.grad_buf)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_module_api_training_loop_matches_native_step():
+    """The reference's loop shape (utils/train.py:285-343): enc(batch) -> dec(latent) -> Chamfer + l1 -> backward -> two
+    torch Adams, on the fused module path (ONE flat parameter per network), against the native graph-replayed step."""
+    from lgn.step import NativeTrainStep, chamfer_loss, get_real
+    z, m, enc, dec, batch = _golden_setup()
+    _, _, enc2, dec2, _ = _golden_setup()
+    ref = NativeTrainStep(enc2, dec2, batch_size=m["B"], lr=5e-4, l1_lambda=1e-8, use_graph=True)
+    assert enc._fused_ok() and dec._fused_ok()
+    oe, od = torch.optim.Adam(enc.parameters(), 5e-4), torch.optim.Adam(dec.parameters(), 5e-4)
+    target = batch["p4"]
+    for it in range(3):
+        rec = dec(enc(batch))
+        loss = chamfer_loss(get_real(rec, "sum"), target) + 1e-8 * (enc.l1_norm() + dec.l1_norm())
+        oe.zero_grad(); od.zero_grad()
+        loss.backward()
+        oe.step(); od.step()
+        lr, _ = ref.step(batch)
+        U.assert_close(loss, lr, 1e-10, f"loss at step {it}")
+    U.assert_close(torch.cat([enc.flat_params.detach(), dec.flat_params.detach()]), ref.flat.flat, 1e-9, "parameters after 3 steps")

@@ -135,3 +135,53 @@ def test_lorentz_D_matches_reference_matrices():
     eta = torch.diag(torch.tensor([1.0, -1, -1, -1], dtype=torch.float64))
     U.assert_close(R @ eta @ R.t(), eta, 1e-13, "R eta R^T")
     assert R[0, 0].item() == pytest.approx(3.7621956910836314, rel=1e-13)
+
+
+def test_flat_parameter_block_keeps_the_reference_state_dict_surface():
+    """One flat nn.Parameter per network (lgn/models/common.py): parameters() is a single leaf, state_dict() /
+    load_state_dict() keep the reference's keys, order and strictness, views follow .to() / deepcopy / re-homing."""
+    import copy
+    import __graft_entry__ as G
+    enc, dec = G._models(30, (3, 3, 4, 4), (4, 4, 3, 3), torch.device("cpu"), seed=0)
+    for mod, n in ((enc, 34146), (dec, 29342)):
+        assert [k for k, _ in mod.named_parameters()] == ["flat_params"] and mod.flat_params.numel() == n
+        assert mod.num_learnable_parameters == n
+        sd = mod.state_dict()
+        assert sum(v.numel() for v in sd.values()) == n
+        assert all(v.untyped_storage().data_ptr() == mod.flat_params.untyped_storage().data_ptr() for v in sd.values())
+        new = {k: torch.full_like(v, float(i)) for i, (k, v) in enumerate(sd.items())}
+        mod.load_state_dict(new)
+        for i, (k, v) in enumerate(mod.named_parameter_views()):
+            assert (v == float(i)).all(), k
+        assert mod.lgn_cg.mlp_levels[1].linear[3].weight.eq(float(list(sd).index("lgn_cg.mlp_levels.1.linear.3.weight"))).all()
+        with pytest.raises(RuntimeError, match="Missing key"):
+            mod.load_state_dict({k: v for k, v in list(new.items())[1:]})
+        with pytest.raises(RuntimeError, match="Unexpected key"):
+            mod.load_state_dict(dict(new, extra=torch.zeros(1)))
+        with pytest.raises(RuntimeError, match="size mismatch"):
+            mod.load_state_dict(dict(new, **{list(new)[0]: torch.zeros(3)}))
+        twin = copy.deepcopy(mod)
+        twin.flat_params.data.zero_()
+        assert twin.input_func_node.weight((1, 1)).abs().max() == 0 and mod.input_func_node.weight((1, 1)).abs().max() > 0
+        mod.double()                                   # nn.Module._apply path: views must follow the (possibly new) storage
+        mod.flat_params.data.fill_(2.5)
+        assert (mod.rad_funcs.rad_funcs[0].a == 2.5).all()
+        assert float(mod.l1_norm()) == 2.5 * n
+        opt = torch.optim.Adam(mod.parameters(), 1e-3)   # what utils/initialize.py:156-158 builds
+        mod.l1_norm().backward()
+        opt.step()
+        assert all(g is not None and (g == 1).all() for _, g in mod.named_grads())
+        assert (mod.rad_funcs.rad_funcs[0].a < 2.5).all()
+
+
+def test_native_step_refuses_configurations_it_does_not_implement():
+    """lgn_step_fwd_bwd_f64 is the maxdim = 2 closed form; a maxdim = 3 (or non min&max) network must be refused on the
+    host instead of being read with the wrong weight layout (checked before any GPU requirement)."""
+    import __graft_entry__ as G
+    from lgn.step import NativeTrainStep
+    enc, dec = G._models(30, (4, 4, 6, 6), (6, 6, 4, 4), torch.device("cpu"), seed=0, maxdim=3)
+    with pytest.raises(NotImplementedError, match="maxdim=2"):
+        NativeTrainStep(enc, dec, batch_size=4)
+    enc, dec = G._models(12, (3, 3, 4, 4), (4, 4, 3, 3), torch.device("cpu"), seed=0, map_to_latent="mean+max")
+    with pytest.raises(NotImplementedError, match="min&max"):
+        NativeTrainStep(enc, dec, batch_size=4)
