@@ -8,13 +8,20 @@ resident in HBM: encoder -> decoder -> get_real('sum') -> Chamfer + 1e-8 L1 -> b
 (gradient all-reduce over RCCL when N > 1) -> Adam, i.e. the inner loop of the reference's
 utils/train.py:280-343.  fp64 throughout (the reference's precision).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg1|cfg2|cfg4|cfg5] [--batch B | --global-batch G]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+Scaling modes: default = WEAK (every GPU processes the config's batch, 512 jets for cfg2: `value` = N x per-GPU rate);
+``--global-batch G`` = STRONG (G jets split over the N ranks -- BASELINE's cfg3 is ``--global-batch 512`` on 8 GPUs,
+64 jets per GPU).  The mode is named in ``scaling`` and in ``config.workload``.
+
+Rank 0 prints ONE JSON line (contract in the task statement) with extra objects:
   roofline     -- dominant kernel (the fused level BACKWARD of the widest encoder level; its forward twin is reported
-                  next to it), timed live with events on the launch stream, priced with SURVEY 8(d)'s algorithmic flops
+                  next to it), timed live with events on the launch stream, priced with SURVEY 8(d)'s algorithmic flops;
+                  ``decoder_pairwise`` = the same step with the decoder levels as O(N^2) pair sweeps (SURVEY a-14)
+  module_api   -- the same step through the reference's own loop shape on the nn.Module API (enc(batch), dec(latent),
+                  torch Chamfer + l1_norm(), loss.backward(), two torch Adams): what a drop-in user gets (N=1 only)
   cpu_baseline -- the oracle (CPU restatement of the reference, materialised like the reference) timed on
                   this box's host cores on a bounded sample of the same workload (rank 0, N=1 only)
 """
@@ -32,10 +39,18 @@ for p in (ROOT, os.path.join(ROOT, "lgn-autoencoder_amd")):
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-N_PART = 30
-BATCH = 512
-CH_ENC = (3, 3, 4, 4)
-CH_DEC = (4, 4, 3, 3)
+# BASELINE.json configs (cfg3 = cfg2 sharded: --global-batch 512 under torch.distributed.run)
+CONFIGS = {
+    "cfg1": dict(B=32, N=30, ch_enc=(3, 3, 4, 4), ch_dec=(4, 4, 3, 3), maxdim=2,
+                 text="cfg1: synthetic 30-particle jets, bs=32, maxdim=2, enc 3-3-4-4 / dec 4-4-3-3"),
+    "cfg2": dict(B=512, N=30, ch_enc=(3, 3, 4, 4), ch_dec=(4, 4, 3, 3), maxdim=2,
+                 text="cfg2: synthetic 30-particle jets, bs=512, maxdim=2, enc 3-3-4-4 / dec 4-4-3-3"),
+    "cfg4": dict(B=256, N=150, ch_enc=(3, 3, 4, 4), ch_dec=(4, 4, 3, 3), maxdim=2,
+                 text="cfg4: synthetic 150-particle jets, bs=256, maxdim=2, enc 3-3-4-4 / dec 4-4-3-3"),
+    "cfg5": dict(B=512, N=30, ch_enc=(4, 4, 6, 6), ch_dec=(6, 6, 4, 4), maxdim=3,
+                 text="cfg5: synthetic 30-particle jets, bs=512, maxdim=3, enc 4-4-6-6 / dec 6-6-4-4"),
+}
+N_PART, BATCH, CH_ENC, CH_DEC = 30, 512, (3, 3, 4, 4), (4, 4, 3, 3)      # cfg2 (used by the tests' workers)
 FP64_VECTOR_PEAK_TFLOPS = 78.6     # MI355X fp64 vector == fp64 matrix peak (MI355X_MICROARCH.md: FP32 157.3 / 2)
 
 
@@ -52,7 +67,7 @@ def synthetic_jets(B, N, seed):
 
 
 def level_fwd_flops(N, C, CO, decoder):
-    """Algorithmic flops of one fused level forward per jet, SURVEY 8(d) counting rules."""
+    """Algorithmic flops of one fused maxdim=2 level forward per jet, SURVEY 8(d) counting rules."""
     edge = N * N * ((40 + 30 * C) if decoder else (25 + 120 + 160 * C + 30 * C))
     pairs_d1d2 = 4 * 1 + 4 * 4 + 1 * 1 + 1 * 4          # (11,00) (11,11) (00,00) (00,11)
     nnz = 4 + 4 + 1 + 4
@@ -62,11 +77,25 @@ def level_fwd_flops(N, C, CO, decoder):
     return edge + aggregate + power + catmix
 
 
+def _events_us(fn, reps):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record()
+    for _ in range(reps):
+        fn()
+    stop.record()
+    torch.cuda.synchronize()
+    return start.elapsed_time(stop) * 1e3 / reps
+
+
 def time_dominant_kernel(enc, batch, reps=20):
     """Average duration of the dominant kernel -- the fused BACKWARD of the widest encoder level, the largest single
     launch of the step (profiles/) -- and of the matching fused forward, measured with events on the stream they are
     launched on (torch's current stream).  Both go through the C ABI with preallocated buffers; for N <= 40 the
-    backward is ONE kernel (level_bwd3_kernel), its partial-row reductions are separate launches and not timed here."""
+    backward is ONE kernel (level_bwd3_kernel), its partial-row reductions are separate launches and not timed here.
+    (maxdim = 2 levels only.)"""
     import ctypes as C
     from lgn import _native as Nn
     lvl = max(range(enc.num_cg_levels), key=lambda l: enc.num_channels[l] * enc.num_channels[l + 1])
@@ -82,20 +111,8 @@ def time_dominant_kernel(enc, batch, reps=20):
     p = batch["p4"].to(dev).contiguous()
     mask = batch["labels"].to(dev).contiguous()
 
-    def timed(fn):
-        for _ in range(3):
-            fn()
-        torch.cuda.synchronize()
-        start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        start.record()
-        for _ in range(reps):
-            fn()
-        stop.record()
-        torch.cuda.synchronize()
-        return start.elapsed_time(stop) * 1e3 / reps
-
     # forward (the loop also allocates 4 output tensors per call from torch's caching allocator: no device sync)
-    us_fwd = timed(lambda: Nn.level_fwd(False, s, v, p, mask, rad, wm0, wm1))
+    us_fwd = _events_us(lambda: Nn.level_fwd(False, s, v, p, mask, rad, wm0, wm1), reps)
     ag0, ag1, so, vo = Nn.level_fwd(False, s, v, p, mask, rad, wm0, wm1)
     gs = torch.randn(so.shape, dtype=torch.float64, generator=g).to(dev)
     gv = torch.randn(vo.shape, dtype=torch.float64, generator=g).to(dev)
@@ -115,47 +132,103 @@ def time_dominant_kernel(enc, batch, reps=20):
                                  P(part_mix), P(part_rad), Nn.stream_ptr())
         Nn._check(rc, "lgn_level_bwd_f64")
 
-    us_bwd = timed(bwd)
+    us_bwd = _events_us(bwd, reps)
     fwd_flops = B * level_fwd_flops(N, Cc, CO, False)
     single = N <= 40
-    return {"kernel": f"level_bwd3_kernel<{Cc}, false, false>" if single else "level_bwd (nodes2 + rad2 + mix kernels)",
+    return {"kernel": f"level_bwd3_kernel<{Cc}, false, false>" if single else "level_bwd (mix + nodes2 + rad2 kernels)",
             "level": lvl, "us": us_bwd, "flops": 2 * fwd_flops,          # backward = 2 x forward
             "forward": {"kernel": f"level_fwd2_kernel<{Cc}, false, false>", "us": us_fwd, "flops": fwd_flops}}
 
 
-def cpu_baseline(seconds_budget=25.0):
-    """Oracle (port of the reference's CPU path) on the host cores, bounded sample of the same workload."""
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(cfg, seconds_budget=28.0):
+    """Oracle (port of the reference's CPU path, same op sequence and materialised temporaries) on the host cores, on a
+    BOUNDED sample of the same workload: a few steps at bs=32 (anomaly detection off, and on as main.py:420 runs it) and,
+    for 30-particle configs, one step at the full bs=512 (peak RSS ~7.4 GB).  `value` = the fastest of
+    the anomaly-off figures (i.e. the most favourable one for the CPU)."""
     from oracle import lgn_oracle as O
     # the GPU box gives one GPU a share of 16 host cores; more threads only add contention on these small ops
     ncores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(ncores)
-    ce = O.NetConfig(num_particles=N_PART, num_channels=CH_ENC)
-    cd = O.NetConfig(num_particles=N_PART, num_channels=CH_DEC)
+    N, maxdim = cfg["N"], cfg["maxdim"]
+    ce = O.NetConfig(num_particles=N, num_channels=cfg["ch_enc"], maxdim=maxdim)
+    cd = O.NetConfig(num_particles=N, num_channels=cfg["ch_dec"], maxdim=maxdim)
     torch.manual_seed(0)
     Pe = {k: v.requires_grad_(True) for k, v in O.init_encoder_params(ce).items()}
     Pd = {k: v.requires_grad_(True) for k, v in O.init_decoder_params(cd, (2, 16)).items()}
-    bs = 32
-    p4, labels = synthetic_jets(bs, N_PART, seed=0)
 
-    def one():
-        for P in (Pe, Pd):
-            for v in P.values():
-                v.grad = None
-        loss, _ = O.autoencoder_loss(Pe, Pd, ce, cd, p4, labels, l1_lambda=1e-8)
-        loss.backward()
+    def timed(bs, budget, max_steps, warm):
+        p4, labels = synthetic_jets(bs, N, seed=0)
 
-    tw = time.perf_counter()
-    one()                                   # warm-up (allocator, CG tables)
-    tw = time.perf_counter() - tw
-    t0 = time.perf_counter(); n = 0
-    while True:
-        one(); n += 1
-        if time.perf_counter() - t0 + tw > seconds_budget or n >= 16:
-            break
-    dt = time.perf_counter() - t0
-    return {"value": bs * n / dt, "unit": "jets/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} fwd+bwd steps of bs={bs}, N={N_PART}, maxdim=2, fp64, oracle/lgn_oracle.py (materialised "
-                      f"restatement of the reference CPU path), {dt:.1f}s"}
+        def one():
+            for P in (Pe, Pd):
+                for v in P.values():
+                    v.grad = None
+            loss, _ = O.autoencoder_loss(Pe, Pd, ce, cd, p4, labels, l1_lambda=1e-8)
+            loss.backward()
+        if warm:
+            one()                            # allocator, CG tables
+        t0 = time.perf_counter(); n = 0
+        while True:
+            one(); n += 1
+            if time.perf_counter() - t0 > budget or n >= max_steps:
+                break
+        dt = time.perf_counter() - t0
+        return bs * n / dt, n, dt
+
+    small = 32 if N <= 40 else 4            # N=150: bs=16 already needs 5.7 GB and ~13 s per step (SURVEY section 6)
+    t_all = time.perf_counter()
+    r_small, n_small, dt_small = timed(small, seconds_budget * 0.3, 16, warm=True)
+    with torch.autograd.set_detect_anomaly(True):
+        r_anom, n_anom, dt_anom = timed(small, seconds_budget * 0.15, 4, warm=False)
+    out = {"unit": "jets/s", "cores": torch.get_num_threads(), "cpu_model": _cpu_model(), "kind": "port",
+           "anomaly_off": {"value": r_small, "batch": small, "steps": n_small, "seconds": dt_small},
+           "anomaly_on": {"value": r_anom, "batch": small, "steps": n_anom, "seconds": dt_anom,
+                          "note": "torch.autograd.set_detect_anomaly(True), as main.py:420 / test.py:374 run"}}
+    best = r_small
+    sample = f"{n_small} fwd+bwd steps of bs={small}"
+    if N <= 40 and cfg["B"] >= 512 and time.perf_counter() - t_all < seconds_budget * 0.6:
+        r_full, n_full, dt_full = timed(cfg["B"], 0.0, 1, warm=False)
+        out["full_batch"] = {"value": r_full, "batch": cfg["B"], "steps": n_full, "seconds": dt_full}
+        sample += f" and {n_full} step of bs={cfg['B']}"
+        best = max(best, r_full)
+    else:
+        out["full_batch"] = None
+        out["full_batch_note"] = ("not run: at N=150 the reference-style materialised temporaries need ~90 GB at bs=256"
+                                  if N > 40 else "not run (time budget)")
+    out["value"] = best
+    out["sample"] = (f"{sample}, N={N}, maxdim={maxdim}, fp64, oracle/lgn_oracle.py (materialised restatement of the "
+                     f"reference CPU path), {time.perf_counter() - t_all:.1f}s in total; value = best anomaly-off rate")
+    return out
+
+
+def _time_steps(trainer, batch, steps, warmup, world):
+    for _ in range(warmup):
+        trainer.step(batch)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss, _ = trainer.step(batch)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    assert torch.isfinite(loss).item(), "non-finite loss"
+    return elapsed
 
 
 def main():
@@ -163,11 +236,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=BATCH, help="jets per GPU (default: BASELINE cfg2)")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg2", help="BASELINE.json configuration (default cfg2)")
+    ap.add_argument("--batch", type=int, default=None, help="jets per GPU (weak scaling; default: the config's batch)")
+    ap.add_argument("--global-batch", type=int, default=None,
+                    help="total jets per step, split over the ranks (strong scaling; BASELINE cfg3 = --global-batch 512)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--harness", choices=["native", "native-nograph", "modular"], default="native",
-                    help="native: one C call per step replayed from a HIP graph (default); modular: nn.Module + autograd path")
+    ap.add_argument("--no-extras", action="store_true", help="skip the module_api and decoder_pairwise legs")
+    ap.add_argument("--harness", choices=["native", "native-nograph", "module", "modular"], default=None,
+                    help="native: one C call per step replayed from a HIP graph (default for maxdim=2); module: the "
+                         "reference's loop on the nn.Module API (default for cfg5 until the native step covers maxdim=3)")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -180,75 +259,105 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    import __graft_entry__ as G
-    from lgn.step import NativeTrainStep, TrainStep
-    enc, dec = G._models(N_PART, CH_ENC, CH_DEC, dev, seed=0)      # identical replicas on every rank
-    if args.harness == "modular":
-        trainer = TrainStep(enc, dec, lr=5e-4, l1_lambda=1e-8)
+    if args.global_batch is not None:
+        if args.batch is not None:
+            raise SystemExit("--batch and --global-batch are exclusive")
+        if args.global_batch % world:
+            raise SystemExit(f"--global-batch {args.global_batch} is not divisible by {world} ranks")
+        per_gpu, scaling = args.global_batch // world, "strong"
     else:
-        trainer = NativeTrainStep(enc, dec, batch_size=args.batch, lr=5e-4, l1_lambda=1e-8,
-                                  use_graph=args.harness == "native")
-    p4, labels = synthetic_jets(args.batch, N_PART, seed=rank)     # per-rank shard, resident in HBM
-    batch = {"p4": p4.to(dev), "labels": labels.to(dev)}
+        per_gpu, scaling = (args.batch or cfg["B"]), "weak"
+    N = cfg["N"]
+    harness = args.harness or ("native" if cfg["maxdim"] == 2 else "module")
+    harness = "module" if harness == "modular" else harness
 
-    for _ in range(args.warmup):
-        trainer.step(batch)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss, _ = trainer.step(batch)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    import __graft_entry__ as G
+    from lgn.step import NativeTrainStep, ReferenceLoopStep
+
+    def build(which):
+        enc, dec = G._models(N, cfg["ch_enc"], cfg["ch_dec"], dev, seed=0, maxdim=cfg["maxdim"])   # identical replicas on every rank
+        if which == "module":
+            return enc, ReferenceLoopStep(enc, dec, lr=5e-4, l1_lambda=1e-8)
+        return enc, NativeTrainStep(enc, dec, batch_size=per_gpu, lr=5e-4, l1_lambda=1e-8, use_graph=which == "native")
+
+    enc, trainer = build(harness)
+    p4, labels = synthetic_jets(per_gpu, N, seed=rank)     # per-rank shard, resident in HBM
+    batch = {"p4": p4.to(dev), "labels": labels.to(dev)}
+    elapsed = _time_steps(trainer, batch, args.steps, args.warmup, world)
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    assert torch.isfinite(loss).item(), "non-finite loss"
 
     if rank == 0:
-        dom = time_dominant_kernel(enc, batch)
-        achieved = dom["flops"] / (dom["us"] * 1e-6) / 1e12
-        traffic = None          # HBM bytes per launch of the dominant kernel, from the PMC passes recorded under profiles/
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_v8_traffic.json")) as fh:
-                traffic = json.load(fh).get(dom["kernel"], {}).get("hbm_bytes_per_launch")
-        except OSError:
-            pass
+        mode = (f"weak scaling: {per_gpu} jets on each of {world} GPU(s)" if scaling == "weak" else
+                f"strong scaling: {per_gpu * world} jets per step split over {world} GPU(s) = {per_gpu} per GPU")
         out = {
-            "metric": "jets/sec fwd+bwd, 30-particle maxdim=2 bs=512",
-            "value": args.batch * world * args.steps / elapsed,
+            "metric": "jets/sec fwd+bwd, 30-particle maxdim=2 bs=512" if args.config == "cfg2" else f"jets/sec fwd+bwd, {args.config}",
+            "value": per_gpu * world * args.steps / elapsed,
             "unit": "jets/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "cfg2: synthetic 30-particle jets, maxdim=2, enc 3-3-4-4 / dec 4-4-3-3, tau-latent 1s/8v, "
-                                   "min&max, chamfer + 1e-8 L1, fwd+bwd+Adam, zero-padded Nobj~U{10..30}",
-                       "jets_per_gpu": args.batch, "global_batch": args.batch * world, "particles": N_PART,
+            "config": {"workload": f"{cfg['text']}, tau-latent 1s/8v, min&max, chamfer + 1e-8 L1, fwd+bwd+Adam, zero-padded "
+                                   f"Nobj~U{{10..{N}}}; {mode}",
+                       "name": args.config, "jets_per_gpu": per_gpu, "global_batch": per_gpu * world, "particles": N,
+                       "maxdim": cfg["maxdim"],
                        "parallelism": f"dp{world}" + (" (one RCCL all-reduce of the flat gradient per step)" if world > 1 else ""),
-                       "harness": args.harness},
-            "roofline": {"bound": "mfma", "pipe": "fp64 vector ALU (same peak as fp64 MFMA on MI355X; the kernel is "
-                                                   "FMA-bound, neither HBM- nor matrix-core-bound)",
-                         "kernel": dom["kernel"], "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic,
-                         "traffic_note": "bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction), separate rocprofv3 "
-                                         "--pmc passes recorded in profiles/r01_v8_traffic.json; 0.5 TB/s, HBM is not the bound",
-                         "us_per_launch": dom["us"], "algorithmic_flops_per_launch": dom["flops"],
-                         "forward_kernel": {"kernel": dom["forward"]["kernel"], "us_per_launch": dom["forward"]["us"],
-                                            "algorithmic_flops_per_launch": dom["forward"]["flops"],
-                                            "achieved": dom["forward"]["flops"] / (dom["forward"]["us"] * 1e-6) / 1e12,
-                                            "frac": dom["forward"]["flops"] / (dom["forward"]["us"] * 1e-6) / 1e12 / FP64_VECTOR_PEAK_TFLOPS},
-                         "note": "the decoder levels run the separable O(N C) form (SURVEY a-14: an algorithmic change, "
-                                 "not counted as roofline gain); this kernel is an encoder level and is unaffected"},
+                       "harness": {"native": "NativeTrainStep: lgn_step_fwd_bwd_f64 + lgn_step_finalize_f64 replayed from a HIP graph",
+                                   "native-nograph": "NativeTrainStep without graph capture",
+                                   "module": "ReferenceLoopStep: reference loop on the nn.Module API"}[harness]},
         }
+        if cfg["maxdim"] == 2:
+            dom = time_dominant_kernel(enc, batch)
+            achieved = dom["flops"] / (dom["us"] * 1e-6) / 1e12
+            traffic = None          # HBM bytes per launch of the dominant kernel, from the PMC passes recorded under profiles/
+            if args.config == "cfg2" and per_gpu == 512:
+                try:
+                    with open(os.path.join(ROOT, "profiles", "r01_v8_traffic.json")) as fh:
+                        traffic = json.load(fh).get(dom["kernel"], {}).get("hbm_bytes_per_launch")
+                except OSError:
+                    pass
+            fw = dom["forward"]
+            out["roofline"] = {
+                "bound": "mfma", "pipe": "fp64 vector ALU (same peak as fp64 MFMA on MI355X; the kernel is "
+                                         "FMA-bound, neither HBM- nor matrix-core-bound)",
+                "kernel": dom["kernel"], "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic,
+                "traffic_note": "bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction; an ESTIMATE: the guide "
+                                "calibrates the x2 on 16 B/lane loads, this kernel issues 8 B/lane), separate rocprofv3 "
+                                "--pmc passes recorded in profiles/r01_v8_traffic.json; 0.5 TB/s, HBM is not the bound",
+                "us_per_launch": dom["us"], "algorithmic_flops_per_launch": dom["flops"],
+                "forward_kernel": {"kernel": fw["kernel"], "us_per_launch": fw["us"], "algorithmic_flops_per_launch": fw["flops"],
+                                   "achieved": fw["flops"] / (fw["us"] * 1e-6) / 1e12,
+                                   "frac": fw["flops"] / (fw["us"] * 1e-6) / 1e12 / FP64_VECTOR_PEAK_TFLOPS},
+                "note": "the decoder levels run the separable O(N C) form (SURVEY a-14: an algorithmic change, "
+                        "not counted as roofline gain); this kernel is an encoder level and is unaffected"}
+        if world == 1 and not args.no_extras and cfg["maxdim"] == 2:
+            if harness != "module":
+                del trainer
+                _, mod = build("module")
+                e2 = _time_steps(mod, batch, args.steps, args.warmup, 1)
+                out["module_api"] = {"value": per_gpu * args.steps / e2, "unit": "jets/s", "ms_per_step": 1e3 * e2 / args.steps,
+                                     "harness": "ReferenceLoopStep (lgn/step.py): enc(batch) -> dec(latent) -> torch Chamfer + "
+                                                "l1_norm() -> loss.backward() -> 2 x torch.optim.Adam, fused whole-network "
+                                                "native calls under autograd, no graph capture"}
+                del mod
+            if harness == "native" and "roofline" in out:
+                os.environ["LGN_AMD_DEC_PAIRWISE"] = "1"
+                try:
+                    _, pw = build("native")
+                    e3 = _time_steps(pw, batch, args.steps, args.warmup, 1)
+                    out["roofline"]["decoder_pairwise"] = {
+                        "value": per_gpu * args.steps / e3, "unit": "jets/s", "ms_per_step": 1e3 * e3 / args.steps,
+                        "note": "same step with LGN_AMD_DEC_PAIRWISE=1: decoder levels as O(N^2) pair sweeps, the reference's "
+                                "formulation whose flops SURVEY 8(d) counts"}
+                    del pw
+                finally:
+                    del os.environ["LGN_AMD_DEC_PAIRWISE"]
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

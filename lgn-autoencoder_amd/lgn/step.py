@@ -119,6 +119,43 @@ class TrainStep:
         return total, recon
 
 
+class ReferenceLoopStep:
+    """The reference's inner loop, line for line in shape (utils/train.py:283-343, utils/initialize.py:153-158), on
+    the module API: ``latent = encoder(batch)``, ``recon = decoder(latent)``, ``ChamferLoss(get_real(recon), p4) +
+    l1_lambda * (encoder.l1_norm() + decoder.l1_norm())``, ``zero_grad`` x 2, ``loss.backward()``, two ``torch.optim.Adam``.
+    Nothing is re-homed or captured: this is what a user who only swaps the ``lgn`` package gets.  Under data
+    parallelism the two flat gradients are all-reduced (SUM) and the L1 term is weighted 1/world per rank."""
+
+    def __init__(self, encoder, decoder, lr: float = 5e-4, l1_lambda: float = 1e-8, get_real_method: str = "sum",
+                 process_group=None, optimizer: bool = True):
+        self.encoder, self.decoder = encoder, decoder
+        self.l1_lambda, self.get_real_method = l1_lambda, get_real_method
+        self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        self.group = process_group
+        self.opt_enc = torch.optim.Adam(encoder.parameters(), lr) if optimizer else None
+        self.opt_dec = torch.optim.Adam(decoder.parameters(), lr) if optimizer else None
+
+    def step(self, batch):
+        latent = self.encoder(batch)
+        recon = self.decoder(latent)
+        real = get_real(recon, self.get_real_method)
+        target = batch["p4"].to(device=real.device, dtype=real.dtype)
+        chamfer = chamfer_loss(real, target)
+        l1 = self.encoder.l1_norm() + self.decoder.l1_norm()
+        loss = chamfer + (self.l1_lambda / self.world) * l1
+        for m in (self.encoder, self.decoder):
+            m.zero_grad(set_to_none=True)
+        loss.backward()
+        if self.world > 1:
+            for m in (self.encoder, self.decoder):
+                for p in m.parameters():
+                    dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=self.group)
+        if self.opt_enc is not None:
+            self.opt_enc.step()
+            self.opt_dec.step()
+        return (chamfer + self.l1_lambda * l1).detach(), recon
+
+
 # ---------------------------------------------------------------------------------------------------
 # fully native step: one C call for encoder -> decoder -> loss -> backward, captured in a HIP graph
 # ---------------------------------------------------------------------------------------------------
