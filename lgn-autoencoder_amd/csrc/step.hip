@@ -396,19 +396,19 @@ NetScratch carve_scratch(const lgn_net_desc& d, bool dec, double* base) {
   const int* ch = dec ? d.dec_channels : d.enc_channels;
   int cmax = 0;
   for (int l = 0; l <= L; ++l) cmax = cmax > ch[l] ? cmax : ch[l];
-  for (int q = 0; q < 2; ++q) {
-    w.gs[q] = b.take(2 * BN * cmax);
-    w.gv[q] = b.take(8 * BN * cmax);
-  }
-  w.gsmix = b.take(2 * BN * cmax);
-  w.g_ag = b.take(20 * BN * cmax);
-  {
+  {  // zero-initialised block FIRST: a caller that places `grads` right in front of the scratch gets one memset for both
     const size_t z0 = b.off;
     w.zeros_s = b.take(2 * BN * cmax);
     w.g_p = b.take(dec ? 8 * BN : 0);
     w.g_lat_s = b.take(dec ? 0 : (size_t)2 * d.B * 2 * Ts);
     w.zero_doubles = b.off - z0;
   }
+  for (int q = 0; q < 2; ++q) {
+    w.gs[q] = b.take(2 * BN * cmax);
+    w.gv[q] = b.take(8 * BN * cmax);
+  }
+  w.gsmix = b.take(2 * BN * cmax);
+  w.g_ag = b.take(20 * BN * cmax);
   size_t psum = 0;
   for (int l = 0; l < L; ++l) {
     int rm, rr;
@@ -426,6 +426,17 @@ NetScratch carve_scratch(const lgn_net_desc& d, bool dec, double* base) {
   w.parts_size = psum;
   s.total = b.off;
   return s;
+}
+
+// grads [n] and the zero block [nz]: one memset when the caller laid them out back to back (lgn/ops.py does)
+int zero_grads_and_block(double* grads, size_t n, double* zeros, size_t nz, hipStream_t st) {
+  if (zeros >= grads + n && zeros <= grads + n + 16) {
+    HIPOK(hipMemsetAsync(grads, 0, sizeof(double) * (size_t)((zeros + nz) - grads), st));
+  } else {
+    HIPOK(hipMemsetAsync(grads, 0, sizeof(double) * n, st));
+    HIPOK(hipMemsetAsync(zeros, 0, sizeof(double) * nz, st));
+  }
+  return 0;
 }
 
 int check_mlp_contiguous(const lgn_net_desc& d, bool dec, const int64_t* off) {
@@ -487,8 +498,7 @@ int lgn_encoder_bwd_f64(const lgn_net_desc* d, const double* params, double* gra
   const Slots S{d->n_levels, d->mlp_nlin};
   const int L = d->n_levels, B = d->B, N = d->N, Ts = d->tau_s, Tv = d->tau_v;
   const int* ce = d->enc_channels;
-  HIPOK(hipMemsetAsync(grads, 0, sizeof(double) * (size_t)n_params, st));
-  HIPOK(hipMemsetAsync(w.zeros_s, 0, sizeof(double) * w.zero_doubles, st));
+  LGN_TRY(zero_grads_and_block(grads, (size_t)n_params, w.zeros_s, w.zero_doubles, st));
   Deferred dq;
   dq.parts = w.parts;
   dq.cap = w.parts_size;
@@ -548,8 +558,7 @@ int lgn_decoder_bwd_f64(const lgn_net_desc* d, const double* params, double* gra
   const Slots S{d->n_levels, d->mlp_nlin};
   const int L = d->n_levels, B = d->B, N = d->N, Tin = d->tau_v_in > 0 ? d->tau_v_in : 2 * d->tau_v;
   const int* cd = d->dec_channels;
-  HIPOK(hipMemsetAsync(grads, 0, sizeof(double) * (size_t)n_params, st));
-  HIPOK(hipMemsetAsync(w.zeros_s, 0, sizeof(double) * w.zero_doubles, st));
+  LGN_TRY(zero_grads_and_block(grads, (size_t)n_params, w.zeros_s, w.zero_doubles, st));
   Deferred dq;
   dq.parts = w.parts;
   dq.cap = w.parts_size;

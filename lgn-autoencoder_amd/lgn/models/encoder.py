@@ -139,10 +139,12 @@ class LGNEncoder(CGModule, LevelTablesMixin):
             data = {"p4": data}
         elif isinstance(data, np.ndarray):
             data = {"p4": torch.from_numpy(data)}
-        node_ps = data["p4"].to(device=self.device, dtype=self.dtype) * self.scale
+        node_ps = data["p4"].to(device=self.device, dtype=self.dtype)
+        if self.scale != 1.0:
+            node_ps = node_ps * self.scale
         for key in ("labels", "masks", "mask"):
             if key in data:
-                node_mask = data[key].to(device=self.device).to(torch.uint8)
+                node_mask = data[key].to(device=self.device, dtype=torch.uint8)
                 break
         else:
             node_mask = (data["p4"][..., 0] != 0).to(device=self.device, dtype=torch.uint8)

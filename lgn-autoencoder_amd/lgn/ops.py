@@ -302,41 +302,49 @@ def net_handle(net, decoder: bool, B: int) -> NetHandle:
     return h
 
 
+def _r16(n: int) -> int:
+    return (n + 15) & ~15
+
+
 class EncoderFn(torch.autograd.Function):
     """LGNEncoder.forward (lgn/models/lgn_encoder.py:255-336; 'min&max' pooling) as ONE native call, and the backward
-    autograd would run through it as one more.  args: net, p4 (B,N,4) already scaled, mask (B,N) uint8, flat_params."""
+    autograd would run through it as one more.  args: net, p4 (B,N,4) already scaled, mask (B,N) uint8, flat_params.
+    One allocation per direction: forward = [latent scalars | latent vectors | activations kept for the backward],
+    backward = [parameter gradients | scratch] (the native call zero-fills gradients + its zero block with one memset)."""
 
     @staticmethod
     def forward(ctx, net, p4, mask, flat):
         B = p4.shape[0]
         h = net_handle(net, False, B)
-        dev, dt = flat.device, flat.dtype
         Ts, Tv = h.desc.tau_s, h.desc.tau_v
-        act = torch.empty(h.n_act, device=dev, dtype=dt)
-        lat_s = torch.empty(2, B, 1, 2 * Ts, 1, device=dev, dtype=dt)
-        lat_v = torch.empty(2, B, 1, 2 * Tv, 4, device=dev, dtype=dt)
-        flat_d = flat.detach()
-        rc = N.lib().lgn_encoder_fwd_f64(h.ref, N.ptr(flat_d), h.off, N.ptr(p4), N.ptr(mask), N.ptr(act), h.n_act,
-                                         N.ptr(lat_s), N.ptr(lat_v), N.stream_ptr())
+        ns, nv = _r16(4 * B * Ts), _r16(16 * B * Tv)
+        buf = torch.empty(ns + nv + h.n_act, device=flat.device, dtype=flat.dtype)
+        lat_s = buf[:4 * B * Ts].view(2, B, 1, 2 * Ts, 1)
+        lat_v = buf[ns:ns + 16 * B * Tv].view(2, B, 1, 2 * Tv, 4)
+        base = buf.data_ptr()
+        rc = N.lib().lgn_encoder_fwd_f64(h.ref, flat.data_ptr(), h.off, N.ptr(p4), N.ptr(mask), base + 8 * (ns + nv), h.n_act,
+                                         base, base + 8 * ns, N.stream_ptr())
         N._check(rc, "lgn_encoder_fwd_f64")
-        ctx.h = h
-        ctx.save_for_backward(p4, mask, flat, act)
+        ctx.h, ctx.act_off = h, ns + nv
+        ctx.save_for_backward(p4, mask, flat, buf)
         ctx.set_materialize_grads(False)
         return lat_s, lat_v
 
     @staticmethod
     def backward(ctx, g_s, g_v):
-        p4, mask, flat, act = ctx.saved_tensors
+        p4, mask, flat, buf = ctx.saved_tensors
         h = ctx.h
-        grads = torch.empty_like(flat)
+        npar = _r16(h.n_params)
+        out = torch.empty(npar + h.n_scratch, device=flat.device, dtype=flat.dtype)
+        grads = out[:h.n_params]
         if g_v is None:
             if g_s is None:
                 return None, None, None, grads.zero_()
             g_v = torch.zeros(2, h.desc.B, 1, 2 * h.desc.tau_v, 4, device=flat.device, dtype=flat.dtype)
-        scratch = torch.empty(h.n_scratch, device=flat.device, dtype=flat.dtype)
-        rc = N.lib().lgn_encoder_bwd_f64(h.ref, N.ptr(flat.detach()), N.ptr(grads), h.n_params, h.off, N.ptr(p4), N.ptr(mask),
-                                         N.ptr(act), h.n_act, N.ptr(None if g_s is None else N.f64(g_s)), N.ptr(N.f64(g_v)),
-                                         N.ptr(scratch), h.n_scratch, N.stream_ptr())
+        base = out.data_ptr()
+        rc = N.lib().lgn_encoder_bwd_f64(h.ref, flat.data_ptr(), base, h.n_params, h.off, N.ptr(p4), N.ptr(mask),
+                                         buf.data_ptr() + 8 * ctx.act_off, h.n_act, N.ptr(None if g_s is None else N.f64(g_s)),
+                                         N.ptr(N.f64(g_v)), base + 8 * npar, h.n_scratch, N.stream_ptr())
         N._check(rc, "lgn_encoder_bwd_f64")
         return None, None, None, grads
 
@@ -350,24 +358,42 @@ class DecoderFn(torch.autograd.Function):
         lat_v = N.f64(lat_v)
         B = lat_v.shape[1]
         h = net_handle(net, True, B)
-        dev, dt = flat.device, flat.dtype
-        act = torch.empty(h.n_act, device=dev, dtype=dt)
-        recon = torch.empty(2, B, h.desc.N, 4, device=dev, dtype=dt)
-        rc = N.lib().lgn_decoder_fwd_f64(h.ref, N.ptr(flat.detach()), h.off, N.ptr(lat_v), N.ptr(act), h.n_act, N.ptr(recon),
-                                         N.stream_ptr())
+        nr = _r16(8 * B * h.desc.N)
+        buf = torch.empty(nr + h.n_act, device=flat.device, dtype=flat.dtype)
+        recon = buf[:8 * B * h.desc.N].view(2, B, h.desc.N, 4)
+        base = buf.data_ptr()
+        rc = N.lib().lgn_decoder_fwd_f64(h.ref, flat.data_ptr(), h.off, N.ptr(lat_v), base + 8 * nr, h.n_act, base, N.stream_ptr())
         N._check(rc, "lgn_decoder_fwd_f64")
-        ctx.h = h
-        ctx.save_for_backward(lat_v, flat, act)
+        ctx.h, ctx.act_off = h, nr
+        ctx.save_for_backward(lat_v, flat, buf)
         return recon
 
     @staticmethod
     def backward(ctx, g_recon):
-        lat_v, flat, act = ctx.saved_tensors
+        lat_v, flat, buf = ctx.saved_tensors
         h = ctx.h
-        grads = torch.empty_like(flat)
-        g_lat = torch.empty_like(lat_v)
-        scratch = torch.empty(h.n_scratch, device=flat.device, dtype=flat.dtype)
-        rc = N.lib().lgn_decoder_bwd_f64(h.ref, N.ptr(flat.detach()), N.ptr(grads), h.n_params, h.off, N.ptr(lat_v), N.ptr(act),
-                                         h.n_act, N.ptr(N.f64(g_recon)), N.ptr(g_lat), N.ptr(scratch), h.n_scratch, N.stream_ptr())
+        npar, nl = _r16(h.n_params), _r16(lat_v.numel())
+        out = torch.empty(nl + npar + h.n_scratch, device=flat.device, dtype=flat.dtype)
+        g_lat = out[:lat_v.numel()].view(lat_v.shape)
+        grads = out[nl:nl + h.n_params]
+        base = out.data_ptr()
+        rc = N.lib().lgn_decoder_bwd_f64(h.ref, flat.data_ptr(), base + 8 * nl, h.n_params, h.off, N.ptr(lat_v),
+                                         buf.data_ptr() + 8 * ctx.act_off, h.n_act, N.ptr(N.f64(g_recon)), base,
+                                         base + 8 * (nl + npar), h.n_scratch, N.stream_ptr())
         N._check(rc, "lgn_decoder_bwd_f64")
         return None, g_lat, grads
+
+
+class L1Fn(torch.autograd.Function):
+    """sum |w| over a flat parameter block (CGModule.l1_norm, lgn_encoder.py:249-250): one reduction kernel forward,
+    g * sign(w) backward (torch's abs backward: sign(0) = 0)."""
+
+    @staticmethod
+    def forward(ctx, flat):
+        ctx.save_for_backward(flat)
+        return torch.linalg.vector_norm(flat.detach(), 1)
+
+    @staticmethod
+    def backward(ctx, g):
+        (flat,) = ctx.saved_tensors
+        return torch.sign(flat.detach()).mul_(g)
