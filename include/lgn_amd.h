@@ -145,7 +145,7 @@ int lgn_local_partial_rows(int nodes);
 int lgn_local_bwd_f64(int nodes, int C, int CO, int Q, int Qout, const lgn_local_tables* t, const double* X, const double* U,
                       const double* wcat, const double* g_out, double* gU, double* gX, double* part, void* stream);
 
-/* ---- whole training step, maxdim = 2 (utils/train.py:283-343 inner loop) ---------------------------
+/* ---- whole training step (utils/train.py:283-343 inner loop); fused maxdim = 2 or table-driven networks -------
  * One call enqueues encoder -> decoder -> get_real('sum') -> Chamfer -> full backward (~80 launches, no host
  * sync, all buffers caller-owned and static => capturable in a HIP graph).  Parameters of both networks
  * live in ONE flat buffer `params`; gradients are written into `grads` at the same offsets (the call zero-
@@ -165,6 +165,16 @@ typedef struct lgn_net_desc {
   int mlp_hidden_mul;      /* CGMLP hidden width = mlp_hidden_mul * 2C  (reference: mlp_width) */
   int mlp_nlin;            /* Linear layers per CGMLP (mlp_depth + 1) */
   int tau_v_in;            /* decoder: latent vectors it consumes; 0 = 2 * tau_v (the 'min&max' concatenation) */
+  /* Table-driven networks (any level with maxdim = 3): set enc_tables[l] / dec_tables[l] for EVERY level of that network
+   * (host structs holding device pointers, as for lgn_local_fwd_f64; all NULL = the fused maxdim = 2 kernels).  The level
+   * features are then the packed tensors X_l [2][B][N][C_l][Q_l] of lgn_moments_fwd_f64 / lgn_local_fwd_f64 with
+   * Q_l = *_Q[l] components per channel, the scalar irrep (0,0) at component *_qs[l] and the vector irrep (1,1) at
+   * components *_qv[l] .. +3 (l = 0 .. n_levels).  The CatMix parameter slot (.., 0) of level l is the lowest offset of the
+   * level's CatMix weights in the flat block; tables[l]->out_w0 are offsets from there (slot (.., 1) is ignored). */
+  const lgn_local_tables* enc_tables[4];
+  const lgn_local_tables* dec_tables[4];
+  int enc_Q[5], enc_qs[5], enc_qv[5];
+  int dec_Q[5], dec_qs[5], dec_qv[5];
 } lgn_net_desc;
 
 int lgn_step_param_slots(const lgn_net_desc* d, int decoder);

@@ -1,6 +1,5 @@
 // lgn-autoencoder_amd/csrc/api.hip -- extern "C" entry points declared in include/lgn_amd.h
-#include "ops.hpp"
-#include "../../include/lgn_amd.h"
+#include "net.hpp"
 
 using namespace lgn;
 
@@ -124,18 +123,6 @@ int lgn_moments_bwd_f64(int B, int N, int C, int Q, int decoder, const double* X
   a.gU = gU; a.gX = gX; a.g_p = g_p; a.part_rad = part_rad;
   if (int rc2 = moments_dispatch(a, decoder, 1, (hipStream_t)stream)) return rc2;
   return moments_dispatch(a, decoder, 2, (hipStream_t)stream);
-}
-
-static int local_args(LocalArgs& a, int nodes, int C, int CO, int Q, int Qout, const lgn_local_tables* t) {
-  LGN_CHECK_ARG(t && t->row_ptr && t->t_type && t->t_a && t->t_b && t->t_coef && t->out_dim && t->out_nblk && t->out_row0 &&
-                    t->out_q0 && t->out_w0 && t->u_ptr && t->u_row && t->u_coef && t->x_ptr && t->x_row && t->x_other && t->x_coef,
-                "local: incomplete tables");
-  LGN_CHECK_ARG(t->n_terms > 0 && t->n_u >= 0 && t->n_x >= 0, "local: table lengths missing");
-  a.nodes = nodes; a.C = C; a.CO = CO; a.Q = Q; a.Qout = Qout;
-  a.n_terms = t->n_terms; a.n_u = t->n_u; a.n_x = t->n_x;
-  a.t = LocalTables{t->n_rows, t->n_out, t->n_w, t->row_ptr, t->t_type, t->t_a, t->t_b, t->t_coef, t->out_dim, t->out_nblk,
-                    t->out_row0, t->out_q0, t->out_w0, t->u_ptr, t->u_row, t->u_coef, t->x_ptr, t->x_row, t->x_other, t->x_coef};
-  return 0;
 }
 
 int lgn_local_fwd_f64(int nodes, int C, int CO, int Q, int Qout, const lgn_local_tables* t, const double* X, const double* U,

@@ -148,6 +148,10 @@ __global__ __launch_bounds__(BLOCK) void local_fwd_kernel(LocalArgs a) {
       const size_t oe = ((size_t)node * CO + o) * Qo + q;
       a.out[oe] = acc0.r + acc1.r;
       a.out[plo + oe] = acc0.i + acc1.i;
+      if (a.s_copy && q == a.q_s) {                        // pre-MLP scalars kept for the CGMLP backward
+        a.s_copy[(size_t)node * CO + o] = acc0.r + acc1.r;
+        a.s_copy[(size_t)a.nodes * CO + (size_t)node * CO + o] = acc0.i + acc1.i;
+      }
     }
     __syncthreads();                                       // cat is rewritten by the next node; its Ul / Xl are in place
   }
@@ -332,13 +336,52 @@ __global__ __launch_bounds__(BLOCK) void local_bwd_kernel(LocalArgs a) {
       int l = 0, base = 0;
       while (l + 1 < a.t.n_out && w >= base + CO * a.t.out_nblk[l] * C) { base += CO * a.t.out_nblk[l] * C; ++l; }
       const int sz = CO * a.t.out_nblk[l] * C, rel = w - base;
-      part[2 * base + rel] = dw[k].r;            // plane 0 of irrep l
-      part[2 * base + sz + rel] = dw[k].i;       // plane 1
+      part[a.t.out_w0[l] + rel] = dw[k].r;       // plane 0 of irrep l (same offsets as the weights in wcat)
+      part[a.t.out_w0[l] + sz + rel] = dw[k].i;  // plane 1
     }
   }
 }
 
 int local_partial_rows(int nodes) { return cdiv(nodes, NODES_PER_WG); }
+
+// ---- packed <-> separate layouts at the ends of a table-driven network ---------------------------------------------
+// X [2][nodes][C][Q]  <->  s [2][nodes][C] (component q_s), v [2][nodes][C][4] (components q_v .. q_v+3)
+__global__ __launch_bounds__(BLOCK) void gen_pack_kernel(size_t total, int Q, int q_s, int q_v, const double* __restrict__ s,
+                                                        const double* __restrict__ v, double* __restrict__ X) {
+  for (size_t e = (size_t)blockIdx.x * BLOCK + threadIdx.x; e < 2 * total * Q; e += (size_t)gridDim.x * BLOCK) {
+    const size_t nc = e / Q;                 // (plane, node, channel)
+    const int q = (int)(e - nc * Q);
+    double val = 0.0;                        // components other than (0,0) / (1,1) are zero-filled
+    if (q == q_s) val = s[nc];
+    else if (q >= q_v && q < q_v + 4) val = v[nc * 4 + (q - q_v)];
+    X[e] = val;
+  }
+}
+__global__ __launch_bounds__(BLOCK) void gen_unpack_kernel(size_t total, int Q, int q_s, int q_v, const double* __restrict__ X,
+                                                          double* __restrict__ s, double* __restrict__ v) {
+  for (size_t e = (size_t)blockIdx.x * BLOCK + threadIdx.x; e < 2 * total * 5; e += (size_t)gridDim.x * BLOCK) {
+    const size_t nc = e / 5;
+    const int k = (int)(e - nc * 5);
+    if (k == 4) s[nc] = X[nc * Q + q_s];
+    else v[nc * 4 + k] = X[nc * Q + q_v + k];
+  }
+}
+static int glue_grid(size_t n) {
+  size_t g = (n + BLOCK - 1) / BLOCK;
+  return (int)(g < 4096 ? (g ? g : 1) : 4096);
+}
+int gen_pack(size_t nodes_x_C, int Q, int q_s, int q_v, const double* s, const double* v, double* X, hipStream_t st) {
+  LGN_CHECK_ARG(Q >= 5 && q_s >= 0 && q_s < Q && q_v >= 0 && q_v + 4 <= Q && (q_s < q_v || q_s >= q_v + 4), "gen_pack: bad component offsets");
+  hipLaunchKernelGGL(gen_pack_kernel, dim3(glue_grid(2 * nodes_x_C * Q)), dim3(BLOCK), 0, st, nodes_x_C, Q, q_s, q_v, s, v, X);
+  LGN_CHECK_LAUNCH();
+  return 0;
+}
+int gen_unpack(size_t nodes_x_C, int Q, int q_s, int q_v, const double* X, double* s, double* v, hipStream_t st) {
+  LGN_CHECK_ARG(Q >= 5 && q_s >= 0 && q_s < Q && q_v >= 0 && q_v + 4 <= Q && (q_s < q_v || q_s >= q_v + 4), "gen_unpack: bad component offsets");
+  hipLaunchKernelGGL(gen_unpack_kernel, dim3(glue_grid(2 * nodes_x_C * 5)), dim3(BLOCK), 0, st, nodes_x_C, Q, q_s, q_v, X, s, v);
+  LGN_CHECK_LAUNCH();
+  return 0;
+}
 
 int local_fwd(const LocalArgs& a, hipStream_t st) {
   LGN_CHECK_ARG(a.nodes > 0 && a.C >= 1 && a.CO >= 1, "local_fwd: empty input");
@@ -355,6 +398,9 @@ int local_bwd(const LocalArgs& a, hipStream_t st) {
   LGN_CHECK_ARG(a.nodes > 0 && a.C >= 1 && a.CO >= 1, "local_bwd: empty input");
   LGN_CHECK_ARG(a.C * a.Q <= BLOCK && a.C * a.Q * 10 <= PF_U * BLOCK && a.CO * a.Qout <= BLOCK, "local_bwd: C*Q=%d too large", a.C * a.Q);
   LGN_CHECK_ARG(a.t.n_w <= MAXW * BLOCK, "local_bwd: %d CatMix weights exceed the per-workgroup accumulator budget", a.t.n_w);
+  // widths of the bit-packed decode tables of the kernel (winfo: row < 1024, q0 < 64, d < 16, o < 16, c < 128; rinfo: q < 256)
+  LGN_CHECK_ARG(a.t.n_rows < 1024 && a.Qout < 64 && a.CO <= 15 && a.C <= 127 && a.Q < 256,
+                "local_bwd: n_rows=%d Qout=%d CO=%d exceed the packed table fields", a.t.n_rows, a.Qout, a.CO);
   const size_t smem = sizeof(double) * ((size_t)a.t.n_rows * a.C * 4 + (size_t)a.CO * a.Qout * 2 + (size_t)a.C * a.Q * 12) +
                       sizeof(int) * ((size_t)a.t.n_w + 2 * (size_t)a.t.n_rows + 5 * (size_t)a.Q + 2 + (size_t)a.n_u) +
                       sizeof(double) * (size_t)a.n_u;

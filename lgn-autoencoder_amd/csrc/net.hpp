@@ -33,4 +33,17 @@ int dec_output_fwd(int B, int N, int C, const double* v, const double* wo1, doub
 int dec_output_bwd(int B, int N, int C, const double* v, const double* wo1, const double* g_recon, double* g_v, double* part, hipStream_t);
 int finalize_step(double* w, double* g, long n, const double* loss_part, int nB, double lambda, double* m, double* v, long* step_dev,
                   double lr, double beta1, double beta2, double eps, int do_adam, double* loss_out, hipStream_t st);
+// LocalArgs from the C-ABI table struct (shared by api.hip and step.hip)
+inline int local_args(LocalArgs& a, int nodes, int C, int CO, int Q, int Qout, const lgn_local_tables* t) {
+  LGN_CHECK_ARG(t && t->row_ptr && t->t_type && t->t_a && t->t_b && t->t_coef && t->out_dim && t->out_nblk && t->out_row0 &&
+                    t->out_q0 && t->out_w0 && t->u_ptr && t->u_row && t->u_coef && t->x_ptr && t->x_row && t->x_other && t->x_coef,
+                "local: incomplete tables");
+  LGN_CHECK_ARG(t->n_terms > 0 && t->n_u >= 0 && t->n_x >= 0, "local: table lengths missing");
+  a.nodes = nodes; a.C = C; a.CO = CO; a.Q = Q; a.Qout = Qout;
+  a.n_terms = t->n_terms; a.n_u = t->n_u; a.n_x = t->n_x;
+  a.t = LocalTables{t->n_rows, t->n_out, t->n_w, t->row_ptr, t->t_type, t->t_a, t->t_b, t->t_coef, t->out_dim, t->out_nblk,
+                    t->out_row0, t->out_q0, t->out_w0, t->u_ptr, t->u_row, t->u_coef, t->x_ptr, t->x_row, t->x_other, t->x_coef};
+  return 0;
+}
+
 }  // namespace lgn

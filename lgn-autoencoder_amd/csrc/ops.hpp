@@ -47,6 +47,9 @@ struct MlpArgs {
   T* g_in;          // [2][M][C]
   T* part;          // [nblk][psize] partial parameter gradients, layout = concat_l (W_l, b_l)
   int psize;
+  // element stride of s_out / g_out / g_in (s_in is always dense): 1 = [2][M][C]; Q = the scalar column of a packed
+  // feature tensor [2][M][C][Q] (pointer already offset to that column) -- the table-driven levels apply the MLP in place
+  int ld = 1;
 };
 template <typename T> int mlp_dispatch(const MlpArgs<T>&, bool backward, hipStream_t);
 int mlp_mfma_dispatch(const MlpArgs<double>&, bool backward, hipStream_t);
@@ -105,10 +108,15 @@ struct LocalArgs {
   const double* g_out;
   double* gU;               // [nodes][C][Q][5][2]
   double* gX;               // [2][nodes][C][Q]  (overwritten)
-  double* part;             // [nblk][2*n_w]  layout per irrep like wcat
+  double* part;             // [nblk][2*n_w]  layout per irrep like wcat (irrep l at t.out_w0[l])
+  double* s_copy;           // optional [2][nodes][CO]: copy of output component q_s (the pre-MLP scalars)
+  int q_s;
 };
 int local_fwd(const LocalArgs& a, hipStream_t st);
 int local_bwd(const LocalArgs& a, hipStream_t st);
 int local_partial_rows(int nodes);
+// packed X [2][nodes][C][Q] <-> s [2][nodes][C] (component q_s) + v [2][nodes][C][4] (components q_v..q_v+3); pack zero-fills the rest
+int gen_pack(size_t nodes_x_C, int Q, int q_s, int q_v, const double* s, const double* v, double* X, hipStream_t st);
+int gen_unpack(size_t nodes_x_C, int Q, int q_s, int q_v, const double* X, double* s, double* v, hipStream_t st);
 
 }  // namespace lgn

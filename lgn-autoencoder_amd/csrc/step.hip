@@ -237,7 +237,635 @@ int check_desc(const lgn_net_desc* d) {
 
 }  // namespace lgn
 
+
+namespace lgn {
+namespace {
+// grads [n] and the zero block [nz]: one memset when the caller laid them out back to back (lgn/ops.py does)
+int zero_grads_and_block(double* grads, size_t n, double* zeros, size_t nz, hipStream_t st) {
+  if (zeros >= grads + n && zeros <= grads + n + 16) {
+    HIPOK(hipMemsetAsync(grads, 0, sizeof(double) * (size_t)((zeros + nz) - grads), st));
+  } else {
+    HIPOK(hipMemsetAsync(grads, 0, sizeof(double) * n, st));
+    HIPOK(hipMemsetAsync(zeros, 0, sizeof(double) * nz, st));
+  }
+  return 0;
+}
+
+int check_mlp_contiguous(const lgn_net_desc& d, bool dec, const int64_t* off) {
+  const Slots S{d.n_levels, d.mlp_nlin};
+  const int* ch = dec ? d.dec_channels : d.enc_channels;
+  for (int l = 0; l < d.n_levels; ++l) {
+    const int D = 2 * ch[l + 1], H = d.mlp_hidden_mul * D;
+    int64_t expect = off[S.mlp(dec, l, 0)];
+    for (int q = 0; q < d.mlp_nlin; ++q) {
+      const int hin = q == 0 ? D : H, hout = q == d.mlp_nlin - 1 ? D : H;
+      LGN_CHECK_ARG(off[S.mlp(dec, l, 2 * q)] == expect, "MLP weights are not contiguous in the flat parameter buffer");
+      expect += (int64_t)hin * hout;
+      LGN_CHECK_ARG(off[S.mlp(dec, l, 2 * q + 1)] == expect, "MLP biases are not contiguous in the flat parameter buffer");
+      expect += hout;
+    }
+  }
+  return 0;
+}
+
+}  // namespace
+}  // namespace lgn
+
+// ---------------------------------------------------------------------------------------------------------
+// table-driven networks (maxdim = 3): same structure as above on packed features X_l [2][B][N][C_l][Q_l]
+//   level forward : moments (generic_moments.hip) -> sparse CG + CatMix (generic_local.hip) -> CGMLP in place on the
+//                   scalar column; backward in reverse.  Reference: LGNCG.forward lgn/models/lgn_cg.py:164-172.
+// ---------------------------------------------------------------------------------------------------------
+namespace lgn {
+namespace {
+
+inline bool is_generic(const lgn_net_desc& d, bool dec) { return (dec ? d.dec_tables[0] : d.enc_tables[0]) != nullptr; }
+
+struct GenGeom {                   // per-network view of the descriptor
+  const int *ch, *Q, *qs, *qv;
+  const lgn_local_tables* const* tab;
+};
+inline GenGeom geom(const lgn_net_desc& d, bool dec) {
+  return dec ? GenGeom{d.dec_channels, d.dec_Q, d.dec_qs, d.dec_qv, d.dec_tables}
+             : GenGeom{d.enc_channels, d.enc_Q, d.enc_qs, d.enc_qv, d.enc_tables};
+}
+
+int check_generic(const lgn_net_desc& d, bool dec) {
+  const GenGeom g = geom(d, dec);
+  for (int l = 0; l < d.n_levels; ++l) {
+    LGN_CHECK_ARG(g.tab[l], "table-driven network: level %d has no tables (every level needs one)", l);
+    LGN_CHECK_ARG(g.tab[l]->n_w > 0 && g.tab[l]->n_rows > 0, "table-driven network: empty tables at level %d", l);
+  }
+  for (int l = 0; l <= d.n_levels; ++l)
+    LGN_CHECK_ARG(g.Q[l] >= 5 && g.Q[l] <= 64 && g.qs[l] >= 0 && g.qs[l] < g.Q[l] && g.qv[l] >= 0 && g.qv[l] + 4 <= g.Q[l],
+                  "table-driven network: bad component layout at level %d (Q=%d qs=%d qv=%d)", l, g.Q[l], g.qs[l], g.qv[l]);
+  LGN_CHECK_ARG(g.Q[0] == 5, "table-driven network: the input level carries (1,1) and (0,0) only (Q=5), got %d", g.Q[0]);
+  return 0;
+}
+
+struct GenAct {                     // written by the forward, read by the backward
+  double *s0, *v0;                  // input-kernel outputs [2][BN][C0], [2][BN][C0][4]
+  double *X[5], *U[4], *smix[4];
+  double *sL, *vL;                  // (0,0) / (1,1) of the last level, unpacked for the end kernels
+  double* pdec;
+  int* idx;
+  size_t total;
+};
+GenAct carve_gen_act(const lgn_net_desc& d, bool dec, double* base) {
+  GenAct a{};
+  Bump b{base};
+  const GenGeom g = geom(d, dec);
+  const size_t BN = (size_t)d.B * d.N;
+  const int L = d.n_levels;
+  a.s0 = b.take(2 * BN * g.ch[0]);
+  a.v0 = b.take(8 * BN * g.ch[0]);
+  for (int l = 0; l <= L; ++l) a.X[l] = b.take(2 * BN * g.ch[l] * g.Q[l]);
+  for (int l = 0; l < L; ++l) {
+    a.U[l] = b.take(10 * BN * g.ch[l] * g.Q[l]);
+    a.smix[l] = b.take(2 * BN * g.ch[l + 1]);
+  }
+  a.sL = b.take(2 * BN * g.ch[L]);
+  a.vL = b.take(8 * BN * g.ch[L]);
+  if (dec) a.pdec = b.take(8 * BN);
+  else a.idx = reinterpret_cast<int*>(b.take(((size_t)d.B * 2 * (d.tau_s + d.tau_v) * 2 + 1) / 2 + 8));
+  a.total = b.off;
+  return a;
+}
+
+struct GenScratch {
+  double *zero0, *g_p, *g_lat_s;    // zero block (first): zeros for a missing scalar gradient | decoder d p | encoder g_lat_s stand-in
+  size_t zero_doubles;
+  double *gs, *gv;                  // unpacked gradients at the two ends
+  double *gX[2], *gU;
+  double* tot[4];
+  double* parts;
+  size_t parts_size, total;
+};
+GenScratch carve_gen_scratch(const lgn_net_desc& d, bool dec, double* base) {
+  GenScratch s{};
+  Bump b{base};
+  const GenGeom g = geom(d, dec);
+  const size_t BN = (size_t)d.B * d.N;
+  const int L = d.n_levels;
+  size_t cq = 0, cmax = 0;
+  for (int l = 0; l <= L; ++l) {
+    cq = cq > (size_t)g.ch[l] * g.Q[l] ? cq : (size_t)g.ch[l] * g.Q[l];
+    cmax = cmax > (size_t)g.ch[l] ? cmax : (size_t)g.ch[l];
+  }
+  {
+    const size_t z0 = b.off;
+    s.zero0 = b.take(2 * BN * cmax);
+    s.g_p = b.take(dec ? 8 * BN : 0);
+    s.g_lat_s = b.take(dec ? 0 : (size_t)2 * d.B * 2 * d.tau_s);
+    s.zero_doubles = b.off - z0;
+  }
+  s.gs = b.take(2 * BN * cmax);
+  s.gv = b.take(8 * BN * cmax);
+  s.gX[0] = b.take(2 * BN * cq);
+  s.gX[1] = b.take(2 * BN * cq);
+  s.gU = b.take(10 * BN * cq);
+  size_t psum = 0;
+  for (int l = 0; l < L; ++l) {
+    const size_t nrad = rad_partial_size(g.ch[l], dec);
+    psum += (((size_t)local_partial_rows((int)BN) * 2 * g.tab[l]->n_w + 15) & ~size_t(15)) + (((size_t)d.B * nrad + 15) & ~size_t(15));
+    psum += ((size_t)mlp_partial_rows((int)BN) * mlp_psize(g.ch[l + 1], d.mlp_hidden_mul * 2 * g.ch[l + 1], d.mlp_nlin) + 15) & ~size_t(15);
+    s.tot[l] = b.take(nrad + 16);
+  }
+  const int Tin = d.tau_v_in > 0 ? d.tau_v_in : 2 * d.tau_v;
+  if (dec) psum += (((size_t)d.B * 2 * g.ch[L] + 15) & ~size_t(15)) + (((size_t)d.B * (4 * g.ch[0] + 2 * (size_t)d.N * Tin) + 15) & ~size_t(15));
+  else psum += (((size_t)d.B * 2 * (d.tau_s + d.tau_v) * g.ch[L] + 15) & ~size_t(15)) + (((size_t)d.B * 4 * g.ch[0] + 15) & ~size_t(15));
+  s.parts = b.take(psum);
+  s.parts_size = psum;
+  s.total = b.off;
+  return s;
+}
+
+GenArgs gen_level_args(const lgn_net_desc& d, bool dec, int l, const double* P, const int64_t* off, const double* X, const double* pos,
+                       const uint8_t* mask) {
+  const Slots S{d.n_levels, d.mlp_nlin};
+  const GenGeom g = geom(d, dec);
+  GenArgs a{};
+  a.B = d.B; a.N = d.N; a.C = g.ch[l]; a.Q = g.Q[l]; a.X = X; a.p = pos; a.mask = mask;
+  a.ra = P + off[S.rad(dec, l, 0)]; a.rb = P + off[S.rad(dec, l, 1)]; a.rc = P + off[S.rad(dec, l, 2)];
+  a.w0 = P + off[S.rad(dec, l, 3)]; a.b0 = P + off[S.rad(dec, l, 4)]; a.w1 = P + off[S.rad(dec, l, 5)]; a.b1 = P + off[S.rad(dec, l, 6)];
+  return a;
+}
+
+// X[0] (packed input features) must be in place; fills X[1..L], U, smix
+int gen_levels_fwd(const lgn_net_desc& d, bool dec, const double* P, const int64_t* off, GenAct& a, const double* pos,
+                   const uint8_t* mask, hipStream_t st) {
+  const Slots S{d.n_levels, d.mlp_nlin};
+  const GenGeom g = geom(d, dec);
+  const int BN = d.B * d.N;
+  for (int l = 0; l < d.n_levels; ++l) {
+    GenArgs m = gen_level_args(d, dec, l, P, off, a.X[l], pos, mask);
+    m.U = a.U[l];
+    LGN_TRY(moments_dispatch(m, dec, 0, st));
+    LocalArgs la{};
+    LGN_TRY(local_args(la, BN, g.ch[l], g.ch[l + 1], g.Q[l], g.Q[l + 1], g.tab[l]));
+    la.X = a.X[l]; la.U = a.U[l]; la.wcat = P + off[S.mix(dec, l, 0)]; la.out = a.X[l + 1];
+    la.s_copy = a.smix[l]; la.q_s = g.qs[l + 1];
+    LGN_TRY(local_fwd(la, st));
+    MlpArgs<double> mm{};
+    mm.M = BN; mm.C = g.ch[l + 1]; mm.H = d.mlp_hidden_mul * 2 * g.ch[l + 1]; mm.nlin = d.mlp_nlin;
+    for (int q = 0; q < d.mlp_nlin; ++q) { mm.w[q] = P + off[S.mlp(dec, l, 2 * q)]; mm.b[q] = P + off[S.mlp(dec, l, 2 * q + 1)]; }
+    mm.s_in = a.smix[l]; mm.s_out = a.X[l + 1] + g.qs[l + 1]; mm.ld = g.Q[l + 1];
+    LGN_TRY(mlp_dispatch<double>(mm, false, st));
+  }
+  return 0;
+}
+
+// On entry sc.gX[cur] holds the gradient w.r.t. X[L] (scalar column = 0 when !has_s_grad); on exit sc.gX[cur] the one w.r.t. X[0].
+int gen_levels_bwd(const lgn_net_desc& d, bool dec, const double* P, double* G, const int64_t* off, const GenAct& a, const double* pos,
+                   const uint8_t* mask, GenScratch& sc, Deferred& dq, RadFinJob& fin, int& cur, bool has_s_grad, hipStream_t st) {
+  const Slots S{d.n_levels, d.mlp_nlin};
+  const GenGeom g = geom(d, dec);
+  const int BN = d.B * d.N;
+  for (int l = d.n_levels - 1; l >= 0; --l) {
+    const int C = g.ch[l], CO = g.ch[l + 1];
+    if (has_s_grad) {     // CGMLP backward, in place on the scalar column of the gradient
+      MlpArgs<double> m{};
+      m.M = BN; m.C = CO; m.H = d.mlp_hidden_mul * 2 * CO; m.nlin = d.mlp_nlin;
+      for (int q = 0; q < d.mlp_nlin; ++q) { m.w[q] = P + off[S.mlp(dec, l, 2 * q)]; m.b[q] = P + off[S.mlp(dec, l, 2 * q + 1)]; }
+      m.s_in = a.smix[l]; m.g_out = sc.gX[cur] + g.qs[l + 1]; m.g_in = sc.gX[cur] + g.qs[l + 1]; m.ld = g.Q[l + 1];
+      m.psize = mlp_psize(CO, m.H, m.nlin);
+      m.part = dq.take((size_t)mlp_partial_rows(BN) * m.psize);
+      LGN_TRY(mlp_dispatch<double>(m, true, st));
+      dq.add(m.part, mlp_partial_rows(BN), m.psize, 0, m.psize, G + off[S.mlp(dec, l, 0)]);
+    }
+    const int nxt = cur ^ 1;
+    LocalArgs la{};
+    LGN_TRY(local_args(la, BN, C, CO, g.Q[l], g.Q[l + 1], g.tab[l]));
+    const int rows = local_partial_rows(BN), nw2 = 2 * g.tab[l]->n_w;
+    la.X = a.X[l]; la.U = a.U[l]; la.wcat = P + off[S.mix(dec, l, 0)]; la.g_out = sc.gX[cur];
+    la.gU = sc.gU; la.gX = sc.gX[nxt]; la.part = dq.take((size_t)rows * nw2);
+    LGN_TRY(local_bwd(la, st));
+    dq.add(la.part, rows, nw2, 0, nw2, G + off[S.mix(dec, l, 0)]);
+    GenArgs m = gen_level_args(d, dec, l, P, off, a.X[l], pos, mask);
+    const int nrad = rad_partial_size(C, dec);
+    m.gU = sc.gU; m.gX = sc.gX[nxt]; m.g_p = dec ? sc.g_p : nullptr; m.part_rad = dq.take((size_t)d.B * nrad);
+    LGN_TRY(moments_dispatch(m, dec, 1, st));
+    LGN_TRY(moments_dispatch(m, dec, 2, st));
+    if (dec) {
+      dq.add(m.part_rad, d.B, nrad, 0, C, G + off[S.rad(dec, l, 4)]);
+      dq.add(m.part_rad, d.B, nrad, C, C, G + off[S.rad(dec, l, 6)]);
+    } else {
+      dq.add(m.part_rad, d.B, nrad, 0, nrad, sc.tot[l]);
+      fin.it[fin.n++] = RadFinJob::Item{sc.tot[l], C, m.ra, m.rb, m.rc, m.w0, m.w1, G + off[S.rad(dec, l, 0)], G + off[S.rad(dec, l, 1)],
+                                        G + off[S.rad(dec, l, 2)], G + off[S.rad(dec, l, 3)], G + off[S.rad(dec, l, 4)],
+                                        G + off[S.rad(dec, l, 5)], G + off[S.rad(dec, l, 6)]};
+    }
+    cur = nxt;
+    has_s_grad = true;
+  }
+  return 0;
+}
+
+// ---- one table-driven network, forward / backward (shared by the per-network API and the whole step) ----------------
+int gen_encoder_fwd(const lgn_net_desc& d, const double* P, const int64_t* off, const double* p4, const uint8_t* mask, GenAct& a,
+                    double* lat_s, double* lat_v, hipStream_t st) {
+  const Slots S{d.n_levels, d.mlp_nlin};
+  const GenGeom g = geom(d, false);
+  const int L = d.n_levels;
+  const size_t BN = (size_t)d.B * d.N;
+  LGN_TRY(enc_input_fwd(d.B, d.N, g.ch[0], p4, P + off[0], P + off[1], a.s0, a.v0, st));
+  LGN_TRY(gen_pack(BN * g.ch[0], g.Q[0], g.qs[0], g.qv[0], a.s0, a.v0, a.X[0], st));
+  LGN_TRY(gen_levels_fwd(d, false, P, off, a, p4, mask, st));
+  LGN_TRY(gen_unpack(BN * g.ch[L], g.Q[L], g.qs[L], g.qv[L], a.X[L], a.sL, a.vL, st));
+  LGN_TRY(enc_latent_fwd(d.B, d.N, g.ch[L], d.tau_s, d.tau_v, a.sL, a.vL, P + off[S.out0(false)], P + off[S.out0(false) + 1], lat_s,
+                         lat_v, a.idx, st));
+  return 0;
+}
+
+// the caller has zero-filled G and sc's zero block
+int gen_encoder_bwd(const lgn_net_desc& d, const double* P, double* G, const int64_t* off, const double* p4, const uint8_t* mask,
+                    const GenAct& a, const double* g_lat_s, const double* g_lat_v, GenScratch& sc, hipStream_t st) {
+  const Slots S{d.n_levels, d.mlp_nlin};
+  const GenGeom g = geom(d, false);
+  const int L = d.n_levels, B = d.B, N = d.N, Ts = d.tau_s, Tv = d.tau_v;
+  const size_t BN = (size_t)B * N;
+  Deferred dq;
+  dq.parts = sc.parts;
+  dq.cap = sc.parts_size;
+  RadFinJob fin{};
+  int cur = 0;
+  {
+    const int CL = g.ch[L], rowe = 2 * (Ts + Tv) * CL;
+    double* parte = dq.take((size_t)B * rowe);
+    LGN_TRY(enc_latent_bwd(B, N, CL, Ts, Tv, a.sL, a.vL, P + off[S.out0(false)], P + off[S.out0(false) + 1],
+                           g_lat_s ? g_lat_s : sc.g_lat_s, g_lat_v, a.idx, sc.gs, sc.gv, parte, st));
+    dq.add(parte, B, rowe, 0, 2 * Ts * CL, G + off[S.out0(false)]);
+    dq.add(parte, B, rowe, 2 * Ts * CL, 2 * Tv * CL, G + off[S.out0(false) + 1]);
+    LGN_TRY(gen_pack(BN * CL, g.Q[L], g.qs[L], g.qv[L], g_lat_s ? sc.gs : sc.zero0, sc.gv, sc.gX[cur], st));
+  }
+  LGN_TRY(gen_levels_bwd(d, false, P, G, off, a, p4, mask, sc, dq, fin, cur, g_lat_s != nullptr, st));
+  {
+    const int C0 = g.ch[0];
+    LGN_TRY(gen_unpack(BN * C0, g.Q[0], g.qs[0], g.qv[0], sc.gX[cur], sc.gs, sc.gv, st));
+    double* part = dq.take((size_t)B * 4 * C0);
+    LGN_TRY(enc_input_bwd(B, N, C0, p4, sc.gs, sc.gv, part, st));
+    dq.add(part, B, 4 * C0, 0, 2 * C0, G + off[0]);
+    dq.add(part, B, 4 * C0, 2 * C0, 2 * C0, G + off[1]);
+  }
+  LGN_CHECK_ARG(dq.off <= dq.cap, "encoder_bwd: partial-row workspace overflow (%zu > %zu)", dq.off, dq.cap);
+  LGN_TRY(dq.flush(st));
+  LGN_TRY(rad_finalize_batch(fin, st));
+  return 0;
+}
+
+// forward up to the unpacked last-level features (the caller applies dec_output_fwd or the fused output + loss kernel)
+int gen_decoder_fwd(const lgn_net_desc& d, const double* P, const int64_t* off, const double* lat_v, GenAct& a, hipStream_t st) {
+  const GenGeom g = geom(d, true);
+  const int L = d.n_levels, Tin = d.tau_v_in > 0 ? d.tau_v_in : 2 * d.tau_v;
+  const size_t BN = (size_t)d.B * d.N;
+  LGN_TRY(dec_input_fwd(d.B, d.N, g.ch[0], Tin, lat_v, P + off[1], P + off[2], P + off[3], a.pdec, a.s0, a.v0, st));
+  LGN_TRY(gen_pack(BN * g.ch[0], g.Q[0], g.qs[0], g.qv[0], a.s0, a.v0, a.X[0], st));
+  LGN_TRY(gen_levels_fwd(d, true, P, off, a, a.pdec, nullptr, st));
+  LGN_TRY(gen_unpack(BN * g.ch[L], g.Q[L], g.qs[L], g.qv[L], a.X[L], a.sL, a.vL, st));
+  return 0;
+}
+
+// sc.gv holds the gradient w.r.t. the last level's (1,1) features (from dec_output_bwd / dec_output_loss); dq carries the
+// caller's pending reductions and is flushed by the caller
+int gen_decoder_bwd(const lgn_net_desc& d, const double* P, double* G, const int64_t* off, const double* lat_v, const GenAct& a,
+                    double* g_lat_v, GenScratch& sc, Deferred& dq, RadFinJob& fin, hipStream_t st) {
+  const GenGeom g = geom(d, true);
+  const int L = d.n_levels, B = d.B, N = d.N, Tin = d.tau_v_in > 0 ? d.tau_v_in : 2 * d.tau_v;
+  const size_t BN = (size_t)B * N;
+  int cur = 0;
+  LGN_TRY(gen_pack(BN * g.ch[L], g.Q[L], g.qs[L], g.qv[L], sc.zero0, sc.gv, sc.gX[cur], st));
+  LGN_TRY(gen_levels_bwd(d, true, P, G, off, a, a.pdec, nullptr, sc, dq, fin, cur, /*has_s_grad=*/false, st));
+  const int C0 = g.ch[0], row = 4 * C0 + 2 * N * Tin;
+  LGN_TRY(gen_unpack(BN * C0, g.Q[0], g.qs[0], g.qv[0], sc.gX[cur], sc.gs, sc.gv, st));
+  double* part = dq.take((size_t)B * row);
+  LGN_TRY(dec_input_bwd(B, N, C0, Tin, lat_v, P + off[1], P + off[3], a.pdec, sc.g_p, sc.gs, sc.gv, g_lat_v, part, st));
+  dq.add(part, B, row, 0, 2 * C0, G + off[2]);
+  dq.add(part, B, row, 2 * C0, 2 * C0, G + off[3]);
+  dq.add(part, B, row, 4 * C0, 2 * N * Tin, G + off[1]);
+  return 0;
+}
+
+// ---- whole training step on table-driven networks -------------------------------------------------------------------
+struct GenStep {
+  GenAct ea, da;
+  GenScratch es, ds;
+  double *lat_s, *lat_v, *g_lat_v;
+  size_t total;
+};
+GenStep carve_gen_step(const lgn_net_desc& d, double* base) {
+  GenStep g{};
+  auto at = [&](size_t off) { return base ? base + off : nullptr; };
+  size_t off = 0;
+  g.ea = carve_gen_act(d, false, at(off)); off += (g.ea.total + 15) & ~size_t(15);
+  g.da = carve_gen_act(d, true, at(off)); off += (g.da.total + 15) & ~size_t(15);
+  g.es = carve_gen_scratch(d, false, at(off)); off += (g.es.total + 15) & ~size_t(15);
+  g.ds = carve_gen_scratch(d, true, at(off)); off += (g.ds.total + 15) & ~size_t(15);
+  const int Tin = d.tau_v_in > 0 ? d.tau_v_in : 2 * d.tau_v;
+  g.lat_s = at(off); off += ((size_t)2 * d.B * 2 * d.tau_s + 15) & ~size_t(15);
+  g.lat_v = at(off); off += ((size_t)2 * d.B * Tin * 4 + 15) & ~size_t(15);
+  g.g_lat_v = at(off); off += ((size_t)2 * d.B * Tin * 4 + 15) & ~size_t(15);
+  g.total = off;
+  return g;
+}
+
+int gen_step_fwd_bwd(const lgn_net_desc& d, const double* params, double* grads, long long n_params, const int64_t* enc_off,
+                     const int64_t* dec_off, const double* p4, const double* target, const uint8_t* mask, double* workspace,
+                     long long workspace_doubles, double* recon, double* loss_part, hipStream_t st) {
+  LGN_CHECK_ARG(is_generic(d, false) && is_generic(d, true), "step: encoder and decoder must both be table-driven (or both fused)");
+  if (int rc = check_generic(d, false)) return rc;
+  if (int rc = check_generic(d, true)) return rc;
+  LGN_CHECK_ARG(d.tau_v_in == 0 || d.tau_v_in == 2 * d.tau_v, "step: the decoder must consume the encoder's 2*tau_v latent vectors");
+  GenStep g = carve_gen_step(d, workspace);
+  LGN_CHECK_ARG((long long)g.total <= workspace_doubles, "step: workspace holds %lld doubles, this configuration needs %zu",
+                workspace_doubles, g.total);
+  if (int rc = check_mlp_contiguous(d, false, enc_off)) return rc;
+  if (int rc = check_mlp_contiguous(d, true, dec_off)) return rc;
+  const Slots S{d.n_levels, d.mlp_nlin};
+  const int L = d.n_levels, B = d.B, N = d.N, CL = d.dec_channels[L];
+  HIPOK(hipMemsetAsync(grads, 0, sizeof(double) * (size_t)n_params, st));
+  HIPOK(hipMemsetAsync(g.es.zero0, 0, sizeof(double) * g.es.zero_doubles, st));
+  HIPOK(hipMemsetAsync(g.ds.zero0, 0, sizeof(double) * g.ds.zero_doubles, st));
+  LGN_TRY(gen_encoder_fwd(d, params, enc_off, p4, mask, g.ea, g.lat_s, g.lat_v, st));
+  LGN_TRY(gen_decoder_fwd(d, params, dec_off, g.lat_v, g.da, st));
+  Deferred dq;
+  dq.parts = g.ds.parts;
+  dq.cap = g.ds.parts_size;
+  RadFinJob fin{};
+  {
+    double* part = dq.take((size_t)B * 2 * CL);
+    LGN_TRY(dec_output_loss(B, N, CL, g.da.vL, params + dec_off[S.out0(true) + 1], target, 1.0, recon, loss_part, g.ds.gv, part, st));
+    dq.add(part, B, 2 * CL, 0, 2 * CL, grads + dec_off[S.out0(true) + 1]);
+  }
+  LGN_TRY(gen_decoder_bwd(d, params, grads, dec_off, g.lat_v, g.da, g.g_lat_v, g.ds, dq, fin, st));
+  LGN_CHECK_ARG(dq.off <= dq.cap, "step: partial-row workspace overflow (%zu > %zu)", dq.off, dq.cap);
+  LGN_TRY(dq.flush(st));
+  // the decoder never reads the latent scalars: no gradient on them
+  LGN_TRY(gen_encoder_bwd(d, params, grads, enc_off, p4, mask, g.ea, nullptr, g.g_lat_v, g.es, st));
+  return 0;
+}
+
+}  // namespace
+}  // namespace lgn
+
+// ---------------------------------------------------------------------------------------------------------
+// one network at a time (module API: LGNEncoder.forward / LGNDecoder.forward and their autograd backward)
+// ---------------------------------------------------------------------------------------------------------
+namespace lgn {
+namespace {
+
+struct NetAct {                     // written by *_fwd, read by *_bwd
+  NetBuf n;
+  double* pdec;                     // decoder: complex canonical positions [2][B][N][4]
+  int* idx;                         // encoder: pooling indices
+  size_t total;
+};
+NetAct carve_act(const lgn_net_desc& d, bool dec, double* base) {
+  NetAct a{};
+  Bump b{base};
+  const size_t BN = (size_t)d.B * d.N;
+  const int* ch = dec ? d.dec_channels : d.enc_channels;
+  for (int l = 0; l <= d.n_levels; ++l) {
+    a.n.s[l] = b.take(2 * BN * ch[l]);
+    a.n.v[l] = b.take(8 * BN * ch[l]);
+  }
+  for (int l = 0; l < d.n_levels; ++l) {
+    a.n.smix[l] = b.take(2 * BN * ch[l + 1]);
+    a.n.ag0[l] = b.take(4 * BN * ch[l]);
+    a.n.ag1[l] = b.take(16 * BN * ch[l]);
+  }
+  if (dec) a.pdec = b.take(8 * BN);
+  else a.idx = reinterpret_cast<int*>(b.take(((size_t)d.B * 2 * (d.tau_s + d.tau_v) * 2 + 1) / 2 + 8));
+  a.total = b.off;
+  return a;
+}
+
+struct NetScratch {                 // backward only
+  Work w;                           // gs, gv, gsmix, g_ag, zeros_s, g_p, g_lat_s (zero block), tot, parts
+  size_t total;
+};
+NetScratch carve_scratch(const lgn_net_desc& d, bool dec, double* base) {
+  NetScratch s{};
+  Work& w = s.w;
+  Bump b{base};
+  const size_t BN = (size_t)d.B * d.N;
+  const int L = d.n_levels, Ts = d.tau_s, Tv = d.tau_v;
+  const int* ch = dec ? d.dec_channels : d.enc_channels;
+  int cmax = 0;
+  for (int l = 0; l <= L; ++l) cmax = cmax > ch[l] ? cmax : ch[l];
+  {  // zero-initialised block FIRST: a caller that places `grads` right in front of the scratch gets one memset for both
+    const size_t z0 = b.off;
+    w.zeros_s = b.take(2 * BN * cmax);
+    w.g_p = b.take(dec ? 8 * BN : 0);
+    w.g_lat_s = b.take(dec ? 0 : (size_t)2 * d.B * 2 * Ts);
+    w.zero_doubles = b.off - z0;
+  }
+  for (int q = 0; q < 2; ++q) {
+    w.gs[q] = b.take(2 * BN * cmax);
+    w.gv[q] = b.take(8 * BN * cmax);
+  }
+  w.gsmix = b.take(2 * BN * cmax);
+  w.g_ag = b.take(20 * BN * cmax);
+  size_t psum = 0;
+  for (int l = 0; l < L; ++l) {
+    int rm, rr;
+    level_bwd_partial_rows(d.B, d.N, dec, &rm, &rr);
+    const size_t nmix = (size_t)4 * ch[l + 1] * 5 * ch[l], nrad = rad_partial_size(ch[l], dec);
+    psum += ((rm * nmix + 15) & ~size_t(15)) + ((rr * nrad + 15) & ~size_t(15));
+    psum += ((size_t)mlp_partial_rows((int)BN) * mlp_psize(ch[l + 1], d.mlp_hidden_mul * 2 * ch[l + 1], d.mlp_nlin) + 15) & ~size_t(15);
+    w.tot[dec ? 1 : 0][l] = b.take(nrad + 16);
+  }
+  // input / output ends: decoder  B x (2 C_L) + B x (4 C_0 + 2 N Tin);  encoder  B x 2 (Ts + Tv) C_L + B x 4 C_0
+  const int Tin = d.tau_v_in > 0 ? d.tau_v_in : 2 * Tv;
+  if (dec) psum += (((size_t)d.B * 2 * ch[L] + 15) & ~size_t(15)) + (((size_t)d.B * (4 * ch[0] + 2 * (size_t)d.N * Tin) + 15) & ~size_t(15));
+  else psum += (((size_t)d.B * 2 * (Ts + Tv) * ch[L] + 15) & ~size_t(15)) + (((size_t)d.B * 4 * ch[0] + 15) & ~size_t(15));
+  w.parts = b.take(psum);
+  w.parts_size = psum;
+  s.total = b.off;
+  return s;
+}
+
+}  // namespace
+}  // namespace lgn
+
 using namespace lgn;
+
+extern "C" {
+
+long long lgn_net_workspace_doubles(const lgn_net_desc* d, int decoder, int which) {
+  if (check_desc(d)) return -1;
+  if (is_generic(*d, decoder != 0)) {
+    if (check_generic(*d, decoder != 0)) return -1;
+    return which == 0 ? (long long)carve_gen_act(*d, decoder != 0, nullptr).total : (long long)carve_gen_scratch(*d, decoder != 0, nullptr).total;
+  }
+  return which == 0 ? (long long)carve_act(*d, decoder != 0, nullptr).total : (long long)carve_scratch(*d, decoder != 0, nullptr).total;
+}
+
+int lgn_encoder_fwd_f64(const lgn_net_desc* d, const double* params, const int64_t* off, const double* p4, const uint8_t* mask,
+                        double* act, long long act_doubles, double* lat_s, double* lat_v, void* stream) {
+  if (int rc = check_desc(d)) return rc;
+  LGN_CHECK_ARG(params && off && p4 && mask && act && lat_s && lat_v, "encoder_fwd: null pointer");
+  if (is_generic(*d, false)) {
+    if (int rc = check_generic(*d, false)) return rc;
+    GenAct ga = carve_gen_act(*d, false, act);
+    LGN_CHECK_ARG((long long)ga.total <= act_doubles, "encoder_fwd: activation buffer holds %lld doubles, needs %zu", act_doubles, ga.total);
+    return gen_encoder_fwd(*d, params, off, p4, mask, ga, lat_s, lat_v, (hipStream_t)stream);
+  }
+  NetAct a = carve_act(*d, false, act);
+  LGN_CHECK_ARG((long long)a.total <= act_doubles, "encoder_fwd: activation buffer holds %lld doubles, needs %zu", act_doubles, a.total);
+  hipStream_t st = (hipStream_t)stream;
+  const Slots S{d->n_levels, d->mlp_nlin};
+  const int L = d->n_levels;
+  const int* ce = d->enc_channels;
+  LGN_TRY(enc_input_fwd(d->B, d->N, ce[0], p4, params + off[0], params + off[1], a.n.s[0], a.n.v[0], st));
+  LGN_TRY(levels_fwd(*d, false, ce, params, off, a.n, p4, mask, st));
+  LGN_TRY(enc_latent_fwd(d->B, d->N, ce[L], d->tau_s, d->tau_v, a.n.s[L], a.n.v[L], params + off[S.out0(false)],
+                         params + off[S.out0(false) + 1], lat_s, lat_v, a.idx, st));
+  return 0;
+}
+
+int lgn_encoder_bwd_f64(const lgn_net_desc* d, const double* params, double* grads, long long n_params, const int64_t* off,
+                        const double* p4, const uint8_t* mask, const double* act, long long act_doubles, const double* g_lat_s,
+                        const double* g_lat_v, double* scratch, long long scratch_doubles, void* stream) {
+  if (int rc = check_desc(d)) return rc;
+  LGN_CHECK_ARG(params && grads && off && p4 && mask && act && g_lat_v && scratch && n_params > 0, "encoder_bwd: null pointer");
+  if (is_generic(*d, false)) {
+    if (int rc = check_generic(*d, false)) return rc;
+    GenAct ga = carve_gen_act(*d, false, const_cast<double*>(act));
+    GenScratch gs = carve_gen_scratch(*d, false, scratch);
+    LGN_CHECK_ARG((long long)ga.total <= act_doubles && (long long)gs.total <= scratch_doubles,
+                  "encoder_bwd: buffers hold %lld / %lld doubles, need %zu / %zu", act_doubles, scratch_doubles, ga.total, gs.total);
+    if (int rc = check_mlp_contiguous(*d, false, off)) return rc;
+    LGN_TRY(zero_grads_and_block(grads, (size_t)n_params, gs.zero0, gs.zero_doubles, (hipStream_t)stream));
+    return gen_encoder_bwd(*d, params, grads, off, p4, mask, ga, g_lat_s, g_lat_v, gs, (hipStream_t)stream);
+  }
+  NetAct a = carve_act(*d, false, const_cast<double*>(act));
+  NetScratch sc = carve_scratch(*d, false, scratch);
+  LGN_CHECK_ARG((long long)a.total <= act_doubles && (long long)sc.total <= scratch_doubles,
+                "encoder_bwd: buffers hold %lld / %lld doubles, need %zu / %zu", act_doubles, scratch_doubles, a.total, sc.total);
+  if (int rc = check_mlp_contiguous(*d, false, off)) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  Work& w = sc.w;
+  const Slots S{d->n_levels, d->mlp_nlin};
+  const int L = d->n_levels, B = d->B, N = d->N, Ts = d->tau_s, Tv = d->tau_v;
+  const int* ce = d->enc_channels;
+  LGN_TRY(zero_grads_and_block(grads, (size_t)n_params, w.zeros_s, w.zero_doubles, st));
+  Deferred dq;
+  dq.parts = w.parts;
+  dq.cap = w.parts_size;
+  RadFinJob fin{};
+  int cur = 0;
+  {
+    const int CL = ce[L], rowe = 2 * (Ts + Tv) * CL;
+    double* parte = dq.take((size_t)B * rowe);
+    LGN_TRY(enc_latent_bwd(B, N, CL, Ts, Tv, a.n.s[L], a.n.v[L], params + off[S.out0(false)], params + off[S.out0(false) + 1],
+                           g_lat_s ? g_lat_s : w.g_lat_s, g_lat_v, a.idx, w.gs[cur], w.gv[cur], parte, st));
+    dq.add(parte, B, rowe, 0, 2 * Ts * CL, grads + off[S.out0(false)]);
+    dq.add(parte, B, rowe, 2 * Ts * CL, 2 * Tv * CL, grads + off[S.out0(false) + 1]);
+  }
+  // without an upstream gradient on the latent scalars the last level's scalars (and its CGMLP) receive none
+  LGN_TRY(levels_bwd(*d, false, ce, params, grads, off, a.n, p4, mask, w, dq, fin, cur, /*has_s_grad=*/g_lat_s != nullptr, st));
+  {
+    const int C0 = ce[0];
+    double* part = dq.take((size_t)B * 4 * C0);
+    LGN_TRY(enc_input_bwd(B, N, C0, p4, w.gs[cur], w.gv[cur], part, st));
+    dq.add(part, B, 4 * C0, 0, 2 * C0, grads + off[0]);
+    dq.add(part, B, 4 * C0, 2 * C0, 2 * C0, grads + off[1]);
+  }
+  LGN_CHECK_ARG(dq.off <= dq.cap, "encoder_bwd: partial-row workspace overflow (%zu > %zu)", dq.off, dq.cap);
+  LGN_TRY(dq.flush(st));
+  LGN_TRY(rad_finalize_batch(fin, st));
+  return 0;
+}
+
+int lgn_decoder_fwd_f64(const lgn_net_desc* d, const double* params, const int64_t* off, const double* lat_v, double* act,
+                        long long act_doubles, double* recon, void* stream) {
+  if (int rc = check_desc(d)) return rc;
+  LGN_CHECK_ARG(params && off && lat_v && act && recon, "decoder_fwd: null pointer");
+  if (is_generic(*d, true)) {
+    if (int rc = check_generic(*d, true)) return rc;
+    GenAct ga = carve_gen_act(*d, true, act);
+    LGN_CHECK_ARG((long long)ga.total <= act_doubles, "decoder_fwd: activation buffer holds %lld doubles, needs %zu", act_doubles, ga.total);
+    LGN_TRY(gen_decoder_fwd(*d, params, off, lat_v, ga, (hipStream_t)stream));
+    const Slots Sg{d->n_levels, d->mlp_nlin};
+    return dec_output_fwd(d->B, d->N, d->dec_channels[d->n_levels], ga.vL, params + off[Sg.out0(true) + 1], recon, (hipStream_t)stream);
+  }
+  NetAct a = carve_act(*d, true, act);
+  LGN_CHECK_ARG((long long)a.total <= act_doubles, "decoder_fwd: activation buffer holds %lld doubles, needs %zu", act_doubles, a.total);
+  hipStream_t st = (hipStream_t)stream;
+  const Slots S{d->n_levels, d->mlp_nlin};
+  const int L = d->n_levels, Tin = d->tau_v_in > 0 ? d->tau_v_in : 2 * d->tau_v;
+  const int* cd = d->dec_channels;
+  LGN_TRY(dec_input_fwd(d->B, d->N, cd[0], Tin, lat_v, params + off[1], params + off[2], params + off[3], a.pdec, a.n.s[0], a.n.v[0], st));
+  LGN_TRY(levels_fwd(*d, true, cd, params, off, a.n, a.pdec, nullptr, st));
+  LGN_TRY(dec_output_fwd(d->B, d->N, cd[L], a.n.v[L], params + off[S.out0(true) + 1], recon, st));
+  return 0;
+}
+
+int lgn_decoder_bwd_f64(const lgn_net_desc* d, const double* params, double* grads, long long n_params, const int64_t* off,
+                        const double* lat_v, const double* act, long long act_doubles, const double* g_recon, double* g_lat_v,
+                        double* scratch, long long scratch_doubles, void* stream) {
+  if (int rc = check_desc(d)) return rc;
+  LGN_CHECK_ARG(params && grads && off && lat_v && act && g_recon && g_lat_v && scratch && n_params > 0, "decoder_bwd: null pointer");
+  if (is_generic(*d, true)) {
+    if (int rc = check_generic(*d, true)) return rc;
+    hipStream_t gst = (hipStream_t)stream;
+    GenAct ga = carve_gen_act(*d, true, const_cast<double*>(act));
+    GenScratch gs = carve_gen_scratch(*d, true, scratch);
+    LGN_CHECK_ARG((long long)ga.total <= act_doubles && (long long)gs.total <= scratch_doubles,
+                  "decoder_bwd: buffers hold %lld / %lld doubles, need %zu / %zu", act_doubles, scratch_doubles, ga.total, gs.total);
+    if (int rc = check_mlp_contiguous(*d, true, off)) return rc;
+    LGN_TRY(zero_grads_and_block(grads, (size_t)n_params, gs.zero0, gs.zero_doubles, gst));
+    const Slots Sg{d->n_levels, d->mlp_nlin};
+    const int CL = d->dec_channels[d->n_levels];
+    Deferred dq;
+    dq.parts = gs.parts;
+    dq.cap = gs.parts_size;
+    RadFinJob fin{};
+    double* part = dq.take((size_t)d->B * 2 * CL);
+    LGN_TRY(dec_output_bwd(d->B, d->N, CL, ga.vL, params + off[Sg.out0(true) + 1], g_recon, gs.gv, part, gst));
+    dq.add(part, d->B, 2 * CL, 0, 2 * CL, grads + off[Sg.out0(true) + 1]);
+    LGN_TRY(gen_decoder_bwd(*d, params, grads, off, lat_v, ga, g_lat_v, gs, dq, fin, gst));
+    LGN_CHECK_ARG(dq.off <= dq.cap, "decoder_bwd: partial-row workspace overflow (%zu > %zu)", dq.off, dq.cap);
+    LGN_TRY(dq.flush(gst));
+    return 0;
+  }
+  NetAct a = carve_act(*d, true, const_cast<double*>(act));
+  NetScratch sc = carve_scratch(*d, true, scratch);
+  LGN_CHECK_ARG((long long)a.total <= act_doubles && (long long)sc.total <= scratch_doubles,
+                "decoder_bwd: buffers hold %lld / %lld doubles, need %zu / %zu", act_doubles, scratch_doubles, a.total, sc.total);
+  if (int rc = check_mlp_contiguous(*d, true, off)) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  Work& w = sc.w;
+  const Slots S{d->n_levels, d->mlp_nlin};
+  const int L = d->n_levels, B = d->B, N = d->N, Tin = d->tau_v_in > 0 ? d->tau_v_in : 2 * d->tau_v;
+  const int* cd = d->dec_channels;
+  LGN_TRY(zero_grads_and_block(grads, (size_t)n_params, w.zeros_s, w.zero_doubles, st));
+  Deferred dq;
+  dq.parts = w.parts;
+  dq.cap = w.parts_size;
+  RadFinJob fin{};
+  int cur = 0;
+  {
+    double* part = dq.take((size_t)B * 2 * cd[L]);
+    LGN_TRY(dec_output_bwd(B, N, cd[L], a.n.v[L], params + off[S.out0(true) + 1], g_recon, w.gv[cur], part, st));
+    dq.add(part, B, 2 * cd[L], 0, 2 * cd[L], grads + off[S.out0(true) + 1]);
+  }
+  LGN_TRY(levels_bwd(*d, true, cd, params, grads, off, a.n, a.pdec, nullptr, w, dq, fin, cur, /*has_s_grad=*/false, st));
+  {
+    const int C0 = cd[0], row = 4 * C0 + 2 * N * Tin;
+    double* part = dq.take((size_t)B * row);
+    LGN_TRY(dec_input_bwd(B, N, C0, Tin, lat_v, params + off[1], params + off[3], a.pdec, w.g_p, w.gs[cur], w.gv[cur], g_lat_v, part, st));
+    dq.add(part, B, row, 0, 2 * C0, grads + off[2]);
+    dq.add(part, B, row, 2 * C0, 2 * C0, grads + off[3]);
+    dq.add(part, B, row, 4 * C0, 2 * N * Tin, grads + off[1]);
+  }
+  LGN_CHECK_ARG(dq.off <= dq.cap, "decoder_bwd: partial-row workspace overflow (%zu > %zu)", dq.off, dq.cap);
+  LGN_TRY(dq.flush(st));
+  LGN_TRY(rad_finalize_batch(fin, st));
+  return 0;
+}
+
+}  // extern "C"
 
 extern "C" {
 
@@ -248,6 +876,10 @@ int lgn_step_param_slots(const lgn_net_desc* d, int decoder) {
 
 long long lgn_step_workspace_doubles(const lgn_net_desc* d) {
   if (check_desc(d)) return -1;
+  if (is_generic(*d, false) || is_generic(*d, true)) {
+    if (check_generic(*d, false) || check_generic(*d, true)) return -1;
+    return (long long)carve_gen_step(*d, nullptr).total;
+  }
   return (long long)carve(*d, nullptr).total;
 }
 
@@ -258,6 +890,9 @@ int lgn_step_fwd_bwd_f64(const lgn_net_desc* d, const double* params, double* gr
   LGN_CHECK_ARG(params && grads && enc_off && dec_off && p4 && target && mask && workspace && recon && loss_part && n_params > 0,
                 "step_fwd_bwd: null pointer");
   hipStream_t st = (hipStream_t)stream;
+  if (is_generic(*d, false) || is_generic(*d, true))
+    return gen_step_fwd_bwd(*d, params, grads, n_params, enc_off, dec_off, p4, target, mask, workspace, workspace_doubles, recon,
+                            loss_part, st);
   Work w = carve(*d, workspace);
   // the layout depends on run-time switches (LGN_AMD_DEC_PAIRWISE / LGN_AMD_LEVEL_V2 change the partial-row counts):
   // refuse before anything is enqueued if the caller sized the workspace under different settings
@@ -346,241 +981,6 @@ int lgn_step_finalize_f64(double* params, double* grads, long long n_params, con
   hipStream_t st = (hipStream_t)stream;
   LGN_TRY(finalize_step(params, grads, (long)n_params, loss_part, n_loss, l1_lambda, adam_m, adam_v, reinterpret_cast<long*>(step_dev),
                         lr, beta1, beta2, eps, do_adam, loss_out, st));
-  return 0;
-}
-
-}  // extern "C"
-
-// ---------------------------------------------------------------------------------------------------------
-// one network at a time (module API: LGNEncoder.forward / LGNDecoder.forward and their autograd backward)
-// ---------------------------------------------------------------------------------------------------------
-namespace lgn {
-namespace {
-
-struct NetAct {                     // written by *_fwd, read by *_bwd
-  NetBuf n;
-  double* pdec;                     // decoder: complex canonical positions [2][B][N][4]
-  int* idx;                         // encoder: pooling indices
-  size_t total;
-};
-NetAct carve_act(const lgn_net_desc& d, bool dec, double* base) {
-  NetAct a{};
-  Bump b{base};
-  const size_t BN = (size_t)d.B * d.N;
-  const int* ch = dec ? d.dec_channels : d.enc_channels;
-  for (int l = 0; l <= d.n_levels; ++l) {
-    a.n.s[l] = b.take(2 * BN * ch[l]);
-    a.n.v[l] = b.take(8 * BN * ch[l]);
-  }
-  for (int l = 0; l < d.n_levels; ++l) {
-    a.n.smix[l] = b.take(2 * BN * ch[l + 1]);
-    a.n.ag0[l] = b.take(4 * BN * ch[l]);
-    a.n.ag1[l] = b.take(16 * BN * ch[l]);
-  }
-  if (dec) a.pdec = b.take(8 * BN);
-  else a.idx = reinterpret_cast<int*>(b.take(((size_t)d.B * 2 * (d.tau_s + d.tau_v) * 2 + 1) / 2 + 8));
-  a.total = b.off;
-  return a;
-}
-
-struct NetScratch {                 // backward only
-  Work w;                           // gs, gv, gsmix, g_ag, zeros_s, g_p, g_lat_s (zero block), tot, parts
-  size_t total;
-};
-NetScratch carve_scratch(const lgn_net_desc& d, bool dec, double* base) {
-  NetScratch s{};
-  Work& w = s.w;
-  Bump b{base};
-  const size_t BN = (size_t)d.B * d.N;
-  const int L = d.n_levels, Ts = d.tau_s, Tv = d.tau_v;
-  const int* ch = dec ? d.dec_channels : d.enc_channels;
-  int cmax = 0;
-  for (int l = 0; l <= L; ++l) cmax = cmax > ch[l] ? cmax : ch[l];
-  {  // zero-initialised block FIRST: a caller that places `grads` right in front of the scratch gets one memset for both
-    const size_t z0 = b.off;
-    w.zeros_s = b.take(2 * BN * cmax);
-    w.g_p = b.take(dec ? 8 * BN : 0);
-    w.g_lat_s = b.take(dec ? 0 : (size_t)2 * d.B * 2 * Ts);
-    w.zero_doubles = b.off - z0;
-  }
-  for (int q = 0; q < 2; ++q) {
-    w.gs[q] = b.take(2 * BN * cmax);
-    w.gv[q] = b.take(8 * BN * cmax);
-  }
-  w.gsmix = b.take(2 * BN * cmax);
-  w.g_ag = b.take(20 * BN * cmax);
-  size_t psum = 0;
-  for (int l = 0; l < L; ++l) {
-    int rm, rr;
-    level_bwd_partial_rows(d.B, d.N, dec, &rm, &rr);
-    const size_t nmix = (size_t)4 * ch[l + 1] * 5 * ch[l], nrad = rad_partial_size(ch[l], dec);
-    psum += ((rm * nmix + 15) & ~size_t(15)) + ((rr * nrad + 15) & ~size_t(15));
-    psum += ((size_t)mlp_partial_rows((int)BN) * mlp_psize(ch[l + 1], d.mlp_hidden_mul * 2 * ch[l + 1], d.mlp_nlin) + 15) & ~size_t(15);
-    w.tot[dec ? 1 : 0][l] = b.take(nrad + 16);
-  }
-  // input / output ends: decoder  B x (2 C_L) + B x (4 C_0 + 2 N Tin);  encoder  B x 2 (Ts + Tv) C_L + B x 4 C_0
-  const int Tin = d.tau_v_in > 0 ? d.tau_v_in : 2 * Tv;
-  if (dec) psum += (((size_t)d.B * 2 * ch[L] + 15) & ~size_t(15)) + (((size_t)d.B * (4 * ch[0] + 2 * (size_t)d.N * Tin) + 15) & ~size_t(15));
-  else psum += (((size_t)d.B * 2 * (Ts + Tv) * ch[L] + 15) & ~size_t(15)) + (((size_t)d.B * 4 * ch[0] + 15) & ~size_t(15));
-  w.parts = b.take(psum);
-  w.parts_size = psum;
-  s.total = b.off;
-  return s;
-}
-
-// grads [n] and the zero block [nz]: one memset when the caller laid them out back to back (lgn/ops.py does)
-int zero_grads_and_block(double* grads, size_t n, double* zeros, size_t nz, hipStream_t st) {
-  if (zeros >= grads + n && zeros <= grads + n + 16) {
-    HIPOK(hipMemsetAsync(grads, 0, sizeof(double) * (size_t)((zeros + nz) - grads), st));
-  } else {
-    HIPOK(hipMemsetAsync(grads, 0, sizeof(double) * n, st));
-    HIPOK(hipMemsetAsync(zeros, 0, sizeof(double) * nz, st));
-  }
-  return 0;
-}
-
-int check_mlp_contiguous(const lgn_net_desc& d, bool dec, const int64_t* off) {
-  const Slots S{d.n_levels, d.mlp_nlin};
-  const int* ch = dec ? d.dec_channels : d.enc_channels;
-  for (int l = 0; l < d.n_levels; ++l) {
-    const int D = 2 * ch[l + 1], H = d.mlp_hidden_mul * D;
-    int64_t expect = off[S.mlp(dec, l, 0)];
-    for (int q = 0; q < d.mlp_nlin; ++q) {
-      const int hin = q == 0 ? D : H, hout = q == d.mlp_nlin - 1 ? D : H;
-      LGN_CHECK_ARG(off[S.mlp(dec, l, 2 * q)] == expect, "MLP weights are not contiguous in the flat parameter buffer");
-      expect += (int64_t)hin * hout;
-      LGN_CHECK_ARG(off[S.mlp(dec, l, 2 * q + 1)] == expect, "MLP biases are not contiguous in the flat parameter buffer");
-      expect += hout;
-    }
-  }
-  return 0;
-}
-
-}  // namespace
-}  // namespace lgn
-
-extern "C" {
-
-long long lgn_net_workspace_doubles(const lgn_net_desc* d, int decoder, int which) {
-  if (check_desc(d)) return -1;
-  return which == 0 ? (long long)carve_act(*d, decoder != 0, nullptr).total : (long long)carve_scratch(*d, decoder != 0, nullptr).total;
-}
-
-int lgn_encoder_fwd_f64(const lgn_net_desc* d, const double* params, const int64_t* off, const double* p4, const uint8_t* mask,
-                        double* act, long long act_doubles, double* lat_s, double* lat_v, void* stream) {
-  if (int rc = check_desc(d)) return rc;
-  LGN_CHECK_ARG(params && off && p4 && mask && act && lat_s && lat_v, "encoder_fwd: null pointer");
-  NetAct a = carve_act(*d, false, act);
-  LGN_CHECK_ARG((long long)a.total <= act_doubles, "encoder_fwd: activation buffer holds %lld doubles, needs %zu", act_doubles, a.total);
-  hipStream_t st = (hipStream_t)stream;
-  const Slots S{d->n_levels, d->mlp_nlin};
-  const int L = d->n_levels;
-  const int* ce = d->enc_channels;
-  LGN_TRY(enc_input_fwd(d->B, d->N, ce[0], p4, params + off[0], params + off[1], a.n.s[0], a.n.v[0], st));
-  LGN_TRY(levels_fwd(*d, false, ce, params, off, a.n, p4, mask, st));
-  LGN_TRY(enc_latent_fwd(d->B, d->N, ce[L], d->tau_s, d->tau_v, a.n.s[L], a.n.v[L], params + off[S.out0(false)],
-                         params + off[S.out0(false) + 1], lat_s, lat_v, a.idx, st));
-  return 0;
-}
-
-int lgn_encoder_bwd_f64(const lgn_net_desc* d, const double* params, double* grads, long long n_params, const int64_t* off,
-                        const double* p4, const uint8_t* mask, const double* act, long long act_doubles, const double* g_lat_s,
-                        const double* g_lat_v, double* scratch, long long scratch_doubles, void* stream) {
-  if (int rc = check_desc(d)) return rc;
-  LGN_CHECK_ARG(params && grads && off && p4 && mask && act && g_lat_v && scratch && n_params > 0, "encoder_bwd: null pointer");
-  NetAct a = carve_act(*d, false, const_cast<double*>(act));
-  NetScratch sc = carve_scratch(*d, false, scratch);
-  LGN_CHECK_ARG((long long)a.total <= act_doubles && (long long)sc.total <= scratch_doubles,
-                "encoder_bwd: buffers hold %lld / %lld doubles, need %zu / %zu", act_doubles, scratch_doubles, a.total, sc.total);
-  if (int rc = check_mlp_contiguous(*d, false, off)) return rc;
-  hipStream_t st = (hipStream_t)stream;
-  Work& w = sc.w;
-  const Slots S{d->n_levels, d->mlp_nlin};
-  const int L = d->n_levels, B = d->B, N = d->N, Ts = d->tau_s, Tv = d->tau_v;
-  const int* ce = d->enc_channels;
-  LGN_TRY(zero_grads_and_block(grads, (size_t)n_params, w.zeros_s, w.zero_doubles, st));
-  Deferred dq;
-  dq.parts = w.parts;
-  dq.cap = w.parts_size;
-  RadFinJob fin{};
-  int cur = 0;
-  {
-    const int CL = ce[L], rowe = 2 * (Ts + Tv) * CL;
-    double* parte = dq.take((size_t)B * rowe);
-    LGN_TRY(enc_latent_bwd(B, N, CL, Ts, Tv, a.n.s[L], a.n.v[L], params + off[S.out0(false)], params + off[S.out0(false) + 1],
-                           g_lat_s ? g_lat_s : w.g_lat_s, g_lat_v, a.idx, w.gs[cur], w.gv[cur], parte, st));
-    dq.add(parte, B, rowe, 0, 2 * Ts * CL, grads + off[S.out0(false)]);
-    dq.add(parte, B, rowe, 2 * Ts * CL, 2 * Tv * CL, grads + off[S.out0(false) + 1]);
-  }
-  // without an upstream gradient on the latent scalars the last level's scalars (and its CGMLP) receive none
-  LGN_TRY(levels_bwd(*d, false, ce, params, grads, off, a.n, p4, mask, w, dq, fin, cur, /*has_s_grad=*/g_lat_s != nullptr, st));
-  {
-    const int C0 = ce[0];
-    double* part = dq.take((size_t)B * 4 * C0);
-    LGN_TRY(enc_input_bwd(B, N, C0, p4, w.gs[cur], w.gv[cur], part, st));
-    dq.add(part, B, 4 * C0, 0, 2 * C0, grads + off[0]);
-    dq.add(part, B, 4 * C0, 2 * C0, 2 * C0, grads + off[1]);
-  }
-  LGN_CHECK_ARG(dq.off <= dq.cap, "encoder_bwd: partial-row workspace overflow (%zu > %zu)", dq.off, dq.cap);
-  LGN_TRY(dq.flush(st));
-  LGN_TRY(rad_finalize_batch(fin, st));
-  return 0;
-}
-
-int lgn_decoder_fwd_f64(const lgn_net_desc* d, const double* params, const int64_t* off, const double* lat_v, double* act,
-                        long long act_doubles, double* recon, void* stream) {
-  if (int rc = check_desc(d)) return rc;
-  LGN_CHECK_ARG(params && off && lat_v && act && recon, "decoder_fwd: null pointer");
-  NetAct a = carve_act(*d, true, act);
-  LGN_CHECK_ARG((long long)a.total <= act_doubles, "decoder_fwd: activation buffer holds %lld doubles, needs %zu", act_doubles, a.total);
-  hipStream_t st = (hipStream_t)stream;
-  const Slots S{d->n_levels, d->mlp_nlin};
-  const int L = d->n_levels, Tin = d->tau_v_in > 0 ? d->tau_v_in : 2 * d->tau_v;
-  const int* cd = d->dec_channels;
-  LGN_TRY(dec_input_fwd(d->B, d->N, cd[0], Tin, lat_v, params + off[1], params + off[2], params + off[3], a.pdec, a.n.s[0], a.n.v[0], st));
-  LGN_TRY(levels_fwd(*d, true, cd, params, off, a.n, a.pdec, nullptr, st));
-  LGN_TRY(dec_output_fwd(d->B, d->N, cd[L], a.n.v[L], params + off[S.out0(true) + 1], recon, st));
-  return 0;
-}
-
-int lgn_decoder_bwd_f64(const lgn_net_desc* d, const double* params, double* grads, long long n_params, const int64_t* off,
-                        const double* lat_v, const double* act, long long act_doubles, const double* g_recon, double* g_lat_v,
-                        double* scratch, long long scratch_doubles, void* stream) {
-  if (int rc = check_desc(d)) return rc;
-  LGN_CHECK_ARG(params && grads && off && lat_v && act && g_recon && g_lat_v && scratch && n_params > 0, "decoder_bwd: null pointer");
-  NetAct a = carve_act(*d, true, const_cast<double*>(act));
-  NetScratch sc = carve_scratch(*d, true, scratch);
-  LGN_CHECK_ARG((long long)a.total <= act_doubles && (long long)sc.total <= scratch_doubles,
-                "decoder_bwd: buffers hold %lld / %lld doubles, need %zu / %zu", act_doubles, scratch_doubles, a.total, sc.total);
-  if (int rc = check_mlp_contiguous(*d, true, off)) return rc;
-  hipStream_t st = (hipStream_t)stream;
-  Work& w = sc.w;
-  const Slots S{d->n_levels, d->mlp_nlin};
-  const int L = d->n_levels, B = d->B, N = d->N, Tin = d->tau_v_in > 0 ? d->tau_v_in : 2 * d->tau_v;
-  const int* cd = d->dec_channels;
-  LGN_TRY(zero_grads_and_block(grads, (size_t)n_params, w.zeros_s, w.zero_doubles, st));
-  Deferred dq;
-  dq.parts = w.parts;
-  dq.cap = w.parts_size;
-  RadFinJob fin{};
-  int cur = 0;
-  {
-    double* part = dq.take((size_t)B * 2 * cd[L]);
-    LGN_TRY(dec_output_bwd(B, N, cd[L], a.n.v[L], params + off[S.out0(true) + 1], g_recon, w.gv[cur], part, st));
-    dq.add(part, B, 2 * cd[L], 0, 2 * cd[L], grads + off[S.out0(true) + 1]);
-  }
-  LGN_TRY(levels_bwd(*d, true, cd, params, grads, off, a.n, a.pdec, nullptr, w, dq, fin, cur, /*has_s_grad=*/false, st));
-  {
-    const int C0 = cd[0], row = 4 * C0 + 2 * N * Tin;
-    double* part = dq.take((size_t)B * row);
-    LGN_TRY(dec_input_bwd(B, N, C0, Tin, lat_v, params + off[1], params + off[3], a.pdec, w.g_p, w.gs[cur], w.gv[cur], g_lat_v, part, st));
-    dq.add(part, B, row, 0, 2 * C0, grads + off[2]);
-    dq.add(part, B, row, 2 * C0, 2 * C0, grads + off[3]);
-    dq.add(part, B, row, 4 * C0, 2 * N * Tin, grads + off[1]);
-  }
-  LGN_CHECK_ARG(dq.off <= dq.cap, "decoder_bwd: partial-row workspace overflow (%zu > %zu)", dq.off, dq.cap);
-  LGN_TRY(dq.flush(st));
-  LGN_TRY(rad_finalize_batch(fin, st));
   return 0;
 }
 

@@ -39,13 +39,6 @@ _SIGNATURES = {
 }
 
 
-class NetDesc(C.Structure):
-    """lgn_net_desc of include/lgn_amd.h."""
-    _fields_ = [("B", C.c_int), ("N", C.c_int), ("n_levels", C.c_int), ("enc_channels", C.c_int * 5),
-                ("dec_channels", C.c_int * 5), ("tau_s", C.c_int), ("tau_v", C.c_int), ("mlp_hidden_mul", C.c_int),
-                ("mlp_nlin", C.c_int), ("tau_v_in", C.c_int)]
-
-
 class LocalTables(C.Structure):
     """lgn_local_tables of include/lgn_amd.h (device pointers)."""
     _fields_ = [("n_rows", C.c_int), ("n_out", C.c_int), ("n_w", C.c_int), ("n_terms", C.c_int), ("n_u", C.c_int),
@@ -54,8 +47,20 @@ class LocalTables(C.Structure):
                                         "out_w0", "u_ptr", "u_row", "u_coef", "x_ptr", "x_row", "x_other", "x_coef")]
 
 
-_dp = C.POINTER(NetDesc)
 _tp = C.POINTER(LocalTables)
+
+
+class NetDesc(C.Structure):
+    """lgn_net_desc of include/lgn_amd.h."""
+    _fields_ = [("B", C.c_int), ("N", C.c_int), ("n_levels", C.c_int), ("enc_channels", C.c_int * 5),
+                ("dec_channels", C.c_int * 5), ("tau_s", C.c_int), ("tau_v", C.c_int), ("mlp_hidden_mul", C.c_int),
+                ("mlp_nlin", C.c_int), ("tau_v_in", C.c_int),
+                ("enc_tables", _tp * 4), ("dec_tables", _tp * 4),
+                ("enc_Q", C.c_int * 5), ("enc_qs", C.c_int * 5), ("enc_qv", C.c_int * 5),
+                ("dec_Q", C.c_int * 5), ("dec_qs", C.c_int * 5), ("dec_qv", C.c_int * 5)]
+
+
+_dp = C.POINTER(NetDesc)
 _ll = C.c_longlong
 _d = C.c_double
 _SIGNATURES.update({

@@ -93,21 +93,8 @@ class LGNEncoder(CGModule, LevelTablesMixin):
             self._bind(self._p_views)
 
     def _fused_ok(self) -> bool:
-        ok = self.__dict__.get("_fused")
-        if ok is None:
-            from ..plan import check_maxdim2_layout
-            ok = (self.map_to_latent == "min&max" and bool(self.mlp) and self.mlp_depth == 6 and self.num_basis_fn == 10
-                  and 1 <= self.num_cg_levels <= 4 and all(m == 2 for m in self.level_maxdim)
-                  and all(1 <= c <= 8 for c in self.num_channels)
-                  and self.mlp_width * 2 * max(self.num_channels[1:]) <= 96)
-            if ok:
-                try:
-                    for plan in self.plans:
-                        check_maxdim2_layout(plan)
-                except RuntimeError:
-                    ok = False
-            self.__dict__["_fused"] = ok
-        return ok
+        """True when a whole-network native implementation covers this configuration (lgn/ops.py: native_kind)."""
+        return ops.native_kind(self) is not None
 
     def _forward_modular(self, node_ps, node_mask, covariance_test):
         # input features: (0,0) = (sqrt|p^2|, 0), (1,1) = canonical(p)   (lgn_encoder.py:287-293,376)

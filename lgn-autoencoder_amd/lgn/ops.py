@@ -238,8 +238,38 @@ class GenericLevelFn(torch.autograd.Function):
 # whole networks: one native call per direction (csrc/step.hip: lgn_encoder_* / lgn_decoder_*)
 # ---------------------------------------------------------------------------------------------
 
+def native_kind(net):
+    """Which whole-network native implementation (csrc/step.hip) covers this network: 'fused' (every level is the
+    maxdim = 2 closed form), 'generic' (table-driven levels, e.g. maxdim = 3) or None (per-operator autograd path only)."""
+    kind = net.__dict__.get("_native_kind", 0)
+    if kind == 0:
+        from .plan import check_maxdim2_layout
+        ok = (bool(net.mlp) and net.mlp_depth == 6 and net.num_basis_fn == 10 and 1 <= net.num_cg_levels <= 4
+              and all(1 <= c <= 8 for c in net.num_channels) and net.mlp_width * 2 * max(net.num_channels[1:]) <= 96
+              and (not hasattr(net, "map_to_latent") or net.map_to_latent == "min&max"))
+        kind = None
+        if ok:
+            fused = all(m == 2 for m in net.level_maxdim)
+            if fused:
+                try:
+                    for plan in net.plans:
+                        check_maxdim2_layout(plan)
+                except RuntimeError:
+                    fused = False
+            if fused:
+                kind = "fused"
+            else:
+                p0 = net.plans[0]
+                if sorted(p0.node_order) == [(0, 0), (1, 1)] and all((0, 0) in p.out_order and (1, 1) in p.out_order for p in net.plans):
+                    kind = "generic"
+        net.__dict__["_native_kind"] = kind
+    return kind
+
+
 def slot_tensors(net, decoder: bool):
-    """Parameter views of a network in the slot order of include/lgn_amd.h (lgn_step_fwd_bwd_f64)."""
+    """Parameter views of a network in the slot order of include/lgn_amd.h (lgn_step_fwd_bwd_f64).  Table-driven levels
+    have one CatMix base per level (the lowest-addressed weight of the level, twice: the second slot is ignored)."""
+    generic = native_kind(net) == "generic"
     out = []
     if decoder:
         out += [net.latent_to_graph.weight((0, 0)), net.latent_to_graph.weight((1, 1))]
@@ -247,12 +277,60 @@ def slot_tensors(net, decoder: bool):
     for rf in net.rad_funcs.rad_funcs:
         out += rf.flat_params()
     for lvl in net.lgn_cg.node_levels:
-        out += [lvl.cat_mix.mix_reps.weight((0, 0)), lvl.cat_mix.mix_reps.weight((1, 1))]
+        mix = lvl.cat_mix.mix_reps
+        if generic:
+            first = min((mix.weight(r) for r in lvl.plan.out_order), key=lambda t: t.data_ptr())
+            out += [first, first]
+        else:
+            out += [mix.weight((0, 0)), mix.weight((1, 1))]
     for mlp in net.lgn_cg.mlp_levels:
         out += mlp.flat_params()
     last = net.mix_to_output if decoder else net.mix_reps
     out += [last.weight((0, 0)), last.weight((1, 1))]
     return out
+
+
+def flat_level_tables(net, lvl: int):
+    """Device tables of a table-driven level whose CatMix weight offsets point into the network's flat parameter block
+    (relative to the level's lowest-addressed CatMix weight); cached until the block moves."""
+    from .plan import build_local_tables
+    net._check_views()
+    cache = net.__dict__.setdefault("_native_cache", {})
+    key = ("tables", lvl)
+    if key not in cache:
+        mix = net.lgn_cg.node_levels[lvl].cat_mix.mix_reps
+        plan = net.plans[lvl]
+        base = min(mix.weight(r).data_ptr() for r in plan.out_order)
+        offs = {r: (mix.weight(r).data_ptr() - base) // 8 for r in plan.out_order}
+        cache[key] = N.DeviceTables(build_local_tables(plan, net.cg_dict, weight_offsets=offs), net.flat_params.device)
+    return cache[key]
+
+
+def describe_network(d, net, decoder: bool):
+    """Fill the per-network part of an lgn_net_desc (channels, latent sizes, and for table-driven networks the level tables
+    and packed-component layout).  Returns objects that must stay alive as long as the descriptor is used."""
+    from .plan import packed_offsets
+    keep = []
+    ch = d.dec_channels if decoder else d.enc_channels
+    for i, c in enumerate(net.num_channels):
+        ch[i] = c
+    if decoder:
+        d.tau_v_in = net.tau_latent_vectors
+    else:
+        d.tau_s, d.tau_v = net.tau_latent[(0, 0)], net.tau_latent[(1, 1)]
+    if native_kind(net) == "generic":
+        tabs = d.dec_tables if decoder else d.enc_tables
+        Q, qs, qv = (d.dec_Q, d.dec_qs, d.dec_qv) if decoder else (d.enc_Q, d.enc_qs, d.enc_qv)
+        orders = [net.plans[0].node_order] + [p.out_order for p in net.plans]
+        for l, order in enumerate(orders):
+            off, q = packed_offsets(order)
+            Q[l], qs[l], qv[l] = q, off[(0, 0)], off[(1, 1)]
+        import ctypes as C
+        for l in range(net.num_cg_levels):
+            t = flat_level_tables(net, l)
+            keep.append(t)
+            tabs[l] = C.pointer(t.struct)
+    return keep
 
 
 class NetHandle:
@@ -262,18 +340,12 @@ class NetHandle:
         import ctypes as C
         d = N.NetDesc()
         d.B, d.n_levels = B, net.num_cg_levels
-        ch = d.dec_channels if decoder else d.enc_channels
-        for i, c in enumerate(net.num_channels):
-            ch[i] = c
         other = d.enc_channels if decoder else d.dec_channels
         for i in range(len(net.num_channels)):
             other[i] = 1
-        if decoder:
-            d.N = net.num_output_particles
-            d.tau_s, d.tau_v, d.tau_v_in = 1, 1, net.tau_latent_vectors
-        else:
-            d.N = net.num_input_particles
-            d.tau_s, d.tau_v, d.tau_v_in = net.tau_latent[(0, 0)], net.tau_latent[(1, 1)], 0
+        d.N = net.num_output_particles if decoder else net.num_input_particles
+        d.tau_s, d.tau_v, d.tau_v_in = 1, 1, 0
+        self.keep = describe_network(d, net, decoder)
         d.mlp_hidden_mul, d.mlp_nlin = net.mlp_width, net.mlp_depth + 1
         lib = N.lib()
         slots = slot_tensors(net, decoder)

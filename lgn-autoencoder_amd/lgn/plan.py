@@ -152,7 +152,16 @@ def irrep_dim(r: Irrep) -> int:
     return (r[0] + 1) * (r[1] + 1)
 
 
-def build_local_tables(plan: LevelPlan, cg_dict, tol: float = 1e-14):
+def packed_offsets(order: Sequence[Irrep]) -> Tuple[Dict[Irrep, int], int]:
+    """Component offset of every irrep inside a packed feature vector with the irreps in ``order``; total length Q."""
+    off, q = {}, 0
+    for r in order:
+        off[r] = q
+        q += irrep_dim(r)
+    return off, q
+
+
+def build_local_tables(plan: LevelPlan, cg_dict, tol: float = 1e-14, weight_offsets: Dict[Irrep, int] = None):
     """Flatten (aggregate CG, power CG, concatenation) of one level into CSR term lists for
     csrc/generic_local.hip (struct lgn_local_tables of include/lgn_amd.h).
 
@@ -162,7 +171,12 @@ def build_local_tables(plan: LevelPlan, cg_dict, tol: float = 1e-14):
       type 1: node component X[q]                                                             -- node block
       type 2: products X[q1] X[q2]                                                            -- power blocks
     with the Clebsch-Gordan coefficient as weight (reference: the CG matmul of cg_ops.py:195-204 applied to the
-    Kronecker index m1*d2 + m2 of cg_ops.py:281-288)."""
+    Kronecker index m1*d2 + m2 of cg_ops.py:281-288).
+
+    ``weight_offsets`` ({irrep: offset in doubles of its CatMix weight (2, CO, K) from the level's weight base}): where the
+    kernels find each irrep's weights (and write its gradient partials).  Default: the weights concatenated in
+    ``plan.out_order`` (what the per-operator autograd path passes); the whole-network native calls give the offsets
+    inside the flat parameter block instead, so that nothing is gathered or scattered at run time."""
     import numpy as np
     qoff, q = {}, 0
     for r in plan.node_order:
@@ -177,7 +191,8 @@ def build_local_tables(plan: LevelPlan, cg_dict, tol: float = 1e-14):
     for L in out_irreps:
         d = irrep_dim(L)
         blocks = plan.cat_blocks[L]
-        out_dim.append(d); out_nblk.append(len(blocks)); out_row0.append(nrows); out_q0.append(qo); out_w0.append(2 * wbase)
+        out_dim.append(d); out_nblk.append(len(blocks)); out_row0.append(nrows); out_q0.append(qo)
+        out_w0.append(2 * wbase if weight_offsets is None else int(weight_offsets[L]))
         qo += d
         wbase += CO * len(blocks) * C
         for (src, r1, r2) in blocks:

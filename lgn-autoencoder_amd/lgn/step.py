@@ -175,13 +175,16 @@ class NativeTrainStep:
         import ctypes as C
         from . import _native as N
         self.N = N
-        if not (encoder._fused_ok() and decoder._fused_ok()):
-            # lgn_step_fwd_bwd_f64 is the maxdim = 2 closed form: [2][CO][5C] CatMix weights, 20 radial basis functions,
-            # 7-layer CGMLPs.  Anything else would be read with the wrong layout -> refuse instead of computing garbage.
+        from .ops import native_kind as _kind
+        if _kind(encoder) is None or _kind(encoder) != _kind(decoder):
+            # lgn_step_fwd_bwd_f64 covers networks whose levels are all the fused maxdim=2 closed form or all table driven
+            # (maxdim=3), with 20 radial basis functions and 7-layer CGMLPs.  Anything else would be read with the wrong
+            # layout -> refuse instead of computing garbage.
             raise NotImplementedError(
-                "the native step implements maxdim=2 networks with map_to_latent='min&max', CGMLP levels (mlp_depth=6), "
-                f"num_basis_fn=10 and <= 8 channels; got encoder maxdim={encoder.level_maxdim} map_to_latent="
-                f"{encoder.map_to_latent!r} mlp={encoder.mlp}, decoder maxdim={decoder.level_maxdim} mlp={decoder.mlp}")
+                "the native step implements maxdim=2 / maxdim=3 networks (the same kind for encoder and decoder) with "
+                "map_to_latent='min&max', CGMLP levels (mlp_depth=6), num_basis_fn=10 and <= 8 channels; got encoder "
+                f"maxdim={encoder.level_maxdim} map_to_latent={encoder.map_to_latent!r} mlp={encoder.mlp} mlp_depth="
+                f"{encoder.mlp_depth}, decoder maxdim={decoder.level_maxdim} mlp={decoder.mlp}")
         encoder._require_gpu()
         self.encoder, self.decoder = encoder, decoder
         self.l1_lambda, self.lr, self.betas, self.eps = l1_lambda, lr, betas, eps
@@ -195,13 +198,11 @@ class NativeTrainStep:
         dev, dt = self.flat.flat.device, self.flat.flat.dtype
         L = encoder.num_cg_levels
         d = N.NetDesc()
+        from .ops import describe_network, native_kind
         d.B, d.N, d.n_levels = batch_size, encoder.num_input_particles, L
-        for i, c in enumerate(encoder.num_channels):
-            d.enc_channels[i] = c
-        for i, c in enumerate(decoder.num_channels):
-            d.dec_channels[i] = c
-        d.tau_s, d.tau_v = encoder.tau_latent[(0, 0)], encoder.tau_latent[(1, 1)]
+        self._keep = describe_network(d, encoder, False) + describe_network(d, decoder, True)    # (after FlatParams re-homed the blocks)
         d.mlp_hidden_mul, d.mlp_nlin = encoder.mlp_width, encoder.mlp_depth + 1
+        fused = native_kind(encoder) == "fused"
         if decoder.tau_latent_vectors != 2 * d.tau_v or decoder.num_output_particles != d.N:
             raise ValueError("decoder latent size / particle count does not match the encoder (min&max doubles tau)")
         self.desc = d
@@ -217,7 +218,7 @@ class NativeTrainStep:
             ch = net.num_channels
             for l in range(L):                   # sizes the kernels assume for the per-level slots
                 mix0 = ts[(2 if dec else 0) + 2 + 7 * L + 2 * l]
-                assert mix0.numel() == 2 * ch[l + 1] * 5 * ch[l], "CatMix weight is not [2][CO][5C]: not a maxdim=2 level"
+                assert not fused or mix0.numel() == 2 * ch[l + 1] * 5 * ch[l], "CatMix weight is not [2][CO][5C]: not a maxdim=2 level"
                 ra = ts[(2 if dec else 0) + 2 + 7 * l]
                 assert ra.numel() == 20, "radial network must have 2 * num_basis_fn = 20 basis functions"
             offs = [(t.data_ptr() - base) // 8 for t in ts]

@@ -176,11 +176,18 @@ def test_flat_parameter_block_keeps_the_reference_state_dict_surface():
 
 def test_native_step_refuses_configurations_it_does_not_implement():
     """lgn_step_fwd_bwd_f64 is the maxdim = 2 closed form; a maxdim = 3 (or non min&max) network must be refused on the
-    host instead of being read with the wrong weight layout (checked before any GPU requirement)."""
+    host instead of being read with the wrong weight layout (checked before any GPU requirement).  (maxdim = 3 networks are
+    covered by the table-driven native step since round 2.)"""
     import __graft_entry__ as G
     from lgn.step import NativeTrainStep
-    enc, dec = G._models(30, (4, 4, 6, 6), (6, 6, 4, 4), torch.device("cpu"), seed=0, maxdim=3)
-    with pytest.raises(NotImplementedError, match="maxdim=2"):
+    enc, _ = G._models(30, (4, 4, 6, 6), (6, 6, 4, 4), torch.device("cpu"), seed=0, maxdim=3)
+    _, dec = G._models(30, (4, 4, 6, 6), (6, 6, 4, 4), torch.device("cpu"), seed=0, maxdim=2)
+    with pytest.raises(NotImplementedError, match="same kind"):       # mixed fused / table-driven networks
+        NativeTrainStep(enc, dec, batch_size=4)
+    enc, dec = G._models(30, (3, 3, 4, 4), (4, 4, 3, 3), torch.device("cpu"), seed=0)
+    enc.mlp_depth = 5                                                   # the native CGMLP is the 7-Linear stack only
+    enc.__dict__.pop("_native_kind", None)
+    with pytest.raises(NotImplementedError, match="mlp_depth"):
         NativeTrainStep(enc, dec, batch_size=4)
     enc, dec = G._models(12, (3, 3, 4, 4), (4, 4, 3, 3), torch.device("cpu"), seed=0, map_to_latent="mean+max")
     with pytest.raises(NotImplementedError, match="min&max"):
