@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LGN_AMD_ABI_VERSION 3   /* bump on ANY struct or signature change (lgn/_native.py: ABI_VERSION) */
+#define LGN_AMD_ABI_VERSION 4   /* bump on ANY struct or signature change (lgn/_native.py: ABI_VERSION) */
 
 int lgn_abi_version(void);
 const char* lgn_last_error(void);
@@ -117,11 +117,14 @@ int lgn_mixreps_bwd_f64(int rows, int Cin, int Cout, int d, const double* w, con
 int lgn_moments_fwd_f64(int B, int N, int C, int Q, int decoder, const double* X, const double* p, const uint8_t* mask,
                         const double* ra, const double* rb, const double* rc, const double* w0, const double* b0,
                         const double* w1, const double* b1, double* U, void* stream);
-/* gX [2][B][N][C][Q] and g_p (decoder) are ACCUMULATED into; part_rad [B][lgn_level_rad_partial_len(C, decoder)]. */
+/* gX [2][B][N][C][Q] and g_p (decoder) are ACCUMULATED into; part_rad [B][lgn_level_rad_partial_len(C, decoder)];
+ * scratch: lgn_moments_scratch_doubles(B, N, C, decoder) doubles (0 = none needed, NULL allowed: jets of up to 32 particles
+ * run channel-outermost kernels whose encoder radial backward parks the per-pair gradients there). */
+long long lgn_moments_scratch_doubles(int B, int N, int C, int decoder);
 int lgn_moments_bwd_f64(int B, int N, int C, int Q, int decoder, const double* X, const double* p, const uint8_t* mask,
                         const double* ra, const double* rb, const double* rc, const double* w0, const double* b0,
                         const double* w1, const double* b1, const double* gU, double* gX, double* g_p,
-                        double* part_rad, void* stream);
+                        double* part_rad, double* scratch, void* stream);
 
 typedef struct lgn_local_tables {
   int n_rows, n_out, n_w;          /* concatenated rows (irrep, block, m); output irreps; complex CatMix weights */

@@ -113,14 +113,18 @@ int lgn_moments_fwd_f64(int B, int N, int C, int Q, int decoder, const double* X
   return moments_dispatch(a, decoder, 0, (hipStream_t)stream);
 }
 
+long long lgn_moments_scratch_doubles(int B, int N, int C, int decoder) {
+  return (decoder || N > 32) ? 0 : (long long)moments2_gbuf_doubles(B, N, C);
+}
+
 int lgn_moments_bwd_f64(int B, int N, int C, int Q, int decoder, const double* X, const double* p, const uint8_t* mask,
                         const double* ra, const double* rb, const double* rc, const double* w0, const double* b0,
                         const double* w1, const double* b1, const double* gU, double* gX, double* g_p, double* part_rad,
-                        void* stream) {
+                        double* scratch, void* stream) {
   LGN_CHECK_ARG(X && p && b0 && b1 && gU && gX && part_rad, "moments_bwd: null pointer");
   LGN_CHECK_ARG(decoder ? (g_p != nullptr) : (mask && ra && rb && rc && w0 && w1), "moments_bwd: missing decoder g_p / encoder radial parameters");
   GenArgs a = gen_args(B, N, C, Q, X, p, mask, ra, rb, rc, w0, b0, w1, b1);
-  a.gU = gU; a.gX = gX; a.g_p = g_p; a.part_rad = part_rad;
+  a.gU = gU; a.gX = gX; a.g_p = g_p; a.part_rad = part_rad; a.gbuf = scratch;
   if (int rc2 = moments_dispatch(a, decoder, 1, (hipStream_t)stream)) return rc2;
   return moments_dispatch(a, decoder, 2, (hipStream_t)stream);
 }

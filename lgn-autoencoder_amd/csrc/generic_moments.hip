@@ -14,6 +14,8 @@
 // Mapping = level_fwd2 / level_bwd2: wave = 4 particles, tiles of 4 partners, lane = (pair slot, channel in group),
 // radial Linear layers on v_mfma_f64_16x16x4_f64; the component axis q is processed in chunks of QC so that the
 // accumulators stay in registers (the radial part is recomputed per chunk).
+#include <stdlib.h>
+
 #include "level_dev.hpp"
 #include "ops.hpp"
 
@@ -593,9 +595,19 @@ static int launch_moments(const GenArgs& a, int which, hipStream_t st) {
   return 0;
 }
 
-// which: 0 forward, 1 backward j-centric, 2 backward i-centric (one partial row per jet)
+bool moments2_fits(const GenArgs& a, int decoder);                                               // generic_moments2.hip
+int moments2_dispatch(const GenArgs& a, int decoder, int which, double* Gbuf, hipStream_t st);
+
+// which: 0 forward, 1 backward j-centric, 2 backward i-centric (one partial row per jet).
+// Jets that fit in LDS take the channel-outermost kernels of generic_moments2.hip (the encoder's i-centric pass then needs
+// a.gbuf, moments2_gbuf_doubles(B, N, C) doubles of scratch); LGN_AMD_MOMENTS_V1=1 keeps this file's kernels.
 int moments_dispatch(const GenArgs& a, int decoder, int which, hipStream_t st) {
   LGN_CHECK_ARG(a.B > 0 && a.N > 0 && a.Q > 0, "moments: empty input (B=%d N=%d Q=%d)", a.B, a.N, a.Q);
+  {
+    const char* e = getenv("LGN_AMD_MOMENTS_V1");
+    const bool v1 = e && e[0] == '1';
+    if (!v1 && moments2_fits(a, decoder) && (decoder || which != 2 || a.gbuf)) return moments2_dispatch(a, decoder, which, a.gbuf, st);
+  }
 #define LGN_CASE(CC) case CC: return decoder ? launch_moments<CC, true>(a, which, st) : launch_moments<CC, false>(a, which, st);
   switch (a.C) {
     LGN_CASE(1) LGN_CASE(2) LGN_CASE(3) LGN_CASE(4) LGN_CASE(5) LGN_CASE(6) LGN_CASE(7) LGN_CASE(8)

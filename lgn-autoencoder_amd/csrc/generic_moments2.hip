@@ -1,0 +1,622 @@
+// lgn-autoencoder_amd/csrc/generic_moments2.hip -- the N^2 part of a table-driven level (see generic_moments.hip for the
+// operator), v2 for jets that fit in LDS (N <= 40): CHANNEL-OUTERMOST sweeps.
+//
+// v1 keeps all channels of a 16-pair tile in flight (lane = (pair, channel group)) and therefore has to cut the component
+// axis q into chunks of 5 -- the radial network is evaluated once per chunk (4x at maxdim 3) -- and its backward kernels read
+// the 200 doubles of dU of every (pair, channel) straight from global memory, i.e. N times each.  Here a workgroup owns a jet
+// and loops over the channels; per channel c it
+//   1. evaluates the radial functions of all N^2 pairs once into LDS:  R[i][j] = (R0r, R0i, R1r, R1i)    (one thread per pair)
+//   2. stages that channel's slice of the features / of dU in LDS (10 KB / 48 KB at N = 30, Q = 20)
+//   3. sweeps the pairs with every lane owning COMPLETE sums: wave = group of QPT components, lane = (row, half of the partner
+//      range); the two halves meet by one DPP add at the end.  No quad reductions, no idle channel slots, no re-reads.
+// Forward:   U[i][c][q][k]  = sum_j X_j[c][q] e_k(i,j)[c]
+// Backward:  dX[j][c][q]   += sum_i sum_k dU[i][c][q][k] conj(e_k(i,j)[c])                           (j-centric sweep)
+//            G_k(i,j)[c]    = sum_q dU[i][c][q][k] conj(X_j[c][q])  ->  G_R0, G_R1 of the pair          (i-centric sweep)
+//            encoder: G_R0 / G_R1 go to a global buffer [B][N*N][4C] consumed by the radial-parameter reduction kernel
+//            (the [4C x pairs] . [pairs x 42] matrix-core GEMM of v1, now without the q loop); decoder: bias sums and d p.
+#include "level_dev.hpp"
+#include "ops.hpp"
+
+namespace lgn {
+namespace m2 {
+
+constexpr int MAXN = 32;      // lane >> 1 indexes the row: 32 rows per sweep
+
+__device__ __forceinline__ double fast_rcp(double u) {
+  double r = __builtin_amdgcn_rcp(u);
+  double e = __builtin_fma(-u, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-u, r, 1.0);
+  return __builtin_fma(r, e, r);
+}
+// add the value held by the neighbouring lane (lane ^ 1)
+__device__ __forceinline__ double pair_sum(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true);     // quad_perm [1,0,3,2]
+  hi = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true);
+  return v + __hiloint2double(hi, lo);
+}
+
+// LDS image of a jet: positions, mask, and per channel the pair table R
+struct Jet {
+  double* pj;        // [N][PS]
+  uint8_t* mk;       // [N]
+  double* Rl;        // [N][RP][4]   RP = row pitch in pairs (odd multiple keeps the 32-byte reads of a wave on distinct banks)
+  double* wl;        // encoder: [20][8] = a_k, b_k, c_k^2, pad, w(R0r), w(R0i), w(R1r), w(R1i) of the current channel; [160..163] biases
+};
+__host__ __device__ inline int row_pitch(int N) { return (N | 1) + ((((N | 1) & 3) == 1) ? 0 : 2); }   // == 1 mod 4
+
+template <bool DEC>
+__device__ __forceinline__ void load_jet(const GenArgs& a, int b, Jet& J) {
+  const int N = a.N, B = a.B;
+  if (DEC) {
+    const size_t plane_p = (size_t)B * N * 4;
+    const double* p0 = a.p + (size_t)b * N * 4;
+    for (int e = threadIdx.x; e < N * 4; e += BLOCK) {
+      const int j = e >> 2, m = e & 3;
+      J.pj[j * 8 + m] = p0[e];
+      J.pj[j * 8 + 4 + m] = p0[plane_p + e];
+    }
+  } else {
+    const double* p0 = a.p + (size_t)b * N * 4;
+    for (int e = threadIdx.x; e < N * 4; e += BLOCK) J.pj[e] = p0[e];
+    for (int e = threadIdx.x; e < N; e += BLOCK) J.mk[e] = a.mask[(size_t)b * N + e];
+  }
+}
+
+// radial constants of channel c -> LDS (encoder)
+__device__ __forceinline__ void load_channel_consts(const GenArgs& a, int c, double* wl) {
+  for (int k = threadIdx.x; k < NB; k += BLOCK) {
+    const double cc = a.rc[k];
+    wl[k * 8 + 0] = a.ra[k];
+    wl[k * 8 + 1] = a.rb[k];
+    wl[k * 8 + 2] = cc * cc;
+    wl[k * 8 + 3] = 0.0;
+    wl[k * 8 + 4] = a.w0[(2 * c) * NB + k];
+    wl[k * 8 + 5] = a.w0[(2 * c + 1) * NB + k];
+    wl[k * 8 + 6] = a.w1[(2 * c) * NB + k];
+    wl[k * 8 + 7] = a.w1[(2 * c + 1) * NB + k];
+  }
+  if (threadIdx.x < 4) {
+    const int q = threadIdx.x;
+    wl[NB * 8 + q] = ((q >> 1) ? a.b1 : a.b0)[2 * c + (q & 1)];
+  }
+}
+
+// R table of channel c for all ordered pairs (i, j): one thread per pair.  Masked pairs carry the Linear bias
+// (position_levels.py:144-149); the decoder's radial functions ARE the biases (lgn_decoder.py:335-340).
+template <bool DEC>
+__device__ __forceinline__ void fill_R(const GenArgs& a, int c, const Jet& J, int RP) {
+  const int N = a.N;
+  if (DEC) {
+    const double b0 = a.b0[c], b1 = a.b1[c];
+    for (int p = threadIdx.x; p < N * N; p += BLOCK) {
+      const int i = p / N, j = p - i * N;
+      double* r = J.Rl + ((size_t)i * RP + j) * 4;
+      r[0] = b0; r[1] = b0; r[2] = b1; r[3] = b1;
+    }
+    return;
+  }
+  for (int p = threadIdx.x; p < N * N; p += BLOCK) {
+    const int i = p / N, j = p - i * N;
+    const double* pi = J.pj + i * 4;
+    const double* pq = J.pj + j * 4;
+    const double d0 = pi[0] - pq[0], d1 = pi[1] - pq[1], d2 = pi[2] - pq[2], d3 = pi[3] - pq[3];
+    const double q0 = d0 * d0, q1 = d1 * d1, q2 = d2 * d2, q3 = d3 * d3;
+    const double nsq = (2.0 * q0 - (((q0 + q1) + q2) + q3)) + 1e-16;
+    const double an = fabs(nsq);
+    const bool on = J.mk[i] != 0 && J.mk[j] != 0 && nsq != 0.0;
+    double r0 = J.wl[NB * 8 + 0], r1 = J.wl[NB * 8 + 1], r2 = J.wl[NB * 8 + 2], r3 = J.wl[NB * 8 + 3];
+    if (on) {
+#pragma unroll 4
+      for (int k = 0; k < NB; ++k) {
+        const double* w = J.wl + k * 8;
+        const double beta = __builtin_fma(w[1], fast_rcp((1.0 + w[2] * an) + 1e-16), w[0]);
+        r0 = __builtin_fma(w[4], beta, r0);
+        r1 = __builtin_fma(w[5], beta, r1);
+        r2 = __builtin_fma(w[6], beta, r2);
+        r3 = __builtin_fma(w[7], beta, r3);
+      }
+    }
+    double* r = J.Rl + ((size_t)i * RP + j) * 4;
+    r[0] = r0; r[1] = r1; r[2] = r2; r[3] = r3;
+  }
+}
+
+// canonical components of p_i - p_j (encoder: real Cartesian input; decoder: complex canonical input)
+template <bool DEC>
+__device__ __forceinline__ void rel_q(const double* pi, const double* pq, cx<double> (&q)[4]) {
+  if (DEC) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) q[m] = {pi[m] - pq[m], pi[4 + m] - pq[4 + m]};
+  } else {
+    const double d0 = pi[0] - pq[0], d1 = pi[1] - pq[1], d2 = pi[2] - pq[2], d3 = pi[3] - pq[3];
+    const double h = rsqrt2<double>();
+    q[0] = {d0, 0.0};
+    q[1] = {d1 * h, -d2 * h};
+    q[2] = {d3, 0.0};
+    q[3] = {-d1 * h, -d2 * h};
+  }
+}
+__device__ __forceinline__ void edge_from_R(const double* r, const cx<double> (&q)[4], cx<double> (&e)[5]) {
+  e[0] = {r[0] - r[1], r[0] + r[1]};               // R0 (1 + i)
+  const cx<double> R1 = {r[2], r[3]};
+#pragma unroll
+  for (int m = 0; m < 4; ++m) e[1 + m] = cmul(R1, q[m]);
+}
+
+// =========================================================================================================
+// forward
+// =========================================================================================================
+template <bool DEC, int QPT>
+__global__ __launch_bounds__(BLOCK) void moments_fwd2_kernel(GenArgs a) {
+  constexpr int PS = DEC ? 8 : 4;
+  const int N = a.N, B = a.B, Q = a.Q, C = a.C, RP = row_pitch(N);
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  Jet J;
+  J.Rl = reinterpret_cast<double*>(smem_raw);                  // N * RP * 4
+  double* xs = J.Rl + (size_t)N * RP * 4;                      // [N][Q][2] of the current channel
+  J.pj = xs + (size_t)N * Q * 2;
+  J.wl = J.pj + (size_t)N * PS;
+  J.mk = reinterpret_cast<uint8_t*>(J.wl + NB * 8 + 4);
+  load_jet<DEC>(a, b, J);
+  const size_t plane = (size_t)B * N * C * Q;
+  const int half = lane & 1, i = lane >> 1;                    // 32 rows x 2 halves of the partner range
+  const bool iok = i < N;
+  const int ii = iok ? i : N - 1;
+  const int jmid = (N + 1) >> 1, jb = half ? jmid : 0, je = half ? N : jmid;
+  for (int c = 0; c < C; ++c) {
+    __syncthreads();                                           // previous channel's sweeps are done with Rl / xs / wl
+    if (!DEC) load_channel_consts(a, c, J.wl);
+    for (int e = threadIdx.x; e < N * Q; e += BLOCK) {
+      const int j = e / Q, q = e - j * Q;
+      const size_t g = (((size_t)b * N + j) * C + c) * Q + q;
+      xs[2 * e] = a.X[g];
+      xs[2 * e + 1] = a.X[plane + g];
+    }
+    __syncthreads();
+    fill_R<DEC>(a, c, J, RP);
+    __syncthreads();
+    for (int q0 = wave * QPT; q0 < Q; q0 += 4 * QPT) {         // wave-uniform
+      cx<double> acc[QPT][5];
+#pragma unroll
+      for (int x = 0; x < QPT; ++x)
+#pragma unroll
+        for (int k = 0; k < 5; ++k) acc[x][k] = {0, 0};
+      double pi[PS];
+#pragma unroll
+      for (int m = 0; m < PS; ++m) pi[m] = J.pj[ii * PS + m];
+      for (int j = jb; j < je; ++j) {
+        cx<double> q[4], e[5];
+        rel_q<DEC>(pi, J.pj + j * PS, q);
+        edge_from_R(J.Rl + ((size_t)ii * RP + j) * 4, q, e);
+        const double* xj = xs + ((size_t)j * Q + q0) * 2;
+#pragma unroll
+        for (int x = 0; x < QPT; ++x) {
+          if (q0 + x < Q) {
+            const cx<double> xv = {xj[2 * x], xj[2 * x + 1]};
+#pragma unroll
+            for (int k = 0; k < 5; ++k) cfma(acc[x][k], xv, e[k]);
+          }
+        }
+      }
+      double* u = a.U + ((((size_t)b * N + ii) * C + c) * Q + q0) * 10;
+#pragma unroll
+      for (int x = 0; x < QPT; ++x)
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+          const double sr = pair_sum(acc[x][k].r), si = pair_sum(acc[x][k].i);
+          if (half == 0 && iok && q0 + x < Q) {
+            u[(x * 5 + k) * 2] = sr;
+            u[(x * 5 + k) * 2 + 1] = si;
+          }
+        }
+    }
+  }
+}
+
+// =========================================================================================================
+// backward, j-centric:  dX[j][c][q] += sum_i sum_k dU[i][c][q][k] conj(e_k(i,j)[c])      (+ decoder d p_j)
+// =========================================================================================================
+template <bool DEC, int QPT>
+__global__ __launch_bounds__(BLOCK) void moments_bwd_nodes2_kernel(GenArgs a) {
+  constexpr int PS = DEC ? 8 : 4;
+  const int N = a.N, B = a.B, Q = a.Q, C = a.C, RP = N;          // lanes differ in j here: consecutive 32-byte entries, no padding
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  Jet J;
+  J.Rl = reinterpret_cast<double*>(smem_raw);                  // N * RP * 4
+  double* gu = J.Rl + (size_t)N * RP * 4;                      // [N][Q*5][2] of the current channel
+  J.pj = gu + (size_t)N * Q * 10;
+  J.wl = J.pj + (size_t)N * PS;
+  double* gq = J.wl + NB * 8 + 4;                              // decoder: [4 waves][N][8]  d p_j partials of the component groups
+  J.mk = reinterpret_cast<uint8_t*>(gq + (DEC ? 4 * N * 8 : 0));
+  load_jet<DEC>(a, b, J);
+  const size_t plane = (size_t)B * N * C * Q;
+  const int half = lane & 1, j = lane >> 1;
+  const bool jok = j < N;
+  const int jj = jok ? j : N - 1;
+  const int imid = (N + 1) >> 1, ib = half ? imid : 0, ie = half ? N : imid;
+  cx<double> Gq[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};         // decoder: gradient w.r.t. q = p_i - p_j, summed over i, c, q
+  for (int c = 0; c < C; ++c) {
+    __syncthreads();
+    if (!DEC) load_channel_consts(a, c, J.wl);
+    for (int e = threadIdx.x; e < N * Q * 10; e += BLOCK) {
+      const int i = e / (Q * 10), r = e - i * Q * 10;
+      gu[e] = a.gU[(((size_t)b * N + i) * C + c) * Q * 10 + r];
+    }
+    __syncthreads();
+    fill_R<DEC>(a, c, J, RP);
+    __syncthreads();
+    for (int q0 = wave * QPT; q0 < Q; q0 += 4 * QPT) {
+      cx<double> acc[QPT], xme[QPT];
+#pragma unroll
+      for (int x = 0; x < QPT; ++x) {
+        acc[x] = {0, 0};
+        xme[x] = {0, 0};
+        if (DEC && q0 + x < Q) {
+          const size_t g = (((size_t)b * N + jj) * C + c) * Q + q0 + x;
+          xme[x] = {a.X[g], a.X[plane + g]};
+        }
+      }
+      double pme[PS];
+#pragma unroll
+      for (int m = 0; m < PS; ++m) pme[m] = J.pj[jj * PS + m];
+      for (int i = ib; i < ie; ++i) {
+        cx<double> q[4], e[5];
+        rel_q<DEC>(J.pj + i * PS, pme, q);
+        const double* r = J.Rl + ((size_t)i * RP + jj) * 4;
+        edge_from_R(r, q, e);
+        const cx<double> R1 = {r[2], r[3]};
+        const double* gi = gu + ((size_t)i * Q + q0) * 10;
+#pragma unroll
+        for (int x = 0; x < QPT; ++x) {
+          if (q0 + x < Q) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+              const cx<double> gv = {gi[(x * 5 + k) * 2], gi[(x * 5 + k) * 2 + 1]};
+              cfmac(acc[x], gv, e[k]);
+              if (DEC && k > 0) cfmac(Gq[k - 1], cmulc(gv, xme[x]), R1);   // G_e1[m] = dU[q][1+m] conj(X_j[q]);  G_q[m] += G_e1[m] conj(R1)
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int x = 0; x < QPT; ++x) {
+        const double sr = pair_sum(acc[x].r), si = pair_sum(acc[x].i);
+        if (half == 0 && jok && q0 + x < Q) {
+          const size_t g = (((size_t)b * N + j) * C + c) * Q + q0 + x;
+          a.gX[g] += sr;
+          a.gX[plane + g] += si;
+        }
+      }
+    }
+  }
+  if (DEC) {     // d p_j = - sum of G_q over partners, channels and components: halves by DPP, component groups (waves) through LDS
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const double sr = pair_sum(Gq[m].r), si = pair_sum(Gq[m].i);
+      if (half == 0 && jok) {
+        gq[((size_t)wave * N + j) * 8 + m] = sr;
+        gq[((size_t)wave * N + j) * 8 + 4 + m] = si;
+      }
+    }
+    __syncthreads();
+    const size_t plp = (size_t)B * N * 4;
+    for (int e = threadIdx.x; e < N * 8; e += BLOCK) {
+      const int jn = e >> 3, r = e & 7;
+      const double s = (gq[((size_t)0 * N + jn) * 8 + r] + gq[((size_t)1 * N + jn) * 8 + r]) +
+                       (gq[((size_t)2 * N + jn) * 8 + r] + gq[((size_t)3 * N + jn) * 8 + r]);
+      a.g_p[(r >> 2) * plp + ((size_t)b * N + jn) * 4 + (r & 3)] -= s;
+    }
+  }
+}
+
+// =========================================================================================================
+// backward, i-centric: gradient of the pair's radial values,  G_k(i,j) = sum_q dU[i][q][k] conj(X_j[q])
+//   encoder: Gbuf[b][i*N + j][4C]: per channel (G_R0r, G_R0i, G_R1r, G_R1i), consumed by moments_rad_reduce2_kernel
+//   decoder: bias-gradient sums (one partial row per jet) and d p_i
+// wave = group of partners? no: lane = (row i, half of the partner range), wave = quarter of ... the q loop is the
+// reduction here, so the four waves split the PARTNER range instead (each lane: one row, N/8 partners, all q).
+// =========================================================================================================
+template <bool DEC>
+__global__ __launch_bounds__(BLOCK) void moments_bwd_G2_kernel(GenArgs a, double* Gbuf) {
+  constexpr int PS = DEC ? 8 : 4;
+  const int N = a.N, B = a.B, Q = a.Q, C = a.C;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  Jet J;                                                       // (no pair table: the gradient w.r.t. R does not depend on R)
+  J.Rl = nullptr;
+  double* gu = reinterpret_cast<double*>(smem_raw);            // [N][Q*5][2]
+  double* xs = gu + (size_t)N * Q * 10;                        // [N][Q][2]
+  J.pj = xs + (size_t)N * Q * 2;
+  J.wl = J.pj + (size_t)N * PS;
+  double* red = J.wl + NB * 8 + 4;                             // decoder: [8 groups][N][8] d p_i partials | [8][2] bias partials per channel
+  J.mk = reinterpret_cast<uint8_t*>(red + (DEC ? 8 * N * 8 + 8 * 2 * 8 : 0));
+  load_jet<DEC>(a, b, J);
+  const size_t plane = (size_t)B * N * C * Q;
+  const int grp = wave * 2 + (lane & 1), i = lane >> 1;        // 8 partner groups
+  const bool iok = i < N;
+  const int ii = iok ? i : N - 1;
+  const int per = (N + 7) >> 3, jb = grp * per, je = min(N, jb + per);
+  cx<double> Gq[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+  for (int c = 0; c < C; ++c) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < N * Q * 10; e += BLOCK) {
+      const int n = e / (Q * 10), r = e - n * Q * 10;
+      gu[e] = a.gU[(((size_t)b * N + n) * C + c) * Q * 10 + r];
+    }
+    for (int e = threadIdx.x; e < N * Q; e += BLOCK) {
+      const int n = e / Q, q = e - n * Q;
+      const size_t g = (((size_t)b * N + n) * C + c) * Q + q;
+      xs[2 * e] = a.X[g];
+      xs[2 * e + 1] = a.X[plane + g];
+    }
+    __syncthreads();
+    double pi[PS];
+#pragma unroll
+    for (int m = 0; m < PS; ++m) pi[m] = J.pj[ii * PS + m];
+    double dB0 = 0.0, dB1 = 0.0;
+    const double* gi = gu + (size_t)ii * Q * 10;
+    for (int j = jb; j < je; ++j) {
+      const double* xj = xs + (size_t)j * Q * 2;
+      cx<double> ge[5] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}};
+      for (int x = 0; x < Q; ++x) {
+        const cx<double> xv = {xj[2 * x], xj[2 * x + 1]};
+#pragma unroll
+        for (int k = 0; k < 5; ++k) cfmac(ge[k], cx<double>{gi[x * 10 + 2 * k], gi[x * 10 + 2 * k + 1]}, xv);
+      }
+      cx<double> q[4];
+      rel_q<DEC>(pi, J.pj + j * PS, q);
+      cx<double> gR1 = {0, 0};
+#pragma unroll
+      for (int m = 0; m < 4; ++m) cfmac(gR1, ge[1 + m], q[m]);
+      const double G0r = ge[0].r + ge[0].i, G0i = ge[0].i - ge[0].r;     // e0 = R0 (1 + i)  ->  G_R0 = G_e0 conj(1 + i)
+      if (DEC) {
+        const cx<double> R1 = {a.b1[c], a.b1[c]};
+#pragma unroll
+        for (int m = 0; m < 4; ++m) cfmac(Gq[m], ge[1 + m], R1);
+        if (iok) {
+          dB0 += G0r + G0i;              // R0 = b0 (1 + i) on both planes: d b0 = Re G_R0 + Im G_R0
+          dB1 += gR1.r + gR1.i;
+        }
+      } else if (iok) {
+        double* g = Gbuf + (((size_t)b * N * N + (size_t)i * N + j) * C + c) * 4;
+        g[0] = G0r; g[1] = G0i; g[2] = gR1.r; g[3] = gR1.i;
+      }
+    }
+    if (DEC) {      // bias gradients of channel c: sum over all lanes of the workgroup
+      for (int m = 1; m < 64; m <<= 1) { dB0 += shfl_xor(dB0, m); dB1 += shfl_xor(dB1, m); }
+      double* bred = red + 8 * N * 8;
+      if (lane == 0) { bred[(c * 4 + wave) * 2] = dB0; bred[(c * 4 + wave) * 2 + 1] = dB1; }
+    }
+  }
+  if (DEC) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      if (iok) {
+        red[((size_t)grp * N + i) * 8 + m] = Gq[m].r;
+        red[((size_t)grp * N + i) * 8 + 4 + m] = Gq[m].i;
+      }
+    }
+    __syncthreads();
+    const size_t plp = (size_t)B * N * 4;
+    for (int e = tid; e < N * 8; e += BLOCK) {
+      const int n = e >> 3, r = e & 7;
+      double s = 0.0;
+      for (int g = 0; g < 8; ++g) s += red[((size_t)g * N + n) * 8 + r];
+      a.g_p[(r >> 2) * plp + ((size_t)b * N + n) * 4 + (r & 3)] += s;
+    }
+    const double* bred = red + 8 * N * 8;
+    double* part = a.part_rad + (size_t)b * rad_partial_size(C, true);
+    if (tid < 2 * C) {
+      const int lin = tid / C, ch = tid - lin * C;
+      part[tid] = (bred[(ch * 4 + 0) * 2 + lin] + bred[(ch * 4 + 1) * 2 + lin]) + (bred[(ch * 4 + 2) * 2 + lin] + bred[(ch * 4 + 3) * 2 + lin]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// encoder: radial-parameter sums from the pair gradients Gbuf -- the [4C x pairs] . [pairs x 42] GEMM of
+// moments_bwd_rad_kernel (generic_moments.hip) on the matrix cores, without the q loop.
+//   T1[r][k] = sum_p G[p][r] on rho_k    T2[r][k] = sum_p G[p][r] on n^2 rho_k^2    S[r] = sum_p G on    dB[r] = sum_p G
+// ---------------------------------------------------------------------------------------------------------
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+template <int C>
+__global__ __launch_bounds__(BLOCK) void moments_rad_reduce2_kernel(GenArgs a, const double* Gbuf) {
+  constexpr int NG = (C + 3) / 4;
+  const int N = a.N;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  double* pj = reinterpret_cast<double*>(smem_raw);            // N * 4
+  double* red = pj + (size_t)N * 4;                            // 4 waves * 64 lanes * NG * 12
+  uint8_t* mk = reinterpret_cast<uint8_t*>(red + 4 * 64 * NG * 12);
+  {
+    const double* p0 = a.p + (size_t)b * N * 4;
+    for (int e = tid; e < N * 4; e += BLOCK) pj[e] = p0[e];
+    for (int e = tid; e < N; e += BLOCK) mk[e] = a.mask[(size_t)b * N + e];
+  }
+  __syncthreads();
+  // MFMA operands: A[row r][k = pair slot], B[k = pair slot][col]; lane l supplies A[l & 15][l >> 4] and B[l >> 4][l & 15].
+  // rows r' = cc + 4 * quantity (quantity = R0r, R0i, R1r, R1i) of channel group g; 4 pairs per MFMA (k dimension).
+  double ck2[3], akk = 0;   // this lane's basis column(s): col = lane & 15 of the three column blocks [rho_0..15 | n2rho2_0..15 | rho_16..19, n2rho2_16..19, on, 1]
+  (void)akk;
+  const int col = lane & 15, kq = lane >> 4;
+  {
+    const double c0 = a.rc[col];
+    ck2[0] = c0 * c0;
+    const int k2 = col < 4 ? 16 + col : (col < 8 ? 16 + col - 4 : 0);
+    const double c2 = a.rc[k2];
+    ck2[1] = c2 * c2;
+    ck2[2] = 0;
+  }
+  v4d T[NG][3];
+#pragma unroll
+  for (int g = 0; g < NG; ++g)
+#pragma unroll
+    for (int t = 0; t < 3; ++t) T[g][t] = v4d{0, 0, 0, 0};
+  const int npairs = N * N;
+  for (int p0 = wave * 4; p0 < npairs; p0 += 16) {             // 4 pairs per MFMA step, waves interleaved
+    const int p = p0 + kq;                                     // this lane's pair for the B operand and the A operand
+    const bool ok = p < npairs;
+    const int pp = ok ? p : npairs - 1;
+    const int i = pp / N, j = pp - i * N;
+    const double* pi = pj + i * 4;
+    const double* pq = pj + j * 4;
+    const double d0 = pi[0] - pq[0], d1 = pi[1] - pq[1], d2 = pi[2] - pq[2], d3 = pi[3] - pq[3];
+    const double q0 = d0 * d0, q1 = d1 * d1, q2 = d2 * d2, q3 = d3 * d3;
+    const double nsq = (2.0 * q0 - (((q0 + q1) + q2) + q3)) + 1e-16;
+    const double an = fabs(nsq);
+    const bool on = ok && mk[i] != 0 && mk[j] != 0 && nsq != 0.0;
+    // B fragments: three column blocks of 16
+    const double rho0 = on ? fast_rcp((1.0 + ck2[0] * an) + 1e-16) : 0.0;
+    const double rho2 = on ? fast_rcp((1.0 + ck2[1] * an) + 1e-16) : 0.0;
+    double bv[3];
+    bv[0] = rho0;
+    bv[1] = an * rho0 * rho0;
+    bv[2] = col < 4 ? rho2 : (col < 8 ? an * rho2 * rho2 : (col == 8 ? (on ? 1.0 : 0.0) : (col == 9 ? (ok ? 1.0 : 0.0) : 0.0)));
+    const double* gp = Gbuf + ((size_t)b * npairs + pp) * C * 4;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const int rr = lane & 15, quant = rr >> 2, ch = 4 * g + (rr & 3);
+      const double av = (ok && ch < C) ? gp[ch * 4 + quant] : 0.0;
+#pragma unroll
+      for (int t = 0; t < 3; ++t) T[g][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[t], T[g][t], 0, 0, 0);
+    }
+  }
+  // D fragment: lane holds rows (lane >> 4) + 4 * reg = channel cc = lane >> 4 of group g, quantity reg; column lane & 15
+  {
+    double* mine = red + (size_t)(wave * 64 + lane) * NG * 12;
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) mine[(g * 3 + t) * 4 + q] = T[g][t][q];
+  }
+  __syncthreads();
+  double* part = a.part_rad + (size_t)blockIdx.x * rad_partial_size(C, false);
+  if (wave == 0) {
+    constexpr int R = 4 * C;
+    const int cg = lane >> 4;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const int ch = 4 * g + cg;
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int e = (g * 3 + t) * 4 + q;
+          const double v = (red[(size_t)(0 * 64 + lane) * NG * 12 + e] + red[(size_t)(1 * 64 + lane) * NG * 12 + e]) +
+                           (red[(size_t)(2 * 64 + lane) * NG * 12 + e] + red[(size_t)(3 * 64 + lane) * NG * 12 + e]);
+          if (ch >= C) continue;
+          const int r = (q >> 1) * 2 * C + 2 * ch + (q & 1);
+          if (t == 0) part[r * NB + col] = v;
+          else if (t == 1) part[R * NB + r * NB + col] = v;
+          else {
+            if (col < 4) part[r * NB + 16 + col] = v;
+            else if (col < 8) part[R * NB + r * NB + 16 + (col - 4)] = v;
+            else if (col == 8) part[2 * R * NB + r] = v;
+            else if (col == 9) part[2 * R * NB + R + r] = v;
+          }
+        }
+    }
+  }
+}
+
+template <typename K>
+static int set_smem(K kern, size_t smem, const char* what) {
+  if (smem > 160 * 1024) {
+    set_error("%s needs %zu B of LDS (> 160 KiB)", what, smem);
+    return -1;
+  }
+  if (smem > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) { set_error("hipFuncSetAttribute(%s): %s", what, hipGetErrorString(e)); return (int)e; }
+  }
+  return 0;
+}
+
+static size_t base_smem(const GenArgs& a, bool dec, int pitch) {     // pair table (pitch 0: none) + positions + radial constants + mask
+  const int PS = dec ? 8 : 4;
+  return sizeof(double) * ((size_t)a.N * pitch * 4 + (size_t)a.N * PS + NB * 8 + 4) + a.N + 16;
+}
+
+template <bool DEC>
+static int launch(const GenArgs& a, int which, double* Gbuf, hipStream_t st) {
+  const size_t xs = sizeof(double) * (size_t)a.N * a.Q * 2, gu = sizeof(double) * (size_t)a.N * a.Q * 10;
+  int rc;
+  if (which == 0) {
+    const size_t smem = base_smem(a, DEC, row_pitch(a.N)) + xs;
+    if (a.Q <= 8) {
+      auto k = moments_fwd2_kernel<DEC, 2>;
+      if ((rc = set_smem(k, smem, "moments_fwd2"))) return rc;
+      hipLaunchKernelGGL(k, dim3(a.B), dim3(BLOCK), smem, st, a);
+    } else {
+      auto k = moments_fwd2_kernel<DEC, 5>;
+      if ((rc = set_smem(k, smem, "moments_fwd2"))) return rc;
+      hipLaunchKernelGGL(k, dim3(a.B), dim3(BLOCK), smem, st, a);
+    }
+  } else if (which == 1) {
+    const size_t smem = base_smem(a, DEC, a.N) + gu + (DEC ? sizeof(double) * 4 * a.N * 8 : 0);
+    if (a.Q <= 8) {
+      auto k = moments_bwd_nodes2_kernel<DEC, 2>;
+      if ((rc = set_smem(k, smem, "moments_bwd_nodes2"))) return rc;
+      hipLaunchKernelGGL(k, dim3(a.B), dim3(BLOCK), smem, st, a);
+    } else {
+      auto k = moments_bwd_nodes2_kernel<DEC, 5>;
+      if ((rc = set_smem(k, smem, "moments_bwd_nodes2"))) return rc;
+      hipLaunchKernelGGL(k, dim3(a.B), dim3(BLOCK), smem, st, a);
+    }
+  } else {
+    const size_t smem = base_smem(a, DEC, 0) + gu + xs + (DEC ? sizeof(double) * (8 * a.N * 8 + 8 * 2 * 8) : 0);
+    auto k = moments_bwd_G2_kernel<DEC>;
+    if ((rc = set_smem(k, smem, "moments_bwd_G2"))) return rc;
+    hipLaunchKernelGGL(k, dim3(a.B), dim3(BLOCK), smem, st, a, Gbuf);
+  }
+  LGN_CHECK_LAUNCH();
+  return 0;
+}
+
+template <int C>
+static int launch_reduce(const GenArgs& a, const double* Gbuf, hipStream_t st) {
+  constexpr int NG = (C + 3) / 4;
+  const size_t smem = sizeof(double) * ((size_t)a.N * 4 + 4 * 64 * NG * 12) + a.N + 16;
+  auto k = moments_rad_reduce2_kernel<C>;
+  if (int rc = set_smem(k, smem, "moments_rad_reduce2")) return rc;
+  hipLaunchKernelGGL(k, dim3(a.B), dim3(BLOCK), smem, st, a, Gbuf);
+  LGN_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // namespace m2
+
+// Does the channel-outermost form apply?  (the jet's pair table, one channel's dU slice and its X slice must fit in LDS)
+bool moments2_fits(const GenArgs& a, int decoder) {
+  if (a.N > m2::MAXN || a.C > 8) return false;
+  const size_t worst = m2::base_smem(a, decoder != 0, m2::row_pitch(a.N)) + sizeof(double) * (size_t)a.N * a.Q * 12 +
+                       (decoder ? sizeof(double) * (8 * a.N * 8 + 8 * 2 * 8) : 0);
+  return worst <= 160 * 1024;
+}
+// scratch (doubles) the encoder's i-centric backward needs for the pair gradients
+size_t moments2_gbuf_doubles(int B, int N, int C) { return (size_t)B * N * N * C * 4; }
+
+// which: 0 forward, 1 backward j-centric, 2 backward i-centric (Gbuf: encoder only, moments2_gbuf_doubles)
+int moments2_dispatch(const GenArgs& a, int decoder, int which, double* Gbuf, hipStream_t st) {
+  LGN_CHECK_ARG(a.B > 0 && a.N > 0 && a.Q > 0, "moments: empty input (B=%d N=%d Q=%d)", a.B, a.N, a.Q);
+  LGN_CHECK_ARG(a.C >= 1 && a.C <= 8, "moments: C=%d unsupported (1..8)", a.C);
+  if (decoder) return m2::launch<true>(a, which, nullptr, st);
+  if (which != 2) return m2::launch<false>(a, which, nullptr, st);
+  LGN_CHECK_ARG(Gbuf, "moments: the encoder's radial backward needs the pair-gradient scratch buffer");
+  if (int rc = m2::launch<false>(a, 2, Gbuf, st)) return rc;
+#define LGN_CASE(CC) case CC: return m2::launch_reduce<CC>(a, Gbuf, st);
+  switch (a.C) {
+    LGN_CASE(1) LGN_CASE(2) LGN_CASE(3) LGN_CASE(4) LGN_CASE(5) LGN_CASE(6) LGN_CASE(7) LGN_CASE(8)
+    default: return -1;
+  }
+#undef LGN_CASE
+}
+
+}  // namespace lgn

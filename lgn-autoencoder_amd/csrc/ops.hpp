@@ -83,7 +83,10 @@ struct GenArgs {
   double* gX;               // [2][B][N][C][Q], accumulated into
   double* g_p;              // decoder, accumulated into
   double* part_rad;         // [B][rad_partial_size]
+  double* gbuf;             // encoder i-centric backward, N <= 32: pair-gradient scratch, moments2_gbuf_doubles(B, N, C) doubles (optional:
+                            // without it the v1 kernel of generic_moments.hip runs)
 };
+size_t moments2_gbuf_doubles(int B, int N, int C);
 int moments_dispatch(const GenArgs& a, int decoder, int which, hipStream_t st);
 
 // sparse description of (aggregate CG, power CG, concatenation) of one level, see lgn/plan.py:build_local_tables

@@ -337,6 +337,7 @@ struct GenScratch {
   size_t zero_doubles;
   double *gs, *gv;                  // unpacked gradients at the two ends
   double *gX[2], *gU;
+  double* gbuf;                     // encoder: pair-gradient scratch of the channel-outermost radial backward (generic_moments2.hip)
   double* tot[4];
   double* parts;
   size_t parts_size, total;
@@ -364,6 +365,7 @@ GenScratch carve_gen_scratch(const lgn_net_desc& d, bool dec, double* base) {
   s.gX[0] = b.take(2 * BN * cq);
   s.gX[1] = b.take(2 * BN * cq);
   s.gU = b.take(10 * BN * cq);
+  s.gbuf = (!dec && d.N <= 32) ? b.take(moments2_gbuf_doubles(d.B, d.N, (int)cmax)) : nullptr;
   size_t psum = 0;
   for (int l = 0; l < L; ++l) {
     const size_t nrad = rad_partial_size(g.ch[l], dec);
@@ -444,6 +446,7 @@ int gen_levels_bwd(const lgn_net_desc& d, bool dec, const double* P, double* G, 
     GenArgs m = gen_level_args(d, dec, l, P, off, a.X[l], pos, mask);
     const int nrad = rad_partial_size(C, dec);
     m.gU = sc.gU; m.gX = sc.gX[nxt]; m.g_p = dec ? sc.g_p : nullptr; m.part_rad = dq.take((size_t)d.B * nrad);
+    m.gbuf = sc.gbuf;
     LGN_TRY(moments_dispatch(m, dec, 1, st));
     LGN_TRY(moments_dispatch(m, dec, 2, st));
     if (dec) {

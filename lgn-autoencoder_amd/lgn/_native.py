@@ -15,7 +15,7 @@ import torch  # imported before the .so so that the process-wide libamdhip64 is 
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_lib", "liblgn_amd.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 FINALIZE_SCRATCH = 2048      # include/lgn_amd.h: LGN_FINALIZE_SCRATCH
 
 _lib: Optional[C.CDLL] = None
@@ -65,7 +65,7 @@ _ll = C.c_longlong
 _d = C.c_double
 _SIGNATURES.update({
     "lgn_moments_fwd_f64": [_i] * 5 + [_vp] * 12,
-    "lgn_moments_bwd_f64": [_i] * 5 + [_vp] * 15,
+    "lgn_moments_bwd_f64": [_i] * 5 + [_vp] * 16,
     "lgn_local_fwd_f64": [_i] * 5 + [_tp] + [_vp] * 5,
     "lgn_local_partial_rows": [_i],
     "lgn_local_bwd_f64": [_i] * 5 + [_tp] + [_vp] * 8,
@@ -77,7 +77,8 @@ _SIGNATURES.update({
     "lgn_decoder_bwd_f64": [_dp, _vp, _vp, _ll, _vp, _vp, _vp, _ll, _vp, _vp, _vp, _ll, _vp],
     "lgn_step_finalize_f64": [_vp, _vp, _ll, _vp, _i, _d, _vp, _vp, _vp, _d, _d, _d, _d, _i, _vp, _vp],
 })
-EXPORTED_SYMBOLS = ["lgn_abi_version", "lgn_last_error", "lgn_step_workspace_doubles", "lgn_net_workspace_doubles"] + list(_SIGNATURES)
+EXPORTED_SYMBOLS = ["lgn_abi_version", "lgn_last_error", "lgn_step_workspace_doubles", "lgn_net_workspace_doubles",
+                    "lgn_moments_scratch_doubles"] + list(_SIGNATURES)
 
 
 def lib() -> C.CDLL:
@@ -102,6 +103,8 @@ def lib() -> C.CDLL:
         l.lgn_step_workspace_doubles.restype = C.c_longlong
         l.lgn_net_workspace_doubles.argtypes = [_dp, _i, _i]
         l.lgn_net_workspace_doubles.restype = C.c_longlong
+        l.lgn_moments_scratch_doubles.argtypes = [_i, _i, _i, _i]
+        l.lgn_moments_scratch_doubles.restype = C.c_longlong
         _lib = l
     return _lib
 
@@ -304,9 +307,12 @@ def moments_bwd(decoder, X, p, mask, rad, gU, gX, g_p):
     L = lib()
     nrad = L.lgn_level_rad_partial_len(Cc, int(decoder))
     part = torch.empty(B, nrad, device=X.device, dtype=X.dtype)
+    nscr = L.lgn_moments_scratch_doubles(B, N, Cc, int(decoder))
+    scratch = torch.empty(nscr, device=X.device, dtype=X.dtype) if nscr > 0 else None
     a, b, c, w0, b0, w1, b1 = rad
     _check(L.lgn_moments_bwd_f64(B, N, Cc, Q, int(decoder), ptr(X), ptr(p), ptr(mask), ptr(a), ptr(b), ptr(c), ptr(w0), ptr(b0),
-                                 ptr(w1), ptr(b1), ptr(gU), ptr(gX), ptr(g_p), ptr(part), stream_ptr()), "lgn_moments_bwd_f64")
+                                 ptr(w1), ptr(b1), ptr(gU), ptr(gX), ptr(g_p), ptr(part), ptr(scratch), stream_ptr()),
+           "lgn_moments_bwd_f64")
     tot = torch.empty(nrad, device=X.device, dtype=X.dtype)
     reduce_partials(part, tot)
     if decoder:

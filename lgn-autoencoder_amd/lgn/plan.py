@@ -190,6 +190,8 @@ def build_local_tables(plan: LevelPlan, cg_dict, tol: float = 1e-14, weight_offs
     C, CO = plan.channels_in, plan.channels_out
     for L in out_irreps:
         d = irrep_dim(L)
+        if d not in (1, 3, 4, 9):
+            raise NotImplementedError(f"irrep {L} (dimension {d}): the table-driven kernels are instantiated for maxdim <= 3")
         blocks = plan.cat_blocks[L]
         out_dim.append(d); out_nblk.append(len(blocks)); out_row0.append(nrows); out_q0.append(qo)
         out_w0.append(2 * wbase if weight_offsets is None else int(weight_offsets[L]))
