@@ -385,16 +385,8 @@ int gen_unpack(size_t nodes_x_C, int Q, int q_s, int q_v, const double* X, doubl
   return 0;
 }
 
-int local2_fwd(const LocalArgs& a, hipStream_t st);     // generic_local2.hip
-int local2_bwd(const LocalArgs& a, hipStream_t st);
-static bool use_v1() {     // the lane = (node, channel) kernels of generic_local2.hip are opt-in until they beat this file's
-  const char* e = getenv("LGN_AMD_LOCAL_V2");
-  return !(e && e[0] == '1');
-}
-
 int local_fwd(const LocalArgs& a, hipStream_t st) {
   LGN_CHECK_ARG(a.nodes > 0 && a.C >= 1 && a.CO >= 1, "local_fwd: empty input");
-  if (!use_v1()) return local2_fwd(a, st);
   LGN_CHECK_ARG(a.C * a.Q <= BLOCK && a.C * a.Q * 10 <= PF_U * BLOCK && a.CO * a.Qout <= BLOCK, "local_fwd: C*Q=%d too large", a.C * a.Q);
   const size_t smem = sizeof(double) * ((size_t)a.t.n_rows * a.C * 2 + (size_t)a.C * a.Q * 12);
   LGN_CHECK_ARG(smem <= 160 * 1024, "local_fwd: %zu B of LDS needed", smem);
@@ -406,7 +398,6 @@ int local_fwd(const LocalArgs& a, hipStream_t st) {
 
 int local_bwd(const LocalArgs& a, hipStream_t st) {
   LGN_CHECK_ARG(a.nodes > 0 && a.C >= 1 && a.CO >= 1, "local_bwd: empty input");
-  if (!use_v1()) return local2_bwd(a, st);
   LGN_CHECK_ARG(a.C * a.Q <= BLOCK && a.C * a.Q * 10 <= PF_U * BLOCK && a.CO * a.Qout <= BLOCK, "local_bwd: C*Q=%d too large", a.C * a.Q);
   LGN_CHECK_ARG(a.t.n_w <= MAXW * BLOCK, "local_bwd: %d CatMix weights exceed the per-workgroup accumulator budget", a.t.n_w);
   // widths of the bit-packed decode tables of the kernel (winfo: row < 1024, q0 < 64, d < 16, o < 16, c < 128; rinfo: q < 256)
