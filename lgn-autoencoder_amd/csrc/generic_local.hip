@@ -59,11 +59,32 @@ __device__ __forceinline__ void commit_node(const LocalArgs& a, const NodePrefet
   if (go && tid < COQ) { go[2 * tid] = P.g0;  go[2 * tid + 1] = P.g1; }
 }
 
+// The walk tables (row bounds, packed term codes, CG coefficients) are staged in LDS once per workgroup: every cat element
+// otherwise starts with a chain of three dependent global loads (row_ptr -> term -> operand).
+struct WalkTables {
+  const int* row_ptr;            // [n_rows + 1]
+  const int* code;               // [n_terms]: type | a << 2 | b << 12
+  const double* coef;            // [n_terms]
+};
+__device__ __forceinline__ WalkTables stage_tables(const LocalArgs& a, double* coef, int* ints) {
+  int* row_ptr = ints;
+  int* code = ints + a.t.n_rows + 1;
+  for (int e = threadIdx.x; e < a.n_terms; e += BLOCK) {
+    coef[e] = a.t.t_coef[e];
+    code[e] = a.t.t_type[e] | (a.t.t_a[e] << 2) | (a.t.t_b[e] << 12);
+  }
+  for (int e = threadIdx.x; e <= a.t.n_rows; e += BLOCK) row_ptr[e] = a.t.row_ptr[e];
+  return WalkTables{row_ptr, code, coef};
+}
+__host__ __device__ inline size_t walk_table_bytes(int n_rows, int n_terms) {
+  return sizeof(double) * (size_t)n_terms + sizeof(int) * (((size_t)n_rows + 1 + n_terms + 1) & ~size_t(1));
+}
+
 // cat[row][c] = sum_terms coef * value.  A row's terms are fetched four at a time (clamped index, zero coefficient past
 // the end, loads of all three operand kinds issued unconditionally) so that the round trips of a walk overlap; the terms
 // are still added in list order.
-__device__ __forceinline__ void build_cat(const LocalTables& t, int C, int Q, const double* Ul, const double* Xl, double* cat) {
-  for (int e = threadIdx.x; e < t.n_rows * C; e += BLOCK) {
+__device__ __forceinline__ void build_cat(const WalkTables& t, int n_rows, int C, int Q, const double* Ul, const double* Xl, double* cat) {
+  for (int e = threadIdx.x; e < n_rows * C; e += BLOCK) {
     const int row = e / C, c = e - row * C;
     const int beg = t.row_ptr[row], end = t.row_ptr[row + 1];
     const double* ub = Ul + (c * Q) * 10;
@@ -75,10 +96,11 @@ __device__ __forceinline__ void build_cat(const LocalTables& t, int C, int Q, co
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int kk = min(k + j, end - 1);
-        ty[j] = t.t_type[kk];
-        ia[j] = t.t_a[kk];
-        ib[j] = t.t_b[kk];
-        cf[j] = k + j < end ? t.t_coef[kk] : 0.0;
+        const int code = t.code[kk];
+        ty[j] = code & 3;
+        ia[j] = (code >> 2) & 1023;
+        ib[j] = code >> 12;
+        cf[j] = k + j < end ? t.coef[kk] : 0.0;
       }
       cx<double> u[4], x[4], y[4];
 #pragma unroll
@@ -118,6 +140,8 @@ __global__ __launch_bounds__(BLOCK) void local_fwd_kernel(LocalArgs a) {
   const int C = a.C, CO = a.CO, Qo = a.Qout;
   double* Ul = cat + (size_t)a.t.n_rows * C * 2;              // C * Q * 10
   double* Xl = Ul + (size_t)C * a.Q * 10;                     // C * Q * 2
+  double* tcoef = Xl + (size_t)C * a.Q * 2;                   // walk tables
+  const WalkTables T = stage_tables(a, tcoef, reinterpret_cast<int*>(tcoef + a.n_terms));
   const size_t plo = (size_t)a.nodes * CO * Qo;
   NodePrefetch P;
   if ((int)blockIdx.x * NODES_PER_WG < a.nodes) stage_node(a, blockIdx.x * NODES_PER_WG, Ul, Xl);
@@ -127,7 +151,7 @@ __global__ __launch_bounds__(BLOCK) void local_fwd_kernel(LocalArgs a) {
     if (node >= a.nodes) break;
     const bool more = nl + 1 < NODES_PER_WG && node + 1 < a.nodes;
     if (more) prefetch_node(a, node + 1, false, P);
-    build_cat(a.t, C, a.Q, Ul, Xl, cat);
+    build_cat(T, a.t.n_rows, C, a.Q, Ul, Xl, cat);
     __syncthreads();
     if (more) commit_node(a, P, Ul, Xl, nullptr);          // Ul / Xl are free once the cat rows exist
     for (int e = threadIdx.x; e < CO * Qo; e += BLOCK) {
@@ -188,6 +212,8 @@ __global__ __launch_bounds__(BLOCK) void local_bwd_kernel(LocalArgs a) {
   int* uptr = rwoff + a.t.n_rows;                            // 5 Q + 1
   int* urow = uptr + (5 * Q + 1);                            // n_u
   double* ucoef = reinterpret_cast<double*>(urow + a.n_u + ((5 * Q + 1 + a.n_u + a.t.n_w + 2 * a.t.n_rows) & 1));   // 8-byte aligned
+  double* tcoef = ucoef + a.n_u;                              // walk tables of build_cat
+  const WalkTables T = stage_tables(a, tcoef, reinterpret_cast<int*>(tcoef + a.n_terms));
   for (int e = threadIdx.x; e < 5 * Q + 1; e += BLOCK) uptr[e] = a.t.u_ptr[e];
   for (int e = threadIdx.x; e < a.n_u; e += BLOCK) { urow[e] = a.t.u_row[e];  ucoef[e] = a.t.u_coef[e]; }
   const size_t plx = (size_t)a.nodes * C * Q;
@@ -208,7 +234,7 @@ __global__ __launch_bounds__(BLOCK) void local_bwd_kernel(LocalArgs a) {
     }
     if (more) prefetch_node(a, node + 1, true, P);
     if (nl == 0) STAMP(1);
-    build_cat(a.t, C, Q, Ul, Xl, cat);
+    build_cat(T, a.t.n_rows, C, Q, Ul, Xl, cat);
     __syncthreads();
     if (nl == 0) STAMP(2);
     // gradient of the concatenated rows
@@ -388,7 +414,8 @@ int gen_unpack(size_t nodes_x_C, int Q, int q_s, int q_v, const double* X, doubl
 int local_fwd(const LocalArgs& a, hipStream_t st) {
   LGN_CHECK_ARG(a.nodes > 0 && a.C >= 1 && a.CO >= 1, "local_fwd: empty input");
   LGN_CHECK_ARG(a.C * a.Q <= BLOCK && a.C * a.Q * 10 <= PF_U * BLOCK && a.CO * a.Qout <= BLOCK, "local_fwd: C*Q=%d too large", a.C * a.Q);
-  const size_t smem = sizeof(double) * ((size_t)a.t.n_rows * a.C * 2 + (size_t)a.C * a.Q * 12);
+  LGN_CHECK_ARG(a.Q * 5 < 1024 && a.n_terms > 0, "local_fwd: Q=%d exceeds the packed term code", a.Q);
+  const size_t smem = sizeof(double) * ((size_t)a.t.n_rows * a.C * 2 + (size_t)a.C * a.Q * 12) + walk_table_bytes(a.t.n_rows, a.n_terms);
   LGN_CHECK_ARG(smem <= 160 * 1024, "local_fwd: %zu B of LDS needed", smem);
   if (smem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(local_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   hipLaunchKernelGGL(local_fwd_kernel, dim3(local_partial_rows(a.nodes)), dim3(BLOCK), smem, st, a);
@@ -405,7 +432,8 @@ int local_bwd(const LocalArgs& a, hipStream_t st) {
                 "local_bwd: n_rows=%d Qout=%d CO=%d exceed the packed table fields", a.t.n_rows, a.Qout, a.CO);
   const size_t smem = sizeof(double) * ((size_t)a.t.n_rows * a.C * 4 + (size_t)a.CO * a.Qout * 2 + (size_t)a.C * a.Q * 12) +
                       sizeof(int) * ((size_t)a.t.n_w + 2 * (size_t)a.t.n_rows + 5 * (size_t)a.Q + 2 + (size_t)a.n_u) +
-                      sizeof(double) * (size_t)a.n_u;
+                      sizeof(double) * (size_t)a.n_u + 8 + walk_table_bytes(a.t.n_rows, a.n_terms);
+  LGN_CHECK_ARG(a.Q * 5 < 1024 && a.n_terms > 0, "local_bwd: Q=%d exceeds the packed term code", a.Q);
   LGN_CHECK_ARG(smem <= 160 * 1024, "local_bwd: %zu B of LDS needed", smem);
   if (smem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(local_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   hipLaunchKernelGGL(local_bwd_kernel, dim3(local_partial_rows(a.nodes)), dim3(BLOCK), smem, st, a);
