@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LGN_AMD_ABI_VERSION 4   /* bump on ANY struct or signature change (lgn/_native.py: ABI_VERSION) */
+#define LGN_AMD_ABI_VERSION 5   /* bump on ANY struct or signature change (lgn/_native.py: ABI_VERSION) */
 
 int lgn_abi_version(void);
 const char* lgn_last_error(void);
@@ -130,7 +130,9 @@ typedef struct lgn_local_tables {
   int n_rows, n_out, n_w;          /* concatenated rows (irrep, block, m); output irreps; complex CatMix weights */
   int n_terms, n_u, n_x;           /* lengths of the three CSR term lists (= row_ptr[n_rows], u_ptr[5 Q], x_ptr[Q]); the backward keeps
                                       the U list in LDS and the host sizes it from n_u */
-  const int *row_ptr, *t_type, *t_a, *t_b;      /* CSR terms per row: type 0: U[a = q*5+k], 1: X[a], 2: X[a]*X[b] */
+  int n_units, reserved;           /* forward walk units: sum over output irreps of ceil(dim / 4) * blocks (<= 128) */
+  const int *row_ptr, *t_type, *t_a, *t_b;      /* CSR terms per row: type (t_type & 3) 0: U[a = q*5+k], 1: X[a], 2: X[a]*X[b];
+                                                   t_type & 4 marks the last term of a row (every row has >= 1 term) */
   const double* t_coef;
   const int *out_dim, *out_nblk, *out_row0, *out_q0, *out_w0;   /* per output irrep */
   const int *u_ptr, *u_row;                     /* transposed lists for the backward */

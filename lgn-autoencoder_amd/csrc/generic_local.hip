@@ -71,7 +71,7 @@ __device__ __forceinline__ WalkTables stage_tables(const LocalArgs& a, double* c
   int* code = ints + a.t.n_rows + 1;
   for (int e = threadIdx.x; e < a.n_terms; e += BLOCK) {
     coef[e] = a.t.t_coef[e];
-    code[e] = a.t.t_type[e] | (a.t.t_a[e] << 2) | (a.t.t_b[e] << 12);
+    code[e] = (a.t.t_type[e] & 3) | (a.t.t_a[e] << 2) | (a.t.t_b[e] << 12);     // (bit 2 of t_type = end-of-row flag of the v2 walk)
   }
   for (int e = threadIdx.x; e <= a.t.n_rows; e += BLOCK) row_ptr[e] = a.t.row_ptr[e];
   return WalkTables{row_ptr, code, coef};
@@ -187,8 +187,8 @@ __global__ __launch_bounds__(BLOCK) void local_bwd_kernel(LocalArgs a) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int C = a.C, CO = a.CO, Q = a.Q, Qo = a.Qout;
   double* cat = reinterpret_cast<double*>(smem_raw);          // n_rows * C * 2
-  double* gcat = cat + (size_t)a.t.n_rows * C * 2;            // n_rows * C * 2
-  double* go = gcat + (size_t)a.t.n_rows * C * 2;             // CO * Qo * 2
+  double* gcat = cat;                                         // the row gradients overwrite the rows once the weight gradient has used them
+  double* go = cat + (size_t)a.t.n_rows * C * 2;              // CO * Qo * 2
   double* Ul = go + (size_t)CO * Qo * 2;                      // C * Q * 10
   double* Xl = Ul + (size_t)C * Q * 10;                       // C * Q * 2
   int* winfo = reinterpret_cast<int*>(Xl + (size_t)C * Q * 2);  // n_w packed (first cat row, q0, d, o, c) of every CatMix weight
@@ -237,6 +237,20 @@ __global__ __launch_bounds__(BLOCK) void local_bwd_kernel(LocalArgs a) {
     build_cat(T, a.t.n_rows, C, Q, Ul, Xl, cat);
     __syncthreads();
     if (nl == 0) STAMP(2);
+    // CatMix weight gradient, accumulated over this workgroup's nodes:  dW_l[o][k] += sum_m g_out[o][q0+m] conj(cat[row][c])
+#pragma unroll
+    for (int k = 0; k < MAXW; ++k) {
+      const int w = threadIdx.x + k * BLOCK;
+      if (w < a.t.n_w) {
+        const int info = winfo[w];
+        const int row = info & 1023, q0 = (info >> 10) & 63, d = (info >> 16) & 15, o = (info >> 20) & 15, c = info >> 24;
+        for (int m = 0; m < d; ++m)
+          cfmac(dw[k], cx<double>{go[2 * (o * Qo + q0 + m)], go[2 * (o * Qo + q0 + m) + 1]},
+                cx<double>{cat[2 * ((row + m) * C + c)], cat[2 * ((row + m) * C + c) + 1]});
+      }
+    }
+    if (nl == 0) STAMP(3);
+    __syncthreads();                                       // every read of cat is done: its buffer now takes the row gradients
     // gradient of the concatenated rows
     for (int e = threadIdx.x; e < a.t.n_rows * C; e += BLOCK) {
       const int row = e / C, c = e - row * C;
@@ -259,19 +273,6 @@ __global__ __launch_bounds__(BLOCK) void local_bwd_kernel(LocalArgs a) {
       acc.i += acc1.i;
       gcat[2 * e] = acc.r;
       gcat[2 * e + 1] = acc.i;
-    }
-    if (nl == 0) STAMP(3);
-    // CatMix weight gradient, accumulated over this workgroup's nodes:  dW_l[o][k] += sum_m g_out[o][q0+m] conj(cat[row][c])
-#pragma unroll
-    for (int k = 0; k < MAXW; ++k) {
-      const int w = threadIdx.x + k * BLOCK;
-      if (w < a.t.n_w) {
-        const int info = winfo[w];
-        const int row = info & 1023, q0 = (info >> 10) & 63, d = (info >> 16) & 15, o = (info >> 20) & 15, c = info >> 24;
-        for (int m = 0; m < d; ++m)
-          cfmac(dw[k], cx<double>{go[2 * (o * Qo + q0 + m)], go[2 * (o * Qo + q0 + m) + 1]},
-                cx<double>{cat[2 * ((row + m) * C + c)], cat[2 * ((row + m) * C + c) + 1]});
-      }
     }
     if (nl == 0) STAMP(4);
     __syncthreads();
@@ -430,7 +431,7 @@ int local_bwd(const LocalArgs& a, hipStream_t st) {
   // widths of the bit-packed decode tables of the kernel (winfo: row < 1024, q0 < 64, d < 16, o < 16, c < 128; rinfo: q < 256)
   LGN_CHECK_ARG(a.t.n_rows < 1024 && a.Qout < 64 && a.CO <= 15 && a.C <= 127 && a.Q < 256,
                 "local_bwd: n_rows=%d Qout=%d CO=%d exceed the packed table fields", a.t.n_rows, a.Qout, a.CO);
-  const size_t smem = sizeof(double) * ((size_t)a.t.n_rows * a.C * 4 + (size_t)a.CO * a.Qout * 2 + (size_t)a.C * a.Q * 12) +
+  const size_t smem = sizeof(double) * ((size_t)a.t.n_rows * a.C * 2 + (size_t)a.CO * a.Qout * 2 + (size_t)a.C * a.Q * 12) +
                       sizeof(int) * ((size_t)a.t.n_w + 2 * (size_t)a.t.n_rows + 5 * (size_t)a.Q + 2 + (size_t)a.n_u) +
                       sizeof(double) * (size_t)a.n_u + 8 + walk_table_bytes(a.t.n_rows, a.n_terms);
   LGN_CHECK_ARG(a.Q * 5 < 1024 && a.n_terms > 0, "local_bwd: Q=%d exceeds the packed term code", a.Q);

@@ -40,7 +40,7 @@ inline int local_args(LocalArgs& a, int nodes, int C, int CO, int Q, int Qout, c
                 "local: incomplete tables");
   LGN_CHECK_ARG(t->n_terms > 0 && t->n_u >= 0 && t->n_x >= 0, "local: table lengths missing");
   a.nodes = nodes; a.C = C; a.CO = CO; a.Q = Q; a.Qout = Qout;
-  a.n_terms = t->n_terms; a.n_u = t->n_u; a.n_x = t->n_x;
+  a.n_terms = t->n_terms; a.n_u = t->n_u; a.n_x = t->n_x; a.n_units = t->n_units;
   a.t = LocalTables{t->n_rows, t->n_out, t->n_w, t->row_ptr, t->t_type, t->t_a, t->t_b, t->t_coef, t->out_dim, t->out_nblk,
                     t->out_row0, t->out_q0, t->out_w0, t->u_ptr, t->u_row, t->u_coef, t->x_ptr, t->x_row, t->x_other, t->x_coef};
   return 0;

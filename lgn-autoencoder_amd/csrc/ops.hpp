@@ -103,6 +103,7 @@ struct LocalTables {
 struct LocalArgs {
   int nodes, C, CO, Q, Qout;
   int n_terms, n_u, n_x;    // lengths of the CSR term lists (row_ptr[n_rows], u_ptr[5Q], x_ptr[Q])
+  int n_units;              // forward walk units (irrep, chunk of <= 4 rows, block)
   LocalTables t;
   const double* X;          // [2][nodes][C][Q]
   const double* U;          // [nodes][C][Q][5][2]

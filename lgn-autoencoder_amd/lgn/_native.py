@@ -14,8 +14,8 @@ from typing import Optional, Sequence
 import torch  # imported before the .so so that the process-wide libamdhip64 is torch's
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_lib", "liblgn_amd.so")
-ABI_VERSION = 4
+LIB_PATH = os.environ.get("LGN_AMD_LIB") or os.path.join(_HERE, "_lib", "liblgn_amd.so")   # LGN_AMD_LIB: debug builds (tools/)
+ABI_VERSION = 5
 FINALIZE_SCRATCH = 2048      # include/lgn_amd.h: LGN_FINALIZE_SCRATCH
 
 _lib: Optional[C.CDLL] = None
@@ -42,7 +42,7 @@ _SIGNATURES = {
 class LocalTables(C.Structure):
     """lgn_local_tables of include/lgn_amd.h (device pointers)."""
     _fields_ = [("n_rows", C.c_int), ("n_out", C.c_int), ("n_w", C.c_int), ("n_terms", C.c_int), ("n_u", C.c_int),
-                ("n_x", C.c_int)] + [
+                ("n_x", C.c_int), ("n_units", C.c_int), ("reserved", C.c_int)] + [
         (name, C.c_void_p) for name in ("row_ptr", "t_type", "t_a", "t_b", "t_coef", "out_dim", "out_nblk", "out_row0", "out_q0",
                                         "out_w0", "u_ptr", "u_row", "u_coef", "x_ptr", "x_row", "x_other", "x_coef")]
 
@@ -281,6 +281,7 @@ class DeviceTables:
         st = LocalTables()
         st.n_rows, st.n_out, st.n_w = tab["n_rows"], tab["n_out"], tab["n_w"]
         st.n_terms, st.n_u, st.n_x = len(tab["ints"]["t_type"]), len(tab["ints"]["u_row"]), len(tab["ints"]["x_row"])
+        st.n_units = tab["n_units"]
         for name, vals in tab["ints"].items():
             t = torch.tensor(vals if len(vals) else [0], dtype=torch.int32, device=device)
             self.tensors[name] = t

@@ -216,6 +216,9 @@ def build_local_tables(plan: LevelPlan, cg_dict, tol: float = 1e-14, weight_offs
                             else:
                                 t_type.append(2); t_a.append(qoff[r1] + m1); t_b.append(qoff[r2] + m2)
                             t_coef.append(cf)
+                if len(t_type) == row_ptr[-1]:      # a row whose CG coefficients all vanish still needs one (null) term:
+                    t_type.append(1); t_a.append(0); t_b.append(0); t_coef.append(0.0)      # the walk marks row ends on terms
+                t_type[-1] |= 4                     # bit 2: last term of its row (the type is t_type & 3)
                 row_ptr.append(len(t_type))
                 nrows += 1
     # transposed lists
@@ -223,9 +226,9 @@ def build_local_tables(plan: LevelPlan, cg_dict, tol: float = 1e-14, weight_offs
     x_lists = [[] for _ in range(Q)]
     for row in range(nrows):
         for t in range(row_ptr[row], row_ptr[row + 1]):
-            if t_type[t] == 0:
+            if t_type[t] & 3 == 0:
                 u_lists[t_a[t]].append((row, t_coef[t]))
-            elif t_type[t] == 1:
+            elif t_type[t] & 3 == 1:
                 x_lists[t_a[t]].append((row, -1, t_coef[t]))
             else:
                 x_lists[t_a[t]].append((row, t_b[t], t_coef[t]))
@@ -243,5 +246,6 @@ def build_local_tables(plan: LevelPlan, cg_dict, tol: float = 1e-14, weight_offs
     ints = dict(row_ptr=row_ptr, t_type=t_type, t_a=t_a, t_b=t_b, out_dim=out_dim, out_nblk=out_nblk, out_row0=out_row0,
                 out_q0=out_q0, out_w0=out_w0, u_ptr=u_ptr, u_row=u_row, x_ptr=x_ptr, x_row=x_row, x_other=x_other)
     dbls = dict(t_coef=t_coef, u_coef=u_coef, x_coef=x_coef)
-    return dict(Q=Q, Qout=qo, n_rows=nrows, n_out=len(out_irreps), n_w=wbase, ints=ints, dbls=dbls,
+    n_units = sum(((d + 3) // 4) * nb for d, nb in zip(out_dim, out_nblk))       # (irrep, chunk of <= 4 rows, block) units of the forward walk
+    return dict(Q=Q, Qout=qo, n_rows=nrows, n_out=len(out_irreps), n_w=wbase, n_units=n_units, ints=ints, dbls=dbls,
                 in_irreps=list(plan.node_order), out_irreps=out_irreps)
