@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LGN_AMD_ABI_VERSION 5   /* bump on ANY struct or signature change (lgn/_native.py: ABI_VERSION) */
+#define LGN_AMD_ABI_VERSION 6   /* bump on ANY struct or signature change (lgn/_native.py: ABI_VERSION) */
 
 int lgn_abi_version(void);
 const char* lgn_last_error(void);
@@ -149,6 +149,23 @@ int lgn_local_partial_rows(int nodes);
 /* gU, gX overwritten; part [lgn_local_partial_rows][2*n_w] (layout like wcat). */
 int lgn_local_bwd_f64(int nodes, int C, int CO, int Q, int Qout, const lgn_local_tables* t, const double* X, const double* U,
                       const double* wcat, const double* g_out, double* gU, double* gX, double* part, void* stream);
+
+/* The two level kinds of maxdim = 3 networks (kind 1: first level, node irreps (1,1), (0,0); kind 2: later levels, all five
+ * irreps) have their tables compiled in (csrc/cg_static_tables.hpp): same operator as lgn_local_fwd_f64 on tile-blocked,
+ * node-innermost layouts (node n = 64 tile + lane; buffers cover ceil(nodes / 64) whole tiles):
+ *   XT [tile][C][Q][2][64], UT [tile][C][5 Q][2][64], outT [tile][CO][Qout][2][64];
+ * w0[5] = offset of each output irrep's weights in wcat (host array); wpacked: scratch of
+ * lgn_local_static_packed_doubles(kind, C, CO) doubles (the call repacks the weights into it);
+ * s_copy optional [2][nodes][CO] copy of output component q_s (dense). */
+long long lgn_local_static_packed_doubles(int kind, int C, int CO);
+/* Backward of lgn_local_fwd_static_f64: goT [tile][CO][Qout][2][64] -> gUT [tile][C][5 Q][2][64], gXT [tile][C][Q][2][64]
+ * (both overwritten) and g_wcat += CatMix weight gradient (wcat layout; caller zero-initialises).  Scratch: wpacked and
+ * gpacked (lgn_local_static_packed_doubles doubles each), part (ceil(nodes / 64) rows of that length). */
+int lgn_local_bwd_static_f64(int kind, int nodes, int C, int CO, const double* XT, const double* UT, const double* wcat,
+                             const int* w0, double* wpacked, const double* goT, double* gUT, double* gXT, double* part,
+                             double* gpacked, double* g_wcat, void* stream);
+int lgn_local_fwd_static_f64(int kind, int nodes, int C, int CO, const double* XT, const double* UT, const double* wcat,
+                             const int* w0, double* wpacked, double* outT, double* s_copy, int q_s, void* stream);
 
 /* ---- whole training step (utils/train.py:283-343 inner loop); fused maxdim = 2 or table-driven networks -------
  * One call enqueues encoder -> decoder -> get_real('sum') -> Chamfer -> full backward (~80 launches, no host

@@ -140,6 +140,25 @@ int lgn_local_fwd_f64(int nodes, int C, int CO, int Q, int Qout, const lgn_local
 
 int lgn_local_partial_rows(int nodes) { return local_partial_rows(nodes); }
 
+int lgn_local_bwd_static_f64(int kind, int nodes, int C, int CO, const double* XT, const double* UT, const double* wcat, const int* w0,
+                             double* wpacked, const double* goT, double* gUT, double* gXT, double* part, double* gpacked, double* g_wcat,
+                             void* stream) {
+  LGN_CHECK_ARG(XT && UT && wcat && w0 && wpacked && goT && gUT && gXT && part && gpacked && g_wcat, "local_bwd_static: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  if (int rc = local_bwd_static(kind, nodes, C, CO, XT, UT, wcat, w0, wpacked, goT, gUT, gXT, part, st)) return rc;
+  const int np = (int)local_static_packed_doubles(kind, C, CO), tiles = (nodes + 63) / 64;
+  if (int rc = reduce_partials<double>(part, tiles, np, gpacked, 0, st)) return rc;
+  return local_static_unpack_grads(kind, C, CO, w0, gpacked, g_wcat, st);
+}
+
+long long lgn_local_static_packed_doubles(int kind, int C, int CO) { return (long long)local_static_packed_doubles(kind, C, CO); }
+
+int lgn_local_fwd_static_f64(int kind, int nodes, int C, int CO, const double* XT, const double* UT, const double* wcat, const int* w0,
+                             double* wpacked, double* outT, double* s_copy, int q_s, void* stream) {
+  LGN_CHECK_ARG(XT && UT && wcat && w0 && wpacked && outT, "local_fwd_static: null pointer");
+  return local_fwd_static(kind, nodes, C, CO, XT, UT, wcat, w0, wpacked, outT, s_copy, q_s, (hipStream_t)stream);
+}
+
 int lgn_local_bwd_f64(int nodes, int C, int CO, int Q, int Qout, const lgn_local_tables* t, const double* X, const double* U,
                       const double* wcat, const double* g_out, double* gU, double* gX, double* part, void* stream) {
   LocalArgs a{};

@@ -50,16 +50,22 @@ template <typename T>
 __device__ __forceinline__ cx<T> cmulc(cx<T> a, cx<T> b) {
   return {a.r * b.r + a.i * b.i, a.i * b.r - a.r * b.i};
 }
+// acc += a * b as two fused multiply-adds per component.  (Written "acc.r += a.r * b.r - a.i * b.i" the compiler forms the
+// product first -- mul + fma -- and then needs a third instruction to add it to the accumulator.)
 template <typename T>
 __device__ __forceinline__ void cfma(cx<T>& acc, cx<T> a, cx<T> b) {
-  acc.r += a.r * b.r - a.i * b.i;
-  acc.i += a.r * b.i + a.i * b.r;
+  acc.r = __builtin_fma(a.r, b.r, acc.r);
+  acc.r = __builtin_fma(-a.i, b.i, acc.r);
+  acc.i = __builtin_fma(a.r, b.i, acc.i);
+  acc.i = __builtin_fma(a.i, b.r, acc.i);
 }
 // acc += a * conj(b)
 template <typename T>
 __device__ __forceinline__ void cfmac(cx<T>& acc, cx<T> a, cx<T> b) {
-  acc.r += a.r * b.r + a.i * b.i;
-  acc.i += a.i * b.r - a.r * b.i;
+  acc.r = __builtin_fma(a.r, b.r, acc.r);
+  acc.r = __builtin_fma(a.i, b.i, acc.r);
+  acc.i = __builtin_fma(a.i, b.r, acc.i);
+  acc.i = __builtin_fma(-a.r, b.i, acc.i);
 }
 
 template <typename T>

@@ -15,7 +15,7 @@ import torch  # imported before the .so so that the process-wide libamdhip64 is 
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LGN_AMD_LIB") or os.path.join(_HERE, "_lib", "liblgn_amd.so")   # LGN_AMD_LIB: debug builds (tools/)
-ABI_VERSION = 5
+ABI_VERSION = 6
 FINALIZE_SCRATCH = 2048      # include/lgn_amd.h: LGN_FINALIZE_SCRATCH
 
 _lib: Optional[C.CDLL] = None
@@ -68,6 +68,8 @@ _SIGNATURES.update({
     "lgn_moments_bwd_f64": [_i] * 5 + [_vp] * 16,
     "lgn_local_fwd_f64": [_i] * 5 + [_tp] + [_vp] * 5,
     "lgn_local_partial_rows": [_i],
+    "lgn_local_fwd_static_f64": [_i] * 4 + [_vp] * 3 + [_ip] + [_vp] * 3 + [_i, _vp],
+    "lgn_local_bwd_static_f64": [_i] * 4 + [_vp] * 3 + [_ip] + [_vp] * 8,
     "lgn_local_bwd_f64": [_i] * 5 + [_tp] + [_vp] * 8,
     "lgn_step_param_slots": [_dp, _i],
     "lgn_step_fwd_bwd_f64": [_dp, _vp, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _vp, _vp],
@@ -78,7 +80,7 @@ _SIGNATURES.update({
     "lgn_step_finalize_f64": [_vp, _vp, _ll, _vp, _i, _d, _vp, _vp, _vp, _d, _d, _d, _d, _i, _vp, _vp],
 })
 EXPORTED_SYMBOLS = ["lgn_abi_version", "lgn_last_error", "lgn_step_workspace_doubles", "lgn_net_workspace_doubles",
-                    "lgn_moments_scratch_doubles"] + list(_SIGNATURES)
+                    "lgn_moments_scratch_doubles", "lgn_local_static_packed_doubles"] + list(_SIGNATURES)
 
 
 def lib() -> C.CDLL:
@@ -105,6 +107,8 @@ def lib() -> C.CDLL:
         l.lgn_net_workspace_doubles.restype = C.c_longlong
         l.lgn_moments_scratch_doubles.argtypes = [_i, _i, _i, _i]
         l.lgn_moments_scratch_doubles.restype = C.c_longlong
+        l.lgn_local_static_packed_doubles.argtypes = [_i, _i, _i]
+        l.lgn_local_static_packed_doubles.restype = C.c_longlong
         _lib = l
     return _lib
 

@@ -249,3 +249,36 @@ def build_local_tables(plan: LevelPlan, cg_dict, tol: float = 1e-14, weight_offs
     n_units = sum(((d + 3) // 4) * nb for d, nb in zip(out_dim, out_nblk))       # (irrep, chunk of <= 4 rows, block) units of the forward walk
     return dict(Q=Q, Qout=qo, n_rows=nrows, n_out=len(out_irreps), n_w=wbase, n_units=n_units, ints=ints, dbls=dbls,
                 in_irreps=list(plan.node_order), out_irreps=out_irreps)
+
+
+# ---------------------------------------------------------------------------------------------------
+# the two level kinds of maxdim = 3 networks, matched against compile-time tables (csrc/cg_static_tables.hpp)
+# ---------------------------------------------------------------------------------------------------
+_STATIC_CACHE = {}
+
+
+def canonical_static_tables():
+    """{kind: tables} of the first level (kind 1: node irreps (1,1), (0,0)) and of a later level (kind 2: all five irreps) of a
+    maxdim = 3 network with CGMLP levels; the channel counts do not enter the walk tables."""
+    if not _STATIC_CACHE:
+        from .cg_lib import CGDict
+        cg = CGDict(maxdim=3)
+        tau0 = {(0, 0): 2, (1, 1): 2}
+        plans = build_level_plans([2, 2, 2], [3, 3], [1, 1], True, tau0, param_key_order(sorted(tau0)))
+        for kind, plan in ((1, plans[0]), (2, plans[1])):
+            _STATIC_CACHE[kind] = build_local_tables(plan, cg)
+    return _STATIC_CACHE
+
+
+_STATIC_KEYS_I = ("out_dim", "out_nblk", "out_row0", "out_q0", "row_ptr", "t_type", "t_a", "t_b", "u_ptr", "u_row")
+_STATIC_KEYS_D = ("t_coef", "u_coef")
+
+
+def static_kind(tab: dict) -> int:
+    """1 / 2 when a level's tables are exactly those compiled into csrc/cg_static_tables.hpp, else 0."""
+    for kind, ref in canonical_static_tables().items():
+        if (tab["Q"] == ref["Q"] and tab["Qout"] == ref["Qout"] and tab["n_rows"] == ref["n_rows"]
+                and all(list(tab["ints"][k]) == list(ref["ints"][k]) for k in _STATIC_KEYS_I)
+                and all(list(tab["dbls"][k]) == list(ref["dbls"][k]) for k in _STATIC_KEYS_D)):
+            return kind
+    return 0
