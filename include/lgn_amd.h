@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LGN_AMD_ABI_VERSION 6   /* bump on ANY struct or signature change (lgn/_native.py: ABI_VERSION) */
+#define LGN_AMD_ABI_VERSION 7   /* bump on ANY struct or signature change (lgn/_native.py: ABI_VERSION) */
 
 int lgn_abi_version(void);
 const char* lgn_last_error(void);
@@ -130,7 +130,9 @@ typedef struct lgn_local_tables {
   int n_rows, n_out, n_w;          /* concatenated rows (irrep, block, m); output irreps; complex CatMix weights */
   int n_terms, n_u, n_x;           /* lengths of the three CSR term lists (= row_ptr[n_rows], u_ptr[5 Q], x_ptr[Q]); the backward keeps
                                       the U list in LDS and the host sizes it from n_u */
-  int n_units, reserved;           /* forward walk units: sum over output irreps of ceil(dim / 4) * blocks (<= 128) */
+  int n_units, static_kind;        /* n_units: reserved (0).  static_kind: 1 / 2 when these tables are exactly the ones compiled into
+                                      the library for the first / later levels of maxdim = 3 networks (csrc/cg_static_tables.hpp,
+                                      lgn/plan.py: static_kind), else 0: whole-network calls then run the compile-time-table kernels */
   const int *row_ptr, *t_type, *t_a, *t_b;      /* CSR terms per row: type (t_type & 3) 0: U[a = q*5+k], 1: X[a], 2: X[a]*X[b];
                                                    t_type & 4 marks the last term of a row (every row has >= 1 term) */
   const double* t_coef;
@@ -139,6 +141,7 @@ typedef struct lgn_local_tables {
   const double* u_coef;
   const int *x_ptr, *x_row, *x_other;
   const double* x_coef;
+  int h_out_w0[8];                 /* host copy of out_w0 (first n_out entries): the compile-time-table kernels take the offsets by value */
 } lgn_local_tables;
 
 /* X [2][nodes][C][Q], U [nodes][C][Q][5][2], wcat = CatMix weights of all irreps ([2][CO][nblk*C] each, at out_w0),

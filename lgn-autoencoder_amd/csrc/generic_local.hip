@@ -395,6 +395,39 @@ __global__ __launch_bounds__(BLOCK) void gen_unpack_kernel(size_t total, int Q, 
     else v[nc * 4 + k] = X[nc * Q + q_v + k];
   }
 }
+// tile-blocked variants: XT [tile][C][Q][2][64]
+__global__ __launch_bounds__(BLOCK) void gen_pack_tb_kernel(int M, int C, int Q, int q_s, int q_v, const double* __restrict__ s,
+                                                           const double* __restrict__ v, double* __restrict__ XT) {
+  const size_t tiles = (M + 63) / 64, total = tiles * C * Q * 128, pl = (size_t)M * C;
+  for (size_t e = (size_t)blockIdx.x * BLOCK + threadIdx.x; e < total; e += (size_t)gridDim.x * BLOCK) {
+    const int lane = e & 63, z = (e >> 6) & 1;
+    const size_t r = e >> 7;                  // (tile, c, q)
+    const int q = (int)(r % Q), c = (int)((r / Q) % C);
+    const size_t n = (r / ((size_t)Q * C)) * 64 + lane;
+    double val = 0.0;
+    if (n < (size_t)M) {
+      const size_t nc = z * pl + n * C + c;
+      if (q == q_s) val = s[nc];
+      else if (q >= q_v && q < q_v + 4) val = v[nc * 4 + (q - q_v)];
+    }
+    XT[e] = val;
+  }
+}
+__global__ __launch_bounds__(BLOCK) void gen_unpack_tb_kernel(int M, int C, int Q, int q_s, int q_v, const double* __restrict__ XT,
+                                                             double* __restrict__ s, double* __restrict__ v) {
+  const size_t total = (size_t)2 * M * C * 5, pl = (size_t)M * C;
+  for (size_t e = (size_t)blockIdx.x * BLOCK + threadIdx.x; e < total; e += (size_t)gridDim.x * BLOCK) {
+    const size_t nc = e / 5;                  // (plane, node, channel)
+    const int k = (int)(e - nc * 5), z = (int)(nc / pl);
+    const size_t r = nc - z * pl;
+    const int n = (int)(r / C), c = (int)(r - (size_t)n * C);
+    const int q = k == 4 ? q_s : q_v + k;
+    const double val = XT[((size_t)((n >> 6) * C + c) * Q + q) * 128 + z * 64 + (n & 63)];
+    if (k == 4) s[nc] = val;
+    else v[nc * 4 + k] = val;
+  }
+}
+
 static int glue_grid(size_t n) {
   size_t g = (n + BLOCK - 1) / BLOCK;
   return (int)(g < 4096 ? (g ? g : 1) : 4096);
@@ -402,6 +435,18 @@ static int glue_grid(size_t n) {
 int gen_pack(size_t nodes_x_C, int Q, int q_s, int q_v, const double* s, const double* v, double* X, hipStream_t st) {
   LGN_CHECK_ARG(Q >= 5 && q_s >= 0 && q_s < Q && q_v >= 0 && q_v + 4 <= Q && (q_s < q_v || q_s >= q_v + 4), "gen_pack: bad component offsets");
   hipLaunchKernelGGL(gen_pack_kernel, dim3(glue_grid(2 * nodes_x_C * Q)), dim3(BLOCK), 0, st, nodes_x_C, Q, q_s, q_v, s, v, X);
+  LGN_CHECK_LAUNCH();
+  return 0;
+}
+int gen_pack_tb(int M, int C, int Q, int q_s, int q_v, const double* s, const double* v, double* XT, hipStream_t st) {
+  LGN_CHECK_ARG(Q >= 5 && q_s >= 0 && q_s < Q && q_v >= 0 && q_v + 4 <= Q && (q_s < q_v || q_s >= q_v + 4), "gen_pack_tb: bad component offsets");
+  hipLaunchKernelGGL(gen_pack_tb_kernel, dim3(glue_grid((size_t)((M + 63) / 64) * C * Q * 128)), dim3(BLOCK), 0, st, M, C, Q, q_s, q_v, s, v, XT);
+  LGN_CHECK_LAUNCH();
+  return 0;
+}
+int gen_unpack_tb(int M, int C, int Q, int q_s, int q_v, const double* XT, double* s, double* v, hipStream_t st) {
+  LGN_CHECK_ARG(Q >= 5 && q_s >= 0 && q_s < Q && q_v >= 0 && q_v + 4 <= Q && (q_s < q_v || q_s >= q_v + 4), "gen_unpack_tb: bad component offsets");
+  hipLaunchKernelGGL(gen_unpack_tb_kernel, dim3(glue_grid((size_t)2 * M * C * 5)), dim3(BLOCK), 0, st, M, C, Q, q_s, q_v, XT, s, v);
   LGN_CHECK_LAUNCH();
   return 0;
 }

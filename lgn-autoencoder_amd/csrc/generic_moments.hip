@@ -608,6 +608,7 @@ int moments_dispatch(const GenArgs& a, int decoder, int which, hipStream_t st) {
     const bool v1 = e && e[0] == '1';
     if (!v1 && moments2_fits(a, decoder) && (decoder || which != 2 || a.gbuf)) return moments2_dispatch(a, decoder, which, a.gbuf, st);
   }
+  LGN_CHECK_ARG(!a.tb, "moments: the tile-blocked layout is implemented by the channel-outermost kernels only (N <= 32)");
 #define LGN_CASE(CC) case CC: return decoder ? launch_moments<CC, true>(a, which, st) : launch_moments<CC, false>(a, which, st);
   switch (a.C) {
     LGN_CASE(1) LGN_CASE(2) LGN_CASE(3) LGN_CASE(4) LGN_CASE(5) LGN_CASE(6) LGN_CASE(7) LGN_CASE(8)

@@ -169,11 +169,10 @@ __global__ __launch_bounds__(BLOCK) void moments_fwd2_kernel(GenArgs a) {
   for (int c = 0; c < C; ++c) {
     __syncthreads();                                           // previous channel's sweeps are done with Rl / xs / wl
     if (!DEC) load_channel_consts(a, c, J.wl);
-    for (int e = threadIdx.x; e < N * Q; e += BLOCK) {
-      const int j = e / Q, q = e - j * Q;
-      const size_t g = (((size_t)b * N + j) * C + c) * Q + q;
-      xs[2 * e] = a.X[g];
-      xs[2 * e + 1] = a.X[plane + g];
+    for (int e = threadIdx.x; e < N * Q; e += BLOCK) {         // fastest index = the one that is contiguous in memory
+      const int q = a.tb ? e / N : e % Q, j = a.tb ? e % N : e / Q;
+      xs[2 * (j * Q + q)] = a.X[feat_index(a.tb, plane, C, Q, b * N + j, c, q, 0)];
+      xs[2 * (j * Q + q) + 1] = a.X[feat_index(a.tb, plane, C, Q, b * N + j, c, q, 1)];
     }
     __syncthreads();
     fill_R<DEC>(a, c, J, RP);
@@ -208,8 +207,13 @@ __global__ __launch_bounds__(BLOCK) void moments_fwd2_kernel(GenArgs a) {
         for (int k = 0; k < 5; ++k) {
           const double sr = pair_sum(acc[x][k].r), si = pair_sum(acc[x][k].i);
           if (half == 0 && iok && q0 + x < Q) {
-            u[(x * 5 + k) * 2] = sr;
-            u[(x * 5 + k) * 2 + 1] = si;
+            if (a.tb) {
+              a.U[feat_index(true, 0, C, 5 * Q, b * N + ii, c, (q0 + x) * 5 + k, 0)] = sr;
+              a.U[feat_index(true, 0, C, 5 * Q, b * N + ii, c, (q0 + x) * 5 + k, 1)] = si;
+            } else {
+              u[(x * 5 + k) * 2] = sr;
+              u[(x * 5 + k) * 2 + 1] = si;
+            }
           }
         }
     }
@@ -242,9 +246,16 @@ __global__ __launch_bounds__(BLOCK) void moments_bwd_nodes2_kernel(GenArgs a) {
   for (int c = 0; c < C; ++c) {
     __syncthreads();
     if (!DEC) load_channel_consts(a, c, J.wl);
-    for (int e = threadIdx.x; e < N * Q * 10; e += BLOCK) {
-      const int i = e / (Q * 10), r = e - i * Q * 10;
-      gu[e] = a.gU[(((size_t)b * N + i) * C + c) * Q * 10 + r];
+    if (a.tb) {
+      for (int e = threadIdx.x; e < N * Q * 10; e += BLOCK) {
+        const int r = e / N, i = e - r * N;                    // r = (q * 5 + k) * 2 + z; i fastest
+        gu[(size_t)i * Q * 10 + r] = a.gU[feat_index(true, 0, C, 5 * Q, b * N + i, c, r >> 1, r & 1)];
+      }
+    } else {
+      for (int e = threadIdx.x; e < N * Q * 10; e += BLOCK) {
+        const int i = e / (Q * 10), r = e - i * Q * 10;
+        gu[e] = a.gU[(((size_t)b * N + i) * C + c) * Q * 10 + r];
+      }
     }
     __syncthreads();
     fill_R<DEC>(a, c, J, RP);
@@ -255,10 +266,8 @@ __global__ __launch_bounds__(BLOCK) void moments_bwd_nodes2_kernel(GenArgs a) {
       for (int x = 0; x < QPT; ++x) {
         acc[x] = {0, 0};
         xme[x] = {0, 0};
-        if (DEC && q0 + x < Q) {
-          const size_t g = (((size_t)b * N + jj) * C + c) * Q + q0 + x;
-          xme[x] = {a.X[g], a.X[plane + g]};
-        }
+        if (DEC && q0 + x < Q)
+          xme[x] = {a.X[feat_index(a.tb, plane, C, Q, b * N + jj, c, q0 + x, 0)], a.X[feat_index(a.tb, plane, C, Q, b * N + jj, c, q0 + x, 1)]};
       }
       double pme[PS];
 #pragma unroll
@@ -286,9 +295,8 @@ __global__ __launch_bounds__(BLOCK) void moments_bwd_nodes2_kernel(GenArgs a) {
       for (int x = 0; x < QPT; ++x) {
         const double sr = pair_sum(acc[x].r), si = pair_sum(acc[x].i);
         if (half == 0 && jok && q0 + x < Q) {
-          const size_t g = (((size_t)b * N + j) * C + c) * Q + q0 + x;
-          a.gX[g] += sr;
-          a.gX[plane + g] += si;
+          a.gX[feat_index(a.tb, plane, C, Q, b * N + j, c, q0 + x, 0)] += sr;
+          a.gX[feat_index(a.tb, plane, C, Q, b * N + j, c, q0 + x, 1)] += si;
         }
       }
     }
@@ -343,15 +351,21 @@ __global__ __launch_bounds__(BLOCK) void moments_bwd_G2_kernel(GenArgs a, double
   cx<double> Gq[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
   for (int c = 0; c < C; ++c) {
     __syncthreads();
-    for (int e = threadIdx.x; e < N * Q * 10; e += BLOCK) {
-      const int n = e / (Q * 10), r = e - n * Q * 10;
-      gu[e] = a.gU[(((size_t)b * N + n) * C + c) * Q * 10 + r];
+    if (a.tb) {
+      for (int e = threadIdx.x; e < N * Q * 10; e += BLOCK) {
+        const int r = e / N, n = e - r * N;
+        gu[(size_t)n * Q * 10 + r] = a.gU[feat_index(true, 0, C, 5 * Q, b * N + n, c, r >> 1, r & 1)];
+      }
+    } else {
+      for (int e = threadIdx.x; e < N * Q * 10; e += BLOCK) {
+        const int n = e / (Q * 10), r = e - n * Q * 10;
+        gu[e] = a.gU[(((size_t)b * N + n) * C + c) * Q * 10 + r];
+      }
     }
     for (int e = threadIdx.x; e < N * Q; e += BLOCK) {
-      const int n = e / Q, q = e - n * Q;
-      const size_t g = (((size_t)b * N + n) * C + c) * Q + q;
-      xs[2 * e] = a.X[g];
-      xs[2 * e + 1] = a.X[plane + g];
+      const int q = a.tb ? e / N : e % Q, n = a.tb ? e % N : e / Q;
+      xs[2 * (n * Q + q)] = a.X[feat_index(a.tb, plane, C, Q, b * N + n, c, q, 0)];
+      xs[2 * (n * Q + q) + 1] = a.X[feat_index(a.tb, plane, C, Q, b * N + n, c, q, 1)];
     }
     __syncthreads();
     double pi[PS];

@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256 * NT) void mlp_fwd_mfma_kernel(MlpArgs<double> 
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = blockIdx.x * 64 + mt * 16 + g + 4 * r;
-      if (c < D && row < M) a.s_out[((size_t)(c & 1) * M * a.C + (size_t)row * a.C + (c >> 1)) * a.ld] = acc[r];
+      if (c < D && row < M) a.s_out[mlp_out_index(a, c & 1, row, c >> 1)] = acc[r];
     }
   }
 }
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256 * NT) void mlp_bwd_mfma_kernel(MlpArgs<double> 
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = blockIdx.x * 64 + mt * 16 + g + 4 * r;
-      gpre[r] = (c < D && row < M) ? a.g_out[((size_t)(c & 1) * M * a.C + (size_t)row * a.C + (c >> 1)) * a.ld] : 0.0;
+      gpre[r] = (c < D && row < M) ? a.g_out[mlp_out_index(a, c & 1, row, c >> 1)] : 0.0;
     }
   }
   int poff_end = a.psize;
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256 * NT) void mlp_bwd_mfma_kernel(MlpArgs<double> 
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = blockIdx.x * 64 + mt * 16 + g + 4 * r;
-        if (c < D && row < M) a.g_in[((size_t)(c & 1) * M * a.C + (size_t)row * a.C + (c >> 1)) * a.ld] = gin[r];
+        if (c < D && row < M) a.g_in[mlp_out_index(a, c & 1, row, c >> 1)] = gin[r];
       }
     }
   }

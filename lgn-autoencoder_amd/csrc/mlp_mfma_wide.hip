@@ -152,7 +152,7 @@ __global__ __launch_bounds__(64 * MT * NT) void mlp_fwd_wide_kernel(MlpArgs<doub
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = row0 + mt * 16 + g + 4 * r;
-      if (c < D && row < M) a.s_out[((size_t)(c & 1) * M * a.C + (size_t)row * a.C + (c >> 1)) * a.ld] = acc[r];
+      if (c < D && row < M) a.s_out[mlp_out_index(a, c & 1, row, c >> 1)] = acc[r];
     }
   }
   (void)S;
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(64 * MT * NT) void mlp_bwd_wide_kernel(MlpArgs<doub
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = row0 + mt * 16 + g + 4 * r;
-        gpre[r] = (c < D && row < M) ? a.g_out[((size_t)(c & 1) * M * a.C + (size_t)row * a.C + (c >> 1)) * a.ld] : 0.0;
+        gpre[r] = (c < D && row < M) ? a.g_out[mlp_out_index(a, c & 1, row, c >> 1)] : 0.0;
       }
     }
     int poff_end = a.psize;
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(64 * MT * NT) void mlp_bwd_wide_kernel(MlpArgs<doub
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = row0 + mt * 16 + g + 4 * r;
-          if (c < D && row < M) a.g_in[((size_t)(c & 1) * M * a.C + (size_t)row * a.C + (c >> 1)) * a.ld] = gin[r];
+          if (c < D && row < M) a.g_in[mlp_out_index(a, c & 1, row, c >> 1)] = gin[r];
         }
       }
     }

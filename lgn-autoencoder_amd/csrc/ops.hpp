@@ -50,7 +50,16 @@ struct MlpArgs {
   // element stride of s_out / g_out / g_in (s_in is always dense): 1 = [2][M][C]; Q = the scalar column of a packed
   // feature tensor [2][M][C][Q] (pointer already offset to that column) -- the table-driven levels apply the MLP in place
   int ld = 1;
+  // tbQ > 0: s_out / g_out / g_in are the scalar column of a tile-blocked tensor [tile][C][tbQ][2][64] (pointer offset to the
+  // column: + q_s * 128); element (plane z, row, channel ch) at (((row >> 6) * C + ch) * tbQ) * 128 + z * 64 + (row & 63)
+  int tbQ = 0;
 };
+// address of (z, row, ch) in the MLP's strided operands
+template <typename T>
+__host__ __device__ inline size_t mlp_out_index(const MlpArgs<T>& a, int z, int row, int ch) {
+  if (a.tbQ > 0) return ((size_t)((row >> 6) * a.C + ch) * a.tbQ) * 128 + z * 64 + (row & 63);
+  return ((size_t)z * a.M * a.C + (size_t)row * a.C + ch) * a.ld;
+}
 template <typename T> int mlp_dispatch(const MlpArgs<T>&, bool backward, hipStream_t);
 int mlp_mfma_dispatch(const MlpArgs<double>&, bool backward, hipStream_t);
 int mlp_mfma_wide_dispatch(const MlpArgs<double>&, bool backward, hipStream_t);   // 48 < H <= 96 (mlp_mfma_wide.hip)
@@ -85,7 +94,13 @@ struct GenArgs {
   double* part_rad;         // [B][rad_partial_size]
   double* gbuf;             // encoder i-centric backward, N <= 32: pair-gradient scratch, moments2_gbuf_doubles(B, N, C) doubles (optional:
                             // without it the v1 kernel of generic_moments.hip runs)
+  int tb;                   // 1: X / gX are [tile][C][Q][2][64] and U / gU [tile][C][5 Q][2][64] (node n = b N + j = 64 tile + lane),
+                            // the layouts of generic_local_static.hip (channel-outermost kernels of generic_moments2.hip only)
 };
+// element (node n, channel c, component q, plane z) of a feature tensor in either layout; Qx = components per channel
+__host__ __device__ inline size_t feat_index(bool tb, size_t plane, int C, int Qx, int n, int c, int q, int z) {
+  return tb ? ((size_t)((n >> 6) * C + c) * Qx + q) * 128 + z * 64 + (n & 63) : (size_t)z * plane + ((size_t)n * C + c) * Qx + q;
+}
 size_t moments2_gbuf_doubles(int B, int N, int C);
 int moments_dispatch(const GenArgs& a, int decoder, int which, hipStream_t st);
 
@@ -129,5 +144,8 @@ int local_fwd_static(int kind, int M, int C, int CO, const double* XT, const dou
 // packed X [2][nodes][C][Q] <-> s [2][nodes][C] (component q_s) + v [2][nodes][C][4] (components q_v..q_v+3); pack zero-fills the rest
 int gen_pack(size_t nodes_x_C, int Q, int q_s, int q_v, const double* s, const double* v, double* X, hipStream_t st);
 int gen_unpack(size_t nodes_x_C, int Q, int q_s, int q_v, const double* X, double* s, double* v, hipStream_t st);
+// the same with the packed tensor tile-blocked: XT [tile][C][Q][2][64]  (M nodes; whole tiles are written, padding lanes zero)
+int gen_pack_tb(int M, int C, int Q, int q_s, int q_v, const double* s, const double* v, double* XT, hipStream_t st);
+int gen_unpack_tb(int M, int C, int Q, int q_s, int q_v, const double* XT, double* s, double* v, hipStream_t st);
 
 }  // namespace lgn

@@ -5,6 +5,8 @@
 // on the caller's stream, no host synchronisation, every buffer caller-owned and static -> the call can be
 // captured into a HIP graph (the Python harness does so) and replayed.  Parameter gradients are written
 // straight into the caller's flat gradient buffer at the same offsets as the parameters.
+#include <stdlib.h>
+
 #include <vector>
 
 #include "net.hpp"
@@ -290,6 +292,18 @@ inline GenGeom geom(const lgn_net_desc& d, bool dec) {
              : GenGeom{d.enc_channels, d.enc_Q, d.enc_qs, d.enc_qv, d.enc_tables};
 }
 
+// every level has compile-time tables and the jets fit the channel-outermost moments kernels: tile-blocked feature layouts
+// [tile][C][Q][2][64] end to end, generic_local_static.hip for the per-node part
+inline bool is_static(const lgn_net_desc& d, bool dec) {
+  const GenGeom g = geom(d, dec);
+  if (d.N > 32) return false;
+  for (int l = 0; l < d.n_levels; ++l)
+    if (!g.tab[l] || g.tab[l]->static_kind == 0) return false;
+  const char* e = getenv("LGN_AMD_NO_STATIC");          // =1: run-time-table kernels (cross-check)
+  return !(e && e[0] == '1');
+}
+inline size_t tb_doubles(const lgn_net_desc& d, int C, int Qx) { return (size_t)(((size_t)d.B * d.N + 63) / 64) * C * Qx * 128; }
+
 int check_generic(const lgn_net_desc& d, bool dec) {
   const GenGeom g = geom(d, dec);
   for (int l = 0; l < d.n_levels; ++l) {
@@ -306,6 +320,7 @@ int check_generic(const lgn_net_desc& d, bool dec) {
 struct GenAct {                     // written by the forward, read by the backward
   double *s0, *v0;                  // input-kernel outputs [2][BN][C0], [2][BN][C0][4]
   double *X[5], *U[4], *smix[4];
+  double* wp[4];                    // static path: packed CatMix weights of each level (repacked by every forward / backward call)
   double *sL, *vL;                  // (0,0) / (1,1) of the last level, unpacked for the end kernels
   double* pdec;
   int* idx;
@@ -319,10 +334,12 @@ GenAct carve_gen_act(const lgn_net_desc& d, bool dec, double* base) {
   const int L = d.n_levels;
   a.s0 = b.take(2 * BN * g.ch[0]);
   a.v0 = b.take(8 * BN * g.ch[0]);
-  for (int l = 0; l <= L; ++l) a.X[l] = b.take(2 * BN * g.ch[l] * g.Q[l]);
+  const bool tb = is_static(d, dec);                  // whole tiles of 64 nodes
+  for (int l = 0; l <= L; ++l) a.X[l] = b.take(tb ? tb_doubles(d, g.ch[l], g.Q[l]) : 2 * BN * g.ch[l] * g.Q[l]);
   for (int l = 0; l < L; ++l) {
-    a.U[l] = b.take(10 * BN * g.ch[l] * g.Q[l]);
+    a.U[l] = b.take(tb ? tb_doubles(d, g.ch[l], 5 * g.Q[l]) : 10 * BN * g.ch[l] * g.Q[l]);
     a.smix[l] = b.take(2 * BN * g.ch[l + 1]);
+    a.wp[l] = tb ? b.take(local_static_packed_doubles(g.tab[l]->static_kind, g.ch[l], g.ch[l + 1])) : nullptr;
   }
   a.sL = b.take(2 * BN * g.ch[L]);
   a.vL = b.take(8 * BN * g.ch[L]);
@@ -338,6 +355,7 @@ struct GenScratch {
   double *gs, *gv;                  // unpacked gradients at the two ends
   double *gX[2], *gU;
   double* gbuf;                     // encoder: pair-gradient scratch of the channel-outermost radial backward (generic_moments2.hip)
+  double* gpk[4];                   // static path: reduced packed CatMix weight gradients per level
   double* tot[4];
   double* parts;
   size_t parts_size, total;
@@ -362,14 +380,20 @@ GenScratch carve_gen_scratch(const lgn_net_desc& d, bool dec, double* base) {
   }
   s.gs = b.take(2 * BN * cmax);
   s.gv = b.take(8 * BN * cmax);
-  s.gX[0] = b.take(2 * BN * cq);
-  s.gX[1] = b.take(2 * BN * cq);
-  s.gU = b.take(10 * BN * cq);
+  const bool tb = is_static(d, dec);
+  const size_t tiles = (BN + 63) / 64;
+  s.gX[0] = b.take(tb ? tiles * cq * 128 : 2 * BN * cq);
+  s.gX[1] = b.take(tb ? tiles * cq * 128 : 2 * BN * cq);
+  s.gU = b.take(tb ? tiles * cq * 640 : 10 * BN * cq);
+  for (int l = 0; l < L; ++l)
+    s.gpk[l] = tb ? b.take(local_static_packed_doubles(g.tab[l]->static_kind, g.ch[l], g.ch[l + 1])) : nullptr;
   s.gbuf = (!dec && d.N <= 32) ? b.take(moments2_gbuf_doubles(d.B, d.N, (int)cmax)) : nullptr;
   size_t psum = 0;
   for (int l = 0; l < L; ++l) {
     const size_t nrad = rad_partial_size(g.ch[l], dec);
-    psum += (((size_t)local_partial_rows((int)BN) * 2 * g.tab[l]->n_w + 15) & ~size_t(15)) + (((size_t)d.B * nrad + 15) & ~size_t(15));
+    const size_t lrows = tb ? tiles * local_static_packed_doubles(g.tab[l]->static_kind, g.ch[l], g.ch[l + 1])
+                            : (size_t)local_partial_rows((int)BN) * 2 * g.tab[l]->n_w;
+    psum += ((lrows + 15) & ~size_t(15)) + (((size_t)d.B * nrad + 15) & ~size_t(15));
     psum += ((size_t)mlp_partial_rows((int)BN) * mlp_psize(g.ch[l + 1], d.mlp_hidden_mul * 2 * g.ch[l + 1], d.mlp_nlin) + 15) & ~size_t(15);
     s.tot[l] = b.take(nrad + 16);
   }
@@ -399,51 +423,84 @@ int gen_levels_fwd(const lgn_net_desc& d, bool dec, const double* P, const int64
   const Slots S{d.n_levels, d.mlp_nlin};
   const GenGeom g = geom(d, dec);
   const int BN = d.B * d.N;
+  const bool tb = is_static(d, dec);
   for (int l = 0; l < d.n_levels; ++l) {
     GenArgs m = gen_level_args(d, dec, l, P, off, a.X[l], pos, mask);
     m.U = a.U[l];
+    m.tb = tb;
     LGN_TRY(moments_dispatch(m, dec, 0, st));
-    LocalArgs la{};
-    LGN_TRY(local_args(la, BN, g.ch[l], g.ch[l + 1], g.Q[l], g.Q[l + 1], g.tab[l]));
-    la.X = a.X[l]; la.U = a.U[l]; la.wcat = P + off[S.mix(dec, l, 0)]; la.out = a.X[l + 1];
-    la.s_copy = a.smix[l]; la.q_s = g.qs[l + 1];
-    LGN_TRY(local_fwd(la, st));
+    if (tb) {
+      int w0[8];
+      for (int k = 0; k < 5; ++k) w0[k] = g.tab[l]->h_out_w0[k];
+      LGN_TRY(local_fwd_static(g.tab[l]->static_kind, BN, g.ch[l], g.ch[l + 1], a.X[l], a.U[l], P + off[S.mix(dec, l, 0)], w0, a.wp[l],
+                               a.X[l + 1], a.smix[l], g.qs[l + 1], st));
+    } else {
+      LocalArgs la{};
+      LGN_TRY(local_args(la, BN, g.ch[l], g.ch[l + 1], g.Q[l], g.Q[l + 1], g.tab[l]));
+      la.X = a.X[l]; la.U = a.U[l]; la.wcat = P + off[S.mix(dec, l, 0)]; la.out = a.X[l + 1];
+      la.s_copy = a.smix[l]; la.q_s = g.qs[l + 1];
+      LGN_TRY(local_fwd(la, st));
+    }
     MlpArgs<double> mm{};
     mm.M = BN; mm.C = g.ch[l + 1]; mm.H = d.mlp_hidden_mul * 2 * g.ch[l + 1]; mm.nlin = d.mlp_nlin;
     for (int q = 0; q < d.mlp_nlin; ++q) { mm.w[q] = P + off[S.mlp(dec, l, 2 * q)]; mm.b[q] = P + off[S.mlp(dec, l, 2 * q + 1)]; }
-    mm.s_in = a.smix[l]; mm.s_out = a.X[l + 1] + g.qs[l + 1]; mm.ld = g.Q[l + 1];
+    mm.s_in = a.smix[l];
+    if (tb) { mm.s_out = a.X[l + 1] + (size_t)g.qs[l + 1] * 128; mm.tbQ = g.Q[l + 1]; }
+    else { mm.s_out = a.X[l + 1] + g.qs[l + 1]; mm.ld = g.Q[l + 1]; }
     LGN_TRY(mlp_dispatch<double>(mm, false, st));
   }
   return 0;
 }
 
+// packed CatMix weight gradients (static path) are unpacked into the flat gradient AFTER the deferred reductions ran
+struct UnpackJob { int kind, C, CO; int w0[5]; const double* gpacked; double* gw; };
+int run_unpack_jobs(const std::vector<UnpackJob>& post, hipStream_t st) {
+  for (const UnpackJob& j : post) LGN_TRY(local_static_unpack_grads(j.kind, j.C, j.CO, j.w0, j.gpacked, j.gw, st));
+  return 0;
+}
+
 // On entry sc.gX[cur] holds the gradient w.r.t. X[L] (scalar column = 0 when !has_s_grad); on exit sc.gX[cur] the one w.r.t. X[0].
 int gen_levels_bwd(const lgn_net_desc& d, bool dec, const double* P, double* G, const int64_t* off, const GenAct& a, const double* pos,
-                   const uint8_t* mask, GenScratch& sc, Deferred& dq, RadFinJob& fin, int& cur, bool has_s_grad, hipStream_t st) {
+                   const uint8_t* mask, GenScratch& sc, Deferred& dq, RadFinJob& fin, std::vector<UnpackJob>& post, int& cur,
+                   bool has_s_grad, hipStream_t st) {
   const Slots S{d.n_levels, d.mlp_nlin};
   const GenGeom g = geom(d, dec);
   const int BN = d.B * d.N;
+  const bool tb = is_static(d, dec);
   for (int l = d.n_levels - 1; l >= 0; --l) {
     const int C = g.ch[l], CO = g.ch[l + 1];
     if (has_s_grad) {     // CGMLP backward, in place on the scalar column of the gradient
       MlpArgs<double> m{};
       m.M = BN; m.C = CO; m.H = d.mlp_hidden_mul * 2 * CO; m.nlin = d.mlp_nlin;
       for (int q = 0; q < d.mlp_nlin; ++q) { m.w[q] = P + off[S.mlp(dec, l, 2 * q)]; m.b[q] = P + off[S.mlp(dec, l, 2 * q + 1)]; }
-      m.s_in = a.smix[l]; m.g_out = sc.gX[cur] + g.qs[l + 1]; m.g_in = sc.gX[cur] + g.qs[l + 1]; m.ld = g.Q[l + 1];
+      m.s_in = a.smix[l];
+      if (tb) { m.g_out = sc.gX[cur] + (size_t)g.qs[l + 1] * 128; m.g_in = sc.gX[cur] + (size_t)g.qs[l + 1] * 128; m.tbQ = g.Q[l + 1]; }
+      else { m.g_out = sc.gX[cur] + g.qs[l + 1]; m.g_in = sc.gX[cur] + g.qs[l + 1]; m.ld = g.Q[l + 1]; }
       m.psize = mlp_psize(CO, m.H, m.nlin);
       m.part = dq.take((size_t)mlp_partial_rows(BN) * m.psize);
       LGN_TRY(mlp_dispatch<double>(m, true, st));
       dq.add(m.part, mlp_partial_rows(BN), m.psize, 0, m.psize, G + off[S.mlp(dec, l, 0)]);
     }
     const int nxt = cur ^ 1;
-    LocalArgs la{};
-    LGN_TRY(local_args(la, BN, C, CO, g.Q[l], g.Q[l + 1], g.tab[l]));
-    const int rows = local_partial_rows(BN), nw2 = 2 * g.tab[l]->n_w;
-    la.X = a.X[l]; la.U = a.U[l]; la.wcat = P + off[S.mix(dec, l, 0)]; la.g_out = sc.gX[cur];
-    la.gU = sc.gU; la.gX = sc.gX[nxt]; la.part = dq.take((size_t)rows * nw2);
-    LGN_TRY(local_bwd(la, st));
-    dq.add(la.part, rows, nw2, 0, nw2, G + off[S.mix(dec, l, 0)]);
+    if (tb) {       // compile-time-table kernel; its packed partial rows are reduced with everything else, then unpacked (post)
+      int w0[8];
+      for (int k = 0; k < 5; ++k) w0[k] = g.tab[l]->h_out_w0[k];
+      const int kind = g.tab[l]->static_kind, np = (int)local_static_packed_doubles(kind, C, CO), tiles = (BN + 63) / 64;
+      double* part = dq.take((size_t)tiles * np);
+      LGN_TRY(local_bwd_static(kind, BN, C, CO, a.X[l], a.U[l], P + off[S.mix(dec, l, 0)], w0, a.wp[l], sc.gX[cur], sc.gU, sc.gX[nxt], part, st));
+      dq.add(part, tiles, np, 0, np, sc.gpk[l]);
+      post.push_back(UnpackJob{kind, C, CO, {w0[0], w0[1], w0[2], w0[3], w0[4]}, sc.gpk[l], G + off[S.mix(dec, l, 0)]});
+    } else {
+      LocalArgs la{};
+      LGN_TRY(local_args(la, BN, C, CO, g.Q[l], g.Q[l + 1], g.tab[l]));
+      const int rows = local_partial_rows(BN), nw2 = 2 * g.tab[l]->n_w;
+      la.X = a.X[l]; la.U = a.U[l]; la.wcat = P + off[S.mix(dec, l, 0)]; la.g_out = sc.gX[cur];
+      la.gU = sc.gU; la.gX = sc.gX[nxt]; la.part = dq.take((size_t)rows * nw2);
+      LGN_TRY(local_bwd(la, st));
+      dq.add(la.part, rows, nw2, 0, nw2, G + off[S.mix(dec, l, 0)]);
+    }
     GenArgs m = gen_level_args(d, dec, l, P, off, a.X[l], pos, mask);
+    m.tb = tb;
     const int nrad = rad_partial_size(C, dec);
     m.gU = sc.gU; m.gX = sc.gX[nxt]; m.g_p = dec ? sc.g_p : nullptr; m.part_rad = dq.take((size_t)d.B * nrad);
     m.gbuf = sc.gbuf;
@@ -464,17 +521,28 @@ int gen_levels_bwd(const lgn_net_desc& d, bool dec, const double* P, double* G, 
   return 0;
 }
 
+// packed <-> separate (0,0) / (1,1) features at the ends of the level stack, in the layout the network runs on
+int net_pack(const lgn_net_desc& d, bool dec, int l, const double* s, const double* v, double* X, hipStream_t st) {
+  const GenGeom g = geom(d, dec);
+  if (is_static(d, dec)) return gen_pack_tb(d.B * d.N, g.ch[l], g.Q[l], g.qs[l], g.qv[l], s, v, X, st);
+  return gen_pack((size_t)d.B * d.N * g.ch[l], g.Q[l], g.qs[l], g.qv[l], s, v, X, st);
+}
+int net_unpack(const lgn_net_desc& d, bool dec, int l, const double* X, double* s, double* v, hipStream_t st) {
+  const GenGeom g = geom(d, dec);
+  if (is_static(d, dec)) return gen_unpack_tb(d.B * d.N, g.ch[l], g.Q[l], g.qs[l], g.qv[l], X, s, v, st);
+  return gen_unpack((size_t)d.B * d.N * g.ch[l], g.Q[l], g.qs[l], g.qv[l], X, s, v, st);
+}
+
 // ---- one table-driven network, forward / backward (shared by the per-network API and the whole step) ----------------
 int gen_encoder_fwd(const lgn_net_desc& d, const double* P, const int64_t* off, const double* p4, const uint8_t* mask, GenAct& a,
                     double* lat_s, double* lat_v, hipStream_t st) {
   const Slots S{d.n_levels, d.mlp_nlin};
   const GenGeom g = geom(d, false);
   const int L = d.n_levels;
-  const size_t BN = (size_t)d.B * d.N;
   LGN_TRY(enc_input_fwd(d.B, d.N, g.ch[0], p4, P + off[0], P + off[1], a.s0, a.v0, st));
-  LGN_TRY(gen_pack(BN * g.ch[0], g.Q[0], g.qs[0], g.qv[0], a.s0, a.v0, a.X[0], st));
+  LGN_TRY(net_pack(d, false, 0, a.s0, a.v0, a.X[0], st));
   LGN_TRY(gen_levels_fwd(d, false, P, off, a, p4, mask, st));
-  LGN_TRY(gen_unpack(BN * g.ch[L], g.Q[L], g.qs[L], g.qv[L], a.X[L], a.sL, a.vL, st));
+  LGN_TRY(net_unpack(d, false, L, a.X[L], a.sL, a.vL, st));
   LGN_TRY(enc_latent_fwd(d.B, d.N, g.ch[L], d.tau_s, d.tau_v, a.sL, a.vL, P + off[S.out0(false)], P + off[S.out0(false) + 1], lat_s,
                          lat_v, a.idx, st));
   return 0;
@@ -486,7 +554,6 @@ int gen_encoder_bwd(const lgn_net_desc& d, const double* P, double* G, const int
   const Slots S{d.n_levels, d.mlp_nlin};
   const GenGeom g = geom(d, false);
   const int L = d.n_levels, B = d.B, N = d.N, Ts = d.tau_s, Tv = d.tau_v;
-  const size_t BN = (size_t)B * N;
   Deferred dq;
   dq.parts = sc.parts;
   dq.cap = sc.parts_size;
@@ -499,12 +566,13 @@ int gen_encoder_bwd(const lgn_net_desc& d, const double* P, double* G, const int
                            g_lat_s ? g_lat_s : sc.g_lat_s, g_lat_v, a.idx, sc.gs, sc.gv, parte, st));
     dq.add(parte, B, rowe, 0, 2 * Ts * CL, G + off[S.out0(false)]);
     dq.add(parte, B, rowe, 2 * Ts * CL, 2 * Tv * CL, G + off[S.out0(false) + 1]);
-    LGN_TRY(gen_pack(BN * CL, g.Q[L], g.qs[L], g.qv[L], g_lat_s ? sc.gs : sc.zero0, sc.gv, sc.gX[cur], st));
+    LGN_TRY(net_pack(d, false, L, g_lat_s ? sc.gs : sc.zero0, sc.gv, sc.gX[cur], st));
   }
-  LGN_TRY(gen_levels_bwd(d, false, P, G, off, a, p4, mask, sc, dq, fin, cur, g_lat_s != nullptr, st));
+  std::vector<UnpackJob> post;
+  LGN_TRY(gen_levels_bwd(d, false, P, G, off, a, p4, mask, sc, dq, fin, post, cur, g_lat_s != nullptr, st));
   {
     const int C0 = g.ch[0];
-    LGN_TRY(gen_unpack(BN * C0, g.Q[0], g.qs[0], g.qv[0], sc.gX[cur], sc.gs, sc.gv, st));
+    LGN_TRY(net_unpack(d, false, 0, sc.gX[cur], sc.gs, sc.gv, st));
     double* part = dq.take((size_t)B * 4 * C0);
     LGN_TRY(enc_input_bwd(B, N, C0, p4, sc.gs, sc.gv, part, st));
     dq.add(part, B, 4 * C0, 0, 2 * C0, G + off[0]);
@@ -512,6 +580,7 @@ int gen_encoder_bwd(const lgn_net_desc& d, const double* P, double* G, const int
   }
   LGN_CHECK_ARG(dq.off <= dq.cap, "encoder_bwd: partial-row workspace overflow (%zu > %zu)", dq.off, dq.cap);
   LGN_TRY(dq.flush(st));
+  LGN_TRY(run_unpack_jobs(post, st));
   LGN_TRY(rad_finalize_batch(fin, st));
   return 0;
 }
@@ -520,26 +589,24 @@ int gen_encoder_bwd(const lgn_net_desc& d, const double* P, double* G, const int
 int gen_decoder_fwd(const lgn_net_desc& d, const double* P, const int64_t* off, const double* lat_v, GenAct& a, hipStream_t st) {
   const GenGeom g = geom(d, true);
   const int L = d.n_levels, Tin = d.tau_v_in > 0 ? d.tau_v_in : 2 * d.tau_v;
-  const size_t BN = (size_t)d.B * d.N;
   LGN_TRY(dec_input_fwd(d.B, d.N, g.ch[0], Tin, lat_v, P + off[1], P + off[2], P + off[3], a.pdec, a.s0, a.v0, st));
-  LGN_TRY(gen_pack(BN * g.ch[0], g.Q[0], g.qs[0], g.qv[0], a.s0, a.v0, a.X[0], st));
+  LGN_TRY(net_pack(d, true, 0, a.s0, a.v0, a.X[0], st));
   LGN_TRY(gen_levels_fwd(d, true, P, off, a, a.pdec, nullptr, st));
-  LGN_TRY(gen_unpack(BN * g.ch[L], g.Q[L], g.qs[L], g.qv[L], a.X[L], a.sL, a.vL, st));
+  LGN_TRY(net_unpack(d, true, L, a.X[L], a.sL, a.vL, st));
   return 0;
 }
 
 // sc.gv holds the gradient w.r.t. the last level's (1,1) features (from dec_output_bwd / dec_output_loss); dq carries the
 // caller's pending reductions and is flushed by the caller
 int gen_decoder_bwd(const lgn_net_desc& d, const double* P, double* G, const int64_t* off, const double* lat_v, const GenAct& a,
-                    double* g_lat_v, GenScratch& sc, Deferred& dq, RadFinJob& fin, hipStream_t st) {
+                    double* g_lat_v, GenScratch& sc, Deferred& dq, RadFinJob& fin, std::vector<UnpackJob>& post, hipStream_t st) {
   const GenGeom g = geom(d, true);
   const int L = d.n_levels, B = d.B, N = d.N, Tin = d.tau_v_in > 0 ? d.tau_v_in : 2 * d.tau_v;
-  const size_t BN = (size_t)B * N;
   int cur = 0;
-  LGN_TRY(gen_pack(BN * g.ch[L], g.Q[L], g.qs[L], g.qv[L], sc.zero0, sc.gv, sc.gX[cur], st));
-  LGN_TRY(gen_levels_bwd(d, true, P, G, off, a, a.pdec, nullptr, sc, dq, fin, cur, /*has_s_grad=*/false, st));
+  LGN_TRY(net_pack(d, true, L, sc.zero0, sc.gv, sc.gX[cur], st));
+  LGN_TRY(gen_levels_bwd(d, true, P, G, off, a, a.pdec, nullptr, sc, dq, fin, post, cur, /*has_s_grad=*/false, st));
   const int C0 = g.ch[0], row = 4 * C0 + 2 * N * Tin;
-  LGN_TRY(gen_unpack(BN * C0, g.Q[0], g.qs[0], g.qv[0], sc.gX[cur], sc.gs, sc.gv, st));
+  LGN_TRY(net_unpack(d, true, 0, sc.gX[cur], sc.gs, sc.gv, st));
   double* part = dq.take((size_t)B * row);
   LGN_TRY(dec_input_bwd(B, N, C0, Tin, lat_v, P + off[1], P + off[3], a.pdec, sc.g_p, sc.gs, sc.gv, g_lat_v, part, st));
   dq.add(part, B, row, 0, 2 * C0, G + off[2]);
@@ -599,9 +666,11 @@ int gen_step_fwd_bwd(const lgn_net_desc& d, const double* params, double* grads,
     LGN_TRY(dec_output_loss(B, N, CL, g.da.vL, params + dec_off[S.out0(true) + 1], target, 1.0, recon, loss_part, g.ds.gv, part, st));
     dq.add(part, B, 2 * CL, 0, 2 * CL, grads + dec_off[S.out0(true) + 1]);
   }
-  LGN_TRY(gen_decoder_bwd(d, params, grads, dec_off, g.lat_v, g.da, g.g_lat_v, g.ds, dq, fin, st));
+  std::vector<UnpackJob> post;
+  LGN_TRY(gen_decoder_bwd(d, params, grads, dec_off, g.lat_v, g.da, g.g_lat_v, g.ds, dq, fin, post, st));
   LGN_CHECK_ARG(dq.off <= dq.cap, "step: partial-row workspace overflow (%zu > %zu)", dq.off, dq.cap);
   LGN_TRY(dq.flush(st));
+  LGN_TRY(run_unpack_jobs(post, st));
   // the decoder never reads the latent scalars: no gradient on them
   LGN_TRY(gen_encoder_bwd(d, params, grads, enc_off, p4, mask, g.ea, nullptr, g.g_lat_v, g.es, st));
   return 0;
@@ -827,10 +896,11 @@ int lgn_decoder_bwd_f64(const lgn_net_desc* d, const double* params, double* gra
     double* part = dq.take((size_t)d->B * 2 * CL);
     LGN_TRY(dec_output_bwd(d->B, d->N, CL, ga.vL, params + off[Sg.out0(true) + 1], g_recon, gs.gv, part, gst));
     dq.add(part, d->B, 2 * CL, 0, 2 * CL, grads + off[Sg.out0(true) + 1]);
-    LGN_TRY(gen_decoder_bwd(*d, params, grads, off, lat_v, ga, g_lat_v, gs, dq, fin, gst));
+    std::vector<UnpackJob> post;
+    LGN_TRY(gen_decoder_bwd(*d, params, grads, off, lat_v, ga, g_lat_v, gs, dq, fin, post, gst));
     LGN_CHECK_ARG(dq.off <= dq.cap, "decoder_bwd: partial-row workspace overflow (%zu > %zu)", dq.off, dq.cap);
     LGN_TRY(dq.flush(gst));
-    return 0;
+    return run_unpack_jobs(post, gst);
   }
   NetAct a = carve_act(*d, true, const_cast<double*>(act));
   NetScratch sc = carve_scratch(*d, true, scratch);

@@ -15,7 +15,7 @@ import torch  # imported before the .so so that the process-wide libamdhip64 is 
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LGN_AMD_LIB") or os.path.join(_HERE, "_lib", "liblgn_amd.so")   # LGN_AMD_LIB: debug builds (tools/)
-ABI_VERSION = 6
+ABI_VERSION = 7
 FINALIZE_SCRATCH = 2048      # include/lgn_amd.h: LGN_FINALIZE_SCRATCH
 
 _lib: Optional[C.CDLL] = None
@@ -42,9 +42,9 @@ _SIGNATURES = {
 class LocalTables(C.Structure):
     """lgn_local_tables of include/lgn_amd.h (device pointers)."""
     _fields_ = [("n_rows", C.c_int), ("n_out", C.c_int), ("n_w", C.c_int), ("n_terms", C.c_int), ("n_u", C.c_int),
-                ("n_x", C.c_int), ("n_units", C.c_int), ("reserved", C.c_int)] + [
+                ("n_x", C.c_int), ("n_units", C.c_int), ("static_kind", C.c_int)] + [
         (name, C.c_void_p) for name in ("row_ptr", "t_type", "t_a", "t_b", "t_coef", "out_dim", "out_nblk", "out_row0", "out_q0",
-                                        "out_w0", "u_ptr", "u_row", "u_coef", "x_ptr", "x_row", "x_other", "x_coef")]
+                                        "out_w0", "u_ptr", "u_row", "u_coef", "x_ptr", "x_row", "x_other", "x_coef")] + [("h_out_w0", C.c_int * 8)]
 
 
 _tp = C.POINTER(LocalTables)
@@ -285,7 +285,11 @@ class DeviceTables:
         st = LocalTables()
         st.n_rows, st.n_out, st.n_w = tab["n_rows"], tab["n_out"], tab["n_w"]
         st.n_terms, st.n_u, st.n_x = len(tab["ints"]["t_type"]), len(tab["ints"]["u_row"]), len(tab["ints"]["x_row"])
-        st.n_units = tab["n_units"]
+        st.n_units = 0
+        from .plan import static_kind
+        st.static_kind = static_kind(tab)
+        for i, w0 in enumerate(tab["ints"]["out_w0"][:8]):
+            st.h_out_w0[i] = w0
         for name, vals in tab["ints"].items():
             t = torch.tensor(vals if len(vals) else [0], dtype=torch.int32, device=device)
             self.tensors[name] = t
