@@ -14,6 +14,8 @@
 //            G_k(i,j)[c]    = sum_q dU[i][c][q][k] conj(X_j[c][q])  ->  G_R0, G_R1 of the pair          (i-centric sweep)
 //            encoder: G_R0 / G_R1 go to a global buffer [B][N*N][4C] consumed by the radial-parameter reduction kernel
 //            (the [4C x pairs] . [pairs x 42] matrix-core GEMM of v1, now without the q loop); decoder: bias sums and d p.
+#include <stdlib.h>
+
 #include "level_dev.hpp"
 #include "ops.hpp"
 
@@ -431,6 +433,214 @@ __global__ __launch_bounds__(BLOCK) void moments_bwd_G2_kernel(GenArgs a, double
   }
 }
 
+
+// =========================================================================================================
+// decoder in separable form (SURVEY a-14; the same algebraic change as the SEP instantiations of level_fwd2 / level_bwd3 at
+// maxdim 2, NOT a roofline gain).  The decoder's edge mask is identically zero (lgn_decoder.py:335-340), so its radial functions
+// are the Linear biases: e0 = b0 (1 + i)^2 ... precisely R0 = b0 (1 + i), e0 = R0 (1 + i), R1 = b1 (1 + i), e_{1+m} = R1 (p_i - p_j)[m],
+// constants per channel.  Every pair sum then separates into jet-level sums, O(N Q) per channel instead of O(N^2 Q):
+//   forward    U[i][q][0] = e0 SX[q],   U[i][q][1+m] = R1 (P_i[m] SX[q] - SXP[q][m])        SX = sum_j X_j,  SXP = sum_j X_j P_j
+//   backward   S[q][k] = sum_i dU[i][q][k],  SP[q][m] = sum_i dU[i][q][1+m] conj(P_i[m]):
+//              dX[j][q] += conj(e0) S[q][0] + conj(R1) sum_m (SP[q][m] - conj(P_j[m]) S[q][1+m])
+//              d p_i    += conj(R1) sum_q dU[i][q][1+m] conj(SX[q]),     d p_j -= conj(R1) sum_q S[q][1+m] conj(X_j[q])
+//              d b0 = 2 Im A0,  A0 = sum_q S[q][0] conj(SX[q]);   d b1 = Re A1 + Im A1,  A1 = sum_{q,m} SP conj(SX) - S[1+m] conj(SXP)
+// Momenta are centred on the jet mean first (differences are unchanged; the sums then do not cancel digits the pair sweep would
+// keep under large boosts).  LGN_AMD_DEC_PAIRWISE=1 keeps the pair sweeps above.  One workgroup per jet, channels in a loop.
+// =========================================================================================================
+__device__ __forceinline__ void load_centred(const GenArgs& a, int b, double* pc) {       // pc [N][8]: centred complex canonical momenta
+  const int N = a.N;
+  const size_t plane_p = (size_t)a.B * N * 4;
+  const double* p0 = a.p + (size_t)b * N * 4;
+  __shared__ double mean[8];
+  if (threadIdx.x < 8) {
+    const int m = threadIdx.x & 3, z = threadIdx.x >> 2;
+    double s = 0.0;
+    for (int j = 0; j < N; ++j) s += p0[z * plane_p + j * 4 + m];
+    mean[threadIdx.x] = s / N;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < N * 8; e += BLOCK) {
+    const int j = e >> 3, r = e & 7;
+    pc[e] = p0[(r >> 2) * plane_p + j * 4 + (r & 3)] - mean[r];
+  }
+}
+
+__global__ __launch_bounds__(BLOCK) void moments_dec_sep_fwd_kernel(GenArgs a) {
+  const int N = a.N, Q = a.Q, C = a.C, b = blockIdx.x;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  double* pc = reinterpret_cast<double*>(smem_raw);            // [N][8]
+  double* xs = pc + (size_t)N * 8;                             // [N][Q][2]
+  double* sx = xs + (size_t)N * Q * 2;                         // [Q][5][2]: SX | SXP[0..3]
+  load_centred(a, b, pc);
+  const size_t plane = (size_t)a.B * N * C * Q;
+  for (int c = 0; c < C; ++c) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < N * Q; e += BLOCK) {
+      const int q = a.tb ? e / N : e % Q, j = a.tb ? e % N : e / Q;
+      xs[2 * (j * Q + q)] = a.X[feat_index(a.tb, plane, C, Q, b * N + j, c, q, 0)];
+      xs[2 * (j * Q + q) + 1] = a.X[feat_index(a.tb, plane, C, Q, b * N + j, c, q, 1)];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < Q * 5; e += BLOCK) {         // jet-level sums, in particle order
+      const int q = e / 5, k = e - q * 5;
+      cx<double> s = {0, 0};
+      for (int j = 0; j < N; ++j) {
+        const cx<double> x = {xs[2 * (j * Q + q)], xs[2 * (j * Q + q) + 1]};
+        if (k == 0) { s.r += x.r; s.i += x.i; }
+        else cfma(s, x, cx<double>{pc[j * 8 + k - 1], pc[j * 8 + 4 + k - 1]});
+      }
+      sx[2 * e] = s.r;
+      sx[2 * e + 1] = s.i;
+    }
+    __syncthreads();
+    const double b0 = a.b0[c], b1 = a.b1[c];
+    const cx<double> e0 = {0.0, 2.0 * b0}, R1 = {b1, b1};      // R0 (1 + i) with R0 = b0 (1 + i);  R1 = b1 (1 + i)
+    for (int e = threadIdx.x; e < N * Q * 5; e += BLOCK) {
+      const int i = e / (Q * 5), r = e - i * Q * 5, q = r / 5, k = r - q * 5;
+      const cx<double> SX = {sx[2 * (q * 5)], sx[2 * (q * 5) + 1]};
+      cx<double> u;
+      if (k == 0) u = cmul(e0, SX);
+      else {
+        const cx<double> P = {pc[i * 8 + k - 1], pc[i * 8 + 4 + k - 1]};
+        cx<double> t = cmul(P, SX);
+        t.r -= sx[2 * (q * 5 + k)];
+        t.i -= sx[2 * (q * 5 + k) + 1];
+        u = cmul(R1, t);
+      }
+      if (a.tb) {
+        a.U[feat_index(true, 0, C, 5 * Q, b * N + i, c, r, 0)] = u.r;
+        a.U[feat_index(true, 0, C, 5 * Q, b * N + i, c, r, 1)] = u.i;
+      } else {
+        double* dst = a.U + ((((size_t)b * N + i) * C + c) * Q) * 10 + 2 * r;
+        dst[0] = u.r;
+        dst[1] = u.i;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(BLOCK) void moments_dec_sep_bwd_kernel(GenArgs a) {
+  const int N = a.N, Q = a.Q, C = a.C, b = blockIdx.x, tid = threadIdx.x;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  double* pc = reinterpret_cast<double*>(smem_raw);            // [N][8]
+  double* xs = pc + (size_t)N * 8;                             // [N][Q][2]
+  double* gu = xs + (size_t)N * Q * 2;                         // [N][Q*5][2]
+  double* sx = gu + (size_t)N * Q * 10;                        // [Q][5][2]  SX | SXP
+  double* sg = sx + (size_t)Q * 10;                            // [Q][5][2]  S
+  double* sp = sg + (size_t)Q * 10;                            // [Q][4][2]  SP
+  double* gp = sp + (size_t)Q * 8;                             // [N][8]     d p accumulated over the channels
+  double* ab = gp + (size_t)N * 8;                             // [Q][4]     per-q terms of A0, A1
+  load_centred(a, b, pc);
+  for (int e = tid; e < N * 8; e += BLOCK) gp[e] = 0.0;
+  const size_t plane = (size_t)a.B * N * C * Q;
+  double* part = a.part_rad + (size_t)b * rad_partial_size(C, true);
+  for (int c = 0; c < C; ++c) {
+    __syncthreads();
+    for (int e = tid; e < N * Q; e += BLOCK) {
+      const int q = a.tb ? e / N : e % Q, j = a.tb ? e % N : e / Q;
+      xs[2 * (j * Q + q)] = a.X[feat_index(a.tb, plane, C, Q, b * N + j, c, q, 0)];
+      xs[2 * (j * Q + q) + 1] = a.X[feat_index(a.tb, plane, C, Q, b * N + j, c, q, 1)];
+    }
+    if (a.tb) {
+      for (int e = tid; e < N * Q * 10; e += BLOCK) {
+        const int r = e / N, i = e - r * N;
+        gu[(size_t)i * Q * 10 + r] = a.gU[feat_index(true, 0, C, 5 * Q, b * N + i, c, r >> 1, r & 1)];
+      }
+    } else {
+      for (int e = tid; e < N * Q * 10; e += BLOCK) {
+        const int i = e / (Q * 10), r = e - i * Q * 10;
+        gu[e] = a.gU[(((size_t)b * N + i) * C + c) * Q * 10 + r];
+      }
+    }
+    __syncthreads();
+    // jet-level sums (particle order): SX, SXP from X;  S, SP from dU
+    for (int e = tid; e < Q * 14; e += BLOCK) {
+      const int q = e / 14, w = e - q * 14;
+      cx<double> s = {0, 0};
+      if (w < 5) {                                             // SX (w = 0), SXP[w - 1]
+        for (int j = 0; j < N; ++j) {
+          const cx<double> x = {xs[2 * (j * Q + q)], xs[2 * (j * Q + q) + 1]};
+          if (w == 0) { s.r += x.r; s.i += x.i; }
+          else cfma(s, x, cx<double>{pc[j * 8 + w - 1], pc[j * 8 + 4 + w - 1]});
+        }
+        sx[2 * (q * 5 + w)] = s.r;  sx[2 * (q * 5 + w) + 1] = s.i;
+      } else if (w < 10) {                                     // S[k], k = w - 5
+        const int k = w - 5;
+        for (int i = 0; i < N; ++i) { s.r += gu[((size_t)i * Q + q) * 10 + 2 * k]; s.i += gu[((size_t)i * Q + q) * 10 + 2 * k + 1]; }
+        sg[2 * (q * 5 + k)] = s.r;  sg[2 * (q * 5 + k) + 1] = s.i;
+      } else {                                                 // SP[m], m = w - 10
+        const int mm = w - 10;
+        for (int i = 0; i < N; ++i)
+          cfmac(s, cx<double>{gu[((size_t)i * Q + q) * 10 + 2 * (1 + mm)], gu[((size_t)i * Q + q) * 10 + 2 * (1 + mm) + 1]},
+                cx<double>{pc[i * 8 + mm], pc[i * 8 + 4 + mm]});
+        sp[2 * (q * 4 + mm)] = s.r;  sp[2 * (q * 4 + mm) + 1] = s.i;
+      }
+    }
+    __syncthreads();
+    const double b0 = a.b0[c], b1 = a.b1[c];
+    const cx<double> e0 = {0.0, 2.0 * b0}, R1 = {b1, b1};
+    // d X[j][q] += conj(e0) S[q][0] + conj(R1) sum_m (SP[q][m] - conj(P_j[m]) S[q][1+m])
+    for (int e = tid; e < N * Q; e += BLOCK) {
+      const int q = a.tb ? e / N : e % Q, j = a.tb ? e % N : e / Q;
+      cx<double> t = {0, 0};
+#pragma unroll
+      for (int mm = 0; mm < 4; ++mm) {
+        t.r += sp[2 * (q * 4 + mm)];
+        t.i += sp[2 * (q * 4 + mm) + 1];
+        const cx<double> ps = cmulc(cx<double>{sg[2 * (q * 5 + 1 + mm)], sg[2 * (q * 5 + 1 + mm) + 1]}, cx<double>{pc[j * 8 + mm], pc[j * 8 + 4 + mm]});
+        t.r -= ps.r;
+        t.i -= ps.i;
+      }
+      cx<double> g = cmulc(cx<double>{sg[2 * (q * 5)], sg[2 * (q * 5) + 1]}, e0);
+      cfmac(g, t, R1);
+      a.gX[feat_index(a.tb, plane, C, Q, b * N + j, c, q, 0)] += g.r;
+      a.gX[feat_index(a.tb, plane, C, Q, b * N + j, c, q, 1)] += g.i;
+    }
+    // d p_i[m] += conj(R1) sum_q dU[i][q][1+m] conj(SX[q]);   d p_j[m] -= conj(R1) sum_q S[q][1+m] conj(X_j[q])
+    for (int e = tid; e < N * 4; e += BLOCK) {
+      const int n = e >> 2, mm = e & 3;
+      cx<double> t = {0, 0};
+      for (int q = 0; q < Q; ++q) {
+        cfmac(t, cx<double>{gu[((size_t)n * Q + q) * 10 + 2 * (1 + mm)], gu[((size_t)n * Q + q) * 10 + 2 * (1 + mm) + 1]},
+              cx<double>{sx[2 * (q * 5)], sx[2 * (q * 5) + 1]});
+        cx<double> u = cmulc(cx<double>{sg[2 * (q * 5 + 1 + mm)], sg[2 * (q * 5 + 1 + mm) + 1]}, cx<double>{xs[2 * (n * Q + q)], xs[2 * (n * Q + q) + 1]});
+        t.r -= u.r;
+        t.i -= u.i;
+      }
+      const cx<double> g = cmulc(t, R1);
+      gp[n * 8 + mm] += g.r;
+      gp[n * 8 + 4 + mm] += g.i;
+    }
+    // bias gradients: A0 = sum_q S[q][0] conj(SX[q]);  A1 = sum_{q,m} SP[q][m] conj(SX[q]) - S[q][1+m] conj(SXP[q][m])
+    for (int q = tid; q < Q; q += BLOCK) {
+      const cx<double> SX = {sx[2 * (q * 5)], sx[2 * (q * 5) + 1]};
+      const cx<double> a0 = cmulc(cx<double>{sg[2 * (q * 5)], sg[2 * (q * 5) + 1]}, SX);
+      cx<double> a1 = {0, 0};
+#pragma unroll
+      for (int mm = 0; mm < 4; ++mm) {
+        cfmac(a1, cx<double>{sp[2 * (q * 4 + mm)], sp[2 * (q * 4 + mm) + 1]}, SX);
+        const cx<double> u = cmulc(cx<double>{sg[2 * (q * 5 + 1 + mm)], sg[2 * (q * 5 + 1 + mm) + 1]},
+                                   cx<double>{sx[2 * (q * 5 + 1 + mm)], sx[2 * (q * 5 + 1 + mm) + 1]});
+        a1.r -= u.r;
+        a1.i -= u.i;
+      }
+      ab[q * 4] = a0.r;  ab[q * 4 + 1] = a0.i;  ab[q * 4 + 2] = a1.r;  ab[q * 4 + 3] = a1.i;
+    }
+    __syncthreads();
+    if (tid < 2) {
+      double s = 0.0;
+      for (int q = 0; q < Q; ++q) s += tid == 0 ? 2.0 * ab[q * 4 + 1] : ab[q * 4 + 2] + ab[q * 4 + 3];
+      part[tid * C + c] = s;                                   // dB0[c] | dB1[c]
+    }
+  }
+  __syncthreads();
+  const size_t plp = (size_t)a.B * N * 4;
+  for (int e = tid; e < N * 8; e += BLOCK) {
+    const int n = e >> 3, r = e & 7;
+    a.g_p[(r >> 2) * plp + ((size_t)b * N + n) * 4 + (r & 3)] += gp[e];
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // encoder: radial-parameter sums from the pair gradients Gbuf -- the [4C x pairs] . [pairs x 42] GEMM of
 // moments_bwd_rad_kernel (generic_moments.hip) on the matrix cores, without the q loop.
@@ -621,7 +831,23 @@ size_t moments2_gbuf_doubles(int B, int N, int C) { return (size_t)B * N * N * C
 int moments2_dispatch(const GenArgs& a, int decoder, int which, double* Gbuf, hipStream_t st) {
   LGN_CHECK_ARG(a.B > 0 && a.N > 0 && a.Q > 0, "moments: empty input (B=%d N=%d Q=%d)", a.B, a.N, a.Q);
   LGN_CHECK_ARG(a.C >= 1 && a.C <= 8, "moments: C=%d unsupported (1..8)", a.C);
-  if (decoder) return m2::launch<true>(a, which, nullptr, st);
+  if (decoder) {
+    const char* pw = getenv("LGN_AMD_DEC_PAIRWISE");         // =1: O(N^2) pair sweeps (cross-check of the separable form)
+    if (pw && pw[0] == '1') return m2::launch<true>(a, which, nullptr, st);
+    if (which == 2) return 0;                               // the separable backward does both passes in one launch
+    const size_t base = sizeof(double) * ((size_t)a.N * 8 + (size_t)a.N * a.Q * 2);
+    if (which == 0) {
+      const size_t smem = base + sizeof(double) * (size_t)a.Q * 10;
+      if (int rc = m2::set_smem(m2::moments_dec_sep_fwd_kernel, smem, "moments_dec_sep_fwd")) return rc;
+      hipLaunchKernelGGL(m2::moments_dec_sep_fwd_kernel, dim3(a.B), dim3(BLOCK), smem, st, a);
+    } else {
+      const size_t smem = base + sizeof(double) * ((size_t)a.N * a.Q * 10 + (size_t)a.Q * 28 + (size_t)a.N * 8 + (size_t)a.Q * 4);
+      if (int rc = m2::set_smem(m2::moments_dec_sep_bwd_kernel, smem, "moments_dec_sep_bwd")) return rc;
+      hipLaunchKernelGGL(m2::moments_dec_sep_bwd_kernel, dim3(a.B), dim3(BLOCK), smem, st, a);
+    }
+    LGN_CHECK_LAUNCH();
+    return 0;
+  }
   if (which != 2) return m2::launch<false>(a, which, nullptr, st);
   LGN_CHECK_ARG(Gbuf, "moments: the encoder's radial backward needs the pair-gradient scratch buffer");
   if (int rc = m2::launch<false>(a, 2, Gbuf, st)) return rc;

@@ -240,6 +240,22 @@ def _build(meta, dev):
 def test_generic_level_fwd_bwd(dev, O, decoder, maxdim, full, C, CO, N, B):
     """Table-driven level (moments + sparse CG + CatMix) for arbitrary irreps vs the oracle's cg_product /
     CatMixReps, forward and all gradients.  `full`: the node carries all five maxdim=3 irreps."""
+    _generic_level_case(dev, O, decoder, maxdim, full, C, CO, N, B)
+
+
+@pytest.mark.parametrize("flag", ["LGN_AMD_DEC_PAIRWISE", "LGN_AMD_MOMENTS_V1"])
+@pytest.mark.parametrize("decoder", [False, True])
+@pytest.mark.parametrize("maxdim,full,C,CO,N,B", [(3, True, 4, 6, 30, 2), (3, False, 4, 4, 30, 2)])
+def test_generic_level_alternative_moments_kernels(dev, O, monkeypatch, flag, decoder, maxdim, full, C, CO, N, B):
+    """The same level with LGN_AMD_DEC_PAIRWISE=1 (decoder moments as O(N^2) pair sweeps instead of the separable jet-level
+    sums) and with LGN_AMD_MOMENTS_V1=1 (the all-channels-in-flight kernels that serve N > 32)."""
+    if flag == "LGN_AMD_DEC_PAIRWISE" and not decoder:
+        pytest.skip("decoder-only switch")
+    monkeypatch.setenv(flag, "1")
+    _generic_level_case(dev, O, decoder, maxdim, full, C, CO, N, B)
+
+
+def _generic_level_case(dev, O, decoder, maxdim, full, C, CO, N, B):
     from lgn import ops, _native as Nn
     from lgn.cg_lib import CGDict
     from lgn.plan import build_level_plans, build_local_tables, param_key_order
