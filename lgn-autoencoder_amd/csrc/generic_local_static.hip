@@ -22,6 +22,12 @@
 
 namespace lgn {
 namespace {
+LGN_STAMP_DECL
+#ifdef LGN_STAMPS
+#define SSTAMP(i) do { if ((threadIdx.x & 63) == 0 && blockIdx.x == 0 && blockIdx.y == 0) g_stamps[i] = clock64(); } while (0)
+#else
+#define SSTAMP(i) do { } while (0)
+#endif
 
 constexpr int COMAX = 8;
 
@@ -130,14 +136,19 @@ __global__ __launch_bounds__(BLOCK) void pack_weights_kernel(PackArgs p, const d
 }
 
 // =====================================================================================================================
-// backward.  Wave = (tile of 64 nodes, input channel c): the gradient of the node features of channel c depends on that
-// channel alone (the power products are channel-wise), so the lane owns d X[c][.] in registers while it walks ALL rows:
-//   g_cat[row] = sum_o g_out[o][q] conj(W[o][blk, c])          (recomputed per row from the packed weights: scalar loads)
-//   d X, d U   : g_cat pushed through the row's terms -- compile-time indices, register accumulators for d X; a moment feeds
-//                ~1 row, its gradient goes straight to dUT (store for the first contribution in walk order, else RMW)
-//   d W[o][blk, c] = sum_nodes sum_m g_out[o][q0 + m] conj(cat[row])   : the only cross-lane sum.  Per block the 2 COT lane
-//                values are transposed through a 6 KB LDS image and each (o, plane) is summed by four lanes (fixed order:
-//                deterministic); one partial row per tile in the packed weight layout, reduced over tiles afterwards.
+// backward.  Workgroup = (tile of 64 nodes, input channel c): the gradient of the node features of channel c depends on that
+// channel alone (the power products are channel-wise).  lane = node; the walk is unrolled completely, block by block:
+//   g_cat[row] = sum_o g_out[o][q] conj(W[o][blk, c])          (recomputed per row from the packed weights: scalar loads; the
+//                upstream gradient rows of the irrep stay in registers over its blocks)
+//   d X        : a block reads two contiguous feature ranges (the two factors of its Clebsch-Gordan product); their values and
+//                the gradients the block's terms produce live in registers, the gradients are added to the wave's d X image
+//                in LDS once per block (plain 16-byte read-modify-write of lane-private columns -- LDS float atomics per term
+//                were the bottleneck of an earlier version: ~40 cycles per wave-wide ds_add_f64)
+//   d U        : a moment feeds a few rows of a block; register accumulators per block, started from the value an earlier
+//                irrep's block left in d U where there is one.  The moments (and those old values) of block b + 1 are loaded
+//                while block b computes: the kernel runs one wave per SIMD (~500 registers), nothing else hides HBM latency
+//   d W[o][blk, c] = sum_nodes sum_m g_out[o][q0 + m] conj(cat[row])   : the only cross-lane sum, a register butterfly
+//                (wave_sum_store); one partial row per tile in the packed weight layout, reduced over tiles afterwards.
 // =====================================================================================================================
 struct StaticBwdArgs {
   int M, C, CO;
@@ -152,7 +163,6 @@ struct StaticBwdArgs {
   int n_packed;
 };
 
-constexpr int RED_PITCH = 65;
 
 template <int CTRL>
 __device__ __forceinline__ double dpp_add(double v) {
@@ -160,170 +170,309 @@ __device__ __forceinline__ double dpp_add(double v) {
   const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, true);
   return v + __hiloint2double(hi, lo);
 }
-// d X accumulator: lane-private LDS column gxl[q * 128 + {0, 1}] (pointer already offset by the lane); LDS float atomics
-// without return: fire and forget, executed in program order (one lane per address: deterministic)
-__device__ __forceinline__ void gx_add(double* gxl, int q, cx<double> v) {
-#ifdef SB_NO_GX
-  if (v.r == 12345.678) gxl[q * 128] = v.i;
-  return;
-#endif
-  __hip_atomic_fetch_add(gxl + q * 128, v.r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-  __hip_atomic_fetch_add(gxl + q * 128 + 1, v.i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-}
-
-// sum the NV = 2 * COT values every lane holds over the 64 lanes; lanes 0, 4, 8, ... return the sum of value (lane >> 2)
-template <int NV>
-__device__ __forceinline__ double wave_transpose_sum(const double (&v)[NV], double* red, int lane) {
-#pragma unroll
-  for (int k = 0; k < NV; ++k) red[k * RED_PITCH + lane] = v[k];
-  __builtin_amdgcn_wave_barrier();
-  const int k = lane >> 2, s = lane & 3;
-  double acc = 0.0;
-  if (k < NV) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc += red[k * RED_PITCH + i * 4 + s];
+// Sum of the NV = 2 * COT values every lane holds over the 64 lanes, as a transposing butterfly in registers: every
+// stage halves the number of live values while it halves the lanes a partial sum is spread over. The two cross-row
+// stages use gfx950's v_permlane32_swap / v_permlane16_swap (3 instructions per pair of values), the in-row stages
+// DPP (row_mirror, row_half_mirror, then the two quad_perm steps on the one value left). About 50 VALU instructions
+// for NV = 12, no LDS, no waiting on another unit. The sum of value k is stored from one lane (wave_sum_store).
+typedef unsigned uint2_t __attribute__((ext_vector_type(2)));
+template <bool ROW32>
+__device__ __forceinline__ double swap_add(double a, double b) {
+  uint2_t lo, hi;
+  if (ROW32) {
+    lo = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
+    hi = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
+  } else {
+    lo = __builtin_amdgcn_permlane16_swap(__double2loint(a), __double2loint(b), false, false);
+    hi = __builtin_amdgcn_permlane16_swap(__double2hiint(a), __double2hiint(b), false, false);
   }
-  acc = dpp_add<0xB1>(acc);
-  acc = dpp_add<0x4E>(acc);
-  __builtin_amdgcn_wave_barrier();
-  return acc;
+  return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+// lanes with `first` keep a and fetch the partner's a; the others keep b and fetch the partner's b
+template <int CTRL>
+__device__ __forceinline__ double dpp_pair_add(double a, double b, bool first) {
+  const double keep = first ? a : b, send = first ? b : a;
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(send), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(send), CTRL, 0xF, 0xF, true);
+  return keep + __hiloint2double(hi, lo);
+}
+template <int NV>
+__device__ __forceinline__ void wave_sum_store(const double (&v)[NV], double* __restrict__ dst, int lane) {
+  static_assert(NV == 8 || NV == 12 || NV == 16, "two cross-row stages need NV % 4 == 0");
+  constexpr int N1 = NV / 2, N2 = NV / 4, N3 = (N2 + 1) / 2;
+  double r[N1], t[N2], u[N3];
+#pragma unroll
+  for (int p = 0; p < N1; ++p) r[p] = swap_add<true>(v[2 * p], v[2 * p + 1]);       // 32-lane half h holds value 2p + h
+#pragma unroll
+  for (int q = 0; q < N2; ++q) t[q] = swap_add<false>(r[2 * q], r[2 * q + 1]);      // row rho holds value 4q + 2(rho & 1) + (rho >> 1)
+  const int i = lane & 15, rho = lane >> 4;
+#pragma unroll
+  for (int j = 0; j < N2 / 2; ++j) u[j] = dpp_pair_add<0x140>(t[2 * j], t[2 * j + 1], i < 8);      // row_mirror
+  if (N2 & 1) u[N3 - 1] = dpp_add<0x140>(t[N2 - 1]);
+  double w;
+  if (N3 == 2) w = dpp_pair_add<0x141>(u[0], u[1], (i & 4) == 0);      // row_half_mirror
+  else w = dpp_add<0x141>(u[0]);
+  w = dpp_add<0xB1>(w);
+  w = dpp_add<0x4E>(w);
+  const int jsel = N3 == 2 ? (i >> 2) & 1 : 0;
+  const bool single = (N2 & 1) && jsel == N3 - 1;         // the unpaired value: both half rows hold it
+  const int q = single ? N2 - 1 : 2 * jsel + (i >> 3);
+  const bool owner = (i & 3) == 0 && (N3 == 2 || (i & 4) == 0) && (!single || i < 8);
+  if (owner) dst[4 * q + 2 * (rho & 1) + (rho >> 1)] = w;
 }
 
-template <class T, int L, int M0, int ROWS, int COT>
-__device__ __forceinline__ void item_bwd(const StaticBwdArgs& a, int tile, int lane, int c, const cx<double> (&x)[T::Q],
-                                         double* gxl, double* red) {
-  constexpr int D = T::DIM[L], NB = T::NBLK[L], ROW0 = T::ROW0[L], Q = T::Q, QO = T::QOUT, QBASE = T::Q0[L] + M0;
-  const int C = a.C, CO = a.CO;
-  typedef const double __attribute__((address_space(4))) * cptr;
-  cptr wc = (cptr)(a.wp + a.wp0[L]) + (size_t)c * NB * COT * 2;
-  const double* __restrict__ uc = a.UT + ((size_t)tile * C + c) * Q * 640 + lane;
-  double* __restrict__ guc = a.gUT + ((size_t)tile * C + c) * Q * 640 + lane;
-  const double* __restrict__ got = a.goT + (size_t)tile * CO * QO * 128 + lane;
-  double* __restrict__ part = a.part + (size_t)tile * a.n_packed + a.wp0[L] + (size_t)c * NB * COT * 2;
-  cx<double> go[COT][ROWS];
+// feature index range [lo, hi) a block's terms touch through T_A (which = 0) / T_B (which = 1; product terms only)
+template <class T>
+constexpr int blk_lo(int row0, int rows, int which) {
+  int lo = 1 << 30;
+  for (int t = T::ROW_PTR[row0]; t < T::ROW_PTR[row0 + rows]; ++t) {
+    if (T::T_TYPE[t] == 0 || (which == 1 && T::T_TYPE[t] != 2)) continue;
+    const int v = which ? T::T_B[t] : T::T_A[t];
+    if (v < lo) lo = v;
+  }
+  return lo == (1 << 30) ? 0 : lo;
+}
+template <class T>
+constexpr int blk_hi(int row0, int rows, int which) {
+  int hi = 0;
+  for (int t = T::ROW_PTR[row0]; t < T::ROW_PTR[row0 + rows]; ++t) {
+    if (T::T_TYPE[t] == 0 || (which == 1 && T::T_TYPE[t] != 2)) continue;
+    const int v = (which ? T::T_B[t] : T::T_A[t]) + 1;
+    if (v > hi) hi = v;
+  }
+  return hi;
+}
+
+// one row of the backward walk: gradient of the cat row, its scatter into the block's d X accumulators (registers) / d U
+// (global), the row's value and its contribution to the block's weight gradient.  xa / ga cover the features [A0, A0 + NA)
+// the block's terms read through T_A, xb / gb those read through T_B.
+template <class T, int ROW, int COT, int A0, int NA, int B0, int NB, int NU>
+__device__ __forceinline__ void row_bwd(const cx<double> (&gom)[COT], const cx<double> (&w)[COT], const cx<double> (&uv)[NU],
+                                        cx<double> (&gu)[NU], const cx<double> (&xa)[NA], cx<double> (&ga)[NA],
+                                        const cx<double> (&xb)[NB], cx<double> (&gb)[NB], double (&dw)[2 * COT]) {
+  cx<double> gc = {0, 0};
 #pragma unroll
-  for (int o = 0; o < COT; ++o) {
-    const int oo = o < CO ? o : CO - 1;
+  for (int o = 0; o < COT; ++o) cfmac(gc, gom[o], w[o]);
+  cx<double> cat = {0, 0};
 #pragma unroll
-    for (int mm = 0; mm < ROWS; ++mm) {
-      go[o][mm] = {got[(size_t)(oo * QO + QBASE + mm) * 128], got[(size_t)(oo * QO + QBASE + mm) * 128 + 64]};
-      if (o >= CO) go[o][mm] = {0, 0};
+  for (int t = T::ROW_PTR[ROW]; t < T::ROW_PTR[ROW + 1]; ++t) {
+    const int ty = T::T_TYPE[t], ia = T::T_A[t], ib = T::T_B[t];
+    const double cf = T::T_COEF[t];
+    const cx<double> g = {cf * gc.r, cf * gc.i};
+    if (ty == 0) {
+      const int k = T::T_USLOT[t];
+      cat.r = __builtin_fma(cf, uv[k].r, cat.r);
+      cat.i = __builtin_fma(cf, uv[k].i, cat.i);
+      gu[k].r += g.r;
+      gu[k].i += g.i;
+    } else if (ty == 1) {
+      cat.r = __builtin_fma(cf, xa[ia - A0].r, cat.r);
+      cat.i = __builtin_fma(cf, xa[ia - A0].i, cat.i);
+      ga[ia - A0].r += g.r;
+      ga[ia - A0].i += g.i;
+    } else {
+      const cx<double> p = cmul(xa[ia - A0], xb[ib - B0]);
+      cat.r = __builtin_fma(cf, p.r, cat.r);
+      cat.i = __builtin_fma(cf, p.i, cat.i);
+      cfmac(ga[ia - A0], g, xb[ib - B0]);
+      cfmac(gb[ib - B0], g, xa[ia - A0]);
     }
   }
 #pragma unroll
-  for (int blk = 0; blk < NB; ++blk) {
+  for (int o = 0; o < COT; ++o) {
+    cx<double> d = {dw[2 * o], dw[2 * o + 1]};
+    cfmac(d, gom[o], cat);
+    dw[2 * o] = d.r;
+    dw[2 * o + 1] = d.i;
+  }
+}
+
+// rows ROWB + MM .. of a block (compile-time recursion: every row index is a template constant)
+template <class T, int ROWB, int MM, int D, int COT, int A0, int NA, int B0, int NB, int NU>
+__device__ __forceinline__ void rows_bwd(const cx<double> (&go)[COT][D], const cx<double> (&w)[COT], const cx<double> (&uv)[NU],
+                                         cx<double> (&gu)[NU], const cx<double> (&xa)[NA], cx<double> (&ga)[NA],
+                                         const cx<double> (&xb)[NB], cx<double> (&gb)[NB], double (&dw)[2 * COT]) {
+  if constexpr (MM < D) {
+    cx<double> gom[COT];
+#pragma unroll
+    for (int o = 0; o < COT; ++o) gom[o] = go[o][MM];
+    row_bwd<T, ROWB + MM, COT, A0, NA, B0, NB, NU>(gom, w, uv, gu, xa, ga, xb, gb, dw);
+    if constexpr (MM % 3 == 2) __builtin_amdgcn_sched_barrier(0);      // three rows at a time
+    rows_bwd<T, ROWB, MM + 1, D, COT, A0, NA, B0, NB, NU>(go, w, uv, gu, xa, ga, xb, gb, dw);
+  }
+}
+
+// d X accumulator of the wave in LDS, lane-private columns gxl[q * 128 + {0, 1}] (pointer already offset by the lane): plain
+// read-modify-write per block, one 16-byte read and write per feature the block touches
+template <int N>
+__device__ __forceinline__ void gx_flush(double* gxl, int q0, const cx<double> (&g)[N]) {
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    gxl[(q0 + k) * 128] += g[k].r;
+    gxl[(q0 + k) * 128 + 1] += g[k].i;
+  }
+}
+
+// moments a block reads: BLK_UELEM[BLK_UPTR[bid] ..], bid = BLK0[l] + blk (array sizes: at least 1)
+template <class T> constexpr int blk_u0(int l, int blk) { return blk < T::NBLK[l] ? T::BLK_UPTR[T::BLK0[l] + blk] : 0; }
+template <class T> constexpr int blk_nu(int l, int blk) {
+  return blk < T::NBLK[l] ? T::BLK_UPTR[T::BLK0[l] + blk + 1] - T::BLK_UPTR[T::BLK0[l] + blk] : 0;
+}
+template <class T> constexpr int blk_nu1(int l, int blk) { return blk_nu<T>(l, blk) > 0 ? blk_nu<T>(l, blk) : 1; }
+// issue the loads of a block's moments and, where an earlier block (of another irrep) has written the gradient, of its value
+template <class T, int L, int BLK, int N>
+__device__ __forceinline__ void load_moments(const double* __restrict__ uc, const double* guc, cx<double> (&uv)[N], cx<double> (&gold)[N]) {
+  constexpr int P0 = blk_u0<T>(L, BLK), NU = blk_nu<T>(L, BLK);
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    uv[k] = {0, 0};
+    gold[k] = {0, 0};
+    if (k < NU) {
+      const int e = T::BLK_UELEM[P0 + k];
+      uv[k] = {uc[e * 128], uc[e * 128 + 64]};
+      if (!T::BLK_UFIRST[P0 + k]) gold[k] = {guc[e * 128], guc[e * 128 + 64]};
+    }
+  }
+}
+
+template <class T, int L, int BLK, int BEND, int COT>
+__device__ __forceinline__ void blocks_bwd(const cx<double> (&go)[COT][T::DIM[L]], cx<double> (&wn)[COT],
+                                           const double __attribute__((address_space(4))) * wc, const double* __restrict__ uc,
+                                           double* guc, const cx<double> (&uv)[blk_nu1<T>(L, BLK)],
+                                           const cx<double> (&gold)[blk_nu1<T>(L, BLK)], const double* xl, double* gxl,
+                                           double* __restrict__ part, int lane) {
+  constexpr int D = T::DIM[L], ROWB = T::ROW0[L] + BLK * D;
+  if constexpr (BLK < BEND) {
+    constexpr int A0 = blk_lo<T>(ROWB, D, 0), A1 = blk_hi<T>(ROWB, D, 0), B0 = blk_lo<T>(ROWB, D, 1), B1 = blk_hi<T>(ROWB, D, 1);
+    constexpr int NA = A1 > A0 ? A1 - A0 : 1, NB = B1 > B0 ? B1 - B0 : 1, NU = blk_nu<T>(L, BLK), NU1 = blk_nu1<T>(L, BLK);
     cx<double> w[COT];
 #pragma unroll
-    for (int o = 0; o < COT; ++o) w[o] = {wc[(blk * COT + o) * 2], wc[(blk * COT + o) * 2 + 1]};
+    for (int o = 0; o < COT; ++o) w[o] = wn[o];
+    // software pipeline: the next block's weights and moments are in flight during this block
+    cx<double> uvn[blk_nu1<T>(L, BLK + 1)], goldn[blk_nu1<T>(L, BLK + 1)];
+    if constexpr (BLK + 1 < BEND) {
+#pragma unroll
+      for (int o = 0; o < COT; ++o) wn[o] = {wc[((BLK + 1) * COT + o) * 2], wc[((BLK + 1) * COT + o) * 2 + 1]};
+      load_moments<T, L, BLK + 1>(uc, guc, uvn, goldn);
+      if constexpr (blk_nu<T>(L, BLK + 1) > 0) __builtin_amdgcn_sched_barrier(0);      // (issued here, not wherever the scheduler likes)
+    }
+    // the features the block reads, and register accumulators for the gradients of what it reads
+    cx<double> xa[NA], xb[NB], ga[NA], gb[NB], gu[NU1];
+#pragma unroll
+    for (int k = 0; k < NA; ++k) {
+      if (A1 > A0) xa[k] = {xl[(A0 + k) * 128], xl[(A0 + k) * 128 + 1]};
+      ga[k] = {0, 0};
+    }
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+      if (B1 > B0) xb[k] = {xl[(B0 + k) * 128], xl[(B0 + k) * 128 + 1]};
+      gb[k] = {0, 0};
+    }
+#pragma unroll
+    for (int k = 0; k < NU1; ++k) gu[k] = gold[k];
     double dw[2 * COT];
 #pragma unroll
     for (int k = 0; k < 2 * COT; ++k) dw[k] = 0.0;
+    rows_bwd<T, ROWB, 0, D, COT, A0, NA, B0, NB, NU1>(go, w, uv, gu, xa, ga, xb, gb, dw);
+    if constexpr (A1 > A0) gx_flush<NA>(gxl, A0, ga);
+    if constexpr (B1 > B0) gx_flush<NB>(gxl, B0, gb);
 #pragma unroll
-    for (int mm = 0; mm < ROWS; ++mm) {
-      const int row = ROW0 + blk * D + M0 + mm;
-      cx<double> gc = {0, 0};
-#pragma unroll
-      for (int o = 0; o < COT; ++o) cfmac(gc, go[o][mm], w[o]);
-      cx<double> cat = {0, 0};
-#pragma unroll
-      for (int t = T::ROW_PTR[row]; t < T::ROW_PTR[row + 1]; ++t) {
-        const int ty = T::T_TYPE[t], ia = T::T_A[t], ib = T::T_B[t];
-        const double cf = T::T_COEF[t];
-        const cx<double> g = {cf * gc.r, cf * gc.i};
-        if (ty == 0) {
-          cat.r = __builtin_fma(cf, uc[ia * 128], cat.r);
-          cat.i = __builtin_fma(cf, uc[ia * 128 + 64], cat.i);
-          if (T::T_UFIRST[t]) {
-            guc[ia * 128] = g.r;
-            guc[ia * 128 + 64] = g.i;
-          } else {
-            guc[ia * 128] += g.r;
-            guc[ia * 128 + 64] += g.i;
-          }
-        } else if (ty == 1) {
-          cat.r = __builtin_fma(cf, x[ia].r, cat.r);
-          cat.i = __builtin_fma(cf, x[ia].i, cat.i);
-          gx_add(gxl, ia, g);
-        } else {
-          const cx<double> p = cmul(x[ia], x[ib]);
-          cat.r = __builtin_fma(cf, p.r, cat.r);
-          cat.i = __builtin_fma(cf, p.i, cat.i);
-          gx_add(gxl, ia, cmulc(g, x[ib]));
-          gx_add(gxl, ib, cmulc(g, x[ia]));
-        }
-      }
-#pragma unroll
-      for (int o = 0; o < COT; ++o) {
-        cx<double> d = {dw[2 * o], dw[2 * o + 1]};
-        cfmac(d, go[o][mm], cat);
-        dw[2 * o] = d.r;
-        dw[2 * o + 1] = d.i;
-      }
-      __builtin_amdgcn_sched_barrier(0);               // one row at a time: keeps the live set (and the spills) bounded
+    for (int k = 0; k < NU; ++k) {
+      const int e = T::BLK_UELEM[blk_u0<T>(L, BLK) + k];
+      guc[e * 128] = gu[k].r;
+      guc[e * 128 + 64] = gu[k].i;
     }
-#ifdef SB_NO_DW
-    const double sum = dw[0] + dw[1];
-#else
-    const double sum = wave_transpose_sum<2 * COT>(dw, red, lane);
-#endif
-    if ((lane & 3) == 0 && (lane >> 2) < 2 * COT) {
-      double* dst = part + blk * COT * 2 + (lane >> 2);
-      if (M0 == 0) *dst = sum;
-      else *dst += sum;                                // later row chunks of the same irrep add to the first chunk's partial
+    wave_sum_store<2 * COT>(dw, part + BLK * COT * 2, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    blocks_bwd<T, L, BLK + 1, BEND, COT>(go, wn, wc, uc, guc, uvn, goldn, xl, gxl, part, lane);
+  }
+}
+
+// blocks BBEG .. BEND - 1 of one output irrep, all rows (walk order of T_UFIRST: irrep, block, row, term).  The upstream
+// gradient rows are loaded once and stay in registers over the blocks.
+template <class T, int L, int BBEG, int BEND, int COT>
+__device__ __forceinline__ void irrep_bwd(const StaticBwdArgs& a, int tile, int lane, int c, const double* xl, double* gxl) {
+  if constexpr (BBEG < BEND) {
+    constexpr int D = T::DIM[L], NB = T::NBLK[L], Q = T::Q, QO = T::QOUT, QBASE = T::Q0[L];
+    static_assert(BEND <= NB, "block range");
+    const int C = a.C, CO = a.CO;
+    typedef const double __attribute__((address_space(4))) * cptr;
+    cptr wc = (cptr)(a.wp + a.wp0[L]) + (size_t)c * NB * COT * 2;
+    const double* __restrict__ uc = a.UT + ((size_t)tile * C + c) * Q * 640 + lane;
+    double* guc = a.gUT + ((size_t)tile * C + c) * Q * 640 + lane;
+    const double* __restrict__ got = a.goT + (size_t)tile * CO * QO * 128 + lane;
+    double* __restrict__ part = a.part + (size_t)tile * a.n_packed + a.wp0[L] + (size_t)c * NB * COT * 2;
+    cx<double> go[COT][D];
+#pragma unroll
+    for (int o = 0; o < COT; ++o) {
+      const int oo = o < CO ? o : CO - 1;
+#pragma unroll
+      for (int mm = 0; mm < D; ++mm) {
+        go[o][mm] = {got[(size_t)(oo * QO + QBASE + mm) * 128], got[(size_t)(oo * QO + QBASE + mm) * 128 + 64]};
+        if (o >= CO) go[o][mm] = {0, 0};
+      }
     }
+    cx<double> wn[COT];
+#pragma unroll
+    for (int o = 0; o < COT; ++o) wn[o] = {wc[(BBEG * COT + o) * 2], wc[(BBEG * COT + o) * 2 + 1]};
+    cx<double> uv[blk_nu1<T>(L, BBEG)], gold[blk_nu1<T>(L, BBEG)];
+    load_moments<T, L, BBEG>(uc, guc, uv, gold);
+    blocks_bwd<T, L, BBEG, BEND, COT>(go, wn, wc, uc, guc, uv, gold, xl, gxl, part, lane);
     __builtin_amdgcn_sched_barrier(0);
   }
 }
 
+// Workgroup = (tile of 64 nodes, input channel c), two waves that share the channel's features in LDS and split the blocks
+// (the kernel holds one wave per SIMD -- 512 registers -- and the grid is ~1.4 such rounds: half-size jobs fill the tail):
+//   wave 0: every moment / feature block (it alone touches U and d U), the product blocks of irreps 0, 1, 4
+//   wave 1: the product blocks of irreps 2 and 3
+// Each wave accumulates d X in its own LDS image; the two are added at the end (fixed order: deterministic).
 template <class T, int COT>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void local_bwd_static_kernel(StaticBwdArgs a) {
-  static_assert(T::N_OUT == 5 && T::DIM[0] == 4 && T::DIM[1] == 3 && T::DIM[2] == 3 && T::DIM[3] == 9 && T::DIM[4] == 1 && T::CHUNK == 3,
-                "item list / walk order of T_UFIRST");
-  __shared__ double red[2 * COT * RED_PITCH];
-  __shared__ double gxs[T::Q * 128];
+__global__ __launch_bounds__(128) void local_bwd_static_kernel(StaticBwdArgs a) {
+  static_assert(T::N_OUT == 5, "wave assignment");
   constexpr int Q = T::Q;
-  const int tile = blockIdx.x, c = blockIdx.y, lane = threadIdx.x, C = a.C;
-  const double* __restrict__ xc = a.XT + ((size_t)tile * C + c) * Q * 128 + lane;
-  double* gxl = gxs + 2 * lane;
-  cx<double> x[Q];
-#pragma unroll
-  for (int q = 0; q < Q; ++q) {
-    x[q] = {xc[q * 128], xc[q * 128 + 64]};
-    gxl[q * 128] = 0.0;
-    gxl[q * 128 + 1] = 0.0;
-  }
-  {  // moments that feed no row get a zero gradient
-    double* __restrict__ guc = a.gUT + ((size_t)tile * C + c) * Q * 640 + lane;
-#pragma unroll
-    for (int k = 0; k < T::N_UNUSED; ++k) {
-      guc[T::U_UNUSED[k] * 128] = 0.0;
-      guc[T::U_UNUSED[k] * 128 + 64] = 0.0;
+  __shared__ double xs[Q * 128];                       // this channel's features, lane-private columns [q][lane][2]
+  __shared__ double gxs[2][Q * 128];                   // d X per wave, same layout
+  const int tile = blockIdx.x, c = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, C = a.C;
+  {
+    const double* __restrict__ xc = a.XT + ((size_t)tile * C + c) * Q * 128;
+    for (int e = threadIdx.x; e < Q * 128; e += 128) {
+      xs[(e & ~127) + 2 * (e & 63) + ((e >> 6) & 1)] = xc[e];
+      gxs[0][e] = 0.0;
+      gxs[1][e] = 0.0;
     }
+    // moments that feed no row get a zero gradient
+    double* __restrict__ guc = a.gUT + ((size_t)tile * C + c) * Q * 640;
+    for (int e = threadIdx.x; e < T::N_UNUSED * 128; e += 128) guc[T::U_UNUSED[e >> 7] * 128 + (e & 127)] = 0.0;
   }
-  // walk order = the order tools/gen_static_tables.py assumed for T_UFIRST: irrep, chunk of 3 rows, block, row, term
-#ifndef SB_ONLY3
-  item_bwd<T, 0, 0, 3, COT>(a, tile, lane, c, x, gxl, red);
-  __builtin_amdgcn_sched_barrier(0);
-  item_bwd<T, 0, 3, 1, COT>(a, tile, lane, c, x, gxl, red);
-  __builtin_amdgcn_sched_barrier(0);
-  item_bwd<T, 1, 0, 3, COT>(a, tile, lane, c, x, gxl, red);
-  __builtin_amdgcn_sched_barrier(0);
-  item_bwd<T, 2, 0, 3, COT>(a, tile, lane, c, x, gxl, red);
-  __builtin_amdgcn_sched_barrier(0);
-#endif
-  item_bwd<T, 3, 0, 3, COT>(a, tile, lane, c, x, gxl, red);
-  __builtin_amdgcn_sched_barrier(0);
-  item_bwd<T, 3, 3, 3, COT>(a, tile, lane, c, x, gxl, red);
-  __builtin_amdgcn_sched_barrier(0);
-  item_bwd<T, 3, 6, 3, COT>(a, tile, lane, c, x, gxl, red);
-  __builtin_amdgcn_sched_barrier(0);
-  item_bwd<T, 4, 0, 1, COT>(a, tile, lane, c, x, gxl, red);
-  __builtin_amdgcn_sched_barrier(0);
-  double* __restrict__ gxc = a.gXT + ((size_t)tile * C + c) * Q * 128 + lane;
-#pragma unroll
-  for (int q = 0; q < Q; ++q) {
-    gxc[q * 128] = gxl[q * 128];
-    gxc[q * 128 + 64] = gxl[q * 128 + 1];
+  __syncthreads();
+  const double* xl = xs + 2 * lane;
+  double* gxl = gxs[wave] + 2 * lane;
+  if (wave == 0) {
+    SSTAMP(0);
+    irrep_bwd<T, 0, 0, T::NBLK[0], COT>(a, tile, lane, c, xl, gxl);
+    SSTAMP(1);
+    irrep_bwd<T, 1, 0, T::NBLK[1], COT>(a, tile, lane, c, xl, gxl);
+    SSTAMP(2);
+    irrep_bwd<T, 2, 0, T::NUBLK[2], COT>(a, tile, lane, c, xl, gxl);
+    SSTAMP(3);
+    irrep_bwd<T, 3, 0, T::NUBLK[3], COT>(a, tile, lane, c, xl, gxl);
+    SSTAMP(4);
+    irrep_bwd<T, 4, 0, T::NBLK[4], COT>(a, tile, lane, c, xl, gxl);
+    SSTAMP(5);
+  } else {
+    SSTAMP(10);
+    irrep_bwd<T, 2, T::NUBLK[2], T::NBLK[2], COT>(a, tile, lane, c, xl, gxl);
+    SSTAMP(11);
+    irrep_bwd<T, 3, T::NUBLK[3], T::NBLK[3], COT>(a, tile, lane, c, xl, gxl);
+    SSTAMP(12);
+  }
+  __syncthreads();
+  SSTAMP(6);
+  double* __restrict__ gxc = a.gXT + ((size_t)tile * C + c) * Q * 128;
+  for (int e = threadIdx.x; e < Q * 128; e += 128) {
+    const int k = (e & ~127) + 2 * (e & 63) + ((e >> 6) & 1);
+    gxc[e] = gxs[0][k] + gxs[1][k];
   }
 }
 
@@ -376,6 +525,7 @@ static void fill_pack(PackArgs& p, int C, int CO, const int* w0) {
 }
 
 }  // namespace
+LGN_STAMP_READER(lgn_debug_stamps_local_static)
 
 // doubles of the packed weight image of a level
 size_t local_static_packed_doubles(int kind, int C, int CO) {
@@ -400,8 +550,12 @@ int local_fwd_static(int kind, int M, int C, int CO, const double* XT, const dou
   for (int l = 0; l < 5; ++l) a.wp0[l] = p.wp0[l];
   dim3 grid(cdiv(M, 64), N_ITEMS);
 #define LGN_LAUNCH(KIND, COT) hipLaunchKernelGGL((local_fwd_static_kernel<cgs::KIND, COT>), grid, dim3(64), 0, st, a)
+#ifdef SB_ONLY_K2C6      // (compile-time experiments: one instantiation)
+  LGN_LAUNCH(Kind2, 6);
+#else
   if (kind == 1) { if (CO <= 4) LGN_LAUNCH(Kind1, 4); else if (CO <= 6) LGN_LAUNCH(Kind1, 6); else LGN_LAUNCH(Kind1, 8); }
   else { if (CO <= 4) LGN_LAUNCH(Kind2, 4); else if (CO <= 6) LGN_LAUNCH(Kind2, 6); else LGN_LAUNCH(Kind2, 8); }
+#endif
 #undef LGN_LAUNCH
   LGN_CHECK_LAUNCH();
   return 0;
@@ -422,9 +576,13 @@ int local_bwd_static(int kind, int M, int C, int CO, const double* XT, const dou
   StaticBwdArgs a{M, C, CO, XT, UT, wp, {0, 0, 0, 0, 0, 0, 0, 0}, goT, gUT, gXT, part, (int)local_static_packed_doubles(kind, C, CO)};
   for (int l = 0; l < 5; ++l) a.wp0[l] = p.wp0[l];
   dim3 grid(cdiv(M, 64), C);
-#define LGN_LAUNCH(KIND, COT) hipLaunchKernelGGL((local_bwd_static_kernel<cgs::KIND, COT>), grid, dim3(64), 0, st, a)
+#define LGN_LAUNCH(KIND, COT) hipLaunchKernelGGL((local_bwd_static_kernel<cgs::KIND, COT>), grid, dim3(128), 0, st, a)
+#ifdef SB_ONLY_K2C6      // (compile-time experiments: one instantiation)
+  LGN_LAUNCH(Kind2, 6);
+#else
   if (kind == 1) { if (CO <= 4) LGN_LAUNCH(Kind1, 4); else if (CO <= 6) LGN_LAUNCH(Kind1, 6); else LGN_LAUNCH(Kind1, 8); }
   else { if (CO <= 4) LGN_LAUNCH(Kind2, 4); else if (CO <= 6) LGN_LAUNCH(Kind2, 6); else LGN_LAUNCH(Kind2, 8); }
+#endif
 #undef LGN_LAUNCH
   LGN_CHECK_LAUNCH();
   return 0;

@@ -43,7 +43,7 @@ def timed(fn, reps=10):
 
 
 def stamps(name):
-    if not STAMPS:
+    if not STAMPS or not hasattr(Nn.lib(), name):
         return
     buf = (ctypes.c_longlong * 64)()
     getattr(Nn.lib(), name)(buf)
@@ -95,6 +95,7 @@ if kind:
         Nn._check(Nn.lib().lgn_local_bwd_static_f64(kind, M, C, CO, Nn.ptr(XT), Nn.ptr(UT), Nn.ptr(wcat), w0, Nn.ptr(wp), Nn.ptr(goT),
                                                     Nn.ptr(gUT), Nn.ptr(gXT), Nn.ptr(part), Nn.ptr(gpk), Nn.ptr(gw), Nn.stream_ptr()), "static bwd")
     print("local_bwd_static us", timed(bcall))
+    stamps("lgn_debug_stamps_local_static")
     rgU, rgX, rgw = Nn.local_bwd(tables, CO, X, U, wcat, gout)
     rel = lambda a, b: ((a - b).abs().max() / b.abs().max()).item()
     print("  static bwd vs v1: gU", rel(from_tb(gUT, Q * 5).reshape(2, M, C, Q, 5).permute(1, 2, 3, 4, 0).reshape(B, N, C, Q, 5, 2), rgU),
