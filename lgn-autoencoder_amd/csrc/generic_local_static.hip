@@ -424,12 +424,12 @@ __device__ __forceinline__ void irrep_bwd(const StaticBwdArgs& a, int tile, int 
 
 // Workgroup = (tile of 64 nodes, input channel c), two waves that share the channel's features in LDS and split the blocks
 // (the kernel holds one wave per SIMD -- 512 registers -- and the grid is ~1.4 such rounds: half-size jobs fill the tail):
-//   wave 0: every moment / feature block (it alone touches U and d U), the product blocks of irreps 0, 1, 4
-//   wave 1: the product blocks of irreps 2 and 3
+//   wave 0: every moment / feature block (it alone touches U and d U), the product blocks of irreps 0 and 1 (but the last)
+//   wave 1: the product blocks of irreps 2, 3, 4 and the last one of irrep 1        (balanced on measured wave times)
 // Each wave accumulates d X in its own LDS image; the two are added at the end (fixed order: deterministic).
 template <class T, int COT>
 __global__ __launch_bounds__(128) void local_bwd_static_kernel(StaticBwdArgs a) {
-  static_assert(T::N_OUT == 5, "wave assignment");
+  static_assert(T::N_OUT == 5 && T::NUBLK[1] < T::NBLK[1], "wave assignment");
   constexpr int Q = T::Q;
   __shared__ double xs[Q * 128];                       // this channel's features, lane-private columns [q][lane][2]
   __shared__ double gxs[2][Q * 128];                   // d X per wave, same layout
@@ -452,13 +452,13 @@ __global__ __launch_bounds__(128) void local_bwd_static_kernel(StaticBwdArgs a) 
     SSTAMP(0);
     irrep_bwd<T, 0, 0, T::NBLK[0], COT>(a, tile, lane, c, xl, gxl);
     SSTAMP(1);
-    irrep_bwd<T, 1, 0, T::NBLK[1], COT>(a, tile, lane, c, xl, gxl);
+    irrep_bwd<T, 1, 0, T::NBLK[1] - 1, COT>(a, tile, lane, c, xl, gxl);
     SSTAMP(2);
     irrep_bwd<T, 2, 0, T::NUBLK[2], COT>(a, tile, lane, c, xl, gxl);
     SSTAMP(3);
     irrep_bwd<T, 3, 0, T::NUBLK[3], COT>(a, tile, lane, c, xl, gxl);
     SSTAMP(4);
-    irrep_bwd<T, 4, 0, T::NBLK[4], COT>(a, tile, lane, c, xl, gxl);
+    irrep_bwd<T, 4, 0, T::NUBLK[4], COT>(a, tile, lane, c, xl, gxl);
     SSTAMP(5);
   } else {
     SSTAMP(10);
@@ -466,6 +466,9 @@ __global__ __launch_bounds__(128) void local_bwd_static_kernel(StaticBwdArgs a) 
     SSTAMP(11);
     irrep_bwd<T, 3, T::NUBLK[3], T::NBLK[3], COT>(a, tile, lane, c, xl, gxl);
     SSTAMP(12);
+    irrep_bwd<T, 4, T::NUBLK[4], T::NBLK[4], COT>(a, tile, lane, c, xl, gxl);
+    irrep_bwd<T, 1, T::NBLK[1] - 1, T::NBLK[1], COT>(a, tile, lane, c, xl, gxl);
+    SSTAMP(13);
   }
   __syncthreads();
   SSTAMP(6);
