@@ -828,6 +828,8 @@ bool moments2_fits(const GenArgs& a, int decoder) {
 size_t moments2_gbuf_doubles(int B, int N, int C) { return (size_t)B * N * N * C * 4; }
 
 // which: 0 forward, 1 backward j-centric, 2 backward i-centric (Gbuf: encoder only, moments2_gbuf_doubles)
+int moments_dec_sep_tb_dispatch(const GenArgs& a, int which, hipStream_t st);      // generic_moments_sep.hip
+
 int moments2_dispatch(const GenArgs& a, int decoder, int which, double* Gbuf, hipStream_t st) {
   LGN_CHECK_ARG(a.B > 0 && a.N > 0 && a.Q > 0, "moments: empty input (B=%d N=%d Q=%d)", a.B, a.N, a.Q);
   LGN_CHECK_ARG(a.C >= 1 && a.C <= 8, "moments: C=%d unsupported (1..8)", a.C);
@@ -835,6 +837,7 @@ int moments2_dispatch(const GenArgs& a, int decoder, int which, double* Gbuf, hi
     const char* pw = getenv("LGN_AMD_DEC_PAIRWISE");         // =1: O(N^2) pair sweeps (cross-check of the separable form)
     if (pw && pw[0] == '1') return m2::launch<true>(a, which, nullptr, st);
     if (which == 2) return 0;                               // the separable backward does both passes in one launch
+    if (const int rc = moments_dec_sep_tb_dispatch(a, which, st); rc != -2) return rc;      // tile-blocked layouts: generic_moments_sep.hip
     const size_t base = sizeof(double) * ((size_t)a.N * 8 + (size_t)a.N * a.Q * 2);
     if (which == 0) {
       const size_t smem = base + sizeof(double) * (size_t)a.Q * 10;
