@@ -315,7 +315,7 @@ def main():
             traffic = None          # HBM bytes per launch of the dominant kernel, from the PMC passes recorded under profiles/
             if args.config == "cfg2" and per_gpu == 512:
                 try:
-                    with open(os.path.join(ROOT, "profiles", "r01_v8_traffic.json")) as fh:
+                    with open(os.path.join(ROOT, "profiles", "r02_traffic.json")) as fh:
                         traffic = json.load(fh).get(dom["kernel"], {}).get("hbm_bytes_per_launch")
                 except OSError:
                     pass
@@ -327,7 +327,7 @@ def main():
                 "frac": achieved / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic,
                 "traffic_note": "bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction; an ESTIMATE: the guide "
                                 "calibrates the x2 on 16 B/lane loads, this kernel issues 8 B/lane), separate rocprofv3 "
-                                "--pmc passes recorded in profiles/r01_v8_traffic.json; 0.5 TB/s, HBM is not the bound",
+                                "--pmc passes recorded in profiles/r02_traffic.json; 0.5 TB/s, HBM is not the bound",
                 "us_per_launch": dom["us"], "algorithmic_flops_per_launch": dom["flops"],
                 "forward_kernel": {"kernel": fw["kernel"], "us_per_launch": fw["us"], "algorithmic_flops_per_launch": fw["flops"],
                                    "achieved": fw["flops"] / (fw["us"] * 1e-6) / 1e12,
