@@ -67,6 +67,27 @@ def test_native_step_matches_reference_golden(name, use_graph):
                 assert torch.equal(g.cpu(), lam * torch.sign(sd[k])), f"{pre}.{k}: dead parameter must get exactly the L1 term"
 
 
+@pytest.mark.parametrize("flag", ["LGN_AMD_NO_STATIC", "LGN_AMD_DEC_PAIRWISE", "LGN_AMD_MOMENTS_V1"])
+def test_native_step_maxdim3_alternative_kernels(flag, monkeypatch):
+    """The table-driven (maxdim 3) native step through its cross-check kernels: run-time-table local kernels instead of the
+    compile-time-table ones (LGN_AMD_NO_STATIC), decoder moments as pair sweeps instead of the separable jet sums
+    (LGN_AMD_DEC_PAIRWISE), component-chunked moments kernels (LGN_AMD_MOMENTS_V1).  Same golden vectors, same tolerances;
+    the switches are read per call, so the step object is built after setting them (the workspace is sized per form)."""
+    from lgn.step import NativeTrainStep
+    monkeypatch.setenv(flag, "1")
+    z, m, enc, dec, batch = _golden_setup("g2_e2e_maxdim3.npz")
+    step = NativeTrainStep(enc, dec, batch_size=m["B"], l1_lambda=m["l1_lambda"], optimizer=False, use_graph=False)
+    total, recon = step.step(batch)
+    U.assert_close(total, z["loss_total"], 1e-11, "total loss")
+    U.assert_close(recon, z["recon"], 1e-11, "recon")
+    lam = m["l1_lambda"]
+    for pre, mod in (("enc", enc), ("dec", dec)):
+        sd = U.params_from(z, pre)
+        for k, g in mod.named_grads():
+            ref = torch.from_numpy(z[f"grad.{pre}.{k}"]) + lam * torch.sign(sd[k])
+            U.assert_close(g, ref, 1e-9, f"grad {pre}.{k}")
+
+
 def test_native_adam_matches_torch_adam_and_modular_path():
     """Three optimiser steps: native graph-replayed step vs the autograd/module path with torch.optim.Adam."""
     from lgn.step import NativeTrainStep, TrainStep

@@ -192,3 +192,17 @@ def test_native_step_refuses_configurations_it_does_not_implement():
     enc, dec = G._models(12, (3, 3, 4, 4), (4, 4, 3, 3), torch.device("cpu"), seed=0, map_to_latent="mean+max")
     with pytest.raises(NotImplementedError, match="min&max"):
         NativeTrainStep(enc, dec, batch_size=4)
+
+
+def test_generated_static_tables_are_up_to_date_and_match_the_runtime_matcher():
+    """csrc/cg_static_tables.hpp is generated from lgn.plan.build_local_tables (tools/gen_static_tables.py); the committed
+    file must equal a fresh rendering, and plan.static_kind must recognise exactly the levels it was generated from."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_static_tables", os.path.join(ROOT, "tools", "gen_static_tables.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    with open(gen.OUT) as fh:
+        assert fh.read() == gen.render(), "run tools/gen_static_tables.py"
+    from lgn.plan import canonical_static_tables, static_kind
+    for kind, tab in canonical_static_tables().items():
+        assert static_kind(tab) == kind
