@@ -75,6 +75,8 @@ def test_native_step_maxdim3_alternative_kernels(flag, monkeypatch):
     the switches are read per call, so the step object is built after setting them (the workspace is sized per form)."""
     from lgn.step import NativeTrainStep
     monkeypatch.setenv(flag, "1")
+    if flag == "LGN_AMD_MOMENTS_V1":        # those kernels know the node-major layout only (the library says so otherwise)
+        monkeypatch.setenv("LGN_AMD_NO_STATIC", "1")
     z, m, enc, dec, batch = _golden_setup("g2_e2e_maxdim3.npz")
     step = NativeTrainStep(enc, dec, batch_size=m["B"], l1_lambda=m["l1_lambda"], optimizer=False, use_graph=False)
     total, recon = step.step(batch)
