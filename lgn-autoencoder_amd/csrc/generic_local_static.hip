@@ -497,12 +497,8 @@ int local_fwd_static(int kind, int M, int C, int CO, const double* XT, const dou
   for (int l = 0; l < 5; ++l) a.wp0[l] = p.wp0[l];
   dim3 grid(cdiv(M, 64), N_ITEMS);
 #define LGN_LAUNCH(KIND, COT) hipLaunchKernelGGL((local_fwd_static_kernel<cgs::KIND, COT>), grid, dim3(64), 0, st, a)
-#ifdef SB_ONLY_K2C6      // (compile-time experiments: one instantiation)
-  LGN_LAUNCH(Kind2, 6);
-#else
   if (kind == 1) { if (CO <= 4) LGN_LAUNCH(Kind1, 4); else if (CO <= 6) LGN_LAUNCH(Kind1, 6); else LGN_LAUNCH(Kind1, 8); }
   else { if (CO <= 4) LGN_LAUNCH(Kind2, 4); else if (CO <= 6) LGN_LAUNCH(Kind2, 6); else LGN_LAUNCH(Kind2, 8); }
-#endif
 #undef LGN_LAUNCH
   LGN_CHECK_LAUNCH();
   return 0;
@@ -524,12 +520,8 @@ int local_bwd_static(int kind, int M, int C, int CO, const double* XT, const dou
   for (int l = 0; l < 5; ++l) a.wp0[l] = p.wp0[l];
   dim3 grid(cdiv(M, 64), C);
 #define LGN_LAUNCH(KIND, COT) hipLaunchKernelGGL((local_bwd_static_kernel<cgs::KIND, COT>), grid, dim3(128), 0, st, a)
-#ifdef SB_ONLY_K2C6      // (compile-time experiments: one instantiation)
-  LGN_LAUNCH(Kind2, 6);
-#else
   if (kind == 1) { if (CO <= 4) LGN_LAUNCH(Kind1, 4); else if (CO <= 6) LGN_LAUNCH(Kind1, 6); else LGN_LAUNCH(Kind1, 8); }
   else { if (CO <= 4) LGN_LAUNCH(Kind2, 4); else if (CO <= 6) LGN_LAUNCH(Kind2, 6); else LGN_LAUNCH(Kind2, 8); }
-#endif
 #undef LGN_LAUNCH
   LGN_CHECK_LAUNCH();
   return 0;
