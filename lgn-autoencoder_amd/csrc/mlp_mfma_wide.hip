@@ -32,7 +32,13 @@ struct Geo {
   static constexpr int NPF = (HP * 16 + THREADS - 1) / THREADS;   // passes for the first layer image (16 columns)
   static_assert(NPF <= NPH, "prefetch registers");
   static constexpr size_t fwd_doubles() { return WSIZE + MT * TSIZE + MT * T0SIZE; }
-  static constexpr size_t bwd_doubles() { return WSIZE + 2 * MT * TSIZE + MT * T0SIZE + MT * HP; }
+  static constexpr int BWD_BASE = WSIZE + 2 * MT * TSIZE + MT * T0SIZE + MT * HP;
+  // backward: the activations of the first NHL hidden layers stay in LDS tiles of their own (the LDS left over decides how
+  // many): they are the next layer's input in the recompute and the dW operand of the sweep as they lie, and the registers
+  // that would hold them until the sweep are free (the kernel is register bound: 10..12 waves -> 168 VGPRs)
+  static constexpr int NHL_FIT = (160 * 1024 / 8 - BWD_BASE) / (MT * TSIZE);
+  static constexpr int NHL = NHL_FIT > 5 ? 5 : NHL_FIT;
+  static constexpr size_t bwd_doubles() { return BWD_BASE + NHL * MT * TSIZE; }
 };
 
 // ---- weight staging: thread-constant bases, wave-uniform strides (see mlp_mfma.hip) ---------------------------------
@@ -173,6 +179,8 @@ __global__ __launch_bounds__(64 * MT * NT) void mlp_bwd_wide_kernel(MlpArgs<doub
   double* Gt = X + MT * G::TSIZE;                          // MT g_pre tiles
   double* X0 = Gt + MT * G::TSIZE;                         // MT MLP input tiles
   double* dbw = X0 + MT * G::T0SIZE;                       // MT x HP column sums
+  double* Hl = dbw + MT * HP;                              // NHL x MT tiles: post-activations of hidden layers 0 .. NHL - 1
+  constexpr int NHL = G::NHL;
   double* part = a.part + (size_t)blockIdx.x * a.psize;
 
   for (int pass = 0; pass < 64 / (16 * MT); ++pass) {      // 32-row passes of this workgroup's 64 rows
@@ -188,11 +196,12 @@ __global__ __launch_bounds__(64 * MT * NT) void mlp_bwd_wide_kernel(MlpArgs<doub
 #pragma unroll
     for (int l = 0; l < NH; ++l) {
       prefetch_hidden<NT>(a.w[l + 1], a.b[l + 1], l + 1 == NH ? D : H, H, regs, breg);   // after the last hidden layer: the output layer
-      h[l] = dense<NT>(l == 0, Wl, X0, X, mt, nt, lane, ksh);
+      h[l] = dense<NT>(l == 0, Wl, X0, (l >= 1 && l - 1 < NHL) ? Hl + (l - 1) * MT * G::TSIZE : X, mt, nt, lane, ksh);
 #pragma unroll
       for (int r = 0; r < 4; ++r) h[l][r] = leaky(h[l][r]);
       __syncthreads();
-      if (l + 1 < NH) store_tile<NT>(X, mt, nt, lane, h[l]);
+      if (l < NHL) store_tile<NT>(Hl + l * MT * G::TSIZE, mt, nt, lane, h[l]);
+      else if (l + 1 < NH) store_tile<NT>(X, mt, nt, lane, h[l]);
       commit_hidden<NT>(Wl, regs, breg);
       __syncthreads();
     }
@@ -217,7 +226,9 @@ __global__ __launch_bounds__(64 * MT * NT) void mlp_bwd_wide_kernel(MlpArgs<doub
       else if (l > 1) prefetch_hidden<NT>(a.w[l - 1], a.b[l - 1], H, H, regs, breg);
 
       store_tile<NT>(Gt, mt, nt, lane, gpre);
-      if (l > 0) store_tile<NT>(X, mt, nt, lane, h[l > 0 ? l - 1 : 0]);
+      const bool in_lds = l > 0 && l - 1 < NHL;            // layer input: already in its own tiles / from registers
+      double* Xl = in_lds ? Hl + (l > 0 ? l - 1 : 0) * MT * G::TSIZE : X;
+      if (l > 0 && !in_lds) store_tile<NT>(X, mt, nt, lane, h[l > 0 ? l - 1 : 0]);
       {
         double v = (gpre[0] + gpre[1]) + (gpre[2] + gpre[3]);   // bias gradient: column sums over this tile's 16 rows
         v += shfl_xor(v, 16);
@@ -240,7 +251,7 @@ __global__ __launch_bounds__(64 * MT * NT) void mlp_bwd_wide_kernel(MlpArgs<doub
         for (int tile = wave; tile < ntiles; tile += NW) {
           const int t = tile / nti, u = tile - t * nti;
           const double* ga = Gt + g * S + 16 * t + c;
-          const double* xb = l == 0 ? X0 + g * G::S0 + c : X + g * S + 16 * u + c;
+          const double* xb = l == 0 ? X0 + g * G::S0 + c : Xl + g * S + 16 * u + c;
           const int xts = l == 0 ? G::T0SIZE : G::TSIZE, xss = l == 0 ? G::S0 : S;
           v4d acc0 = v4d{0, 0, 0, 0}, acc1 = v4d{0, 0, 0, 0};
 #pragma unroll
@@ -264,8 +275,12 @@ __global__ __launch_bounds__(64 * MT * NT) void mlp_bwd_wide_kernel(MlpArgs<doub
         }
       }
       if (l > 0) {
+        const double* hd = Xl + mt * G::TSIZE + g * S + 16 * nt + c;      // this wave's tile of the layer input, D layout
 #pragma unroll
-        for (int r = 0; r < 4; ++r) gpre[r] = gin[r] * (h[l > 0 ? l - 1 : 0][r] > 0.0 ? 1.0 : 0.01);
+        for (int r = 0; r < 4; ++r) {
+          const double hv = in_lds ? hd[4 * r * S] : h[l > 0 ? l - 1 : 0][r];
+          gpre[r] = gin[r] * (hv > 0.0 ? 1.0 : 0.01);
+        }
         __syncthreads();                                     // every read of the weight image and of the tiles is done
         if (l == 1) commit_first<NT>(Wl, regs, breg);
         else commit_hidden<NT>(Wl, regs, breg);
