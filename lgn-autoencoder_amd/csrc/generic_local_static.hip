@@ -437,6 +437,36 @@ __global__ __launch_bounds__(BLOCK) void unpack_weight_grads_kernel(PackArgs p, 
   }
 }
 
+// several levels per launch (blockIdx.y = job): the sequencers pack every level of a network before its forward and unpack
+// every level's gradient after the deferred reductions -- one launch each instead of one per level
+constexpr int PACK_MAX_JOBS = 8;
+struct PackBatch {
+  PackArgs p[PACK_MAX_JOBS];
+  const double* src[PACK_MAX_JOBS];
+  double* dst[PACK_MAX_JOBS];
+};
+__global__ __launch_bounds__(BLOCK) void pack_batch_kernel(PackBatch b, int unpack) {
+  const PackArgs& p = b.p[blockIdx.y];
+  const double* __restrict__ src = b.src[blockIdx.y];
+  double* __restrict__ dst = b.dst[blockIdx.y];
+  for (int l = 0; l < p.n_out; ++l) {
+    const int nb = p.nblk[l], K = nb * p.C, total = p.C * nb * p.COT;
+    for (int e = blockIdx.x * BLOCK + threadIdx.x; e < total; e += gridDim.x * BLOCK) {
+      const int o = e % p.COT, blk = (e / p.COT) % nb, c = e / (p.COT * nb);
+      const size_t ire = p.w0[l] + (size_t)o * K + blk * p.C + c, iim = ire + (size_t)p.CO * K;
+      if (unpack) {
+        if (o < p.CO) {
+          dst[ire] += src[p.wp0[l] + 2 * e];
+          dst[iim] += src[p.wp0[l] + 2 * e + 1];
+        }
+      } else {
+        dst[p.wp0[l] + 2 * e] = o < p.CO ? src[ire] : 0.0;
+        dst[p.wp0[l] + 2 * e + 1] = o < p.CO ? src[iim] : 0.0;
+      }
+    }
+  }
+}
+
 // items of a level kind: every output irrep in chunks of <= 2 rows (few accumulators: two waves per SIMD); both kinds have output dims 4,3,3,9,1
 constexpr int N_ITEMS = 12;
 template <class T, int COT>
@@ -486,13 +516,15 @@ size_t local_static_packed_doubles(int kind, int C, int CO) {
 // kind: 1 / 2 (cg_static_tables.hpp); w0: per-irrep weight offsets in wcat (host array of 5); wp: scratch of
 // local_static_packed_doubles(kind, C, CO) doubles (written here); layouts: see the head of this file
 int local_fwd_static(int kind, int M, int C, int CO, const double* XT, const double* UT, const double* w, const int* w0, double* wp,
-                     double* outT, double* s_copy, int q_s, hipStream_t st) {
+                     double* outT, double* s_copy, int q_s, hipStream_t st, bool packed) {
   LGN_CHECK_ARG(kind == 1 || kind == 2, "local_fwd_static: unknown level kind %d", kind);
   LGN_CHECK_ARG(M > 0 && C >= 1 && C <= 8 && CO >= 1 && CO <= COMAX, "local_fwd_static: unsupported shape (M=%d C=%d CO=%d)", M, C, CO);
   PackArgs p{};
   if (kind == 1) fill_pack<cgs::Kind1>(p, C, CO, w0); else fill_pack<cgs::Kind2>(p, C, CO, w0);
-  hipLaunchKernelGGL(pack_weights_kernel, dim3(8), dim3(BLOCK), 0, st, p, w, wp);
-  LGN_CHECK_LAUNCH();
+  if (!packed) {
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(8), dim3(BLOCK), 0, st, p, w, wp);
+    LGN_CHECK_LAUNCH();
+  }
   StaticArgs a{M, C, CO, XT, UT, wp, {0, 0, 0, 0, 0, 0, 0, 0}, outT, s_copy, q_s};
   for (int l = 0; l < 5; ++l) a.wp0[l] = p.wp0[l];
   dim3 grid(cdiv(M, 64), N_ITEMS);
@@ -509,13 +541,15 @@ int local_fwd_static(int kind, int M, int C, int CO, const double* XT, const dou
 // (every entry written); gpacked: packed doubles (the caller reduces `part` over the tiles into it, then calls
 // local_static_unpack_grads).  goT / gUT / gXT: see StaticBwdArgs.
 int local_bwd_static(int kind, int M, int C, int CO, const double* XT, const double* UT, const double* w, const int* w0, double* wp,
-                     const double* goT, double* gUT, double* gXT, double* part, hipStream_t st) {
+                     const double* goT, double* gUT, double* gXT, double* part, hipStream_t st, bool packed) {
   LGN_CHECK_ARG(kind == 1 || kind == 2, "local_bwd_static: unknown level kind %d", kind);
   LGN_CHECK_ARG(M > 0 && C >= 1 && C <= 8 && CO >= 1 && CO <= COMAX, "local_bwd_static: unsupported shape (M=%d C=%d CO=%d)", M, C, CO);
   PackArgs p{};
   if (kind == 1) fill_pack<cgs::Kind1>(p, C, CO, w0); else fill_pack<cgs::Kind2>(p, C, CO, w0);
-  hipLaunchKernelGGL(pack_weights_kernel, dim3(8), dim3(BLOCK), 0, st, p, w, wp);
-  LGN_CHECK_LAUNCH();
+  if (!packed) {       // (the sequencers keep the forward's packed image)
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(8), dim3(BLOCK), 0, st, p, w, wp);
+    LGN_CHECK_LAUNCH();
+  }
   StaticBwdArgs a{M, C, CO, XT, UT, wp, {0, 0, 0, 0, 0, 0, 0, 0}, goT, gUT, gXT, part, (int)local_static_packed_doubles(kind, C, CO)};
   for (int l = 0; l < 5; ++l) a.wp0[l] = p.wp0[l];
   dim3 grid(cdiv(M, 64), C);
@@ -533,6 +567,26 @@ int local_static_unpack_grads(int kind, int C, int CO, const int* w0, const doub
   if (kind == 1) fill_pack<cgs::Kind1>(p, C, CO, w0); else fill_pack<cgs::Kind2>(p, C, CO, w0);
   hipLaunchKernelGGL(unpack_weight_grads_kernel, dim3(8), dim3(BLOCK), 0, st, p, gpacked, gw);
   LGN_CHECK_LAUNCH();
+  return 0;
+}
+
+// n <= 8 jobs in one launch.  unpack = false: dst = packed image of the CatMix weights src;  unpack = true: dst (CatMix
+// parameter layout) += unpacked src (packed gradients)
+int local_static_pack_batch(const StaticPackJob* jobs, int n, bool unpack, hipStream_t st) {
+  for (int i0 = 0; i0 < n; i0 += PACK_MAX_JOBS) {
+    PackBatch b{};
+    const int m = n - i0 < PACK_MAX_JOBS ? n - i0 : PACK_MAX_JOBS;
+    for (int i = 0; i < m; ++i) {
+      const StaticPackJob& j = jobs[i0 + i];
+      LGN_CHECK_ARG((j.kind == 1 || j.kind == 2) && j.C >= 1 && j.C <= 8 && j.CO >= 1 && j.CO <= COMAX && j.src && j.dst,
+                    "local_static_pack_batch: bad job %d (kind=%d C=%d CO=%d)", i0 + i, j.kind, j.C, j.CO);
+      if (j.kind == 1) fill_pack<cgs::Kind1>(b.p[i], j.C, j.CO, j.w0); else fill_pack<cgs::Kind2>(b.p[i], j.C, j.CO, j.w0);
+      b.src[i] = j.src;
+      b.dst[i] = j.dst;
+    }
+    hipLaunchKernelGGL(pack_batch_kernel, dim3(8, m), dim3(BLOCK), 0, st, b, unpack ? 1 : 0);
+    LGN_CHECK_LAUNCH();
+  }
   return 0;
 }
 

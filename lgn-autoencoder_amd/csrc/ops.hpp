@@ -137,10 +137,14 @@ int local_partial_rows(int nodes);
 // compile-time-table kernels for the two maxdim = 3 level kinds (generic_local_static.hip), node-innermost layouts
 size_t local_static_packed_doubles(int kind, int C, int CO);
 int local_bwd_static(int kind, int M, int C, int CO, const double* XT, const double* UT, const double* w, const int* w0, double* wp,
-                     const double* goT, double* gUT, double* gXT, double* part, hipStream_t st);
+                     const double* goT, double* gUT, double* gXT, double* part, hipStream_t st, bool packed = false);
 int local_static_unpack_grads(int kind, int C, int CO, const int* w0, const double* gpacked, double* gw, hipStream_t st);
 int local_fwd_static(int kind, int M, int C, int CO, const double* XT, const double* UT, const double* w, const int* w0, double* wp,
-                     double* outT, double* s_copy, int q_s, hipStream_t st);
+                     double* outT, double* s_copy, int q_s, hipStream_t st, bool packed = false);
+// packed = true: wp already holds the level's packed weight image.  Batched (un)packing, one launch for up to 8 levels:
+// pack: dst = packed image of the CatMix weights src;  unpack: dst (CatMix parameter layout) += unpacked packed gradients src
+struct StaticPackJob { int kind, C, CO; int w0[5]; const double* src; double* dst; };
+int local_static_pack_batch(const StaticPackJob* jobs, int n, bool unpack, hipStream_t st);
 // packed X [2][nodes][C][Q] <-> s [2][nodes][C] (component q_s) + v [2][nodes][C][4] (components q_v..q_v+3); pack zero-fills the rest
 int gen_pack(size_t nodes_x_C, int Q, int q_s, int q_v, const double* s, const double* v, double* X, hipStream_t st);
 int gen_unpack(size_t nodes_x_C, int Q, int q_s, int q_v, const double* X, double* s, double* v, hipStream_t st);

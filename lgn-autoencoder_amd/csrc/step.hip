@@ -320,7 +320,7 @@ int check_generic(const lgn_net_desc& d, bool dec) {
 struct GenAct {                     // written by the forward, read by the backward
   double *s0, *v0;                  // input-kernel outputs [2][BN][C0], [2][BN][C0][4]
   double *X[5], *U[4], *smix[4];
-  double* wp[4];                    // static path: packed CatMix weights of each level (repacked by every forward / backward call)
+  double* wp[4];                    // static path: packed CatMix weights of each level (written by the forward, reused by the backward)
   double *sL, *vL;                  // (0,0) / (1,1) of the last level, unpacked for the end kernels
   double* pdec;
   int* idx;
@@ -424,6 +424,14 @@ int gen_levels_fwd(const lgn_net_desc& d, bool dec, const double* P, const int64
   const GenGeom g = geom(d, dec);
   const int BN = d.B * d.N;
   const bool tb = is_static(d, dec);
+  if (tb) {       // the packed CatMix weight images of all levels, one launch (the backward reuses them)
+    StaticPackJob jobs[8];
+    for (int l = 0; l < d.n_levels; ++l) {
+      jobs[l] = StaticPackJob{g.tab[l]->static_kind, g.ch[l], g.ch[l + 1], {0, 0, 0, 0, 0}, P + off[S.mix(dec, l, 0)], a.wp[l]};
+      for (int k = 0; k < 5; ++k) jobs[l].w0[k] = g.tab[l]->h_out_w0[k];
+    }
+    LGN_TRY(local_static_pack_batch(jobs, d.n_levels, false, st));
+  }
   for (int l = 0; l < d.n_levels; ++l) {
     GenArgs m = gen_level_args(d, dec, l, P, off, a.X[l], pos, mask);
     m.U = a.U[l];
@@ -433,7 +441,7 @@ int gen_levels_fwd(const lgn_net_desc& d, bool dec, const double* P, const int64
       int w0[8];
       for (int k = 0; k < 5; ++k) w0[k] = g.tab[l]->h_out_w0[k];
       LGN_TRY(local_fwd_static(g.tab[l]->static_kind, BN, g.ch[l], g.ch[l + 1], a.X[l], a.U[l], P + off[S.mix(dec, l, 0)], w0, a.wp[l],
-                               a.X[l + 1], a.smix[l], g.qs[l + 1], st));
+                               a.X[l + 1], a.smix[l], g.qs[l + 1], st, /*packed=*/true));
     } else {
       LocalArgs la{};
       LGN_TRY(local_args(la, BN, g.ch[l], g.ch[l + 1], g.Q[l], g.Q[l + 1], g.tab[l]));
@@ -453,10 +461,10 @@ int gen_levels_fwd(const lgn_net_desc& d, bool dec, const double* P, const int64
 }
 
 // packed CatMix weight gradients (static path) are unpacked into the flat gradient AFTER the deferred reductions ran
-struct UnpackJob { int kind, C, CO; int w0[5]; const double* gpacked; double* gw; };
+typedef StaticPackJob UnpackJob;      // src = reduced packed gradients, dst = the CatMix slot of the flat gradient
 int run_unpack_jobs(const std::vector<UnpackJob>& post, hipStream_t st) {
-  for (const UnpackJob& j : post) LGN_TRY(local_static_unpack_grads(j.kind, j.C, j.CO, j.w0, j.gpacked, j.gw, st));
-  return 0;
+  if (post.empty()) return 0;
+  return local_static_pack_batch(post.data(), (int)post.size(), true, st);
 }
 
 // On entry sc.gX[cur] holds the gradient w.r.t. X[L] (scalar column = 0 when !has_s_grad); on exit sc.gX[cur] the one w.r.t. X[0].
@@ -487,7 +495,8 @@ int gen_levels_bwd(const lgn_net_desc& d, bool dec, const double* P, double* G, 
       for (int k = 0; k < 5; ++k) w0[k] = g.tab[l]->h_out_w0[k];
       const int kind = g.tab[l]->static_kind, np = (int)local_static_packed_doubles(kind, C, CO), tiles = (BN + 63) / 64;
       double* part = dq.take((size_t)tiles * np);
-      LGN_TRY(local_bwd_static(kind, BN, C, CO, a.X[l], a.U[l], P + off[S.mix(dec, l, 0)], w0, a.wp[l], sc.gX[cur], sc.gU, sc.gX[nxt], part, st));
+      LGN_TRY(local_bwd_static(kind, BN, C, CO, a.X[l], a.U[l], P + off[S.mix(dec, l, 0)], w0, a.wp[l], sc.gX[cur], sc.gU, sc.gX[nxt], part, st,
+                               /*packed=*/true));
       dq.add(part, tiles, np, 0, np, sc.gpk[l]);
       post.push_back(UnpackJob{kind, C, CO, {w0[0], w0[1], w0[2], w0[3], w0[4]}, sc.gpk[l], G + off[S.mix(dec, l, 0)]});
     } else {
