@@ -48,6 +48,26 @@ struct Jet {
 };
 __host__ __device__ inline int row_pitch(int N) { return (N | 1) + ((((N | 1) & 3) == 1) ? 0 : 2); }   // == 1 mod 4
 
+// One channel of a tile-blocked tensor ([tile][C][Qx][2][64], node n = 64 tile + lane) -> LDS rows dst[node * pitch + 2 r + plane],
+// r = 0 .. Qx - 1.  lane = particle of the jet (a jet's particles are consecutive lanes of one or two tiles: every load is a
+// coalesced run), waves take rows r round robin; no index arithmetic per element, the loads of an unrolled group in flight together.
+__device__ __forceinline__ void stage_tb(const double* __restrict__ src, int Qx, int C, int c, int b, int N, double* dst, int pitch) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane >= N) return;
+  const int n = b * N + lane;
+  const double* __restrict__ s = src + ((size_t)(n >> 6) * C + c) * Qx * 128 + (n & 63);
+  double* d = dst + (size_t)lane * pitch;
+  int r = wave;
+  for (; r + 12 < Qx; r += 16) {
+    double v[4][2];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { v[u][0] = s[(r + 4 * u) * 128]; v[u][1] = s[(r + 4 * u) * 128 + 64]; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { d[2 * (r + 4 * u)] = v[u][0]; d[2 * (r + 4 * u) + 1] = v[u][1]; }
+  }
+  for (; r < Qx; r += 4) { d[2 * r] = s[r * 128]; d[2 * r + 1] = s[r * 128 + 64]; }
+}
+
 template <bool DEC>
 __device__ __forceinline__ void load_jet(const GenArgs& a, int b, Jet& J) {
   const int N = a.N, B = a.B;
@@ -171,10 +191,14 @@ __global__ __launch_bounds__(BLOCK) void moments_fwd2_kernel(GenArgs a) {
   for (int c = 0; c < C; ++c) {
     __syncthreads();                                           // previous channel's sweeps are done with Rl / xs / wl
     if (!DEC) load_channel_consts(a, c, J.wl);
-    for (int e = threadIdx.x; e < N * Q; e += BLOCK) {         // fastest index = the one that is contiguous in memory
-      const int q = a.tb ? e / N : e % Q, j = a.tb ? e % N : e / Q;
-      xs[2 * (j * Q + q)] = a.X[feat_index(a.tb, plane, C, Q, b * N + j, c, q, 0)];
-      xs[2 * (j * Q + q) + 1] = a.X[feat_index(a.tb, plane, C, Q, b * N + j, c, q, 1)];
+    if (a.tb) {
+      stage_tb(a.X, Q, C, c, b, N, xs, 2 * Q);
+    } else {
+      for (int e = threadIdx.x; e < N * Q; e += BLOCK) {
+        const int q = e % Q, j = e / Q;
+        xs[2 * (j * Q + q)] = a.X[feat_index(false, plane, C, Q, b * N + j, c, q, 0)];
+        xs[2 * (j * Q + q) + 1] = a.X[feat_index(false, plane, C, Q, b * N + j, c, q, 1)];
+      }
     }
     __syncthreads();
     fill_R<DEC>(a, c, J, RP);
@@ -249,10 +273,7 @@ __global__ __launch_bounds__(BLOCK) void moments_bwd_nodes2_kernel(GenArgs a) {
     __syncthreads();
     if (!DEC) load_channel_consts(a, c, J.wl);
     if (a.tb) {
-      for (int e = threadIdx.x; e < N * Q * 10; e += BLOCK) {
-        const int r = e / N, i = e - r * N;                    // r = (q * 5 + k) * 2 + z; i fastest
-        gu[(size_t)i * Q * 10 + r] = a.gU[feat_index(true, 0, C, 5 * Q, b * N + i, c, r >> 1, r & 1)];
-      }
+      stage_tb(a.gU, 5 * Q, C, c, b, N, gu, Q * 10);
     } else {
       for (int e = threadIdx.x; e < N * Q * 10; e += BLOCK) {
         const int i = e / (Q * 10), r = e - i * Q * 10;
@@ -330,6 +351,8 @@ __global__ __launch_bounds__(BLOCK) void moments_bwd_nodes2_kernel(GenArgs a) {
 // wave = group of partners? no: lane = (row i, half of the partner range), wave = quarter of ... the q loop is the
 // reduction here, so the four waves split the PARTNER range instead (each lane: one row, N/8 partners, all q).
 // =========================================================================================================
+__host__ __device__ inline int g2_row_pitch(int Q) { return Q * 10 + 2; }
+
 template <bool DEC>
 __global__ __launch_bounds__(BLOCK) void moments_bwd_G2_kernel(GenArgs a, double* Gbuf) {
   constexpr int PS = DEC ? 8 : 4;
@@ -338,8 +361,11 @@ __global__ __launch_bounds__(BLOCK) void moments_bwd_G2_kernel(GenArgs a, double
   extern __shared__ __align__(16) unsigned char smem_raw[];
   Jet J;                                                       // (no pair table: the gradient w.r.t. R does not depend on R)
   J.Rl = nullptr;
-  double* gu = reinterpret_cast<double*>(smem_raw);            // [N][Q*5][2]
-  double* xs = gu + (size_t)N * Q * 10;                        // [N][Q][2]
+  // lane = row i reads ITS row of dU: a row pitch of Q * 10 doubles (1600 B at Q = 20) would put all 32 rows on two bank
+  // groups; + 2 doubles makes the 16-byte reads of eight consecutive rows hit eight different bank quads
+  const int GS = g2_row_pitch(Q);
+  double* gu = reinterpret_cast<double*>(smem_raw);            // [N][GS]: (q, k, plane) of row n
+  double* xs = gu + (size_t)N * GS;                            // [N][Q][2]
   J.pj = xs + (size_t)N * Q * 2;
   J.wl = J.pj + (size_t)N * PS;
   double* red = J.wl + NB * 8 + 4;                             // decoder: [8 groups][N][8] d p_i partials | [8][2] bias partials per channel
@@ -354,45 +380,59 @@ __global__ __launch_bounds__(BLOCK) void moments_bwd_G2_kernel(GenArgs a, double
   for (int c = 0; c < C; ++c) {
     __syncthreads();
     if (a.tb) {
-      for (int e = threadIdx.x; e < N * Q * 10; e += BLOCK) {
-        const int r = e / N, n = e - r * N;
-        gu[(size_t)n * Q * 10 + r] = a.gU[feat_index(true, 0, C, 5 * Q, b * N + n, c, r >> 1, r & 1)];
-      }
+      stage_tb(a.gU, 5 * Q, C, c, b, N, gu, GS);
+      stage_tb(a.X, Q, C, c, b, N, xs, 2 * Q);
     } else {
       for (int e = threadIdx.x; e < N * Q * 10; e += BLOCK) {
         const int n = e / (Q * 10), r = e - n * Q * 10;
-        gu[e] = a.gU[(((size_t)b * N + n) * C + c) * Q * 10 + r];
+        gu[(size_t)n * GS + r] = a.gU[(((size_t)b * N + n) * C + c) * Q * 10 + r];
       }
-    }
-    for (int e = threadIdx.x; e < N * Q; e += BLOCK) {
-      const int q = a.tb ? e / N : e % Q, n = a.tb ? e % N : e / Q;
-      xs[2 * (n * Q + q)] = a.X[feat_index(a.tb, plane, C, Q, b * N + n, c, q, 0)];
-      xs[2 * (n * Q + q) + 1] = a.X[feat_index(a.tb, plane, C, Q, b * N + n, c, q, 1)];
+      for (int e = threadIdx.x; e < N * Q; e += BLOCK) {
+        const int q = e % Q, n = e / Q;
+        xs[2 * (n * Q + q)] = a.X[feat_index(false, plane, C, Q, b * N + n, c, q, 0)];
+        xs[2 * (n * Q + q) + 1] = a.X[feat_index(false, plane, C, Q, b * N + n, c, q, 1)];
+      }
     }
     __syncthreads();
     double pi[PS];
 #pragma unroll
     for (int m = 0; m < PS; ++m) pi[m] = J.pj[ii * PS + m];
     double dB0 = 0.0, dB1 = 0.0;
-    const double* gi = gu + (size_t)ii * Q * 10;
-    for (int j = jb; j < je; ++j) {
-      const double* xj = xs + (size_t)j * Q * 2;
-      cx<double> ge[5] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}};
-      for (int x = 0; x < Q; ++x) {
-        const cx<double> xv = {xj[2 * x], xj[2 * x + 1]};
+    const double* gi = gu + (size_t)ii * GS;
+    // component loop outermost: the lane's own dU values of a component (5 complex) are read once for ALL of its partners
+    // (read per partner, the LDS reads -- 6 per 20 fused multiply-adds -- were the limit, not the arithmetic)
+    constexpr int JP = (MAXN + 7) / 8;                         // partners per lane, at most
+    cx<double> ge[JP][5];
 #pragma unroll
-        for (int k = 0; k < 5; ++k) cfmac(ge[k], cx<double>{gi[x * 10 + 2 * k], gi[x * 10 + 2 * k + 1]}, xv);
+    for (int t = 0; t < JP; ++t)
+#pragma unroll
+      for (int k = 0; k < 5; ++k) ge[t][k] = {0, 0};
+    for (int x = 0; x < Q; ++x) {
+      cx<double> gv[5];
+#pragma unroll
+      for (int k = 0; k < 5; ++k) gv[k] = {gi[x * 10 + 2 * k], gi[x * 10 + 2 * k + 1]};
+#pragma unroll
+      for (int t = 0; t < JP; ++t) {
+        const int j = min(jb + t, N - 1);                      // (partners beyond the group's range are computed and dropped)
+        const cx<double> xv = {xs[((size_t)j * Q + x) * 2], xs[((size_t)j * Q + x) * 2 + 1]};
+#pragma unroll
+        for (int k = 0; k < 5; ++k) cfmac(ge[t][k], gv[k], xv);
       }
+    }
+#pragma unroll
+    for (int t = 0; t < JP; ++t) {
+      const int j = jb + t;
+      if (j >= je) continue;
       cx<double> q[4];
       rel_q<DEC>(pi, J.pj + j * PS, q);
       cx<double> gR1 = {0, 0};
 #pragma unroll
-      for (int m = 0; m < 4; ++m) cfmac(gR1, ge[1 + m], q[m]);
-      const double G0r = ge[0].r + ge[0].i, G0i = ge[0].i - ge[0].r;     // e0 = R0 (1 + i)  ->  G_R0 = G_e0 conj(1 + i)
+      for (int m = 0; m < 4; ++m) cfmac(gR1, ge[t][1 + m], q[m]);
+      const double G0r = ge[t][0].r + ge[t][0].i, G0i = ge[t][0].i - ge[t][0].r;     // e0 = R0 (1 + i)  ->  G_R0 = G_e0 conj(1 + i)
       if (DEC) {
         const cx<double> R1 = {a.b1[c], a.b1[c]};
 #pragma unroll
-        for (int m = 0; m < 4; ++m) cfmac(Gq[m], ge[1 + m], R1);
+        for (int m = 0; m < 4; ++m) cfmac(Gq[m], ge[t][1 + m], R1);
         if (iok) {
           dB0 += G0r + G0i;              // R0 = b0 (1 + i) on both planes: d b0 = Re G_R0 + Im G_R0
           dB1 += gR1.r + gR1.i;
@@ -795,7 +835,7 @@ static int launch(const GenArgs& a, int which, double* Gbuf, hipStream_t st) {
       hipLaunchKernelGGL(k, dim3(a.B), dim3(BLOCK), smem, st, a);
     }
   } else {
-    const size_t smem = base_smem(a, DEC, 0) + gu + xs + (DEC ? sizeof(double) * (8 * a.N * 8 + 8 * 2 * 8) : 0);
+    const size_t smem = base_smem(a, DEC, 0) + sizeof(double) * (size_t)a.N * g2_row_pitch(a.Q) + xs + (DEC ? sizeof(double) * (8 * a.N * 8 + 8 * 2 * 8) : 0);
     auto k = moments_bwd_G2_kernel<DEC>;
     if ((rc = set_smem(k, smem, "moments_bwd_G2"))) return rc;
     hipLaunchKernelGGL(k, dim3(a.B), dim3(BLOCK), smem, st, a, Gbuf);
@@ -820,7 +860,7 @@ static int launch_reduce(const GenArgs& a, const double* Gbuf, hipStream_t st) {
 // Does the channel-outermost form apply?  (the jet's pair table, one channel's dU slice and its X slice must fit in LDS)
 bool moments2_fits(const GenArgs& a, int decoder) {
   if (a.N > m2::MAXN || a.C > 8) return false;
-  const size_t worst = m2::base_smem(a, decoder != 0, m2::row_pitch(a.N)) + sizeof(double) * (size_t)a.N * a.Q * 12 +
+  const size_t worst = m2::base_smem(a, decoder != 0, m2::row_pitch(a.N)) + sizeof(double) * ((size_t)a.N * a.Q * 12 + 2 * (size_t)a.N) +
                        (decoder ? sizeof(double) * (8 * a.N * 8 + 8 * 2 * 8) : 0);
   return worst <= 160 * 1024;
 }
