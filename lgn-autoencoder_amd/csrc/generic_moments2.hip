@@ -188,7 +188,7 @@ __global__ __launch_bounds__(BLOCK) void moments_fwd2_kernel(GenArgs a) {
   const bool iok = i < N;
   const int ii = iok ? i : N - 1;
   const int jmid = (N + 1) >> 1, jb = half ? jmid : 0, je = half ? N : jmid;
-  for (int c = 0; c < C; ++c) {
+  for (int c = blockIdx.y; c < C; c += gridDim.y) {        // encoder: one workgroup per (jet, channel) -- grid.y = C; decoder sums run over c here
     __syncthreads();                                           // previous channel's sweeps are done with Rl / xs / wl
     if (!DEC) load_channel_consts(a, c, J.wl);
     if (a.tb) {
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(BLOCK) void moments_bwd_nodes2_kernel(GenArgs a) {
   const int jj = jok ? j : N - 1;
   const int imid = (N + 1) >> 1, ib = half ? imid : 0, ie = half ? N : imid;
   cx<double> Gq[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};         // decoder: gradient w.r.t. q = p_i - p_j, summed over i, c, q
-  for (int c = 0; c < C; ++c) {
+  for (int c = blockIdx.y; c < C; c += gridDim.y) {        // encoder: one workgroup per (jet, channel) -- grid.y = C; decoder sums run over c here
     __syncthreads();
     if (!DEC) load_channel_consts(a, c, J.wl);
     if (a.tb) {
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(BLOCK) void moments_bwd_G2_kernel(GenArgs a, double
   const int ii = iok ? i : N - 1;
   const int per = (N + 7) >> 3, jb = grp * per, je = min(N, jb + per);
   cx<double> Gq[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
-  for (int c = 0; c < C; ++c) {
+  for (int c = blockIdx.y; c < C; c += gridDim.y) {        // encoder: one workgroup per (jet, channel) -- grid.y = C; decoder sums run over c here
     __syncthreads();
     if (a.tb) {
       stage_tb(a.gU, 5 * Q, C, c, b, N, gu, GS);
@@ -811,34 +811,37 @@ static size_t base_smem(const GenArgs& a, bool dec, int pitch) {     // pair tab
 template <bool DEC>
 static int launch(const GenArgs& a, int which, double* Gbuf, hipStream_t st) {
   const size_t xs = sizeof(double) * (size_t)a.N * a.Q * 2, gu = sizeof(double) * (size_t)a.N * a.Q * 10;
+  // encoder: channels are independent -> one workgroup per (jet, channel): 3x .. 6x more workgroups in flight to hide the staging
+  // and the barriers; the decoder kernels (pair-sweep cross-check only) accumulate d p and the bias gradients over the channels
+  const dim3 grid(a.B, DEC ? 1 : a.C);
   int rc;
   if (which == 0) {
     const size_t smem = base_smem(a, DEC, row_pitch(a.N)) + xs;
     if (a.Q <= 8) {
       auto k = moments_fwd2_kernel<DEC, 2>;
       if ((rc = set_smem(k, smem, "moments_fwd2"))) return rc;
-      hipLaunchKernelGGL(k, dim3(a.B), dim3(BLOCK), smem, st, a);
+      hipLaunchKernelGGL(k, grid, dim3(BLOCK), smem, st, a);
     } else {
       auto k = moments_fwd2_kernel<DEC, 5>;
       if ((rc = set_smem(k, smem, "moments_fwd2"))) return rc;
-      hipLaunchKernelGGL(k, dim3(a.B), dim3(BLOCK), smem, st, a);
+      hipLaunchKernelGGL(k, grid, dim3(BLOCK), smem, st, a);
     }
   } else if (which == 1) {
     const size_t smem = base_smem(a, DEC, a.N) + gu + (DEC ? sizeof(double) * 4 * a.N * 8 : 0);
     if (a.Q <= 8) {
       auto k = moments_bwd_nodes2_kernel<DEC, 2>;
       if ((rc = set_smem(k, smem, "moments_bwd_nodes2"))) return rc;
-      hipLaunchKernelGGL(k, dim3(a.B), dim3(BLOCK), smem, st, a);
+      hipLaunchKernelGGL(k, grid, dim3(BLOCK), smem, st, a);
     } else {
       auto k = moments_bwd_nodes2_kernel<DEC, 5>;
       if ((rc = set_smem(k, smem, "moments_bwd_nodes2"))) return rc;
-      hipLaunchKernelGGL(k, dim3(a.B), dim3(BLOCK), smem, st, a);
+      hipLaunchKernelGGL(k, grid, dim3(BLOCK), smem, st, a);
     }
   } else {
     const size_t smem = base_smem(a, DEC, 0) + sizeof(double) * (size_t)a.N * g2_row_pitch(a.Q) + xs + (DEC ? sizeof(double) * (8 * a.N * 8 + 8 * 2 * 8) : 0);
     auto k = moments_bwd_G2_kernel<DEC>;
     if ((rc = set_smem(k, smem, "moments_bwd_G2"))) return rc;
-    hipLaunchKernelGGL(k, dim3(a.B), dim3(BLOCK), smem, st, a, Gbuf);
+    hipLaunchKernelGGL(k, grid, dim3(BLOCK), smem, st, a, Gbuf);
   }
   LGN_CHECK_LAUNCH();
   return 0;
