@@ -406,3 +406,69 @@ def test_bad_arguments_fail_loudly(dev):
         N.level_fwd(True, s, v, p, None, (None, None, None, None, b, None, b), w, w)
     with pytest.raises(RuntimeError, match="CPU"):
         N.mixreps_fwd(torch.zeros(2, 1, 1, dtype=torch.float64), torch.zeros(2, 3, 1, 1, dtype=torch.float64))
+
+
+@pytest.mark.parametrize("decoder", [False, True])
+def test_static_local_kernels_match_runtime_table_kernels(dev, decoder):
+    """The compile-time-table kernels of generic_local_static.hip (tile-blocked layouts; what the native maxdim-3 sequencers
+    run) against the run-time-table kernels of generic_local.hip (oracle-tested above), level by level, through the C ABI:
+    both level kinds, every padded output width COT in {4, 6, 8} (the lane-sum butterflies of 8 / 12 / 16 values), channel
+    counts 2..8, and a node count that leaves the last 64-node tile partly empty."""
+    import ctypes
+    import __graft_entry__ as G
+    from lgn import _native as Nn
+    from lgn.plan import static_kind
+    enc, dec = G._models(30, (2, 4, 7, 8), (8, 6, 5, 3), dev, seed=3, maxdim=3)
+    net = dec if decoder else enc
+    B, N = 5, 30
+    M = B * N
+    tiles = (M + 63) // 64
+    Mp = tiles * 64
+    g = torch.Generator().manual_seed(11 + int(decoder))
+
+    def to_tb(t2):          # [2][M][C][K] -> [tile][C][K][2][64]
+        z = torch.zeros(2, Mp, t2.shape[2], t2.shape[3], device=dev, dtype=torch.float64)
+        z[:, :M] = t2
+        return z.reshape(2, tiles, 64, t2.shape[2], t2.shape[3]).permute(1, 3, 4, 0, 2).contiguous()
+
+    def from_tb(tb, K):     # [tile][C][K][2][64] -> [2][M][C][K]
+        return tb.permute(3, 0, 4, 1, 2).reshape(2, Mp, tb.shape[1], K)[:, :M]
+
+    seen = set()
+    for lvl in range(3):
+        tables, plan = net.level_tables(lvl), net.plans[lvl]
+        C, CO, Q, Qo = plan.channels_in, plan.channels_out, tables.meta["Q"], tables.meta["Qout"]
+        kind = static_kind(tables.meta)
+        assert kind in (1, 2), "every maxdim-3 level must match one of the two generated table sets"
+        seen.add((kind, 4 if CO <= 4 else 6 if CO <= 6 else 8))
+        X = torch.randn(2, B, N, C, Q, dtype=torch.float64, generator=g).to(dev)
+        Um = torch.randn(B, N, C, Q, 5, 2, dtype=torch.float64, generator=g).to(dev)
+        gout = torch.randn(2, B, N, CO, Qo, dtype=torch.float64, generator=g).to(dev)
+        mix = net.lgn_cg.node_levels[lvl].cat_mix.mix_reps
+        wcat = torch.cat([mix.weight(r).detach().reshape(-1) for r in tables.meta["out_irreps"]]).contiguous()
+        wcat = wcat + 0.3 * torch.randn(wcat.shape, dtype=torch.float64, generator=g).to(dev)     # (the init gain is tiny)
+        ref_out = Nn.local_fwd(tables, CO, X, Um, wcat)
+        ref_gU, ref_gX, ref_gw = Nn.local_bwd(tables, CO, X, Um, wcat, gout)
+
+        XT = to_tb(X.reshape(2, M, C, Q))
+        UT = to_tb(Um.reshape(M, C, Q * 5, 2).permute(3, 0, 1, 2))
+        goT = to_tb(gout.reshape(2, M, CO, Qo))
+        outT = torch.zeros(tiles, CO, Qo, 2, 64, device=dev, dtype=torch.float64)
+        w0 = (ctypes.c_int * 5)(*tables.meta["ints"]["out_w0"])
+        npk = Nn.lib().lgn_local_static_packed_doubles(kind, C, CO)
+        wp = torch.empty(npk, device=dev, dtype=torch.float64)
+        Nn._check(Nn.lib().lgn_local_fwd_static_f64(kind, M, C, CO, Nn.ptr(XT), Nn.ptr(UT), Nn.ptr(wcat), w0, Nn.ptr(wp), Nn.ptr(outT),
+                                                    None, -1, Nn.stream_ptr()), "lgn_local_fwd_static_f64")
+        U.assert_close(from_tb(outT, Qo).reshape(2, B, N, CO, Qo), ref_out, 1e-12, f"level {lvl} (kind {kind}, {C}->{CO}) forward")
+        gUT, gXT = torch.full_like(UT, float("nan")), torch.full_like(XT, float("nan"))      # every entry must be written
+        part = torch.empty(tiles, npk, device=dev, dtype=torch.float64)
+        gpk = torch.empty(npk, device=dev, dtype=torch.float64)
+        gw = torch.zeros_like(wcat)
+        Nn._check(Nn.lib().lgn_local_bwd_static_f64(kind, M, C, CO, Nn.ptr(XT), Nn.ptr(UT), Nn.ptr(wcat), w0, Nn.ptr(wp), Nn.ptr(goT),
+                                                    Nn.ptr(gUT), Nn.ptr(gXT), Nn.ptr(part), Nn.ptr(gpk), Nn.ptr(gw), Nn.stream_ptr()),
+                  "lgn_local_bwd_static_f64")
+        got_gU = from_tb(gUT, Q * 5).reshape(2, M, C, Q, 5).permute(1, 2, 3, 4, 0).reshape(B, N, C, Q, 5, 2)
+        U.assert_close(got_gU, ref_gU, 1e-12, f"level {lvl} (kind {kind}, {C}->{CO}) d U")
+        U.assert_close(from_tb(gXT, Q).reshape(2, B, N, C, Q), ref_gX, 1e-12, f"level {lvl} d X")
+        U.assert_close(gw, ref_gw, 1e-12, f"level {lvl} d W")
+    assert seen == ({(1, 6), (2, 6), (2, 4)} if decoder else {(1, 4), (2, 8)}), seen

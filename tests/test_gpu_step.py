@@ -229,3 +229,27 @@ def test_module_api_training_loop_matches_native_step():
         lr, _ = ref.step(batch)
         U.assert_close(loss, lr, 1e-10, f"loss at step {it}")
     U.assert_close(torch.cat([enc.flat_params.detach(), dec.flat_params.detach()]), ref.flat.flat, 1e-9, "parameters after 3 steps")
+
+
+@pytest.mark.parametrize("N", [13, 32])
+def test_native_step_maxdim3_other_shapes_match_per_op_path(N):
+    """Table-driven native step at shapes the golden fixture does not have -- channel counts 2..8 (every padded output width of
+    the compile-time-table kernels, both level kinds), jets of 13 and of 32 particles (tiles of 64 nodes cut jets at other
+    places, the last tile partly empty), zero-padded jets -- against the per-operator module path (each operator oracle-tested
+    on its own in test_gpu_parity.py) on the same weights."""
+    import __graft_entry__ as G
+    from lgn.step import NativeTrainStep, TrainStep
+    from oracle import lgn_oracle as O
+    dev = torch.device("cuda:0")
+    enc, dec = G._models(N, (2, 4, 7, 8), (8, 6, 5, 3), dev, seed=5, maxdim=3)
+    enc2, dec2 = G._models(N, (2, 4, 7, 8), (8, 6, 5, 3), dev, seed=5, maxdim=3)
+    enc2.use_fused = dec2.use_fused = False
+    p4, labels = O.synthetic_jets(5, N, seed=4, pad=True)
+    batch = {"p4": p4.to(dev), "labels": labels.to(dev)}
+    a = NativeTrainStep(enc, dec, batch_size=5, optimizer=False, use_graph=False)
+    b = TrainStep(enc2, dec2, optimizer=False)
+    la, ra = a.step(batch)
+    lb, rb = b.forward_backward(batch)
+    U.assert_close(la, lb, 1e-11, "loss")
+    U.assert_close(ra, rb, 1e-11, "recon")
+    U.assert_close(a.flat.grad, b.flat.grad, 1e-9, "flat gradient")
