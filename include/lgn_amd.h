@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LGN_AMD_ABI_VERSION 7   /* bump on ANY struct or signature change (lgn/_native.py: ABI_VERSION) */
+#define LGN_AMD_ABI_VERSION 8   /* bump on ANY struct or signature change (lgn/_native.py: ABI_VERSION) */
 
 int lgn_abi_version(void);
 const char* lgn_last_error(void);
@@ -93,8 +93,10 @@ int lgn_radial_finalize_f64(const double* tot, int C, const double* ra, const do
  * after all but the last.  w / b: host arrays of nlin device pointers. */
 int lgn_cgmlp_fwd_f64(int M, int C, int H, int nlin, const double* const* w, const double* const* b,
                       const double* s_in, double* s_out, void* stream);
-int lgn_cgmlp_partial_rows(int M);
-/* part [rows][psize], psize = sum_l (out_l*in_l + out_l), layout concat_l (W_l, b_l). */
+/* rows of the partial weight-gradient buffer for M rows at hidden width H: one per workgroup of the backward (64 rows; 16 rows
+ * for H <= 48 when M is small enough that 64-row workgroups would leave most CUs idle). */
+int lgn_cgmlp_partial_rows(int M, int H);
+/* part [lgn_cgmlp_partial_rows(M, H)][psize], psize = sum_l (out_l*in_l + out_l), layout concat_l (W_l, b_l). */
 int lgn_cgmlp_bwd_f64(int M, int C, int H, int nlin, const double* const* w, const double* const* b,
                       const double* s_in, const double* g_out, double* g_in, double* part, int psize, void* stream);
 

@@ -69,7 +69,7 @@ int lgn_cgmlp_fwd_f64(int M, int C, int H, int nlin, const double* const* w, con
   return mlp_dispatch<double>(a, false, (hipStream_t)stream);
 }
 
-int lgn_cgmlp_partial_rows(int M) { return (M + 63) / 64; }
+int lgn_cgmlp_partial_rows(int M, int H) { return mlp_partial_rows(M, H); }
 
 int lgn_cgmlp_bwd_f64(int M, int C, int H, int nlin, const double* const* w, const double* const* b, const double* s_in,
                       const double* g_out, double* g_in, double* part, int psize, void* stream) {

@@ -33,7 +33,10 @@ __host__ __device__ constexpr int pad4(int x) { return (x + 3) & ~3; }
 // smallest stride >= x with stride == 2 (mod 4): 16 rows x 2 k's of a ds_read_b64 group hit 32 distinct bank pairs
 __host__ __device__ constexpr int lds_stride(int x) { return x + ((6 - (x & 3)) & 3); }
 
-template <int NT>
+// MT = M-tiles (16 rows each) per workgroup: 4 (64 rows) in general; 1 when the batch has too few rows to give every CU a
+// 64-row workgroup (mlp_rows_per_workgroup): 4x the workgroups, each with a quarter of the MFMAs per layer -- at 64 jets the
+// layer time is the matrix-pipe time of ONE CU's 64 rows while 200 CUs idle.
+template <int NT, int MT = 4>
 struct Geo {
   static constexpr int HP = NT * 16;                  // padded hidden width
   static constexpr int S = lds_stride(HP);            // row stride of weight image and activation tiles
@@ -41,9 +44,12 @@ struct Geo {
   static constexpr int WSIZE = HP * S;                // one weight image
   static constexpr int TSIZE = 16 * S;                // one 16-row activation tile
   static constexpr int T0SIZE = 16 * S0;              // one 16-row input tile
-  static constexpr int THREADS = 256 * NT;            // 4 M-tiles x NT N-tiles waves
-  static constexpr size_t fwd_doubles() { return 2 * WSIZE + 8 * TSIZE + 4 * T0SIZE; }
-  static constexpr size_t bwd_doubles() { return 2 * WSIZE + 16 * TSIZE + 4 * T0SIZE + 8 * HP; }
+  static constexpr int THREADS = 64 * MT * NT;        // MT M-tiles x NT N-tiles waves
+  static constexpr int NPH = 4 * NT / MT;             // staging passes of a hidden-layer image (4 MT rows per pass)
+  static constexpr int NPF = 4 / MT;                  // staging passes of the first-layer image (4 MT NT rows per pass)
+  static_assert(MT == 1 || MT == 2 || MT == 4, "M-tiles per workgroup");
+  static constexpr size_t fwd_doubles() { return 2 * WSIZE + 2 * MT * TSIZE + MT * T0SIZE; }
+  static constexpr size_t bwd_doubles() { return 2 * WSIZE + 4 * MT * TSIZE + MT * T0SIZE + 2 * MT * HP; }
 };
 
 // ---- weight staging ------------------------------------------------------------------------------
@@ -51,47 +57,52 @@ struct Geo {
 // feeds the MFMAs zeros, padded neurons produce exact zeros) and its bias at Wl[o*S + HP] (S >= HP + 2).
 // Hidden / output layers (HP input columns): thread tid stages column k = tid % HP of rows tid / HP + 16 i, so every
 // address is a thread-constant base plus a compile-time (LDS) or wave-uniform (global) multiple of i.
-template <int NT>
+template <int NT, int MT>
 __device__ __forceinline__ void prefetch_hidden(const double* __restrict__ W, const double* __restrict__ bias, int Hout,
-                                                int Hin, double (&regs)[NT], double& breg) {
-  constexpr int HP = Geo<NT>::HP;
+                                                int Hin, double (&regs)[Geo<NT, MT>::NPH], double& breg) {
+  constexpr int HP = Geo<NT, MT>::HP, RPP = 4 * MT;
   const int o0 = (int)threadIdx.x / HP, k = (int)threadIdx.x - o0 * HP;
   const double* src = W + (o0 * Hin + k);
 #pragma unroll
-  for (int i = 0; i < NT; ++i) regs[i] = (k < Hin && o0 + 16 * i < Hout) ? src[16 * i * Hin] : 0.0;
+  for (int i = 0; i < Geo<NT, MT>::NPH; ++i) regs[i] = (k < Hin && o0 + RPP * i < Hout) ? src[RPP * i * Hin] : 0.0;
   breg = ((int)threadIdx.x < Hout) ? bias[threadIdx.x] : 0.0;
 }
-template <int NT>
-__device__ __forceinline__ void commit_hidden(double* Wl, const double (&regs)[NT], double breg) {
-  constexpr int HP = Geo<NT>::HP, S = Geo<NT>::S;
+template <int NT, int MT>
+__device__ __forceinline__ void commit_hidden(double* Wl, const double (&regs)[Geo<NT, MT>::NPH], double breg) {
+  constexpr int HP = Geo<NT, MT>::HP, S = Geo<NT, MT>::S, RPP = 4 * MT;
   const int o0 = (int)threadIdx.x / HP, k = (int)threadIdx.x - o0 * HP;
   double* dst = Wl + (o0 * S + k);
 #pragma unroll
-  for (int i = 0; i < NT; ++i) dst[16 * i * S] = regs[i];
+  for (int i = 0; i < Geo<NT, MT>::NPH; ++i) dst[RPP * i * S] = regs[i];
   if ((int)threadIdx.x < HP) Wl[threadIdx.x * S + HP] = breg;
 }
-// First layer (2C <= 16 input columns): one element per thread, o = tid / 16 < HP.
-template <int NT>
+// First layer (2C <= 16 input columns): thread -> column tid % 16 of rows tid / 16 + 4 MT NT i.
+template <int NT, int MT>
 __device__ __forceinline__ void prefetch_first(const double* __restrict__ W, const double* __restrict__ bias, int Hout,
-                                               int Hin, double& reg, double& breg) {
-  const int o = (int)threadIdx.x >> 4, k = (int)threadIdx.x & 15;
-  reg = (o < Hout && k < Hin) ? W[o * Hin + k] : 0.0;
+                                               int Hin, double (&regs)[Geo<NT, MT>::NPH], double& breg) {
+  const int o0 = (int)threadIdx.x >> 4, k = (int)threadIdx.x & 15;
+#pragma unroll
+  for (int i = 0; i < Geo<NT, MT>::NPF; ++i) {
+    const int o = o0 + 4 * MT * NT * i;
+    regs[i] = (o < Hout && k < Hin) ? W[o * Hin + k] : 0.0;
+  }
   breg = ((int)threadIdx.x < Hout) ? bias[threadIdx.x] : 0.0;
 }
-template <int NT>
-__device__ __forceinline__ void commit_first(double* Wl, double reg, double breg) {
-  constexpr int HP = Geo<NT>::HP, S = Geo<NT>::S;
-  Wl[((int)threadIdx.x >> 4) * S + ((int)threadIdx.x & 15)] = reg;
+template <int NT, int MT>
+__device__ __forceinline__ void commit_first(double* Wl, const double (&regs)[Geo<NT, MT>::NPH], double breg) {
+  constexpr int HP = Geo<NT, MT>::HP, S = Geo<NT, MT>::S;
+#pragma unroll
+  for (int i = 0; i < Geo<NT, MT>::NPF; ++i) Wl[(((int)threadIdx.x >> 4) + 4 * MT * NT * i) * S + ((int)threadIdx.x & 15)] = regs[i];
   if ((int)threadIdx.x < HP) Wl[threadIdx.x * S + HP] = breg;
 }
 
 // rows of the scalar irrep [2][M][C] -> the workgroup's 4 input tiles, feature k = 2c + z, zero padded to 16 columns
-template <int NT>
+template <int NT, int MT>
 __device__ __forceinline__ void load_input_tiles(const double* __restrict__ s, int M, int C, int wg_row0, double* X0) {
   const int D = 2 * C;
-  for (int e = threadIdx.x; e < 64 * 16; e += Geo<NT>::THREADS) {
+  for (int e = threadIdx.x; e < 16 * MT * 16; e += Geo<NT, MT>::THREADS) {
     const int r = e >> 4, k = e & 15, row = wg_row0 + r;
-    X0[(r >> 4) * Geo<NT>::T0SIZE + (r & 15) * Geo<NT>::S0 + k] =
+    X0[(r >> 4) * Geo<NT, MT>::T0SIZE + (r & 15) * Geo<NT, MT>::S0 + k] =
         (row < M && k < D) ? s[(size_t)(k & 1) * M * C + (size_t)row * C + (k >> 1)] : 0.0;
   }
 }
@@ -121,51 +132,52 @@ __device__ __forceinline__ void mma_transposed(const double* ga, const double* w
 // One forward layer for this wave's tile (shared by the forward kernel and the backward's recompute).
 //   l == 0 reads the input tiles (K = 16), hidden layers the activation buffer of parity l&1; writes LeakyReLU(pre)
 //   into the buffer of parity (l+1)&1 when `store`.
-template <int NT, int KSH>
+template <int NT, int KSH, int MT>
 __device__ __forceinline__ v4d forward_layer(int l, const double* Wcur, const double* X0, double* Xb, int mt, int nt, int lane,
                                              int ksh, bool store) {
-  using G = Geo<NT>;
+  using G = Geo<NT, MT>;
   constexpr int S = G::S;
   const int c = lane & 15, g = lane >> 4;
   const double bias = Wcur[(16 * nt + c) * S + G::HP];
   v4d acc = v4d{bias, bias, bias, bias};
   const double* wb = Wcur + (16 * nt + c) * S + g;
   if (l == 0) mma_rowmajor<4>(X0 + mt * G::T0SIZE + c * G::S0 + g, wb, 4, acc);
-  else mma_rowmajor<KSH>(Xb + ((l & 1) * 4 + mt) * G::TSIZE + c * S + g, wb, ksh, acc);
+  else mma_rowmajor<KSH>(Xb + ((l & 1) * MT + mt) * G::TSIZE + c * S + g, wb, ksh, acc);
 #pragma unroll
   for (int r = 0; r < 4; ++r) acc[r] = leaky(acc[r]);
   if (store) {
-    double* Xn = Xb + (((l + 1) & 1) * 4 + mt) * G::TSIZE + g * S + 16 * nt + c;
+    double* Xn = Xb + (((l + 1) & 1) * MT + mt) * G::TSIZE + g * S + 16 * nt + c;
 #pragma unroll
     for (int r = 0; r < 4; ++r) Xn[4 * r * S] = acc[r];
   }
   return acc;
 }
 
-template <int NT, int NH, int KSH>
-__global__ __launch_bounds__(256 * NT) void mlp_fwd_mfma_kernel(MlpArgs<double> a) {
-  using G = Geo<NT>;
+template <int NT, int NH, int KSH, int MT>
+__global__ __launch_bounds__(64 * MT * NT) void mlp_fwd_mfma_kernel(MlpArgs<double> a) {
+  using G = Geo<NT, MT>;
   constexpr int S = G::S;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int mt = wave & 3, nt = wave >> 2;
+  const int mt = wave % MT, nt = wave / MT;
   const int D = 2 * a.C, H = a.H, M = a.M;
   const int ksh = pad4(H) >> 2;
+  const int wg_row0 = blockIdx.x * 16 * MT;
   extern __shared__ __align__(16) unsigned char smem_raw[];
   double* Wl = reinterpret_cast<double*>(smem_raw);          // 2 weight images
-  double* Xb = Wl + 2 * G::WSIZE;                            // 2 x 4 activation tiles
-  double* X0 = Xb + 8 * G::TSIZE;                            // 4 input tiles
+  double* Xb = Wl + 2 * G::WSIZE;                            // 2 x MT activation tiles
+  double* X0 = Xb + 2 * MT * G::TSIZE;                       // MT input tiles
 
-  double regs[NT], breg;
-  prefetch_first<NT>(a.w[0], a.b[0], H, D, regs[0], breg);
-  load_input_tiles<NT>(a.s_in, M, a.C, blockIdx.x * 64, X0);
-  commit_first<NT>(Wl, regs[0], breg);
+  double regs[G::NPH], breg;
+  prefetch_first<NT, MT>(a.w[0], a.b[0], H, D, regs, breg);
+  load_input_tiles<NT, MT>(a.s_in, M, a.C, wg_row0, X0);
+  commit_first<NT, MT>(Wl, regs, breg);
   __syncthreads();
 #pragma unroll
   for (int l = 0; l < NH; ++l) {
     const double* Wcur = Wl + (l & 1) * G::WSIZE;
-    prefetch_hidden<NT>(a.w[l + 1], a.b[l + 1], l + 1 == NH ? D : H, H, regs, breg);
-    forward_layer<NT, KSH>(l, Wcur, X0, Xb, mt, nt, lane, ksh, true);
-    commit_hidden<NT>(Wl + ((l + 1) & 1) * G::WSIZE, regs, breg);
+    prefetch_hidden<NT, MT>(a.w[l + 1], a.b[l + 1], l + 1 == NH ? D : H, H, regs, breg);
+    forward_layer<NT, KSH, MT>(l, Wcur, X0, Xb, mt, nt, lane, ksh, true);
+    commit_hidden<NT, MT>(Wl + ((l + 1) & 1) * G::WSIZE, regs, breg);
     __syncthreads();
   }
   if (nt == 0) {                                             // output layer: one N-tile (2C <= 16 neurons), no activation
@@ -173,46 +185,47 @@ __global__ __launch_bounds__(256 * NT) void mlp_fwd_mfma_kernel(MlpArgs<double> 
     const double* Wcur = Wl + (NH & 1) * G::WSIZE;
     const double bias = Wcur[c * S + G::HP];
     v4d acc = v4d{bias, bias, bias, bias};
-    mma_rowmajor<KSH>(Xb + ((NH & 1) * 4 + mt) * G::TSIZE + c * S + g, Wcur + c * S + g, ksh, acc);
+    mma_rowmajor<KSH>(Xb + ((NH & 1) * MT + mt) * G::TSIZE + c * S + g, Wcur + c * S + g, ksh, acc);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int row = blockIdx.x * 64 + mt * 16 + g + 4 * r;
+      const int row = wg_row0 + mt * 16 + g + 4 * r;
       if (c < D && row < M) a.s_out[mlp_out_index(a, c & 1, row, c >> 1)] = acc[r];
     }
   }
 }
 
-template <int NT, int NH, int KSH>
-__global__ __launch_bounds__(256 * NT) void mlp_bwd_mfma_kernel(MlpArgs<double> a) {
-  using G = Geo<NT>;
-  constexpr int S = G::S, HP = G::HP;
+template <int NT, int NH, int KSH, int MT>
+__global__ __launch_bounds__(64 * MT * NT) void mlp_bwd_mfma_kernel(MlpArgs<double> a) {
+  using G = Geo<NT, MT>;
+  constexpr int S = G::S, HP = G::HP, NW = MT * NT;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int mt = wave & 3, nt = wave >> 2;
+  const int mt = wave % MT, nt = wave / MT;
   const int c = lane & 15, g = lane >> 4;
   const int D = 2 * a.C, H = a.H, M = a.M;
   const int ksh = pad4(H) >> 2;
+  const int wg_row0 = blockIdx.x * 16 * MT;
   extern __shared__ __align__(16) unsigned char smem_raw[];
   double* Wl = reinterpret_cast<double*>(smem_raw);          // 2 weight images
-  double* Xb = Wl + 2 * G::WSIZE;                            // 2 x 4 layer-input tiles
-  double* Gb = Xb + 8 * G::TSIZE;                            // 2 x 4 g_pre tiles
-  double* X0 = Gb + 8 * G::TSIZE;                            // 4 MLP input tiles
-  double* dbw = X0 + 4 * G::T0SIZE;                          // 2 x 4 x HP column sums
+  double* Xb = Wl + 2 * G::WSIZE;                            // 2 x MT layer-input tiles
+  double* Gb = Xb + 2 * MT * G::TSIZE;                       // 2 x MT g_pre tiles
+  double* X0 = Gb + 2 * MT * G::TSIZE;                       // MT MLP input tiles
+  double* dbw = X0 + MT * G::T0SIZE;                         // 2 x MT x HP column sums
   double* part = a.part + (size_t)blockIdx.x * a.psize;
 
   // ---- forward recompute; h[l] = post-activation of hidden layer l, this wave's tile, D layout ---------
-  double regs[NT], breg;
-  prefetch_first<NT>(a.w[0], a.b[0], H, D, regs[0], breg);
-  load_input_tiles<NT>(a.s_in, M, a.C, blockIdx.x * 64, X0);
-  commit_first<NT>(Wl, regs[0], breg);
+  double regs[G::NPH], breg;
+  prefetch_first<NT, MT>(a.w[0], a.b[0], H, D, regs, breg);
+  load_input_tiles<NT, MT>(a.s_in, M, a.C, wg_row0, X0);
+  commit_first<NT, MT>(Wl, regs, breg);
   __syncthreads();
   v4d h[NH];
 #pragma unroll
   for (int l = 0; l < NH; ++l) {
     const double* Wcur = Wl + (l & 1) * G::WSIZE;
     // the weights of the next forward layer; after the last hidden layer: the output layer (first backward layer)
-    prefetch_hidden<NT>(a.w[l + 1], a.b[l + 1], l + 1 == NH ? D : H, H, regs, breg);
-    h[l] = forward_layer<NT, KSH>(l, Wcur, X0, Xb, mt, nt, lane, ksh, l + 1 < NH);
-    commit_hidden<NT>(Wl + ((l + 1) & 1) * G::WSIZE, regs, breg);
+    prefetch_hidden<NT, MT>(a.w[l + 1], a.b[l + 1], l + 1 == NH ? D : H, H, regs, breg);
+    h[l] = forward_layer<NT, KSH, MT>(l, Wcur, X0, Xb, mt, nt, lane, ksh, l + 1 < NH);
+    commit_hidden<NT, MT>(Wl + ((l + 1) & 1) * G::WSIZE, regs, breg);
     __syncthreads();
   }
 
@@ -221,7 +234,7 @@ __global__ __launch_bounds__(256 * NT) void mlp_bwd_mfma_kernel(MlpArgs<double> 
   if (nt == 0) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int row = blockIdx.x * 64 + mt * 16 + g + 4 * r;
+      const int row = wg_row0 + mt * 16 + g + 4 * r;
       gpre[r] = (c < D && row < M) ? a.g_out[mlp_out_index(a, c & 1, row, c >> 1)] : 0.0;
     }
   }
@@ -234,12 +247,12 @@ __global__ __launch_bounds__(256 * NT) void mlp_bwd_mfma_kernel(MlpArgs<double> 
     double* pW = part + poff_end;
     double* pB = pW + Hout * Hin;
     const double* Wcur = Wl + (l & 1) * G::WSIZE;            // image of W_l (staged by the previous iteration)
-    if (l == 1) prefetch_first<NT>(a.w[0], a.b[0], H, D, regs[0], breg);
-    else if (l > 1) prefetch_hidden<NT>(a.w[l - 1], a.b[l - 1], H, H, regs, breg);
+    if (l == 1) prefetch_first<NT, MT>(a.w[0], a.b[0], H, D, regs, breg);
+    else if (l > 1) prefetch_hidden<NT, MT>(a.w[l - 1], a.b[l - 1], H, H, regs, breg);
 
     // operands of this layer to LDS: g_pre tile and layer-input tile (h[l-1]; the MLP input tiles serve l == 0)
-    double* Gq = Gb + q * 4 * G::TSIZE;
-    double* Xq = Xb + q * 4 * G::TSIZE;
+    double* Gq = Gb + q * MT * G::TSIZE;
+    double* Xq = Xb + q * MT * G::TSIZE;
     {
       double* gt = Gq + mt * G::TSIZE + g * S + 16 * nt + c;
 #pragma unroll
@@ -253,7 +266,7 @@ __global__ __launch_bounds__(256 * NT) void mlp_bwd_mfma_kernel(MlpArgs<double> 
       double v = (gpre[0] + gpre[1]) + (gpre[2] + gpre[3]);
       v += shfl_xor(v, 16);
       v += shfl_xor(v, 32);
-      if (g == 0) dbw[(q * 4 + mt) * HP + 16 * nt + c] = v;
+      if (g == 0) dbw[(q * MT + mt) * HP + 16 * nt + c] = v;
     }
     __syncthreads();
 
@@ -265,23 +278,32 @@ __global__ __launch_bounds__(256 * NT) void mlp_bwd_mfma_kernel(MlpArgs<double> 
       if (l == NH) mma_transposed<4, S>(ga, wb, 4, gin);     // K = 2C <= 16 output neurons
       else mma_transposed<KSH, S>(ga, wb, ksh, gin);
     }
-    // (b) dW tile number `wave` over the workgroup's 64 rows, two accumulation chains (row blocks {0,1}, {2,3})
+    // (b) dW tiles over the workgroup's 16 MT rows, dealt round robin to the waves (MT = 4: 9 tiles on 12 waves, one each);
+    //     two accumulation chains over the row blocks
     {
       const int nti = l == 0 ? 1 : NT, ntiles = (l == NH ? 1 : NT) * nti;
-      if (wave < ntiles) {
-        const int t = wave / nti, u = wave - t * nti;
+      for (int tile = wave; tile < ntiles; tile += NW) {
+        const int t = tile / nti, u = tile - t * nti;
         const double* ga = Gq + g * S + 16 * t + c;
         const double* xb = l == 0 ? X0 + g * G::S0 + c : Xq + g * S + 16 * u + c;
         const int xts = l == 0 ? G::T0SIZE : G::TSIZE, xss = l == 0 ? G::S0 : S;
         v4d acc0 = v4d{0, 0, 0, 0}, acc1 = v4d{0, 0, 0, 0};
+        if (MT >= 2) {
 #pragma unroll
-        for (int w = 0; w < 2; ++w)
+          for (int w = 0; w < MT / 2; ++w)
 #pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ga[w * G::TSIZE + 4 * s * S], xb[w * xts + 4 * s * xss], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ga[(w + 2) * G::TSIZE + 4 * s * S], xb[(w + 2) * xts + 4 * s * xss], acc1, 0,
-                                                        0, 0);
+            for (int s = 0; s < 4; ++s) {
+              acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ga[w * G::TSIZE + 4 * s * S], xb[w * xts + 4 * s * xss], acc0, 0, 0, 0);
+              acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ga[(w + MT / 2) * G::TSIZE + 4 * s * S], xb[(w + MT / 2) * xts + 4 * s * xss],
+                                                          acc1, 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ga[4 * s * S], xb[4 * s * xss], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ga[4 * (s + 2) * S], xb[4 * (s + 2) * xss], acc1, 0, 0, 0);
           }
+        }
         const int k = 16 * u + c;                            // D[i = o][j = k]
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -289,38 +311,48 @@ __global__ __launch_bounds__(256 * NT) void mlp_bwd_mfma_kernel(MlpArgs<double> 
           if (o < Hout && k < Hin) pW[o * Hin + k] = acc0[r] + acc1[r];
         }
       }
-      const double* dq = dbw + q * 4 * HP;
-      if (tid < Hout) pB[tid] = (dq[tid] + dq[HP + tid]) + (dq[2 * HP + tid] + dq[3 * HP + tid]);
+      const double* dq = dbw + q * MT * HP;
+      if (tid < Hout) {
+        double v = dq[tid];
+#pragma unroll
+        for (int w = 1; w < MT; ++w) v += dq[w * HP + tid];
+        pB[tid] = v;
+      }
     }
     // next layer down
     if (l > 0) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) gpre[r] = gin[r] * (h[l > 0 ? l - 1 : 0][r] > 0.0 ? 1.0 : 0.01);
       // W_{l-1} goes into the image buffer last read two layers up; every wave is past that layer's barrier
-      if (l == 1) commit_first<NT>(Wl, regs[0], breg);
-      else commit_hidden<NT>(Wl + ((l - 1) & 1) * G::WSIZE, regs, breg);
+      if (l == 1) commit_first<NT, MT>(Wl, regs, breg);
+      else commit_hidden<NT, MT>(Wl + ((l - 1) & 1) * G::WSIZE, regs, breg);
     } else if (nt == 0) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = blockIdx.x * 64 + mt * 16 + g + 4 * r;
+        const int row = wg_row0 + mt * 16 + g + 4 * r;
         if (c < D && row < M) a.g_in[mlp_out_index(a, c & 1, row, c >> 1)] = gin[r];
       }
     }
   }
 }
 
-template <int NT, int KSH>
-static int launch_mlp_mfma(const MlpArgs<double>& a, bool backward, hipStream_t stream) {
-  using G = Geo<NT>;
+template <int NT, int KSH, int MT>
+static int launch_mlp_mfma_mt(const MlpArgs<double>& a, bool backward, hipStream_t stream) {
+  using G = Geo<NT, MT>;
   constexpr int NH = 6;
-  const int nblk = cdiv(a.M, 64);
+  const int nblk = cdiv(a.M, 16 * MT);
   const size_t smem = sizeof(double) * (backward ? G::bwd_doubles() : G::fwd_doubles());
   static_assert(sizeof(double) * G::bwd_doubles() <= 160 * 1024, "LDS budget");
-  auto kern = backward ? mlp_bwd_mfma_kernel<NT, NH, KSH> : mlp_fwd_mfma_kernel<NT, NH, KSH>;
+  auto kern = backward ? mlp_bwd_mfma_kernel<NT, NH, KSH, MT> : mlp_fwd_mfma_kernel<NT, NH, KSH, MT>;
   if (smem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   hipLaunchKernelGGL(kern, dim3(nblk), dim3(G::THREADS), smem, stream, a);
   LGN_CHECK_LAUNCH();
   return 0;
+}
+template <int NT, int KSH>
+static int launch_mlp_mfma(const MlpArgs<double>& a, bool backward, hipStream_t stream) {
+  return mlp_rows_per_workgroup(a.M, a.H) == 16 ? launch_mlp_mfma_mt<NT, KSH, 1>(a, backward, stream)
+                                                 : launch_mlp_mfma_mt<NT, KSH, 4>(a, backward, stream);
 }
 
 // H <= 48, 2C <= 16, 7 Linear layers.  Returns -2 if the shape is outside this kernel's range.

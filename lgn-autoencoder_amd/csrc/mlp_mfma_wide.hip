@@ -4,7 +4,7 @@
 //   * NT = 4..6 N-tiles: a weight image is 34..75 KB, so it is single buffered and a layer costs two barriers
 //     (operands visible / all reads done) instead of one; the tiles need no ping-pong then either;
 //   * a workgroup runs 2 M-tiles x NT N-tiles = 8..12 waves (one 16x16 output tile per wave);
-//   * the backward keeps the 64-rows-per-partial-row contract of lgn_cgmlp_partial_rows by making two 32-row passes per
+//   * the backward keeps the 64-rows-per-partial-row contract of lgn_cgmlp_partial_rows (H > 48) by making two 32-row passes per
 //     workgroup, the second pass adding into the partial row the first one wrote.
 #include "ops.hpp"
 

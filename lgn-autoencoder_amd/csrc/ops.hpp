@@ -63,7 +63,10 @@ __host__ __device__ inline size_t mlp_out_index(const MlpArgs<T>& a, int z, int 
 template <typename T> int mlp_dispatch(const MlpArgs<T>&, bool backward, hipStream_t);
 int mlp_mfma_dispatch(const MlpArgs<double>&, bool backward, hipStream_t);
 int mlp_mfma_wide_dispatch(const MlpArgs<double>&, bool backward, hipStream_t);   // 48 < H <= 96 (mlp_mfma_wide.hip)
-inline int mlp_partial_rows(int M) { return (M + 63) / 64; }
+// rows a CGMLP workgroup (= a partial row of its weight gradients) covers: 64, or 16 for H <= 48 when the batch would give
+// fewer than 128 64-row workgroups (small batches: more, shorter workgroups; mlp_mfma.hip)
+inline int mlp_rows_per_workgroup(int M, int H) { return (H <= 48 && (M + 63) / 64 < 128) ? 16 : 64; }
+inline int mlp_partial_rows(int M, int H) { const int r = mlp_rows_per_workgroup(M, H); return (M + r - 1) / r; }
 
 // ---- MixReps (mixreps.hip) -----------------------------------------------------------------------------
 template <typename T>

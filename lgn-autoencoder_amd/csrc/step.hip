@@ -120,7 +120,7 @@ Work carve(const lgn_net_desc& d, double* base) {
       level_bwd_partial_rows(d.B, d.N, dec, &rm, &rr);
       const size_t nmix = (size_t)4 * ch[l + 1] * 5 * ch[l], nrad = rad_partial_size(ch[l], dec != 0);
       psum += ((rm * nmix + 15) & ~size_t(15)) + ((rr * nrad + 15) & ~size_t(15));
-      psum += ((size_t)mlp_partial_rows((int)BN) * mlp_psize(ch[l + 1], d.mlp_hidden_mul * 2 * ch[l + 1], d.mlp_nlin) + 15) & ~size_t(15);
+      psum += ((size_t)mlp_partial_rows((int)BN, d.mlp_hidden_mul * 2 * ch[l + 1]) * mlp_psize(ch[l + 1], d.mlp_hidden_mul * 2 * ch[l + 1], d.mlp_nlin) + 15) & ~size_t(15);
       w.tot[dec][l] = b.take(nrad + 16);
     }
   }
@@ -187,10 +187,10 @@ int levels_bwd(const lgn_net_desc& d, bool dec, const int* ch, const double* P, 
       for (int q = 0; q < d.mlp_nlin; ++q) { m.w[q] = p(S.mlp(dec, l, 2 * q)); m.b[q] = p(S.mlp(dec, l, 2 * q + 1)); }
       m.s_in = n.smix[l]; m.g_out = w.gs[cur]; m.g_in = w.gsmix;
       m.psize = mlp_psize(CO, m.H, m.nlin);
-      m.part = dq.take((size_t)mlp_partial_rows(BN) * m.psize);
+      m.part = dq.take((size_t)mlp_partial_rows(BN, m.H) * m.psize);
       LGN_TRY(mlp_dispatch<double>(m, true, st));
       // the MLP's parameters are contiguous in the flat buffer in (W_0, b_0, W_1, ...) order (checked at plan time)
-      dq.add(m.part, mlp_partial_rows(BN), m.psize, 0, m.psize, g(S.mlp(dec, l, 0)));
+      dq.add(m.part, mlp_partial_rows(BN, m.H), m.psize, 0, m.psize, g(S.mlp(dec, l, 0)));
       g_smix = w.gsmix;
     }
     int rm, rr;
@@ -394,7 +394,7 @@ GenScratch carve_gen_scratch(const lgn_net_desc& d, bool dec, double* base) {
     const size_t lrows = tb ? tiles * local_static_packed_doubles(g.tab[l]->static_kind, g.ch[l], g.ch[l + 1])
                             : (size_t)local_partial_rows((int)BN) * 2 * g.tab[l]->n_w;
     psum += ((lrows + 15) & ~size_t(15)) + (((size_t)d.B * nrad + 15) & ~size_t(15));
-    psum += ((size_t)mlp_partial_rows((int)BN) * mlp_psize(g.ch[l + 1], d.mlp_hidden_mul * 2 * g.ch[l + 1], d.mlp_nlin) + 15) & ~size_t(15);
+    psum += ((size_t)mlp_partial_rows((int)BN, d.mlp_hidden_mul * 2 * g.ch[l + 1]) * mlp_psize(g.ch[l + 1], d.mlp_hidden_mul * 2 * g.ch[l + 1], d.mlp_nlin) + 15) & ~size_t(15);
     s.tot[l] = b.take(nrad + 16);
   }
   const int Tin = d.tau_v_in > 0 ? d.tau_v_in : 2 * d.tau_v;
@@ -485,9 +485,9 @@ int gen_levels_bwd(const lgn_net_desc& d, bool dec, const double* P, double* G, 
       if (tb) { m.g_out = sc.gX[cur] + (size_t)g.qs[l + 1] * 128; m.g_in = sc.gX[cur] + (size_t)g.qs[l + 1] * 128; m.tbQ = g.Q[l + 1]; }
       else { m.g_out = sc.gX[cur] + g.qs[l + 1]; m.g_in = sc.gX[cur] + g.qs[l + 1]; m.ld = g.Q[l + 1]; }
       m.psize = mlp_psize(CO, m.H, m.nlin);
-      m.part = dq.take((size_t)mlp_partial_rows(BN) * m.psize);
+      m.part = dq.take((size_t)mlp_partial_rows(BN, m.H) * m.psize);
       LGN_TRY(mlp_dispatch<double>(m, true, st));
-      dq.add(m.part, mlp_partial_rows(BN), m.psize, 0, m.psize, G + off[S.mlp(dec, l, 0)]);
+      dq.add(m.part, mlp_partial_rows(BN, m.H), m.psize, 0, m.psize, G + off[S.mlp(dec, l, 0)]);
     }
     const int nxt = cur ^ 1;
     if (tb) {       // compile-time-table kernel; its packed partial rows are reduced with everything else, then unpacked (post)
@@ -752,7 +752,7 @@ NetScratch carve_scratch(const lgn_net_desc& d, bool dec, double* base) {
     level_bwd_partial_rows(d.B, d.N, dec, &rm, &rr);
     const size_t nmix = (size_t)4 * ch[l + 1] * 5 * ch[l], nrad = rad_partial_size(ch[l], dec);
     psum += ((rm * nmix + 15) & ~size_t(15)) + ((rr * nrad + 15) & ~size_t(15));
-    psum += ((size_t)mlp_partial_rows((int)BN) * mlp_psize(ch[l + 1], d.mlp_hidden_mul * 2 * ch[l + 1], d.mlp_nlin) + 15) & ~size_t(15);
+    psum += ((size_t)mlp_partial_rows((int)BN, d.mlp_hidden_mul * 2 * ch[l + 1]) * mlp_psize(ch[l + 1], d.mlp_hidden_mul * 2 * ch[l + 1], d.mlp_nlin) + 15) & ~size_t(15);
     w.tot[dec ? 1 : 0][l] = b.take(nrad + 16);
   }
   // input / output ends: decoder  B x (2 C_L) + B x (4 C_0 + 2 N Tin);  encoder  B x 2 (Ts + Tv) C_L + B x 4 C_0

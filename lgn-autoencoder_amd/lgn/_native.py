@@ -15,7 +15,7 @@ import torch  # imported before the .so so that the process-wide libamdhip64 is 
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LGN_AMD_LIB") or os.path.join(_HERE, "_lib", "liblgn_amd.so")   # LGN_AMD_LIB: debug builds (tools/)
-ABI_VERSION = 7
+ABI_VERSION = 8
 FINALIZE_SCRATCH = 2048      # include/lgn_amd.h: LGN_FINALIZE_SCRATCH
 
 _lib: Optional[C.CDLL] = None
@@ -31,7 +31,7 @@ _SIGNATURES = {
     "lgn_reduce_partials_f64": [_vp, _i, _i, _vp, _i, _vp],
     "lgn_radial_finalize_f64": [_vp, _i] + [_vp] * 13,
     "lgn_cgmlp_fwd_f64": [_i] * 4 + [_vp] * 5,
-    "lgn_cgmlp_partial_rows": [_i],
+    "lgn_cgmlp_partial_rows": [_i, _i],
     "lgn_cgmlp_bwd_f64": [_i] * 4 + [_vp] * 6 + [_i, _vp],
     "lgn_mixreps_fwd_f64": [_i] * 4 + [_vp] * 4,
     "lgn_mixreps_partial_rows": [_i],
@@ -232,7 +232,7 @@ def cgmlp_bwd(s_in, ws, bs, g_out):
     _, B, N, Cc = s_in.shape
     H = ws[0].shape[0]
     L = lib()
-    rows = L.lgn_cgmlp_partial_rows(B * N)
+    rows = L.lgn_cgmlp_partial_rows(B * N, H)
     psize = sum(w.numel() + b.numel() for w, b in zip(ws, bs))
     part = torch.empty(rows, psize, device=s_in.device, dtype=s_in.dtype)
     g_in = torch.empty_like(s_in)

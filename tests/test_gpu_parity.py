@@ -179,7 +179,8 @@ def _level_case(dev, O, decoder, C, CO, N, B):
     U.assert_close(wm1.grad, P["lgn_cg.node_levels.0.cat_mix.mix_reps.weights.(1, 1)"].grad, GRAD_TOL, "g_wm1")
 
 
-@pytest.mark.parametrize("C,B,N", [(3, 2, 30), (4, 3, 30), (4, 1, 150), (2, 1, 5), (6, 1, 40), (6, 3, 37), (5, 2, 30), (8, 1, 70)])
+@pytest.mark.parametrize("C,B,N", [(3, 2, 30), (4, 3, 30), (4, 1, 150), (2, 1, 5), (6, 1, 40), (6, 3, 37), (5, 2, 30), (8, 1, 70),
+                                   (4, 300, 30), (3, 275, 30)])      # >= 8192 rows: 64-row workgroups (fewer rows: 16-row ones, H <= 48)
 def test_cgmlp(dev, O, C, B, N):
     from lgn import ops
     g = torch.Generator().manual_seed(C * 7 + N)
