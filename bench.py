@@ -331,8 +331,9 @@ def main():
                     pass
             fw = dom["forward"]
             out["roofline"] = {
-                "bound": "mfma", "pipe": "fp64 vector ALU (same peak as fp64 MFMA on MI355X; the kernel is "
-                                         "FMA-bound, neither HBM- nor matrix-core-bound)",
+                "bound": "mfma", "pipe": "fp64 datapath: v_fma_f64 and v_mfma_f64 share it on MI355X (measured, "
+                                         "csrc/probes/mfma_rate_probe.hip: an MFMA wave and an FMA wave on one SIMD take the SUM "
+                                         "of their times) -- one 78.6 TFLOP/s budget for the kernel's vector and matrix flops",
                 "kernel": dom["kernel"], "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic,
                 "traffic_note": "bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction; an ESTIMATE: the guide "
