@@ -9,8 +9,8 @@ template <typename T> int level_fwd_dispatch(const LevelArgs<T>&, int decoder, h
 template <typename T> int level_bwd_dispatch(const LevelBwdArgs<T>&, int decoder, hipStream_t);
 template <typename T> int reduce_partials(const T* part, int rows, int n, T* out, int accumulate, hipStream_t);
 template <typename T> int reduce_partials_strided(const T* part, int rows, int stride, int col0, int n, T* out, hipStream_t);
-// one launch reducing up to 8 column ranges:  seg.out[c] = sum_r seg.part[r*stride + col0 + c]
-constexpr int RED_MAX_SEG = 24;
+// one launch reducing up to RED_MAX_SEG column ranges (a whole cfg2 step has ~30):  seg.out[c] = sum_r seg.part[r*stride + col0 + c]
+constexpr int RED_MAX_SEG = 48;
 template <typename T> struct RedSeg { const T* part; int rows, stride, col0, n; T* out; };
 template <typename T> struct RedJob {
   int nseg;
