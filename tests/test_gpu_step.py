@@ -253,3 +253,20 @@ def test_native_step_maxdim3_other_shapes_match_per_op_path(N):
     U.assert_close(la, lb, 1e-11, "loss")
     U.assert_close(ra, rb, 1e-11, "recon")
     U.assert_close(a.flat.grad, b.flat.grad, 1e-9, "flat gradient")
+
+
+@pytest.mark.parametrize("maxdim,ch_enc,ch_dec", [(2, (3, 3, 4, 4), (4, 4, 3, 3)), (3, (4, 4, 6, 6), (6, 6, 4, 4))])
+def test_native_step_trains(maxdim, ch_enc, ch_dec):
+    """Sixty graph-replayed Adam steps on one synthetic batch: the loss must fall well below its starting value and stay finite
+    (the whole native step -- forward, Chamfer, backward, L1, Adam, device-side step counter -- as a training loop would run it)."""
+    import __graft_entry__ as G
+    from lgn.step import NativeTrainStep
+    from oracle import lgn_oracle as O
+    dev = torch.device("cuda:0")
+    enc, dec = G._models(30, ch_enc, ch_dec, dev, seed=0, maxdim=maxdim)
+    p4, labels = O.synthetic_jets(32, 30, seed=0, pad=True)
+    step = NativeTrainStep(enc, dec, batch_size=32, lr=5e-4, l1_lambda=1e-8, use_graph=True)
+    step.load_batch({"p4": p4.to(dev), "labels": labels.to(dev)})
+    losses = [float(step.step()[0]) for _ in range(60)]
+    assert all(l == l and l < float("inf") for l in losses), "non-finite loss"
+    assert losses[-1] < 0.75 * losses[0], f"loss did not fall: {losses[0]:.4f} -> {losses[-1]:.4f}"
