@@ -177,6 +177,18 @@ class CGModule(nn.Module):
                     v.copy_(state_dict[k])
         return _IncompatibleKeys(missing, unexpected)
 
+    def zero_grad(self, set_to_none: bool = True):
+        """nn.Module.zero_grad walks the whole module tree (~100 sub-modules, 0.1 ms of host time per call); every parameter
+        of the network lives in ``flat_params``, so this is all there is to clear."""
+        p = self._parameters.get("flat_params")
+        if p is None:
+            return super().zero_grad(set_to_none=set_to_none)
+        if p.grad is not None:
+            if set_to_none:
+                p.grad = None
+            else:
+                p.grad.detach_().zero_()
+
     def l1_norm(self) -> torch.Tensor:
         return ops.L1Fn.apply(self.flat_params)
 

@@ -143,8 +143,12 @@ class ReferenceLoopStep:
         chamfer = chamfer_loss(real, target)
         l1 = self.encoder.l1_norm() + self.decoder.l1_norm()
         loss = chamfer + (self.l1_lambda / self.world) * l1
-        for m in (self.encoder, self.decoder):
-            m.zero_grad(set_to_none=True)
+        if self.opt_enc is not None:         # utils/train.py:324-325
+            self.opt_enc.zero_grad()
+            self.opt_dec.zero_grad()
+        else:
+            self.encoder.zero_grad()
+            self.decoder.zero_grad()
         loss.backward()
         if self.world > 1:
             for m in (self.encoder, self.decoder):
