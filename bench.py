@@ -12,9 +12,15 @@ utils/train.py:280-343.  fp64 throughout (the reference's precision).
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Scaling modes: default = WEAK (every GPU processes the config's batch, 512 jets for cfg2: `value` = N x per-GPU rate);
-``--global-batch G`` = STRONG (G jets split over the N ranks -- BASELINE's cfg3 is ``--global-batch 512`` on 8 GPUs,
-64 jets per GPU).  The mode is named in ``scaling`` and in ``config.workload``.
+Launch: under ``torch.distributed.run`` (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment) each process is one
+rank; a plain ``python bench.py --gpus N`` with N > 1 and no WORLD_SIZE starts the N ranks ITSELF as fresh child processes
+(the parent never touches a GPU) and exits with their worst exit code.
+
+Scaling modes: default = STRONG -- BASELINE's metric is "bs=512 at 1/2/4/8 MI355X": the config's batch is the GLOBAL batch,
+split over the N ranks (cfg3 = cfg2 on 8 GPUs = 64 jets per GPU); `value` = global batch x steps / time.  With N > 1 the
+line also carries ``weak_scaling`` (the config's batch on EVERY GPU) as an extra object.  ``--weak`` / ``--batch B`` make the
+weak figure the primary one; ``--global-batch G`` picks another global batch.  The mode is named in ``scaling`` and in
+``config.workload``.  N = 1: both modes are the same run.
 
 Rank 0 prints ONE JSON line (contract in the task statement) with extra objects:
   roofline     -- dominant kernel (the fused level BACKWARD of the widest encoder level; its forward twin is reported
@@ -240,15 +246,75 @@ def _time_steps(trainer, batch, steps, warmup, world):
     return elapsed
 
 
+def _spawn_ranks(n, argv):
+    """``python bench.py --gpus N`` without a launcher: start N fresh rank processes of this script (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_ADDR / MASTER_PORT as torch.distributed.run would set them), rank 0 inherits stdout and prints the
+    JSON line.  The parent touches no GPU.  Returns the worst exit code; if a rank fails the others are terminated (by PID)."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    worst, live = 0, list(procs)
+    while live:
+        for p in list(live):
+            rc = p.poll()
+            if rc is None:
+                continue
+            live.remove(p)
+            if rc != 0:
+                worst = worst or rc
+                for q in live:              # a failed rank leaves the others waiting in a collective
+                    q.terminate()
+        time.sleep(0.05)
+    return worst
+
+
+def _dry_run(args, world, rank):
+    """LGN_BENCH_DRY=1 (CPU tests of the launch plumbing): gloo rendezvous, the same barrier / max-over-ranks timing
+    shape as the real run around a trivial CPU step, rank 0 prints the line marked ``"dry_run": true``."""
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    x = torch.ones(4, dtype=torch.float64) * (rank + 1)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        y = x.clone()
+        if world > 1:
+            dist.all_reduce(y, op=dist.ReduceOp.SUM)
+    if world > 1:
+        dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "steps": args.steps, "sum": float(y[0]),
+                          "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "elapsed": float(t.item())}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg2", help="BASELINE.json configuration (default cfg2)")
-    ap.add_argument("--batch", type=int, default=None, help="jets per GPU (weak scaling; default: the config's batch)")
+    ap.add_argument("--batch", type=int, default=None, help="jets per GPU (weak scaling)")
     ap.add_argument("--global-batch", type=int, default=None,
-                    help="total jets per step, split over the ranks (strong scaling; BASELINE cfg3 = --global-batch 512)")
+                    help="total jets per step, split over the ranks (strong scaling; default: the config's batch, so that "
+                         "--gpus 8 on cfg2 is BASELINE's cfg3)")
+    ap.add_argument("--weak", action="store_true", help="weak scaling as the primary figure: the config's batch on every GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the module_api and decoder_pairwise legs")
     ap.add_argument("--harness", choices=["native", "native-nograph", "module", "modular"], default=None,
@@ -257,25 +323,31 @@ def main():
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher: this process only starts the ranks (it never initialises a GPU) and passes their exit code on
+        raise SystemExit(_spawn_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node must equal --gpus")
+    if sum(x is not None for x in (args.batch, args.global_batch)) + int(args.weak) > 1:
+        raise SystemExit("--batch, --global-batch and --weak are exclusive")
+    if os.environ.get("LGN_BENCH_DRY") == "1":
+        return _dry_run(args, world, rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    if args.gpus != world:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    if args.global_batch is not None:
-        if args.batch is not None:
-            raise SystemExit("--batch and --global-batch are exclusive")
-        if args.global_batch % world:
-            raise SystemExit(f"--global-batch {args.global_batch} is not divisible by {world} ranks")
-        per_gpu, scaling = args.global_batch // world, "strong"
-    else:
+    if args.batch is not None or args.weak:
         per_gpu, scaling = (args.batch or cfg["B"]), "weak"
+    else:
+        gb = args.global_batch if args.global_batch is not None else cfg["B"]
+        if gb % world:
+            raise SystemExit(f"global batch {gb} is not divisible by {world} ranks")
+        per_gpu, scaling = gb // world, "strong"
     N = cfg["N"]
     harness = args.harness or "native"
     harness = "module" if harness == "modular" else harness
@@ -283,20 +355,35 @@ def main():
     import __graft_entry__ as G
     from lgn.step import NativeTrainStep, ReferenceLoopStep
 
-    def build(which):
+    def build(which, jets=None):
         enc, dec = G._models(N, cfg["ch_enc"], cfg["ch_dec"], dev, seed=0, maxdim=cfg["maxdim"])   # identical replicas on every rank
         if which == "module":
             return enc, ReferenceLoopStep(enc, dec, lr=5e-4, l1_lambda=1e-8)
-        return enc, NativeTrainStep(enc, dec, batch_size=per_gpu, lr=5e-4, l1_lambda=1e-8, use_graph=which == "native")
+        return enc, NativeTrainStep(enc, dec, batch_size=jets or per_gpu, lr=5e-4, l1_lambda=1e-8, use_graph=which == "native")
+
+    def timed(tr, b):
+        e = _time_steps(tr, b, args.steps, args.warmup, world)
+        if world > 1:                                      # MAX over ranks
+            t = torch.tensor([e], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            e = float(t.item())
+        return e
 
     enc, trainer = build(harness)
     p4, labels = synthetic_jets(per_gpu, N, seed=rank)     # per-rank shard, resident in HBM
     batch = {"p4": p4.to(dev), "labels": labels.to(dev)}
-    elapsed = _time_steps(trainer, batch, args.steps, args.warmup, world)
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = timed(trainer, batch)
+    weak = None
+    if world > 1 and scaling == "strong" and harness != "module":
+        # the weak-scaling figure next to the primary (strong) one: the config's batch on EVERY GPU (all ranks take part)
+        del trainer
+        _, tw = build(harness, cfg["B"])
+        pw, lw = synthetic_jets(cfg["B"], N, seed=rank)
+        ew = timed(tw, {"p4": pw.to(dev), "labels": lw.to(dev)})
+        weak = {"value": cfg["B"] * world * args.steps / ew, "unit": "jets/s", "ms_per_step": 1e3 * ew / args.steps,
+                "jets_per_gpu": cfg["B"], "global_batch": cfg["B"] * world, "scaling": "weak"}
+        del tw
+        trainer = None
 
     if rank == 0:
         mode = (f"weak scaling: {per_gpu} jets on each of {world} GPU(s)" if scaling == "weak" else
@@ -319,6 +406,8 @@ def main():
                                    "native-nograph": "NativeTrainStep without graph capture",
                                    "module": "ReferenceLoopStep: reference loop on the nn.Module API"}[harness]},
         }
+        if weak is not None:
+            out["weak_scaling"] = weak
         if cfg["maxdim"] == 2:
             dom = time_dominant_kernel(enc, batch)
             achieved = dom["flops"] / (dom["us"] * 1e-6) / 1e12

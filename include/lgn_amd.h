@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LGN_AMD_ABI_VERSION 8   /* bump on ANY struct or signature change (lgn/_native.py: ABI_VERSION) */
+#define LGN_AMD_ABI_VERSION 9   /* bump on ANY struct or signature change (lgn/_native.py: ABI_VERSION) */
 
 int lgn_abi_version(void);
 const char* lgn_last_error(void);
@@ -202,7 +202,13 @@ typedef struct lgn_net_desc {
   const lgn_local_tables* dec_tables[4];
   int enc_Q[5], enc_qs[5], enc_qv[5];
   int dec_Q[5], dec_qs[5], dec_qv[5];
+  /* LGN_NET_* bits.  Switches that change the LAYOUT of buffers living across calls (the activations a forward leaves for
+   * its backward) are part of the descriptor, fixed when the caller creates it -- not read from the environment per call, so
+   * a forward and its backward can never disagree. */
+  int flags;
 } lgn_net_desc;
+#define LGN_NET_NO_STATIC 1   /* table-driven levels: run-time-table kernels + node-major features (cross-check of the
+                                 compile-time-table kernels; lgn/_native.py sets it from LGN_AMD_NO_STATIC at creation) */
 
 int lgn_step_param_slots(const lgn_net_desc* d, int decoder);
 long long lgn_step_workspace_doubles(const lgn_net_desc* d);

@@ -264,8 +264,11 @@ template <class T> constexpr int blk_nu(int l, int blk) {
 }
 template <class T> constexpr int blk_nu1(int l, int blk) { return blk_nu<T>(l, blk) > 0 ? blk_nu<T>(l, blk) : 1; }
 // issue the loads of a block's moments and, where an earlier block (of another irrep) has written the gradient, of its value
+// (valid = false on the padding lanes of the last tile: nothing ever wrote their moments -- the loads stay in bounds, the
+// values are replaced by zeros so that 0 * garbage cannot put a NaN into the lane sums of the weight gradient)
 template <class T, int L, int BLK, int N>
-__device__ __forceinline__ void load_moments(const double* __restrict__ uc, const double* guc, cx<double> (&uv)[N], cx<double> (&gold)[N]) {
+__device__ __forceinline__ void load_moments(const double* __restrict__ uc, const double* guc, cx<double> (&uv)[N], cx<double> (&gold)[N],
+                                             bool valid) {
   constexpr int P0 = blk_u0<T>(L, BLK), NU = blk_nu<T>(L, BLK);
 #pragma unroll
   for (int k = 0; k < N; ++k) {
@@ -273,7 +276,8 @@ __device__ __forceinline__ void load_moments(const double* __restrict__ uc, cons
     gold[k] = {0, 0};
     if (k < NU) {
       const int e = T::BLK_UELEM[P0 + k];
-      uv[k] = {uc[e * 128], uc[e * 128 + 64]};
+      const double ur = uc[e * 128], ui = uc[e * 128 + 64];
+      uv[k] = {valid ? ur : 0.0, valid ? ui : 0.0};
       if (!T::BLK_UFIRST[P0 + k]) gold[k] = {guc[e * 128], guc[e * 128 + 64]};
     }
   }
@@ -284,7 +288,7 @@ __device__ __forceinline__ void blocks_bwd(const cx<double> (&go)[COT][T::DIM[L]
                                            const double __attribute__((address_space(4))) * wc, const double* __restrict__ uc,
                                            double* guc, const cx<double> (&uv)[blk_nu1<T>(L, BLK)],
                                            const cx<double> (&gold)[blk_nu1<T>(L, BLK)], const double* xl, double* gxl,
-                                           double* __restrict__ part, int lane) {
+                                           double* __restrict__ part, int lane, bool valid) {
   constexpr int D = T::DIM[L], ROWB = T::ROW0[L] + BLK * D;
   if constexpr (BLK < BEND) {
     constexpr int A0 = blk_lo<T>(ROWB, D, 0), A1 = blk_hi<T>(ROWB, D, 0), B0 = blk_lo<T>(ROWB, D, 1), B1 = blk_hi<T>(ROWB, D, 1);
@@ -297,7 +301,7 @@ __device__ __forceinline__ void blocks_bwd(const cx<double> (&go)[COT][T::DIM[L]
     if constexpr (BLK + 1 < BEND) {
 #pragma unroll
       for (int o = 0; o < COT; ++o) wn[o] = {wc[((BLK + 1) * COT + o) * 2], wc[((BLK + 1) * COT + o) * 2 + 1]};
-      load_moments<T, L, BLK + 1>(uc, guc, uvn, goldn);
+      load_moments<T, L, BLK + 1>(uc, guc, uvn, goldn, valid);
       if constexpr (blk_nu<T>(L, BLK + 1) > 0) __builtin_amdgcn_sched_barrier(0);      // (issued here, not wherever the scheduler likes)
     }
     // the features the block reads, and register accumulators for the gradients of what it reads
@@ -328,7 +332,7 @@ __device__ __forceinline__ void blocks_bwd(const cx<double> (&go)[COT][T::DIM[L]
     }
     wave_sum_store<2 * COT>(dw, part + BLK * COT * 2, lane);
     __builtin_amdgcn_sched_barrier(0);
-    blocks_bwd<T, L, BLK + 1, BEND, COT>(go, wn, wc, uc, guc, uvn, goldn, xl, gxl, part, lane);
+    blocks_bwd<T, L, BLK + 1, BEND, COT>(go, wn, wc, uc, guc, uvn, goldn, xl, gxl, part, lane, valid);
   }
 }
 
@@ -336,6 +340,7 @@ __device__ __forceinline__ void blocks_bwd(const cx<double> (&go)[COT][T::DIM[L]
 // gradient rows are loaded once and stay in registers over the blocks.
 template <class T, int L, int BBEG, int BEND, int COT>
 __device__ __forceinline__ void irrep_bwd(const StaticBwdArgs& a, int tile, int lane, int c, const double* xl, double* gxl) {
+  const bool valid = tile * 64 + lane < a.M;
   if constexpr (BBEG < BEND) {
     constexpr int D = T::DIM[L], NB = T::NBLK[L], Q = T::Q, QO = T::QOUT, QBASE = T::Q0[L];
     static_assert(BEND <= NB, "block range");
@@ -353,15 +358,15 @@ __device__ __forceinline__ void irrep_bwd(const StaticBwdArgs& a, int tile, int 
 #pragma unroll
       for (int mm = 0; mm < D; ++mm) {
         go[o][mm] = {got[(size_t)(oo * QO + QBASE + mm) * 128], got[(size_t)(oo * QO + QBASE + mm) * 128 + 64]};
-        if (o >= CO) go[o][mm] = {0, 0};
+        if (o >= CO || !valid) go[o][mm] = {0, 0};
       }
     }
     cx<double> wn[COT];
 #pragma unroll
     for (int o = 0; o < COT; ++o) wn[o] = {wc[(BBEG * COT + o) * 2], wc[(BBEG * COT + o) * 2 + 1]};
     cx<double> uv[blk_nu1<T>(L, BBEG)], gold[blk_nu1<T>(L, BBEG)];
-    load_moments<T, L, BBEG>(uc, guc, uv, gold);
-    blocks_bwd<T, L, BBEG, BEND, COT>(go, wn, wc, uc, guc, uv, gold, xl, gxl, part, lane);
+    load_moments<T, L, BBEG>(uc, guc, uv, gold, valid);
+    blocks_bwd<T, L, BBEG, BEND, COT>(go, wn, wc, uc, guc, uv, gold, xl, gxl, part, lane, valid);
     __builtin_amdgcn_sched_barrier(0);
   }
 }
@@ -381,7 +386,8 @@ __global__ __launch_bounds__(128) void local_bwd_static_kernel(StaticBwdArgs a) 
   {
     const double* __restrict__ xc = a.XT + ((size_t)tile * C + c) * Q * 128;
     for (int e = threadIdx.x; e < Q * 128; e += 128) {
-      xs[(e & ~127) + 2 * (e & 63) + ((e >> 6) & 1)] = xc[e];
+      // padding lanes of the last tile (node >= M): zeros, whatever the buffer holds there (see load_moments)
+      xs[(e & ~127) + 2 * (e & 63) + ((e >> 6) & 1)] = tile * 64 + (e & 63) < a.M ? xc[e] : 0.0;
       gxs[0][e] = 0.0;
       gxs[1][e] = 0.0;
     }

@@ -47,8 +47,11 @@ struct Deferred {
   std::vector<RedSeg<double>> segs;
   double* parts;
   size_t off = 0, cap = 0;
+  // nullptr when the slice does not fit: callers test it (DQ_TAKE) BEFORE enqueuing the kernel that would write there --
+  // the capacity is a hand-maintained mirror of the take sequence (carve*), a disagreement must not reach the device
   double* take(size_t n) {
     n = (n + 15) & ~size_t(15);
+    if (off + n > cap) return nullptr;
     double* p = parts + off;
     off += n;
     return p;
@@ -142,6 +145,11 @@ struct Slots {                      // canonical parameter slot order shared wit
 };
 
 #define HIPOK(e) do { hipError_t e_ = (e); if (e_ != hipSuccess) { set_error("%s: %s", #e, hipGetErrorString(e_)); return (int)e_; } } while (0)
+#define DQ_NEW(var, n) double* var = nullptr; DQ_TAKE(var, n)
+#define DQ_TAKE(lhs, n)                                                                                           \
+  lhs = dq.take(n);                                                                                             \
+  LGN_CHECK_ARG((lhs) != nullptr, "partial-row workspace overflow: %zu + %zu doubles > capacity %zu (carve / take mismatch)", \
+                dq.off, (size_t)(n), dq.cap)
 #define LGN_TRY(expr)            \
   do {                           \
     int rc_ = (expr);            \
@@ -187,7 +195,7 @@ int levels_bwd(const lgn_net_desc& d, bool dec, const int* ch, const double* P, 
       for (int q = 0; q < d.mlp_nlin; ++q) { m.w[q] = p(S.mlp(dec, l, 2 * q)); m.b[q] = p(S.mlp(dec, l, 2 * q + 1)); }
       m.s_in = n.smix[l]; m.g_out = w.gs[cur]; m.g_in = w.gsmix;
       m.psize = mlp_psize(CO, m.H, m.nlin);
-      m.part = dq.take((size_t)mlp_partial_rows(BN, m.H) * m.psize);
+      DQ_TAKE(m.part, (size_t)mlp_partial_rows(BN, m.H) * m.psize);
       LGN_TRY(mlp_dispatch<double>(m, true, st));
       // the MLP's parameters are contiguous in the flat buffer in (W_0, b_0, W_1, ...) order (checked at plan time)
       dq.add(m.part, mlp_partial_rows(BN, m.H), m.psize, 0, m.psize, g(S.mlp(dec, l, 0)));
@@ -196,8 +204,8 @@ int levels_bwd(const lgn_net_desc& d, bool dec, const int* ch, const double* P, 
     int rm, rr;
     level_bwd_partial_rows(d.B, d.N, dec, &rm, &rr);
     const int nmix = 4 * CO * 5 * C, nrad = rad_partial_size(C, dec);
-    double* part_mix = dq.take((size_t)rm * nmix);
-    double* part_rad = dq.take((size_t)rr * nrad);
+    DQ_NEW(part_mix, (size_t)rm * nmix);
+    DQ_NEW(part_rad, (size_t)rr * nrad);
     const int nxt = cur ^ 1;
     LevelBwdArgs<double> a{d.B, d.N, C, CO, n.s[l], n.v[l], pos, mask,
                            p(S.rad(dec, l, 0)), p(S.rad(dec, l, 1)), p(S.rad(dec, l, 2)), p(S.rad(dec, l, 3)), p(S.rad(dec, l, 4)),
@@ -299,8 +307,7 @@ inline bool is_static(const lgn_net_desc& d, bool dec) {
   if (d.N > 32) return false;
   for (int l = 0; l < d.n_levels; ++l)
     if (!g.tab[l] || g.tab[l]->static_kind == 0) return false;
-  const char* e = getenv("LGN_AMD_NO_STATIC");          // =1: run-time-table kernels (cross-check)
-  return !(e && e[0] == '1');
+  return !(d.flags & LGN_NET_NO_STATIC);                // run-time-table kernels (cross-check): fixed at descriptor creation
 }
 inline size_t tb_doubles(const lgn_net_desc& d, int C, int Qx) { return (size_t)(((size_t)d.B * d.N + 63) / 64) * C * Qx * 128; }
 
@@ -485,7 +492,7 @@ int gen_levels_bwd(const lgn_net_desc& d, bool dec, const double* P, double* G, 
       if (tb) { m.g_out = sc.gX[cur] + (size_t)g.qs[l + 1] * 128; m.g_in = sc.gX[cur] + (size_t)g.qs[l + 1] * 128; m.tbQ = g.Q[l + 1]; }
       else { m.g_out = sc.gX[cur] + g.qs[l + 1]; m.g_in = sc.gX[cur] + g.qs[l + 1]; m.ld = g.Q[l + 1]; }
       m.psize = mlp_psize(CO, m.H, m.nlin);
-      m.part = dq.take((size_t)mlp_partial_rows(BN, m.H) * m.psize);
+      DQ_TAKE(m.part, (size_t)mlp_partial_rows(BN, m.H) * m.psize);
       LGN_TRY(mlp_dispatch<double>(m, true, st));
       dq.add(m.part, mlp_partial_rows(BN, m.H), m.psize, 0, m.psize, G + off[S.mlp(dec, l, 0)]);
     }
@@ -494,7 +501,7 @@ int gen_levels_bwd(const lgn_net_desc& d, bool dec, const double* P, double* G, 
       int w0[8];
       for (int k = 0; k < 5; ++k) w0[k] = g.tab[l]->h_out_w0[k];
       const int kind = g.tab[l]->static_kind, np = (int)local_static_packed_doubles(kind, C, CO), tiles = (BN + 63) / 64;
-      double* part = dq.take((size_t)tiles * np);
+      DQ_NEW(part, (size_t)tiles * np);
       LGN_TRY(local_bwd_static(kind, BN, C, CO, a.X[l], a.U[l], P + off[S.mix(dec, l, 0)], w0, a.wp[l], sc.gX[cur], sc.gU, sc.gX[nxt], part, st,
                                /*packed=*/true));
       dq.add(part, tiles, np, 0, np, sc.gpk[l]);
@@ -504,14 +511,14 @@ int gen_levels_bwd(const lgn_net_desc& d, bool dec, const double* P, double* G, 
       LGN_TRY(local_args(la, BN, C, CO, g.Q[l], g.Q[l + 1], g.tab[l]));
       const int rows = local_partial_rows(BN), nw2 = 2 * g.tab[l]->n_w;
       la.X = a.X[l]; la.U = a.U[l]; la.wcat = P + off[S.mix(dec, l, 0)]; la.g_out = sc.gX[cur];
-      la.gU = sc.gU; la.gX = sc.gX[nxt]; la.part = dq.take((size_t)rows * nw2);
+      la.gU = sc.gU; la.gX = sc.gX[nxt]; DQ_TAKE(la.part, (size_t)rows * nw2);
       LGN_TRY(local_bwd(la, st));
       dq.add(la.part, rows, nw2, 0, nw2, G + off[S.mix(dec, l, 0)]);
     }
     GenArgs m = gen_level_args(d, dec, l, P, off, a.X[l], pos, mask);
     m.tb = tb;
     const int nrad = rad_partial_size(C, dec);
-    m.gU = sc.gU; m.gX = sc.gX[nxt]; m.g_p = dec ? sc.g_p : nullptr; m.part_rad = dq.take((size_t)d.B * nrad);
+    m.gU = sc.gU; m.gX = sc.gX[nxt]; m.g_p = dec ? sc.g_p : nullptr; DQ_TAKE(m.part_rad, (size_t)d.B * nrad);
     m.gbuf = sc.gbuf;
     LGN_TRY(moments_dispatch(m, dec, 1, st));
     LGN_TRY(moments_dispatch(m, dec, 2, st));
@@ -570,7 +577,7 @@ int gen_encoder_bwd(const lgn_net_desc& d, const double* P, double* G, const int
   int cur = 0;
   {
     const int CL = g.ch[L], rowe = 2 * (Ts + Tv) * CL;
-    double* parte = dq.take((size_t)B * rowe);
+    DQ_NEW(parte, (size_t)B * rowe);
     LGN_TRY(enc_latent_bwd(B, N, CL, Ts, Tv, a.sL, a.vL, P + off[S.out0(false)], P + off[S.out0(false) + 1],
                            g_lat_s ? g_lat_s : sc.g_lat_s, g_lat_v, a.idx, sc.gs, sc.gv, parte, st));
     dq.add(parte, B, rowe, 0, 2 * Ts * CL, G + off[S.out0(false)]);
@@ -582,7 +589,7 @@ int gen_encoder_bwd(const lgn_net_desc& d, const double* P, double* G, const int
   {
     const int C0 = g.ch[0];
     LGN_TRY(net_unpack(d, false, 0, sc.gX[cur], sc.gs, sc.gv, st));
-    double* part = dq.take((size_t)B * 4 * C0);
+    DQ_NEW(part, (size_t)B * 4 * C0);
     LGN_TRY(enc_input_bwd(B, N, C0, p4, sc.gs, sc.gv, part, st));
     dq.add(part, B, 4 * C0, 0, 2 * C0, G + off[0]);
     dq.add(part, B, 4 * C0, 2 * C0, 2 * C0, G + off[1]);
@@ -616,7 +623,7 @@ int gen_decoder_bwd(const lgn_net_desc& d, const double* P, double* G, const int
   LGN_TRY(gen_levels_bwd(d, true, P, G, off, a, a.pdec, nullptr, sc, dq, fin, post, cur, /*has_s_grad=*/false, st));
   const int C0 = g.ch[0], row = 4 * C0 + 2 * N * Tin;
   LGN_TRY(net_unpack(d, true, 0, sc.gX[cur], sc.gs, sc.gv, st));
-  double* part = dq.take((size_t)B * row);
+  DQ_NEW(part, (size_t)B * row);
   LGN_TRY(dec_input_bwd(B, N, C0, Tin, lat_v, P + off[1], P + off[3], a.pdec, sc.g_p, sc.gs, sc.gv, g_lat_v, part, st));
   dq.add(part, B, row, 0, 2 * C0, G + off[2]);
   dq.add(part, B, row, 2 * C0, 2 * C0, G + off[3]);
@@ -671,7 +678,7 @@ int gen_step_fwd_bwd(const lgn_net_desc& d, const double* params, double* grads,
   dq.cap = g.ds.parts_size;
   RadFinJob fin{};
   {
-    double* part = dq.take((size_t)B * 2 * CL);
+    DQ_NEW(part, (size_t)B * 2 * CL);
     LGN_TRY(dec_output_loss(B, N, CL, g.da.vL, params + dec_off[S.out0(true) + 1], target, 1.0, recon, loss_part, g.ds.gv, part, st));
     dq.add(part, B, 2 * CL, 0, 2 * CL, grads + dec_off[S.out0(true) + 1]);
   }
@@ -837,7 +844,7 @@ int lgn_encoder_bwd_f64(const lgn_net_desc* d, const double* params, double* gra
   int cur = 0;
   {
     const int CL = ce[L], rowe = 2 * (Ts + Tv) * CL;
-    double* parte = dq.take((size_t)B * rowe);
+    DQ_NEW(parte, (size_t)B * rowe);
     LGN_TRY(enc_latent_bwd(B, N, CL, Ts, Tv, a.n.s[L], a.n.v[L], params + off[S.out0(false)], params + off[S.out0(false) + 1],
                            g_lat_s ? g_lat_s : w.g_lat_s, g_lat_v, a.idx, w.gs[cur], w.gv[cur], parte, st));
     dq.add(parte, B, rowe, 0, 2 * Ts * CL, grads + off[S.out0(false)]);
@@ -847,7 +854,7 @@ int lgn_encoder_bwd_f64(const lgn_net_desc* d, const double* params, double* gra
   LGN_TRY(levels_bwd(*d, false, ce, params, grads, off, a.n, p4, mask, w, dq, fin, cur, /*has_s_grad=*/g_lat_s != nullptr, st));
   {
     const int C0 = ce[0];
-    double* part = dq.take((size_t)B * 4 * C0);
+    DQ_NEW(part, (size_t)B * 4 * C0);
     LGN_TRY(enc_input_bwd(B, N, C0, p4, w.gs[cur], w.gv[cur], part, st));
     dq.add(part, B, 4 * C0, 0, 2 * C0, grads + off[0]);
     dq.add(part, B, 4 * C0, 2 * C0, 2 * C0, grads + off[1]);
@@ -902,7 +909,7 @@ int lgn_decoder_bwd_f64(const lgn_net_desc* d, const double* params, double* gra
     dq.parts = gs.parts;
     dq.cap = gs.parts_size;
     RadFinJob fin{};
-    double* part = dq.take((size_t)d->B * 2 * CL);
+    DQ_NEW(part, (size_t)d->B * 2 * CL);
     LGN_TRY(dec_output_bwd(d->B, d->N, CL, ga.vL, params + off[Sg.out0(true) + 1], g_recon, gs.gv, part, gst));
     dq.add(part, d->B, 2 * CL, 0, 2 * CL, grads + off[Sg.out0(true) + 1]);
     std::vector<UnpackJob> post;
@@ -928,14 +935,14 @@ int lgn_decoder_bwd_f64(const lgn_net_desc* d, const double* params, double* gra
   RadFinJob fin{};
   int cur = 0;
   {
-    double* part = dq.take((size_t)B * 2 * cd[L]);
+    DQ_NEW(part, (size_t)B * 2 * cd[L]);
     LGN_TRY(dec_output_bwd(B, N, cd[L], a.n.v[L], params + off[S.out0(true) + 1], g_recon, w.gv[cur], part, st));
     dq.add(part, B, 2 * cd[L], 0, 2 * cd[L], grads + off[S.out0(true) + 1]);
   }
   LGN_TRY(levels_bwd(*d, true, cd, params, grads, off, a.n, a.pdec, nullptr, w, dq, fin, cur, /*has_s_grad=*/false, st));
   {
     const int C0 = cd[0], row = 4 * C0 + 2 * N * Tin;
-    double* part = dq.take((size_t)B * row);
+    DQ_NEW(part, (size_t)B * row);
     LGN_TRY(dec_input_bwd(B, N, C0, Tin, lat_v, params + off[1], params + off[3], a.pdec, w.g_p, w.gs[cur], w.gv[cur], g_lat_v, part, st));
     dq.add(part, B, row, 0, 2 * C0, grads + off[2]);
     dq.add(part, B, row, 2 * C0, 2 * C0, grads + off[3]);
@@ -1018,7 +1025,7 @@ int lgn_step_fwd_bwd_f64(const lgn_net_desc* d, const double* params, double* gr
   // ---------------- loss + backward ----------------
   int cur = 0;
   {
-    double* part = dq.take((size_t)B * 2 * cd[L]);
+    DQ_NEW(part, (size_t)B * 2 * cd[L]);
     LGN_TRY(dec_output_loss(B, N, cd[L], w.dec.v[L], params + dec_off[S.out0(true) + 1], target, 1.0, recon, loss_part, w.gv[cur], part, st));
     dq.add(part, B, 2 * cd[L], 0, 2 * cd[L], grads + dec_off[S.out0(true) + 1]);
   }
@@ -1026,8 +1033,8 @@ int lgn_step_fwd_bwd_f64(const lgn_net_desc* d, const double* params, double* gr
   {
     const int C0 = cd[0], Tin = 2 * Tv, row = 4 * C0 + 2 * N * Tin;
     const int CL = ce[L], rowe = 2 * (Ts + Tv) * CL;
-    double* part = dq.take((size_t)B * row);
-    double* parte = dq.take((size_t)B * rowe);
+    DQ_NEW(part, (size_t)B * row);
+    DQ_NEW(parte, (size_t)B * rowe);
     // reads the gradient w.r.t. the decoder's level-0 features, writes the one w.r.t. the encoder's last level into the
     // other buffer pair (jets do not occupy the same slices when the two channel counts differ)
     const int rd = cur, wr = cur ^ 1;
@@ -1044,7 +1051,7 @@ int lgn_step_fwd_bwd_f64(const lgn_net_desc* d, const double* params, double* gr
   LGN_TRY(levels_bwd(*d, false, ce, params, grads, enc_off, w.enc, p4, mask, w, dq, fin, cur, /*has_s_grad=*/false, st));
   {
     const int C0 = ce[0];
-    double* part = dq.take((size_t)B * 4 * C0);
+    DQ_NEW(part, (size_t)B * 4 * C0);
     LGN_TRY(enc_input_bwd(B, N, C0, p4, w.gs[cur], w.gv[cur], part, st));
     dq.add(part, B, 4 * C0, 0, 2 * C0, grads + enc_off[0]);
     dq.add(part, B, 4 * C0, 2 * C0, 2 * C0, grads + enc_off[1]);

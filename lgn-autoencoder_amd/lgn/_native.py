@@ -15,7 +15,7 @@ import torch  # imported before the .so so that the process-wide libamdhip64 is 
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LGN_AMD_LIB") or os.path.join(_HERE, "_lib", "liblgn_amd.so")   # LGN_AMD_LIB: debug builds (tools/)
-ABI_VERSION = 8
+ABI_VERSION = 9
 FINALIZE_SCRATCH = 2048      # include/lgn_amd.h: LGN_FINALIZE_SCRATCH
 
 _lib: Optional[C.CDLL] = None
@@ -57,7 +57,19 @@ class NetDesc(C.Structure):
                 ("mlp_nlin", C.c_int), ("tau_v_in", C.c_int),
                 ("enc_tables", _tp * 4), ("dec_tables", _tp * 4),
                 ("enc_Q", C.c_int * 5), ("enc_qs", C.c_int * 5), ("enc_qv", C.c_int * 5),
-                ("dec_Q", C.c_int * 5), ("dec_qs", C.c_int * 5), ("dec_qv", C.c_int * 5)]
+                ("dec_Q", C.c_int * 5), ("dec_qs", C.c_int * 5), ("dec_qv", C.c_int * 5), ("flags", C.c_int)]
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.flags = net_flags()
+
+
+NET_NO_STATIC = 1
+
+
+def net_flags() -> int:
+    """LGN_NET_* bits of a descriptor created now (include/lgn_amd.h): layout switches are frozen into the descriptor."""
+    return NET_NO_STATIC if os.environ.get("LGN_AMD_NO_STATIC", "") == "1" else 0
 
 
 _dp = C.POINTER(NetDesc)

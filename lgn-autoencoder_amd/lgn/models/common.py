@@ -133,6 +133,10 @@ class CGModule(nn.Module):
         new = cls.__new__(cls)
         memo[id(self)] = new
         for k, v in self.__dict__.items():
+            # derived, rebuilt on demand: device-side tables and descriptors hold ctypes pointers (not copyable), and the
+            # parameter views must point into the COPY's flat block
+            if k in ("_native_cache", "_level_tables", "_p_views", "_views_ptr"):
+                continue
             new.__dict__[k] = copy.deepcopy(v, memo)
         if "flat_params" in new._parameters:
             new._rebind_views()
@@ -152,10 +156,37 @@ class CGModule(nn.Module):
 
     def state_dict(self, *args, destination=None, prefix="", keep_vars=False):
         from collections import OrderedDict
+        if args:      # the deprecated positional form of nn.Module.state_dict: (destination, prefix, keep_vars)
+            destination = args[0] if len(args) > 0 else destination
+            prefix = args[1] if len(args) > 1 else prefix
+            keep_vars = args[2] if len(args) > 2 else keep_vars
         out = destination if destination is not None else OrderedDict()
         for name, view in self.named_parameter_views():
             out[prefix + name] = view if keep_vars else view.detach()
         return out
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        """Called when the network is a CHILD of the module being loaded (an autoencoder wrapper, ...): nn.Module walks the
+        tree with this hook and never reaches the ``load_state_dict`` override below.  Consumes the reference-named entries
+        under ``prefix`` (and removes them from ``state_dict``, which is this sub-tree's private copy, so that the parameter-less
+        sub-modules below do not report them as unexpected)."""
+        views = dict(self.named_parameter_views())
+        mine = [k for k in list(state_dict.keys()) if k.startswith(prefix)]
+        for k in mine:
+            name = k[len(prefix):]
+            v = views.get(name)
+            if v is None:
+                if strict:
+                    unexpected_keys.append(k)
+            elif tuple(state_dict[k].shape) != tuple(v.shape):
+                error_msgs.append(f"size mismatch for {k}: copying a param with shape {tuple(state_dict[k].shape)} from checkpoint, "
+                                  f"the shape in current model is {tuple(v.shape)}.")
+            else:
+                with torch.no_grad():
+                    v.copy_(state_dict[k])
+            del state_dict[k]
+        seen = {k[len(prefix):] for k in mine}
+        missing_keys.extend(prefix + n for n in views if n not in seen)
 
     def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
         from torch.nn.modules.module import _IncompatibleKeys

@@ -368,14 +368,25 @@ class NetHandle:
 def net_handle(net, decoder: bool, B: int) -> NetHandle:
     net._check_views()
     cache = net.__dict__.setdefault("_native_cache", {})
-    h = cache.get(B)
+    key = (B, N.net_flags())           # a handle freezes the layout switches of its descriptor
+    h = cache.get(key)
     if h is None:
-        h = cache[B] = NetHandle(net, decoder, B)
+        h = cache[key] = NetHandle(net, decoder, B)
     return h
 
 
 def _r16(n: int) -> int:
     return (n + 15) & ~15
+
+
+def _alloc(n: int, like: torch.Tensor) -> torch.Tensor:
+    """Uninitialised buffer of n scalars for a whole-network call.  LGN_AMD_POISON=1 (tests) fills it with NaN: every scalar
+    the kernels read must have been written by them first -- padding lanes of partly filled 64-node tiles included."""
+    import os
+    buf = torch.empty(n, device=like.device, dtype=like.dtype)
+    if os.environ.get("LGN_AMD_POISON") == "1":
+        buf.fill_(float("nan"))
+    return buf
 
 
 class EncoderFn(torch.autograd.Function):
@@ -390,7 +401,7 @@ class EncoderFn(torch.autograd.Function):
         h = net_handle(net, False, B)
         Ts, Tv = h.desc.tau_s, h.desc.tau_v
         ns, nv = _r16(4 * B * Ts), _r16(16 * B * Tv)
-        buf = torch.empty(ns + nv + h.n_act, device=flat.device, dtype=flat.dtype)
+        buf = _alloc(ns + nv + h.n_act, flat)
         lat_s = buf[:4 * B * Ts].view(2, B, 1, 2 * Ts, 1)
         lat_v = buf[ns:ns + 16 * B * Tv].view(2, B, 1, 2 * Tv, 4)
         base = buf.data_ptr()
@@ -407,7 +418,7 @@ class EncoderFn(torch.autograd.Function):
         p4, mask, flat, buf = ctx.saved_tensors
         h = ctx.h
         npar = _r16(h.n_params)
-        out = torch.empty(npar + h.n_scratch, device=flat.device, dtype=flat.dtype)
+        out = _alloc(npar + h.n_scratch, flat)
         grads = out[:h.n_params]
         if g_v is None:
             if g_s is None:
@@ -431,7 +442,7 @@ class DecoderFn(torch.autograd.Function):
         B = lat_v.shape[1]
         h = net_handle(net, True, B)
         nr = _r16(8 * B * h.desc.N)
-        buf = torch.empty(nr + h.n_act, device=flat.device, dtype=flat.dtype)
+        buf = _alloc(nr + h.n_act, flat)
         recon = buf[:8 * B * h.desc.N].view(2, B, h.desc.N, 4)
         base = buf.data_ptr()
         rc = N.lib().lgn_decoder_fwd_f64(h.ref, flat.data_ptr(), h.off, N.ptr(lat_v), base + 8 * nr, h.n_act, base, N.stream_ptr())
@@ -445,7 +456,7 @@ class DecoderFn(torch.autograd.Function):
         lat_v, flat, buf = ctx.saved_tensors
         h = ctx.h
         npar, nl = _r16(h.n_params), _r16(lat_v.numel())
-        out = torch.empty(nl + npar + h.n_scratch, device=flat.device, dtype=flat.dtype)
+        out = _alloc(nl + npar + h.n_scratch, flat)
         g_lat = out[:lat_v.numel()].view(lat_v.shape)
         grads = out[nl:nl + h.n_params]
         base = out.data_ptr()

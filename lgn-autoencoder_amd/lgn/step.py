@@ -175,7 +175,7 @@ class NativeTrainStep:
 
     def __init__(self, encoder, decoder, batch_size: int, lr: float = 5e-4, l1_lambda: float = 1e-8,
                  betas=(0.9, 0.999), eps: float = 1e-8, process_group=None, optimizer: bool = True, use_graph: bool = True,
-                 force_collective: bool = False):
+                 force_collective: bool = False, graph_collective: Optional[bool] = None):
         import ctypes as C
         from . import _native as N
         self.N = N
@@ -198,6 +198,16 @@ class NativeTrainStep:
         # force_collective: take the two-graph + all-reduce branch even with one rank (exercises the capture boundaries and
         # the RCCL call on the flat buffer on a single GPU; a 1-rank SUM leaves the buffer unchanged)
         self.collective = self.world > 1 or force_collective
+        # graph_collective: capture the all-reduce INSIDE the step's graph (one launch per step under data parallelism).
+        # None = try, and fall back to [graph | all-reduce | graph] if the backend refuses the capture; LGN_AMD_GRAPH_COLLECTIVE=0
+        # forces the three-launch form.  `self.launches_per_step` says which one is in use after the first step.
+        import os as _os
+        if graph_collective is None and _os.environ.get("LGN_AMD_GRAPH_COLLECTIVE") == "0":
+            graph_collective = False
+        if graph_collective is None and self.collective and dist.get_backend(process_group) != "nccl":
+            graph_collective = False        # gloo stages through the host: nothing a stream capture could record
+        self.graph_collective = graph_collective
+        self.launches_per_step = None
         self.optimizer = optimizer
         dev, dt = self.flat.flat.device, self.flat.flat.dtype
         L = encoder.num_cg_levels
@@ -273,19 +283,40 @@ class NativeTrainStep:
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             self._fwd_bwd()
+            if self.collective:       # communicator / algorithm set-up of this message size happens outside the capture
+                dist.all_reduce(self.flat.grad_buf, op=dist.ReduceOp.SUM, group=self.group)
             self._finalize(False)
         torch.cuda.current_stream().wait_stream(s)
-        self._g1, self._g2 = torch.cuda.CUDAGraph(), None
-        if self.collective:           # the gradient all-reduce sits between the two graphs
+        torch.cuda.synchronize()
+        self._g1, self._g2, self._in_graph = torch.cuda.CUDAGraph(), None, False
+        if self.collective and self.graph_collective is not False:
+            # ONE graph: forward + backward | all-reduce(SUM) of gradients and loss terms | L1 + Adam.  RCCL enqueues its
+            # kernel on the capturing stream like any other launch; if this backend refuses, use the three-launch form below
+            try:
+                with torch.cuda.graph(self._g1):
+                    self._fwd_bwd()
+                    dist.all_reduce(self.flat.grad_buf, op=dist.ReduceOp.SUM, group=self.group)
+                    self._finalize(self.optimizer)
+                self._in_graph = True
+            except Exception as exc:      # noqa: BLE001  (every rank runs the same software: all of them land here together)
+                if self.graph_collective is True:
+                    raise
+                import warnings
+                warnings.warn(f"all-reduce could not be captured in the step graph ({type(exc).__name__}: {exc}); "
+                              "falling back to graph | all-reduce | graph")
+                torch.cuda.synchronize()
+                self._g1 = torch.cuda.CUDAGraph()
+        if self.collective and not self._in_graph:      # the gradient all-reduce sits between two graphs
             self._g2 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._g1):
                 self._fwd_bwd()
             with torch.cuda.graph(self._g2, pool=self._g1.pool()):
                 self._finalize(self.optimizer)
-        else:                         # single process: the whole step is ONE graph launch
+        elif not self.collective:     # single process: the whole step is ONE graph launch
             with torch.cuda.graph(self._g1):
                 self._fwd_bwd()
                 self._finalize(self.optimizer)
+        self.launches_per_step = 3 if self._g2 is not None else 1
         with torch.no_grad():   # capture does not execute, but restore anyway in case a backend replays eagerly
             self.flat.flat.copy_(snap[0]); self.adam_m.copy_(snap[1]); self.adam_v.copy_(snap[2]); self.step_dev.copy_(snap[3])
 
@@ -319,13 +350,12 @@ class NativeTrainStep:
             self._capture()
         if self.use_graph:
             self._g1.replay()
-        else:
-            self._fwd_bwd()
-        if self.collective:     # ONE collective per step: gradients and the per-jet loss terms share a buffer
-            dist.all_reduce(self.flat.grad_buf, op=dist.ReduceOp.SUM, group=self.group)
-        if self.use_graph:
-            if self._g2 is not None:
+            if self._g2 is not None:    # ONE collective per step: gradients and the per-jet loss terms share a buffer
+                dist.all_reduce(self.flat.grad_buf, op=dist.ReduceOp.SUM, group=self.group)
                 self._g2.replay()
         else:
+            self._fwd_bwd()
+            if self.collective:
+                dist.all_reduce(self.flat.grad_buf, op=dist.ReduceOp.SUM, group=self.group)
             self._finalize(self.optimizer)
         return self.loss_out[0], self.recon

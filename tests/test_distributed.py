@@ -104,3 +104,26 @@ def test_two_rank_data_parallel_equals_single_process():
         assert torch.allclose(grad, step.flat.grad, rtol=1e-12, atol=1e-14), f"rank {r} gradient"
         assert torch.allclose(flat, step.flat.flat.detach(), rtol=1e-12, atol=1e-14), f"rank {r} parameters after Adam"
     assert torch.equal(res[0][1], res[1][1]), "replicas diverged"
+
+
+def test_bench_self_spawn_world2_dry_run():
+    """`python bench.py --gpus 2` without a launcher starts its two ranks itself (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*),
+    they rendezvous (gloo stand-in for RCCL: LGN_BENCH_DRY=1 replaces the GPU step by a CPU all-reduce with the same
+    barrier / max-over-ranks shape), rank 0 alone prints the JSON line and the parent returns the ranks' exit code."""
+    import json
+    import subprocess
+    env = dict(os.environ, LGN_BENCH_DRY="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["dry_run"] and out["n_gpus"] == 2 and out["steps"] == 3 and out["local_rank"] == 0
+    assert out["sum"] == 3.0                      # 1 + 2: both ranks took part in the collective
+    # a launcher mismatch is still refused (WORLD_SIZE set by torch.distributed.run but a different --gpus)
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=dict(env, WORLD_SIZE="1", RANK="0"),
+                        capture_output=True, text=True, timeout=120)
+    assert r2.returncode != 0 and "--gpus 2 but WORLD_SIZE=1" in r2.stderr

@@ -184,8 +184,9 @@ def test_native_step_scaled_input_uses_unscaled_target():
 
 def test_native_step_rccl_collective_branch_single_rank():
     """RCCL on the one GPU of the box: an `nccl` process group of world size 1 with ``force_collective=True`` runs the
-    two-graph + all_reduce(grad_buf) branch that data-parallel runs take; it must equal the one-graph step bit for bit
-    (a 1-rank SUM is the identity), over several optimiser steps."""
+    branches data-parallel runs take -- (a) the all-reduce(grad_buf) captured INSIDE the step graph (one launch per step),
+    (b) graph | all-reduce | graph -- and both must equal the plain one-graph step bit for bit (a 1-rank SUM is the
+    identity), over several optimiser steps."""
     import socket
     import torch.distributed as dist
     from lgn.step import NativeTrainStep
@@ -197,15 +198,23 @@ def test_native_step_rccl_collective_branch_single_rank():
     try:
         z, m, enc, dec, batch = _golden_setup()
         _, _, enc2, dec2, _ = _golden_setup()
+        _, _, enc3, dec3, _ = _golden_setup()
         a = NativeTrainStep(enc, dec, batch_size=m["B"], lr=5e-4, l1_lambda=1e-8, use_graph=True, force_collective=True)
         b = NativeTrainStep(enc2, dec2, batch_size=m["B"], lr=5e-4, l1_lambda=1e-8, use_graph=True)
-        assert a._g2 is None and a.collective and not b.collective
+        c = NativeTrainStep(enc3, dec3, batch_size=m["B"], lr=5e-4, l1_lambda=1e-8, use_graph=True, force_collective=True,
+                            graph_collective=False)
+        assert a.collective and c.collective and not b.collective
         for it in range(3):
             la, _ = a.step(batch)
             lb, _ = b.step(batch)
-            assert float(la) == float(lb), f"step {it}: {float(la)!r} vs {float(lb)!r}"
-        assert a._g2 is not None and b._g2 is None
-        assert torch.equal(a.flat.flat, b.flat.flat) and torch.equal(a.flat.grad_buf, b.flat.grad_buf)
+            lc, _ = c.step(batch)
+            assert float(la) == float(lb) == float(lc), f"step {it}: {float(la)!r} vs {float(lb)!r} vs {float(lc)!r}"
+        assert b._g2 is None and b.launches_per_step == 1
+        assert c._g2 is not None and c.launches_per_step == 3
+        print(f"all-reduce inside the step graph: {a._in_graph} (launches per step: {a.launches_per_step})")
+        assert a.launches_per_step in (1, 3)
+        for t in (a, c):
+            assert torch.equal(t.flat.flat, b.flat.flat) and torch.equal(t.flat.grad_buf, b.flat.grad_buf)
     finally:
         dist.destroy_process_group()
 
@@ -253,6 +262,61 @@ def test_native_step_maxdim3_other_shapes_match_per_op_path(N):
     U.assert_close(la, lb, 1e-11, "loss")
     U.assert_close(ra, rb, 1e-11, "recon")
     U.assert_close(a.flat.grad, b.flat.grad, 1e-9, "flat gradient")
+
+
+@pytest.mark.parametrize("maxdim,ch_enc,ch_dec,N,B", [(3, (2, 4, 7, 8), (8, 6, 5, 3), 13, 5), (3, (4, 4, 6, 6), (6, 6, 4, 4), 30, 3),
+                                                     (2, (3, 3, 4, 4), (4, 4, 3, 3), 30, 3), (2, (3, 3, 4, 4), (4, 4, 3, 3), 50, 2)])
+def test_poisoned_buffers_padding_lanes_never_reach_a_result(maxdim, ch_enc, ch_dec, N, B, monkeypatch):
+    """Every workspace / activation / scratch buffer pre-filled with NaN (B * N is not a multiple of the 64-node tile, so the
+    last tile of the tile-blocked maxdim-3 layouts has padding lanes nobody writes): the native step and the whole-network
+    module calls must still give finite results equal to the per-operator path -- a kernel that read a scalar it did not
+    write, or summed padding lanes into a weight gradient (0 * NaN), would show up as NaN."""
+    import __graft_entry__ as G
+    from lgn.step import NativeTrainStep, TrainStep
+    from oracle import lgn_oracle as O
+    dev = torch.device("cuda:0")
+    assert (B * N) % 64 != 0
+    nets = [G._models(N, ch_enc, ch_dec, dev, seed=5, maxdim=maxdim) for _ in range(3)]
+    nets[2][0].use_fused = nets[2][1].use_fused = False
+    p4, labels = O.synthetic_jets(B, N, seed=4, pad=True)
+    batch = {"p4": p4.to(dev), "labels": labels.to(dev)}
+    ref = TrainStep(*nets[2], optimizer=False)
+    lb, rb = ref.forward_backward(batch)
+    a = NativeTrainStep(*nets[0], batch_size=B, optimizer=False, use_graph=False)
+    a.workspace.fill_(float("nan"))
+    a.recon.fill_(float("nan"))
+    a.flat.grad_buf.fill_(float("nan"))
+    la, ra = a.step(batch)
+    assert torch.isfinite(a.flat.grad).all() and torch.isfinite(ra).all() and torch.isfinite(la)
+    U.assert_close(la, lb, 1e-11, "native step: loss")
+    U.assert_close(a.flat.grad, ref.flat.grad, 1e-9, "native step: flat gradient")
+    monkeypatch.setenv("LGN_AMD_POISON", "1")
+    m = TrainStep(*nets[1], optimizer=False)          # whole-network native calls under autograd
+    lm, rm = m.forward_backward(batch)
+    assert torch.isfinite(m.flat.grad).all() and torch.isfinite(rm).all()
+    U.assert_close(lm, lb, 1e-11, "module path: loss")
+    U.assert_close(m.flat.grad, ref.flat.grad, 1e-9, "module path: flat gradient")
+
+
+def test_deepcopy_of_a_network_that_has_run():
+    """copy.deepcopy(encoder) after a GPU forward (EMA copy, best-model snapshot): the native cache (ctypes descriptors,
+    device tables) is rebuilt for the copy, which then computes the same result from its own parameter block."""
+    import copy
+    import __graft_entry__ as G
+    from oracle import lgn_oracle as O
+    dev = torch.device("cuda:0")
+    for maxdim, che, chd in ((2, (3, 3, 4, 4), (4, 4, 3, 3)), (3, (4, 4, 6, 6), (6, 6, 4, 4))):
+        enc, dec = G._models(30, che, chd, dev, seed=2, maxdim=maxdim)
+        p4, labels = O.synthetic_jets(3, 30, seed=1, pad=True)
+        batch = {"p4": p4.to(dev), "labels": labels.to(dev)}
+        r0 = dec(enc(batch)).detach().clone()
+        assert "_native_cache" in enc.__dict__
+        enc2, dec2 = copy.deepcopy(enc), copy.deepcopy(dec)
+        assert enc2.flat_params.data_ptr() != enc.flat_params.data_ptr()
+        with torch.no_grad():
+            enc.flat_params.zero_(); dec.flat_params.zero_()          # the copies must not look at the originals
+        r1 = dec2(enc2(batch)).detach()
+        assert torch.equal(r0, r1)
 
 
 @pytest.mark.parametrize("maxdim,ch_enc,ch_dec", [(2, (3, 3, 4, 4), (4, 4, 3, 3)), (3, (4, 4, 6, 6), (6, 6, 4, 4))])

@@ -174,6 +174,51 @@ def test_flat_parameter_block_keeps_the_reference_state_dict_surface():
         assert (mod.rad_funcs.rad_funcs[0].a < 2.5).all()
 
 
+def test_networks_nested_in_a_wrapper_round_trip_state_dict_and_deepcopy_after_use():
+    """(i) An autoencoder wrapper holding both networks: ``parent.state_dict()`` emits the reference keys under the child
+    prefixes and ``parent.load_state_dict`` takes them back (nn.Module walks children through _load_from_state_dict, not
+    through the networks' own load_state_dict), with strict-mode errors intact.  (ii) deepcopy of a network that has already
+    run on the GPU: its native cache holds ctypes descriptors (pointers: not copyable) and must be skipped, the copy's views
+    must point into the copy's own flat block."""
+    import copy
+    import ctypes
+    import __graft_entry__ as G
+
+    class Wrapper(torch.nn.Module):
+        def __init__(self, e, d):
+            super().__init__()
+            self.e, self.d = e, d
+
+    a = Wrapper(*G._models(30, (3, 3, 4, 4), (4, 4, 3, 3), torch.device("cpu"), seed=0))
+    b = Wrapper(*G._models(30, (3, 3, 4, 4), (4, 4, 3, 3), torch.device("cpu"), seed=5))
+    sd = a.state_dict()
+    assert list(sd)[0] == "e.rad_funcs.rad_funcs.0.a" and "e.flat_params" not in sd and len(sd) == len(a.e.state_dict()) + len(a.d.state_dict())
+    assert not torch.equal(a.e.flat_params, b.e.flat_params)
+    res = b.load_state_dict(sd)
+    assert not res.missing_keys and not res.unexpected_keys
+    assert torch.equal(a.e.flat_params, b.e.flat_params) and torch.equal(a.d.flat_params, b.d.flat_params)
+    bad = dict(sd)
+    gone = list(bad)[3]
+    del bad[gone]
+    bad["d.bogus"] = torch.zeros(1)
+    with pytest.raises(RuntimeError, match="Missing key"):
+        b.load_state_dict(bad)
+    res = b.load_state_dict(bad, strict=False)
+    assert res.missing_keys == [gone] and res.unexpected_keys == ["d.bogus"]
+    with pytest.raises(RuntimeError, match="size mismatch"):
+        b.load_state_dict(dict(sd, **{gone: torch.zeros(7)}))
+    assert list(a.e.state_dict(None, "pre.", False))[0] == "pre.rad_funcs.rad_funcs.0.a"      # positional form
+    # what a first GPU forward leaves behind (NetHandle: byref + descriptor with pointer fields; DeviceTables likewise)
+    a.e.__dict__["_native_cache"] = {4: ctypes.byref(ctypes.c_int(3))}
+    a.e.__dict__["_level_tables"] = {0: ctypes.pointer(ctypes.c_int(3))}
+    twin = copy.deepcopy(a)
+    assert "_native_cache" not in twin.e.__dict__ and "_level_tables" not in twin.e.__dict__
+    assert twin.e.flat_params.data_ptr() != a.e.flat_params.data_ptr() and torch.equal(twin.e.flat_params, a.e.flat_params)
+    assert twin.e._p_views[0].data_ptr() == twin.e.flat_params.data_ptr()
+    twin.e.flat_params.data.zero_()
+    assert twin.e.input_func_node.weight((1, 1)).abs().max() == 0 and a.e.input_func_node.weight((1, 1)).abs().max() > 0
+
+
 def test_native_step_refuses_configurations_it_does_not_implement():
     """lgn_step_fwd_bwd_f64 is the maxdim = 2 closed form; a maxdim = 3 (or non min&max) network must be refused on the
     host instead of being read with the wrong weight layout (checked before any GPU requirement).  (maxdim = 3 networks are
