@@ -215,11 +215,15 @@ long long lgn_step_workspace_doubles(const lgn_net_desc* d);
 /* p4 [B][N][4] real Cartesian encoder input (already multiplied by the encoder's `scale`, lgn_encoder.py:376);
  * target [B][N][4] the UNscaled batch the reconstruction is compared with (utils/train.py:285-292; may alias p4 when
  * scale == 1); mask [B][N]; recon [2][B][N][4]; loss_part [B].  workspace_doubles = capacity of `workspace`: the call
- * fails before enqueuing anything if the current configuration needs more (lgn_step_workspace_doubles). */
+ * fails before enqueuing anything if the current configuration needs more (lgn_step_workspace_doubles).
+ * side_stream (may be NULL): a second stream of the same device on which the batch reductions of the parameter gradients run
+ * beside the backward kernels on `stream` (forked and joined with events the library owns; under stream capture these become
+ * a branch of the captured graph).  On return every side-stream launch is ordered before whatever is enqueued on `stream`
+ * next.  NULL: all reductions run on `stream` after the backward. */
 int lgn_step_fwd_bwd_f64(const lgn_net_desc* d, const double* params, double* grads, long long n_params,
                          const int64_t* enc_off, const int64_t* dec_off, const double* p4, const double* target,
                          const uint8_t* mask, double* workspace, long long workspace_doubles, double* recon,
-                         double* loss_part, void* stream);
+                         double* loss_part, void* stream, void* side_stream);
 /* grads += l1_lambda*sign(params) (utils/train.py:484-487); loss_out[0..2] = total, chamfer, sum|w|; optional Adam
  * (torch.optim.Adam defaults; the step counter lives on the device so that graph replays stay correct).
  * loss_out must hold 3 + LGN_FINALIZE_SCRATCH doubles: the results, then scratch for the per-workgroup |w| partials. */

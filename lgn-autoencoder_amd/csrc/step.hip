@@ -59,6 +59,33 @@ struct Deferred {
   void add(const double* part, int rows, int stride, int col0, int n, double* out) {
     if (n > 0) segs.push_back(RedSeg<double>{part, rows, stride, col0, n, out});
   }
+  // Forked reductions.  The partial rows of a finished producer are reduced on `side` while `main` goes on with the next
+  // level: main --record--> side waits --> reduce on side ... join(): side --record--> main waits.  Under stream capture the
+  // record / wait pairs become graph edges, i.e. a branch of the step's graph; eagerly they are ordinary events.  The
+  // reductions move ~100 MB of CGMLP weight-gradient partials per cfg2 step (HBM-bound) beside kernels that are not.
+  hipStream_t side = nullptr;
+  hipEvent_t* ev = nullptr;          // pool of >= 2 * MAX_FORKS events owned by the library (per device)
+  int nfork = 0;
+  bool forked = false;
+  static constexpr int MAX_FORKS = 6;
+  int max_forks = MAX_FORKS;
+  int fork_flush(hipStream_t main_st) {
+    if (!side || segs.empty() || nfork >= max_forks) return 0;        // (no side stream: everything waits for flush())
+    hipError_t e = hipEventRecord(ev[nfork], main_st);
+    if (e == hipSuccess) e = hipStreamWaitEvent(side, ev[nfork], 0);
+    if (e != hipSuccess) { set_error("fork_flush: %s", hipGetErrorString(e)); return (int)e; }
+    ++nfork;
+    forked = true;
+    return flush(side);
+  }
+  int join(hipStream_t main_st) {
+    if (!forked) return 0;
+    hipError_t e = hipEventRecord(ev[MAX_FORKS], side);
+    if (e == hipSuccess) e = hipStreamWaitEvent(main_st, ev[MAX_FORKS], 0);
+    if (e != hipSuccess) { set_error("join: %s", hipGetErrorString(e)); return (int)e; }
+    forked = false;
+    return 0;
+  }
   int flush(hipStream_t st) {
     for (size_t i = 0; i < segs.size(); i += RED_MAX_SEG) {
       RedJob<double> job{};
@@ -69,6 +96,29 @@ struct Deferred {
     return 0;
   }
 };
+
+// events for Deferred::fork_flush, created on first use (outside any capture: NativeTrainStep warms the step up eagerly
+// before it captures) and kept for the life of the process
+hipEvent_t* fork_events() {
+  static hipEvent_t pool[16][Deferred::MAX_FORKS + 1];
+  static bool ready[16] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  if (!ready[dev]) {
+    for (int i = 0; i <= Deferred::MAX_FORKS; ++i)
+      if (hipEventCreateWithFlags(&pool[dev][i], hipEventDisableTiming) != hipSuccess) return nullptr;
+    ready[dev] = true;
+  }
+  return pool[dev];
+}
+int attach_side(Deferred& dq, void* side_stream) {
+  if (!side_stream) return 0;
+  dq.ev = fork_events();
+  LGN_CHECK_ARG(dq.ev, "step: could not create the events of the forked reductions");
+  dq.side = (hipStream_t)side_stream;
+  if (const char* e = getenv("LGN_AMD_MAX_FORKS")) dq.max_forks = atoi(e) < Deferred::MAX_FORKS ? atoi(e) : Deferred::MAX_FORKS;
+  return 0;
+}
 
 int mlp_psize(int C, int H, int nlin) {
   const int D = 2 * C;
@@ -181,7 +231,7 @@ int levels_fwd(const lgn_net_desc& d, bool dec, const int* ch, const double* P, 
 // scalars never reach the loss).  On exit gs[cur]/gv[cur] hold the gradient w.r.t. level 0.
 int levels_bwd(const lgn_net_desc& d, bool dec, const int* ch, const double* P, double* G, const int64_t* off, const NetBuf& n,
                const double* pos, const uint8_t* mask, Work& w, Deferred& dq, RadFinJob& fin, int& cur, bool has_s_grad,
-               hipStream_t st) {
+               hipStream_t st, bool fork_last = false) {
   const Slots S{d.n_levels, d.mlp_nlin};
   const int BN = d.B * d.N;
   for (int l = d.n_levels - 1; l >= 0; --l) {
@@ -227,6 +277,9 @@ int levels_bwd(const lgn_net_desc& d, bool dec, const int* ch, const double* P, 
     }
     cur = nxt;
     has_s_grad = true;       // the level input scalars do carry gradient
+    // this level's partial rows (and whatever was pending) are reduced on the side stream while the next level runs; the
+    // very last level of the step keeps its rows for the closing flush on the main stream
+    if (l > 0 || fork_last) LGN_TRY(dq.fork_flush(st));
   }
   return 0;
 }
@@ -656,7 +709,7 @@ GenStep carve_gen_step(const lgn_net_desc& d, double* base) {
 
 int gen_step_fwd_bwd(const lgn_net_desc& d, const double* params, double* grads, long long n_params, const int64_t* enc_off,
                      const int64_t* dec_off, const double* p4, const double* target, const uint8_t* mask, double* workspace,
-                     long long workspace_doubles, double* recon, double* loss_part, hipStream_t st) {
+                     long long workspace_doubles, double* recon, double* loss_part, hipStream_t st, void* side_stream) {
   LGN_CHECK_ARG(is_generic(d, false) && is_generic(d, true), "step: encoder and decoder must both be table-driven (or both fused)");
   if (int rc = check_generic(d, false)) return rc;
   if (int rc = check_generic(d, true)) return rc;
@@ -676,6 +729,7 @@ int gen_step_fwd_bwd(const lgn_net_desc& d, const double* params, double* grads,
   Deferred dq;
   dq.parts = g.ds.parts;
   dq.cap = g.ds.parts_size;
+  LGN_TRY(attach_side(dq, side_stream));
   RadFinJob fin{};
   {
     DQ_NEW(part, (size_t)B * 2 * CL);
@@ -685,10 +739,17 @@ int gen_step_fwd_bwd(const lgn_net_desc& d, const double* params, double* grads,
   std::vector<UnpackJob> post;
   LGN_TRY(gen_decoder_bwd(d, params, grads, dec_off, g.lat_v, g.da, g.g_lat_v, g.ds, dq, fin, post, st));
   LGN_CHECK_ARG(dq.off <= dq.cap, "step: partial-row workspace overflow (%zu > %zu)", dq.off, dq.cap);
-  LGN_TRY(dq.flush(st));
-  LGN_TRY(run_unpack_jobs(post, st));
+  // the decoder's reductions (+ the unpacking of its packed CatMix gradients) run on the side stream beside the encoder backward
+  if (dq.side) {
+    LGN_TRY(dq.fork_flush(st));
+    LGN_TRY(run_unpack_jobs(post, dq.side));
+  } else {
+    LGN_TRY(dq.flush(st));
+    LGN_TRY(run_unpack_jobs(post, st));
+  }
   // the decoder never reads the latent scalars: no gradient on them
   LGN_TRY(gen_encoder_bwd(d, params, grads, enc_off, p4, mask, g.ea, nullptr, g.g_lat_v, g.es, st));
+  LGN_TRY(dq.join(st));
   return 0;
 }
 
@@ -974,14 +1035,14 @@ long long lgn_step_workspace_doubles(const lgn_net_desc* d) {
 
 int lgn_step_fwd_bwd_f64(const lgn_net_desc* d, const double* params, double* grads, long long n_params, const int64_t* enc_off,
                          const int64_t* dec_off, const double* p4, const double* target, const uint8_t* mask, double* workspace,
-                         long long workspace_doubles, double* recon, double* loss_part, void* stream) {
+                         long long workspace_doubles, double* recon, double* loss_part, void* stream, void* side_stream) {
   if (int rc = check_desc(d)) return rc;
   LGN_CHECK_ARG(params && grads && enc_off && dec_off && p4 && target && mask && workspace && recon && loss_part && n_params > 0,
                 "step_fwd_bwd: null pointer");
   hipStream_t st = (hipStream_t)stream;
   if (is_generic(*d, false) || is_generic(*d, true))
     return gen_step_fwd_bwd(*d, params, grads, n_params, enc_off, dec_off, p4, target, mask, workspace, workspace_doubles, recon,
-                            loss_part, st);
+                            loss_part, st, side_stream);
   Work w = carve(*d, workspace);
   // the layout depends on run-time switches (LGN_AMD_DEC_PAIRWISE / LGN_AMD_LEVEL_V2 change the partial-row counts):
   // refuse before anything is enqueued if the caller sized the workspace under different settings
@@ -1010,6 +1071,7 @@ int lgn_step_fwd_bwd_f64(const lgn_net_desc* d, const double* params, double* gr
   Deferred dq;
   dq.parts = w.parts;
   dq.cap = w.parts_size;
+  LGN_TRY(attach_side(dq, side_stream));
   RadFinJob fin{};
 
   // ---------------- forward ----------------
@@ -1029,7 +1091,8 @@ int lgn_step_fwd_bwd_f64(const lgn_net_desc* d, const double* params, double* gr
     LGN_TRY(dec_output_loss(B, N, cd[L], w.dec.v[L], params + dec_off[S.out0(true) + 1], target, 1.0, recon, loss_part, w.gv[cur], part, st));
     dq.add(part, B, 2 * cd[L], 0, 2 * cd[L], grads + dec_off[S.out0(true) + 1]);
   }
-  LGN_TRY(levels_bwd(*d, true, cd, params, grads, dec_off, w.dec, w.pdec, nullptr, w, dq, fin, cur, /*has_s_grad=*/false, st));
+  LGN_TRY(levels_bwd(*d, true, cd, params, grads, dec_off, w.dec, w.pdec, nullptr, w, dq, fin, cur, /*has_s_grad=*/false, st,
+                     /*fork_last=*/true));
   {
     const int C0 = cd[0], Tin = 2 * Tv, row = 4 * C0 + 2 * N * Tin;
     const int CL = ce[L], rowe = 2 * (Ts + Tv) * CL;
@@ -1057,7 +1120,8 @@ int lgn_step_fwd_bwd_f64(const lgn_net_desc* d, const double* params, double* gr
     dq.add(part, B, 4 * C0, 2 * C0, 2 * C0, grads + enc_off[1]);
   }
   LGN_CHECK_ARG(dq.off <= dq.cap, "step: partial-row workspace overflow (%zu > %zu)", dq.off, dq.cap);
-  LGN_TRY(dq.flush(st));                       // every batch reduction of the step, in one or two launches
+  LGN_TRY(dq.flush(st));                       // what the last level and the input layer produced (all of it without a side stream)
+  LGN_TRY(dq.join(st));
   LGN_TRY(rad_finalize_batch(fin, st));
   return 0;
 }

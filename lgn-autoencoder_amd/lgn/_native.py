@@ -84,7 +84,7 @@ _SIGNATURES.update({
     "lgn_local_bwd_static_f64": [_i] * 4 + [_vp] * 3 + [_ip] + [_vp] * 8,
     "lgn_local_bwd_f64": [_i] * 5 + [_tp] + [_vp] * 8,
     "lgn_step_param_slots": [_dp, _i],
-    "lgn_step_fwd_bwd_f64": [_dp, _vp, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _vp, _vp],
+    "lgn_step_fwd_bwd_f64": [_dp, _vp, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _vp, _vp, _vp],
     "lgn_encoder_fwd_f64": [_dp, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _vp, _vp],
     "lgn_encoder_bwd_f64": [_dp, _vp, _vp, _ll, _vp, _vp, _vp, _vp, _ll, _vp, _vp, _vp, _ll, _vp],
     "lgn_decoder_fwd_f64": [_dp, _vp, _vp, _vp, _vp, _ll, _vp, _vp],

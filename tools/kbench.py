@@ -28,7 +28,7 @@ def main():
     g = torch.Generator().manual_seed(1)
     decoder = what.endswith("_dec")
     net = dec if decoder else enc
-    lvl = 2 if not decoder else 0            # C=4 -> 4 level
+    lvl = int(os.environ.get("KB_LEVEL", 2 if not decoder else 0))            # default: the C=4 -> 4 level
     C, CO = net.num_channels[lvl], net.num_channels[lvl + 1]
     s = torch.randn(2, B, N, C, dtype=torch.float64, generator=g).to(dev)
     v = torch.randn(2, B, N, C, 4, dtype=torch.float64, generator=g).to(dev)
