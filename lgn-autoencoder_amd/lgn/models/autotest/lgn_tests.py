@@ -89,10 +89,16 @@ def get_output(encoder, decoder, data):
     return decoder(latent, covariance_test=True, nodes_all=nodes)
 
 
-def node_dev(a, b, eps=1e-16, mode="mean"):
+REFERENCE_IRREPS = ((0, 0), (1, 1))        # what the reference's get_node_dev measures, whatever maxdim (autotest/utils.py:22-45)
+
+
+def node_dev(a, b, eps=1e-16, mode="mean", irreps=REFERENCE_IRREPS):
+    """irreps='all': every irrep both GVecs carry -- at maxdim 3 the internal features also have (2,0), (0,2), (2,2), which
+    the reference rotates (rotate_rep) but never compares."""
+    ws = [w for w in a.keys() if w in b.keys()] if irreps == "all" else list(irreps)
     if mode == "max":
-        return {w: ((a[w] - b[w]) / (b[w] + eps)).abs().max().item() for w in [(0, 0), (1, 1)]}
-    return {w: abs((a[w] - b[w]).mean().item() / (b[w].mean().item() + eps)) for w in [(0, 0), (1, 1)]}
+        return {w: ((a[w] - b[w]) / (b[w] + eps)).abs().max().item() for w in ws}
+    return {w: abs((a[w] - b[w]).mean().item() / (b[w].mean().item() + eps)) for w in ws}
 
 
 def _angles(kind, value, axis):
@@ -101,7 +107,7 @@ def _angles(kind, value, axis):
 
 
 @torch.no_grad()
-def covariance_test(encoder, decoder, data, test_type, axis="z", alpha_max=None, cg_dict=None, unit="GeV"):
+def covariance_test(encoder, decoder, data, test_type, axis="z", alpha_max=None, cg_dict=None, unit="GeV", irreps=REFERENCE_IRREPS):
     cg_dict = encoder.cg_dict if cg_dict is None else cg_dict
     data = dict(data)
     data["p4"] = data["p4"].to(encoder.device, encoder.dtype)
@@ -123,7 +129,7 @@ def covariance_test(encoder, decoder, data, test_type, axis="z", alpha_max=None,
         out_in, nodes_in = get_output(encoder, decoder, moved)                  # transform, then network
         out_rot = rotate_rep(ref_out, *ang, cg_dict)                            # network, then transform
         dev_output.append(node_dev(out_in, out_rot))
-        dev_internal.append([node_dev(a, rotate_rep(b, *ang, cg_dict)) for a, b in zip(nodes_in, ref_nodes)])
+        dev_internal.append([node_dev(a, rotate_rep(b, *ang, cg_dict), irreps=irreps) for a, b in zip(nodes_in, ref_nodes)])
     if kind == "boost":
         return {"gammas": [cosh(x) for x in grid], "boost_dev_output": dev_output, "boost_dev_internal": dev_internal}
     return {"thetas": grid, "rot_dev_output": dev_output, "rot_dev_internal": dev_internal}
@@ -158,16 +164,18 @@ def _avg(dicts):
 
 
 @torch.no_grad()
-def lgn_tests(args, encoder, decoder, dataloader, axis="z", alpha_max=None, theta_max=None, cg_dict=None, unit="GeV"):
-    """Same call shape and result keys as the reference's lgn_tests (lgn_tests.py:292-423); prints plain tables."""
+def lgn_tests(args, encoder, decoder, dataloader, axis="z", alpha_max=None, theta_max=None, cg_dict=None, unit="GeV",
+              irreps=REFERENCE_IRREPS):
+    """Same call shape and result keys as the reference's lgn_tests (lgn_tests.py:292-423); prints plain tables.
+    irreps='all' extends the internal-feature tables to every irrep of the level (extension: see node_dev)."""
     t0 = time.time()
     logging.info("Covariance test begins...")
     encoder.eval(); decoder.eval()
     boosts, rots, pinv, pequi = [], [], [], []
     max_batches = getattr(args, "num_test_batch", -1) if args is not None else -1
     for idx, data in enumerate(dataloader):
-        boosts.append(covariance_test(encoder, decoder, data, "boost", axis, alpha_max, cg_dict, unit))
-        rots.append(covariance_test(encoder, decoder, data, "rotation", axis, theta_max, cg_dict, unit))
+        boosts.append(covariance_test(encoder, decoder, data, "boost", axis, alpha_max, cg_dict, unit, irreps))
+        rots.append(covariance_test(encoder, decoder, data, "rotation", axis, theta_max, cg_dict, unit, irreps))
         a, b = permutation_invariance_test(encoder, decoder, data)
         pinv.append(a); pequi.append(b)
         if max_batches and max_batches > 0 and idx + 1 >= max_batches:

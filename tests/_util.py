@@ -54,3 +54,21 @@ def assert_rep_close(rep, ref, tol, what="", check_order=True):
         assert set(rep.keys()) == set(ref.keys())
     for k in ref.keys():
         assert_close(rep[k], ref[k], tol, f"{what}{k}")
+
+
+class OracleNet:
+    """Gives the oracle (CPU restatement of the reference) the module call shape the equivariance harness expects."""
+
+    def __init__(self, O, P, cfg, decoder, cg, maxdim=2):
+        self.O, self.P, self.cfg, self.decoder = O, P, cfg, decoder
+        self.maxdim, self.device, self.dtype, self.cg_dict = maxdim, torch.device("cpu"), torch.float64, cg
+
+    def eval(self):
+        return self
+
+    def __call__(self, data, covariance_test=False, nodes_all=None):
+        O = self.O
+        if not self.decoder:
+            return O.encoder_forward(self.P, self.cfg, data["p4"], data.get("labels"), covariance_test=True)
+        gen, nodes = O.decoder_forward(self.P, self.cfg, data, covariance_test=True)
+        return gen, list(nodes_all) + nodes

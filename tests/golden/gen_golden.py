@@ -19,6 +19,9 @@ Fixtures
   g5_tables.npz       CGDict(maxdim=3) coefficient tables (dense) + LorentzD matrices
   g6_e2e_mix.npz      end-to-end, B=3 N=12 maxdim=2 ch 2233/3322, map_to_latent='mix' (learned mixing over particles)
   g7_e2e_meanmax.npz  end-to-end, B=3 N=12, map_to_latent=mean+max
+  g8_harness.npz      the reference's own equivariance harness (lgn/models/autotest/lgn_tests.py:292-423) run on the g1 weights
+                      (maxdim 2) and the g2 weights (maxdim 3): gamma / theta grids, output and internal-feature deviation
+                      tables, permutation results, on fixed zero-padded jets (SURVEY 8c "G6 harness")
 
 `python gen_golden.py g6 g7` regenerates only the named fixtures.
 """
@@ -235,6 +238,37 @@ def tables():
     print("g5_tables.npz", len(store))
 
 
+def harness():
+    """The reference's lgn_tests on fixed weights and jets.  unit='TeV': the 'GeV' branch divides data['p4'] in place, once per
+    covariance_test call (lgn_tests.py:94-96), so its tables depend on how often the loader's tensors were seen."""
+    from lgn.models.autotest.lgn_tests import lgn_tests
+    store = {}
+    args = types.SimpleNamespace(num_test_batch=-1)
+    for tag, (N, maxdim, che, chd, seed) in {"g1": (30, 2, (3, 3, 4, 4), (4, 4, 3, 3), 0),
+                                             "g2": (30, 3, (4, 4, 6, 6), (6, 6, 4, 4), 1)}.items():
+        enc, dec = build(N, maxdim, che, chd, seed)                  # == the weights stored in the g1 / g2 fixtures
+        p4, labels = jets(6, N, 21 + maxdim, pad_rows=((1, 12), (4, 23)))
+        store[f"{tag}.p4"], store[f"{tag}.labels"] = npy(p4), npy(labels)
+        torch.manual_seed(1234)                                      # randperm of the permutation test
+        res = lgn_tests(args, enc, dec, [{"p4": p4.clone(), "labels": labels.clone()}], unit="TeV")
+        store[f"{tag}.gammas"] = np.array(res["gammas"], dtype=np.float64)
+        store[f"{tag}.thetas"] = np.array(res["thetas"], dtype=np.float64)
+        irreps = [(0, 0), (1, 1)]                                    # what get_node_dev measures (autotest/utils.py:22-45)
+        for kind in ("boost", "rot"):
+            out = res[f"{kind}_dev_output"]
+            store[f"{tag}.{kind}_dev_output"] = np.array([[d[w] for w in irreps] for d in out], dtype=np.float64)
+            inner = res[f"{kind}_dev_internal"]
+            store[f"{tag}.{kind}_dev_internal"] = np.array([[[d[w] for w in irreps] for d in layer] for layer in inner], dtype=np.float64)
+        store[f"{tag}.perm_invariance"] = np.array([res["perm_invariance_dev_output"][w] for w in irreps], dtype=np.float64)
+        store[f"{tag}.perm_equivariance"] = np.array([res["perm_equivariance_dev_output"][w] for w in irreps], dtype=np.float64)
+        print(tag, "harness: max rot dev", store[f"{tag}.rot_dev_output"].max(), "max boost dev", store[f"{tag}.boost_dev_output"].max(),
+              "internal shape", store[f"{tag}.rot_dev_internal"].shape)
+    store["meta"] = np.array(json.dumps(dict(unit="TeV", irreps=[[0, 0], [1, 1]], perm_seed=1234,
+                                             note="tables of the reference's lgn_tests; rows = 26 alphas, internal [alpha][layer][irrep]")))
+    np.savez_compressed(os.path.join(OUT, "g8_harness.npz"), **store)
+    print("g8_harness.npz", len(store))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     only = set(sys.argv[1:])
@@ -251,5 +285,7 @@ if __name__ == "__main__":
         tables()
     if want("g6"):
         e2e("g6_e2e_mix.npz", 3, 12, 2, (2, 2, 3, 3), (3, 3, 2, 2), seed=3, pad_rows=((1, 8),), map_to_latent="mix")
+    if want("g8"):
+        harness()
     if want("g7"):
         e2e("g7_e2e_meanmax.npz", 3, 12, 2, (2, 2, 3, 3), (3, 3, 2, 2), seed=4, pad_rows=((2, 9),), map_to_latent="mean+max")
