@@ -94,10 +94,12 @@ REFERENCE_IRREPS = ((0, 0), (1, 1))        # what the reference's get_node_dev m
 
 def node_dev(a, b, eps=1e-16, mode="mean", irreps=REFERENCE_IRREPS):
     """irreps='all': every irrep both GVecs carry -- at maxdim 3 the internal features also have (2,0), (0,2), (2,2), which
-    the reference rotates (rotate_rep) but never compares."""
+    the reference rotates (rotate_rep) but never compares (used with mode='maxnorm' for the extended tables)."""
     ws = [w for w in a.keys() if w in b.keys()] if irreps == "all" else list(irreps)
     if mode == "max":
         return {w: ((a[w] - b[w]) / (b[w] + eps)).abs().max().item() for w in ws}
+    if mode == "maxnorm":     # max |a - b| / max |b|: well defined for the traceless irreps, whose MEAN is ~0 (the reference's
+        return {w: ((a[w] - b[w]).abs().max() / (b[w].abs().max() + eps)).item() for w in ws}     # metric is 0/0 noise there)
     return {w: abs((a[w] - b[w]).mean().item() / (b[w].mean().item() + eps)) for w in ws}
 
 
@@ -120,7 +122,7 @@ def covariance_test(encoder, decoder, data, test_type, axis="z", alpha_max=None,
         alpha_max = 10.0 if kind == "boost" else 2 * np.pi
     grid = np.arange(0, alpha_max + 0.01, step=alpha_max / 25.0)
     ref_out, ref_nodes = get_output(encoder, decoder, data)
-    dev_output, dev_internal = [], []
+    dev_output, dev_internal, dev_all = [], [], []
     for value in grid:
         ang = _angles("boost" if kind == "boost" else "rot", value, axis)
         R = cartesian_lorentz(lorentz_D((1, 1), *ang, cg_dict, dtype=encoder.dtype, device=encoder.device))
@@ -129,10 +131,14 @@ def covariance_test(encoder, decoder, data, test_type, axis="z", alpha_max=None,
         out_in, nodes_in = get_output(encoder, decoder, moved)                  # transform, then network
         out_rot = rotate_rep(ref_out, *ang, cg_dict)                            # network, then transform
         dev_output.append(node_dev(out_in, out_rot))
-        dev_internal.append([node_dev(a, rotate_rep(b, *ang, cg_dict), irreps=irreps) for a, b in zip(nodes_in, ref_nodes)])
+        moved_nodes = [rotate_rep(b, *ang, cg_dict) for b in ref_nodes]
+        dev_internal.append([node_dev(a, b) for a, b in zip(nodes_in, moved_nodes)])
+        if irreps == "all":
+            dev_all.append([node_dev(a, b, mode="maxnorm", irreps="all") for a, b in zip(nodes_in, moved_nodes)])
+    extra = {f"{kind}_dev_internal_all": dev_all} if irreps == "all" else {}
     if kind == "boost":
-        return {"gammas": [cosh(x) for x in grid], "boost_dev_output": dev_output, "boost_dev_internal": dev_internal}
-    return {"thetas": grid, "rot_dev_output": dev_output, "rot_dev_internal": dev_internal}
+        return {"gammas": [cosh(x) for x in grid], "boost_dev_output": dev_output, "boost_dev_internal": dev_internal, **extra}
+    return {"thetas": grid, "rot_dev_output": dev_output, "rot_dev_internal": dev_internal, **extra}
 
 
 @torch.no_grad()
@@ -167,7 +173,8 @@ def _avg(dicts):
 def lgn_tests(args, encoder, decoder, dataloader, axis="z", alpha_max=None, theta_max=None, cg_dict=None, unit="GeV",
               irreps=REFERENCE_IRREPS):
     """Same call shape and result keys as the reference's lgn_tests (lgn_tests.py:292-423); prints plain tables.
-    irreps='all' extends the internal-feature tables to every irrep of the level (extension: see node_dev)."""
+    irreps='all' adds the tables ``boost_dev_internal_all`` / ``rot_dev_internal_all``: EVERY irrep of every internal GVec with
+    the max-norm deviation (extension: see node_dev); the reference-shaped tables are unchanged."""
     t0 = time.time()
     logging.info("Covariance test begins...")
     encoder.eval(); decoder.eval()
@@ -187,6 +194,9 @@ def lgn_tests(args, encoder, decoder, dataloader, axis="z", alpha_max=None, thet
         n_layers = len(runs[0][f"{key}_dev_internal"][0])
         res[f"{name}_dev_internal"] = [[_avg([r[f"{key}_dev_internal"][i][l] for r in runs]) for l in range(n_layers)]
                                        for i in range(n_alpha)]
+        if f"{key}_dev_internal_all" in runs[0]:
+            res[f"{name}_dev_internal_all"] = [[_avg([r[f"{key}_dev_internal_all"][i][l] for r in runs]) for l in range(n_layers)]
+                                               for i in range(n_alpha)]
     res["perm_invariance_dev_output"] = _avg(pinv)
     res["perm_equivariance_dev_output"] = _avg(pequi)
     print(f"Covariance test completed! Time taken: {round((time.time() - t0) / 60, 2)} min")

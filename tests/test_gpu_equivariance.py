@@ -47,12 +47,13 @@ def test_equivariance_harness_native_vs_reference_tables(tag):
     # deviation is rounding noise that grows like eps * gamma^2 and scatters by an order of magnitude from one gamma to the
     # next, so a point passes if it is within 20x of the reference's value at the same point OR under the smooth envelope.
     irreps = [(0, 0), (1, 1)]
-    floor = 1e-13 if maxdim == 2 else 1e-11
+    floor = 1e-13 if maxdim == 2 else 1e-10      # (maxdim 3: the reference's own rotation table scatters between 1e-12 and 6e-10)
     for kind, xs in (("rot", np.ones(26)), ("boost", gam)):
         ref = h[f"{tag}.{kind}_dev_output"]
         for row, (a, gm) in enumerate(zip(res[f"{kind}_dev_output"], xs)):
             for col, irrep in enumerate(irreps):
-                bound = max(20 * max(ref[row][col], floor), floor + (1e-14 if maxdim == 2 else 1e-12) * float(gm) ** 2)
+                # (envelope: the reference's own table reaches 2.4e-14 gamma^2 at gamma = 7382 for maxdim 2)
+                bound = max(20 * max(ref[row][col], floor), floor + (5e-14 if maxdim == 2 else 1e-12) * float(gm) ** 2)
                 assert a[irrep] <= bound, f"{tag} {kind} output {irrep} gamma={float(gm):.4g}: native {a[irrep]:.2e} vs reference {ref[row][col]:.2e}"
         # internal features of every layer: the reference's two irreps against its table ...
         ref_i = h[f"{tag}.{kind}_dev_internal"]
@@ -62,17 +63,22 @@ def test_equivariance_harness_native_vs_reference_tables(tag):
                 for col, irrep in enumerate(irreps):
                     bound = max(50 * max(ref_i[row][layer][col], floor), 100 * (floor + 1e-12 * float(gm) ** 2))
                     assert d[irrep] <= bound, f"{tag} {kind} internal layer {layer} {irrep} gamma={float(gm):.4g}: {d[irrep]:.2e} vs {ref_i[row][layer][col]:.2e}"
-                # ... and every OTHER irrep the level carries (maxdim 3: (2,0), (0,2), (2,2); the reference rotates them but never
-                # compares them): rotations to 5e-8, boosts up to gamma = 10 to 1e-6
+        # ... and EVERY irrep the level carries (maxdim 3: also (2,0), (0,2), (2,2); the reference rotates them but never compares
+        # them, and its mean-based metric is 0/0 for the traceless ones) with the max-norm deviation.  Limits = 20x what the CPU path
+        # (oracle) shows on the same jets (2.5e-9 for rotations) -- the input scalars sqrt|p^2| of near-massless particles are
+        # cancellation noise (layer 0, up to 6e-8 on the GPU box) -- and 2e-7 + 1e-10 gamma^2 for boosts up to gamma = 1000
+        for per_alpha, gm in zip(res[f"{kind}_dev_internal_all"], xs):
+            for layer, d in enumerate(per_alpha):
                 for irrep, v in d.items():
-                    if irrep in irreps:
-                        continue
                     if kind == "rot":
-                        assert v <= 5e-8, f"{tag} rotation internal layer {layer} {irrep}: {v:.2e}"
-                    elif gm <= 10.0:
-                        assert v <= 1e-6, f"{tag} boost internal layer {layer} {irrep} gamma={float(gm):.3g}: {v:.2e}"
+                        assert v <= 2e-7, f"{tag} rotation internal layer {layer} {irrep}: {v:.2e}"
+                    elif gm <= 1000.0:
+                        # (layer 0 = the network INPUT: its scalars sqrt|p^2| are computed from the boosted momenta of nearly
+                        # massless particles before any kernel runs, noise ~ 5e-9 gamma^2 on either path)
+                        lim = 1e-7 * max(1.0, float(gm) ** 2) if layer == 0 else 2e-7 + 1e-10 * float(gm) ** 2
+                        assert v <= lim, f"{tag} boost internal layer {layer} {irrep} gamma={float(gm):.3g}: {v:.2e}"
     if maxdim == 3:
-        seen = {irrep for per_alpha in res["rot_dev_internal"] for d in per_alpha for irrep in d}
+        seen = {irrep for per_alpha in res["rot_dev_internal_all"] for d in per_alpha for irrep in d}
         assert {(2, 0), (0, 2), (2, 2)} <= seen, f"the maxdim-3 internal features were not all checked: {sorted(seen)}"
     assert max(res["perm_invariance_dev_output"].values()) <= 1e-10
     print(tag, "max rot dev native / reference:", max(max(d[w] for w in irreps) for d in res["rot_dev_output"]), h[f"{tag}.rot_dev_output"].max())
