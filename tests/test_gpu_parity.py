@@ -237,7 +237,10 @@ def _build(meta, dev):
 
 @pytest.mark.parametrize("decoder", [False, True])
 @pytest.mark.parametrize("maxdim,full,C,CO,N,B", [(3, True, 4, 6, 30, 2), (3, False, 4, 4, 30, 2), (3, True, 6, 4, 13, 1),
-                                                  (2, False, 3, 4, 30, 2), (3, True, 2, 3, 5, 1)])
+                                                  (2, False, 3, 4, 30, 2), (3, True, 2, 3, 5, 1),
+                                                  # natural dispatch beyond the channel-outermost moments kernels (N <= 32) and the
+                                                  # tile-blocked separable decoder kernels (N <= 64)
+                                                  (3, True, 4, 6, 40, 1), (3, False, 4, 4, 48, 2), (3, True, 3, 4, 70, 1)])
 def test_generic_level_fwd_bwd(dev, O, decoder, maxdim, full, C, CO, N, B):
     """Table-driven level (moments + sparse CG + CatMix) for arbitrary irreps vs the oracle's cg_product /
     CatMixReps, forward and all gradients.  `full`: the node carries all five maxdim=3 irreps."""

@@ -240,8 +240,14 @@ def test_module_api_training_loop_matches_native_step():
     U.assert_close(torch.cat([enc.flat_params.detach(), dec.flat_params.detach()]), ref.flat.flat, 1e-9, "parameters after 3 steps")
 
 
-@pytest.mark.parametrize("N", [13, 32])
-def test_native_step_maxdim3_other_shapes_match_per_op_path(N):
+WIDE = ((2, 4, 7, 8), (8, 6, 5, 3))
+CFG5 = ((4, 4, 6, 6), (6, 6, 4, 4))
+NARROW = ((3, 3, 4, 4), (4, 4, 3, 3))
+
+
+# 40, 70: beyond the tile-blocked kernels (N <= 32) -- node-major layouts, all-channels-in-flight moments kernels
+@pytest.mark.parametrize("N,chans", [(13, WIDE), (32, WIDE), (40, WIDE), (70, NARROW)])
+def test_native_step_maxdim3_other_shapes_match_per_op_path(N, chans):
     """Table-driven native step at shapes the golden fixture does not have -- channel counts 2..8 (every padded output width of
     the compile-time-table kernels, both level kinds), jets of 13 and of 32 particles (tiles of 64 nodes cut jets at other
     places, the last tile partly empty), zero-padded jets -- against the per-operator module path (each operator oracle-tested
@@ -250,12 +256,13 @@ def test_native_step_maxdim3_other_shapes_match_per_op_path(N):
     from lgn.step import NativeTrainStep, TrainStep
     from oracle import lgn_oracle as O
     dev = torch.device("cuda:0")
-    enc, dec = G._models(N, (2, 4, 7, 8), (8, 6, 5, 3), dev, seed=5, maxdim=3)
-    enc2, dec2 = G._models(N, (2, 4, 7, 8), (8, 6, 5, 3), dev, seed=5, maxdim=3)
+    enc, dec = G._models(N, chans[0], chans[1], dev, seed=5, maxdim=3)
+    enc2, dec2 = G._models(N, chans[0], chans[1], dev, seed=5, maxdim=3)
     enc2.use_fused = dec2.use_fused = False
-    p4, labels = O.synthetic_jets(5, N, seed=4, pad=True)
+    B = 5 if N <= 40 else 2
+    p4, labels = O.synthetic_jets(B, N, seed=4, pad=True)
     batch = {"p4": p4.to(dev), "labels": labels.to(dev)}
-    a = NativeTrainStep(enc, dec, batch_size=5, optimizer=False, use_graph=False)
+    a = NativeTrainStep(enc, dec, batch_size=B, optimizer=False, use_graph=False)
     b = TrainStep(enc2, dec2, optimizer=False)
     la, ra = a.step(batch)
     lb, rb = b.forward_backward(batch)
@@ -317,6 +324,22 @@ def test_deepcopy_of_a_network_that_has_run():
             enc.flat_params.zero_(); dec.flat_params.zero_()          # the copies must not look at the originals
         r1 = dec2(enc2(batch)).detach()
         assert torch.equal(r0, r1)
+
+
+def test_native_step_maxdim3_refuses_jets_that_do_not_fit_lds():
+    """The table-driven kernels keep a jet's packed features in LDS (N * C * Q * 16 B and the gradient beside it): 70 particles
+    with cfg5's 6 channels do not fit 160 KiB (4 channels do: the case above).  The call must come back with an explicit error
+    that names the limit -- no launch with a truncated jet."""
+    import __graft_entry__ as G
+    from lgn.step import NativeTrainStep
+    from oracle import lgn_oracle as O
+    dev = torch.device("cuda:0")
+    enc, dec = G._models(70, CFG5[0], CFG5[1], dev, seed=5, maxdim=3)
+    p4, labels = O.synthetic_jets(2, 70, seed=4, pad=True)
+    a = NativeTrainStep(enc, dec, batch_size=2, optimizer=False, use_graph=False)
+    with pytest.raises(RuntimeError, match=r"LDS \(> 160 KiB\)"):
+        a.step({"p4": p4.to(dev), "labels": labels.to(dev)})
+    torch.cuda.synchronize()
 
 
 @pytest.mark.parametrize("maxdim,ch_enc,ch_dec", [(2, (3, 3, 4, 4), (4, 4, 3, 3)), (3, (4, 4, 6, 6), (6, 6, 4, 4))])
