@@ -362,13 +362,16 @@ def test_end_to_end_vs_reference_golden(dev, O, name, fused):
                 U.assert_close(got, ref, GRAD_TOL, f"grad {pre}.{k}")
 
 
-def test_full_size_batch_properties(dev, O):
-    """BASELINE cfg2 size (bs=512, N=30): jets are independent graphs, so (1) any jet's output inside the big
-    batch equals its output in a batch of its own, (2) permuting the jets permutes the outputs, and
-    (3) parameter gradients of the batch equal the sum of gradients of its two halves (the loss is a sum)."""
+@pytest.mark.parametrize("name,B,N,maxdim,che,chd", [("cfg2", 512, 30, 2, (3, 3, 4, 4), (4, 4, 3, 3)),
+                                                     ("cfg4", 256, 150, 2, (3, 3, 4, 4), (4, 4, 3, 3)),
+                                                     ("cfg5", 512, 30, 3, (4, 4, 6, 6), (6, 6, 4, 4))])
+def test_full_size_batch_properties(dev, O, name, B, N, maxdim, che, chd):
+    """BASELINE sizes (cfg2: bs=512 N=30; cfg4: bs=256 N=150; cfg5: bs=512 maxdim=3): jets are independent graphs, so
+    (1) any jet's output inside the big batch equals its output in a batch of its own, (2) permuting the jets permutes the
+    outputs, and (3) parameter gradients of the batch equal the sum of gradients of its two halves (the loss is a sum)."""
     import __graft_entry__ as G
-    enc, dec = G._models(30, (3, 3, 4, 4), (4, 4, 3, 3), dev, seed=5)
-    p4, labels = O.synthetic_jets(512, 30, seed=9, pad=True)
+    enc, dec = G._models(N, che, chd, dev, seed=5, maxdim=maxdim)
+    p4, labels = O.synthetic_jets(B, N, seed=9, pad=True)
     p4d = p4.to(dev)
 
     def run(idx):
@@ -381,19 +384,19 @@ def test_full_size_batch_properties(dev, O):
                            for m in (enc, dec) for p in m.parameters()])
         return rec.detach(), loss.detach(), grads
 
-    all_idx = torch.arange(512)
+    all_idx = torch.arange(B)
     rec, loss, grads = run(all_idx)
     assert torch.isfinite(rec).all() and torch.isfinite(grads).all()
-    sub = torch.tensor([0, 17, 255, 511])
+    sub = torch.tensor([0, 17, B // 2 - 1, B - 1])
     rec_s, _, _ = run(sub)
     assert (rec[:, sub.to(dev)] - rec_s).abs().max().item() <= 1e-13 * rec.abs().max().item()
-    perm = torch.randperm(512, generator=torch.Generator().manual_seed(1))
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(1))
     rec_p, loss_p, grads_p = run(perm)
     assert (rec[:, perm.to(dev)] - rec_p).abs().max().item() <= 1e-13 * rec.abs().max().item()
     U.assert_close(loss_p, loss, 1e-12, "loss under jet permutation")
     U.assert_close(grads_p, grads, 1e-9, "grads under jet permutation")
-    _, l1, g1 = run(all_idx[:256])
-    _, l2, g2 = run(all_idx[256:])
+    _, l1, g1 = run(all_idx[:B // 2])
+    _, l2, g2 = run(all_idx[B // 2:])
     U.assert_close(l1 + l2, loss, 1e-12, "loss additivity")
     U.assert_close(g1 + g2, grads, 1e-9, "gradient additivity over jets")
 

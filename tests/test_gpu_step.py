@@ -105,17 +105,21 @@ def test_native_adam_matches_torch_adam_and_modular_path():
     assert int(a.step_dev.item()) == 3
 
 
-def test_native_step_full_size_properties():
-    """cfg2 size (bs=512): the fused step agrees with the module/autograd path on the same weights."""
+@pytest.mark.parametrize("name,B,N,maxdim,che,chd", [("cfg2", 512, 30, 2, (3, 3, 4, 4), (4, 4, 3, 3)),
+                                                     ("cfg4", 256, 150, 2, (3, 3, 4, 4), (4, 4, 3, 3)),
+                                                     ("cfg5", 512, 30, 3, (4, 4, 6, 6), (6, 6, 4, 4))])
+def test_native_step_full_size_properties(name, B, N, maxdim, che, chd):
+    """BASELINE sizes (cfg2, cfg4, cfg5): the graph-replayed native step agrees with the module / autograd path on the same
+    weights (which the tests of test_gpu_parity.py tie to the oracle and to the reference's golden vectors)."""
     import __graft_entry__ as G
     from lgn.step import NativeTrainStep, TrainStep
     from oracle import lgn_oracle as O
     dev = torch.device("cuda:0")
-    enc, dec = G._models(30, (3, 3, 4, 4), (4, 4, 3, 3), dev, seed=11)
-    enc2, dec2 = G._models(30, (3, 3, 4, 4), (4, 4, 3, 3), dev, seed=11)
-    p4, labels = O.synthetic_jets(512, 30, seed=4, pad=True)
+    enc, dec = G._models(N, che, chd, dev, seed=11, maxdim=maxdim)
+    enc2, dec2 = G._models(N, che, chd, dev, seed=11, maxdim=maxdim)
+    p4, labels = O.synthetic_jets(B, N, seed=4, pad=True)
     batch = {"p4": p4.to(dev), "labels": labels.to(dev)}
-    a = NativeTrainStep(enc, dec, batch_size=512, optimizer=False, use_graph=True)
+    a = NativeTrainStep(enc, dec, batch_size=B, optimizer=False, use_graph=True)
     b = TrainStep(enc2, dec2, optimizer=False)
     la, ra = a.step(batch)
     lb, rb = b.forward_backward(batch)
@@ -324,6 +328,31 @@ def test_deepcopy_of_a_network_that_has_run():
             enc.flat_params.zero_(); dec.flat_params.zero_()          # the copies must not look at the originals
         r1 = dec2(enc2(batch)).detach()
         assert torch.equal(r0, r1)
+
+
+@pytest.mark.parametrize("maxdim,che,chd", [(2, (3, 3, 4, 4), (4, 4, 3, 3)), (3, (4, 4, 6, 6), (6, 6, 4, 4))])
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_native_step_forked_reductions_are_bit_identical(monkeypatch, maxdim, che, chd, use_graph):
+    """LGN_AMD_FORK=1: the batch reductions of the parameter gradients run on a second stream beside the backward kernels
+    (events owned by the library; a branch of the graph under capture).  Same kernels, same summation order: the step must
+    equal the single-stream step bit for bit, eagerly and replayed."""
+    import __graft_entry__ as G
+    from lgn.step import NativeTrainStep
+    from oracle import lgn_oracle as O
+    dev = torch.device("cuda:0")
+    p4, labels = O.synthetic_jets(6, 30, seed=8, pad=True)
+    batch = {"p4": p4.to(dev), "labels": labels.to(dev)}
+    outs = []
+    for fork in ("0", "1"):
+        monkeypatch.setenv("LGN_AMD_FORK", fork)
+        enc, dec = G._models(30, che, chd, dev, seed=3, maxdim=maxdim)
+        st = NativeTrainStep(enc, dec, batch_size=6, lr=5e-4, l1_lambda=1e-8, use_graph=use_graph)
+        assert (st._side is not None) == (fork == "1")
+        losses = [float(st.step(batch)[0]) for _ in range(3)]
+        torch.cuda.synchronize()
+        outs.append((losses, st.flat.flat.clone(), st.flat.grad_buf.clone()))
+    assert outs[0][0] == outs[1][0]
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
 
 
 def test_native_step_maxdim3_refuses_jets_that_do_not_fit_lds():
