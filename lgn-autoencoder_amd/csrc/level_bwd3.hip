@@ -580,12 +580,15 @@ __global__ __launch_bounds__(BLOCK) void level_bwd3_kernel(LevelBwdArgs<double> 
         q[2] = {d3, 0.0};
         q[3] = {-d1 * h, -d2 * h};
         qd0 = d0;  qd3 = d3;  qa = d1 * h;  qb = d2 * h;
-        double beta[5];
+        double beta[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int s = 0; s < 5; ++s) {
-          const double r = fast_rcp((1.0 + ck2[s] * an) + 1e-16);
-          rho[s] = on ? r : 0.0;
-          beta[s] = on ? __builtin_fma(bk[s], r, ak[s]) : 0.0;
+        for (int s = 0; s < 5; ++s) rho[s] = 0.0;
+        if (on) {                                            // (EXEC-masked block: no per-value selects)
+#pragma unroll
+          for (int s = 0; s < 5; ++s) {
+            rho[s] = fast_rcp((1.0 + ck2[s] * an) + 1e-16);
+            beta[s] = __builtin_fma(bk[s], rho[s], ak[s]);
+          }
         }
 #pragma unroll
         for (int g = 0; g < NG; ++g) {

@@ -261,12 +261,10 @@ __global__ __launch_bounds__(2 * BLOCK) void level_fwd2_kernel(LevelArgs<double>
         const bool on = T.ok && mi && (mk[T.jj] != 0) && (nsq != 0.0);
         const double h = rsqrt2<double>();
         T.qd0 = d0;  T.qd3 = d3;  T.qa = d1 * h;  T.qb = d2 * h;
-        double beta[5];
+        double beta[5] = {0.0, 0.0, 0.0, 0.0, 0.0};          // masked edge: basis zeroed, Linear bias survives
+        if (on) {                                            // (EXEC-masked block: no per-value selects)
 #pragma unroll
-        for (int s = 0; s < 5; ++s) {
-          const double u = (1.0 + ck2[s] * an) + 1e-16;
-          const double bv = __builtin_fma(bk[s], fast_rcp(u), ak[s]);
-          beta[s] = on ? bv : 0.0;                           // masked edge: basis zeroed, Linear bias survives
+          for (int s = 0; s < 5; ++s) beta[s] = __builtin_fma(bk[s], fast_rcp((1.0 + ck2[s] * an) + 1e-16), ak[s]);
         }
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
