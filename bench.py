@@ -117,26 +117,32 @@ def time_dominant_kernel(enc, batch, reps=20):
     p = batch["p4"].to(dev).contiguous()
     mask = batch["labels"].to(dev).contiguous()
 
-    # forward (the loop also allocates 4 output tensors per call from torch's caching allocator: no device sync)
-    us_fwd = _events_us(lambda: Nn.level_fwd(False, s, v, p, mask, rad, wm0, wm1), reps)
+    # forward and backward through the C ABI on preallocated buffers with pre-marshalled arguments: the loop's host time per
+    # call stays below the kernel's duration (at 64 jets the kernels take < 20 us)
+    L = Nn.lib()
+    a, b, c, w0, b0, w1, b1 = rad
+    P = Nn.ptr
     ag0, ag1, so, vo = Nn.level_fwd(False, s, v, p, mask, rad, wm0, wm1)
+    fargs = (B, N, Cc, CO, 0, P(s), P(v), P(p), P(mask), P(a), P(b), P(c), P(w0), P(b0), P(w1), P(b1), P(wm0), P(wm1),
+             P(ag0), P(ag1), P(so), P(vo), Nn.stream_ptr())
+
+    def fwd():
+        Nn._check(L.lgn_level_fwd_f64(*fargs), "lgn_level_fwd_f64")
+
+    us_fwd = _events_us(fwd, reps)
     gs = torch.randn(so.shape, dtype=torch.float64, generator=g).to(dev)
     gv = torch.randn(vo.shape, dtype=torch.float64, generator=g).to(dev)
-    L = Nn.lib()
     rm, rr = C.c_int(), C.c_int()
     Nn._check(L.lgn_level_bwd_partial_rows(B, N, 0, C.byref(rm), C.byref(rr)), "lgn_level_bwd_partial_rows")
     part_mix = torch.empty(rm.value, 4 * CO * 5 * Cc, device=dev, dtype=torch.float64)
     part_rad = torch.empty(rr.value, L.lgn_level_rad_partial_len(Cc, 0), device=dev, dtype=torch.float64)
     g_ag = torch.empty(B, N, 20 * Cc, device=dev, dtype=torch.float64)
     g_s_in, g_v_in = torch.empty_like(s), torch.empty_like(v)
-    a, b, c, w0, b0, w1, b1 = rad
-    P = Nn.ptr
+    bargs = (B, N, Cc, CO, 0, P(s), P(v), P(p), P(mask), P(a), P(b), P(c), P(w0), P(b0), P(w1), P(b1), P(wm0), P(wm1), P(ag0), P(ag1),
+             P(gs), P(gv), P(g_ag), P(g_s_in), P(g_v_in), P(None), P(part_mix), P(part_rad), Nn.stream_ptr())
 
     def bwd():
-        rc = L.lgn_level_bwd_f64(B, N, Cc, CO, 0, P(s), P(v), P(p), P(mask), P(a), P(b), P(c), P(w0), P(b0), P(w1), P(b1),
-                                 P(wm0), P(wm1), P(ag0), P(ag1), P(gs), P(gv), P(g_ag), P(g_s_in), P(g_v_in), P(None),
-                                 P(part_mix), P(part_rad), Nn.stream_ptr())
-        Nn._check(rc, "lgn_level_bwd_f64")
+        Nn._check(L.lgn_level_bwd_f64(*bargs), "lgn_level_bwd_f64")
 
     us_bwd = _events_us(bwd, reps)
     fwd_flops = B * level_fwd_flops(N, Cc, CO, False)

@@ -75,4 +75,16 @@ __host__ __device__ constexpr int rad_partial_size(int C, bool dec) {
   return dec ? 2 * C : (2 * 4 * C * NB + 8 * C);
 }
 
+// Workgroups per jet of the pair-sweep level kernels for jets of <= 40 particles (level_fwd2.hip, level_bwd3.hip).  A jet is
+// one workgroup whose waves each sweep a group of 4 particles against the whole jet; with 512 jets that fills the chip (two
+// workgroups per CU), with 64 jets three quarters of the CUs idle while each busy one works through a whole jet (31 us for the
+// backward whatever the batch).  Small batches therefore give the groups of a jet to several workgroups -- every one stages the
+// jet, sweeps its own groups and writes its own rows of the outputs and its own partial rows of the parameter gradients.
+inline int level_jet_split(int B, int N) {
+  const int groups = (N + 3) / 4;
+  int s = 1;
+  while (s * 2 <= groups && B * s * 2 <= 512) s *= 2;
+  return s;
+}
+
 }  // namespace lgn

@@ -440,9 +440,10 @@ static bool use_v3(int N) {   // single-kernel backward (default when the jet fi
 // number of partial rows the backward launch writes (host side must size the workspace with these)
 void level_bwd_partial_rows(int B, int N, int decoder, int* rows_mix, int* rows_rad) {
   const int tiles = cdiv(N, 32);
-  if (use_v3(N)) {                       // level_bwd3: one partial row per jet for both
-    *rows_mix = B;
-    *rows_rad = B;
+  if (use_v3(N)) {                       // level_bwd3: one partial row per workgroup for both (small batches: several per jet)
+    const int split = (decoder && !dec_pairwise()) ? 1 : level_jet_split(B, N);
+    *rows_mix = B * split;
+    *rows_rad = B * split;
     return;
   }
   *rows_mix = B * tiles;

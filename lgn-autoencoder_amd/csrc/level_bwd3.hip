@@ -54,16 +54,19 @@ LGN_STAMP_DECL
 }  // namespace
 LGN_STAMP_READER(lgn_debug_stamps_bwd3)
 
-template <int C, bool DEC>
+// NWV = waves per workgroup (4; 8 was measured for small batches: 31 -> 28.5 us at 64 jets -- a lone workgroup already keeps
+// its CU's SIMDs two thirds busy, the idle CUs are what a small batch wastes: level_jet_split spreads a jet over several CUs)
+template <int C, bool DEC, int NWV = 4>
 struct Bwd3 {
+  static constexpr int BLK = 64 * NWV;
   static constexpr int NG = (C + 3) / 4;
   static constexpr int NS = node_stride(C);
   static constexpr int PS = DEC ? 8 : 4;
-  static constexpr int TRSZ = DEC ? 4 * 64 : (4 * (NG + 3) * 16 * TS > 4 * 64 * NG * 12 ? 4 * (NG + 3) * 16 * TS : 4 * 64 * NG * 12);
+  static constexpr int TRSZ = DEC ? NWV * 64 : (NWV * (NG + 3) * 16 * TS > NWV * 64 * NG * 12 ? NWV * (NG + 3) * 16 * TS : NWV * 64 * NG * 12);
   // phase-1 scratch (upstream gradient tile + CatMix weights) and phase-2 scratch (transpose tiles) share one region
   // phase 1: upstream gradient tile | CatMix weights | aggregate saved by the forward; then (aliased, after a barrier)
   // the per-part partial sums of the CatMix weight gradient
-  static constexpr int MIXP = BLOCK / (5 * C) < 16 ? BLOCK / (5 * C) : 16;   // node parts of the CatMix weight gradient
+  static constexpr int MIXP = BLK / (5 * C) < 16 ? BLK / (5 * C) : 16;       // node parts of the CatMix weight gradient
   __host__ __device__ static size_t scratch(int N, int CO) {
     size_t p1 = (size_t)N * 10 * CO + 4 * CO * 5 * C + (size_t)N * 20 * C;
     const size_t red = (size_t)MIXP * CO * 5 * C * 4;
@@ -82,13 +85,19 @@ struct Bwd3 {
 //   stage 1   per (node, channel): the node's terms of S, VS, SP, VP (forward) and of the sums of g_ag (backward)
 //   stage 2   per (channel, term): sum over the nodes in node order
 //   outputs   node gradient, position gradient and bias gradients from O(N C) closed forms.
-template <int C, bool DEC, bool SEP>
-__global__ __launch_bounds__(BLOCK) void level_bwd3_kernel(LevelBwdArgs<double> a) {
-  using F = Bwd3<C, DEC>;
+template <int C, bool DEC, bool SEP, int NWV>
+__global__ __launch_bounds__(64 * NWV) void level_bwd3_kernel(LevelBwdArgs<double> a) {
+  using F = Bwd3<C, DEC, NWV>;
+  constexpr int BLK = F::BLK;
   using G = GA3<C>;
   constexpr int NG = F::NG, NS = F::NS, PS = F::PS, K = 5 * C;
   const int N = a.N, B = a.B, CO = a.CO;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // this workgroup's share of the jet (level_jet_split): groups [glo, ghi) of 4 particles = nodes [nlo, nhi)
+  const int ngroups = (N + 3) >> 2, gper = (ngroups + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int glo = min(ngroups, (int)blockIdx.y * gper), ghi = min(ngroups, glo + gper);
+  const int nlo = min(N, 4 * glo), nhi = min(N, 4 * ghi);
+  const size_t prow = (size_t)b * gridDim.y + blockIdx.y;       // partial row of this workgroup
 
   extern __shared__ __align__(16) unsigned char smem_raw[];
   double* nd = reinterpret_cast<double*>(smem_raw);            // N * NS      node features entering the level
@@ -105,13 +114,13 @@ __global__ __launch_bounds__(BLOCK) void level_bwd3_kernel(LevelBwdArgs<double> 
   // ---------------- staging ----------------------------------------------------------------------------
   STAMP(0);
   load_jet<double, C, DEC>(a.s_in, a.v_in, a.p, a.mask, B, N, b, nd, pj, mk);
-  for (int e = tid; e < 2 * CO * K; e += BLOCK) {
+  for (int e = tid; e < 2 * CO * K; e += BLK) {
     wm[e] = a.wm0[e];
     wm[2 * CO * K + e] = a.wm1[e];
   }
   {
     const size_t plo = (size_t)B * N * CO;
-    for (int e = tid; e < N * CO; e += BLOCK) {
+    for (int e = tid; e < N * CO; e += BLK) {
       const size_t idx = (size_t)b * N * CO + e;
       double* g = go + e * 10;
       g[0] = a.g_s_out[idx];
@@ -123,7 +132,7 @@ __global__ __launch_bounds__(BLOCK) void level_bwd3_kernel(LevelBwdArgs<double> 
       }
     }
     const size_t pa = (size_t)B * N * 2 * C;
-    for (int e = tid; e < N * 2 * C; e += BLOCK) {
+    for (int e = tid; e < N * 2 * C; e += BLK) {
       const size_t ea = (size_t)b * N * 2 * C + e;
       double* x = agl + e * 10;
       x[0] = a.ag0[ea];
@@ -141,8 +150,8 @@ __global__ __launch_bounds__(BLOCK) void level_bwd3_kernel(LevelBwdArgs<double> 
   // ---------------- phase 1a: per (node, channel) CatMix^H, power backward ---------------------------------
   // waves 0,1: aggregate blocks (cat slots q = 0,1) -> g_ag;  waves 2,3: node + power blocks (q = 2,3,4) -> direct part
   {
-    const int half = tid >> 7;
-    for (int e = tid & 127; e < N * C; e += 128) {
+    const int half = tid >= BLK / 2;
+    for (int e = half ? tid - BLK / 2 : tid; e < N * C; e += BLK / 2) {
       const int n = e / C, c = e - n * C;
       const double* w0r = wm + c;                          // [z][o][k]: + (z * CO + o) * K + q * C
       const double* w1r = wm + 2 * CO * K + c;
@@ -223,17 +232,17 @@ __global__ __launch_bounds__(BLOCK) void level_bwd3_kernel(LevelBwdArgs<double> 
   // lane = (node part, cat slot k): builds the slot's cat entry x of each of its nodes once and updates all out
   // channels; the parts' sums meet in LDS in a fixed order (deterministic)
   {
-    double* part = a.part_mix + (size_t)b * (4 * CO * K);
+    double* part = a.part_mix + prow * (4 * CO * K);
     constexpr int NPART = F::MIXP;
-    const int OK = CO * K, nper = (N + NPART - 1) / NPART;
+    const int OK = CO * K, nper = (nhi - nlo + NPART - 1) / NPART;
     const int pi = tid / K, k = tid - pi * K;
     cx<double> d0[8], d1[8];
 #pragma unroll
     for (int o = 0; o < 8; ++o) d0[o] = d1[o] = {0, 0};
     if (pi < NPART) {
       const int q = k / C, c = k - q * C;
-      const int n1 = min(N, (pi + 1) * nper);
-      for (int n = pi * nper; n < n1; ++n) {
+      const int n1 = min(nhi, nlo + (pi + 1) * nper);
+      for (int n = nlo + pi * nper; n < n1; ++n) {
         cx<double> x0, x1[4];
         if (q < 2) {                                  // aggregate blocks, saved by the forward
           const double* x = agl + (n * 2 * C + k) * 10;
@@ -281,7 +290,7 @@ __global__ __launch_bounds__(BLOCK) void level_bwd3_kernel(LevelBwdArgs<double> 
     STAMP(50);
     __syncthreads();
     STAMP(51);
-    for (int e = tid; e < OK; e += BLOCK) {
+    for (int e = tid; e < OK; e += BLK) {
       double v[4];
 #pragma unroll
       for (int x = 0; x < 4; ++x) v[x] = red[e * 4 + x];
@@ -311,7 +320,7 @@ __global__ __launch_bounds__(BLOCK) void level_bwd3_kernel(LevelBwdArgs<double> 
       if (part == 0) sm[k] = mean / N;
     }
     __syncthreads();
-    for (int e = tid; e < N * 8; e += BLOCK) pj[e] -= sm[e & 7];
+    for (int e = tid; e < N * 8; e += BLK) pj[e] -= sm[e & 7];
     __syncthreads();
     // ---- jet-level sums, three rounds of <= 20 reals per (node, channel) through the scratch region -----------
     //   sm[c*50 + ..]: S 0 | VS[m] 2+2m | SP[m] 10+2m | VP 18 | SG4 20 | SG3 22 | SG1[m] 24+2m | SG2[m] 32+2m | GP2 40 | GP3[m] 42+2m
@@ -319,7 +328,7 @@ __global__ __launch_bounds__(BLOCK) void level_bwd3_kernel(LevelBwdArgs<double> 
 #pragma unroll
     for (int round = 0; round < 3; ++round) {
       const int nv = round == 2 ? 10 : 20;
-      for (int e = tid; e < N * C; e += BLOCK) {
+      for (int e = tid; e < N * C; e += BLK) {
         const int n = e / C, c = e - n * C;
         const double* ni = nd + n * NS + c * 10;
         const double* pn = pj + n * 8;
@@ -376,7 +385,7 @@ __global__ __launch_bounds__(BLOCK) void level_bwd3_kernel(LevelBwdArgs<double> 
     STAMP(5);
     // ---- node gradient: neighbour part from the sums + direct part, written once --------------------------------
     const size_t pls = (size_t)B * N * C;
-    for (int e = tid; e < N * C; e += BLOCK) {
+    for (int e = tid; e < N * C; e += BLK) {
       const int n = e / C, c = e - n * C;
       const double* q = sm + c * 50;
       const double* pn = pj + n * 8;
@@ -420,7 +429,7 @@ __global__ __launch_bounds__(BLOCK) void level_bwd3_kernel(LevelBwdArgs<double> 
     // ---- position gradient: d p_n[m] += sum_c conj(R1) [ gA2_n[m] conj(S) + gA3_n conj(VSt[m]) - SG2[m] conj(s_n) - SG3 conj(vt_n[m]) ]
     {
       const size_t plp = (size_t)B * N * 4;
-      for (int e = tid; e < N * 4; e += BLOCK) {
+      for (int e = tid; e < N * 4; e += BLK) {
         const int n = e >> 2, m = e & 3;
         const int mp = m == 1 ? 3 : (m == 3 ? 1 : m);      // metric_perm index; component 2 changes sign
         const double sg = m == 2 ? -1.0 : 1.0;
@@ -523,8 +532,7 @@ __global__ __launch_bounds__(BLOCK) void level_bwd3_kernel(LevelBwdArgs<double> 
     for (int t = 0; t < 3; ++t) T[g][t] = v4d{0, 0, 0, 0};
   }
   const size_t pls = (size_t)B * N * C;
-  const int ngroups = (N + 3) >> 2;
-  for (int rg = wave; rg < ngroups; rg += 4) {
+  for (int rg = glo + wave; rg < ghi; rg += NWV) {
     const int j = rg * 4 + tj;
     const bool jok = j < N;
     const int jj = jok ? j : N - 1;
@@ -553,7 +561,7 @@ __global__ __launch_bounds__(BLOCK) void level_bwd3_kernel(LevelBwdArgs<double> 
     for (int m = 0; m < 4; ++m) Gq[m] = {0, 0};
 
     for (int i0 = 0; i0 < N; i0 += 4) {
-      if (rg == 0 && i0 < 32) STAMP(16 + (i0 >> 2) * 4);
+      if (rg == glo && i0 < 32) STAMP(16 + (i0 >> 2) * 4);
       const int i = i0 + ti;
       const bool ok = jok && i < N;
       const int ii = i < N ? i : N - 1;
@@ -612,7 +620,7 @@ __global__ __launch_bounds__(BLOCK) void level_bwd3_kernel(LevelBwdArgs<double> 
         xb[32 * TS + pr * TS + 8 + 2 * cg] = cg == 0 ? (on ? 1.0 : 0.0) : 0.0;
         xb[32 * TS + pr * TS + 9 + 2 * cg] = cg == 0 ? (ok ? 1.0 : 0.0) : 0.0;
       }
-      if (rg == 0 && i0 < 32) STAMP(17 + (i0 >> 2) * 4);
+      if (rg == glo && i0 < 32) STAMP(17 + (i0 >> 2) * 4);
       const double* gi = ga + ii * G::SIZE;
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
@@ -692,7 +700,7 @@ __global__ __launch_bounds__(BLOCK) void level_bwd3_kernel(LevelBwdArgs<double> 
           ta[pr * TS + 12 + cg] = G1i;
         }
       }
-      if (rg == 0 && i0 < 32) STAMP(18 + (i0 >> 2) * 4);
+      if (rg == glo && i0 < 32) STAMP(18 + (i0 >> 2) * 4);
       if (!DEC) {
         wave_sync();
         const double* xb = trw + NG * 16 * TS;
@@ -713,7 +721,7 @@ __global__ __launch_bounds__(BLOCK) void level_bwd3_kernel(LevelBwdArgs<double> 
       }
     }
 
-    if (rg == 0) STAMP(6);
+    if (rg == glo) STAMP(6);
     // node gradient of the wave's 4 particles: neighbour part (quad sum over the i slots) + direct part, written once
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
@@ -755,7 +763,7 @@ __global__ __launch_bounds__(BLOCK) void level_bwd3_kernel(LevelBwdArgs<double> 
   if (DEC) {
     const int ti2 = pr >> 2, tj2 = pr & 3;
     const size_t plp = (size_t)B * N * 4;
-    for (int rg = wave; rg < ngroups; rg += 4) {
+    for (int rg = glo + wave; rg < ghi; rg += NWV) {
       const int i = rg * 4 + ti2;
       const bool iok = i < N;
       const int ii = iok ? i : N - 1;
@@ -804,7 +812,7 @@ __global__ __launch_bounds__(BLOCK) void level_bwd3_kernel(LevelBwdArgs<double> 
   STAMP(8);
   __syncthreads();
   STAMP(9);
-  double* part = a.part_rad + (size_t)blockIdx.x * rad_partial_size(C, DEC);
+  double* part = a.part_rad + prow * rad_partial_size(C, DEC);
   if (DEC) {
     double* red = tr;
 #pragma unroll
@@ -820,7 +828,7 @@ __global__ __launch_bounds__(BLOCK) void level_bwd3_kernel(LevelBwdArgs<double> 
     if (tid < 2 * C) {
       const int lin = tid / C, ch = tid - lin * C, g = ch >> 2, c4 = ch & 3;
       double s = 0;
-      for (int w = 0; w < 4; ++w) s += red[(w * NG + g) * 8 + lin * 4 + c4];
+      for (int w = 0; w < NWV; ++w) s += red[(w * NG + g) * 8 + lin * 4 + c4];
       part[tid] = s;
     }
   } else {
@@ -846,8 +854,11 @@ __global__ __launch_bounds__(BLOCK) void level_bwd3_kernel(LevelBwdArgs<double> 
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int e = (g * 3 + t) * 4 + q;
-            const double v = (red[(size_t)(0 * 64 + lane) * NG * 12 + e] + red[(size_t)(1 * 64 + lane) * NG * 12 + e]) +
-                             (red[(size_t)(2 * 64 + lane) * NG * 12 + e] + red[(size_t)(3 * 64 + lane) * NG * 12 + e]);
+            double v = (red[(size_t)(0 * 64 + lane) * NG * 12 + e] + red[(size_t)(1 * 64 + lane) * NG * 12 + e]) +
+                       (red[(size_t)(2 * 64 + lane) * NG * 12 + e] + red[(size_t)(3 * 64 + lane) * NG * 12 + e]);
+            if (NWV == 8)
+              v += (red[(size_t)(4 * 64 + lane) * NG * 12 + e] + red[(size_t)(5 * 64 + lane) * NG * 12 + e]) +
+                   (red[(size_t)(6 * 64 + lane) * NG * 12 + e] + red[(size_t)(7 * 64 + lane) * NG * 12 + e]);
             if (ch >= C) continue;
             const int r = (q >> 1) * 2 * C + 2 * ch + (q & 1);
             if (t == 0) part[r * NB + col] = v;
@@ -867,16 +878,21 @@ __global__ __launch_bounds__(BLOCK) void level_bwd3_kernel(LevelBwdArgs<double> 
 
 bool level_bwd3_fits(int N) { return N <= 40; }
 
-template <int C, bool DEC, bool SEP>
-static int launch_bwd3(const LevelBwdArgs<double>& a, hipStream_t stream) {
-  const size_t smem = Bwd3<C, DEC>::smem(a.N, a.CO);
+template <int C, bool DEC, bool SEP, int NWV>
+static int launch_bwd3_w(const LevelBwdArgs<double>& a, int split, hipStream_t stream) {
+  const size_t smem = Bwd3<C, DEC, NWV>::smem(a.N, a.CO);
   LGN_CHECK_ARG(smem <= 160 * 1024, "level_bwd: N=%d C=%d needs %zu B of LDS", a.N, a.C, smem);
   LGN_CHECK_ARG(a.CO <= 8, "level_bwd: C_out=%d unsupported (1..8)", a.CO);
-  auto kern = level_bwd3_kernel<C, DEC, SEP>;
+  auto kern = level_bwd3_kernel<C, DEC, SEP, NWV>;
   if (smem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  hipLaunchKernelGGL(kern, dim3(a.B), dim3(BLOCK), smem, stream, a);
+  hipLaunchKernelGGL(kern, dim3(a.B, split), dim3(64 * NWV), smem, stream, a);
   LGN_CHECK_LAUNCH();
   return 0;
+}
+template <int C, bool DEC, bool SEP>
+static int launch_bwd3(const LevelBwdArgs<double>& a, hipStream_t stream) {
+  // small batches: several workgroups per jet (level.hpp: level_jet_split); the separable decoder form has no sweep to split
+  return launch_bwd3_w<C, DEC, SEP, 4>(a, SEP ? 1 : level_jet_split(a.B, a.N), stream);
 }
 
 // whole level backward in one launch; one CatMix partial row and one radial partial row per jet

@@ -178,9 +178,12 @@ __global__ __launch_bounds__(2 * BLOCK) void level_fwd2_kernel(LevelArgs<double>
     __syncthreads();
   }
 
-  // rows are processed in chunks of `chunk` (a multiple of 16; the whole jet when it fits the LDS budget)
-  for (int c0 = 0; c0 < N; c0 += chunk) {
-  const int c1 = min(N, c0 + chunk);
+  // this workgroup's share of the jet's rows (level.hpp: level_jet_split; the whole jet unless the batch is small), processed
+  // in chunks of `chunk` rows (a multiple of 16; all of them when they fit the LDS budget)
+  const int ngroups = (N + 3) >> 2, gper = (ngroups + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int rlo = min(N, 4 * (int)blockIdx.y * gper), rhi = min(N, rlo + 4 * gper);
+  for (int c0 = rlo; c0 < rhi; c0 += chunk) {
+  const int c1 = min(rhi, c0 + chunk);
   if constexpr (DEC && SEP) {
     for (int e = tid; e < (c1 - c0) * C; e += nthr) {
       const int rl = e / C, c = e - rl * C, n = c0 + rl;
@@ -460,7 +463,7 @@ __global__ __launch_bounds__(2 * BLOCK) void level_fwd2_kernel(LevelArgs<double>
     }
   }
   STAMP(22);
-  if (c1 < N) __syncthreads();                           // the chunk's aggregate rows are reused
+  if (c1 < rhi) __syncthreads();                         // the chunk's aggregate rows are reused
   }
   STAMP(40);
 }
@@ -491,7 +494,9 @@ static int launch_level_fwd2(const LevelArgs<double>& a, hipStream_t stream) {
   }
   // 8 waves per jet when the batch has no more jets than the chip has CUs and the jet has enough row groups (cfg4)
   const int nthreads = wide ? 2 * BLOCK : BLOCK;
-  hipLaunchKernelGGL(kern, dim3(a.B), dim3(nthreads), smem, stream, a, chunk);
+  // small batches of small jets: several workgroups per jet, each with its own rows (level.hpp: level_jet_split)
+  const int split = (SEP || a.N > 40) ? 1 : level_jet_split(a.B, a.N);
+  hipLaunchKernelGGL(kern, dim3(a.B, split), dim3(nthreads), smem, stream, a, chunk);
   LGN_CHECK_LAUNCH();
   return 0;
 }
