@@ -113,14 +113,46 @@ __global__ __launch_bounds__(64 * NWV) void level_bwd3_kernel(LevelBwdArgs<doubl
 
   // ---------------- staging ----------------------------------------------------------------------------
   STAMP(0);
-  load_jet<double, C, DEC>(a.s_in, a.v_in, a.p, a.mask, B, N, b, nd, pj, mk);
-  for (int e = tid; e < 2 * CO * K; e += BLK) {
-    wm[e] = a.wm0[e];
-    wm[2 * CO * K + e] = a.wm1[e];
-  }
+  // Every thread's first item of every array is requested before anything is written to LDS (see load_jet_issue): the jet, the
+  // upstream gradient, the saved aggregate and the CatMix weights arrive in ONE memory round trip instead of six.
   {
-    const size_t plo = (size_t)B * N * CO;
-    for (int e = tid; e < N * CO; e += BLK) {
+    const size_t plo = (size_t)B * N * CO, pa = (size_t)B * N * 2 * C;
+    JetRegs<double> jr;
+    load_jet_issue<double, C, DEC>(a.s_in, a.v_in, a.p, a.mask, B, N, b, jr);
+    const int eg = tid < N * CO ? tid : 0, ea_ = tid < N * 2 * C ? tid : 0, ew = tid < 2 * CO * K ? tid : 0;
+    const size_t ig = (size_t)b * N * CO + eg, ia = (size_t)b * N * 2 * C + ea_;
+    double rg[10], ra[10];
+    rg[0] = a.g_s_out[ig];
+    rg[1] = a.g_s_out[plo + ig];
+    ra[0] = a.ag0[ia];
+    ra[1] = a.ag0[pa + ia];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      rg[2 + m] = a.g_v_out[ig * 4 + m];
+      rg[6 + m] = a.g_v_out[plo * 4 + ig * 4 + m];
+      ra[2 + m] = a.ag1[ia * 4 + m];
+      ra[6 + m] = a.ag1[(pa + ia) * 4 + m];
+    }
+    const double w0v = a.wm0[ew], w1v = a.wm1[ew];
+    load_jet_commit<double, C, DEC>(a.s_in, a.v_in, a.p, a.mask, B, N, b, jr, nd, pj, mk);
+    if (tid < N * CO) {
+#pragma unroll
+      for (int m = 0; m < 10; ++m) go[tid * 10 + m] = rg[m];
+    }
+    if (tid < N * 2 * C) {
+#pragma unroll
+      for (int m = 0; m < 10; ++m) agl[tid * 10 + m] = ra[m];
+    }
+    if (tid < 2 * CO * K) {
+      wm[tid] = w0v;
+      wm[2 * CO * K + tid] = w1v;
+    }
+    // remainders (more than one workgroup's worth of items: wide levels, jets of more than 32 particles)
+    for (int e = tid + BLK; e < 2 * CO * K; e += BLK) {
+      wm[e] = a.wm0[e];
+      wm[2 * CO * K + e] = a.wm1[e];
+    }
+    for (int e = tid + BLK; e < N * CO; e += BLK) {
       const size_t idx = (size_t)b * N * CO + e;
       double* g = go + e * 10;
       g[0] = a.g_s_out[idx];
@@ -131,8 +163,7 @@ __global__ __launch_bounds__(64 * NWV) void level_bwd3_kernel(LevelBwdArgs<doubl
         g[6 + m] = a.g_v_out[plo * 4 + idx * 4 + m];
       }
     }
-    const size_t pa = (size_t)B * N * 2 * C;
-    for (int e = tid; e < N * 2 * C; e += BLK) {
+    for (int e = tid + BLK; e < N * 2 * C; e += BLK) {
       const size_t ea = (size_t)b * N * 2 * C + e;
       double* x = agl + e * 10;
       x[0] = a.ag0[ea];

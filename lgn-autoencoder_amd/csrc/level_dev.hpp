@@ -22,39 +22,92 @@ struct Carve {
 // Cooperative load of one jet's node features / positions / mask into LDS.
 //   nd[j*NS + c*10 + {0: s_r, 1: s_i, 2..5: v_r[m], 6..9: v_i[m]}]
 //   pj[j*PS + ...]  encoder: (E,px,py,pz); decoder: q_r[4], q_i[4] (complex canonical)
+// Thread t takes item t of every array FIRST -- all its global loads are issued together (clamped addresses, no branches)
+// and only then written to LDS: one memory round trip for a 30-particle jet instead of one per array (a loop "load, store"
+// per array serialises the round trips: the stores of one loop wait for its loads before the next loop's loads are issued).
+// Items beyond the first BLOCK of an array (N C > 256) take the plain loops.
+template <typename T>
+struct JetRegs {
+  T s[2], v[8], p[2];
+  uint8_t m;
+};
+template <typename T, int C, bool DEC>
+__device__ __forceinline__ void load_jet_issue(const T* __restrict__ s_in, const T* __restrict__ v_in, const T* __restrict__ p,
+                                               const uint8_t* __restrict__ mask, int B, int N, int b, JetRegs<T>& r) {
+  const int tid = threadIdx.x;
+  const size_t plane_s = (size_t)B * N * C, plane_p = (size_t)B * N * 4;
+  const int e = tid < N * C ? tid : 0, ep = tid < N * 4 ? tid : 0, em = tid < N ? tid : 0;
+  const T* s0 = s_in + (size_t)b * N * C;
+  const T* v0 = v_in + (size_t)b * N * C * 4;
+  const T* p0 = p + (size_t)b * N * 4;
+  r.s[0] = s0[e];
+  r.s[1] = s0[plane_s + e];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    r.v[m] = v0[e * 4 + m];
+    r.v[4 + m] = v0[plane_s * 4 + e * 4 + m];
+  }
+  r.p[0] = p0[ep];
+  r.p[1] = DEC ? p0[plane_p + ep] : T(0);
+  r.m = DEC ? uint8_t(0) : mask[(size_t)b * N + em];
+}
+template <typename T, int C, bool DEC>
+__device__ __forceinline__ void load_jet_commit(const T* __restrict__ s_in, const T* __restrict__ v_in, const T* __restrict__ p,
+                                                const uint8_t* __restrict__ mask, int B, int N, int b, const JetRegs<T>& r,
+                                                T* nd, T* pj, uint8_t* mk) {
+  using L = Carve<C, DEC>;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const size_t plane_s = (size_t)B * N * C;
+  if (tid < N * C) {
+    const int j = tid / C, c = tid - j * C;
+    T* d = nd + j * L::NS + c * 10;
+    d[0] = r.s[0];
+    d[1] = r.s[1];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) d[2 + m] = r.v[m];
+  }
+  if (tid < N * 4) {
+    if (DEC) {
+      pj[(tid >> 2) * 8 + (tid & 3)] = r.p[0];
+      pj[(tid >> 2) * 8 + 4 + (tid & 3)] = r.p[1];
+    } else {
+      pj[tid] = r.p[0];
+    }
+  }
+  if (!DEC && tid < N) mk[tid] = r.m;
+  // remainder (jets with more than BLOCK items per array; also the second half of a 512-thread workgroup's share)
+  const T* s0 = s_in + (size_t)b * N * C;
+  const T* v0 = v_in + (size_t)b * N * C * 4;
+  for (int e = tid + nthr; e < N * C; e += nthr) {
+    int j = e / C, c = e - j * C;
+    T* d = nd + j * L::NS + c * 10;
+    d[0] = s0[e];
+    d[1] = s0[plane_s + e];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      d[2 + m] = v0[e * 4 + m];
+      d[6 + m] = v0[plane_s * 4 + e * 4 + m];
+    }
+  }
+  const T* p0 = p + (size_t)b * N * 4;
+  if (DEC) {
+    const size_t plane_p = (size_t)B * N * 4;
+    for (int e = tid + nthr; e < N * 4; e += nthr) {
+      pj[(e >> 2) * 8 + (e & 3)] = p0[e];
+      pj[(e >> 2) * 8 + 4 + (e & 3)] = p0[plane_p + e];
+    }
+  } else {
+    for (int e = tid + nthr; e < N * 4; e += nthr) pj[e] = p0[e];
+    for (int e = tid + nthr; e < N; e += nthr) mk[e] = mask[(size_t)b * N + e];
+  }
+}
 template <typename T, int C, bool DEC>
 __device__ __forceinline__ void load_jet(const T* __restrict__ s_in, const T* __restrict__ v_in,
                                          const T* __restrict__ p, const uint8_t* __restrict__ mask, int B, int N,
                                          int b, T* nd, T* pj, uint8_t* mk) {
-  using L = Carve<C, DEC>;
-  const int tid = threadIdx.x;
-  const size_t plane_s = (size_t)B * N * C;
-  const T* s0 = s_in + (size_t)b * N * C;
-  for (int e = tid; e < N * C; e += BLOCK) {
-    int j = e / C, c = e - j * C;
-    nd[j * L::NS + c * 10 + 0] = s0[e];
-    nd[j * L::NS + c * 10 + 1] = s0[plane_s + e];
-  }
-  const T* v0 = v_in + (size_t)b * N * C * 4;
-  for (int e = tid; e < N * C * 4; e += BLOCK) {
-    int jc = e >> 2, m = e & 3;
-    int j = jc / C, c = jc - j * C;
-    nd[j * L::NS + c * 10 + 2 + m] = v0[e];
-    nd[j * L::NS + c * 10 + 6 + m] = v0[plane_s * 4 + e];
-  }
-  if (DEC) {
-    const size_t plane_p = (size_t)B * N * 4;
-    const T* p0 = p + (size_t)b * N * 4;
-    for (int e = tid; e < N * 4; e += BLOCK) {
-      int j = e >> 2, m = e & 3;
-      pj[j * 8 + m] = p0[e];
-      pj[j * 8 + 4 + m] = p0[plane_p + e];
-    }
-  } else {
-    const T* p0 = p + (size_t)b * N * 4;
-    for (int e = tid; e < N * 4; e += BLOCK) pj[e] = p0[e];
-    for (int e = tid; e < N; e += BLOCK) mk[e] = mask[(size_t)b * N + e];
-  }
+  JetRegs<T> r;
+  load_jet_issue<T, C, DEC>(s_in, v_in, p, mask, B, N, b, r);
+  load_jet_commit<T, C, DEC>(s_in, v_in, p, mask, B, N, b, r, nd, pj, mk);
 }
 
 // Radial parameters -> LDS.  encoder: a,b,c, Wt[k][R] (transposed so that the R outputs of one basis

@@ -83,10 +83,20 @@ __global__ __launch_bounds__(2 * BLOCK) void level_fwd2_kernel(LevelArgs<double>
   uint8_t* mk = reinterpret_cast<uint8_t*>(sums + 20 * C);            // N
 
   STAMP(0);
-  load_jet<double, C, DEC>(a.s_in, a.v_in, a.p, a.mask, B, N, b, nd, pj, mk);
-  for (int e = tid; e < 2 * CO * 5 * C; e += nthr) {
-    wm[e] = a.wm0[e];
-    wm[2 * CO * 5 * C + e] = a.wm1[e];
+  {  // the jet and the CatMix weights in one memory round trip (level_dev.hpp: load_jet_issue)
+    JetRegs<double> jr;
+    load_jet_issue<double, C, DEC>(a.s_in, a.v_in, a.p, a.mask, B, N, b, jr);
+    const int nw2 = 2 * CO * 5 * C, ew = tid < nw2 ? tid : 0;
+    const double w0v = a.wm0[ew], w1v = a.wm1[ew];
+    load_jet_commit<double, C, DEC>(a.s_in, a.v_in, a.p, a.mask, B, N, b, jr, nd, pj, mk);
+    if (tid < nw2) {
+      wm[tid] = w0v;
+      wm[nw2 + tid] = w1v;
+    }
+    for (int e = tid + nthr; e < nw2; e += nthr) {
+      wm[e] = a.wm0[e];
+      wm[nw2 + e] = a.wm1[e];
+    }
   }
 
   // ---- per-lane constants ---------------------------------------------------------------------------
