@@ -4,8 +4,11 @@
 //   * NT = 4..6 N-tiles: a weight image is 34..75 KB, so it is single buffered and a layer costs two barriers
 //     (operands visible / all reads done) instead of one; the tiles need no ping-pong then either;
 //   * a workgroup runs 2 M-tiles x NT N-tiles = 8..12 waves (one 16x16 output tile per wave);
-//   * the backward keeps the 64-rows-per-partial-row contract of lgn_cgmlp_partial_rows (H > 48) by making two 32-row passes per
-//     workgroup, the second pass adding into the partial row the first one wrote.
+//   * the backward covers its workgroup's 64 rows in ONE pass: a wave owns the tiles (mp, nt) and (mp + 2, nt) of the four
+//     16-row M-tiles (two accumulation chains that share every weight fragment).  Round 2 made two 32-row passes, the second
+//     adding into the partial row the first had written: 450 MB of HBM traffic per launch at cfg5 (PMC, profiles/
+//     r03_pmc_cfg5.json) for 54 MB of partial rows, and every weight image staged twice.  The hidden activations of the
+//     recompute stay in registers (2 tiles x 6 layers; the LDS is taken by the 4 + 4 operand tiles of the weight gradient).
 #include "ops.hpp"
 
 namespace lgn {
@@ -32,13 +35,15 @@ struct Geo {
   static constexpr int NPF = (HP * 16 + THREADS - 1) / THREADS;   // passes for the first layer image (16 columns)
   static_assert(NPF <= NPH, "prefetch registers");
   static constexpr size_t fwd_doubles() { return WSIZE + MT * TSIZE + MT * T0SIZE; }
+  static constexpr int MTB = 4;                         // M-tiles of a backward workgroup (64 rows)
+  //                                          image   X, G tiles       input tiles    column sums
+  static constexpr size_t bwd_doubles() { return WSIZE + 2 * MTB * TSIZE + MTB * T0SIZE + MTB * HP; }
+  static constexpr bool ONE_PASS = sizeof(double) * (WSIZE + 2 * MTB * TSIZE + MTB * T0SIZE + MTB * HP) <= 160 * 1024;
+  // two-pass backward (NT = 6): the activations of the first NHL hidden layers stay in LDS tiles of their own
   static constexpr int BWD_BASE = WSIZE + 2 * MT * TSIZE + MT * T0SIZE + MT * HP;
-  // backward: the activations of the first NHL hidden layers stay in LDS tiles of their own (the LDS left over decides how
-  // many): they are the next layer's input in the recompute and the dW operand of the sweep as they lie, and the registers
-  // that would hold them until the sweep are free (the kernel is register bound: 10..12 waves -> 168 VGPRs)
   static constexpr int NHL_FIT = (160 * 1024 / 8 - BWD_BASE) / (MT * TSIZE);
   static constexpr int NHL = NHL_FIT > 5 ? 5 : NHL_FIT;
-  static constexpr size_t bwd_doubles() { return BWD_BASE + NHL * MT * TSIZE; }
+  static constexpr size_t bwd2p_doubles() { return BWD_BASE + NHL * MT * TSIZE; }
 };
 
 // ---- weight staging: thread-constant bases, wave-uniform strides (see mlp_mfma.hip) ---------------------------------
@@ -85,11 +90,11 @@ __device__ __forceinline__ void commit_first(double* Wl, const double (&regs)[Ge
   if ((int)threadIdx.x < G::HP) Wl[threadIdx.x * G::S + G::HP] = breg;
 }
 // rows of the scalar irrep [2][M][C] -> MT input tiles, feature k = 2c + z, zero padded to 16 columns
-template <int NT>
+template <int NT, int MTILES = MT>
 __device__ __forceinline__ void load_input_tiles(const double* __restrict__ s, int M, int C, int row0, double* X0) {
   using G = Geo<NT>;
   const int D = 2 * C;
-  for (int e = threadIdx.x; e < 16 * MT * 16; e += G::THREADS) {
+  for (int e = threadIdx.x; e < 16 * MTILES * 16; e += G::THREADS) {
     const int r = e >> 4, k = e & 15, row = row0 + r;
     X0[(r >> 4) * G::T0SIZE + (r & 15) * G::S0 + k] = (row < M && k < D) ? s[(size_t)(k & 1) * M * C + (size_t)row * C + (k >> 1)] : 0.0;
   }
@@ -164,8 +169,173 @@ __global__ __launch_bounds__(64 * MT * NT) void mlp_fwd_wide_kernel(MlpArgs<doub
   (void)S;
 }
 
+// pre-activations of the wave's two tiles (mp, nt) and (mp + 2, nt): bias + X W^T, every weight fragment used twice
+template <int NT>
+__device__ __forceinline__ void dense2(bool first, const double* Wl, const double* X0, const double* X, int mp, int nt, int lane, int ksh,
+                                       v4d& acc0, v4d& acc1) {
+  using G = Geo<NT>;
+  constexpr int S = G::S;
+  const int c = lane & 15, g = lane >> 4;
+  const double bias = Wl[(16 * nt + c) * S + G::HP];
+  acc0 = v4d{bias, bias, bias, bias};
+  acc1 = acc0;
+  const double* wb = Wl + (16 * nt + c) * S + g;
+  if (first) {
+    const double* xa = X0 + mp * G::T0SIZE + c * G::S0 + g;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const double w = wb[4 * s];
+      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[4 * s], w, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[2 * G::T0SIZE + 4 * s], w, acc1, 0, 0, 0);
+    }
+  } else {
+    const double* xa = X + mp * G::TSIZE + c * S + g;
+    for (int s = 0; s < ksh; ++s) {
+      const double w = wb[4 * s];
+      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[4 * s], w, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[2 * G::TSIZE + 4 * s], w, acc1, 0, 0, 0);
+    }
+  }
+}
+
 template <int NT, int NH>
 __global__ __launch_bounds__(64 * MT * NT) void mlp_bwd_wide_kernel(MlpArgs<double> a) {
+  using G = Geo<NT>;
+  constexpr int S = G::S, HP = G::HP, NW = MT * NT, MTB = G::MTB;
+  static_assert(MT == 2 && MTB == 4, "a wave owns M-tiles mp and mp + 2");
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int mp = wave % MT, nt = wave / MT;
+  const int c = lane & 15, g = lane >> 4;
+  const int D = 2 * a.C, H = a.H, M = a.M;
+  const int ksh = pad4(H) >> 2;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  double* Wl = reinterpret_cast<double*>(smem_raw);
+  double* X = Wl + G::WSIZE;                               // MTB layer-input tiles
+  double* Gt = X + MTB * G::TSIZE;                         // MTB g_pre tiles
+  double* X0 = Gt + MTB * G::TSIZE;                        // MTB MLP input tiles
+  double* dbw = X0 + MTB * G::T0SIZE;                      // MTB x HP column sums
+  double* part = a.part + (size_t)blockIdx.x * a.psize;
+  const int row0 = blockIdx.x * 16 * MTB;
+
+  // ---- forward recompute; h[q][l] = post-activation of hidden layer l, tile (mp + 2 q, nt), D layout ------------------------
+  double regs[G::NPH], breg;
+  prefetch_first<NT>(a.w[0], a.b[0], H, D, regs, breg);
+  load_input_tiles<NT, MTB>(a.s_in, M, a.C, row0, X0);
+  commit_first<NT>(Wl, regs, breg);
+  __syncthreads();
+  v4d h[2][NH];
+#pragma unroll
+  for (int l = 0; l < NH; ++l) {
+    prefetch_hidden<NT>(a.w[l + 1], a.b[l + 1], l + 1 == NH ? D : H, H, regs, breg);   // after the last hidden layer: the output layer
+    dense2<NT>(l == 0, Wl, X0, X, mp, nt, lane, ksh, h[0][l], h[1][l]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      h[0][l][r] = leaky(h[0][l][r]);
+      h[1][l][r] = leaky(h[1][l][r]);
+    }
+    __syncthreads();                                       // every read of the input tiles and of the weight image is done
+    if (l + 1 < NH) {
+      store_tile<NT>(X, mp, nt, lane, h[0][l]);
+      store_tile<NT>(X, mp + 2, nt, lane, h[1][l]);
+    }
+    commit_hidden<NT>(Wl, regs, breg);
+    __syncthreads();
+  }
+
+  // ---- backward sweep ---------------------------------------------------------------------------------------
+  v4d gpre[2] = {v4d{0, 0, 0, 0}, v4d{0, 0, 0, 0}};
+  if (nt == 0) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = row0 + (mp + 2 * q) * 16 + g + 4 * r;
+        gpre[q][r] = (c < D && row < M) ? a.g_out[mlp_out_index(a, c & 1, row, c >> 1)] : 0.0;
+      }
+  }
+  int poff_end = a.psize;
+#pragma unroll
+  for (int l = NH; l >= 0; --l) {
+    const int Hin = l == 0 ? D : H, Hout = l == NH ? D : H;
+    poff_end -= Hout * Hin + Hout;
+    double* pW = part + poff_end;
+    double* pB = pW + Hout * Hin;
+    if (l == 1) prefetch_first<NT>(a.w[0], a.b[0], H, D, regs, breg);
+    else if (l > 1) prefetch_hidden<NT>(a.w[l - 1], a.b[l - 1], H, H, regs, breg);
+
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      store_tile<NT>(Gt, mp + 2 * q, nt, lane, gpre[q]);
+      if (l > 0) store_tile<NT>(X, mp + 2 * q, nt, lane, h[q][l > 0 ? l - 1 : 0]);
+      double v = (gpre[q][0] + gpre[q][1]) + (gpre[q][2] + gpre[q][3]);   // bias gradient: column sums over the tile's 16 rows
+      v += shfl_xor(v, 16);
+      v += shfl_xor(v, 32);
+      if (g == 0) dbw[(mp + 2 * q) * HP + 16 * nt + c] = v;
+    }
+    __syncthreads();
+
+    // (a) g_in tiles (mp, nt), (mp + 2, nt) = g_pre W; the first layer has a single (16-column) input tile
+    v4d gin[2] = {v4d{0, 0, 0, 0}, v4d{0, 0, 0, 0}};
+    if (l > 0 || nt == 0) {
+      const double* ga = Gt + mp * G::TSIZE + c * S + g;
+      const double* wb = Wl + g * S + 16 * nt + c;
+      const int ks = l == NH ? 4 : ksh;                    // K = output neurons of this layer
+      for (int s = 0; s < ks; ++s) {
+        const double w = wb[4 * s * S];
+        gin[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(ga[4 * s], w, gin[0], 0, 0, 0);
+        gin[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(ga[2 * G::TSIZE + 4 * s], w, gin[1], 0, 0, 0);
+      }
+    }
+    // (b) dW tiles over the workgroup's 64 rows, dealt round-robin to the waves, two accumulation chains
+    {
+      const int nti = l == 0 ? 1 : NT, ntiles = (l == NH ? 1 : NT) * nti;
+      for (int tile = wave; tile < ntiles; tile += NW) {
+        const int t = tile / nti, u = tile - t * nti;
+        const double* ga = Gt + g * S + 16 * t + c;
+        const double* xb = l == 0 ? X0 + g * G::S0 + c : X + g * S + 16 * u + c;
+        const int xts = l == 0 ? G::T0SIZE : G::TSIZE, xss = l == 0 ? G::S0 : S;
+        v4d acc0 = v4d{0, 0, 0, 0}, acc1 = v4d{0, 0, 0, 0};
+#pragma unroll
+        for (int w = 0; w < MTB / 2; ++w)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ga[w * G::TSIZE + 4 * s * S], xb[w * xts + 4 * s * xss], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ga[(w + 2) * G::TSIZE + 4 * s * S], xb[(w + 2) * xts + 4 * s * xss], acc1, 0, 0, 0);
+          }
+        const int k = 16 * u + c;                          // D[i = o][j = k]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int o = 16 * t + g + 4 * r;
+          if (o < Hout && k < Hin) pW[o * Hin + k] = acc0[r] + acc1[r];
+        }
+      }
+      if (tid < Hout) pB[tid] = (dbw[tid] + dbw[HP + tid]) + (dbw[2 * HP + tid] + dbw[3 * HP + tid]);
+    }
+    if (l > 0) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gpre[q][r] = gin[q][r] * (h[q][l > 0 ? l - 1 : 0][r] > 0.0 ? 1.0 : 0.01);
+      __syncthreads();                                     // every read of the weight image and of the tiles is done
+      if (l == 1) commit_first<NT>(Wl, regs, breg);
+      else commit_hidden<NT>(Wl, regs, breg);
+    } else if (nt == 0) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = row0 + (mp + 2 * q) * 16 + g + 4 * r;
+          if (c < D && row < M) a.g_in[mlp_out_index(a, c & 1, row, c >> 1)] = gin[q][r];
+        }
+    }
+  }
+}
+
+// H > 80 (NT = 6: C = 7, 8): the 4 + 4 operand tiles of the one-pass kernel do not fit the LDS beside a 75 KB weight image.
+// Round-2 kernel: two 32-row passes per workgroup, the second adding into the partial row the first one wrote; the
+// activations of the first NHL hidden layers stay in LDS tiles of their own.
+template <int NT, int NH>
+__global__ __launch_bounds__(64 * MT * NT) void mlp_bwd_wide_2pass_kernel(MlpArgs<double> a) {
   using G = Geo<NT>;
   constexpr int S = G::S, HP = G::HP, NW = MT * NT;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -299,9 +469,13 @@ template <int NT>
 static int launch(const MlpArgs<double>& a, bool backward, hipStream_t stream) {
   using G = Geo<NT>;
   constexpr int NH = 6;
-  const size_t smem = sizeof(double) * (backward ? G::bwd_doubles() : G::fwd_doubles());
-  static_assert(sizeof(double) * G::bwd_doubles() <= 160 * 1024 && sizeof(double) * G::fwd_doubles() <= 160 * 1024, "LDS budget");
-  auto kern = backward ? mlp_bwd_wide_kernel<NT, NH> : mlp_fwd_wide_kernel<NT, NH>;
+  const size_t smem = sizeof(double) * (backward ? (G::ONE_PASS ? G::bwd_doubles() : G::bwd2p_doubles()) : G::fwd_doubles());
+  static_assert(sizeof(double) * G::bwd2p_doubles() <= 160 * 1024 && sizeof(double) * G::fwd_doubles() <= 160 * 1024, "LDS budget");
+  void (*kern)(MlpArgs<double>) = mlp_fwd_wide_kernel<NT, NH>;
+  if (backward) {
+    if constexpr (G::ONE_PASS) kern = mlp_bwd_wide_kernel<NT, NH>;
+    else kern = mlp_bwd_wide_2pass_kernel<NT, NH>;
+  }
   if (smem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   const int nblk = backward ? cdiv(a.M, 64) : cdiv(a.M, 16 * MT);
   hipLaunchKernelGGL(kern, dim3(nblk), dim3(G::THREADS), smem, stream, a);
