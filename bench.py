@@ -147,9 +147,66 @@ def time_dominant_kernel(enc, batch, reps=20):
     us_bwd = _events_us(bwd, reps)
     fwd_flops = B * level_fwd_flops(N, Cc, CO, False)
     single = N <= 40
-    return {"kernel": f"level_bwd3_kernel<{Cc}, false, false>" if single else "level_bwd (mix + nodes2 + rad2 kernels)",
+    return {"kernel": f"level_bwd3_kernel<{Cc}, false, false, 4>" if single else "level_bwd (mix + nodes2 + rad2 kernels)",
             "level": lvl, "us": us_bwd, "flops": 2 * fwd_flops,          # backward = 2 x forward
             "forward": {"kernel": f"level_fwd2_kernel<{Cc}, false, false>", "us": us_fwd, "flops": fwd_flops}}
+
+
+def local_level_flops(net, lvl):
+    """Algorithmic flops per node of the PER-NODE part of a table-driven level, forward (SURVEY 8(d) counting rules): the CG
+    matrix of the aggregate 4 nnz per (pair -> irrep) block and channel, the power product 6 d1 d2 per pair + 4 nnz per block,
+    CatMix 8 d_r C_out tau_cat(r).  (The N^2 part -- neighbour sums of node (x) edge -- is the moments kernels' work.)"""
+    plan, cg = net.plans[lvl], net.cg_dict
+    C, CO = plan.channels_in, plan.channels_out
+    dim = lambda r: (r[0] + 1) * (r[1] + 1)          # noqa: E731
+    per_channel, sq_pairs, catmix = 0, set(), 0
+    for r, blocks in plan.cat_blocks.items():
+        for src, r1, r2 in blocks:
+            if src in ("ag", "sq"):
+                per_channel += 4 * int((cg[(r1, r2)][r] != 0).sum().item())
+            if src == "sq":
+                sq_pairs.add((r1, r2))
+        catmix += 8 * dim(r) * CO * C * len(blocks)
+    per_channel += sum(6 * dim(r1) * dim(r2) for r1, r2 in sq_pairs)
+    return C * per_channel + catmix
+
+
+def time_dominant_kernel_generic(net, B, N, reps=10):
+    """maxdim 3: the largest single launch of the step is the per-node backward of the widest table-driven level
+    (local_bwd_static_kernel: d CatMix, d power, d aggregate-CG of 64 nodes x one channel per workgroup).  Timed through its
+    C-ABI entry point on buffers in the kernel's tile-blocked layouts; the entry point also launches the weight packing, the
+    reduction of the partial rows and their unpacking (~3 short kernels: the kernel alone is the rocprof row under profiles/)."""
+    import ctypes as C
+    from lgn import _native as Nn
+    from lgn.plan import static_kind
+    lvl = max(range(net.num_cg_levels), key=lambda l: net.num_channels[l] * net.num_channels[l + 1] * (l > 0))
+    tables = net.level_tables(lvl)
+    kind = static_kind(tables.meta)
+    if not kind:
+        return None
+    dev = net.device
+    Cc, CO, Q, Qo = net.num_channels[lvl], net.num_channels[lvl + 1], tables.meta["Q"], tables.meta["Qout"]
+    M = B * N
+    tiles = (M + 63) // 64
+    g = torch.Generator(device="cpu").manual_seed(2)
+    rnd = lambda *shape: torch.randn(*shape, dtype=torch.float64, generator=g).to(dev)      # noqa: E731
+    XT, UT, goT = rnd(tiles, Cc, Q, 2, 64), rnd(tiles, Cc, 5 * Q, 2, 64), rnd(tiles, CO, Qo, 2, 64)
+    mix = net.lgn_cg.node_levels[lvl].cat_mix.mix_reps
+    wcat = torch.cat([mix.weight(r).detach().reshape(-1) for r in tables.meta["out_irreps"]]).contiguous()
+    L = Nn.lib()
+    w0 = (C.c_int * 5)(*tables.meta["ints"]["out_w0"])
+    npk = L.lgn_local_static_packed_doubles(kind, Cc, CO)
+    wp, gpk = torch.empty(npk, device=dev, dtype=torch.float64), torch.empty(npk, device=dev, dtype=torch.float64)
+    gUT, gXT, part, gw = torch.empty_like(UT), torch.empty_like(XT), torch.empty(tiles, npk, device=dev, dtype=torch.float64), torch.zeros_like(wcat)
+    P = Nn.ptr
+    args = (kind, M, Cc, CO, P(XT), P(UT), P(wcat), w0, P(wp), P(goT), P(gUT), P(gXT), P(part), P(gpk), P(gw), Nn.stream_ptr())
+
+    def bwd():
+        Nn._check(L.lgn_local_bwd_static_f64(*args), "lgn_local_bwd_static_f64")
+
+    us = _events_us(bwd, reps)
+    return {"kernel": f"local_bwd_static_kernel<Kind{kind}, {4 if CO <= 4 else 6 if CO <= 6 else 8}>", "level": lvl, "us": us,
+            "flops": 2 * M * local_level_flops(net, lvl)}
 
 
 def _cpu_model():
@@ -420,9 +477,9 @@ def main():
             traffic = None          # HBM bytes per launch of the dominant kernel, from the PMC passes recorded under profiles/
             if args.config == "cfg2" and per_gpu == 512:
                 try:
-                    with open(os.path.join(ROOT, "profiles", "r02_traffic.json")) as fh:
-                        traffic = json.load(fh).get(dom["kernel"], {}).get("hbm_bytes_per_launch")
-                except OSError:
+                    with open(os.path.join(ROOT, "profiles", "r03_pmc_cfg2.json")) as fh:
+                        traffic = json.load(fh)["kernels"]["lgn::" + dom["kernel"]]["derived"]["hbm_bytes"]
+                except (OSError, KeyError):
                     pass
             fw = dom["forward"]
             out["roofline"] = {
@@ -433,7 +490,7 @@ def main():
                 "frac": achieved / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic,
                 "traffic_note": "bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction; an ESTIMATE: the guide "
                                 "calibrates the x2 on 16 B/lane loads, this kernel issues 8 B/lane), separate rocprofv3 "
-                                "--pmc passes recorded in profiles/r02_traffic.json; 0.5 TB/s, HBM is not the bound",
+                                "--pmc passes recorded in profiles/r03_pmc_cfg2.json; 0.5 TB/s, HBM is not the bound",
                 "us_per_launch": dom["us"], "algorithmic_flops_per_launch": dom["flops"],
                 "forward_kernel": {"kernel": fw["kernel"], "us_per_launch": fw["us"], "algorithmic_flops_per_launch": fw["flops"],
                                    "achieved": fw["flops"] / (fw["us"] * 1e-6) / 1e12,
@@ -441,14 +498,35 @@ def main():
                 "note": "the decoder levels run the separable O(N C) form (SURVEY a-14: an algorithmic change, "
                         "not counted as roofline gain); this kernel is an encoder level and is unaffected"}
         if cfg["maxdim"] != 2:
-            # table-driven levels: no single dominant kernel is priced yet; whole-step algorithmic rate (cfg5 fwd+bwd =
-            # 109.9 MFLOP per jet) against the fp64 peak
+            # table-driven levels: the dominant launch (per-node backward of the widest level) priced with SURVEY 8(d)'s counting
+            # rules, and the whole-step algorithmic rate (cfg5 fwd+bwd = 109.9 MFLOP per jet) next to it
             flops_per_jet = 109.9e6
-            ach = out["value"] * flops_per_jet / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": "whole step (table-driven maxdim=3 levels)", "achieved": ach,
-                               "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_VECTOR_PEAK_TFLOPS,
-                               "traffic": None, "algorithmic_flops_per_jet": flops_per_jet,
-                               "note": "step-level figure: SURVEY 8(d) algorithmic flops per jet x measured jets/s"}
+            ach_step = out["value"] * flops_per_jet / 1e12
+            dom = time_dominant_kernel_generic(enc, per_gpu, N)
+            traffic = None
+            if args.config == "cfg5" and per_gpu == 512 and dom is not None:
+                try:
+                    with open(os.path.join(ROOT, "profiles", "r03_pmc_cfg5.json")) as fh:
+                        ks = json.load(fh)["kernels"]
+                    traffic = ks["lgn::" + dom["kernel"].replace("<Kind", "<lgn::cgs::Kind")]["derived"].get("hbm_bytes")
+                except (OSError, KeyError):
+                    pass
+            if dom is not None:
+                ach = dom["flops"] / (dom["us"] * 1e-6) / 1e12
+                out["roofline"] = {"bound": "mfma", "pipe": "fp64 vector datapath (no matrix instructions in this kernel; schema has hbm|mfma only)",
+                                   "kernel": dom["kernel"], "achieved": ach, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": ach / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic,
+                                   "traffic_note": "2 x FETCH_SIZE + WRITE_SIZE of the rocprofv3 --pmc passes in profiles/r03_pmc_cfg5.json",
+                                   "us_per_launch": dom["us"], "algorithmic_flops_per_launch": dom["flops"],
+                                   "note": "us_per_launch is the C-ABI call (kernel + weight packing + partial-row reduction + unpacking); "
+                                           "the kernel alone: profiles/r03_cfg5_kernel_stats.csv",
+                                   "whole_step": {"achieved": ach_step, "frac": ach_step / FP64_VECTOR_PEAK_TFLOPS,
+                                                  "algorithmic_flops_per_jet": flops_per_jet,
+                                                  "note": "SURVEY 8(d) algorithmic flops per jet x measured jets/s"}}
+            else:
+                out["roofline"] = {"bound": "mfma", "kernel": "whole step (table-driven levels)", "achieved": ach_step,
+                                   "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_step / FP64_VECTOR_PEAK_TFLOPS,
+                                   "traffic": None, "algorithmic_flops_per_jet": flops_per_jet}
         if world == 1 and not args.no_extras:
             if harness != "module":
                 del trainer
