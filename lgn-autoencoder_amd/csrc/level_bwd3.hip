@@ -12,6 +12,7 @@
 //   phase 3  decoder only: i-centric sweep for d p_i
 #include "level_dev.hpp"
 #include "ops.hpp"
+#include "wave_sum.hpp"
 
 namespace lgn {
 
@@ -73,7 +74,8 @@ struct Bwd3 {
     if (red > p1) p1 = red;
     return p1 > (size_t)TRSZ ? p1 : (size_t)TRSZ;
   }
-  static constexpr int SEPSZ = DEC ? 50 * C : 0;        // jet-level sums of the separable decoder form
+  static constexpr int SMS = 52;                         // 50 jet-level sums per channel (+ 2 of padding: 16 + 16 + 12 + 8 lane sums)
+  static constexpr int SEPSZ = DEC ? SMS * C : 0;        // jet-level sums of the separable decoder form
   static size_t smem(int N, int CO) {
     return sizeof(double) * ((((size_t)N * NS + 1) & ~size_t(1)) + (size_t)N * 20 * C + (size_t)N * 10 * C + (size_t)N * PS +
                              scratch(N, CO) + SEPSZ) + N + 16;
@@ -353,72 +355,77 @@ __global__ __launch_bounds__(64 * NWV) void level_bwd3_kernel(LevelBwdArgs<doubl
     __syncthreads();
     for (int e = tid; e < N * 8; e += BLK) pj[e] -= sm[e & 7];
     __syncthreads();
-    // ---- jet-level sums, three rounds of <= 20 reals per (node, channel) through the scratch region -----------
-    //   sm[c*50 + ..]: S 0 | VS[m] 2+2m | SP[m] 10+2m | VP 18 | SG4 20 | SG3 22 | SG1[m] 24+2m | SG2[m] 32+2m | GP2 40 | GP3[m] 42+2m
+    // ---- jet-level sums: wave = channel, lane = node; the 50 per-node terms stay in registers and are summed over the lanes
+    //      by transposing butterflies (wave_sum.hpp) -- no LDS round trip, no barrier per round (round 2: three rounds of 20
+    //      reals per (node, channel) through LDS, each a barrier, a 30-deep serial sum by 80 threads and another barrier)
+    //   sm[c*SMS + ..]: S 0 | VS[m] 2+2m | SP[m] 10+2m | VP 18 | SG4 20 | SG3 22 | SG1[m] 24+2m | SG2[m] 32+2m | GP2 40 | GP3[m] 42+2m
     //   (g_A3 enters with its factor 1/2 everywhere)
+#define LGN_PUT(k, val)                                       \
+  do {                                                        \
+    if ((k) < 16) a0[(k) < 16 ? (k) : 0] += (val);                                        \
+    else if ((k) < 32) a1[(k) >= 16 && (k) < 32 ? (k) - 16 : 0] += (val);                 \
+    else if ((k) < 44) a2[(k) >= 32 && (k) < 44 ? (k) - 32 : 0] += (val);                 \
+    else a3[(k) >= 44 ? (k) - 44 : 0] += (val);                                           \
+  } while (0)
+    for (int c = wave; c < C; c += NWV) {
+      double a0[16], a1[16], a2[12], a3[8];
 #pragma unroll
-    for (int round = 0; round < 3; ++round) {
-      const int nv = round == 2 ? 10 : 20;
-      for (int e = tid; e < N * C; e += BLK) {
-        const int n = e / C, c = e - n * C;
+      for (int k = 0; k < 16; ++k) a0[k] = a1[k] = 0.0;
+#pragma unroll
+      for (int k = 0; k < 12; ++k) a2[k] = 0.0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) a3[k] = 0.0;
+      for (int n = lane; n < N; n += 64) {
         const double* ni = nd + n * NS + c * 10;
         const double* pn = pj + n * 8;
         const double* gi = ga + n * G::SIZE;
-        double* t = tr + e * 20;
-        cx<double> pc[4];
+        cx<double> pc[4], v[4];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) pc[m] = {pn[m], pn[4 + m]};
-        if (round == 0) {
-          const cx<double> sn = {ni[0], ni[1]};
-          cx<double> v[4];
-#pragma unroll
-          for (int m = 0; m < 4; ++m) v[m] = {ni[2 + m], ni[6 + m]};
-          t[0] = sn.r;  t[1] = sn.i;
-#pragma unroll
-          for (int m = 0; m < 4; ++m) {
-            t[2 + 2 * m] = v[m].r;  t[3 + 2 * m] = v[m].i;
-            const cx<double> sp = cmul(sn, pc[m]);
-            t[10 + 2 * m] = sp.r;  t[11 + 2 * m] = sp.i;
-          }
-          const cx<double> vp = bil2(v, pc);
-          t[18] = vp.r;  t[19] = vp.i;
-        } else if (round == 1) {
-          t[0] = gi[G::A4 + 2 * c];        t[1] = gi[G::A4 + 2 * c + 1];
-          t[2] = 0.5 * gi[G::A3 + 2 * c];  t[3] = 0.5 * gi[G::A3 + 2 * c + 1];
-#pragma unroll
-          for (int m = 0; m < 4; ++m) {
-            t[4 + 2 * m] = gi[G::A1 + (c * 4 + m) * 2];   t[5 + 2 * m] = gi[G::A1 + (c * 4 + m) * 2 + 1];
-            t[12 + 2 * m] = gi[G::A2 + (c * 4 + m) * 2];  t[13 + 2 * m] = gi[G::A2 + (c * 4 + m) * 2 + 1];
-          }
-        } else {
-          const cx<double> g3 = {0.5 * gi[G::A3 + 2 * c], 0.5 * gi[G::A3 + 2 * c + 1]};
-          cx<double> gp2 = {0, 0};
-#pragma unroll
-          for (int m = 0; m < 4; ++m) {
-            cfmac(gp2, cx<double>{gi[G::A2 + (c * 4 + m) * 2], gi[G::A2 + (c * 4 + m) * 2 + 1]}, pc[m]);
-            const cx<double> gp3 = cmulc(g3, pc[m]);
-            t[2 + 2 * m] = gp3.r;  t[3 + 2 * m] = gp3.i;
-          }
-          t[0] = gp2.r;  t[1] = gp2.i;
+        for (int m = 0; m < 4; ++m) {
+          pc[m] = {pn[m], pn[4 + m]};
+          v[m] = {ni[2 + m], ni[6 + m]};
         }
+        const cx<double> sn = {ni[0], ni[1]};
+        LGN_PUT(0, sn.r);  LGN_PUT(1, sn.i);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          LGN_PUT(2 + 2 * m, v[m].r);  LGN_PUT(3 + 2 * m, v[m].i);
+          const cx<double> sp = cmul(sn, pc[m]);
+          LGN_PUT(10 + 2 * m, sp.r);  LGN_PUT(11 + 2 * m, sp.i);
+        }
+        const cx<double> vp = bil2(v, pc);
+        LGN_PUT(18, vp.r);  LGN_PUT(19, vp.i);
+        const cx<double> g3 = {0.5 * gi[G::A3 + 2 * c], 0.5 * gi[G::A3 + 2 * c + 1]};
+        LGN_PUT(20, gi[G::A4 + 2 * c]);  LGN_PUT(21, gi[G::A4 + 2 * c + 1]);
+        LGN_PUT(22, g3.r);  LGN_PUT(23, g3.i);
+        cx<double> gp2 = {0, 0};
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const cx<double> g1 = {gi[G::A1 + (c * 4 + m) * 2], gi[G::A1 + (c * 4 + m) * 2 + 1]};
+          const cx<double> g2 = {gi[G::A2 + (c * 4 + m) * 2], gi[G::A2 + (c * 4 + m) * 2 + 1]};
+          LGN_PUT(24 + 2 * m, g1.r);  LGN_PUT(25 + 2 * m, g1.i);
+          LGN_PUT(32 + 2 * m, g2.r);  LGN_PUT(33 + 2 * m, g2.i);
+          cfmac(gp2, g2, pc[m]);
+          const cx<double> gp3 = cmulc(g3, pc[m]);
+          LGN_PUT(42 + 2 * m, gp3.r);  LGN_PUT(43 + 2 * m, gp3.i);
+        }
+        LGN_PUT(40, gp2.r);  LGN_PUT(41, gp2.i);
       }
-      __syncthreads();
-      if (tid < nv * C) {
-        const int c = tid / nv, k = tid - c * nv;
-        double total = 0.0;
-#pragma unroll 8
-        for (int n = 0; n < N; ++n) total += tr[(n * C + c) * 20 + k];
-        sm[c * 50 + round * 20 + k] = total;
-      }
-      __syncthreads();
+      double* q = sm + c * F::SMS;
+      wave_sum_store<16>(a0, q, lane);
+      wave_sum_store<16>(a1, q + 16, lane);
+      wave_sum_store<12>(a2, q + 32, lane);
+      wave_sum_store<8>(a3, q + 44, lane);
     }
+#undef LGN_PUT
+    __syncthreads();
 
     STAMP(5);
     // ---- node gradient: neighbour part from the sums + direct part, written once --------------------------------
     const size_t pls = (size_t)B * N * C;
     for (int e = tid; e < N * C; e += BLK) {
       const int n = e / C, c = e - n * C;
-      const double* q = sm + c * 50;
+      const double* q = sm + c * F::SMS;
       const double* pn = pj + n * 8;
       const double* gdn = gd + e * 10;
       const cx<double> R0 = {a.b0[c], a.b0[c]}, R1 = {a.b1[c], a.b1[c]};
@@ -467,7 +474,7 @@ __global__ __launch_bounds__(64 * NWV) void level_bwd3_kernel(LevelBwdArgs<doubl
         const double* gi = ga + n * G::SIZE;
         cx<double> acc = {0, 0};
         for (int c = 0; c < C; ++c) {
-          const double* q = sm + c * 50;
+          const double* q = sm + c * F::SMS;
           const double* ni = nd + n * NS + c * 10;
           const cx<double> R1 = {a.b1[c], a.b1[c]};
           const cx<double> S = {q[0], q[1]}, SG3 = {q[22], q[23]};
@@ -490,7 +497,7 @@ __global__ __launch_bounds__(64 * NWV) void level_bwd3_kernel(LevelBwdArgs<doubl
     // ---- bias gradients of this jet ----------------------------------------------------------------------------
     if (tid < 2 * C) {
       const int lin = tid / C, c = tid - lin * C;
-      const double* q = sm + c * 50;
+      const double* q = sm + c * F::SMS;
       const cx<double> S = {q[0], q[1]};
       double* part = a.part_rad + (size_t)blockIdx.x * rad_partial_size(C, true);
       if (lin == 0) {

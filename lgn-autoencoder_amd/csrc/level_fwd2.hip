@@ -18,6 +18,7 @@
 //    for the backward) and run CatMix over the items (row, out channel, component).
 #include "level_dev.hpp"
 #include "ops.hpp"
+#include "wave_sum.hpp"
 
 namespace lgn {
 
@@ -149,13 +150,20 @@ __global__ __launch_bounds__(2 * BLOCK) void level_fwd2_kernel(LevelArgs<double>
     __syncthreads();
     for (int e = tid; e < N * 8; e += nthr) pj[e] -= sums[e & 7];
     __syncthreads();
-    // jet-level sums per channel: S | VS[4] | SP[4] | VP.  Stage 1: thread = (node, channel) writes its 10 complex
-    // terms into the (still unused) aggregate rows; stage 2: thread = (channel, term) adds them up in node order
-    double total = 0.0;
-    for (int nb = 0; nb < N; nb += chunk) {
-      const int rows = min(chunk, N - nb);
-      for (int e = tid; e < rows * C; e += nthr) {
-        const int rl = e / C, c = e - rl * C, n = nb + rl;
+    // jet-level sums per channel: S | VS[4] | SP[4] | VP (10 complex numbers).  wave = channel, lane = node: the per-node terms
+    // stay in registers and are summed over the lanes by transposing butterflies (wave_sum.hpp) -- no LDS staging, no barriers
+#define LGN_PUT(k, val)                                           \
+  do {                                                            \
+    if ((k) < 12) a0[(k) < 12 ? (k) : 0] += (val);                \
+    else a1[(k) >= 12 ? (k) - 12 : 0] += (val);                   \
+  } while (0)
+    for (int c = wave; c < C; c += nw) {
+      double a0[12], a1[8];
+#pragma unroll
+      for (int k = 0; k < 12; ++k) a0[k] = 0.0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) a1[k] = 0.0;
+      for (int n = lane; n < N; n += 64) {
         const double* ni = nd + n * F::NS + c * 10;
         const double* pn = pj + n * 8;
         const cx<double> sn = {ni[0], ni[1]};
@@ -165,26 +173,20 @@ __global__ __launch_bounds__(2 * BLOCK) void level_fwd2_kernel(LevelArgs<double>
           v[m] = {ni[2 + m], ni[6 + m]};
           pc[m] = {pn[m], pn[4 + m]};
         }
-        double* t = agl + e * 20;
-        t[0] = sn.r;  t[1] = sn.i;
+        LGN_PUT(0, sn.r);  LGN_PUT(1, sn.i);
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-          t[2 + 2 * m] = v[m].r;  t[3 + 2 * m] = v[m].i;
+          LGN_PUT(2 + 2 * m, v[m].r);  LGN_PUT(3 + 2 * m, v[m].i);
           const cx<double> sp = cmul(sn, pc[m]);
-          t[10 + 2 * m] = sp.r;  t[11 + 2 * m] = sp.i;
+          LGN_PUT(10 + 2 * m, sp.r);  LGN_PUT(11 + 2 * m, sp.i);
         }
         const cx<double> vp = bil2(v, pc);
-        t[18] = vp.r;  t[19] = vp.i;
+        LGN_PUT(18, vp.r);  LGN_PUT(19, vp.i);
       }
-      __syncthreads();
-      if (tid < 20 * C) {
-        const int c = tid / 20, k = tid - c * 20;
-#pragma unroll 8
-        for (int rl = 0; rl < rows; ++rl) total += agl[(rl * C + c) * 20 + k];
-      }
-      __syncthreads();
+      wave_sum_store<12>(a0, sums + c * 20, lane);
+      wave_sum_store<8>(a1, sums + c * 20 + 12, lane);
     }
-    if (tid < 20 * C) sums[tid] = total;
+#undef LGN_PUT
     __syncthreads();
   }
 
