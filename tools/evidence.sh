@@ -1,0 +1,32 @@
+#!/bin/bash
+# One pass over everything profiles/ holds for a round, on the GPU box from the repo root:
+#     bash tools/evidence.sh gpurun_out/ev            (then, here: python tools/evidence_collect.py gpurun_out/ev r03)
+# bench lines (all configs + the 64-jet step), rocprofv3 --kernel-trace --stats of the same commands, and the --pmc passes of
+# cfg2 / cfg5 (tools/pmc_passes.sh).  Every step prints a line, so the call never looks hung.
+set -e
+OUT=${1:-gpurun_out/ev}; ROOT=$(pwd)
+mkdir -p "$OUT"; OUT=$(cd "$OUT" && pwd)
+: > "$OUT/bench.jsonl"
+for spec in "cfg2" "cfg1" "cfg4" "cfg5" "cfg2 --batch 64"; do
+  echo "[evidence] bench --config $spec"
+  python3 bench.py --config $spec 2> "$OUT/bench_err.log" | grep '^{' >> "$OUT/bench.jsonl"
+done
+cd /tmp; export TMPDIR=/tmp
+stats() {  # name, bench args...
+  local name=$1; shift
+  echo "[evidence] rocprofv3 --kernel-trace --stats: bench.py $*"
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/ks_$name" -- python3 "$ROOT/bench.py" --no-cpu-baseline "$@" > "$OUT/ks_$name.log" 2>&1
+  find "$OUT/ks_$name" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$OUT/${name}_kernel_stats.csv"
+  rm -rf "$OUT/ks_$name"
+}
+stats cfg2 --config cfg2 --no-extras
+stats cfg2_module_api --config cfg2 --harness module --no-extras
+stats cfg4 --config cfg4 --no-extras
+stats cfg5 --config cfg5 --no-extras
+stats b64 --config cfg2 --batch 64 --no-extras
+cd "$ROOT"
+for cfg in cfg2 cfg5; do
+  echo "[evidence] pmc passes $cfg"
+  bash tools/pmc_passes.sh $cfg "$OUT/pmc_$cfg" > "$OUT/pmc_$cfg.log" 2>&1
+done
+ls -la "$OUT"
