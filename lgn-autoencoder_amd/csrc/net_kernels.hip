@@ -10,6 +10,9 @@
 
 namespace lgn {
 
+LGN_STAMP_DECL
+LGN_STAMP_READER(lgn_debug_stamps_net)
+
 namespace {
 constexpr double H = 0.70710678118654752440084436210484903928;
 
@@ -129,47 +132,137 @@ __global__ __launch_bounds__(BLOCK) void enc_input_bwd_kernel(int B, int N, int 
 }
 
 // ============================================================================================
+// LDS staging.  The per-jet kernels below work on a few KB per jet: every global operand is copied to LDS first with
+// all loads of a thread in flight together (one HBM round trip per kernel), and every later phase reads LDS only --
+// round 2's versions walked global memory inside run-time loops (one round trip per channel) and ran their pooling /
+// Chamfer phases on 18-60 threads: 17 us per junction kernel for a few kFLOP per jet.
+// ============================================================================================
+// One operand on its way to LDS: issue() puts the first U * BLOCK elements into registers (loads only), commit() stores them
+// through put(element, value) and fetches whatever lies beyond that window (large jets) with a plain loop.  A kernel issues ALL
+// its operands before it commits the first one, so their HBM round trips overlap.
+template <int U>
+struct StageRegs {
+  double r[U];
+  __device__ __forceinline__ void issue(const double* __restrict__ src, int total) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) r[u] = total > 0 ? src[min((int)threadIdx.x + u * BLOCK, total - 1)] : 0.0;   // clamped: no branch per load
+  }
+  template <class Put>
+  __device__ __forceinline__ void commit(const double* __restrict__ src, int total, Put put) const {
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if ((int)threadIdx.x + u * BLOCK < total) put((int)threadIdx.x + u * BLOCK, r[u]);
+    for (int e = threadIdx.x + U * BLOCK; e < total; e += BLOCK) put(e, src[e]);
+  }
+};
+// component m of canon_cplx / cart_from_canon / their gradients from an LDS vector stored re[4] | im[4]
+__device__ __forceinline__ cx<double> canon_cplx_m(const double* p, int m) {
+  if (m == 0) return {p[0], p[4]};
+  if (m == 2) return {p[3], p[7]};
+  const double sg = m == 1 ? 1.0 : -1.0;
+  return {(sg * p[1] + p[6]) * H, (sg * p[5] - p[2]) * H};
+}
+__device__ __forceinline__ cx<double> canon_cplx_bwd_m(const double* g, int m) {
+  if (m == 0) return {g[0], g[4]};
+  if (m == 3) return {g[2], g[6]};
+  if (m == 1) return {(g[1] - g[3]) * H, (g[5] - g[7]) * H};
+  return {-(g[5] + g[7]) * H, (g[1] + g[3]) * H};
+}
+__device__ __forceinline__ cx<double> cart_from_canon_m(const double* c, int m) {
+  if (m == 0) return {c[0], c[4]};
+  if (m == 3) return {c[2], c[6]};
+  if (m == 1) return {(c[1] - c[3]) * H, (c[5] - c[7]) * H};
+  return {-(c[5] + c[7]) * H, (c[1] + c[3]) * H};
+}
+
+// ============================================================================================
 // encoder latent: MixReps -> Cartesian -> min&max pooling
 //   lat_s [2][B][2Ts]  (min block, max block), lat_v [2][B][2Tv][4], idx [B][2][Ts+Tv][2] (plane, channel, min/max)
+// LDS: y [N][2Ts + 8Tv] | sv [N][C][10] | w0l [2][Ts][C] | w1l [2][Tv][C]
 // ============================================================================================
-__device__ __forceinline__ void enc_latent_fwd_body(int B, int N, int C, int Ts, int Tv,
-                                                              const double* __restrict__ s, const double* __restrict__ v,
-                                                              const double* __restrict__ wl0, const double* __restrict__ wl1,
-                                                              double* lat_s, double* lat_v, int* idx, unsigned char* smem_raw) {
-  double* y = reinterpret_cast<double*>(smem_raw);      // [n][t] : scalars 2 (re,im), vectors 8 (cart re[4], im[4])
+__host__ __device__ inline size_t lat_fwd_doubles(int N, int C, int Ts, int Tv) {
+  return (size_t)N * (2 * Ts + 8 * Tv) + (size_t)N * C * 10 + 2 * (size_t)(Ts + Tv) * C;
+}
+// node features of the jet -> sv [N][C][10] (s re, im, v re[4], im[4]) and the two mixing weights; zero_y: y / gy starts at zero
+struct LatentStage {
+  StageRegs<2> sr, si;
+  StageRegs<4> vr, vi;
+  StageRegs<1> w0, w1;
+  const double *s0, *s1, *v0, *v1, *wl0, *wl1;
+  int N, C, Ts, Tv;
+  __device__ __forceinline__ void issue(int B, int N_, int C_, int Ts_, int Tv_, const double* __restrict__ s, const double* __restrict__ v,
+                                        const double* __restrict__ wl0_, const double* __restrict__ wl1_) {
+    N = N_; C = C_; Ts = Ts_; Tv = Tv_; wl0 = wl0_; wl1 = wl1_;
+    const size_t pl = (size_t)B * N * C, j0 = (size_t)blockIdx.x * N * C;
+    s0 = s + j0; s1 = s + pl + j0; v0 = v + j0 * 4; v1 = v + (pl + j0) * 4;
+    vr.issue(v0, N * C * 4); vi.issue(v1, N * C * 4);
+    sr.issue(s0, N * C); si.issue(s1, N * C);
+    w0.issue(wl0, 2 * Ts * C); w1.issue(wl1, 2 * Tv * C);
+  }
+  __device__ __forceinline__ void commit(double* lds, bool zero_y) const {
+    double* sv = lds + N * (2 * Ts + 8 * Tv);
+    double* w0l = sv + N * C * 10;
+    double* w1l = w0l + 2 * Ts * C;
+    if (zero_y)
+      for (int e = threadIdx.x; e < N * (2 * Ts + 8 * Tv); e += BLOCK) lds[e] = 0.0;
+    vr.commit(v0, N * C * 4, [&](int e, double x) { sv[(e >> 2) * 10 + 2 + (e & 3)] = x; });
+    vi.commit(v1, N * C * 4, [&](int e, double x) { sv[(e >> 2) * 10 + 6 + (e & 3)] = x; });
+    sr.commit(s0, N * C, [&](int e, double x) { sv[e * 10] = x; });
+    si.commit(s1, N * C, [&](int e, double x) { sv[e * 10 + 1] = x; });
+    w0.commit(wl0, 2 * Ts * C, [&](int e, double x) { w0l[e] = x; });
+    w1.commit(wl1, 2 * Tv * C, [&](int e, double x) { w1l[e] = x; });
+  }
+};
+// after enc_latent_fwd_stage + a barrier.  TO_LDS: lat_l (LDS [2Tv][8]: re[4] | im[4]) also receives the latent vectors.
+template <bool TO_LDS>
+__device__ __forceinline__ void enc_latent_fwd_body(int B, int N, int C, int Ts, int Tv, double* lat_s, double* lat_v, int* idx,
+                                                    double* lds, double* lat_l) {
   const int b = blockIdx.x, TT = Ts + Tv;
   const int YS = 2 * Ts + 8 * Tv;                       // per-node stride
-  const size_t pl = (size_t)B * N * C;
-  for (int e = threadIdx.x; e < N * TT; e += BLOCK) {
-    const int n = e / TT, t = e - n * TT;
-    const size_t base = ((size_t)b * N + n) * C;
-    if (t < Ts) {
-      cx<double> acc = {0, 0};
-      for (int c = 0; c < C; ++c)
-        cfma(acc, cx<double>{wl0[t * C + c], wl0[Ts * C + t * C + c]}, cx<double>{s[base + c], s[pl + base + c]});
-      y[n * YS + 2 * t] = acc.r;
-      y[n * YS + 2 * t + 1] = acc.i;
-    } else {
-      const int tv = t - Ts;
-      cx<double> acc[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}}, pc[4];
-      for (int c = 0; c < C; ++c) {
-        const cx<double> w = {wl1[tv * C + c], wl1[Tv * C + tv * C + c]};
+  double* y = lds;                                      // [n][t] : scalars 2 (re,im), vectors 8 (cart re[4], im[4])
+  const double* sv = y + N * YS;
+  const double* w0l = sv + N * C * 10;
+  const double* w1l = w0l + 2 * Ts * C;
+  STAMP(1);
+  // MixReps to the latent channels + rep_to_p: one (particle, vector channel) per thread (N Tv = 240 at cfg2: one round), the
+  // few scalar channels in a second, short loop
+  for (int e = threadIdx.x; e < N * Tv; e += BLOCK) {
+    const int n = e / Tv, tv = e - n * Tv;
+    const double* x = sv + n * C * 10;
+    cx<double> acc[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}}, pc[4];
+#pragma unroll 4
+    for (int c = 0; c < C; ++c) {
+      const cx<double> w = {w1l[tv * C + c], w1l[Tv * C + tv * C + c]};
 #pragma unroll
-        for (int m = 0; m < 4; ++m) cfma(acc[m], w, cx<double>{v[(base + c) * 4 + m], v[(pl + base + c) * 4 + m]});
-      }
-      cart_from_canon(acc, pc);
-      double* o = y + n * YS + 2 * Ts + 8 * tv;
-#pragma unroll
-      for (int m = 0; m < 4; ++m) { o[m] = pc[m].r; o[4 + m] = pc[m].i; }
+      for (int m = 0; m < 4; ++m) cfma(acc[m], w, cx<double>{x[c * 10 + 2 + m], x[c * 10 + 6 + m]});
     }
+    cart_from_canon(acc, pc);
+    double* o = y + n * YS + 2 * Ts + 8 * tv;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) { o[m] = pc[m].r; o[4 + m] = pc[m].i; }
+  }
+  for (int e = threadIdx.x; e < N * Ts; e += BLOCK) {
+    const int n = e / Ts, t = e - n * Ts;
+    const double* x = sv + n * C * 10;
+    cx<double> acc = {0, 0};
+#pragma unroll 4
+    for (int c = 0; c < C; ++c) cfma(acc, cx<double>{w0l[t * C + c], w0l[Ts * C + t * C + c]}, cx<double>{x[c * 10], x[c * 10 + 1]});
+    y[n * YS + 2 * t] = acc.r;
+    y[n * YS + 2 * t + 1] = acc.i;
   }
   __syncthreads();
-  // one thread per (plane, channel): arg-min / arg-max over particles (first occurrence), padded particles included
-  for (int e = threadIdx.x; e < 2 * TT; e += BLOCK) {
-    const int z = e / TT, t = e - z * TT;
-    int imin = 0, imax = 0;
+  STAMP(2);
+  // arg-min / arg-max over the particles (first occurrence, padded particles included) per (plane, channel): 8 lanes per
+  // item, lane = every 8th particle, then a butterfly over the 8 lanes on (value, index) -- ties go to the lower index, as the
+  // sequential scan of the reference's torch.min / torch.max does.  (Round 2: one thread per item walked all N particles.)
+  const int l8 = threadIdx.x & 7;
+  constexpr int NONE = 0x7fffffff;
+  for (int it = threadIdx.x >> 3; it < 2 * TT; it += BLOCK / 8) {
+    const int z = it / TT, t = it - z * TT;
+    int imin = NONE, imax = NONE;
     double smin = 0, smax = 0;
-    for (int n = 0; n < N; ++n) {
+#pragma unroll 4
+    for (int n = l8; n < N; n += 8) {
       double lo, hi;
       if (t < Ts) {
         const double val = y[n * YS + 2 * t + z];
@@ -179,20 +272,26 @@ __device__ __forceinline__ void enc_latent_fwd_body(int B, int N, int C, int Ts,
         const double* o = y + n * YS + 2 * Ts + 8 * (t - Ts) + 4 * z;
         lo = hi = o[0] * o[0] - ((o[1] * o[1] + o[2] * o[2]) + o[3] * o[3]);
       }
-      if (n == 0 || lo < smin) { smin = lo; imin = n; }
-      if (n == 0 || hi > smax) { smax = hi; imax = n; }
+      if (imin == NONE || lo < smin) { smin = lo; imin = n; }
+      if (imax == NONE || hi > smax) { smax = hi; imax = n; }
     }
-    idx[(((size_t)b * 2 + z) * TT + t) * 2 + 0] = imin;
-    idx[(((size_t)b * 2 + z) * TT + t) * 2 + 1] = imax;
+#pragma unroll
+    for (int off = 4; off; off >>= 1) {
+      const double om = __shfl_xor(smin, off, 8), oM = __shfl_xor(smax, off, 8);
+      const int oi = __shfl_xor(imin, off, 8), oI = __shfl_xor(imax, off, 8);
+      if (oi != NONE && (imin == NONE || om < smin || (om == smin && oi < imin))) { smin = om; imin = oi; }
+      if (oI != NONE && (imax == NONE || oM > smax || (oM == smax && oI < imax))) { smax = oM; imax = oI; }
+    }
+    imin = __shfl(imin, 0, 8);        // (identical on all 8 lanes unless NaNs are present: lane 0 holds the sequential scan's answer)
+    imax = __shfl(imax, 0, 8);
+    if (l8 < 2) idx[(((size_t)b * 2 + z) * TT + t) * 2 + l8] = l8 ? imax : imin;
     if (t < Ts) {
-      lat_s[((size_t)z * B + b) * 2 * Ts + t] = y[imin * YS + 2 * t + z];
-      lat_s[((size_t)z * B + b) * 2 * Ts + Ts + t] = y[imax * YS + 2 * t + z];
+      if (l8 < 2) lat_s[((size_t)z * B + b) * 2 * Ts + l8 * Ts + t] = y[(l8 ? imax : imin) * YS + 2 * t + z];
     } else {
-      const int tv = t - Ts;
-      for (int m = 0; m < 4; ++m) {
-        lat_v[(((size_t)z * B + b) * 2 * Tv + tv) * 4 + m] = y[imin * YS + 2 * Ts + 8 * tv + 4 * z + m];
-        lat_v[(((size_t)z * B + b) * 2 * Tv + Tv + tv) * 4 + m] = y[imax * YS + 2 * Ts + 8 * tv + 4 * z + m];
-      }
+      const int tv = t - Ts, kind = l8 >> 2, m = l8 & 3;
+      const double val = y[(kind ? imax : imin) * YS + 2 * Ts + 8 * tv + 4 * z + m];
+      lat_v[(((size_t)z * B + b) * 2 * Tv + kind * Tv + tv) * 4 + m] = val;
+      if constexpr (TO_LDS) lat_l[(kind * Tv + tv) * 8 + 4 * z + m] = val;
     }
   }
 }
@@ -201,54 +300,75 @@ __global__ __launch_bounds__(BLOCK) void enc_latent_fwd_kernel(int B, int N, int
                                                               const double* __restrict__ wl0, const double* __restrict__ wl1,
                                                               double* lat_s, double* lat_v, int* idx) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
-  enc_latent_fwd_body(B, N, C, Ts, Tv, s, v, wl0, wl1, lat_s, lat_v, idx, smem_raw);
+  double* lds = reinterpret_cast<double*>(smem_raw);
+  LatentStage st;
+  st.issue(B, N, C, Ts, Tv, s, v, wl0, wl1);
+  st.commit(lds, false);
+  __syncthreads();
+  enc_latent_fwd_body<false>(B, N, C, Ts, Tv, lat_s, lat_v, idx, lds, nullptr);
 }
 
 // backward: scatter the latent gradient to the selected particles, undo rep_to_p and the MixReps.
 // part row per jet: dWl0 [2][Ts][C] then dWl1 [2][Tv][C].  The jet's node features and the mixing weights are staged
 // in LDS once; the weight gradient runs over (channel pair, node part) items whose parts meet in LDS in a fixed order.
-constexpr int LAT_PARTS = 4;
-__device__ __forceinline__ void enc_latent_bwd_body(int B, int N, int C, int Ts, int Tv,
-                                                              const double* __restrict__ s, const double* __restrict__ v,
-                                                              const double* __restrict__ wl0, const double* __restrict__ wl1,
-                                                              const double* __restrict__ g_lat_s, const double* __restrict__ g_lat_v,
-                                                              const int* __restrict__ idx, double* g_s, double* g_v, double* part, unsigned char* smem_raw) {
+// LDS: gy [N][2Ts + 8Tv] | sv [N][C][10] | w0l | w1l | red [LAT_PARTS][TT*C][2]
+constexpr int LAT_PARTS = 6;
+__host__ __device__ inline size_t lat_bwd_doubles(int N, int C, int Ts, int Tv) {
+  return lat_fwd_doubles(N, C, Ts, Tv) + (size_t)LAT_PARTS * (Ts + Tv) * C * 2;
+}
+// FROM_LDS: the latent-vector gradient of this jet comes from g_lat_l (LDS, [2Tv][8]: re[4] | im[4]) instead of g_lat_v
+// `pre`: the pooling indices (and latent-scalar gradients) of this thread's (plane, channel), fetched with the staging loads
+struct LatentBwdPrefetch {
+  int n[2];
+  double gs[2];
+  bool valid;
+  __device__ __forceinline__ void issue(int B, int Ts, int Tv, const int* __restrict__ idx, const double* __restrict__ g_lat_s) {
+    const int TT = Ts + Tv, e = threadIdx.x, b = blockIdx.x;
+    valid = 2 * TT <= BLOCK;
+    if (valid && e < 2 * TT) {
+      const int z = e / TT, t = e - z * TT;
+#pragma unroll
+      for (int kind = 0; kind < 2; ++kind) {
+        n[kind] = idx[(((size_t)b * 2 + z) * TT + t) * 2 + kind];
+        gs[kind] = t < Ts ? g_lat_s[((size_t)z * B + b) * 2 * Ts + kind * Ts + t] : 0.0;
+      }
+    }
+  }
+};
+template <bool FROM_LDS>
+__device__ __forceinline__ void enc_latent_bwd_body(int B, int N, int C, int Ts, int Tv, const double* __restrict__ g_lat_s,
+                                                    const double* __restrict__ g_lat_v, const double* g_lat_l,
+                                                    const int* __restrict__ idx, double* g_s, double* g_v, double* part, double* lds,
+                                                    const LatentBwdPrefetch& pre) {
   const int b = blockIdx.x, TT = Ts + Tv;
   const int YS = 2 * Ts + 8 * Tv;
-  double* gy = reinterpret_cast<double*>(smem_raw);     // [N][YS] same layout as y in the forward; vectors become canonical grads
-  double* sv = gy + N * YS;                             // [N][C][10]: s re, im, v re[4], im[4]
-  double* w0l = sv + N * C * 10;                        // [2][Ts][C]
-  double* w1l = w0l + 2 * Ts * C;                       // [2][Tv][C]
-  double* red = w1l + 2 * Tv * C;                       // [LAT_PARTS][TT*C][2]
+  double* gy = lds;                                     // [N][YS] same layout as y in the forward; vectors become canonical grads
+  const double* sv = gy + N * YS;                       // [N][C][10]: s re, im, v re[4], im[4]
+  const double* w0l = sv + N * C * 10;                  // [2][Ts][C]
+  const double* w1l = w0l + 2 * Ts * C;                 // [2][Tv][C]
+  double* red = const_cast<double*>(w1l) + 2 * Tv * C;  // [LAT_PARTS][TT*C][2]
   const size_t pl = (size_t)B * N * C;
-  for (int e = threadIdx.x; e < N * YS; e += BLOCK) gy[e] = 0.0;
-  for (int e = threadIdx.x; e < N * C; e += BLOCK) {
-    const size_t base = (size_t)b * N * C + e;
-    sv[e * 10] = s[base];
-    sv[e * 10 + 1] = s[pl + base];
-  }
-  for (int e = threadIdx.x; e < N * C * 4; e += BLOCK) {
-    const size_t base = (size_t)b * N * C * 4 + e;
-    sv[(e >> 2) * 10 + 2 + (e & 3)] = v[base];
-    sv[(e >> 2) * 10 + 6 + (e & 3)] = v[pl * 4 + base];
-  }
-  for (int e = threadIdx.x; e < 2 * Ts * C; e += BLOCK) w0l[e] = wl0[e];
-  for (int e = threadIdx.x; e < 2 * Tv * C; e += BLOCK) w1l[e] = wl1[e];
-  __syncthreads();
+  STAMP(14);
   for (int e = threadIdx.x; e < 2 * TT; e += BLOCK) {    // (plane, channel) owners: no write conflicts
     const int z = e / TT, t = e - z * TT;
+#pragma unroll
     for (int kind = 0; kind < 2; ++kind) {
-      const int n = idx[(((size_t)b * 2 + z) * TT + t) * 2 + kind];
+      const int n = pre.valid ? pre.n[kind] : idx[(((size_t)b * 2 + z) * TT + t) * 2 + kind];
       if (t < Ts) {
-        gy[n * YS + 2 * t + z] += g_lat_s[((size_t)z * B + b) * 2 * Ts + kind * Ts + t];
+        gy[n * YS + 2 * t + z] += pre.valid ? pre.gs[kind] : g_lat_s[((size_t)z * B + b) * 2 * Ts + kind * Ts + t];
       } else {
         const int tv = t - Ts;
-        for (int m = 0; m < 4; ++m)
-          gy[n * YS + 2 * Ts + 8 * tv + 4 * z + m] += g_lat_v[(((size_t)z * B + b) * 2 * Tv + kind * Tv + tv) * 4 + m];
+        for (int m = 0; m < 4; ++m) {
+          double g;
+          if constexpr (FROM_LDS) g = g_lat_l[(kind * Tv + tv) * 8 + 4 * z + m];
+          else g = g_lat_v[(((size_t)z * B + b) * 2 * Tv + kind * Tv + tv) * 4 + m];
+          gy[n * YS + 2 * Ts + 8 * tv + 4 * z + m] += g;
+        }
       }
     }
   }
   __syncthreads();
+  STAMP(15);
   for (int e = threadIdx.x; e < N * Tv; e += BLOCK) {    // Cartesian gradient -> canonical gradient, in place
     const int n = e / Tv, tv = e - n * Tv;
     double* o = gy + n * YS + 2 * Ts + 8 * tv;
@@ -258,12 +378,15 @@ __device__ __forceinline__ void enc_latent_bwd_body(int B, int N, int C, int Ts,
     for (int m = 0; m < 4; ++m) { o[m] = gc[m].r; o[4 + m] = gc[m].i; }
   }
   __syncthreads();
+  STAMP(16);
   for (int e = threadIdx.x; e < N * C; e += BLOCK) {     // gradient w.r.t. the last level's node features
     const int n = e / C, c = e - n * C;
     const size_t base = ((size_t)b * N + n) * C + c;
     cx<double> as = {0, 0}, av[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+#pragma unroll 2
     for (int t = 0; t < Ts; ++t)
       cfmac(as, cx<double>{gy[n * YS + 2 * t], gy[n * YS + 2 * t + 1]}, cx<double>{w0l[t * C + c], w0l[Ts * C + t * C + c]});
+#pragma unroll 4
     for (int t = 0; t < Tv; ++t) {
       const cx<double> w = {w1l[t * C + c], w1l[Tv * C + t * C + c]};
       const double* o = gy + n * YS + 2 * Ts + 8 * t;
@@ -276,16 +399,19 @@ __device__ __forceinline__ void enc_latent_bwd_body(int B, int N, int C, int Ts,
     for (int m = 0; m < 4; ++m) { g_v[base * 4 + m] = av[m].r; g_v[pl * 4 + base * 4 + m] = av[m].i; }
   }
   // weight gradients of this jet: item = (node part, latent channel t, node channel c)
+  STAMP(17);
   const int nper = (N + LAT_PARTS - 1) / LAT_PARTS;
   for (int e = threadIdx.x; e < LAT_PARTS * TT * C; e += BLOCK) {
     const int pi = e / (TT * C), r = e - pi * TT * C, t = r / C, c = r - t * C;
     const int n1 = min(N, (pi + 1) * nper);
     cx<double> acc = {0, 0};
     if (t < Ts) {
+#pragma unroll 5
       for (int n = pi * nper; n < n1; ++n)
         cfmac(acc, cx<double>{gy[n * YS + 2 * t], gy[n * YS + 2 * t + 1]}, cx<double>{sv[(n * C + c) * 10], sv[(n * C + c) * 10 + 1]});
     } else {
       const int tv = t - Ts;
+#pragma unroll 5
       for (int n = pi * nper; n < n1; ++n) {
         const double* o = gy + n * YS + 2 * Ts + 8 * tv;
         const double* x = sv + (n * C + c) * 10;
@@ -297,6 +423,7 @@ __device__ __forceinline__ void enc_latent_bwd_body(int B, int N, int C, int Ts,
     red[e * 2 + 1] = acc.i;
   }
   __syncthreads();
+  STAMP(18);
   double* row = part + (size_t)b * 2 * TT * C;
   for (int e = threadIdx.x; e < TT * C; e += BLOCK) {
     const int t = e / C, c = e - t * C;
@@ -317,126 +444,208 @@ __global__ __launch_bounds__(BLOCK) void enc_latent_bwd_kernel(int B, int N, int
                                                               const double* __restrict__ g_lat_s, const double* __restrict__ g_lat_v,
                                                               const int* __restrict__ idx, double* g_s, double* g_v, double* part) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
-  enc_latent_bwd_body(B, N, C, Ts, Tv, s, v, wl0, wl1, g_lat_s, g_lat_v, idx, g_s, g_v, part, smem_raw);
+  double* lds = reinterpret_cast<double*>(smem_raw);
+  LatentStage st;
+  LatentBwdPrefetch pre;
+  st.issue(B, N, C, Ts, Tv, s, v, wl0, wl1);
+  pre.issue(B, Ts, Tv, idx, g_lat_s);
+  st.commit(lds, true);                                  // same regions as the forward; gy takes y's place and starts at zero
+  __syncthreads();
+  enc_latent_bwd_body<false>(B, N, C, Ts, Tv, g_lat_s, g_lat_v, nullptr, idx, g_s, g_v, part, lds, pre);
 }
 
 // ============================================================================================
 // decoder input: latent vectors -> particles (latent_to_graph) -> canonical momenta -> input_func_node
 //   pdec [2][B][N][4]; s0 [2][B][N][C] = W00[c] (1+1i); v0 [2][B][N][C][4] = W11[c] pc[n]
+// LDS: wgl [2][N][Tin] | latl [Tin][8] | cartl [N][8] | w01 [4C] (W00 re, im, W11 re, im)
 // ============================================================================================
-__device__ __forceinline__ void dec_input_fwd_body(int B, int N, int C, int Tin, const double* __restrict__ lat_v,
-                                                             const double* __restrict__ wg1, const double* __restrict__ w0,
-                                                             const double* __restrict__ w1, double* pdec, double* s0, double* v0, unsigned char* smem_raw) {
+__host__ __device__ inline size_t dec_in_fwd_doubles(int N, int C, int Tin) {
+  return 2 * (size_t)N * Tin + (size_t)Tin * 8 + (size_t)N * 8 + 4 * (size_t)C;
+}
+// weights of the decoder input -> LDS (wgl, w01); with_lat: also this jet's latent vectors from global memory
+struct DecInFwdStage {
+  StageRegs<4> wg;
+  StageRegs<1> a0, a1, lr, li;
+  const double *wg1, *w0, *w1, *l0, *l1;
+  int N, C, Tin;
+  bool with_lat;
+  __device__ __forceinline__ void issue(int B, int N_, int C_, int Tin_, const double* __restrict__ lat_v, const double* __restrict__ wg1_,
+                                        const double* __restrict__ w0_, const double* __restrict__ w1_, bool with_lat_) {
+    N = N_; C = C_; Tin = Tin_; wg1 = wg1_; w0 = w0_; w1 = w1_; with_lat = with_lat_;
+    wg.issue(wg1, 2 * N * Tin);
+    a0.issue(w0, 2 * C); a1.issue(w1, 2 * C);
+    if (with_lat) {
+      l0 = lat_v + (size_t)blockIdx.x * Tin * 4; l1 = lat_v + ((size_t)B + blockIdx.x) * Tin * 4;
+      lr.issue(l0, Tin * 4); li.issue(l1, Tin * 4);
+    }
+  }
+  __device__ __forceinline__ void commit(double* lds) const {
+    double* wgl = lds;
+    double* latl = wgl + 2 * N * Tin;
+    double* w01 = latl + Tin * 8 + N * 8;
+    wg.commit(wg1, 2 * N * Tin, [&](int e, double x) { wgl[e] = x; });
+    a0.commit(w0, 2 * C, [&](int e, double x) { w01[e] = x; });
+    a1.commit(w1, 2 * C, [&](int e, double x) { w01[2 * C + e] = x; });
+    if (with_lat) {
+      lr.commit(l0, Tin * 4, [&](int e, double x) { latl[(e >> 2) * 8 + (e & 3)] = x; });
+      li.commit(l1, Tin * 4, [&](int e, double x) { latl[(e >> 2) * 8 + 4 + (e & 3)] = x; });
+    }
+  }
+};
+__device__ __forceinline__ void dec_input_fwd_body(int B, int N, int C, int Tin, double* pdec, double* s0, double* v0, double* lds) {
+  const double* wgl = lds;                               // [2][N][Tin]
+  const double* latl = wgl + 2 * N * Tin;                // [Tin][8]
+  double* cartl = const_cast<double*>(latl) + Tin * 8;   // [N][8] complex Cartesian momenta of the decoder's particles
+  const double* w01 = cartl + N * 8;
   const int b = blockIdx.x;
   const size_t plp = (size_t)B * N * 4, pl = (size_t)B * N * C;
-  // the latent vectors of the jet and latent_to_graph's weights go to LDS first: the sum over the latent channels below
-  // would otherwise be a chain of Tin dependent global round trips per particle
-  double* wgl = reinterpret_cast<double*>(smem_raw);     // [2][N][Tin]
-  double* latl = wgl + 2 * N * Tin;                      // [Tin][8]
-  for (int e = threadIdx.x; e < 2 * N * Tin; e += BLOCK) wgl[e] = wg1[e];
-  for (int e = threadIdx.x; e < Tin * 4; e += BLOCK) {
-    latl[(e >> 2) * 8 + (e & 3)] = lat_v[(size_t)b * Tin * 4 + e];
-    latl[(e >> 2) * 8 + 4 + (e & 3)] = lat_v[((size_t)B + b) * Tin * 4 + e];
+  STAMP(3);
+  for (int e = threadIdx.x; e < N * 4; e += BLOCK) {     // (particle, component): latent_to_graph
+    const int n = e >> 2, m = e & 3;
+    cx<double> acc = {0, 0};
+#pragma unroll 8
+    for (int t = 0; t < Tin; ++t)
+      cfma(acc, cx<double>{wgl[n * Tin + t], wgl[N * Tin + n * Tin + t]}, cx<double>{latl[t * 8 + m], latl[t * 8 + 4 + m]});
+    cartl[n * 8 + m] = acc.r;
+    cartl[n * 8 + 4 + m] = acc.i;
   }
   __syncthreads();
-  for (int n = threadIdx.x; n < N; n += BLOCK) {
-    cx<double> cart[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}}, pc[4];
-    for (int t = 0; t < Tin; ++t) {
-      const cx<double> w = {wgl[n * Tin + t], wgl[N * Tin + n * Tin + t]};
-#pragma unroll
-      for (int m = 0; m < 4; ++m) cfma(cart[m], w, cx<double>{latl[t * 8 + m], latl[t * 8 + 4 + m]});
-    }
-    canon_cplx(cart, pc);
-    const size_t node = (size_t)b * N + n;
-#pragma unroll
-    for (int m = 0; m < 4; ++m) { pdec[node * 4 + m] = pc[m].r; pdec[plp + node * 4 + m] = pc[m].i; }
-    for (int c = 0; c < C; ++c) {
-      const size_t e = node * C + c;
-      // W00 * (1 + 1i): the zonal (0,0) function is ones on both planes (zonal_functions.py:182-186)
-      s0[e] = w0[c] - w0[C + c];
-      s0[pl + e] = w0[C + c] + w0[c];
-      const cx<double> w = {w1[c], w1[C + c]};
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        cx<double> r = cmul(w, pc[m]);
-        v0[e * 4 + m] = r.r;
-        v0[pl * 4 + e * 4 + m] = r.i;
-      }
-    }
+  STAMP(4);
+  for (int e = threadIdx.x; e < N * 4; e += BLOCK) {
+    const cx<double> pc = canon_cplx_m(cartl + (e >> 2) * 8, e & 3);
+    pdec[(size_t)b * N * 4 + e] = pc.r;
+    pdec[plp + (size_t)b * N * 4 + e] = pc.i;
+  }
+  for (int e = threadIdx.x; e < N * C; e += BLOCK) {
+    const int c = e % C;
+    // W00 * (1 + 1i): the zonal (0,0) function is ones on both planes (zonal_functions.py:182-186)
+    s0[(size_t)b * N * C + e] = w01[c] - w01[C + c];
+    s0[pl + (size_t)b * N * C + e] = w01[C + c] + w01[c];
+  }
+  for (int e = threadIdx.x; e < N * C * 4; e += BLOCK) {  // (particle, channel, component)
+    const int i = e >> 2, m = e & 3, n = i / C, c = i - n * C;
+    const cx<double> r = cmul(cx<double>{w01[2 * C + c], w01[3 * C + c]}, canon_cplx_m(cartl + n * 8, m));
+    v0[(size_t)b * N * C * 4 + e] = r.r;
+    v0[pl * 4 + (size_t)b * N * C * 4 + e] = r.i;
   }
 }
 __global__ __launch_bounds__(BLOCK) void dec_input_fwd_kernel(int B, int N, int C, int Tin, const double* __restrict__ lat_v,
                                                              const double* __restrict__ wg1, const double* __restrict__ w0,
                                                              const double* __restrict__ w1, double* pdec, double* s0, double* v0) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
-  dec_input_fwd_body(B, N, C, Tin, lat_v, wg1, w0, w1, pdec, s0, v0, smem_raw);
+  double* lds = reinterpret_cast<double*>(smem_raw);
+  DecInFwdStage st;
+  st.issue(B, N, C, Tin, lat_v, wg1, w0, w1, true);
+  st.commit(lds);
+  __syncthreads();
+  dec_input_fwd_body(B, N, C, Tin, pdec, s0, v0, lds);
 }
 
 // backward.  g_p holds the gradient w.r.t. pdec accumulated by the levels.  part row per jet:
 //   dW00 [2][C] | dW11 [2][C] | dWg1 [2][N][Tin]
-// Every global operand is read once up front; the reductions over the particles run on LDS data.
-__device__ __forceinline__ void dec_input_bwd_body(int B, int N, int C, int Tin, const double* __restrict__ lat_v,
-                                                             const double* __restrict__ wg1, const double* __restrict__ w1,
-                                                             const double* __restrict__ pdec, const double* __restrict__ g_p,
-                                                             const double* __restrict__ g_s0, const double* __restrict__ g_v0,
-                                                             double* g_lat_v, double* part, unsigned char* smem_raw) {
-  double* gcan = reinterpret_cast<double*>(smem_raw);    // [N][8] gradient w.r.t. the canonical momenta
+// LDS: gcan [N][8] | gcart [N][8] | tmp [N*C][4] | wgl [2][N][Tin] | latl [Tin][8] | gp_l [N][8] | pd_l [N][8] | gs_l [N*C][2] |
+//      gv_l [N*C][8] | w1l [2C]
+__host__ __device__ inline size_t dec_in_bwd_doubles(int N, int C, int Tin) {
+  return (size_t)N * 16 + (size_t)N * C * 4 + 2 * (size_t)N * Tin + (size_t)Tin * 8 + (size_t)N * 16 + (size_t)N * C * 10 + 2 * (size_t)C;
+}
+struct DecInBwdStage {
+  StageRegs<4> gvr, gvi, wg;
+  StageRegs<1> gpr, gpi, pdr, pdi, gsr, gsi, lr, li, a1;
+  const double *gv0, *gv1, *wg1, *gp0, *gp1, *pd0, *pd1, *gs0, *gs1, *l0, *l1, *w1;
+  int N, C, Tin;
+  __device__ __forceinline__ void issue(int B, int N_, int C_, int Tin_, const double* __restrict__ lat_v, const double* __restrict__ wg1_,
+                                        const double* __restrict__ w1_, const double* __restrict__ pdec, const double* __restrict__ g_p,
+                                        const double* __restrict__ g_s0, const double* __restrict__ g_v0) {
+    N = N_; C = C_; Tin = Tin_; wg1 = wg1_; w1 = w1_;
+    const int b = blockIdx.x;
+    const size_t plp = (size_t)B * N * 4, pl = (size_t)B * N * C, j4 = (size_t)b * N * 4, jc = (size_t)b * N * C;
+    gv0 = g_v0 + jc * 4; gv1 = g_v0 + (pl + jc) * 4; gp0 = g_p + j4; gp1 = g_p + plp + j4; pd0 = pdec + j4; pd1 = pdec + plp + j4;
+    gs0 = g_s0 + jc; gs1 = g_s0 + pl + jc; l0 = lat_v + (size_t)b * Tin * 4; l1 = lat_v + ((size_t)B + b) * Tin * 4;
+    gvr.issue(gv0, N * C * 4); gvi.issue(gv1, N * C * 4); wg.issue(wg1, 2 * N * Tin);
+    gpr.issue(gp0, N * 4); gpi.issue(gp1, N * 4); pdr.issue(pd0, N * 4); pdi.issue(pd1, N * 4);
+    gsr.issue(gs0, N * C); gsi.issue(gs1, N * C); lr.issue(l0, Tin * 4); li.issue(l1, Tin * 4); a1.issue(w1, 2 * C);
+  }
+  __device__ __forceinline__ void commit(double* lds) const {
+    double* wgl = lds + N * 16 + N * C * 4;
+    double* latl = wgl + 2 * N * Tin;
+    double* gp_l = latl + Tin * 8;
+    double* pd_l = gp_l + N * 8;
+    double* gs_l = pd_l + N * 8;
+    double* gv_l = gs_l + N * C * 2;
+    double* w1l = gv_l + N * C * 8;
+    gvr.commit(gv0, N * C * 4, [&](int e, double x) { gv_l[(e >> 2) * 8 + (e & 3)] = x; });
+    gvi.commit(gv1, N * C * 4, [&](int e, double x) { gv_l[(e >> 2) * 8 + 4 + (e & 3)] = x; });
+    wg.commit(wg1, 2 * N * Tin, [&](int e, double x) { wgl[e] = x; });
+    gpr.commit(gp0, N * 4, [&](int e, double x) { gp_l[(e >> 2) * 8 + (e & 3)] = x; });
+    gpi.commit(gp1, N * 4, [&](int e, double x) { gp_l[(e >> 2) * 8 + 4 + (e & 3)] = x; });
+    pdr.commit(pd0, N * 4, [&](int e, double x) { pd_l[(e >> 2) * 8 + (e & 3)] = x; });
+    pdi.commit(pd1, N * 4, [&](int e, double x) { pd_l[(e >> 2) * 8 + 4 + (e & 3)] = x; });
+    gsr.commit(gs0, N * C, [&](int e, double x) { gs_l[e * 2] = x; });
+    gsi.commit(gs1, N * C, [&](int e, double x) { gs_l[e * 2 + 1] = x; });
+    lr.commit(l0, Tin * 4, [&](int e, double x) { latl[(e >> 2) * 8 + (e & 3)] = x; });
+    li.commit(l1, Tin * 4, [&](int e, double x) { latl[(e >> 2) * 8 + 4 + (e & 3)] = x; });
+    a1.commit(w1, 2 * C, [&](int e, double x) { w1l[e] = x; });
+  }
+};
+// after dec_input_bwd_stage + a barrier.  TO_LDS: g_lat_l (LDS [Tin][8]) also receives this jet's latent-vector gradient.
+template <bool TO_LDS>
+__device__ __forceinline__ void dec_input_bwd_body(int B, int N, int C, int Tin, double* g_lat_v, double* part, double* lds, double* g_lat_l) {
+  double* gcan = lds;                                    // [N][8] gradient w.r.t. the canonical momenta
   double* gcart = gcan + N * 8;                          // [N][8] gradient w.r.t. the complex Cartesian momenta
   double* tmp = gcart + N * 8;                           // [N*C][4] input-mixing terms
-  double* wgl = tmp + N * C * 4;                         // [2][N][Tin]
-  double* latl = wgl + 2 * N * Tin;                      // [Tin][8]
+  const double* wgl = tmp + N * C * 4;                   // [2][N][Tin]
+  const double* latl = wgl + 2 * N * Tin;                // [Tin][8]
+  const double* gp_l = latl + Tin * 8;
+  const double* pd_l = gp_l + N * 8;
+  const double* gs_l = pd_l + N * 8;
+  const double* gv_l = gs_l + N * C * 2;
+  const double* w1l = gv_l + N * C * 8;
   const int b = blockIdx.x;
-  const size_t plp = (size_t)B * N * 4, pl = (size_t)B * N * C;
   double* row = part + (size_t)b * (4 * C + 2 * N * Tin);
-  for (int e = threadIdx.x; e < 2 * N * Tin; e += BLOCK) wgl[e] = wg1[e];
-  for (int e = threadIdx.x; e < Tin * 4; e += BLOCK) {
-    latl[(e >> 2) * 8 + (e & 3)] = lat_v[(size_t)b * Tin * 4 + e];
-    latl[(e >> 2) * 8 + 4 + (e & 3)] = lat_v[((size_t)B + b) * Tin * 4 + e];
-  }
+  STAMP(11);
   for (int e = threadIdx.x; e < N * 4; e += BLOCK) {     // (n, m): G_pc[m] = g_p + sum_c g_v0[c][m] conj(W11[c])
     const int n = e >> 2, m = e & 3;
-    const size_t node = (size_t)b * N + n;
-    cx<double> g = {g_p[node * 4 + m], g_p[plp + node * 4 + m]};
-    for (int c = 0; c < C; ++c) {
-      const size_t x = (node * C + c) * 4 + m;
-      cfmac(g, cx<double>{g_v0[x], g_v0[pl * 4 + x]}, cx<double>{w1[c], w1[C + c]});
-    }
+    cx<double> g = {gp_l[n * 8 + m], gp_l[n * 8 + 4 + m]};
+#pragma unroll 4
+    for (int c = 0; c < C; ++c)
+      cfmac(g, cx<double>{gv_l[(n * C + c) * 8 + m], gv_l[(n * C + c) * 8 + 4 + m]}, cx<double>{w1l[c], w1l[C + c]});
     gcan[n * 8 + m] = g.r;
     gcan[n * 8 + 4 + m] = g.i;
   }
   for (int i = threadIdx.x; i < N * C; i += BLOCK) {     // (n, c): terms of dW00, dW11
     const int n = i / C;
-    const size_t node = (size_t)b * N + n, e = (size_t)b * N * C + i;
     cx<double> d0 = {0, 0}, d1 = {0, 0};
-    cfmac(d0, cx<double>{g_s0[e], g_s0[pl + e]}, cx<double>{1.0, 1.0});
+    cfmac(d0, cx<double>{gs_l[i * 2], gs_l[i * 2 + 1]}, cx<double>{1.0, 1.0});
 #pragma unroll
     for (int m = 0; m < 4; ++m)
-      cfmac(d1, cx<double>{g_v0[e * 4 + m], g_v0[pl * 4 + e * 4 + m]}, cx<double>{pdec[node * 4 + m], pdec[plp + node * 4 + m]});
+      cfmac(d1, cx<double>{gv_l[i * 8 + m], gv_l[i * 8 + 4 + m]}, cx<double>{pd_l[n * 8 + m], pd_l[n * 8 + 4 + m]});
     tmp[i * 4 + 0] = d0.r;  tmp[i * 4 + 1] = d0.i;  tmp[i * 4 + 2] = d1.r;  tmp[i * 4 + 3] = d1.i;
   }
   __syncthreads();
-  for (int n = threadIdx.x; n < N; n += BLOCK) {
-    cx<double> g[4], gc[4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) g[m] = {gcan[n * 8 + m], gcan[n * 8 + 4 + m]};
-    canon_cplx_bwd(g, gc);
-#pragma unroll
-    for (int m = 0; m < 4; ++m) { gcart[n * 8 + m] = gc[m].r; gcart[n * 8 + 4 + m] = gc[m].i; }
+  STAMP(12);
+  for (int e = threadIdx.x; e < N * 4; e += BLOCK) {
+    const cx<double> gc = canon_cplx_bwd_m(gcan + (e >> 2) * 8, e & 3);
+    gcart[(e >> 2) * 8 + (e & 3)] = gc.r;
+    gcart[(e >> 2) * 8 + 4 + (e & 3)] = gc.i;
   }
-  if ((int)threadIdx.x >= 64 && (int)threadIdx.x < 64 + 4 * C) {   // input mixing weights (a wave that is idle above)
-    const int k = (threadIdx.x - 64) / C, c = (threadIdx.x - 64) - k * C;
+  if ((int)threadIdx.x >= BLOCK - 64 && (int)threadIdx.x < BLOCK - 64 + 4 * C) {   // input mixing weights (the last wave: idle above for N <= 48)
+    const int k = (threadIdx.x - (BLOCK - 64)) / C, c = (threadIdx.x - (BLOCK - 64)) - k * C;
     double acc = 0.0;
+#pragma unroll 6
     for (int n = 0; n < N; ++n) acc += tmp[(n * C + c) * 4 + k];
     row[k * C + c] = acc;
   }
   __syncthreads();
+  STAMP(13);
   for (int e = threadIdx.x; e < Tin * 4; e += BLOCK) {    // g_lat_v[t][m] = sum_n G_cart[n][m] conj(Wg1[n][t])
     const int t = e >> 2, m = e & 3;
     cx<double> acc = {0, 0};
+#pragma unroll 6
     for (int n = 0; n < N; ++n)
       cfmac(acc, cx<double>{gcart[n * 8 + m], gcart[n * 8 + 4 + m]}, cx<double>{wgl[n * Tin + t], wgl[N * Tin + n * Tin + t]});
     g_lat_v[((size_t)b * Tin + t) * 4 + m] = acc.r;
     g_lat_v[(((size_t)B + b) * Tin + t) * 4 + m] = acc.i;
+    if constexpr (TO_LDS) { g_lat_l[t * 8 + m] = acc.r; g_lat_l[t * 8 + 4 + m] = acc.i; }
   }
   for (int e = threadIdx.x; e < N * Tin; e += BLOCK) {    // dWg1[n][t] = sum_m G_cart[n][m] conj(lat[t][m])
     const int n = e / Tin, t = e - n * Tin;
@@ -454,38 +663,86 @@ __global__ __launch_bounds__(BLOCK) void dec_input_bwd_kernel(int B, int N, int 
                                                              const double* __restrict__ g_s0, const double* __restrict__ g_v0,
                                                              double* g_lat_v, double* part) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
-  dec_input_bwd_body(B, N, C, Tin, lat_v, wg1, w1, pdec, g_p, g_s0, g_v0, g_lat_v, part, smem_raw);
+  double* lds = reinterpret_cast<double*>(smem_raw);
+  DecInBwdStage st;
+  st.issue(B, N, C, Tin, lat_v, wg1, w1, pdec, g_p, g_s0, g_v0);
+  st.commit(lds);
+  __syncthreads();
+  dec_input_bwd_body<false>(B, N, C, Tin, g_lat_v, part, lds, nullptr);
 }
 
 // ============================================================================================
 // encoder -> decoder junction, one launch per direction: the decoder input of a jet needs only that jet's latent
-// vectors (and vice versa for the gradients), so the two per-jet kernels run back to back in the same workgroup.
+// vectors (and vice versa for the gradients), so the two per-jet kernels run back to back in the same workgroup --
+// both stages' global operands are fetched together up front, the latent vectors (gradients) pass through LDS.
 // ============================================================================================
+// overlap = 0 (large jets: the two stages' LDS blocks would not fit side by side): the stages share LDS and fetch in turn.
 __global__ __launch_bounds__(BLOCK) void junction_fwd_kernel(int B, int N, int CL, int Ts, int Tv, const double* s, const double* v,
                                                             const double* wl0, const double* wl1, double* lat_s, double* lat_v,
                                                             int* idx, int C0, const double* wg1, const double* w0, const double* w1,
-                                                            double* pdec, double* s0, double* v0) {
+                                                            double* pdec, double* s0, double* v0, int overlap) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
-  enc_latent_fwd_body(B, N, CL, Ts, Tv, s, v, wl0, wl1, lat_s, lat_v, idx, smem_raw);
-  __syncthreads();                                       // this jet's lat_v (global) is visible to the whole workgroup
-  dec_input_fwd_body(B, N, C0, 2 * Tv, lat_v, wg1, w0, w1, pdec, s0, v0, smem_raw);
+  double* lat_lds = reinterpret_cast<double*>(smem_raw);
+  // overlap: behind the encoder stage's block; else over its sv / weight regions, which are dead once y is complete
+  double* dec_lds = lat_lds + (overlap ? lat_fwd_doubles(N, CL, Ts, Tv) : (size_t)N * (2 * Ts + 8 * Tv));
+  const int Tin = 2 * Tv;
+  STAMP(0);
+  LatentStage ls;
+  DecInFwdStage ds;
+  ls.issue(B, N, CL, Ts, Tv, s, v, wl0, wl1);
+  if (overlap) ds.issue(B, N, C0, Tin, nullptr, wg1, w0, w1, false);
+  ls.commit(lat_lds, false);
+  if (overlap) ds.commit(dec_lds);
+  __syncthreads();
+  enc_latent_fwd_body<true>(B, N, CL, Ts, Tv, lat_s, lat_v, idx, lat_lds, dec_lds + 2 * N * Tin);
+  if (!overlap) {
+    ds.issue(B, N, C0, Tin, nullptr, wg1, w0, w1, false);
+    ds.commit(dec_lds);
+  }
+  __syncthreads();                                       // the latent vectors of the jet are in the decoder stage's LDS block
+  dec_input_fwd_body(B, N, C0, Tin, pdec, s0, v0, dec_lds);
+  STAMP(5);
 }
 __global__ __launch_bounds__(BLOCK) void junction_bwd_kernel(int B, int N, int C0, int Tin, const double* lat_v, const double* wg1,
                                                             const double* w1, const double* pdec, const double* g_p,
                                                             const double* g_s0, const double* g_v0, double* g_lat_v, double* part_dec,
                                                             int CL, int Ts, int Tv, const double* s, const double* v,
                                                             const double* wl0, const double* wl1, const double* g_lat_s,
-                                                            const int* idx, double* g_s, double* g_v, double* part_enc) {
+                                                            const int* idx, double* g_s, double* g_v, double* part_enc, int overlap) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
-  dec_input_bwd_body(B, N, C0, Tin, lat_v, wg1, w1, pdec, g_p, g_s0, g_v0, g_lat_v, part_dec, smem_raw);
-  __syncthreads();                                       // this jet's g_lat_v is visible; the LDS scratch is free again
-  enc_latent_bwd_body(B, N, CL, Ts, Tv, s, v, wl0, wl1, g_lat_s, g_lat_v, idx, g_s, g_v, part_enc, smem_raw);
+  double* dec_lds = reinterpret_cast<double*>(smem_raw);
+  const size_t nd = dec_in_bwd_doubles(N, C0, Tin), nl = lat_bwd_doubles(N, CL, Ts, Tv);
+  double* g_lat_l = dec_lds + (overlap ? nd : (nd > nl ? nd : nl));      // [Tin][8], outside both stages' blocks
+  double* lat_lds = overlap ? g_lat_l + Tin * 8 : dec_lds;
+  STAMP(10);
+  DecInBwdStage ds;
+  LatentStage ls;
+  LatentBwdPrefetch pre;
+  ds.issue(B, N, C0, Tin, lat_v, wg1, w1, pdec, g_p, g_s0, g_v0);
+  pre.issue(B, Ts, Tv, idx, g_lat_s);
+  if (overlap) ls.issue(B, N, CL, Ts, Tv, s, v, wl0, wl1);
+  ds.commit(dec_lds);
+  if (overlap) ls.commit(lat_lds, true);
+  __syncthreads();
+  dec_input_bwd_body<true>(B, N, C0, Tin, g_lat_v, part_dec, dec_lds, g_lat_l);
+  __syncthreads();                                       // this jet's latent-vector gradient is in LDS; the decoder stage's block is free
+  if (!overlap) {
+    ls.issue(B, N, CL, Ts, Tv, s, v, wl0, wl1);
+    ls.commit(lat_lds, true);
+    __syncthreads();
+  }
+  enc_latent_bwd_body<true>(B, N, CL, Ts, Tv, g_lat_s, nullptr, g_lat_l, idx, g_s, g_v, part_enc, lat_lds, pre);
+  STAMP(19);
 }
 
 // ============================================================================================
 // decoder output + get_real('sum') + Chamfer loss, forward and backward in one pass per jet
 //   recon [2][B][N][4]; loss_part [B]; g_v [2][B][N][C][4]; part row per jet: dWo1 [2][C]
+// LDS: x [N][4] | tg [N][4] | rmin [N] | cmin [N] | gx [N][4] | ycl [N][8] | vl [N*C][8] | tmp [N*C][2] | wol [2C] | rarg, carg [N] ints
 // ============================================================================================
+__host__ __device__ inline size_t dec_out_loss_bytes(int N, int C) {
+  return sizeof(double) * ((size_t)N * 22 + (size_t)N * C * 10 + 2 * (size_t)C) + sizeof(int) * 2 * (size_t)N;
+}
 __global__ __launch_bounds__(BLOCK) void dec_output_loss_kernel(int B, int N, int C, const double* __restrict__ v,
                                                                const double* __restrict__ wo1, const double* __restrict__ target,
                                                                double loss_scale, double* recon, double* loss_part, double* g_v,
@@ -496,104 +753,119 @@ __global__ __launch_bounds__(BLOCK) void dec_output_loss_kernel(int B, int N, in
   double* rmin = tg + N * 4;                             // [N]
   double* cmin = rmin + N;                               // [N]
   double* gx = cmin + N;                                 // [N][4]
-  int* rarg = reinterpret_cast<int*>(gx + N * 4);        // [N]
+  double* ycl = gx + N * 4;                              // [N][8] canonical output (re[4] | im[4])
+  double* vl = ycl + N * 8;                              // [N*C][8] the last level's vectors (re[4] | im[4])
+  double* tmp = vl + N * C * 8;                          // [N*C][2]
+  double* wol = tmp + N * C * 2;                         // [2C]
+  int* rarg = reinterpret_cast<int*>(wol + 2 * C);       // [N]
   int* carg = rarg + N;                                  // [N]
   __shared__ double red[4];
   const int b = blockIdx.x;
-  const size_t plp = (size_t)B * N * 4, pl = (size_t)B * N * C;
-  for (int n = threadIdx.x; n < N; n += BLOCK) {
-    const size_t node = (size_t)b * N + n;
-    cx<double> yc[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}}, pc[4];
-    for (int c = 0; c < C; ++c) {
-      const cx<double> w = {wo1[c], wo1[C + c]};
-      const size_t e = node * C + c;
-#pragma unroll
-      for (int m = 0; m < 4; ++m) cfma(yc[m], w, cx<double>{v[e * 4 + m], v[pl * 4 + e * 4 + m]});
-    }
-    cart_from_canon(yc, pc);
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      recon[node * 4 + m] = pc[m].r;
-      recon[plp + node * 4 + m] = pc[m].i;
-      x[n * 4 + m] = pc[m].r + pc[m].i;                  // get_real(., 'sum')
-      tg[n * 4 + m] = target[node * 4 + m];
-    }
+  const size_t plp = (size_t)B * N * 4, pl = (size_t)B * N * C, j4 = (size_t)b * N * 4, jc = (size_t)b * N * C;
+  STAMP(20);
+  {
+    StageRegs<4> vr, vi;
+    StageRegs<1> tr, wr;
+    vr.issue(v + jc * 4, N * C * 4); vi.issue(v + (pl + jc) * 4, N * C * 4); tr.issue(target + j4, N * 4); wr.issue(wo1, 2 * C);
+    vr.commit(v + jc * 4, N * C * 4, [&](int e, double q) { vl[(e >> 2) * 8 + (e & 3)] = q; });
+    vi.commit(v + (pl + jc) * 4, N * C * 4, [&](int e, double q) { vl[(e >> 2) * 8 + 4 + (e & 3)] = q; });
+    tr.commit(target + j4, N * 4, [&](int e, double q) { tg[e] = q; });
+    wr.commit(wo1, 2 * C, [&](int e, double q) { wol[e] = q; });
   }
   __syncthreads();
-  // squared Euclidean distances d(i,j) = |t_j - x_i|^2; row minima (over j) and column minima (over i)
-  for (int e = threadIdx.x; e < 2 * N; e += BLOCK) {
-    const bool rowwise = e < N;
-    const int a = rowwise ? e : e - N;
+  for (int e = threadIdx.x; e < N * 4; e += BLOCK) {     // (node, component): mix_to_output on the (1,1) irrep
+    const int n = e >> 2, m = e & 3;
+    cx<double> yc = {0, 0};
+#pragma unroll 4
+    for (int c = 0; c < C; ++c)
+      cfma(yc, cx<double>{wol[c], wol[C + c]}, cx<double>{vl[(n * C + c) * 8 + m], vl[(n * C + c) * 8 + 4 + m]});
+    ycl[n * 8 + m] = yc.r;
+    ycl[n * 8 + 4 + m] = yc.i;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < N * 4; e += BLOCK) {
+    const cx<double> pc = cart_from_canon_m(ycl + (e >> 2) * 8, e & 3);
+    recon[j4 + e] = pc.r;
+    recon[plp + j4 + e] = pc.i;
+    x[e] = pc.r + pc.i;                                  // get_real(., 'sum')
+  }
+  __syncthreads();
+  STAMP(21);
+  // squared Euclidean distances d(i,j) = |t_j - x_i|^2; row minima (over j) and column minima (over i), first occurrence:
+  // four lanes per row / column scan a quarter of the range each, then meet on (distance, index)
+  const int nq = (N + 3) / 4;
+  for (int e = threadIdx.x; e < 8 * N; e += BLOCK) {
+    const bool rowwise = (e >> 2) < N;
+    const int a = rowwise ? e >> 2 : (e >> 2) - N, q = e & 3;
     double best = 0;
-    int arg = 0;
-    for (int o = 0; o < N; ++o) {
+    int arg = 0x7fffffff;
+#pragma unroll 4
+    for (int o = q * nq; o < min(N, (q + 1) * nq); ++o) {
       const double* xi = x + (rowwise ? a : o) * 4;
       const double* tj = tg + (rowwise ? o : a) * 4;
       double d0 = tj[0] - xi[0], d1 = tj[1] - xi[1], d2 = tj[2] - xi[2], d3 = tj[3] - xi[3];
       double d = ((d0 * d0 + d1 * d1) + d2 * d2) + d3 * d3;
-      if (o == 0 || d < best) { best = d; arg = o; }
+      if (arg == 0x7fffffff || d < best) { best = d; arg = o; }
     }
-    if (rowwise) { rmin[a] = best; rarg[a] = arg; } else { cmin[a] = best; carg[a] = arg; }
+#pragma unroll
+    for (int off = 2; off; off >>= 1) {
+      const double ob = __shfl_xor(best, off, 4);
+      const int oa = __shfl_xor(arg, off, 4);
+      if (oa != 0x7fffffff && (arg == 0x7fffffff || ob < best || (ob == best && oa < arg))) { best = ob; arg = oa; }
+    }
+    if (q == 0) {
+      if (rowwise) { rmin[a] = best; rarg[a] = arg; } else { cmin[a] = best; carg[a] = arg; }
+    }
   }
   __syncthreads();
+  STAMP(22);
   double lsum = 0;
   for (int n = threadIdx.x; n < N; n += BLOCK) lsum += (rmin[n] + cmin[n]) * 0.5;
   lsum = block_sum(lsum, red);
   if (threadIdx.x == 0) loss_part[b] = lsum;
-  // d loss / d x_i = (x_i - t_{j*(i)}) + sum_{j : i*(j) = i} (x_i - t_j)
-  for (int i = threadIdx.x; i < N; i += BLOCK) {
-    double g[4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) g[m] = x[i * 4 + m] - tg[rarg[i] * 4 + m];
-    for (int j = 0; j < N; ++j)
-      if (carg[j] == i) {
-#pragma unroll
-        for (int m = 0; m < 4; ++m) g[m] += x[i * 4 + m] - tg[j * 4 + m];
-      }
-#pragma unroll
-    for (int m = 0; m < 4; ++m) gx[i * 4 + m] = g[m] * loss_scale;
+  STAMP(23);
+  // d loss / d x_i = (x_i - t_{j*(i)}) + sum_{j : i*(j) = i} (x_i - t_j)      (two lanes per (i, component): a half of the j range each)
+  const int nh = (N + 1) / 2;
+  for (int e = threadIdx.x; e < N * 8; e += BLOCK) {
+    const int im = e >> 1, h = e & 1, i = im >> 2, m = im & 3;
+    const double xi = x[im];
+    double g = h ? 0.0 : xi - tg[rarg[i] * 4 + m];
+#pragma unroll 5
+    for (int j = h * nh; j < min(N, (h + 1) * nh); ++j) g += carg[j] == i ? xi - tg[j * 4 + m] : 0.0;
+    g += __shfl_xor(g, 1, 2);
+    if (h == 0) gx[im] = g * loss_scale;
   }
   __syncthreads();
-  // back through get_real (both planes receive g), rep_to_p and mix_to_output
+  STAMP(24);
+  // back through get_real (both planes receive g), rep_to_p and mix_to_output; dWo1[c] = sum_n sum_m G_yc[n][m] conj(v[n][c][m])
   for (int e = threadIdx.x; e < N * C; e += BLOCK) {
     const int n = e / C, c = e - n * C;
-    cx<double> g[4], gc[4];
+    cx<double> g[4], gc[4], d = {0, 0};
 #pragma unroll
     for (int m = 0; m < 4; ++m) g[m] = {gx[n * 4 + m], gx[n * 4 + m]};
     cart_from_canon_bwd(g, gc);
-    const cx<double> w = {wo1[c], wo1[C + c]};
-    const size_t base = ((size_t)b * N + n) * C + c;
+    const cx<double> w = {wol[c], wol[C + c]};
+    const size_t base = jc + e;
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       cx<double> r = cmulc(gc[m], w);
       g_v[base * 4 + m] = r.r;
       g_v[pl * 4 + base * 4 + m] = r.i;
+      cfmac(d, gc[m], cx<double>{vl[e * 8 + m], vl[e * 8 + 4 + m]});
     }
-  }
-  // dWo1[c] = sum_n sum_m G_yc[n][m] conj(v[n][c][m]): (n, c) terms to LDS (the distance scratch is dead), then 2C sums
-  __syncthreads();
-  double* tmp = x;                                        // [N*C][2] over x | tg (8N doubles >= 2NC for C <= 4) ...
-  double* tmpbig = reinterpret_cast<double*>(carg + N);   // ... or the spill region for wider outputs
-  if (2 * C > 8) tmp = tmpbig;
-  for (int e = threadIdx.x; e < N * C; e += BLOCK) {
-    const int n = e / C;
-    cx<double> g[4], gc[4], d = {0, 0};
-#pragma unroll
-    for (int m = 0; m < 4; ++m) g[m] = {gx[n * 4 + m], gx[n * 4 + m]};
-    cart_from_canon_bwd(g, gc);
-    const size_t base = (size_t)b * N * C + e;
-#pragma unroll
-    for (int m = 0; m < 4; ++m) cfmac(d, gc[m], cx<double>{v[base * 4 + m], v[pl * 4 + base * 4 + m]});
     tmp[e * 2] = d.r;
     tmp[e * 2 + 1] = d.i;
   }
   __syncthreads();
+  STAMP(26);
   if ((int)threadIdx.x < 2 * C) {
     const int k = threadIdx.x / C, c = threadIdx.x - k * C;
     double acc = 0.0;
+#pragma unroll 6
     for (int n = 0; n < N; ++n) acc += tmp[(n * C + c) * 2 + k];
     part[(size_t)b * 2 * C + k * C + c] = acc;
   }
+  STAMP(27);
 }
 
 // ============================================================================================
@@ -735,12 +1007,13 @@ int enc_input_bwd(int B, int N, int C, const double* p4, const double* g_s, cons
   LGN_CHECK_LAUNCH();
   return 0;
 }
-static size_t latent_smem(int N, int Ts, int Tv) { return sizeof(double) * (size_t)N * (2 * Ts + 8 * Tv); }
+#define LGN_LDS_LAUNCH(kernel, what, smem)                                                                            \
+  LGN_CHECK_ARG((smem) <= 160 * 1024, what ": needs %zu B of LDS", (size_t)(smem));                                    \
+  if ((smem) > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(smem))
 int enc_latent_fwd(int B, int N, int C, int Ts, int Tv, const double* s, const double* v, const double* wl0, const double* wl1,
                    double* lat_s, double* lat_v, int* idx, hipStream_t st) {
-  const size_t smem = latent_smem(N, Ts, Tv);
-  LGN_CHECK_ARG(smem <= 160 * 1024, "enc_latent: N=%d tau=(%d,%d) needs %zu B of LDS", N, Ts, Tv, smem);
-  if (smem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(enc_latent_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  const size_t smem = sizeof(double) * lat_fwd_doubles(N, C, Ts, Tv);
+  LGN_LDS_LAUNCH(enc_latent_fwd_kernel, "enc_latent_fwd", smem);
   hipLaunchKernelGGL(enc_latent_fwd_kernel, dim3(B), dim3(BLOCK), smem, st, B, N, C, Ts, Tv, s, v, wl0, wl1, lat_s, lat_v, idx);
   LGN_CHECK_LAUNCH();
   return 0;
@@ -748,9 +1021,8 @@ int enc_latent_fwd(int B, int N, int C, int Ts, int Tv, const double* s, const d
 int enc_latent_bwd(int B, int N, int C, int Ts, int Tv, const double* s, const double* v, const double* wl0, const double* wl1,
                    const double* g_lat_s, const double* g_lat_v, const int* idx, double* g_s, double* g_v, double* part,
                    hipStream_t st) {
-  const size_t smem = latent_smem(N, Ts, Tv) + sizeof(double) * ((size_t)N * C * 10 + 2 * (Ts + Tv) * C + LAT_PARTS * (Ts + Tv) * C * 2);
-  LGN_CHECK_ARG(smem <= 160 * 1024, "enc_latent_bwd: needs %zu B of LDS", smem);
-  if (smem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(enc_latent_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  const size_t smem = sizeof(double) * lat_bwd_doubles(N, C, Ts, Tv);
+  LGN_LDS_LAUNCH(enc_latent_bwd_kernel, "enc_latent_bwd", smem);
   hipLaunchKernelGGL(enc_latent_bwd_kernel, dim3(B), dim3(BLOCK), smem, st, B, N, C, Ts, Tv, s, v, wl0, wl1, g_lat_s, g_lat_v, idx,
                      g_s, g_v, part);
   LGN_CHECK_LAUNCH();
@@ -758,17 +1030,16 @@ int enc_latent_bwd(int B, int N, int C, int Ts, int Tv, const double* s, const d
 }
 int dec_input_fwd(int B, int N, int C, int Tin, const double* lat_v, const double* wg1, const double* w0, const double* w1,
                   double* pdec, double* s0, double* v0, hipStream_t st) {
-  const size_t smem = sizeof(double) * (2 * (size_t)N * Tin + (size_t)Tin * 8);
-  LGN_CHECK_ARG(smem <= 64 * 1024, "dec_input_fwd: needs %zu B of LDS", smem);
+  const size_t smem = sizeof(double) * dec_in_fwd_doubles(N, C, Tin);
+  LGN_LDS_LAUNCH(dec_input_fwd_kernel, "dec_input_fwd", smem);
   hipLaunchKernelGGL(dec_input_fwd_kernel, dim3(B), dim3(BLOCK), smem, st, B, N, C, Tin, lat_v, wg1, w0, w1, pdec, s0, v0);
   LGN_CHECK_LAUNCH();
   return 0;
 }
 int dec_input_bwd(int B, int N, int C, int Tin, const double* lat_v, const double* wg1, const double* w1, const double* pdec,
                   const double* g_p, const double* g_s0, const double* g_v0, double* g_lat_v, double* part, hipStream_t st) {
-  const size_t smem = sizeof(double) * ((size_t)N * 16 + (size_t)N * C * 4 + 2 * (size_t)N * Tin + (size_t)Tin * 8);
-  LGN_CHECK_ARG(smem <= 160 * 1024, "dec_input_bwd: needs %zu B of LDS", smem);
-  if (smem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_input_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  const size_t smem = sizeof(double) * dec_in_bwd_doubles(N, C, Tin);
+  LGN_LDS_LAUNCH(dec_input_bwd_kernel, "dec_input_bwd", smem);
   hipLaunchKernelGGL(dec_input_bwd_kernel, dim3(B), dim3(BLOCK), smem, st, B, N, C, Tin, lat_v, wg1, w1, pdec, g_p,
                      g_s0, g_v0, g_lat_v, part);
   LGN_CHECK_LAUNCH();
@@ -776,7 +1047,8 @@ int dec_input_bwd(int B, int N, int C, int Tin, const double* lat_v, const doubl
 }
 int dec_output_loss(int B, int N, int C, const double* v, const double* wo1, const double* target, double loss_scale, double* recon,
                     double* loss_part, double* g_v, double* part, hipStream_t st) {
-  const size_t smem = sizeof(double) * (size_t)N * 14 + sizeof(int) * (size_t)N * 2 + 16 + (2 * C > 8 ? sizeof(double) * (size_t)N * C * 2 : 0);
+  const size_t smem = dec_out_loss_bytes(N, C);
+  LGN_LDS_LAUNCH(dec_output_loss_kernel, "dec_output_loss", smem);
   hipLaunchKernelGGL(dec_output_loss_kernel, dim3(B), dim3(BLOCK), smem, st, B, N, C, v, wo1, target, loss_scale, recon, loss_part,
                      g_v, part);
   LGN_CHECK_LAUNCH();
@@ -796,21 +1068,17 @@ int dec_output_bwd(int B, int N, int C, const double* v, const double* wo1, cons
   LGN_CHECK_LAUNCH();
   return 0;
 }
-static size_t latent_bwd_smem(int N, int C, int Ts, int Tv) {
-  return latent_smem(N, Ts, Tv) + sizeof(double) * ((size_t)N * C * 10 + 2 * (Ts + Tv) * C + LAT_PARTS * (Ts + Tv) * C * 2);
-}
-static size_t dec_input_bwd_smem(int N, int C, int Tin) {
-  return sizeof(double) * ((size_t)N * 16 + (size_t)N * C * 4 + 2 * (size_t)N * Tin + (size_t)Tin * 8);
-}
+// The two stages of a junction keep their LDS blocks side by side (all fetches up front) while that stays within 64 KB per
+// workgroup; larger jets run them in turn on shared LDS.
 int junction_fwd(int B, int N, int CL, int Ts, int Tv, const double* s, const double* v, const double* wl0, const double* wl1,
                  double* lat_s, double* lat_v, int* idx, int C0, const double* wg1, const double* w0, const double* w1, double* pdec,
                  double* s0, double* v0, hipStream_t st) {
-  const size_t s2 = sizeof(double) * (2 * (size_t)N * 2 * Tv + (size_t)2 * Tv * 8);   // dec_input_fwd part (Tin = 2 Tv)
-  const size_t smem = latent_smem(N, Ts, Tv) > s2 ? latent_smem(N, Ts, Tv) : s2;
-  LGN_CHECK_ARG(smem <= 160 * 1024, "junction_fwd: N=%d tau=(%d,%d) needs %zu B of LDS", N, Ts, Tv, smem);
-  if (smem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(junction_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  const size_t nl = lat_fwd_doubles(N, CL, Ts, Tv), nd = dec_in_fwd_doubles(N, C0, 2 * Tv), ny = (size_t)N * (2 * Ts + 8 * Tv);
+  const int overlap = sizeof(double) * (nl + nd) <= 64 * 1024;
+  const size_t smem = sizeof(double) * (overlap ? nl + nd : ny + (nl - ny > nd ? nl - ny : nd));
+  LGN_LDS_LAUNCH(junction_fwd_kernel, "junction_fwd", smem);
   hipLaunchKernelGGL(junction_fwd_kernel, dim3(B), dim3(BLOCK), smem, st, B, N, CL, Ts, Tv, s, v, wl0, wl1, lat_s, lat_v, idx, C0, wg1,
-                     w0, w1, pdec, s0, v0);
+                     w0, w1, pdec, s0, v0, overlap);
   LGN_CHECK_LAUNCH();
   return 0;
 }
@@ -818,11 +1086,13 @@ int junction_bwd(int B, int N, int C0, int Tin, const double* lat_v, const doubl
                  const double* g_p, const double* g_s0, const double* g_v0, double* g_lat_v, double* part_dec, int CL, int Ts, int Tv,
                  const double* s, const double* v, const double* wl0, const double* wl1, const double* g_lat_s, const int* idx,
                  double* g_s, double* g_v, double* part_enc, hipStream_t st) {
-  const size_t a = dec_input_bwd_smem(N, C0, Tin), b = latent_bwd_smem(N, CL, Ts, Tv), smem = a > b ? a : b;
-  LGN_CHECK_ARG(smem <= 160 * 1024, "junction_bwd: needs %zu B of LDS", smem);
-  if (smem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(junction_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  LGN_CHECK_ARG(Tin == 2 * Tv, "junction_bwd: the decoder takes the 2 Tv = %d pooled latent vectors, got Tin = %d", 2 * Tv, Tin);
+  const size_t nd = dec_in_bwd_doubles(N, C0, Tin), nl = lat_bwd_doubles(N, CL, Ts, Tv);
+  const int overlap = sizeof(double) * (nd + nl + (size_t)Tin * 8) <= 64 * 1024;
+  const size_t smem = sizeof(double) * ((overlap ? nd + nl : (nd > nl ? nd : nl)) + (size_t)Tin * 8);
+  LGN_LDS_LAUNCH(junction_bwd_kernel, "junction_bwd", smem);
   hipLaunchKernelGGL(junction_bwd_kernel, dim3(B), dim3(BLOCK), smem, st, B, N, C0, Tin, lat_v, wg1, w1, pdec, g_p, g_s0, g_v0, g_lat_v,
-                     part_dec, CL, Ts, Tv, s, v, wl0, wl1, g_lat_s, idx, g_s, g_v, part_enc);
+                     part_dec, CL, Ts, Tv, s, v, wl0, wl1, g_lat_s, idx, g_s, g_v, part_enc, overlap);
   LGN_CHECK_LAUNCH();
   return 0;
 }
