@@ -176,7 +176,12 @@ __global__ __launch_bounds__(64 * MT * NT) void mlp_fwd_mfma_kernel(MlpArgs<doub
   for (int l = 0; l < NH; ++l) {
     const double* Wcur = Wl + (l & 1) * G::WSIZE;
     prefetch_hidden<NT, MT>(a.w[l + 1], a.b[l + 1], l + 1 == NH ? D : H, H, regs, breg);
-    forward_layer<NT, KSH, MT>(l, Wcur, X0, Xb, mt, nt, lane, ksh, true);
+    const v4d hv = forward_layer<NT, KSH, MT>(l, Wcur, X0, Xb, mt, nt, lane, ksh, true);
+    if (a.h_saved) {                                           // kept for the backward (rows beyond M: finite values of zero inputs)
+      double* hs = a.h_saved + ((size_t)l * a.h_rows + wg_row0 + mt * 16 + (lane >> 4)) * G::HP + 16 * nt + (lane & 15);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) hs[(size_t)4 * r * G::HP] = hv[r];
+    }
     commit_hidden<NT, MT>(Wl + ((l + 1) & 1) * G::WSIZE, regs, breg);
     __syncthreads();
   }
@@ -212,21 +217,33 @@ __global__ __launch_bounds__(64 * MT * NT) void mlp_bwd_mfma_kernel(MlpArgs<doub
   double* dbw = X0 + MT * G::T0SIZE;                         // 2 x MT x HP column sums
   double* part = a.part + (size_t)blockIdx.x * a.psize;
 
-  // ---- forward recompute; h[l] = post-activation of hidden layer l, this wave's tile, D layout ---------
+  // ---- h[l] = post-activation of hidden layer l, this wave's tile, D layout: read back from the forward's copy, or recomputed
   double regs[G::NPH], breg;
-  prefetch_first<NT, MT>(a.w[0], a.b[0], H, D, regs, breg);
-  load_input_tiles<NT, MT>(a.s_in, M, a.C, wg_row0, X0);
-  commit_first<NT, MT>(Wl, regs, breg);
-  __syncthreads();
   v4d h[NH];
+  if (a.h_saved) {
+    prefetch_hidden<NT, MT>(a.w[NH], a.b[NH], D, H, regs, breg);        // the output layer: first layer of the backward sweep
+    load_input_tiles<NT, MT>(a.s_in, M, a.C, wg_row0, X0);
+    const double* hs = a.h_saved + ((size_t)wg_row0 + mt * 16 + g) * HP + 16 * nt + c;
 #pragma unroll
-  for (int l = 0; l < NH; ++l) {
-    const double* Wcur = Wl + (l & 1) * G::WSIZE;
-    // the weights of the next forward layer; after the last hidden layer: the output layer (first backward layer)
-    prefetch_hidden<NT, MT>(a.w[l + 1], a.b[l + 1], l + 1 == NH ? D : H, H, regs, breg);
-    h[l] = forward_layer<NT, KSH, MT>(l, Wcur, X0, Xb, mt, nt, lane, ksh, l + 1 < NH);
-    commit_hidden<NT, MT>(Wl + ((l + 1) & 1) * G::WSIZE, regs, breg);
+    for (int l = 0; l < NH; ++l)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) h[l][r] = hs[((size_t)l * a.h_rows + 4 * r) * HP];
+    commit_hidden<NT, MT>(Wl + (NH & 1) * G::WSIZE, regs, breg);
     __syncthreads();
+  } else {
+    prefetch_first<NT, MT>(a.w[0], a.b[0], H, D, regs, breg);
+    load_input_tiles<NT, MT>(a.s_in, M, a.C, wg_row0, X0);
+    commit_first<NT, MT>(Wl, regs, breg);
+    __syncthreads();
+#pragma unroll
+    for (int l = 0; l < NH; ++l) {
+      const double* Wcur = Wl + (l & 1) * G::WSIZE;
+      // the weights of the next forward layer; after the last hidden layer: the output layer (first backward layer)
+      prefetch_hidden<NT, MT>(a.w[l + 1], a.b[l + 1], l + 1 == NH ? D : H, H, regs, breg);
+      h[l] = forward_layer<NT, KSH, MT>(l, Wcur, X0, Xb, mt, nt, lane, ksh, l + 1 < NH);
+      commit_hidden<NT, MT>(Wl + ((l + 1) & 1) * G::WSIZE, regs, breg);
+      __syncthreads();
+    }
   }
 
   // ---- backward sweep; tile buffers of parity q alternate per layer -> one barrier per layer ------------
@@ -358,6 +375,8 @@ static int launch_mlp_mfma(const MlpArgs<double>& a, bool backward, hipStream_t 
 // H <= 48, 2C <= 16, 7 Linear layers.  Returns -2 if the shape is outside this kernel's range.
 int mlp_mfma_dispatch(const MlpArgs<double>& a, bool backward, hipStream_t stream) {
   if (a.nlin != 7 || a.H > 48 || 2 * a.C > 16 || a.H < 2 * a.C) return -2;
+  LGN_CHECK_ARG(!a.h_saved || a.h_rows >= mlp_saved_rows(a.M), "CGMLP: the saved-activation buffer has %d rows per layer, %d rows need %d",
+                a.h_rows, a.M, mlp_saved_rows(a.M));
   const int nt = (a.H + 15) / 16;
   // fully unrolled k-loops for the widths of the reference configs (H = 6 * 2C); anything else keeps the run-time loop
   if (a.H == 48) return launch_mlp_mfma<3, 12>(a, backward, stream);

@@ -53,7 +53,20 @@ struct MlpArgs {
   // tbQ > 0: s_out / g_out / g_in are the scalar column of a tile-blocked tensor [tile][C][tbQ][2][64] (pointer offset to the
   // column: + q_s * 128); element (plane z, row, channel ch) at (((row >> 6) * C + ch) * tbQ) * 128 + z * 64 + (row & 63)
   int tbQ = 0;
+  // optional [nlin - 1][h_rows][HP] (HP = H rounded up to 16, h_rows = M rounded up to 64; mlp_saved_doubles): the forward
+  // stores the post-activation of every hidden layer here and the backward reads it back instead of recomputing the forward
+  // chain (the backward is a chain of barrier-separated layer steps: six of its thirteen go away).  H <= 48 kernels only.
+  T* h_saved = nullptr;
+  int h_rows = 0;
 };
+inline int mlp_saved_rows(int M) { return (M + 63) & ~63; }
+inline size_t mlp_saved_doubles(int M, int H, int nlin) {
+  return H <= 48 && nlin == 7 ? (size_t)(nlin - 1) * mlp_saved_rows(M) * ((H + 15) & ~15) : 0;
+}
+// Worth it only for small batches: the copy is 6 x M x 48 doubles per CGMLP (35 MB at 512 x 30 rows: measured, the step got
+// 26 us SLOWER -- writing and re-reading it costs more than the six recomputed layers), while at 64 x 30 rows (4.4 MB) the
+// backward drops from 24 to 17 us.  The step keeps the copy when the batch has at most this many rows.
+constexpr int MLP_SAVE_MAX_ROWS = 4096;
 // address of (z, row, ch) in the MLP's strided operands
 template <typename T>
 __host__ __device__ inline size_t mlp_out_index(const MlpArgs<T>& a, int z, int row, int ch) {

@@ -28,6 +28,7 @@ struct Bump {                       // workspace carving (also used for the size
 
 struct NetBuf {                     // per-network activations kept for the backward pass
   double *s[5], *v[5], *smix[4], *ag0[4], *ag1[4];
+  double* hsave[4];                 // hidden activations of the level's CGMLP, kept for its backward (null: recomputed)
 };
 
 struct Work {
@@ -141,6 +142,9 @@ Work carve(const lgn_net_desc& d, double* base) {
       n.smix[l] = b.take(2 * BN * ch[l + 1]);
       n.ag0[l] = b.take(4 * BN * ch[l]);
       n.ag1[l] = b.take(16 * BN * ch[l]);
+      // the last level's scalars never reach the loss: its CGMLP has no backward
+      const size_t hs = l + 1 < L && BN <= (size_t)MLP_SAVE_MAX_ROWS ? mlp_saved_doubles((int)BN, d.mlp_hidden_mul * 2 * ch[l + 1], d.mlp_nlin) : 0;
+      n.hsave[l] = hs ? b.take(hs) : nullptr;
     }
   };
   net(w.enc, d.enc_channels);
@@ -221,6 +225,7 @@ int levels_fwd(const lgn_net_desc& d, bool dec, const int* ch, const double* P, 
     m.M = d.B * d.N; m.C = ch[l + 1]; m.H = d.mlp_hidden_mul * 2 * ch[l + 1]; m.nlin = d.mlp_nlin;
     for (int q = 0; q < d.mlp_nlin; ++q) { m.w[q] = p(S.mlp(dec, l, 2 * q)); m.b[q] = p(S.mlp(dec, l, 2 * q + 1)); }
     m.s_in = n.smix[l]; m.s_out = n.s[l + 1];
+    m.h_saved = n.hsave[l]; m.h_rows = mlp_saved_rows(m.M);
     LGN_TRY(mlp_dispatch<double>(m, false, st));
   }
   return 0;
@@ -244,6 +249,7 @@ int levels_bwd(const lgn_net_desc& d, bool dec, const int* ch, const double* P, 
       m.M = BN; m.C = CO; m.H = d.mlp_hidden_mul * 2 * CO; m.nlin = d.mlp_nlin;
       for (int q = 0; q < d.mlp_nlin; ++q) { m.w[q] = p(S.mlp(dec, l, 2 * q)); m.b[q] = p(S.mlp(dec, l, 2 * q + 1)); }
       m.s_in = n.smix[l]; m.g_out = w.gs[cur]; m.g_in = w.gsmix;
+      m.h_saved = n.hsave[l]; m.h_rows = mlp_saved_rows(BN);
       m.psize = mlp_psize(CO, m.H, m.nlin);
       DQ_TAKE(m.part, (size_t)mlp_partial_rows(BN, m.H) * m.psize);
       LGN_TRY(mlp_dispatch<double>(m, true, st));
@@ -781,6 +787,9 @@ NetAct carve_act(const lgn_net_desc& d, bool dec, double* base) {
     a.n.smix[l] = b.take(2 * BN * ch[l + 1]);
     a.n.ag0[l] = b.take(4 * BN * ch[l]);
     a.n.ag1[l] = b.take(16 * BN * ch[l]);
+    // (the caller's upstream gradient may reach every level)
+    const size_t hs = BN <= (size_t)MLP_SAVE_MAX_ROWS ? mlp_saved_doubles((int)BN, d.mlp_hidden_mul * 2 * ch[l + 1], d.mlp_nlin) : 0;
+    a.n.hsave[l] = hs ? b.take(hs) : nullptr;
   }
   if (dec) a.pdec = b.take(8 * BN);
   else a.idx = reinterpret_cast<int*>(b.take(((size_t)d.B * 2 * (d.tau_s + d.tau_v) * 2 + 1) / 2 + 8));
