@@ -1,5 +1,6 @@
 // lgn-autoencoder_amd/csrc/ops.hpp -- argument blocks and host entry points shared between translation units.
 #pragma once
+#include <cstdlib>
 #include "level.hpp"
 
 namespace lgn {
@@ -67,6 +68,10 @@ inline size_t mlp_saved_doubles(int M, int H, int nlin) {
 // 26 us SLOWER -- writing and re-reading it costs more than the six recomputed layers), while at 64 x 30 rows (4.4 MB) the
 // backward drops from 24 to 17 us.  The step keeps the copy when the batch has at most this many rows.
 constexpr int MLP_SAVE_MAX_ROWS = 4096;
+inline size_t mlp_save_max_rows() {          // LGN_AMD_MLP_SAVE_ROWS overrides the threshold (tuning; read once)
+  static const long v = [] { const char* e = getenv("LGN_AMD_MLP_SAVE_ROWS"); return e ? atol(e) : (long)MLP_SAVE_MAX_ROWS; }();
+  return (size_t)(v < 0 ? 0 : v);
+}
 // address of (z, row, ch) in the MLP's strided operands
 template <typename T>
 __host__ __device__ inline size_t mlp_out_index(const MlpArgs<T>& a, int z, int row, int ch) {

@@ -143,7 +143,7 @@ Work carve(const lgn_net_desc& d, double* base) {
       n.ag0[l] = b.take(4 * BN * ch[l]);
       n.ag1[l] = b.take(16 * BN * ch[l]);
       // the last level's scalars never reach the loss: its CGMLP has no backward
-      const size_t hs = l + 1 < L && BN <= (size_t)MLP_SAVE_MAX_ROWS ? mlp_saved_doubles((int)BN, d.mlp_hidden_mul * 2 * ch[l + 1], d.mlp_nlin) : 0;
+      const size_t hs = l + 1 < L && BN <= mlp_save_max_rows() ? mlp_saved_doubles((int)BN, d.mlp_hidden_mul * 2 * ch[l + 1], d.mlp_nlin) : 0;
       n.hsave[l] = hs ? b.take(hs) : nullptr;
     }
   };
@@ -788,7 +788,7 @@ NetAct carve_act(const lgn_net_desc& d, bool dec, double* base) {
     a.n.ag0[l] = b.take(4 * BN * ch[l]);
     a.n.ag1[l] = b.take(16 * BN * ch[l]);
     // (the caller's upstream gradient may reach every level)
-    const size_t hs = BN <= (size_t)MLP_SAVE_MAX_ROWS ? mlp_saved_doubles((int)BN, d.mlp_hidden_mul * 2 * ch[l + 1], d.mlp_nlin) : 0;
+    const size_t hs = BN <= mlp_save_max_rows() ? mlp_saved_doubles((int)BN, d.mlp_hidden_mul * 2 * ch[l + 1], d.mlp_nlin) : 0;
     a.n.hsave[l] = hs ? b.take(hs) : nullptr;
   }
   if (dec) a.pdec = b.take(8 * BN);
