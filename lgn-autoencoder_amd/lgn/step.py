@@ -293,6 +293,7 @@ class NativeTrainStep:
             self._finalize(False)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
+        ref = (self.flat.grad_buf.clone(), self._loss_buf[:3].clone())     # the eager step's reduced gradients | loss terms, loss
         self._g1, self._g2, self._in_graph = torch.cuda.CUDAGraph(), None, False
         if self.collective and self.graph_collective is not False:
             # ONE graph: forward + backward | all-reduce(SUM) of gradients and loss terms | L1 + Adam.  RCCL enqueues its
@@ -311,6 +312,13 @@ class NativeTrainStep:
                               "falling back to graph | all-reduce | graph")
                 torch.cuda.synchronize()
                 self._g1 = torch.cuda.CUDAGraph()
+            if self._in_graph and not self._captured_collective_ok(snap, ref):
+                if self.graph_collective is True:
+                    raise RuntimeError("the all-reduce captured in the step graph does not reproduce the eager step")
+                import warnings
+                warnings.warn("the all-reduce captured in the step graph does not reproduce the eager step; "
+                              "falling back to graph | all-reduce | graph")
+                self._g1, self._in_graph = torch.cuda.CUDAGraph(), False
         if self.collective and not self._in_graph:      # the gradient all-reduce sits between two graphs
             self._g2 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._g1):
@@ -324,6 +332,21 @@ class NativeTrainStep:
         self.launches_per_step = 3 if self._g2 is not None else 1
         with torch.no_grad():   # capture does not execute, but restore anyway in case a backend replays eagerly
             self.flat.flat.copy_(snap[0]); self.adam_m.copy_(snap[1]); self.adam_v.copy_(snap[2]); self.step_dev.copy_(snap[3])
+
+    def _captured_collective_ok(self, snap, ref) -> bool:
+        """One replay of the freshly captured [fwd+bwd | all-reduce | L1 + Adam] graph from the snapshotted state: the reduced
+        gradient buffer (gradients + L1 sub-gradient | per-jet loss terms of ALL ranks) and the loss must be what the eager
+        warm-up step produced from the same state -- a capture that silently dropped the collective would leave the local sums.
+        Every rank takes the same decision (MAX over ranks of the failure flag, through an eager all-reduce)."""
+        with torch.no_grad():
+            self.flat.flat.copy_(snap[0]); self.adam_m.copy_(snap[1]); self.adam_v.copy_(snap[2]); self.step_dev.copy_(snap[3])
+        self._g1.replay()
+        torch.cuda.synchronize()
+        tol = dict(rtol=1e-11, atol=1e-300)       # same kernels; only the reduction order inside RCCL may differ
+        bad = not (torch.allclose(self.flat.grad_buf, ref[0], **tol) and torch.allclose(self._loss_buf[:3], ref[1], **tol))
+        flag = torch.tensor([1.0 if bad else 0.0], device=self.flat.flat.device, dtype=torch.float64)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+        return flag.item() == 0.0
 
     def load_batch(self, batch: Dict[str, torch.Tensor]):
         """Stage a batch into the static input buffers (device-to-device copy; labels/masks as in
