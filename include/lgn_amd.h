@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LGN_AMD_ABI_VERSION 9   /* bump on ANY struct or signature change (lgn/_native.py: ABI_VERSION) */
+#define LGN_AMD_ABI_VERSION 10   /* bump on ANY struct or signature change (lgn/_native.py: ABI_VERSION) */
 
 int lgn_abi_version(void);
 const char* lgn_last_error(void);
@@ -89,15 +89,23 @@ int lgn_radial_finalize_f64(const double* tot, int C, const double* ra, const do
 
 /* ---- CGMLP (lgn/models/lgn_levels.py:191-227) ------------------------------------------------
  * rows M = B*N, features 2C (index 2c+z) taken from / written to the scalar irrep [2][M][C];
- * nlin Linear layers (nn.Linear weight [out][in], bias [out]) of hidden width H, LeakyReLU(0.01)
- * after all but the last.  w / b: host arrays of nlin device pointers. */
-int lgn_cgmlp_fwd_f64(int M, int C, int H, int nlin, const double* const* w, const double* const* b,
+ * nlin Linear layers (nn.Linear weight [out][in], bias [out]) of hidden width H, the activation
+ * (LGN_ACT_*: get_activation_fn, lgn/nn/generic_levels.py:119-135) after all but the last.
+ * w / b: host arrays of nlin device pointers. */
+#define LGN_ACT_LEAKYRELU 0   /* nn.LeakyReLU() (slope 0.01): the reference default */
+#define LGN_ACT_RELU 1
+#define LGN_ACT_ELU 2         /* alpha = 1 */
+#define LGN_ACT_SIGMOID 3
+#define LGN_ACT_LOGSIGMOID 4
+#define LGN_ACT_ATAN 5
+#define LGN_ACT_COUNT 6
+int lgn_cgmlp_fwd_f64(int M, int C, int H, int nlin, int activation, const double* const* w, const double* const* b,
                       const double* s_in, double* s_out, void* stream);
 /* rows of the partial weight-gradient buffer for M rows at hidden width H: one per workgroup of the backward (64 rows; 16 rows
  * for H <= 48 when M is small enough that 64-row workgroups would leave most CUs idle). */
 int lgn_cgmlp_partial_rows(int M, int H);
 /* part [lgn_cgmlp_partial_rows(M, H)][psize], psize = sum_l (out_l*in_l + out_l), layout concat_l (W_l, b_l). */
-int lgn_cgmlp_bwd_f64(int M, int C, int H, int nlin, const double* const* w, const double* const* b,
+int lgn_cgmlp_bwd_f64(int M, int C, int H, int nlin, int activation, const double* const* w, const double* const* b,
                       const double* s_in, const double* g_out, double* g_in, double* part, int psize, void* stream);
 
 /* ---- MixReps (lgn/nn/g_nn.py:95-117, lgn/g_lib/cplx_lib.py:7-25) -------------------------------
@@ -206,6 +214,7 @@ typedef struct lgn_net_desc {
    * its backward) are part of the descriptor, fixed when the caller creates it -- not read from the environment per call, so
    * a forward and its backward can never disagree. */
   int flags;
+  int activation;          /* LGN_ACT_* of every CGMLP of both networks (the reference builds them from one --activation) */
 } lgn_net_desc;
 #define LGN_NET_NO_STATIC 1   /* table-driven levels: run-time-table kernels + node-major features (cross-check of the
                                  compile-time-table kernels; lgn/_native.py sets it from LGN_AMD_NO_STATIC at creation) */

@@ -49,9 +49,9 @@ int lgn_radial_finalize_f64(const double* tot, int C, const double* ra, const do
   return rad_finalize<double>(tot, C, ra, rb, rc, w0, w1, g_a, g_b, g_c, g_w0, g_b0, g_w1, g_b1, (hipStream_t)stream);
 }
 
-static int fill_mlp(MlpArgs<double>& a, int M, int C, int H, int nlin, const double* const* w, const double* const* b) {
+static int fill_mlp(MlpArgs<double>& a, int M, int C, int H, int nlin, int activation, const double* const* w, const double* const* b) {
   LGN_CHECK_ARG(nlin >= 1 && nlin <= MLP_MAX_LIN && w && b, "cgmlp: bad layer list (nlin=%d)", nlin);
-  a.M = M; a.C = C; a.H = H; a.nlin = nlin;
+  a.M = M; a.C = C; a.H = H; a.nlin = nlin; a.act = activation;
   for (int l = 0; l < MLP_MAX_LIN; ++l) {
     a.w[l] = l < nlin ? w[l] : nullptr;
     a.b[l] = l < nlin ? b[l] : nullptr;
@@ -60,10 +60,10 @@ static int fill_mlp(MlpArgs<double>& a, int M, int C, int H, int nlin, const dou
   return 0;
 }
 
-int lgn_cgmlp_fwd_f64(int M, int C, int H, int nlin, const double* const* w, const double* const* b, const double* s_in,
-                      double* s_out, void* stream) {
+int lgn_cgmlp_fwd_f64(int M, int C, int H, int nlin, int activation, const double* const* w, const double* const* b,
+                      const double* s_in, double* s_out, void* stream) {
   MlpArgs<double> a{};
-  if (int rc = fill_mlp(a, M, C, H, nlin, w, b)) return rc;
+  if (int rc = fill_mlp(a, M, C, H, nlin, activation, w, b)) return rc;
   LGN_CHECK_ARG(s_in && s_out, "cgmlp_fwd: null pointer");
   a.s_in = s_in; a.s_out = s_out;
   return mlp_dispatch<double>(a, false, (hipStream_t)stream);
@@ -71,10 +71,10 @@ int lgn_cgmlp_fwd_f64(int M, int C, int H, int nlin, const double* const* w, con
 
 int lgn_cgmlp_partial_rows(int M, int H) { return mlp_partial_rows(M, H); }
 
-int lgn_cgmlp_bwd_f64(int M, int C, int H, int nlin, const double* const* w, const double* const* b, const double* s_in,
-                      const double* g_out, double* g_in, double* part, int psize, void* stream) {
+int lgn_cgmlp_bwd_f64(int M, int C, int H, int nlin, int activation, const double* const* w, const double* const* b,
+                      const double* s_in, const double* g_out, double* g_in, double* part, int psize, void* stream) {
   MlpArgs<double> a{};
-  if (int rc = fill_mlp(a, M, C, H, nlin, w, b)) return rc;
+  if (int rc = fill_mlp(a, M, C, H, nlin, activation, w, b)) return rc;
   LGN_CHECK_ARG(s_in && g_out && g_in && part, "cgmlp_bwd: null pointer");
   a.s_in = s_in; a.g_out = g_out; a.g_in = g_in; a.part = part; a.psize = psize;
   return mlp_dispatch<double>(a, true, (hipStream_t)stream);

@@ -98,6 +98,41 @@ template <typename T>
 __device__ __forceinline__ T leaky(T x) {
   return fmax(x, T(0.01) * x);         // == x > 0 ? x : 0.01 x; nn.LeakyReLU default slope (generic_levels.py:121-122)
 }
+// The CGMLP's activation (get_activation_fn, lgn/nn/generic_levels.py:119-135; ids = LGN_ACT_* of include/lgn_amd.h).  The choice is
+// wave uniform; id 0 (LeakyReLU, the reference default) takes the first branch.
+__device__ __forceinline__ double act_apply(double x, int act) {
+  if (act == 0) return fmax(x, 0.01 * x);
+  switch (act) {
+    case 1: return fmax(x, 0.0);                                 // nn.ReLU
+    case 2: return x > 0.0 ? x : expm1(x);                       // nn.ELU(alpha = 1)
+    case 3: return 1.0 / (1.0 + exp(-x));                        // nn.Sigmoid
+    case 4: return fmin(x, 0.0) - log1p(exp(-fabs(x)));          // nn.LogSigmoid (the stable form ATen uses)
+    default: return atan(x);                                     // ATan (generic_levels.py:138-140)
+  }
+}
+// GEN = false instantiations are the LeakyReLU kernels with nothing else compiled in (the run-time switch costs the default
+// path 5 us per CGMLP launch: registers and code of the transcendental branches); GEN = true takes the switch.
+template <bool GEN>
+__device__ __forceinline__ double act_apply_t(double x, int act) {
+  if constexpr (GEN) return act_apply(x, act);
+  else return fmax(x, 0.01 * x);
+}
+// d act / d x expressed through the OUTPUT y = act(x): the backward keeps post-activations only
+__device__ __forceinline__ double act_slope(double y, int act) {
+  if (act == 0) return y > 0.0 ? 1.0 : 0.01;
+  switch (act) {
+    case 1: return y > 0.0 ? 1.0 : 0.0;
+    case 2: return y > 0.0 ? 1.0 : y + 1.0;                      // e^x = y + 1 for x <= 0
+    case 3: return y * (1.0 - y);
+    case 4: return -expm1(y);                                    // 1 - sigmoid(x), sigmoid(x) = e^y
+    default: { const double c = cos(y); return c * c; }          // 1 / (1 + tan^2 y)
+  }
+}
+template <bool GEN>
+__device__ __forceinline__ double act_slope_t(double y, int act) {
+  if constexpr (GEN) return act_slope(y, act);
+  else return y > 0.0 ? 1.0 : 0.01;
+}
 
 // 1/sqrt(2) used by the Cartesian <-> canonical change of basis (zonal_functions.py:266-283)
 template <typename T>

@@ -2,9 +2,11 @@
 //
 // Reference: CGMLP.forward, lgn/models/lgn_levels.py:191-227 -- the (0,0) part (2,B,N,C,1) is viewed as
 // (B*N) rows of 2C real features (index 2c+z), passed through Linear(2C->W), 5 x Linear(W->W),
-// Linear(W->2C) with LeakyReLU(0.01) after all but the last Linear, and written back.  No mask.
+// Linear(W->2C) with the activation (LeakyReLU(0.01) by default; get_activation_fn, lgn/nn/generic_levels.py:119-135) after
+// all but the last Linear, and written back.  No mask.
 // Both kernels run on the fp64 matrix cores: mlp_mfma.hip (W <= 48) and mlp_mfma_wide.hip (48 < W <= 96).
 #include "ops.hpp"
+#include "../../include/lgn_amd.h"
 
 namespace lgn {
 
@@ -19,6 +21,7 @@ int mlp_dispatch(const MlpArgs<T>& a, bool backward, hipStream_t stream) {
   LGN_CHECK_ARG(a.M > 0 && a.C > 0, "cgmlp: empty input (M=%d C=%d)", a.M, a.C);
   LGN_CHECK_ARG(a.nlin == 7, "cgmlp: only mlp_depth=6 (7 Linear layers) is built, got %d", a.nlin);
   LGN_CHECK_ARG(a.C <= 8, "cgmlp: %d channels unsupported (1..8)", a.C);
+  LGN_CHECK_ARG(a.act >= 0 && a.act < LGN_ACT_COUNT, "cgmlp: unknown activation id %d (LGN_ACT_*)", a.act);
   LGN_CHECK_ARG(a.H >= 2 * a.C && a.H <= 96, "cgmlp: hidden width %d unsupported (2C..96)", a.H);
   if (backward) LGN_CHECK_ARG((size_t)a.psize == mlp_param_count(a.C, a.H, a.nlin), "cgmlp: psize mismatch");
   int rc = mlp_mfma_dispatch(a, backward, stream);

@@ -132,9 +132,9 @@ __device__ __forceinline__ void mma_transposed(const double* ga, const double* w
 // One forward layer for this wave's tile (shared by the forward kernel and the backward's recompute).
 //   l == 0 reads the input tiles (K = 16), hidden layers the activation buffer of parity l&1; writes LeakyReLU(pre)
 //   into the buffer of parity (l+1)&1 when `store`.
-template <int NT, int KSH, int MT>
+template <int NT, int KSH, int MT, bool GEN>
 __device__ __forceinline__ v4d forward_layer(int l, const double* Wcur, const double* X0, double* Xb, int mt, int nt, int lane,
-                                             int ksh, bool store) {
+                                             int ksh, bool store, int act) {
   using G = Geo<NT, MT>;
   constexpr int S = G::S;
   const int c = lane & 15, g = lane >> 4;
@@ -144,7 +144,7 @@ __device__ __forceinline__ v4d forward_layer(int l, const double* Wcur, const do
   if (l == 0) mma_rowmajor<4>(X0 + mt * G::T0SIZE + c * G::S0 + g, wb, 4, acc);
   else mma_rowmajor<KSH>(Xb + ((l & 1) * MT + mt) * G::TSIZE + c * S + g, wb, ksh, acc);
 #pragma unroll
-  for (int r = 0; r < 4; ++r) acc[r] = leaky(acc[r]);
+  for (int r = 0; r < 4; ++r) acc[r] = act_apply_t<GEN>(acc[r], act);
   if (store) {
     double* Xn = Xb + (((l + 1) & 1) * MT + mt) * G::TSIZE + g * S + 16 * nt + c;
 #pragma unroll
@@ -153,7 +153,7 @@ __device__ __forceinline__ v4d forward_layer(int l, const double* Wcur, const do
   return acc;
 }
 
-template <int NT, int NH, int KSH, int MT>
+template <int NT, int NH, int KSH, int MT, bool GEN>
 __global__ __launch_bounds__(64 * MT * NT) void mlp_fwd_mfma_kernel(MlpArgs<double> a) {
   using G = Geo<NT, MT>;
   constexpr int S = G::S;
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(64 * MT * NT) void mlp_fwd_mfma_kernel(MlpArgs<doub
   for (int l = 0; l < NH; ++l) {
     const double* Wcur = Wl + (l & 1) * G::WSIZE;
     prefetch_hidden<NT, MT>(a.w[l + 1], a.b[l + 1], l + 1 == NH ? D : H, H, regs, breg);
-    const v4d hv = forward_layer<NT, KSH, MT>(l, Wcur, X0, Xb, mt, nt, lane, ksh, true);
+    const v4d hv = forward_layer<NT, KSH, MT, GEN>(l, Wcur, X0, Xb, mt, nt, lane, ksh, true, a.act);
     if (a.h_saved) {                                           // kept for the backward (rows beyond M: finite values of zero inputs)
       double* hs = a.h_saved + ((size_t)l * a.h_rows + wg_row0 + mt * 16 + (lane >> 4)) * G::HP + 16 * nt + (lane & 15);
 #pragma unroll
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(64 * MT * NT) void mlp_fwd_mfma_kernel(MlpArgs<doub
   }
 }
 
-template <int NT, int NH, int KSH, int MT>
+template <int NT, int NH, int KSH, int MT, bool GEN>
 __global__ __launch_bounds__(64 * MT * NT) void mlp_bwd_mfma_kernel(MlpArgs<double> a) {
   using G = Geo<NT, MT>;
   constexpr int S = G::S, HP = G::HP, NW = MT * NT;
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(64 * MT * NT) void mlp_bwd_mfma_kernel(MlpArgs<doub
       const double* Wcur = Wl + (l & 1) * G::WSIZE;
       // the weights of the next forward layer; after the last hidden layer: the output layer (first backward layer)
       prefetch_hidden<NT, MT>(a.w[l + 1], a.b[l + 1], l + 1 == NH ? D : H, H, regs, breg);
-      h[l] = forward_layer<NT, KSH, MT>(l, Wcur, X0, Xb, mt, nt, lane, ksh, l + 1 < NH);
+      h[l] = forward_layer<NT, KSH, MT, GEN>(l, Wcur, X0, Xb, mt, nt, lane, ksh, l + 1 < NH, a.act);
       commit_hidden<NT, MT>(Wl + ((l + 1) & 1) * G::WSIZE, regs, breg);
       __syncthreads();
     }
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(64 * MT * NT) void mlp_bwd_mfma_kernel(MlpArgs<doub
     // next layer down
     if (l > 0) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) gpre[r] = gin[r] * (h[l > 0 ? l - 1 : 0][r] > 0.0 ? 1.0 : 0.01);
+      for (int r = 0; r < 4; ++r) gpre[r] = gin[r] * act_slope_t<GEN>(h[l > 0 ? l - 1 : 0][r], a.act);
       // W_{l-1} goes into the image buffer last read two layers up; every wave is past that layer's barrier
       if (l == 1) commit_first<NT, MT>(Wl, regs, breg);
       else commit_hidden<NT, MT>(Wl + ((l - 1) & 1) * G::WSIZE, regs, breg);
@@ -360,7 +360,9 @@ static int launch_mlp_mfma_mt(const MlpArgs<double>& a, bool backward, hipStream
   const int nblk = cdiv(a.M, 16 * MT);
   const size_t smem = sizeof(double) * (backward ? G::bwd_doubles() : G::fwd_doubles());
   static_assert(sizeof(double) * G::bwd_doubles() <= 160 * 1024, "LDS budget");
-  auto kern = backward ? mlp_bwd_mfma_kernel<NT, NH, KSH, MT> : mlp_fwd_mfma_kernel<NT, NH, KSH, MT>;
+  // (LeakyReLU, the reference default, has its own instantiation: common.hpp act_apply_t)
+  auto kern = a.act == 0 ? (backward ? mlp_bwd_mfma_kernel<NT, NH, KSH, MT, false> : mlp_fwd_mfma_kernel<NT, NH, KSH, MT, false>)
+                         : (backward ? mlp_bwd_mfma_kernel<NT, NH, KSH, MT, true> : mlp_fwd_mfma_kernel<NT, NH, KSH, MT, true>);
   if (smem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   hipLaunchKernelGGL(kern, dim3(nblk), dim3(G::THREADS), smem, stream, a);
   LGN_CHECK_LAUNCH();

@@ -127,7 +127,7 @@ __device__ __forceinline__ void store_tile(double* T, int mt, int nt, int lane, 
   for (int r = 0; r < 4; ++r) o[4 * r * G::S] = v[r];
 }
 
-template <int NT, int NH>
+template <int NT, int NH, bool GEN>
 __global__ __launch_bounds__(64 * MT * NT) void mlp_fwd_wide_kernel(MlpArgs<double> a) {
   using G = Geo<NT>;
   constexpr int S = G::S;
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(64 * MT * NT) void mlp_fwd_wide_kernel(MlpArgs<doub
     prefetch_hidden<NT>(a.w[l + 1], a.b[l + 1], l + 1 == NH ? D : H, H, regs, breg);
     v4d acc = dense<NT>(l == 0, Wl, X0, X, mt, nt, lane, ksh);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) acc[r] = leaky(acc[r]);
+    for (int r = 0; r < 4; ++r) acc[r] = act_apply_t<GEN>(acc[r], a.act);
     __syncthreads();                                       // every read of the weight image and of the layer input is done
     store_tile<NT>(X, mt, nt, lane, acc);
     commit_hidden<NT>(Wl, regs, breg);
@@ -198,7 +198,7 @@ __device__ __forceinline__ void dense2(bool first, const double* Wl, const doubl
   }
 }
 
-template <int NT, int NH>
+template <int NT, int NH, bool GEN>
 __global__ __launch_bounds__(64 * MT * NT) void mlp_bwd_wide_kernel(MlpArgs<double> a) {
   using G = Geo<NT>;
   constexpr int S = G::S, HP = G::HP, NW = MT * NT, MTB = G::MTB;
@@ -230,8 +230,8 @@ __global__ __launch_bounds__(64 * MT * NT) void mlp_bwd_wide_kernel(MlpArgs<doub
     dense2<NT>(l == 0, Wl, X0, X, mp, nt, lane, ksh, h[0][l], h[1][l]);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      h[0][l][r] = leaky(h[0][l][r]);
-      h[1][l][r] = leaky(h[1][l][r]);
+      h[0][l][r] = act_apply_t<GEN>(h[0][l][r], a.act);
+      h[1][l][r] = act_apply_t<GEN>(h[1][l][r], a.act);
     }
     __syncthreads();                                       // every read of the input tiles and of the weight image is done
     if (l + 1 < NH) {
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(64 * MT * NT) void mlp_bwd_wide_kernel(MlpArgs<doub
 #pragma unroll
       for (int q = 0; q < 2; ++q)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) gpre[q][r] = gin[q][r] * (h[q][l > 0 ? l - 1 : 0][r] > 0.0 ? 1.0 : 0.01);
+        for (int r = 0; r < 4; ++r) gpre[q][r] = gin[q][r] * act_slope_t<GEN>(h[q][l > 0 ? l - 1 : 0][r], a.act);
       __syncthreads();                                     // every read of the weight image and of the tiles is done
       if (l == 1) commit_first<NT>(Wl, regs, breg);
       else commit_hidden<NT>(Wl, regs, breg);
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(64 * MT * NT) void mlp_bwd_wide_kernel(MlpArgs<doub
 // H > 80 (NT = 6: C = 7, 8): the 4 + 4 operand tiles of the one-pass kernel do not fit the LDS beside a 75 KB weight image.
 // Round-2 kernel: two 32-row passes per workgroup, the second adding into the partial row the first one wrote; the
 // activations of the first NHL hidden layers stay in LDS tiles of their own.
-template <int NT, int NH>
+template <int NT, int NH, bool GEN>
 __global__ __launch_bounds__(64 * MT * NT) void mlp_bwd_wide_2pass_kernel(MlpArgs<double> a) {
   using G = Geo<NT>;
   constexpr int S = G::S, HP = G::HP, NW = MT * NT;
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(64 * MT * NT) void mlp_bwd_wide_2pass_kernel(MlpArg
       prefetch_hidden<NT>(a.w[l + 1], a.b[l + 1], l + 1 == NH ? D : H, H, regs, breg);   // after the last hidden layer: the output layer
       h[l] = dense<NT>(l == 0, Wl, X0, (l >= 1 && l - 1 < NHL) ? Hl + (l - 1) * MT * G::TSIZE : X, mt, nt, lane, ksh);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) h[l][r] = leaky(h[l][r]);
+      for (int r = 0; r < 4; ++r) h[l][r] = act_apply_t<GEN>(h[l][r], a.act);
       __syncthreads();
       if (l < NHL) store_tile<NT>(Hl + l * MT * G::TSIZE, mt, nt, lane, h[l]);
       else if (l + 1 < NH) store_tile<NT>(X, mt, nt, lane, h[l]);
@@ -449,7 +449,7 @@ __global__ __launch_bounds__(64 * MT * NT) void mlp_bwd_wide_2pass_kernel(MlpArg
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const double hv = in_lds ? hd[4 * r * S] : h[l > 0 ? l - 1 : 0][r];
-          gpre[r] = gin[r] * (hv > 0.0 ? 1.0 : 0.01);
+          gpre[r] = gin[r] * act_slope_t<GEN>(hv, a.act);
         }
         __syncthreads();                                     // every read of the weight image and of the tiles is done
         if (l == 1) commit_first<NT>(Wl, regs, breg);
@@ -471,10 +471,11 @@ static int launch(const MlpArgs<double>& a, bool backward, hipStream_t stream) {
   constexpr int NH = 6;
   const size_t smem = sizeof(double) * (backward ? (G::ONE_PASS ? G::bwd_doubles() : G::bwd2p_doubles()) : G::fwd_doubles());
   static_assert(sizeof(double) * G::bwd2p_doubles() <= 160 * 1024 && sizeof(double) * G::fwd_doubles() <= 160 * 1024, "LDS budget");
-  void (*kern)(MlpArgs<double>) = mlp_fwd_wide_kernel<NT, NH>;
+  // (LeakyReLU, the reference default, has its own instantiation: common.hpp act_apply_t)
+  void (*kern)(MlpArgs<double>) = a.act == 0 ? mlp_fwd_wide_kernel<NT, NH, false> : mlp_fwd_wide_kernel<NT, NH, true>;
   if (backward) {
-    if constexpr (G::ONE_PASS) kern = mlp_bwd_wide_kernel<NT, NH>;
-    else kern = mlp_bwd_wide_2pass_kernel<NT, NH>;
+    if constexpr (G::ONE_PASS) kern = a.act == 0 ? mlp_bwd_wide_kernel<NT, NH, false> : mlp_bwd_wide_kernel<NT, NH, true>;
+    else kern = a.act == 0 ? mlp_bwd_wide_2pass_kernel<NT, NH, false> : mlp_bwd_wide_2pass_kernel<NT, NH, true>;
   }
   if (smem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   const int nblk = backward ? cdiv(a.M, 64) : cdiv(a.M, 16 * MT);

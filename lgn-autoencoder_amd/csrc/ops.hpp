@@ -59,6 +59,7 @@ struct MlpArgs {
   // chain (the backward is a chain of barrier-separated layer steps: six of its thirteen go away).  H <= 48 kernels only.
   T* h_saved = nullptr;
   int h_rows = 0;
+  int act = 0;      // LGN_ACT_* (include/lgn_amd.h): activation after all but the last Linear
 };
 inline int mlp_saved_rows(int M) { return (M + 63) & ~63; }
 inline size_t mlp_saved_doubles(int M, int H, int nlin) {

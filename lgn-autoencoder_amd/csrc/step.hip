@@ -222,7 +222,7 @@ int levels_fwd(const lgn_net_desc& d, bool dec, const int* ch, const double* P, 
                         n.ag0[l], n.ag1[l], n.smix[l], n.v[l + 1]};
     LGN_TRY(level_fwd_dispatch<double>(a, dec, st));
     MlpArgs<double> m{};
-    m.M = d.B * d.N; m.C = ch[l + 1]; m.H = d.mlp_hidden_mul * 2 * ch[l + 1]; m.nlin = d.mlp_nlin;
+    m.M = d.B * d.N; m.C = ch[l + 1]; m.H = d.mlp_hidden_mul * 2 * ch[l + 1]; m.nlin = d.mlp_nlin; m.act = d.activation;
     for (int q = 0; q < d.mlp_nlin; ++q) { m.w[q] = p(S.mlp(dec, l, 2 * q)); m.b[q] = p(S.mlp(dec, l, 2 * q + 1)); }
     m.s_in = n.smix[l]; m.s_out = n.s[l + 1];
     m.h_saved = n.hsave[l]; m.h_rows = mlp_saved_rows(m.M);
@@ -246,7 +246,7 @@ int levels_bwd(const lgn_net_desc& d, bool dec, const int* ch, const double* P, 
     const double* g_smix = w.zeros_s;
     if (has_s_grad) {
       MlpArgs<double> m{};
-      m.M = BN; m.C = CO; m.H = d.mlp_hidden_mul * 2 * CO; m.nlin = d.mlp_nlin;
+      m.M = BN; m.C = CO; m.H = d.mlp_hidden_mul * 2 * CO; m.nlin = d.mlp_nlin; m.act = d.activation;
       for (int q = 0; q < d.mlp_nlin; ++q) { m.w[q] = p(S.mlp(dec, l, 2 * q)); m.b[q] = p(S.mlp(dec, l, 2 * q + 1)); }
       m.s_in = n.smix[l]; m.g_out = w.gs[cur]; m.g_in = w.gsmix;
       m.h_saved = n.hsave[l]; m.h_rows = mlp_saved_rows(BN);
@@ -516,7 +516,7 @@ int gen_levels_fwd(const lgn_net_desc& d, bool dec, const double* P, const int64
       LGN_TRY(local_fwd(la, st));
     }
     MlpArgs<double> mm{};
-    mm.M = BN; mm.C = g.ch[l + 1]; mm.H = d.mlp_hidden_mul * 2 * g.ch[l + 1]; mm.nlin = d.mlp_nlin;
+    mm.M = BN; mm.C = g.ch[l + 1]; mm.H = d.mlp_hidden_mul * 2 * g.ch[l + 1]; mm.nlin = d.mlp_nlin; mm.act = d.activation;
     for (int q = 0; q < d.mlp_nlin; ++q) { mm.w[q] = P + off[S.mlp(dec, l, 2 * q)]; mm.b[q] = P + off[S.mlp(dec, l, 2 * q + 1)]; }
     mm.s_in = a.smix[l];
     if (tb) { mm.s_out = a.X[l + 1] + (size_t)g.qs[l + 1] * 128; mm.tbQ = g.Q[l + 1]; }
@@ -545,7 +545,7 @@ int gen_levels_bwd(const lgn_net_desc& d, bool dec, const double* P, double* G, 
     const int C = g.ch[l], CO = g.ch[l + 1];
     if (has_s_grad) {     // CGMLP backward, in place on the scalar column of the gradient
       MlpArgs<double> m{};
-      m.M = BN; m.C = CO; m.H = d.mlp_hidden_mul * 2 * CO; m.nlin = d.mlp_nlin;
+      m.M = BN; m.C = CO; m.H = d.mlp_hidden_mul * 2 * CO; m.nlin = d.mlp_nlin; m.act = d.activation;
       for (int q = 0; q < d.mlp_nlin; ++q) { m.w[q] = P + off[S.mlp(dec, l, 2 * q)]; m.b[q] = P + off[S.mlp(dec, l, 2 * q + 1)]; }
       m.s_in = a.smix[l];
       if (tb) { m.g_out = sc.gX[cur] + (size_t)g.qs[l + 1] * 128; m.g_in = sc.gX[cur] + (size_t)g.qs[l + 1] * 128; m.tbQ = g.Q[l + 1]; }

@@ -15,7 +15,7 @@ import torch  # imported before the .so so that the process-wide libamdhip64 is 
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LGN_AMD_LIB") or os.path.join(_HERE, "_lib", "liblgn_amd.so")   # LGN_AMD_LIB: debug builds (tools/)
-ABI_VERSION = 9
+ABI_VERSION = 10
 FINALIZE_SCRATCH = 2048      # include/lgn_amd.h: LGN_FINALIZE_SCRATCH
 
 _lib: Optional[C.CDLL] = None
@@ -30,9 +30,9 @@ _SIGNATURES = {
     "lgn_level_bwd_f64": [_i] * 5 + [_vp] * 24,
     "lgn_reduce_partials_f64": [_vp, _i, _i, _vp, _i, _vp],
     "lgn_radial_finalize_f64": [_vp, _i] + [_vp] * 13,
-    "lgn_cgmlp_fwd_f64": [_i] * 4 + [_vp] * 5,
+    "lgn_cgmlp_fwd_f64": [_i] * 5 + [_vp] * 5,
     "lgn_cgmlp_partial_rows": [_i, _i],
-    "lgn_cgmlp_bwd_f64": [_i] * 4 + [_vp] * 6 + [_i, _vp],
+    "lgn_cgmlp_bwd_f64": [_i] * 5 + [_vp] * 6 + [_i, _vp],
     "lgn_mixreps_fwd_f64": [_i] * 4 + [_vp] * 4,
     "lgn_mixreps_partial_rows": [_i],
     "lgn_mixreps_bwd_f64": [_i] * 4 + [_vp] * 6,
@@ -57,7 +57,8 @@ class NetDesc(C.Structure):
                 ("mlp_nlin", C.c_int), ("tau_v_in", C.c_int),
                 ("enc_tables", _tp * 4), ("dec_tables", _tp * 4),
                 ("enc_Q", C.c_int * 5), ("enc_qs", C.c_int * 5), ("enc_qv", C.c_int * 5),
-                ("dec_Q", C.c_int * 5), ("dec_qs", C.c_int * 5), ("dec_qv", C.c_int * 5), ("flags", C.c_int)]
+                ("dec_Q", C.c_int * 5), ("dec_qs", C.c_int * 5), ("dec_qv", C.c_int * 5), ("flags", C.c_int),
+                ("activation", C.c_int)]
 
     def __init__(self, *a, **kw):
         super().__init__(*a, **kw)
@@ -65,6 +66,15 @@ class NetDesc(C.Structure):
 
 
 NET_NO_STATIC = 1
+# LGN_ACT_* of include/lgn_amd.h: the names get_activation_fn accepts (lgn/nn/generic_levels.py:119-135)
+ACTIVATIONS = {"leakyrelu": 0, "relu": 1, "elu": 2, "sigmoid": 3, "logsigmoid": 4, "atan": 5}
+
+
+def activation_id(name: str) -> int:
+    try:
+        return ACTIVATIONS[name.lower()]
+    except KeyError:
+        raise ValueError(f"Activation function {name} not implemented!") from None
 
 
 def net_flags() -> int:
@@ -230,16 +240,16 @@ def _ptr_array(ts: Sequence[torch.Tensor]):
     return arr
 
 
-def cgmlp_fwd(s_in, ws, bs):
+def cgmlp_fwd(s_in, ws, bs, act: int = 0):
     _, B, N, Cc = s_in.shape
     H = ws[0].shape[0]
     s_out = torch.empty_like(s_in)
-    rc = lib().lgn_cgmlp_fwd_f64(B * N, Cc, H, len(ws), _ptr_array(ws), _ptr_array(bs), ptr(s_in), ptr(s_out), stream_ptr())
+    rc = lib().lgn_cgmlp_fwd_f64(B * N, Cc, H, len(ws), act, _ptr_array(ws), _ptr_array(bs), ptr(s_in), ptr(s_out), stream_ptr())
     _check(rc, "lgn_cgmlp_fwd_f64")
     return s_out
 
 
-def cgmlp_bwd(s_in, ws, bs, g_out):
+def cgmlp_bwd(s_in, ws, bs, g_out, act: int = 0):
     """Returns (g_in, [g_w...], [g_b...])."""
     _, B, N, Cc = s_in.shape
     H = ws[0].shape[0]
@@ -248,7 +258,7 @@ def cgmlp_bwd(s_in, ws, bs, g_out):
     psize = sum(w.numel() + b.numel() for w, b in zip(ws, bs))
     part = torch.empty(rows, psize, device=s_in.device, dtype=s_in.dtype)
     g_in = torch.empty_like(s_in)
-    rc = L.lgn_cgmlp_bwd_f64(B * N, Cc, H, len(ws), _ptr_array(ws), _ptr_array(bs), ptr(s_in), ptr(g_out), ptr(g_in),
+    rc = L.lgn_cgmlp_bwd_f64(B * N, Cc, H, len(ws), act, _ptr_array(ws), _ptr_array(bs), ptr(s_in), ptr(g_out), ptr(g_in),
                              ptr(part), psize, stream_ptr())
     _check(rc, "lgn_cgmlp_bwd_f64")
     flat = torch.empty(psize, device=s_in.device, dtype=s_in.dtype)

@@ -266,7 +266,7 @@ def run_levels(module, decoder: bool, feats, p, mask):
             parts = torch.split(Y, [(r[0] + 1) * (r[1] + 1) for r in tables.meta["out_irreps"]], dim=-1)
             new = dict(zip(tables.meta["out_irreps"], parts))
         if lgn_cg.mlp:
-            s = ops.CGMLPFn.apply(new[(0, 0)].squeeze(-1).contiguous(), *lgn_cg.mlp_levels[lvl].flat_params())
+            s = ops.CGMLPFn.apply(lgn_cg.mlp_levels[lvl].act_id, new[(0, 0)].squeeze(-1).contiguous(), *lgn_cg.mlp_levels[lvl].flat_params())
             new[(0, 0)] = s.unsqueeze(-1)
         feats = {r: new[r] for r in plan.out_order}
         out.append(feats)

@@ -76,8 +76,9 @@ class CGMLP(nn.Module):
 
     def __init__(self, num_channels, num_hidden=3, layer_width_mul=2, activation="sigmoid", device=None, dtype=torch.float64):
         super().__init__()
-        if activation.lower() != "leakyrelu":
-            raise NotImplementedError(f"the native CGMLP implements LeakyReLU(0.01) (the reference default); got {activation}")
+        from .. import _native
+        self.activation = activation
+        self.act_id = _native.activation_id(activation)      # get_activation_fn's names (lgn/nn/generic_levels.py:119-135)
         ns = 2 * num_channels
         width = layer_width_mul * ns
         self.num_scalars, self.width, self.num_hidden = ns, width, num_hidden

@@ -58,23 +58,23 @@ class LevelFn(torch.autograd.Function):
 
 
 class CGMLPFn(torch.autograd.Function):
-    """CGMLP on the scalar irrep (csrc/mlp.hip).  args: s_in, w_0, b_0, ..., w_L, b_L."""
+    """CGMLP on the scalar irrep (csrc/mlp.hip).  args: activation id (N.ACTIVATIONS), s_in, w_0, b_0, ..., w_L, b_L."""
 
     @staticmethod
-    def forward(ctx, s_in, *wb):
+    def forward(ctx, act, s_in, *wb):
         s_in = N.f64(s_in)
         ws = [N.f64(t.detach()) for t in wb[0::2]]
         bs = [N.f64(t.detach()) for t in wb[1::2]]
-        ctx.nl = len(ws)
+        ctx.nl, ctx.act = len(ws), int(act)
         ctx.save_for_backward(s_in, *ws, *bs)
-        return N.cgmlp_fwd(s_in, ws, bs)
+        return N.cgmlp_fwd(s_in, ws, bs, ctx.act)
 
     @staticmethod
     def backward(ctx, g_out):
         s_in, *rest = ctx.saved_tensors
         ws, bs = rest[:ctx.nl], rest[ctx.nl:]
-        g_in, gws, gbs = N.cgmlp_bwd(s_in, ws, bs, N.f64(g_out))
-        out = [g_in]
+        g_in, gws, gbs = N.cgmlp_bwd(s_in, ws, bs, N.f64(g_out), ctx.act)
+        out = [None, g_in]
         for gw, gb in zip(gws, gbs):
             out += [gw, gb]
         return tuple(out)
@@ -347,6 +347,7 @@ class NetHandle:
         d.tau_s, d.tau_v, d.tau_v_in = 1, 1, 0
         self.keep = describe_network(d, net, decoder)
         d.mlp_hidden_mul, d.mlp_nlin = net.mlp_width, net.mlp_depth + 1
+        d.activation = N.activation_id(net.activation)
         lib = N.lib()
         slots = slot_tensors(net, decoder)
         want = lib.lgn_step_param_slots(C.byref(d), int(decoder))

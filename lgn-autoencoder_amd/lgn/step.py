@@ -216,6 +216,10 @@ class NativeTrainStep:
         d.B, d.N, d.n_levels = batch_size, encoder.num_input_particles, L
         self._keep = describe_network(d, encoder, False) + describe_network(d, decoder, True)    # (after FlatParams re-homed the blocks)
         d.mlp_hidden_mul, d.mlp_nlin = encoder.mlp_width, encoder.mlp_depth + 1
+        if N.activation_id(encoder.activation) != N.activation_id(decoder.activation):
+            raise NotImplementedError("the native step takes ONE activation for the CGMLPs of both networks (as --activation gives them); "
+                                      f"got {encoder.activation} / {decoder.activation}")
+        d.activation = N.activation_id(encoder.activation)
         fused = native_kind(encoder) == "fused"
         if decoder.tau_latent_vectors != 2 * d.tau_v or decoder.num_output_particles != d.N:
             raise ValueError("decoder latent size / particle count does not match the encoder (min&max doubles tau)")

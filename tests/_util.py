@@ -47,6 +47,16 @@ def assert_close(a, b, tol, what=""):
     return e
 
 
+def assert_close_scaled(a, b, tol, scale, what=""):
+    """|a - b|max <= tol * max(|b|max, scale): for gradients whose own magnitude is far below the network's gradient scale
+    (rounding noise of the sums they come from is absolute, not relative to the survivor of a cancellation)."""
+    a = torch.as_tensor(a, dtype=torch.float64).detach().cpu(); b = torch.as_tensor(b, dtype=torch.float64).detach().cpu()
+    assert tuple(a.shape) == tuple(b.shape), f"{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
+    err, ref = (a - b).abs().max().item(), max(b.abs().max().item(), scale)
+    assert err <= tol * ref, f"{what}: abs err {err:.3e} > {tol:.1e} * {ref:.3e}"
+    return err / ref
+
+
 def assert_rep_close(rep, ref, tol, what="", check_order=True):
     if check_order:
         assert list(rep.keys()) == list(ref.keys()), f"{what}: key order {list(rep.keys())} vs {list(ref.keys())}"

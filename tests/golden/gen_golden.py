@@ -19,6 +19,9 @@ Fixtures
   g5_tables.npz       CGDict(maxdim=3) coefficient tables (dense) + LorentzD matrices
   g6_e2e_mix.npz      end-to-end, B=3 N=12 maxdim=2 ch 2233/3322, map_to_latent='mix' (learned mixing over particles)
   g7_e2e_meanmax.npz  end-to-end, B=3 N=12, map_to_latent=mean+max
+  g9_activations.npz  CGMLP with every non-default activation of get_activation_fn (lgn/nn/generic_levels.py:119-135): output and
+                      gradients w.r.t. input and parameters for a fixed cotangent
+  g9_e2e_elu.npz      end-to-end, B=3 N=12 maxdim=2 ch 2233/3322, activation='elu'
   g8_harness.npz      the reference's own equivariance harness (lgn/models/autotest/lgn_tests.py:292-423) run on the g1 weights
                       (maxdim 2) and the g2 weights (maxdim 3): gamma / theta grids, output and internal-feature deviation
                       tables, permutation results, on fixed zero-padded jets (SURVEY 8c "G6 harness")
@@ -75,10 +78,10 @@ def jets(B, N, seed, pad_rows=()):
     return p4, labels
 
 
-def build(N, maxdim, ch_enc, ch_dec, seed, map_to_latent="min&max"):
+def build(N, maxdim, ch_enc, ch_dec, seed, map_to_latent="min&max", activation="leakyrelu"):
     torch.manual_seed(seed)
     common = dict(maxdim=[maxdim], max_zf=[1], weight_init="randn", level_gain=[1.0], num_basis_fn=10,
-                  activation="leakyrelu", mlp=True, mlp_depth=6, mlp_width=6, device=CPU, dtype=F64)
+                  activation=activation, mlp=True, mlp_depth=6, mlp_width=6, device=CPU, dtype=F64)
     enc = LGNEncoder(num_input_particles=N, tau_input_scalars=1, tau_input_vectors=1, map_to_latent=map_to_latent,
                      tau_latent_scalars=1, tau_latent_vectors=8, num_channels=list(ch_enc), scale=1.0,
                      jet_features=False, **common)
@@ -88,12 +91,13 @@ def build(N, maxdim, ch_enc, ch_dec, seed, map_to_latent="min&max"):
     return enc, dec
 
 
-def e2e(name, B, N, maxdim, ch_enc, ch_dec, seed, pad_rows=(), map_to_latent="min&max"):
-    enc, dec = build(N, maxdim, ch_enc, ch_dec, seed, map_to_latent)
+def e2e(name, B, N, maxdim, ch_enc, ch_dec, seed, pad_rows=(), map_to_latent="min&max", activation="leakyrelu"):
+    enc, dec = build(N, maxdim, ch_enc, ch_dec, seed, map_to_latent, activation)
     p4, labels = jets(B, N, seed + 100, pad_rows)
-    store = {"p4": npy(p4), "labels": npy(labels),
-             "meta": np.array(json.dumps(dict(B=B, N=N, maxdim=maxdim, ch_enc=list(ch_enc), ch_dec=list(ch_dec),
-                                              seed=seed, l1_lambda=1e-8, map_to_latent=map_to_latent)))}
+    meta = dict(B=B, N=N, maxdim=maxdim, ch_enc=list(ch_enc), ch_dec=list(ch_dec), seed=seed, l1_lambda=1e-8, map_to_latent=map_to_latent)
+    if activation != "leakyrelu":
+        meta["activation"] = activation
+    store = {"p4": npy(p4), "labels": npy(labels), "meta": np.array(json.dumps(meta))}
     for k, v in enc.state_dict().items():
         store["enc." + k] = npy(v)
     for k, v in dec.state_dict().items():
@@ -219,6 +223,32 @@ def ops():
     print("g4_ops.npz", len(store))
 
 
+def activations():
+    """CGMLP (lgn/models/lgn_levels.py:124-241) with each activation get_activation_fn knows besides the default."""
+    store = {}
+    g = torch.Generator().manual_seed(77)
+    node = {(1, 1): torch.randn(2, 3, 7, 4, 4, dtype=F64, generator=g), (0, 0): torch.randn(2, 3, 7, 4, 1, dtype=F64, generator=g)}
+    cot = torch.randn(2, 3, 7, 4, 1, dtype=F64, generator=g)
+    put_rep(store, "in", node)
+    store["cot"] = npy(cot)
+    for act in ("relu", "elu", "sigmoid", "logsigmoid", "atan"):
+        torch.manual_seed(31)
+        mlp = CGMLP({(0, 0): 4, (1, 1): 4}, activation=act, num_hidden=6, layer_width_mul=6, device=CPU, dtype=F64)
+        for k, v in mlp.state_dict().items():
+            store[f"{act}.param.{k}"] = npy(v)
+        x = {k: v.clone() for k, v in node.items()}
+        x[(0, 0)].requires_grad_(True)
+        s_in = x[(0, 0)]
+        out = mlp(GVec(x))
+        put_rep(store, f"{act}.out", out)
+        (out[(0, 0)] * cot).sum().backward()
+        store[f"{act}.grad_in"] = npy(s_in.grad)
+        for k, p_ in mlp.named_parameters():
+            store[f"{act}.grad.{k}"] = npy(p_.grad)
+    np.savez_compressed(os.path.join(OUT, "g9_activations.npz"), **store)
+    print("g9_activations.npz", len(store))
+
+
 def tables():
     store = {}
     cgd = CGDict(maxdim=3, device=CPU, dtype=F64)
@@ -289,3 +319,6 @@ if __name__ == "__main__":
         harness()
     if want("g7"):
         e2e("g7_e2e_meanmax.npz", 3, 12, 2, (2, 2, 3, 3), (3, 3, 2, 2), seed=4, pad_rows=((2, 9),), map_to_latent="mean+max")
+    if want("g9"):
+        activations()
+        e2e("g9_e2e_elu.npz", 3, 12, 2, (2, 2, 3, 3), (3, 3, 2, 2), seed=5, pad_rows=((1, 7),), activation="elu")

@@ -179,12 +179,37 @@ def _level_case(dev, O, decoder, C, CO, N, B):
     U.assert_close(wm1.grad, P["lgn_cg.node_levels.0.cat_mix.mix_reps.weights.(1, 1)"].grad, GRAD_TOL, "g_wm1")
 
 
-@pytest.mark.parametrize("C,B,N", [(3, 2, 30), (4, 3, 30), (4, 1, 150), (2, 1, 5), (6, 1, 40), (6, 3, 37), (5, 2, 30), (8, 1, 70),
-                                   (4, 300, 30), (3, 275, 30)])      # >= 8192 rows: 64-row workgroups (fewer rows: 16-row ones, H <= 48)
-def test_cgmlp(dev, O, C, B, N):
-    from lgn import ops
+@pytest.mark.parametrize("act", ["relu", "elu", "sigmoid", "logsigmoid", "atan"])
+def test_cgmlp_activations_vs_reference_golden(dev, act):
+    """The CGMLP kernels with every non-default activation against vectors of the reference's CGMLP (g9)."""
+    from lgn import ops, _native as Nn
+    z = U.load("g9_activations.npz")
+    P = U.params_from(z, f"{act}.param")
+    s = U.rep_from(z, "in")[(0, 0)].squeeze(-1).to(dev).requires_grad_(True)
+    flat = []
+    for i in range(7):
+        flat += [P[f"linear.{i}.weight"].to(dev).requires_grad_(True), P[f"linear.{i}.bias"].to(dev).requires_grad_(True)]
+    y = ops.CGMLPFn.apply(Nn.activation_id(act), s, *flat)
+    U.assert_close(y.unsqueeze(-1), U.rep_from(z, f"{act}.out")[(0, 0)], FWD_TOL, f"{act} out")
+    (y.unsqueeze(-1) * torch.from_numpy(z["cot"]).to(dev)).sum().backward()
+    U.assert_close(s.grad.unsqueeze(-1), z[f"{act}.grad_in"], GRAD_TOL, f"{act} g_in")
+    for i in range(7):
+        U.assert_close(flat[2 * i].grad, z[f"{act}.grad.linear.{i}.weight"], GRAD_TOL, f"{act} g_w{i}")
+        U.assert_close(flat[2 * i + 1].grad, z[f"{act}.grad.linear.{i}.bias"], GRAD_TOL, f"{act} g_b{i}")
+
+
+@pytest.mark.parametrize("C,B,N,act", [(3, 2, 30, "leakyrelu"), (4, 3, 30, "leakyrelu"), (4, 1, 150, "leakyrelu"), (2, 1, 5, "leakyrelu"),
+                                       (6, 1, 40, "leakyrelu"), (6, 3, 37, "leakyrelu"), (5, 2, 30, "leakyrelu"), (8, 1, 70, "leakyrelu"),
+                                       # >= 8192 rows: 64-row workgroups (fewer rows: 16-row ones, H <= 48)
+                                       (4, 300, 30, "leakyrelu"), (3, 275, 30, "leakyrelu"),
+                                       # the other activations through every kernel family: 16-row and 64-row H <= 48, one-pass and
+                                       # two-pass wide
+                                       (4, 3, 30, "elu"), (4, 300, 30, "sigmoid"), (6, 3, 37, "atan"), (5, 2, 30, "logsigmoid"),
+                                       (8, 1, 70, "relu"), (3, 2, 30, "atan")])
+def test_cgmlp(dev, O, C, B, N, act):
+    from lgn import ops, _native as Nn
     g = torch.Generator().manual_seed(C * 7 + N)
-    cfg = O.NetConfig(num_channels=(C, C))
+    cfg = O.NetConfig(num_channels=(C, C), activation=act)
     P = {}
     torch.manual_seed(C)
     plans = O.build_level_plans(cfg, {(0, 0): C, (1, 1): C})
@@ -201,7 +226,7 @@ def test_cgmlp(dev, O, C, B, N):
     for i in range(7):
         flat += [P[f"lgn_cg.mlp_levels.0.linear.{i}.weight"].detach().to(dev).requires_grad_(True),
                  P[f"lgn_cg.mlp_levels.0.linear.{i}.bias"].detach().to(dev).requires_grad_(True)]
-    y = ops.CGMLPFn.apply(sd, *flat)
+    y = ops.CGMLPFn.apply(Nn.activation_id(act), sd, *flat)
     U.assert_close(y.unsqueeze(-1), out, FWD_TOL, "mlp out")
     (y.unsqueeze(-1) * cot.to(dev)).sum().backward()
     U.assert_close(sd.grad.unsqueeze(-1), s.grad, GRAD_TOL, "mlp g_in")
@@ -231,7 +256,7 @@ def test_mixreps(dev, O, rows, Ci, Co, d):
 def _build(meta, dev):
     import __graft_entry__ as G
     enc, dec = G._models(meta["N"], meta["ch_enc"], meta["ch_dec"], dev, seed=meta["seed"], maxdim=meta["maxdim"],
-                         map_to_latent=meta.get("map_to_latent", "min&max"))
+                         map_to_latent=meta.get("map_to_latent", "min&max"), activation=meta.get("activation", "leakyrelu"))
     return enc, dec
 
 
@@ -322,7 +347,7 @@ def _generic_level_case(dev, O, decoder, maxdim, full, C, CO, N, B):
 
 
 @pytest.mark.parametrize("name", ["g1_e2e_maxdim2.npz", "g3_e2e_n150.npz", "g2_e2e_maxdim3.npz", "g6_e2e_mix.npz",
-                                  "g7_e2e_meanmax.npz"])
+                                  "g7_e2e_meanmax.npz", "g9_e2e_elu.npz"])
 @pytest.mark.parametrize("fused", [True, False])
 def test_end_to_end_vs_reference_golden(dev, O, name, fused):
     """Full encoder -> decoder -> Chamfer forward/backward against vectors captured from the reference, through the
@@ -352,6 +377,9 @@ def test_end_to_end_vs_reference_golden(dev, O, name, fused):
     loss = O.chamfer_loss(rec[0] + rec[1], p4.to(dev))
     U.assert_close(loss, z["loss_chamfer"], FWD_TOL, "chamfer")
     loss.backward()
+    # a gradient tensor 100x below the largest gradient of the step is held to that floor (g9 / ELU: the encoder's input
+    # mixing weight gets 5e-12 against 3e-9, the survivor of a cancellation whose rounding noise is absolute)
+    floor = 1e-2 * max(float(abs(z[k]).max()) for k in z.files if k.startswith("grad."))
     for pre, mod in (("enc", enc), ("dec", dec)):
         assert [n for n, _ in mod.named_parameters()] == ["flat_params"]
         for k, got in mod.named_grads():
@@ -359,7 +387,7 @@ def test_end_to_end_vs_reference_golden(dev, O, name, fused):
             if ref.abs().max() == 0:
                 assert got.abs().max() == 0, f"{pre}.{k} must have exactly zero gradient"
             else:
-                U.assert_close(got, ref, GRAD_TOL, f"grad {pre}.{k}")
+                U.assert_close_scaled(got, ref, GRAD_TOL, floor, f"grad {pre}.{k}")
 
 
 @pytest.mark.parametrize("name,B,N,maxdim,che,chd", [("cfg2", 512, 30, 2, (3, 3, 4, 4), (4, 4, 3, 3)),

@@ -38,12 +38,13 @@ def _golden_setup(name="g1_e2e_maxdim2.npz"):
     dev = torch.device("cuda:0")
     z = U.load(name)
     m = U.meta(z)
-    enc, dec = G._models(m["N"], m["ch_enc"], m["ch_dec"], dev, seed=m["seed"], maxdim=m.get("maxdim", 2))
+    enc, dec = G._models(m["N"], m["ch_enc"], m["ch_dec"], dev, seed=m["seed"], maxdim=m.get("maxdim", 2),
+                         activation=m.get("activation", "leakyrelu"))
     batch = {"p4": torch.from_numpy(z["p4"]).to(dev), "labels": torch.from_numpy(z["labels"]).to(dev)}
     return z, m, enc, dec, batch
 
 
-@pytest.mark.parametrize("name", ["g1_e2e_maxdim2.npz", "g3_e2e_n150.npz", "g2_e2e_maxdim3.npz"])
+@pytest.mark.parametrize("name", ["g1_e2e_maxdim2.npz", "g3_e2e_n150.npz", "g2_e2e_maxdim3.npz", "g9_e2e_elu.npz"])
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_native_step_matches_reference_golden(name, use_graph):
     """lgn_step_fwd_bwd_f64 + lgn_step_finalize_f64 (one native call each, optionally replayed from a HIP graph)

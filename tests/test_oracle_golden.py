@@ -10,13 +10,14 @@ TOL = 1e-12
 
 
 def _cfgs(m):
-    common = dict(num_particles=m["N"], maxdim=m["maxdim"], map_to_latent=m.get("map_to_latent", "min&max"))
+    common = dict(num_particles=m["N"], maxdim=m["maxdim"], map_to_latent=m.get("map_to_latent", "min&max"),
+                  activation=m.get("activation", "leakyrelu"))
     return (O.NetConfig(num_channels=tuple(m["ch_enc"]), **common),
             O.NetConfig(num_channels=tuple(m["ch_dec"]), **common))
 
 
 @pytest.mark.parametrize("name", ["g1_e2e_maxdim2.npz", "g2_e2e_maxdim3.npz", "g3_e2e_n150.npz", "g6_e2e_mix.npz",
-                                  "g7_e2e_meanmax.npz"])
+                                  "g7_e2e_meanmax.npz", "g9_e2e_elu.npz"])
 def test_end_to_end_forward_backward(name):
     z = U.load(name)
     m = U.meta(z)
@@ -131,6 +132,22 @@ def test_cgmlp():
     cfg = O.NetConfig(num_channels=(3, 3))
     out = O.cg_mlp(P, cfg, 0, U.rep_from(z, "mlp.in"))
     U.assert_rep_close(out, U.rep_from(z, "mlp.out"), TOL, "cgmlp")
+
+
+@pytest.mark.parametrize("act", ["relu", "elu", "sigmoid", "logsigmoid", "atan"])
+def test_cgmlp_activations(act):
+    """Every non-default activation of get_activation_fn (lgn/nn/generic_levels.py:119-135): output and all gradients."""
+    z = U.load("g9_activations.npz")
+    P = {"lgn_cg.mlp_levels.0." + k: v.clone().requires_grad_(True) for k, v in U.params_from(z, f"{act}.param").items()}
+    node = U.rep_from(z, "in")
+    node[(0, 0)] = node[(0, 0)].clone().requires_grad_(True)
+    s_in = node[(0, 0)]
+    out = O.cg_mlp(P, O.NetConfig(num_channels=(4, 4), activation=act), 0, node)
+    U.assert_rep_close(out, U.rep_from(z, f"{act}.out"), TOL, f"cgmlp {act}")
+    (out[(0, 0)] * torch.from_numpy(z["cot"])).sum().backward()
+    U.assert_close(s_in.grad, z[f"{act}.grad_in"], 1e-11, f"{act} grad_in")
+    for k, p in P.items():
+        U.assert_close(p.grad, z[f"{act}.grad." + k[len("lgn_cg.mlp_levels.0."):]], 1e-11, f"{act} grad {k}")
 
 
 @pytest.mark.parametrize("method", ["min", "max", "min&max", "mean", "sum", "min+max"])
