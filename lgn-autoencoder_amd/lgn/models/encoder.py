@@ -25,13 +25,15 @@ class LGNEncoder(CGModule, LevelTablesMixin):
         max_zf = adapt_var_list(max_zf, num_cg_levels)
         super().__init__(maxdim=max(maxdim + max_zf), device=device, dtype=dtype, cg_dict=cg_dict)
         logging.info(f"Initializing encoder with device: {self.device} and dtype: {self.dtype}")
-        if jet_features:
-            raise NotImplementedError("jet_features=True is outside the accelerated path (SURVEY section 8)")
+        if jet_features:            # one more node (the jet's momentum) and one more input scalar (lgn_encoder.py:159-161)
+            num_input_particles += 1
+            tau_input_scalars += 1
         if num_cg_levels < 1 or any(m not in (2, 3) for m in maxdim) or any(z != 1 for z in max_zf):
             raise NotImplementedError(
                 f"this build implements maxdim 2 (fused kernels) and 3 (table-driven kernels) with max_zf=1; got maxdim={maxdim}, max_zf={max_zf}")
-        if tau_input_scalars != 1 or tau_input_vectors != 1:
-            raise NotImplementedError("the encoder input is one scalar (mass) and one vector (p4) per particle")
+        if tau_input_scalars < 1 or tau_input_vectors != 1:
+            raise NotImplementedError("the encoder input is the mass (+ extra scalars) and ONE vector (p4) per particle")
+        self.tau_input_scalars = tau_input_scalars
         misc = {"device": self.device, "dtype": self.dtype}
 
         self.num_input_particles = num_input_particles
@@ -80,7 +82,7 @@ class LGNEncoder(CGModule, LevelTablesMixin):
                 ) -> Union[GVec, Tuple[GVec, List[GVec]]]:
         self._require_gpu()
         self._check_views()
-        node_ps, node_mask = self._prepare_input(data)
+        node_ps, node_mask, scalars = self._prepare_input(data)
         if not covariance_test and self.use_fused and self._fused_ok():
             # the whole encoder is one native call (and one more for its backward): csrc/step.hip lgn_encoder_fwd/bwd_f64
             lat_s, lat_v = ops.EncoderFn.apply(self, node_ps, node_mask, self.flat_params)
@@ -88,18 +90,23 @@ class LGNEncoder(CGModule, LevelTablesMixin):
         # module / autograd path: one native call per operator (all irreps, every map_to_latent, internal features)
         self._bind(self._tracked_views())
         try:
-            return self._forward_modular(node_ps, node_mask, covariance_test)
+            return self._forward_modular(node_ps, node_mask, covariance_test, scalars)
         finally:
             self._bind(self._p_views)
 
     def _fused_ok(self) -> bool:
         """True when a whole-network native implementation covers this configuration (lgn/ops.py: native_kind)."""
-        return ops.native_kind(self) is not None
+        # the whole-network calls take the mass as the only input scalar: jet features / extra scalars run per operator
+        return ops.native_kind(self) is not None and self.tau_input_scalars == 1
 
-    def _forward_modular(self, node_ps, node_mask, covariance_test):
-        # input features: (0,0) = (sqrt|p^2|, 0), (1,1) = canonical(p)   (lgn_encoder.py:287-293,376)
+    def _forward_modular(self, node_ps, node_mask, covariance_test, scalars=None):
+        # input features: (0,0) = (sqrt|p^2| [, jet mass, extra scalars], 0), (1,1) = canonical(p)   (lgn_encoder.py:287-293,376)
         mass = ops.normsq4(node_ps).abs().sqrt()
-        s0 = torch.stack([mass, torch.zeros_like(mass)], 0).unsqueeze(-1).unsqueeze(-1)      # (2,B,N,1,1)
+        if scalars is None:
+            s0 = torch.stack([mass, torch.zeros_like(mass)], 0).unsqueeze(-1).unsqueeze(-1)  # (2,B,N,1,1)
+        else:
+            sc = torch.cat([mass.unsqueeze(-1), scalars], -1)                                  # (B,N,S)
+            s0 = torch.stack([sc, torch.zeros_like(sc)], 0).unsqueeze(-1).contiguous()         # (2,B,N,S,1)
         v0 = ops.cart_to_canonical_real(node_ps).unsqueeze(-2)                                 # (2,B,N,1,4)
         s = ops.MixFn.apply(self.input_func_node.weight((0, 0)), s0).squeeze(-1)
         v = ops.MixFn.apply(self.input_func_node.weight((1, 1)), v0)
@@ -121,7 +128,10 @@ class LGNEncoder(CGModule, LevelTablesMixin):
         return latent, [as_gvec(f, o) for f, o in zip(feats, orders)]
 
     def _prepare_input(self, data):
-        """lgn_encoder.py:338-412 (without the jet-feature node)."""
+        """lgn_encoder.py:338-412.  Returns (momenta, node mask, extra scalars or None): with jet_features the jet's momentum is
+        appended as one more (unmasked) node and every node gets the scalar normsq4(sum over ALL nodes) -- the reference sums after
+        appending the jet node and takes no square root, i.e. 4 x the squared jet mass (lgn_encoder.py:377-390) -- as its second
+        input scalar; data['scalars'] (B, N, k) are appended after it (lgn_encoder.py:403-408)."""
         if isinstance(data, torch.Tensor):
             data = {"p4": data}
         elif isinstance(data, np.ndarray):
@@ -135,6 +145,16 @@ class LGNEncoder(CGModule, LevelTablesMixin):
                 break
         else:
             node_mask = (data["p4"][..., 0] != 0).to(device=self.device, dtype=torch.uint8)
+        scalars = None
+        if self.jet_features:
+            node_ps = torch.cat((node_ps, node_ps.sum(dim=-2, keepdim=True)), dim=-2)
+            jet_mass = ops.normsq4(node_ps.sum(dim=-2))                                        # (B,)
+            scalars = jet_mass.unsqueeze(-1).unsqueeze(-1).repeat(1, node_ps.shape[-2], 1)
+            node_mask = torch.cat((node_mask, torch.ones_like(node_mask[..., 0:1])), dim=-1)
         if "scalars" in data:
-            raise NotImplementedError("extra input scalars are outside the accelerated path")
-        return node_ps.contiguous(), node_mask.contiguous()
+            extra = data["scalars"].to(device=self.device, dtype=self.dtype)
+            scalars = extra if scalars is None else torch.cat([scalars, extra], dim=-1)
+        have = 1 + (0 if scalars is None else scalars.shape[-1])
+        if have != self.tau_input_scalars:
+            raise ValueError(f"the encoder was built for {self.tau_input_scalars} input scalars per particle, the batch gives {have}")
+        return node_ps.contiguous(), node_mask.contiguous(), (None if scalars is None else scalars.contiguous())

@@ -189,6 +189,9 @@ class NativeTrainStep:
                 "map_to_latent='min&max', CGMLP levels (mlp_depth=6), num_basis_fn=10 and <= 8 channels; got encoder "
                 f"maxdim={encoder.level_maxdim} map_to_latent={encoder.map_to_latent!r} mlp={encoder.mlp} mlp_depth="
                 f"{encoder.mlp_depth}, decoder maxdim={decoder.level_maxdim} mlp={decoder.mlp}")
+        if getattr(encoder, "tau_input_scalars", 1) != 1:
+            raise NotImplementedError("the native step takes the particle masses as the only input scalars: jet_features / extra "
+                                      "input scalars run through the module API (per-operator path)")
         encoder._require_gpu()
         self.encoder, self.decoder = encoder, decoder
         self.l1_lambda, self.lr, self.betas, self.eps = l1_lambda, lr, betas, eps

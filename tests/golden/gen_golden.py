@@ -22,6 +22,8 @@ Fixtures
   g9_activations.npz  CGMLP with every non-default activation of get_activation_fn (lgn/nn/generic_levels.py:119-135): output and
                       gradients w.r.t. input and parameters for a fixed cotangent
   g9_e2e_elu.npz      end-to-end, B=3 N=12 maxdim=2 ch 2233/3322, activation='elu'
+  g10_e2e_jetfeat.npz end-to-end, B=3 N=12 maxdim=2 ch 2233/3322, jet_features=True (13th node = jet momentum, second input scalar)
+                      plus one extra input scalar per node through data['scalars']
   g8_harness.npz      the reference's own equivariance harness (lgn/models/autotest/lgn_tests.py:292-423) run on the g1 weights
                       (maxdim 2) and the g2 weights (maxdim 3): gamma / theta grids, output and internal-feature deviation
                       tables, permutation results, on fixed zero-padded jets (SURVEY 8c "G6 harness")
@@ -78,25 +80,28 @@ def jets(B, N, seed, pad_rows=()):
     return p4, labels
 
 
-def build(N, maxdim, ch_enc, ch_dec, seed, map_to_latent="min&max", activation="leakyrelu"):
+def build(N, maxdim, ch_enc, ch_dec, seed, map_to_latent="min&max", activation="leakyrelu", jet_features=False, tau_input_scalars=1):
     torch.manual_seed(seed)
     common = dict(maxdim=[maxdim], max_zf=[1], weight_init="randn", level_gain=[1.0], num_basis_fn=10,
                   activation=activation, mlp=True, mlp_depth=6, mlp_width=6, device=CPU, dtype=F64)
-    enc = LGNEncoder(num_input_particles=N, tau_input_scalars=1, tau_input_vectors=1, map_to_latent=map_to_latent,
+    enc = LGNEncoder(num_input_particles=N, tau_input_scalars=tau_input_scalars, tau_input_vectors=1, map_to_latent=map_to_latent,
                      tau_latent_scalars=1, tau_latent_vectors=8, num_channels=list(ch_enc), scale=1.0,
-                     jet_features=False, **common)
+                     jet_features=jet_features, **common)
     mult = len(map_to_latent.split("&"))          # '&' concatenates the pooled features (utils/initialize.py:118-120)
     dec = LGNDecoder(tau_latent_scalars=1 * mult, tau_latent_vectors=8 * mult, num_output_particles=N, tau_output_scalars=1,
                      tau_output_vectors=1, num_channels=list(ch_dec), cg_dict=enc.cg_dict, **common)
     return enc, dec
 
 
-def e2e(name, B, N, maxdim, ch_enc, ch_dec, seed, pad_rows=(), map_to_latent="min&max", activation="leakyrelu"):
-    enc, dec = build(N, maxdim, ch_enc, ch_dec, seed, map_to_latent, activation)
+def e2e(name, B, N, maxdim, ch_enc, ch_dec, seed, pad_rows=(), map_to_latent="min&max", activation="leakyrelu", jet_features=False,
+        extra_scalars=0):
+    enc, dec = build(N, maxdim, ch_enc, ch_dec, seed, map_to_latent, activation, jet_features, 1 + extra_scalars)
     p4, labels = jets(B, N, seed + 100, pad_rows)
     meta = dict(B=B, N=N, maxdim=maxdim, ch_enc=list(ch_enc), ch_dec=list(ch_dec), seed=seed, l1_lambda=1e-8, map_to_latent=map_to_latent)
     if activation != "leakyrelu":
         meta["activation"] = activation
+    if jet_features or extra_scalars:
+        meta["jet_features"], meta["extra_scalars"] = bool(jet_features), extra_scalars
     store = {"p4": npy(p4), "labels": npy(labels), "meta": np.array(json.dumps(meta))}
     for k, v in enc.state_dict().items():
         store["enc." + k] = npy(v)
@@ -104,6 +109,10 @@ def e2e(name, B, N, maxdim, ch_enc, ch_dec, seed, pad_rows=(), map_to_latent="mi
         store["dec." + k] = npy(v)
 
     batch = {"p4": p4, "labels": labels}
+    if extra_scalars:       # data['scalars'] (lgn_encoder.py:403-408): one row per node the encoder works on (incl. the jet node)
+        gs = torch.Generator().manual_seed(seed + 200)
+        batch["scalars"] = torch.randn(B, N + int(jet_features), extra_scalars, dtype=F64, generator=gs)
+        store["scalars"] = npy(batch["scalars"])
     latent, nodes_all = enc(batch, covariance_test=True)
     n_enc = len(nodes_all)
     put_rep(store, "latent", latent)
@@ -322,3 +331,5 @@ if __name__ == "__main__":
     if want("g9"):
         activations()
         e2e("g9_e2e_elu.npz", 3, 12, 2, (2, 2, 3, 3), (3, 3, 2, 2), seed=5, pad_rows=((1, 7),), activation="elu")
+    if want("g10"):
+        e2e("g10_e2e_jetfeat.npz", 3, 12, 2, (2, 2, 3, 3), (3, 3, 2, 2), seed=6, pad_rows=((2, 9),), jet_features=True, extra_scalars=1)

@@ -256,7 +256,8 @@ def test_mixreps(dev, O, rows, Ci, Co, d):
 def _build(meta, dev):
     import __graft_entry__ as G
     enc, dec = G._models(meta["N"], meta["ch_enc"], meta["ch_dec"], dev, seed=meta["seed"], maxdim=meta["maxdim"],
-                         map_to_latent=meta.get("map_to_latent", "min&max"), activation=meta.get("activation", "leakyrelu"))
+                         map_to_latent=meta.get("map_to_latent", "min&max"), activation=meta.get("activation", "leakyrelu"),
+                         jet_features=meta.get("jet_features", False), tau_input_scalars=1 + meta.get("extra_scalars", 0))
     return enc, dec
 
 
@@ -347,7 +348,7 @@ def _generic_level_case(dev, O, decoder, maxdim, full, C, CO, N, B):
 
 
 @pytest.mark.parametrize("name", ["g1_e2e_maxdim2.npz", "g3_e2e_n150.npz", "g2_e2e_maxdim3.npz", "g6_e2e_mix.npz",
-                                  "g7_e2e_meanmax.npz", "g9_e2e_elu.npz"])
+                                  "g7_e2e_meanmax.npz", "g9_e2e_elu.npz", "g10_e2e_jetfeat.npz"])
 @pytest.mark.parametrize("fused", [True, False])
 def test_end_to_end_vs_reference_golden(dev, O, name, fused):
     """Full encoder -> decoder -> Chamfer forward/backward against vectors captured from the reference, through the
@@ -362,6 +363,8 @@ def test_end_to_end_vs_reference_golden(dev, O, name, fused):
     dec.load_state_dict({k: v for k, v in U.params_from(z, "dec").items()})
     p4 = torch.from_numpy(z["p4"]); labels = torch.from_numpy(z["labels"])
     batch = {"p4": p4, "labels": labels}
+    if "scalars" in z.files:                 # g10: jet_features + data['scalars'] (lgn_encoder.py:372-411)
+        batch["scalars"] = torch.from_numpy(z["scalars"])
 
     latent, nodes_all = enc(batch, covariance_test=True)
     U.assert_rep_close(dict(latent.items()), U.rep_from(z, "latent"), FWD_TOL, "latent")

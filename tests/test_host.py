@@ -237,6 +237,12 @@ def test_native_step_refuses_configurations_it_does_not_implement():
     enc, dec = G._models(12, (3, 3, 4, 4), (4, 4, 3, 3), torch.device("cpu"), seed=0, map_to_latent="mean+max")
     with pytest.raises(NotImplementedError, match="min&max"):
         NativeTrainStep(enc, dec, batch_size=4)
+    # jet features / extra input scalars: module API only (the whole-step call takes the masses as the only input scalars)
+    enc, dec = G._models(12, (3, 3, 4, 4), (4, 4, 3, 3), torch.device("cpu"), seed=0, jet_features=True)
+    assert enc.num_input_particles == 13 and enc.tau_input_scalars == 2 and not enc._fused_ok()
+    assert tuple(enc.input_func_node.weight((0, 0)).shape) == (2, 3, 2)
+    with pytest.raises(NotImplementedError, match="jet_features"):
+        NativeTrainStep(enc, dec, batch_size=4)
 
 
 def test_generated_static_tables_are_up_to_date_and_match_the_runtime_matcher():

@@ -12,12 +12,13 @@ TOL = 1e-12
 def _cfgs(m):
     common = dict(num_particles=m["N"], maxdim=m["maxdim"], map_to_latent=m.get("map_to_latent", "min&max"),
                   activation=m.get("activation", "leakyrelu"))
-    return (O.NetConfig(num_channels=tuple(m["ch_enc"]), **common),
+    return (O.NetConfig(num_channels=tuple(m["ch_enc"]), jet_features=m.get("jet_features", False),
+                        tau_input_scalars=1 + m.get("extra_scalars", 0), **common),
             O.NetConfig(num_channels=tuple(m["ch_dec"]), **common))
 
 
 @pytest.mark.parametrize("name", ["g1_e2e_maxdim2.npz", "g2_e2e_maxdim3.npz", "g3_e2e_n150.npz", "g6_e2e_mix.npz",
-                                  "g7_e2e_meanmax.npz", "g9_e2e_elu.npz"])
+                                  "g7_e2e_meanmax.npz", "g9_e2e_elu.npz", "g10_e2e_jetfeat.npz"])
 def test_end_to_end_forward_backward(name):
     z = U.load(name)
     m = U.meta(z)
@@ -25,8 +26,9 @@ def test_end_to_end_forward_backward(name):
     Pe = {k: v.clone().requires_grad_(True) for k, v in U.params_from(z, "enc").items()}
     Pd = {k: v.clone().requires_grad_(True) for k, v in U.params_from(z, "dec").items()}
     p4 = torch.from_numpy(z["p4"]); labels = torch.from_numpy(z["labels"])
+    xs = torch.from_numpy(z["scalars"]) if "scalars" in z.files else None      # data['scalars'] (g10)
 
-    lat, enc_nodes = O.encoder_forward(Pe, ce, p4, labels, covariance_test=True)
+    lat, enc_nodes = O.encoder_forward(Pe, ce, p4, labels, covariance_test=True, extra_scalars=xs)
     U.assert_rep_close(lat, U.rep_from(z, "latent"), TOL, "latent")
     for i, rep in enumerate(enc_nodes):
         U.assert_rep_close(rep, U.rep_from(z, f"enc_nodes.{i}"), TOL, f"enc_nodes[{i}]")
@@ -34,7 +36,7 @@ def test_end_to_end_forward_backward(name):
     for i, rep in enumerate(dec_nodes):
         U.assert_rep_close(rep, U.rep_from(z, f"dec_nodes.{i}"), TOL, f"dec_nodes[{i}]")
 
-    rec = O.decoder_forward(Pd, cd, O.encoder_forward(Pe, ce, p4, labels))
+    rec = O.decoder_forward(Pd, cd, O.encoder_forward(Pe, ce, p4, labels, extra_scalars=xs))
     U.assert_close(rec, z["recon"], TOL, "recon")
     real = O.get_real(rec, "sum")
     U.assert_close(real, z["recon_real"], TOL, "recon_real")
