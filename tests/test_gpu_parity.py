@@ -510,3 +510,47 @@ def test_static_local_kernels_match_runtime_table_kernels(dev, decoder):
         U.assert_close(from_tb(gXT, Q).reshape(2, B, N, C, Q), ref_gX, 1e-12, f"level {lvl} d X")
         U.assert_close(gw, ref_gw, 1e-12, f"level {lvl} d W")
     assert seen == ({(1, 6), (2, 6), (2, 4)} if decoder else {(1, 4), (2, 8)}), seen
+
+
+@pytest.mark.parametrize("tag,kw", [
+    ("mlp_false", dict(mlp=False)),
+    ("scale_elu", dict(scale=0.5, activation="elu")),
+    ("jet_features_maxdim3", dict(jet_features=True, maxdim=3)),
+    ("sigmoid_maxdim3_wide", dict(activation="sigmoid", maxdim=3, ch_enc=(4, 4, 6, 6), ch_dec=(6, 6, 4, 4), N=30, B=2)),
+    ("logsigmoid_n150", dict(activation="logsigmoid", N=150, B=1, ch_enc=(3, 3, 4, 4), ch_dec=(4, 4, 3, 3)))])
+def test_module_option_combinations_vs_oracle(dev, O, tag, kw):
+    """Constructor options no reference fixture combines (mlp=False, scale with a non-default activation, jet features at maxdim 3,
+    non-default activations in the wide CGMLP kernels and at N = 150): module API on the GPU against the oracle, forward and every
+    parameter gradient (gradient tensors far below the step's gradient scale are held to 1 % of that scale)."""
+    from lgn.models import LGNEncoder, LGNDecoder
+    N, B, maxdim = kw.get("N", 12), kw.get("B", 3), kw.get("maxdim", 2)
+    ch_enc, ch_dec = kw.get("ch_enc", (2, 2, 3, 3)), kw.get("ch_dec", (3, 3, 2, 2))
+    act, mlp, scale, jf = kw.get("activation", "leakyrelu"), kw.get("mlp", True), kw.get("scale", 1.0), kw.get("jet_features", False)
+    torch.manual_seed(11)
+    common = dict(maxdim=[maxdim], max_zf=[1], weight_init="randn", level_gain=[1.0], num_basis_fn=10, activation=act, mlp=mlp,
+                  mlp_depth=6, mlp_width=6, device=dev, dtype=torch.float64)
+    enc = LGNEncoder(num_input_particles=N, tau_input_scalars=1, tau_input_vectors=1, map_to_latent="min&max", tau_latent_scalars=1,
+                     tau_latent_vectors=8, num_channels=list(ch_enc), scale=scale, jet_features=jf, **common)
+    dec = LGNDecoder(tau_latent_scalars=2, tau_latent_vectors=16, num_output_particles=N, tau_output_scalars=1, tau_output_vectors=1,
+                     num_channels=list(ch_dec), cg_dict=enc.cg_dict, **common)
+    oc = dict(num_particles=N, maxdim=maxdim, activation=act, mlp=mlp)
+    ce = O.NetConfig(num_channels=tuple(ch_enc), jet_features=jf, scale=scale, **oc)
+    cd = O.NetConfig(num_channels=tuple(ch_dec), **oc)
+    Pe = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in enc.state_dict().items()}
+    Pd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in dec.state_dict().items()}
+    p4, labels = O.synthetic_jets(B, N, seed=5, pad=True)
+    rec = dec(enc({"p4": p4, "labels": labels}))
+    loss = O.chamfer_loss(rec[0] + rec[1], p4.to(dev))
+    loss.backward()
+    rec_o = O.decoder_forward(Pd, cd, O.encoder_forward(Pe, ce, p4, labels))
+    loss_o = O.chamfer_loss(rec_o[0] + rec_o[1], p4)
+    loss_o.backward()
+    U.assert_close(rec, rec_o.detach(), FWD_TOL, f"{tag} recon")
+    U.assert_close(loss.detach(), loss_o.detach(), FWD_TOL, f"{tag} loss")
+    grads = [(f"{pre}.{k}", g, P[k].grad) for pre, mod, P in (("enc", enc, Pe), ("dec", dec, Pd)) for k, g in mod.named_grads()]
+    floor = 1e-2 * max(float(r.abs().max()) for _, _, r in grads if r is not None)
+    for name, g, r in grads:
+        if r is None or r.abs().max() == 0:
+            assert g.abs().max() == 0, f"{tag} {name}: must have exactly zero gradient"
+        else:
+            U.assert_close_scaled(g, r, GRAD_TOL, floor, f"{tag} grad {name}")
