@@ -42,6 +42,18 @@ struct LevelArgs {
   // level output before the CGMLP
   T* s_out;  // [2][B][N][CO]
   T* v_out;  // [2][B][N][CO][4]
+  // Encoder, first level of a whole-network / whole-step call (in_w0 != nullptr): the level forms its own input features from
+  // the momenta -- s = W00[c] * mass, v = W11[c] * canon(p): input_func_node of lgn_encoder.py:284-298,376, the arithmetic of
+  // enc_input_fwd_kernel -- instead of reading s_in / v_in, and writes them to in_s / in_v (== s_in / v_in) for the backward.
+  // It is then the FIRST kernel of the step and also clears z1[0 .. z1n) and z2[0 .. z2n) (gradient buffer, zero block).
+  const T* in_w0 = nullptr;   // [2][C] input_func_node weights of (0,0)
+  const T* in_w1 = nullptr;   // [2][C]                          (1,1)
+  T* in_s = nullptr;
+  T* in_v = nullptr;
+  T* z1 = nullptr;
+  size_t z1n = 0;
+  T* z2 = nullptr;
+  size_t z2n = 0;
 };
 
 template <typename T>

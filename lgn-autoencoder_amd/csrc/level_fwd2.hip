@@ -84,7 +84,54 @@ __global__ __launch_bounds__(2 * BLOCK) void level_fwd2_kernel(LevelArgs<double>
   uint8_t* mk = reinterpret_cast<uint8_t*>(sums + 20 * C);            // N
 
   STAMP(0);
-  {  // the jet and the CatMix weights in one memory round trip (level_dev.hpp: load_jet_issue)
+  if (!DEC && a.in_w0) {
+    // first encoder level of a fused network: input features from the momenta (see LevelArgs::in_w0), buffers to clear
+    {
+      const size_t wg = (size_t)blockIdx.y * gridDim.x + blockIdx.x, stride = (size_t)gridDim.x * gridDim.y * nthr;
+      for (size_t e = wg * nthr + tid; e < a.z1n; e += stride) a.z1[e] = 0.0;
+      for (size_t e = wg * nthr + tid; e < a.z2n; e += stride) a.z2[e] = 0.0;
+    }
+    const double* p0 = a.p + (size_t)b * N * 4;
+    const size_t plane_s = (size_t)B * N * C;
+    const int nw2 = 2 * CO * 5 * C;
+    for (int e = tid; e < N * 4; e += nthr) pj[e] = p0[e];
+    for (int e = tid; e < N; e += nthr) mk[e] = a.mask[(size_t)b * N + e];
+    for (int e = tid; e < nw2; e += nthr) {
+      wm[e] = a.wm0[e];
+      wm[nw2 + e] = a.wm1[e];
+    }
+    for (int e = tid; e < N * C; e += nthr) {
+      const int j = e / C, c = e - j * C;
+      const double* p = p0 + j * 4;
+      const double pe = p[0], px = p[1], py = p[2], pz = p[3];
+      // 2 E^2 - sum p^2 with the left-to-right sum of the reference's CPU reduction (zonal_functions.py:201-218)
+      const double q0 = pe * pe, q1 = px * px, q2 = py * py, q3 = pz * pz;
+      const double mass = sqrt(fabs(2.0 * q0 - (((q0 + q1) + q2) + q3)));
+      constexpr double H = 0.70710678118654752440084436210484903928;
+      const cx<double> q[4] = {{pe, 0.0}, {px * H, -py * H}, {pz, 0.0}, {-px * H, -py * H}};     // p_to_rep (zonal_functions.py:251-289)
+      const double w0r = a.in_w0[c], w0i = a.in_w0[C + c];
+      const cx<double> w1 = {a.in_w1[c], a.in_w1[C + c]};
+      double* d = nd + j * F::NS + c * 10;
+      d[0] = w0r * mass;
+      d[1] = w0i * mass;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const cx<double> r = cmul(w1, q[m]);
+        d[2 + m] = r.r;
+        d[6 + m] = r.i;
+      }
+      if (blockIdx.y == 0) {                                 // one copy for the backward (s_in / v_in of this level)
+        const size_t ge = (size_t)b * N * C + e;
+        a.in_s[ge] = d[0];
+        a.in_s[plane_s + ge] = d[1];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          a.in_v[ge * 4 + m] = d[2 + m];
+          a.in_v[plane_s * 4 + ge * 4 + m] = d[6 + m];
+        }
+      }
+    }
+  } else {  // the jet and the CatMix weights in one memory round trip (level_dev.hpp: load_jet_issue)
     JetRegs<double> jr;
     load_jet_issue<double, C, DEC>(a.s_in, a.v_in, a.p, a.mask, B, N, b, jr);
     const int nw2 = 2 * CO * 5 * C, ew = tid < nw2 ? tid : 0;
@@ -516,6 +563,7 @@ static int launch_level_fwd2(const LevelArgs<double>& a, hipStream_t stream) {
 template <>
 int level_fwd_dispatch<double>(const LevelArgs<double>& a, int decoder, hipStream_t stream) {
   LGN_CHECK_ARG(a.B > 0 && a.N > 0, "level_fwd: empty batch (B=%d N=%d)", a.B, a.N);
+  LGN_CHECK_ARG(!a.in_w0 || (!decoder && a.in_w1 && a.in_s && a.in_v), "level_fwd: the input stage rides on encoder levels only");
   LGN_CHECK_ARG(a.CO >= 1 && a.CO <= 8, "level_fwd: C_out=%d unsupported (1..8)", a.CO);
   // LGN_AMD_DEC_PAIRWISE=1 keeps the decoder on the O(N^2) pair sweep (cross-check of the separable form)
   const char* pw_env = getenv("LGN_AMD_DEC_PAIRWISE");      // read per call: tests flip it

@@ -210,9 +210,19 @@ struct Slots {                      // canonical parameter slot order shared wit
     if (rc_ != 0) return rc_;    \
   } while (0)
 
+// The encoder's input stage (input_func_node on mass and canonical momenta) rides on the first level's kernel, which then
+// is the first kernel of the call and also clears z1 / z2 (LevelArgs::in_w0).
+struct InputStage {
+  const double *w0, *w1;
+  double* z1 = nullptr;
+  size_t z1n = 0;
+  double* z2 = nullptr;
+  size_t z2n = 0;
+};
+
 // forward of one network's level stack; returns via buffers
 int levels_fwd(const lgn_net_desc& d, bool dec, const int* ch, const double* P, const int64_t* off, NetBuf& n, const double* pos,
-               const uint8_t* mask, hipStream_t st) {
+               const uint8_t* mask, hipStream_t st, const InputStage* in0 = nullptr) {
   const Slots S{d.n_levels, d.mlp_nlin};
   for (int l = 0; l < d.n_levels; ++l) {
     auto p = [&](int slot) { return P + off[slot]; };
@@ -220,6 +230,10 @@ int levels_fwd(const lgn_net_desc& d, bool dec, const int* ch, const double* P, 
                         p(S.rad(dec, l, 0)), p(S.rad(dec, l, 1)), p(S.rad(dec, l, 2)), p(S.rad(dec, l, 3)), p(S.rad(dec, l, 4)),
                         p(S.rad(dec, l, 5)), p(S.rad(dec, l, 6)), p(S.mix(dec, l, 0)), p(S.mix(dec, l, 1)),
                         n.ag0[l], n.ag1[l], n.smix[l], n.v[l + 1]};
+    if (l == 0 && !dec && in0) {
+      a.in_w0 = in0->w0; a.in_w1 = in0->w1; a.in_s = n.s[0]; a.in_v = n.v[0];
+      a.z1 = in0->z1; a.z1n = in0->z1n; a.z2 = in0->z2; a.z2n = in0->z2n;
+    }
     LGN_TRY(level_fwd_dispatch<double>(a, dec, st));
     MlpArgs<double> m{};
     m.M = d.B * d.N; m.C = ch[l + 1]; m.H = d.mlp_hidden_mul * 2 * ch[l + 1]; m.nlin = d.mlp_nlin; m.act = d.activation;
@@ -874,8 +888,8 @@ int lgn_encoder_fwd_f64(const lgn_net_desc* d, const double* params, const int64
   const Slots S{d->n_levels, d->mlp_nlin};
   const int L = d->n_levels;
   const int* ce = d->enc_channels;
-  LGN_TRY(enc_input_fwd(d->B, d->N, ce[0], p4, params + off[0], params + off[1], a.n.s[0], a.n.v[0], st));
-  LGN_TRY(levels_fwd(*d, false, ce, params, off, a.n, p4, mask, st));
+  const InputStage in0{params + off[0], params + off[1]};                 // (rides on the first level's kernel)
+  LGN_TRY(levels_fwd(*d, false, ce, params, off, a.n, p4, mask, st, &in0));
   LGN_TRY(enc_latent_fwd(d->B, d->N, ce[L], d->tau_s, d->tau_v, a.n.s[L], a.n.v[L], params + off[S.out0(false)],
                          params + off[S.out0(false) + 1], lat_s, lat_v, a.idx, st));
   return 0;
@@ -1085,9 +1099,9 @@ int lgn_step_fwd_bwd_f64(const lgn_net_desc* d, const double* params, double* gr
 
   // ---------------- forward ----------------
   // the first kernel also zeroes the gradient buffer (dead parameters keep an exact zero) and zeros_s | g_p | g_lat_s
-  LGN_TRY(enc_input_fwd(B, N, ce[0], p4, params + enc_off[0], params + enc_off[1], w.enc.s[0], w.enc.v[0], st, grads,
-                        (size_t)n_params, w.zeros_s, w.zero_doubles));
-  LGN_TRY(levels_fwd(*d, false, ce, params, enc_off, w.enc, p4, mask, st));
+  // (the encoder's input stage and the two clears ride on the first level's kernel: levels_fwd / InputStage)
+  const InputStage in0{params + enc_off[0], params + enc_off[1], grads, (size_t)n_params, w.zeros_s, w.zero_doubles};
+  LGN_TRY(levels_fwd(*d, false, ce, params, enc_off, w.enc, p4, mask, st, &in0));
   LGN_TRY(junction_fwd(B, N, ce[L], Ts, Tv, w.enc.s[L], w.enc.v[L], params + enc_off[S.out0(false)],
                        params + enc_off[S.out0(false) + 1], w.lat_s, w.lat_v, w.idx, cd[0], params + dec_off[1], params + dec_off[2],
                        params + dec_off[3], w.pdec, w.dec.s[0], w.dec.v[0], st));
