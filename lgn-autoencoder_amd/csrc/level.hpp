@@ -76,6 +76,10 @@ struct LevelBwdArgs {
   // per-workgroup partial sums of parameter gradients, reduced by reduce_partials afterwards
   T* part_mix;   // [nblk_mix][2*2*CO*5C]      wm0 then wm1
   T* part_rad;   // [nblk_edge][rad_partial_size(C, decoder)]
+  // Encoder, first level of a whole-network / whole-step call (N <= 40 kernel only): the backward of the input stage
+  // (input_func_node: dW00[c] = sum_n g_s[n][c] mass_n, dW11[c] = sum_n sum_m g_v[n][c][m] conj(q_n[m]); enc_input_bwd_kernel's
+  // arithmetic) rides on this kernel, one partial row [4C] = (dW00 re, im, dW11 re, im) per workgroup like part_mix.
+  T* part_in0 = nullptr;
 };
 
 // Per-node stride (in scalars) of the node tile kept in LDS: [c][ s_r s_i v_r[4] v_i[4] ] + 2 pad.

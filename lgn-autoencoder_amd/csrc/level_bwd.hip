@@ -437,6 +437,9 @@ static bool use_v3(int N) {   // single-kernel backward (default when the jet fi
   return !(e && e[0] == '1') && level_bwd3_fits(N);
 }
 
+// does the level backward for N-particle jets run as the one kernel that can carry the input stage's backward (LevelBwdArgs::part_in0)?
+bool level_bwd_carries_input(int N) { return use_v3(N); }
+
 // number of partial rows the backward launch writes (host side must size the workspace with these)
 void level_bwd_partial_rows(int B, int N, int decoder, int* rows_mix, int* rows_rad) {
   const int tiles = cdiv(N, 32);

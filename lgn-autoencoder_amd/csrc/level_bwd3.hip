@@ -570,6 +570,9 @@ __global__ __launch_bounds__(64 * NWV) void level_bwd3_kernel(LevelBwdArgs<doubl
     for (int t = 0; t < 3; ++t) T[g][t] = v4d{0, 0, 0, 0};
   }
   const size_t pls = (size_t)B * N * C;
+  double in0[NG][4];                                     // input-stage weight-gradient terms of this lane's nodes (LevelBwdArgs::part_in0)
+#pragma unroll
+  for (int g = 0; g < NG; ++g) in0[g][0] = in0[g][1] = in0[g][2] = in0[g][3] = 0.0;
   for (int rg = glo + wave; rg < ghi; rg += NWV) {
     const int j = rg * 4 + tj;
     const bool jok = j < N;
@@ -768,16 +771,35 @@ __global__ __launch_bounds__(64 * NWV) void level_bwd3_kernel(LevelBwdArgs<doubl
       const bool wr = jok && ti == 0 && ch < C;
       const size_t e = ((size_t)b * N + jj) * C + (ch < C ? ch : 0);
       const double* gdn = gd + (jj * C + (ch < C ? ch : 0)) * 10;
+      const double gsr = gdn[0] + sr, gsi = gdn[1] + si;
       if (wr) {
-        a.g_s_in[e] = gdn[0] + sr;
-        a.g_s_in[pls + e] = gdn[1] + si;
+        a.g_s_in[e] = gsr;
+        a.g_s_in[pls + e] = gsi;
       }
+      cx<double> gvn[4];
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
         const double vr = quad_sum(Gv[g][m].r), vi = quad_sum(Gv[g][m].i);
+        gvn[m] = {gdn[2 + m] + vr, gdn[6 + m] + vi};
         if (wr) {
-          a.g_v_in[e * 4 + m] = gdn[2 + m] + vr;
-          a.g_v_in[pls * 4 + e * 4 + m] = gdn[6 + m] + vi;
+          a.g_v_in[e * 4 + m] = gvn[m].r;
+          a.g_v_in[pls * 4 + e * 4 + m] = gvn[m].i;
+        }
+      }
+      if constexpr (!DEC) {
+        if (a.part_in0 && wr) {                              // (wave-uniform pointer test; the terms of node jj, channel ch)
+          // 2 E^2 - sum p^2 left to right, canonical momenta: the arithmetic of enc_input_bwd_kernel (net_kernels.hip)
+          const double q0 = pme[0] * pme[0], q1 = pme[1] * pme[1], q2 = pme[2] * pme[2], q3 = pme[3] * pme[3];
+          const double mass = sqrt(fabs(2.0 * q0 - (((q0 + q1) + q2) + q3)));
+          constexpr double H = 0.70710678118654752440084436210484903928;
+          const cx<double> q[4] = {{pme[0], 0.0}, {pme[1] * H, -pme[2] * H}, {pme[3], 0.0}, {-pme[1] * H, -pme[2] * H}};
+          cx<double> d1 = {0, 0};
+#pragma unroll
+          for (int m = 0; m < 4; ++m) cfmac(d1, gvn[m], q[m]);
+          in0[g][0] += gsr * mass;
+          in0[g][1] += gsi * mass;
+          in0[g][2] += d1.r;
+          in0[g][3] += d1.i;
         }
       }
     }
@@ -846,10 +868,35 @@ __global__ __launch_bounds__(64 * NWV) void level_bwd3_kernel(LevelBwdArgs<doubl
     }
   }
 
+  // ---------------- input-stage partial row (first encoder level of a fused network) -----------------------------
+  __shared__ double in0l[NWV][8][4];
+  if constexpr (!DEC) {
+    if (a.part_in0) {
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          double x = in0[g][k];                              // non-zero on the lanes (ti == 0, tj = pr >> 2) only: sum over the 4 nodes of a group
+          x += shfl_xor(x, 4);
+          x += shfl_xor(x, 8);
+          if (pr == 0 && 4 * g + cg < C) in0l[wave][4 * g + cg][k] = x;
+        }
+    }
+  }
+
   // ---------------- radial partial row of this jet ------------------------------------------------------------
   STAMP(8);
   __syncthreads();
   STAMP(9);
+  if constexpr (!DEC) {
+    if (a.part_in0 && tid < 4 * C) {
+      const int k = tid / C, c = tid - k * C;
+      double s = 0;
+#pragma unroll
+      for (int w = 0; w < NWV; ++w) s += in0l[w][c][k];
+      a.part_in0[prow * 4 * C + k * C + c] = s;
+    }
+  }
   double* part = a.part_rad + prow * rad_partial_size(C, DEC);
   if (DEC) {
     double* red = tr;

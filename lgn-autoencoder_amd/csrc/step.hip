@@ -248,9 +248,12 @@ int levels_fwd(const lgn_net_desc& d, bool dec, const int* ch, const double* P, 
 // backward of one network's level stack.  On entry gs[cur]/gv[cur] hold the gradient w.r.t. (s[L], v[L]);
 // has_s_grad says whether gs is non-zero (false for both networks of the autoencoder: the last level's
 // scalars never reach the loss).  On exit gs[cur]/gv[cur] hold the gradient w.r.t. level 0.
+// in0_grads (encoder only, optional): gradient slots of input_func_node's two weights.  When the first level's backward is the
+// one-kernel form, the input stage's backward rides on it (LevelBwdArgs::part_in0) and *in0_done is set; otherwise the caller
+// launches enc_input_bwd.
 int levels_bwd(const lgn_net_desc& d, bool dec, const int* ch, const double* P, double* G, const int64_t* off, const NetBuf& n,
                const double* pos, const uint8_t* mask, Work& w, Deferred& dq, RadFinJob& fin, int& cur, bool has_s_grad,
-               hipStream_t st, bool fork_last = false) {
+               hipStream_t st, bool fork_last = false, double* const* in0_grads = nullptr, bool* in0_done = nullptr) {
   const Slots S{d.n_levels, d.mlp_nlin};
   const int BN = d.B * d.N;
   for (int l = d.n_levels - 1; l >= 0; --l) {
@@ -281,7 +284,14 @@ int levels_bwd(const lgn_net_desc& d, bool dec, const int* ch, const double* P, 
                            p(S.rad(dec, l, 0)), p(S.rad(dec, l, 1)), p(S.rad(dec, l, 2)), p(S.rad(dec, l, 3)), p(S.rad(dec, l, 4)),
                            p(S.rad(dec, l, 5)), p(S.rad(dec, l, 6)), p(S.mix(dec, l, 0)), p(S.mix(dec, l, 1)), n.ag0[l], n.ag1[l],
                            g_smix, w.gv[cur], w.g_ag, w.gs[nxt], w.gv[nxt], dec ? w.g_p : nullptr, part_mix, part_rad};
+    const bool carry_in0 = !dec && l == 0 && in0_grads && level_bwd_carries_input(d.N);
+    if (carry_in0) { DQ_TAKE(a.part_in0, (size_t)rm * 4 * C); }
     LGN_TRY(level_bwd_dispatch<double>(a, dec, st));
+    if (carry_in0) {
+      dq.add(a.part_in0, rm, 4 * C, 0, 2 * C, in0_grads[0]);
+      dq.add(a.part_in0, rm, 4 * C, 2 * C, 2 * C, in0_grads[1]);
+      *in0_done = true;
+    }
     // deferred reductions: CatMix weights (partial row = [wm0 | wm1]) + radial sums
     dq.add(part_mix, rm, nmix, 0, nmix / 2, g(S.mix(dec, l, 0)));
     dq.add(part_mix, rm, nmix, nmix / 2, nmix / 2, g(S.mix(dec, l, 1)));
@@ -849,7 +859,12 @@ NetScratch carve_scratch(const lgn_net_desc& d, bool dec, double* base) {
   // input / output ends: decoder  B x (2 C_L) + B x (4 C_0 + 2 N Tin);  encoder  B x 2 (Ts + Tv) C_L + B x 4 C_0
   const int Tin = d.tau_v_in > 0 ? d.tau_v_in : 2 * Tv;
   if (dec) psum += (((size_t)d.B * 2 * ch[L] + 15) & ~size_t(15)) + (((size_t)d.B * (4 * ch[0] + 2 * (size_t)d.N * Tin) + 15) & ~size_t(15));
-  else psum += (((size_t)d.B * 2 * (Ts + Tv) * ch[L] + 15) & ~size_t(15)) + (((size_t)d.B * 4 * ch[0] + 15) & ~size_t(15));
+  else {
+    int rm0, rr0;                                          // input-stage partial rows: one per workgroup of the first level's backward
+    level_bwd_partial_rows(d.B, d.N, 0, &rm0, &rr0);
+    if (rm0 < d.B) rm0 = d.B;
+    psum += (((size_t)d.B * 2 * (Ts + Tv) * ch[L] + 15) & ~size_t(15)) + (((size_t)rm0 * 4 * ch[0] + 15) & ~size_t(15));
+  }
   w.parts = b.take(psum);
   w.parts_size = psum;
   s.total = b.off;
@@ -935,8 +950,11 @@ int lgn_encoder_bwd_f64(const lgn_net_desc* d, const double* params, double* gra
     dq.add(parte, B, rowe, 2 * Ts * CL, 2 * Tv * CL, grads + off[S.out0(false) + 1]);
   }
   // without an upstream gradient on the latent scalars the last level's scalars (and its CGMLP) receive none
-  LGN_TRY(levels_bwd(*d, false, ce, params, grads, off, a.n, p4, mask, w, dq, fin, cur, /*has_s_grad=*/g_lat_s != nullptr, st));
-  {
+  double* const in0_grads[2] = {grads + off[0], grads + off[1]};
+  bool in0_done = false;
+  LGN_TRY(levels_bwd(*d, false, ce, params, grads, off, a.n, p4, mask, w, dq, fin, cur, /*has_s_grad=*/g_lat_s != nullptr, st, false,
+                     in0_grads, &in0_done));
+  if (!in0_done) {
     const int C0 = ce[0];
     DQ_NEW(part, (size_t)B * 4 * C0);
     LGN_TRY(enc_input_bwd(B, N, C0, p4, w.gs[cur], w.gv[cur], part, st));
@@ -1134,8 +1152,11 @@ int lgn_step_fwd_bwd_f64(const lgn_net_desc* d, const double* params, double* gr
     dq.add(parte, B, rowe, 0, 2 * Ts * CL, grads + enc_off[S.out0(false)]);
     dq.add(parte, B, rowe, 2 * Ts * CL, 2 * Tv * CL, grads + enc_off[S.out0(false) + 1]);
   }
-  LGN_TRY(levels_bwd(*d, false, ce, params, grads, enc_off, w.enc, p4, mask, w, dq, fin, cur, /*has_s_grad=*/false, st));
-  {
+  double* const in0_grads[2] = {grads + enc_off[0], grads + enc_off[1]};
+  bool in0_done = false;
+  LGN_TRY(levels_bwd(*d, false, ce, params, grads, enc_off, w.enc, p4, mask, w, dq, fin, cur, /*has_s_grad=*/false, st, false, in0_grads,
+                     &in0_done));
+  if (!in0_done) {      // (three-kernel level backward: N > 40, LGN_AMD_LEVEL_V2)
     const int C0 = ce[0];
     DQ_NEW(part, (size_t)B * 4 * C0);
     LGN_TRY(enc_input_bwd(B, N, C0, p4, w.gs[cur], w.gv[cur], part, st));
