@@ -54,6 +54,16 @@ struct LevelArgs {
   size_t z1n = 0;
   T* z2 = nullptr;
   size_t z2n = 0;
+  // Decoder, last level of a whole-step call (loss_wo1 != nullptr; separable form, N <= 40: level_fwd_carries_loss): the decoder
+  // output + get_real('sum') + Chamfer loss of the jet, forward and backward (net_dev.hpp: dec_output_loss_body), run as the tail
+  // of this kernel on the v_out it has just written.
+  const T* loss_wo1 = nullptr;     // mix_to_output weights of (1,1): [2][CO]
+  const T* loss_target = nullptr;  // [B][N][4]
+  T loss_scale = T(1);
+  T* loss_recon = nullptr;         // [2][B][N][4]
+  T* loss_part = nullptr;          // [B]
+  T* loss_gv = nullptr;            // [2][B][N][CO][4] gradient w.r.t. v_out
+  T* loss_wpart = nullptr;         // [B][2 CO]
 };
 
 template <typename T>

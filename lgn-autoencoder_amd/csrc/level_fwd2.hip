@@ -17,6 +17,7 @@
 //  * the aggregate of the whole jet is collected in LDS; after one barrier all 256 threads write it out (it is saved
 //    for the backward) and run CatMix over the items (row, out channel, component).
 #include "level_dev.hpp"
+#include "net_dev.hpp"
 #include "ops.hpp"
 #include "wave_sum.hpp"
 
@@ -525,6 +526,13 @@ __global__ __launch_bounds__(2 * BLOCK) void level_fwd2_kernel(LevelArgs<double>
   if (c1 < rhi) __syncthreads();                         // the chunk's aggregate rows are reused
   }
   STAMP(40);
+  if constexpr (DEC) {
+    if (a.loss_wo1) {      // (one workgroup of BLOCK threads per jet: checked on the host)
+      __syncthreads();     // this jet's v_out is complete and visible to the workgroup; the level's LDS is free
+      dec_output_loss_body(B, N, CO, a.v_out, a.loss_wo1, a.loss_target, a.loss_scale, a.loss_recon, a.loss_part, a.loss_gv,
+                           a.loss_wpart, smem_raw);
+    }
+  }
 }
 
 template <int C, bool DEC, bool SEP>
@@ -544,7 +552,12 @@ static int launch_level_fwd2(const LevelArgs<double>& a, hipStream_t stream) {
     if (chunk > full) chunk = full;
     if (chunk < 16) chunk = 16;
   }
-  const size_t smem = fixed + chunk * row;
+  size_t smem = fixed + chunk * row;
+  if (a.loss_wo1) {
+    LGN_CHECK_ARG(DEC && SEP && a.N <= 40 && !wide && a.loss_target && a.loss_recon && a.loss_part && a.loss_gv && a.loss_wpart,
+                  "level_fwd: the loss rides on the separable decoder forward of jets of <= 40 particles only");
+    if (smem < dec_out_loss_bytes(a.N, a.CO)) smem = dec_out_loss_bytes(a.N, a.CO);
+  }
   LGN_CHECK_ARG(smem <= 160 * 1024, "level_fwd: N=%d C=%d needs %zu B of LDS (> 160 KiB)", a.N, a.C, smem);
   auto kern = level_fwd2_kernel<C, DEC, SEP>;
   if (smem > 64 * 1024) {
@@ -558,6 +571,11 @@ static int launch_level_fwd2(const LevelArgs<double>& a, hipStream_t stream) {
   hipLaunchKernelGGL(kern, dim3(a.B, split), dim3(nthreads), smem, stream, a, chunk);
   LGN_CHECK_LAUNCH();
   return 0;
+}
+
+bool level_fwd_carries_loss(int N) {
+  const char* pw_env = getenv("LGN_AMD_DEC_PAIRWISE");
+  return N <= 40 && !(pw_env && pw_env[0] == '1');
 }
 
 template <>

@@ -30,7 +30,8 @@ struct RadFinJob {
 };
 int rad_finalize_batch(const RadFinJob& job, hipStream_t);
 void level_bwd_partial_rows(int B, int N, int decoder, int* rows_mix, int* rows_rad);
-bool level_bwd_carries_input(int N);   // the encoder's first level may take LevelBwdArgs::part_in0 (one-kernel backward, N <= 40)
+bool level_bwd_carries_input(int N);
+bool level_fwd_carries_loss(int N);    // the decoder's last level may take LevelArgs::loss_* (separable one-workgroup-per-jet forward)   // the encoder's first level may take LevelBwdArgs::part_in0 (one-kernel backward, N <= 40)
 
 // ---- CGMLP (mlp.hip / mlp_mfma.hip) ------------------------------------------------------------------
 constexpr int MLP_MAX_LIN = 8;

@@ -219,10 +219,16 @@ struct InputStage {
   double* z2 = nullptr;
   size_t z2n = 0;
 };
+// The decoder output + Chamfer loss (forward and backward) rides on the decoder's last level forward (LevelArgs::loss_wo1).
+struct LossStage {
+  const double *wo1, *target;
+  double scale;
+  double *recon, *loss_part, *g_v, *wpart;
+};
 
 // forward of one network's level stack; returns via buffers
 int levels_fwd(const lgn_net_desc& d, bool dec, const int* ch, const double* P, const int64_t* off, NetBuf& n, const double* pos,
-               const uint8_t* mask, hipStream_t st, const InputStage* in0 = nullptr) {
+               const uint8_t* mask, hipStream_t st, const InputStage* in0 = nullptr, const LossStage* loss = nullptr) {
   const Slots S{d.n_levels, d.mlp_nlin};
   for (int l = 0; l < d.n_levels; ++l) {
     auto p = [&](int slot) { return P + off[slot]; };
@@ -233,6 +239,10 @@ int levels_fwd(const lgn_net_desc& d, bool dec, const int* ch, const double* P, 
     if (l == 0 && !dec && in0) {
       a.in_w0 = in0->w0; a.in_w1 = in0->w1; a.in_s = n.s[0]; a.in_v = n.v[0];
       a.z1 = in0->z1; a.z1n = in0->z1n; a.z2 = in0->z2; a.z2n = in0->z2n;
+    }
+    if (l + 1 == d.n_levels && dec && loss) {
+      a.loss_wo1 = loss->wo1; a.loss_target = loss->target; a.loss_scale = loss->scale; a.loss_recon = loss->recon;
+      a.loss_part = loss->loss_part; a.loss_gv = loss->g_v; a.loss_wpart = loss->wpart;
     }
     LGN_TRY(level_fwd_dispatch<double>(a, dec, st));
     MlpArgs<double> m{};
@@ -1123,15 +1133,19 @@ int lgn_step_fwd_bwd_f64(const lgn_net_desc* d, const double* params, double* gr
   LGN_TRY(junction_fwd(B, N, ce[L], Ts, Tv, w.enc.s[L], w.enc.v[L], params + enc_off[S.out0(false)],
                        params + enc_off[S.out0(false) + 1], w.lat_s, w.lat_v, w.idx, cd[0], params + dec_off[1], params + dec_off[2],
                        params + dec_off[3], w.pdec, w.dec.s[0], w.dec.v[0], st));
-  LGN_TRY(levels_fwd(*d, true, cd, params, dec_off, w.dec, w.pdec, nullptr, st));
-
-  // ---------------- loss + backward ----------------
+  // ---------------- loss (and its backward), on the last decoder level's kernel when that is one workgroup per jet ----------
   int cur = 0;
   {
     DQ_NEW(part, (size_t)B * 2 * cd[L]);
-    LGN_TRY(dec_output_loss(B, N, cd[L], w.dec.v[L], params + dec_off[S.out0(true) + 1], target, 1.0, recon, loss_part, w.gv[cur], part, st));
+    const LossStage ls{params + dec_off[S.out0(true) + 1], target, 1.0, recon, loss_part, w.gv[cur], part};
+    const bool rides = level_fwd_carries_loss(N);
+    LGN_TRY(levels_fwd(*d, true, cd, params, dec_off, w.dec, w.pdec, nullptr, st, nullptr, rides ? &ls : nullptr));
+    if (!rides)
+      LGN_TRY(dec_output_loss(B, N, cd[L], w.dec.v[L], ls.wo1, target, 1.0, recon, loss_part, w.gv[cur], part, st));
     dq.add(part, B, 2 * cd[L], 0, 2 * cd[L], grads + dec_off[S.out0(true) + 1]);
   }
+
+  // ---------------- backward ----------------
   LGN_TRY(levels_bwd(*d, true, cd, params, grads, dec_off, w.dec, w.pdec, nullptr, w, dq, fin, cur, /*has_s_grad=*/false, st,
                      /*fork_last=*/true));
   {
