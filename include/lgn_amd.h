@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LGN_AMD_ABI_VERSION 10   /* bump on ANY struct or signature change (lgn/_native.py: ABI_VERSION) */
+#define LGN_AMD_ABI_VERSION 11   /* bump on ANY struct or signature change (lgn/_native.py: ABI_VERSION) */
 
 int lgn_abi_version(void);
 const char* lgn_last_error(void);
@@ -75,6 +75,35 @@ int lgn_level_bwd_f64(int B, int N, int C, int CO, int decoder,
                       const double* g_s_out, const double* g_v_out,
                       double* g_ag, double* g_s_in, double* g_v_in, double* g_p,
                       double* part_mix, double* part_rad, void* stream);
+
+/* ---- level + its CGMLP in one launch per direction -----------------------------------------------
+ * LGNNodeLevel followed by CGMLP on the level's scalars, the pair of lgn/models/lgn_cg.py:164-172.  For jets of up to 40
+ * particles, C <= 4, hidden width H <= 48, 7 Linear layers and LeakyReLU (lgn_level_mlp_fused says so) the CGMLP is a phase
+ * of the level kernel: the forward's tail, the backward's head (csrc/mlp_dev.hpp).  Every other shape runs the level and the
+ * CGMLP launches back to back behind the same call -- same results.
+ *  mlp_params: the CGMLP's parameters as ONE block (linear.0.weight, linear.0.bias, linear.1.weight, ...), nn.Linear layouts.
+ *  forward : s_pre [2][B][N][CO] = scalars before the MLP (kept for the backward), s_out = after it.
+ *  backward: g_s_out = gradient w.r.t. s_out; part_mlp [lgn_level_mlp_partial_rows][psize] (psize = the block's length,
+ *            block layout), mlp_scratch [2][B][N][CO] (used by the unfused shapes only; may be NULL when fused);
+ *            everything else as lgn_level_bwd_f64. */
+int lgn_level_mlp_fused(int N, int C, int CO, int H, int nlin, int activation, int decoder);
+int lgn_level_mlp_partial_rows(int B, int N, int C, int CO, int H, int nlin, int activation, int decoder);
+int lgn_level_mlp_fwd_f64(int B, int N, int C, int CO, int decoder,
+                          const double* s_in, const double* v_in, const double* p, const uint8_t* mask,
+                          const double* ra, const double* rb, const double* rc,
+                          const double* w0, const double* b0, const double* w1, const double* b1,
+                          const double* wm0, const double* wm1,
+                          const double* mlp_params, int H, int nlin, int activation,
+                          double* ag0, double* ag1, double* s_pre, double* s_out, double* v_out, void* stream);
+int lgn_level_mlp_bwd_f64(int B, int N, int C, int CO, int decoder,
+                          const double* s_in, const double* v_in, const double* p, const uint8_t* mask,
+                          const double* ra, const double* rb, const double* rc,
+                          const double* w0, const double* b0, const double* w1, const double* b1,
+                          const double* wm0, const double* wm1, const double* ag0, const double* ag1,
+                          const double* mlp_params, int H, int nlin, int activation, const double* s_pre,
+                          const double* g_s_out, const double* g_v_out,
+                          double* g_ag, double* g_s_in, double* g_v_in, double* g_p,
+                          double* part_mix, double* part_rad, double* part_mlp, double* mlp_scratch, void* stream);
 
 /* out[n] = (accumulate ? out[n] : 0) + sum_r part[r][n], fixed summation order. */
 int lgn_reduce_partials_f64(const double* part, int rows, int n, double* out, int accumulate, void* stream);
@@ -218,6 +247,13 @@ typedef struct lgn_net_desc {
 } lgn_net_desc;
 #define LGN_NET_NO_STATIC 1   /* table-driven levels: run-time-table kernels + node-major features (cross-check of the
                                  compile-time-table kernels; lgn/_native.py sets it from LGN_AMD_NO_STATIC at creation) */
+/* kernel-selecting cross-check switches, frozen the same way (lgn/_native.py: net_flags; the partial-row counts, whether the loss
+ * rides on the last decoder level, whether the CGMLPs ride on the level kernels all follow from them -- a forward, its backward
+ * and the workspace sizing can never disagree): */
+#define LGN_NET_DEC_PAIRWISE 2   /* LGN_AMD_DEC_PAIRWISE=1: decoder levels as O(N^2) pair sweeps instead of the separable form */
+#define LGN_NET_LEVEL_V2 4       /* LGN_AMD_LEVEL_V2=1: three-kernel level backward also for N <= 40 */
+#define LGN_NET_NO_FUSED_MLP 8   /* LGN_AMD_NO_FUSED_MLP=1: every CGMLP as its own launches */
+#define LGN_NET_MOMENTS_V1 16    /* LGN_AMD_MOMENTS_V1=1: component-chunked moments kernels (with LGN_NET_NO_STATIC) */
 
 int lgn_step_param_slots(const lgn_net_desc* d, int decoder);
 long long lgn_step_workspace_doubles(const lgn_net_desc* d);

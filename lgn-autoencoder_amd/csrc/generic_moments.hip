@@ -604,8 +604,7 @@ int moments2_dispatch(const GenArgs& a, int decoder, int which, double* Gbuf, hi
 int moments_dispatch(const GenArgs& a, int decoder, int which, hipStream_t st) {
   LGN_CHECK_ARG(a.B > 0 && a.N > 0 && a.Q > 0, "moments: empty input (B=%d N=%d Q=%d)", a.B, a.N, a.Q);
   {
-    const char* e = getenv("LGN_AMD_MOMENTS_V1");
-    const bool v1 = e && e[0] == '1';
+    const bool v1 = (a.flags & LVL_MOMENTS_V1) != 0;
     if (!v1 && moments2_fits(a, decoder) && (decoder || which != 2 || a.gbuf)) return moments2_dispatch(a, decoder, which, a.gbuf, st);
   }
   LGN_CHECK_ARG(!a.tb, "moments: the tile-blocked layout is implemented by the channel-outermost kernels only (N <= 32)");

@@ -877,8 +877,7 @@ int moments2_dispatch(const GenArgs& a, int decoder, int which, double* Gbuf, hi
   LGN_CHECK_ARG(a.B > 0 && a.N > 0 && a.Q > 0, "moments: empty input (B=%d N=%d Q=%d)", a.B, a.N, a.Q);
   LGN_CHECK_ARG(a.C >= 1 && a.C <= 8, "moments: C=%d unsupported (1..8)", a.C);
   if (decoder) {
-    const char* pw = getenv("LGN_AMD_DEC_PAIRWISE");         // =1: O(N^2) pair sweeps (cross-check of the separable form)
-    if (pw && pw[0] == '1') return m2::launch<true>(a, which, nullptr, st);
+    if (a.flags & LVL_DEC_PAIRWISE) return m2::launch<true>(a, which, nullptr, st);   // O(N^2) pair sweeps (cross-check of the separable form)
     if (which == 2) return 0;                               // the separable backward does both passes in one launch
     if (const int rc = moments_dec_sep_tb_dispatch(a, which, st); rc != -2) return rc;      // tile-blocked layouts: generic_moments_sep.hip
     const size_t base = sizeof(double) * ((size_t)a.N * 8 + (size_t)a.N * a.Q * 2);

@@ -426,31 +426,29 @@ int level_bwd_rad2_dispatch(const LevelBwdArgs<double>& a, hipStream_t stream);
 
 int level_bwd3_dispatch(const LevelBwdArgs<double>& a, int decoder, hipStream_t stream);         // level_bwd3.hip
 int level_bwd_dec_sep_dispatch(const LevelBwdArgs<double>& a, hipStream_t stream);               // level_bwd_dec_sep.hip
-static bool dec_pairwise() {   // LGN_AMD_DEC_PAIRWISE=1 keeps the decoder on the O(N^2) pair sweeps (read per call: tests flip it)
-  const char* e = getenv("LGN_AMD_DEC_PAIRWISE");
-  return e && e[0] == '1';
-}
+static bool dec_pairwise(int flags) { return (flags & LVL_DEC_PAIRWISE) != 0; }   // the decoder on the O(N^2) pair sweeps
 bool level_bwd3_fits(int N);
 
-static bool use_v3(int N) {   // single-kernel backward (default when the jet fits in LDS); LGN_AMD_LEVEL_V2=1 forces the 3-kernel
-  const char* e = getenv("LGN_AMD_LEVEL_V2");   // form also for small N (read per call: the parity tests flip it)
-  return !(e && e[0] == '1') && level_bwd3_fits(N);
-}
+// single-kernel backward (default when the jet fits in LDS); LVL_LEVEL_V2 forces the 3-kernel form also for small N
+static bool use_v3(int N, int flags) { return !(flags & LVL_LEVEL_V2) && level_bwd3_fits(N); }
 
 // does the level backward for N-particle jets run as the one kernel that can carry the input stage's backward (LevelBwdArgs::part_in0)?
-bool level_bwd_carries_input(int N) { return use_v3(N); }
+bool level_bwd_carries_input(int N, int flags) { return use_v3(N, flags); }
+bool level_bwd_fuses_mlp(int N, int C, int CO, int H, int nlin, int act, int decoder, int flags) {
+  return use_v3(N, flags) && level_mlp_fusable(N, C, CO, H, nlin, act) && !(flags & LVL_NO_FUSED_MLP) && !(decoder && dec_pairwise(flags));
+}
 
 // number of partial rows the backward launch writes (host side must size the workspace with these)
-void level_bwd_partial_rows(int B, int N, int decoder, int* rows_mix, int* rows_rad) {
+void level_bwd_partial_rows(int B, int N, int decoder, int flags, int* rows_mix, int* rows_rad) {
   const int tiles = cdiv(N, 32);
-  if (use_v3(N)) {                       // level_bwd3: one partial row per workgroup for both (small batches: several per jet)
-    const int split = (decoder && !dec_pairwise()) ? 1 : level_jet_split(B, N);
+  if (use_v3(N, flags)) {                // level_bwd3: one partial row per workgroup for both (small batches: several per jet)
+    const int split = (decoder && !dec_pairwise(flags)) ? 1 : level_jet_split(B, N);
     *rows_mix = B * split;
     *rows_rad = B * split;
     return;
   }
   *rows_mix = B * tiles;
-  if (decoder && dec_pairwise()) {
+  if (decoder && dec_pairwise(flags)) {
     *rows_rad = B * tiles;               // level_bwd_rad_dec: one partial row per 32-node tile
   } else {
     *rows_rad = B;                       // separable decoder backward / level_bwd_rad2: one partial row per jet
@@ -462,7 +460,8 @@ static int launch_level_bwd(const LevelBwdArgs<T>& a, hipStream_t stream) {
   using L = Carve<C, DEC>;
   const int N = a.N, CO = a.CO, tiles = cdiv(N, 32);
   int rc;
-  if (use_v3(N)) return level_bwd3_dispatch(a, DEC, stream);
+  if (use_v3(N, a.flags)) return level_bwd3_dispatch(a, DEC, stream);
+  LGN_CHECK_ARG(!a.mlp.wb, "level_bwd: the CGMLP rides on the one-kernel backward only");
   {  // 1. CatMix / power
     auto kern = level_bwd_mix_kernel<T, C>;
     size_t smem = sizeof(T) * (4 * CO * 5 * C + 32 * (5 * C * 10) + 32 * CO * 10);
@@ -471,7 +470,7 @@ static int launch_level_bwd(const LevelBwdArgs<T>& a, hipStream_t stream) {
     LGN_CHECK_LAUNCH();
   }
   if constexpr (DEC && std::is_same<T, double>::value) {
-    if (!dec_pairwise()) return level_bwd_dec_sep_dispatch(a, stream);   // 2+3. from jet-level sums, O(N C)
+    if (!dec_pairwise(a.flags)) return level_bwd_dec_sep_dispatch(a, stream);   // 2+3. from jet-level sums, O(N C)
   }
   if ((rc = level_bwd_nodes2_dispatch(a, DEC, stream))) return rc;        // 2. j-centric pass
   if (DEC) {  // 3b

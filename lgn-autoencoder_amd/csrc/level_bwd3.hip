@@ -11,6 +11,7 @@
 //            16x16 LDS transposes -> T1|T2|S|dB GEMM on the matrix cores; decoder: bias sums and d p_j
 //   phase 3  decoder only: i-centric sweep for d p_i
 #include "level_dev.hpp"
+#include "mlp_dev.hpp"
 #include "ops.hpp"
 #include "wave_sum.hpp"
 
@@ -87,8 +88,10 @@ struct Bwd3 {
 //   stage 1   per (node, channel): the node's terms of S, VS, SP, VP (forward) and of the sums of g_ag (backward)
 //   stage 2   per (channel, term): sum over the nodes in node order
 //   outputs   node gradient, position gradient and bias gradients from O(N C) closed forms.
+// gsx_off (with a.mlp.wb): offset in doubles of the [N][2 CO] block that receives the CGMLP phase's result -- the level's upstream
+// scalar gradient -- behind both the level's LDS and the phase's (mlp_dev.hpp: bwd_doubles).
 template <int C, bool DEC, bool SEP, int NWV>
-__global__ __launch_bounds__(64 * NWV) void level_bwd3_kernel(LevelBwdArgs<double> a) {
+__global__ __launch_bounds__(64 * NWV) void level_bwd3_kernel(LevelBwdArgs<double> a, int gsx_off) {
   using F = Bwd3<C, DEC, NWV>;
   constexpr int BLK = F::BLK;
   using G = GA3<C>;
@@ -111,7 +114,18 @@ __global__ __launch_bounds__(64 * NWV) void level_bwd3_kernel(LevelBwdArgs<doubl
   double* wm = go + N * 10 * CO;                               //              4 * CO * K CatMix weights
   double* agl = wm + 4 * CO * K;                               //              N * 2C * 10 aggregate [n][q*C+c][s2|v8]
   double* sm = tr + F::scratch(N, CO);                         // decoder: 50 C jet-level sums
-  uint8_t* mk = reinterpret_cast<uint8_t*>(sm + F::SEPSZ);
+  // the CGMLP's backward as the head of this kernel (mlp_dev.hpp): its LDS aliases everything above, its result stays in gsx
+  constexpr bool MLP_OK = C <= 4 && (!DEC || SEP) && NWV == 4;
+  const bool has_mlp = MLP_OK && a.mlp.wb != nullptr;
+  double* gsx = reinterpret_cast<double*>(smem_raw) + gsx_off;  // [N][2 CO], feature k = 2o + z
+  uint8_t* mk = has_mlp ? reinterpret_cast<uint8_t*>(gsx + ((N * 2 * CO + 1) & ~1)) : reinterpret_cast<uint8_t*>(sm + F::SEPSZ);
+  __shared__ int fm_ids[4];
+  if constexpr (MLP_OK) {
+    if (has_mlp) {
+      const fm::BwdIo io{a.mlp.wb, a.mlp.s_pre, a.mlp.g_out, a.mlp.part, B, N, CO, a.mlp.H, b, 0, (int)blockIdx.y, (int)gridDim.y};
+      fm::bwd_phase<false>(io, reinterpret_cast<double*>(smem_raw), fm_ids, gsx);       // (LeakyReLU: level_mlp_fusable)
+    }
+  }
 
   // ---------------- staging ----------------------------------------------------------------------------
   STAMP(0);
@@ -124,8 +138,13 @@ __global__ __launch_bounds__(64 * NWV) void level_bwd3_kernel(LevelBwdArgs<doubl
     const int eg = tid < N * CO ? tid : 0, ea_ = tid < N * 2 * C ? tid : 0, ew = tid < 2 * CO * K ? tid : 0;
     const size_t ig = (size_t)b * N * CO + eg, ia = (size_t)b * N * 2 * C + ea_;
     double rg[10], ra[10];
-    rg[0] = a.g_s_out[ig];
-    rg[1] = a.g_s_out[plo + ig];
+    if (has_mlp) {                                             // gsx[n][2o + z] = gsx[2 (n CO + o) + z]
+      rg[0] = gsx[2 * eg];
+      rg[1] = gsx[2 * eg + 1];
+    } else {
+      rg[0] = a.g_s_out[ig];
+      rg[1] = a.g_s_out[plo + ig];
+    }
     ra[0] = a.ag0[ia];
     ra[1] = a.ag0[pa + ia];
 #pragma unroll
@@ -157,8 +176,8 @@ __global__ __launch_bounds__(64 * NWV) void level_bwd3_kernel(LevelBwdArgs<doubl
     for (int e = tid + BLK; e < N * CO; e += BLK) {
       const size_t idx = (size_t)b * N * CO + e;
       double* g = go + e * 10;
-      g[0] = a.g_s_out[idx];
-      g[1] = a.g_s_out[plo + idx];
+      g[0] = has_mlp ? gsx[2 * e] : a.g_s_out[idx];
+      g[1] = has_mlp ? gsx[2 * e + 1] : a.g_s_out[plo + idx];
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
         g[2 + m] = a.g_v_out[idx * 4 + m];
@@ -965,12 +984,23 @@ bool level_bwd3_fits(int N) { return N <= 40; }
 
 template <int C, bool DEC, bool SEP, int NWV>
 static int launch_bwd3_w(const LevelBwdArgs<double>& a, int split, hipStream_t stream) {
-  const size_t smem = Bwd3<C, DEC, NWV>::smem(a.N, a.CO);
+  size_t smem = Bwd3<C, DEC, NWV>::smem(a.N, a.CO);
+  int gsx_off = 0;
+  if (a.mlp.wb) {
+    constexpr bool MLP_OK = C <= 4 && (!DEC || SEP) && NWV == 4;
+    LGN_CHECK_ARG(MLP_OK && level_mlp_fusable(a.N, C, a.CO, a.mlp.H, 7, a.mlp.act) && a.mlp.s_pre && a.mlp.g_out && a.mlp.part,
+                  "level_bwd: the CGMLP does not ride on this shape (N=%d C=%d CO=%d H=%d)", a.N, C, a.CO, a.mlp.H);
+    // [level data | ...] with the node mask (N bytes) last: the gradient block goes in front of the mask, behind both layouts
+    size_t lvl = (smem - a.N - 16) / sizeof(double);
+    if (lvl < (size_t)fm::bwd_doubles()) lvl = fm::bwd_doubles();
+    gsx_off = (int)((lvl + 1) & ~size_t(1));
+    smem = sizeof(double) * ((size_t)gsx_off + (((size_t)a.N * 2 * a.CO + 1) & ~size_t(1))) + a.N + 16;
+  }
   LGN_CHECK_ARG(smem <= 160 * 1024, "level_bwd: N=%d C=%d needs %zu B of LDS", a.N, a.C, smem);
   LGN_CHECK_ARG(a.CO <= 8, "level_bwd: C_out=%d unsupported (1..8)", a.CO);
   auto kern = level_bwd3_kernel<C, DEC, SEP, NWV>;
   if (smem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  hipLaunchKernelGGL(kern, dim3(a.B, split), dim3(64 * NWV), smem, stream, a);
+  hipLaunchKernelGGL(kern, dim3(a.B, split), dim3(64 * NWV), smem, stream, a, gsx_off);
   LGN_CHECK_LAUNCH();
   return 0;
 }
@@ -982,15 +1012,17 @@ static int launch_bwd3(const LevelBwdArgs<double>& a, hipStream_t stream) {
 
 // whole level backward in one launch; one CatMix partial row and one radial partial row per jet
 int level_bwd3_dispatch(const LevelBwdArgs<double>& a, int decoder, hipStream_t stream) {
-  // LGN_AMD_DEC_PAIRWISE=1 keeps the decoder on the O(N^2) pair sweep (cross-check of the separable form)
-  const char* pw_env = getenv("LGN_AMD_DEC_PAIRWISE");      // read per call: tests flip it
-  const bool pairwise = pw_env && pw_env[0] == '1';
+  const bool pairwise = (a.flags & LVL_DEC_PAIRWISE) != 0;   // the decoder on the O(N^2) pair sweep (cross-check of the separable form)
 #define LGN_CASE(CC)                                                                \
   case CC:                                                                          \
     if (!decoder) return launch_bwd3<CC, false, false>(a, stream);                  \
     return pairwise ? launch_bwd3<CC, true, false>(a, stream) : launch_bwd3<CC, true, true>(a, stream);
   switch (a.C) {
+#ifdef LGN_DEV_ONLY_C4      // development builds: one channel count (compile time)
+    LGN_CASE(4)
+#else
     LGN_CASE(1) LGN_CASE(2) LGN_CASE(3) LGN_CASE(4) LGN_CASE(5) LGN_CASE(6) LGN_CASE(7) LGN_CASE(8)
+#endif
     default: set_error("level_bwd: C_in=%d unsupported (1..8)", a.C); return -1;
   }
 #undef LGN_CASE

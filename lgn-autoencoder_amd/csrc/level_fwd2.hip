@@ -17,6 +17,7 @@
 //  * the aggregate of the whole jet is collected in LDS; after one barrier all 256 threads write it out (it is saved
 //    for the backward) and run CatMix over the items (row, out channel, component).
 #include "level_dev.hpp"
+#include "mlp_dev.hpp"
 #include "net_dev.hpp"
 #include "ops.hpp"
 #include "wave_sum.hpp"
@@ -68,8 +69,9 @@ struct Fwd2 {
 //   A1_i = e0 sum_j v_j            A2_i = R1 (p_i sum_j s_j - sum_j s_j p_j)
 //   A4_i = e0 sum_j s_j            A3_i = R1 (<sum_j v_j, p_i> - sum_j <v_j, p_j>) / 2
 // O(N C) instead of O(N^2 C) work per jet, same values up to summation order.  SEP = false keeps the pair sweep.
+// mlp_off (with a.mlp.wb): offset in doubles of the CGMLP phase's own LDS (first-layer image | MLP input rows) behind the level's.
 template <int C, bool DEC, bool SEP>
-__global__ __launch_bounds__(2 * BLOCK) void level_fwd2_kernel(LevelArgs<double> a, int chunk) {
+__global__ __launch_bounds__(2 * BLOCK) void level_fwd2_kernel(LevelArgs<double> a, int chunk, int mlp_off) {
   using F = Fwd2<C, DEC>;
   constexpr int NG = F::NG;
   const int N = a.N, B = a.B, CO = a.CO;
@@ -83,8 +85,23 @@ __global__ __launch_bounds__(2 * BLOCK) void level_fwd2_kernel(LevelArgs<double>
   double* agl = wm + 4 * CO * 5 * C;                                  // chunk rows * AGS: aggregate of a chunk of rows
   double* sums = agl + chunk * F::AGS;                                // 20 C: jet-level sums of the separable form
   uint8_t* mk = reinterpret_cast<uint8_t*>(sums + 20 * C);            // N
+  // the level's CGMLP as the tail of this kernel (mlp_dev.hpp; the host launches it for one-chunk, four-wave shapes only)
+  constexpr bool MLP_OK = C <= 4 && (!DEC || SEP);
+  const bool has_mlp = MLP_OK && a.mlp.wb != nullptr;
+  double* fimg0 = reinterpret_cast<double*>(smem_raw) + mlp_off;       // first-layer image
+  double* fx0 = fimg0 + fm::IMG0;                                      // MLP input rows [row][S0]
+  __shared__ int fm_ids[4];
+  fm::W0Regs<4> fw0;
+  const fm::Dims md = fm::make_dims(2 * CO, a.mlp.H);
 
   STAMP(0);
+  if constexpr (MLP_OK) {
+    if (has_mlp) {
+      fm::stage0_issue<4>(a.mlp.wb, md, wave, lane, fw0);
+      fm::role_publish(fm_ids, wave, lane);
+      for (int e = tid; e < fm::passes(N) * fm::ROWS * fm::S0; e += nthr) fx0[e] = 0.0;
+    }
+  }
   if (!DEC && a.in_w0) {
     // first encoder level of a fused network: input features from the momenta (see LevelArgs::in_w0), buffers to clear
     {
@@ -179,6 +196,9 @@ __global__ __launch_bounds__(2 * BLOCK) void level_fwd2_kernel(LevelArgs<double>
       const double* bb = (q >> 1) ? a.b1 : a.b0;
       bias[g][q] = ch < C ? (DEC ? bb[ch] : bb[2 * ch + (q & 1)]) : 0.0;
     }
+  }
+  if constexpr (MLP_OK) {
+    if (has_mlp) fm::stage0_commit<4>(fimg0, wave, lane, fw0);
   }
   __syncthreads();
   STAMP(1);
@@ -491,6 +511,12 @@ __global__ __launch_bounds__(2 * BLOCK) void level_fwd2_kernel(LevelArgs<double>
           const size_t e = ((size_t)b * N + r) * CO + o;
           a.s_out[e] = acc.r;
           a.s_out[plo + e] = acc.i;
+          if constexpr (MLP_OK) {
+            if (has_mlp) {                                    // the MLP's input row, feature k = 2o + z
+              fx0[rl * fm::S0 + 2 * o] = acc.r;
+              fx0[rl * fm::S0 + 2 * o + 1] = acc.i;
+            }
+          }
         }
       }
     } else {
@@ -525,6 +551,19 @@ __global__ __launch_bounds__(2 * BLOCK) void level_fwd2_kernel(LevelArgs<double>
   STAMP(22);
   if (c1 < rhi) __syncthreads();                         // the chunk's aggregate rows are reused
   }
+  if constexpr (MLP_OK) {
+    if (has_mlp) {     // (one chunk: local row = row - rlo.  Outside the chunk loop: inside it, every lane-derived address of the phase
+                       //  is hoisted in front of the pair sweep as a loop invariant and spills there)
+      __syncthreads();                                   // the MLP input rows are complete; the level's LDS is dead
+      const int role = fm::role_resolve(fm_ids, wave);
+      fm::WRegs<4> fwr;
+      fm::stage_issue<4>(a.mlp.wb, 1, md, wave, lane, fwr);
+      double* so = a.mlp.s_out + ((size_t)b * N + rlo) * CO;
+      double* img = reinterpret_cast<double*>(smem_raw);
+      const size_t plm = (size_t)B * N * CO;
+      fm::fwd_phase<false>(a.mlp.wb, md, 0, img, fimg0, fx0, rhi - rlo, fwr, role, so, plm, CO);   // (LeakyReLU: level_mlp_fusable)
+    }
+  }
   STAMP(40);
   if constexpr (DEC) {
     if (a.loss_wo1) {      // (one workgroup of BLOCK threads per jet: checked on the host)
@@ -553,6 +592,17 @@ static int launch_level_fwd2(const LevelArgs<double>& a, hipStream_t stream) {
     if (chunk < 16) chunk = 16;
   }
   size_t smem = fixed + chunk * row;
+  // the CGMLP phase: two weight images over the level's (then dead) data, first-layer image + input rows behind them
+  int mlp_off = 0;
+  if (a.mlp.wb) {
+    constexpr bool MLP_OK = C <= 4 && (!DEC || SEP);
+    LGN_CHECK_ARG(MLP_OK && level_mlp_fusable(a.N, C, a.CO, a.mlp.H, 7, a.mlp.act) && chunk == full && !wide && a.mlp.s_out,
+                  "level_fwd: the CGMLP does not ride on this shape (N=%d C=%d CO=%d H=%d)", a.N, C, a.CO, a.mlp.H);
+    size_t base = (smem + 15) & ~size_t(15);
+    if (base < sizeof(double) * fm::fwd_alias_doubles()) base = sizeof(double) * fm::fwd_alias_doubles();
+    mlp_off = (int)(base / sizeof(double));
+    smem = base + sizeof(double) * fm::fwd_own_doubles(a.N);
+  }
   if (a.loss_wo1) {
     LGN_CHECK_ARG(DEC && SEP && a.N <= 40 && !wide && a.loss_target && a.loss_recon && a.loss_part && a.loss_gv && a.loss_wpart,
                   "level_fwd: the loss rides on the separable decoder forward of jets of <= 40 particles only");
@@ -568,14 +618,14 @@ static int launch_level_fwd2(const LevelArgs<double>& a, hipStream_t stream) {
   const int nthreads = wide ? 2 * BLOCK : BLOCK;
   // small batches of small jets: several workgroups per jet, each with its own rows (level.hpp: level_jet_split)
   const int split = (SEP || a.N > 40) ? 1 : level_jet_split(a.B, a.N);
-  hipLaunchKernelGGL(kern, dim3(a.B, split), dim3(nthreads), smem, stream, a, chunk);
+  hipLaunchKernelGGL(kern, dim3(a.B, split), dim3(nthreads), smem, stream, a, chunk, mlp_off);
   LGN_CHECK_LAUNCH();
   return 0;
 }
 
-bool level_fwd_carries_loss(int N) {
-  const char* pw_env = getenv("LGN_AMD_DEC_PAIRWISE");
-  return N <= 40 && !(pw_env && pw_env[0] == '1');
+bool level_fwd_carries_loss(int N, int flags) { return N <= 40 && !(flags & LVL_DEC_PAIRWISE); }
+bool level_fwd_fuses_mlp(int N, int C, int CO, int H, int nlin, int act, int decoder, int flags) {
+  return level_mlp_fusable(N, C, CO, H, nlin, act) && !(flags & LVL_NO_FUSED_MLP) && !(decoder && (flags & LVL_DEC_PAIRWISE));
 }
 
 template <>
@@ -583,15 +633,17 @@ int level_fwd_dispatch<double>(const LevelArgs<double>& a, int decoder, hipStrea
   LGN_CHECK_ARG(a.B > 0 && a.N > 0, "level_fwd: empty batch (B=%d N=%d)", a.B, a.N);
   LGN_CHECK_ARG(!a.in_w0 || (!decoder && a.in_w1 && a.in_s && a.in_v), "level_fwd: the input stage rides on encoder levels only");
   LGN_CHECK_ARG(a.CO >= 1 && a.CO <= 8, "level_fwd: C_out=%d unsupported (1..8)", a.CO);
-  // LGN_AMD_DEC_PAIRWISE=1 keeps the decoder on the O(N^2) pair sweep (cross-check of the separable form)
-  const char* pw_env = getenv("LGN_AMD_DEC_PAIRWISE");      // read per call: tests flip it
-  const bool pairwise = pw_env && pw_env[0] == '1';
+  const bool pairwise = (a.flags & LVL_DEC_PAIRWISE) != 0;   // the decoder on the O(N^2) pair sweep (cross-check of the separable form)
 #define LGN_CASE(CC)                                                                                         \
   case CC:                                                                                                   \
     if (!decoder) return launch_level_fwd2<CC, false, false>(a, stream);                                     \
     return pairwise ? launch_level_fwd2<CC, true, false>(a, stream) : launch_level_fwd2<CC, true, true>(a, stream);
   switch (a.C) {
+#ifdef LGN_DEV_ONLY_C4      // development builds: one channel count (compile time)
+    LGN_CASE(4)
+#else
     LGN_CASE(1) LGN_CASE(2) LGN_CASE(3) LGN_CASE(4) LGN_CASE(5) LGN_CASE(6) LGN_CASE(7) LGN_CASE(8)
+#endif
     default:
       set_error("level_fwd: C_in=%d unsupported (1..8)", a.C);
       return -1;

@@ -29,9 +29,13 @@ struct RadFinJob {
   struct Item { const double* tot; int C; const double *ra, *rb, *rc, *w0, *w1; double *g_a, *g_b, *g_c, *g_w0, *g_b0, *g_w1, *g_b1; } it[4];
 };
 int rad_finalize_batch(const RadFinJob& job, hipStream_t);
-void level_bwd_partial_rows(int B, int N, int decoder, int* rows_mix, int* rows_rad);
-bool level_bwd_carries_input(int N);
-bool level_fwd_carries_loss(int N);    // the decoder's last level may take LevelArgs::loss_* (separable one-workgroup-per-jet forward)   // the encoder's first level may take LevelBwdArgs::part_in0 (one-kernel backward, N <= 40)
+void level_bwd_partial_rows(int B, int N, int decoder, int flags, int* rows_mix, int* rows_rad);
+bool level_bwd_carries_input(int N, int flags);   // the encoder's first level may take LevelBwdArgs::part_in0 (one-kernel backward, N <= 40)
+bool level_fwd_carries_loss(int N, int flags);    // the decoder's last level may take LevelArgs::loss_* (separable one-workgroup-per-jet forward)
+// does the level's CGMLP ride on the level kernel (LevelArgs::mlp / LevelBwdArgs::mlp)?  The forward and the backward decide
+// independently (the forward always leaves the scalars before AND after the MLP)
+bool level_fwd_fuses_mlp(int N, int C, int CO, int H, int nlin, int act, int decoder, int flags);
+bool level_bwd_fuses_mlp(int N, int C, int CO, int H, int nlin, int act, int decoder, int flags);
 
 // ---- CGMLP (mlp.hip / mlp_mfma.hip) ------------------------------------------------------------------
 constexpr int MLP_MAX_LIN = 8;
@@ -118,6 +122,7 @@ struct GenArgs {
   double* part_rad;         // [B][rad_partial_size]
   double* gbuf;             // encoder i-centric backward, N <= 32: pair-gradient scratch, moments2_gbuf_doubles(B, N, C) doubles (optional:
                             // without it the v1 kernel of generic_moments.hip runs)
+  int flags;                // LVL_* (level.hpp)
   int tb;                   // 1: X / gX are [tile][C][Q][2][64] and U / gU [tile][C][5 Q][2][64] (node n = b N + j = 64 tile + lane),
                             // the layouts of generic_local_static.hip (channel-outermost kernels of generic_moments2.hip only)
 };

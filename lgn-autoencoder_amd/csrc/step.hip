@@ -121,6 +121,19 @@ int attach_side(Deferred& dq, void* side_stream) {
   return 0;
 }
 
+// does level l's CGMLP ride on the level kernels (forward tail / backward head; mlp_dev.hpp)?  One answer per descriptor.
+bool fuses_mlp(const lgn_net_desc& d, bool dec, int l, bool backward) {
+  const int* ch = dec ? d.dec_channels : d.enc_channels;
+  const int H = d.mlp_hidden_mul * 2 * ch[l + 1];
+  return backward ? level_bwd_fuses_mlp(d.N, ch[l], ch[l + 1], H, d.mlp_nlin, d.activation, dec, d.flags)
+                  : level_fwd_fuses_mlp(d.N, ch[l], ch[l + 1], H, d.mlp_nlin, d.activation, dec, d.flags);
+}
+// partial rows of level l's CGMLP weight gradients: one per jet and pass when it rides on the level backward
+size_t mlp_part_rows(const lgn_net_desc& d, bool dec, int l) {
+  const int* ch = dec ? d.dec_channels : d.enc_channels;
+  return fuses_mlp(d, dec, l, true) ? (size_t)d.B * level_mlp_passes(d.N) : (size_t)mlp_partial_rows(d.B * d.N, d.mlp_hidden_mul * 2 * ch[l + 1]);
+}
+
 int mlp_psize(int C, int H, int nlin) {
   const int D = 2 * C;
   return nlin == 1 ? D * D + D : (H * D + H) + (nlin - 2) * (H * H + H) + (D * H + D);
@@ -133,7 +146,7 @@ Work carve(const lgn_net_desc& d, double* base) {
   const int L = d.n_levels;
   int cmax = 0;
   for (int l = 0; l <= L; ++l) cmax = cmax > d.enc_channels[l] ? cmax : d.enc_channels[l], cmax = cmax > d.dec_channels[l] ? cmax : d.dec_channels[l];
-  auto net = [&](NetBuf& n, const int* ch) {
+  auto net = [&](NetBuf& n, const int* ch, bool dec) {
     for (int l = 0; l <= L; ++l) {
       n.s[l] = b.take(2 * BN * ch[l]);
       n.v[l] = b.take(8 * BN * ch[l]);
@@ -143,12 +156,14 @@ Work carve(const lgn_net_desc& d, double* base) {
       n.ag0[l] = b.take(4 * BN * ch[l]);
       n.ag1[l] = b.take(16 * BN * ch[l]);
       // the last level's scalars never reach the loss: its CGMLP has no backward
-      const size_t hs = l + 1 < L && BN <= mlp_save_max_rows() ? mlp_saved_doubles((int)BN, d.mlp_hidden_mul * 2 * ch[l + 1], d.mlp_nlin) : 0;
+      // (a CGMLP that rides on the level kernels recomputes: nothing kept)
+      const size_t hs = l + 1 < L && BN <= mlp_save_max_rows() && !fuses_mlp(d, dec, l, false)
+                            ? mlp_saved_doubles((int)BN, d.mlp_hidden_mul * 2 * ch[l + 1], d.mlp_nlin) : 0;
       n.hsave[l] = hs ? b.take(hs) : nullptr;
     }
   };
-  net(w.enc, d.enc_channels);
-  net(w.dec, d.dec_channels);
+  net(w.enc, d.enc_channels, false);
+  net(w.dec, d.dec_channels, true);
   const int Ts = d.tau_s, Tv = d.tau_v;
   w.lat_s = b.take((size_t)2 * d.B * 2 * Ts);
   w.lat_v = b.take((size_t)2 * d.B * 2 * Tv * 4);
@@ -174,10 +189,10 @@ Work carve(const lgn_net_desc& d, double* base) {
     const int* ch = dec ? d.dec_channels : d.enc_channels;
     for (int l = 0; l < L; ++l) {
       int rm, rr;
-      level_bwd_partial_rows(d.B, d.N, dec, &rm, &rr);
+      level_bwd_partial_rows(d.B, d.N, dec, d.flags, &rm, &rr);
       const size_t nmix = (size_t)4 * ch[l + 1] * 5 * ch[l], nrad = rad_partial_size(ch[l], dec != 0);
       psum += ((rm * nmix + 15) & ~size_t(15)) + ((rr * nrad + 15) & ~size_t(15));
-      psum += ((size_t)mlp_partial_rows((int)BN, d.mlp_hidden_mul * 2 * ch[l + 1]) * mlp_psize(ch[l + 1], d.mlp_hidden_mul * 2 * ch[l + 1], d.mlp_nlin) + 15) & ~size_t(15);
+      psum += (mlp_part_rows(d, dec, l) * mlp_psize(ch[l + 1], d.mlp_hidden_mul * 2 * ch[l + 1], d.mlp_nlin) + 15) & ~size_t(15);
       w.tot[dec][l] = b.take(nrad + 16);
     }
   }
@@ -244,6 +259,12 @@ int levels_fwd(const lgn_net_desc& d, bool dec, const int* ch, const double* P, 
       a.loss_wo1 = loss->wo1; a.loss_target = loss->target; a.loss_scale = loss->scale; a.loss_recon = loss->recon;
       a.loss_part = loss->loss_part; a.loss_gv = loss->g_v; a.loss_wpart = loss->wpart;
     }
+    a.flags = d.flags;
+    if (fuses_mlp(d, dec, l, false)) {        // the CGMLP is the tail of the level kernel (parameters contiguous: checked at plan time)
+      a.mlp.wb = p(S.mlp(dec, l, 0)); a.mlp.H = d.mlp_hidden_mul * 2 * ch[l + 1]; a.mlp.act = d.activation; a.mlp.s_out = n.s[l + 1];
+      LGN_TRY(level_fwd_dispatch<double>(a, dec, st));
+      continue;
+    }
     LGN_TRY(level_fwd_dispatch<double>(a, dec, st));
     MlpArgs<double> m{};
     m.M = d.B * d.N; m.C = ch[l + 1]; m.H = d.mlp_hidden_mul * 2 * ch[l + 1]; m.nlin = d.mlp_nlin; m.act = d.activation;
@@ -271,12 +292,14 @@ int levels_bwd(const lgn_net_desc& d, bool dec, const int* ch, const double* P, 
     auto g = [&](int slot) { return G + off[slot]; };
     const int C = ch[l], CO = ch[l + 1];
     const double* g_smix = w.zeros_s;
-    if (has_s_grad) {
+    const bool ride = has_s_grad && fuses_mlp(d, dec, l, true);
+    if (has_s_grad && !ride) {
       MlpArgs<double> m{};
       m.M = BN; m.C = CO; m.H = d.mlp_hidden_mul * 2 * CO; m.nlin = d.mlp_nlin; m.act = d.activation;
       for (int q = 0; q < d.mlp_nlin; ++q) { m.w[q] = p(S.mlp(dec, l, 2 * q)); m.b[q] = p(S.mlp(dec, l, 2 * q + 1)); }
       m.s_in = n.smix[l]; m.g_out = w.gs[cur]; m.g_in = w.gsmix;
-      m.h_saved = n.hsave[l]; m.h_rows = mlp_saved_rows(BN);
+      m.h_saved = fuses_mlp(d, dec, l, false) ? nullptr : n.hsave[l];     // (a riding forward keeps no hidden activations)
+      m.h_rows = mlp_saved_rows(BN);
       m.psize = mlp_psize(CO, m.H, m.nlin);
       DQ_TAKE(m.part, (size_t)mlp_partial_rows(BN, m.H) * m.psize);
       LGN_TRY(mlp_dispatch<double>(m, true, st));
@@ -285,7 +308,7 @@ int levels_bwd(const lgn_net_desc& d, bool dec, const int* ch, const double* P, 
       g_smix = w.gsmix;
     }
     int rm, rr;
-    level_bwd_partial_rows(d.B, d.N, dec, &rm, &rr);
+    level_bwd_partial_rows(d.B, d.N, dec, d.flags, &rm, &rr);
     const int nmix = 4 * CO * 5 * C, nrad = rad_partial_size(C, dec);
     DQ_NEW(part_mix, (size_t)rm * nmix);
     DQ_NEW(part_rad, (size_t)rr * nrad);
@@ -294,8 +317,17 @@ int levels_bwd(const lgn_net_desc& d, bool dec, const int* ch, const double* P, 
                            p(S.rad(dec, l, 0)), p(S.rad(dec, l, 1)), p(S.rad(dec, l, 2)), p(S.rad(dec, l, 3)), p(S.rad(dec, l, 4)),
                            p(S.rad(dec, l, 5)), p(S.rad(dec, l, 6)), p(S.mix(dec, l, 0)), p(S.mix(dec, l, 1)), n.ag0[l], n.ag1[l],
                            g_smix, w.gv[cur], w.g_ag, w.gs[nxt], w.gv[nxt], dec ? w.g_p : nullptr, part_mix, part_rad};
-    const bool carry_in0 = !dec && l == 0 && in0_grads && level_bwd_carries_input(d.N);
+    const bool carry_in0 = !dec && l == 0 && in0_grads && level_bwd_carries_input(d.N, d.flags);
     if (carry_in0) { DQ_TAKE(a.part_in0, (size_t)rm * 4 * C); }
+    a.flags = d.flags;
+    if (ride) {          // the CGMLP's backward is the head of the level kernel: gs[cur] is the gradient w.r.t. the MLP OUTPUT
+      const int H = d.mlp_hidden_mul * 2 * CO, psz = mlp_psize(CO, H, d.mlp_nlin);
+      const size_t rows = mlp_part_rows(d, dec, l);
+      a.mlp.wb = p(S.mlp(dec, l, 0)); a.mlp.H = H; a.mlp.act = d.activation; a.mlp.s_pre = n.smix[l]; a.mlp.g_out = w.gs[cur];
+      DQ_TAKE(a.mlp.part, rows * psz);
+      a.g_s_out = nullptr;
+      dq.add(a.mlp.part, (int)rows, psz, 0, psz, g(S.mlp(dec, l, 0)));
+    }
     LGN_TRY(level_bwd_dispatch<double>(a, dec, st));
     if (carry_in0) {
       dq.add(a.part_in0, rm, 4 * C, 0, 2 * C, in0_grads[0]);
@@ -512,6 +544,7 @@ GenArgs gen_level_args(const lgn_net_desc& d, bool dec, int l, const double* P, 
   const GenGeom g = geom(d, dec);
   GenArgs a{};
   a.B = d.B; a.N = d.N; a.C = g.ch[l]; a.Q = g.Q[l]; a.X = X; a.p = pos; a.mask = mask;
+  a.flags = d.flags;
   a.ra = P + off[S.rad(dec, l, 0)]; a.rb = P + off[S.rad(dec, l, 1)]; a.rc = P + off[S.rad(dec, l, 2)];
   a.w0 = P + off[S.rad(dec, l, 3)]; a.b0 = P + off[S.rad(dec, l, 4)]; a.w1 = P + off[S.rad(dec, l, 5)]; a.b1 = P + off[S.rad(dec, l, 6)];
   return a;
@@ -822,7 +855,8 @@ NetAct carve_act(const lgn_net_desc& d, bool dec, double* base) {
     a.n.ag0[l] = b.take(4 * BN * ch[l]);
     a.n.ag1[l] = b.take(16 * BN * ch[l]);
     // (the caller's upstream gradient may reach every level)
-    const size_t hs = BN <= mlp_save_max_rows() ? mlp_saved_doubles((int)BN, d.mlp_hidden_mul * 2 * ch[l + 1], d.mlp_nlin) : 0;
+    const size_t hs = BN <= mlp_save_max_rows() && !fuses_mlp(d, dec, l, false)
+                          ? mlp_saved_doubles((int)BN, d.mlp_hidden_mul * 2 * ch[l + 1], d.mlp_nlin) : 0;
     a.n.hsave[l] = hs ? b.take(hs) : nullptr;
   }
   if (dec) a.pdec = b.take(8 * BN);
@@ -860,10 +894,10 @@ NetScratch carve_scratch(const lgn_net_desc& d, bool dec, double* base) {
   size_t psum = 0;
   for (int l = 0; l < L; ++l) {
     int rm, rr;
-    level_bwd_partial_rows(d.B, d.N, dec, &rm, &rr);
+    level_bwd_partial_rows(d.B, d.N, dec, d.flags, &rm, &rr);
     const size_t nmix = (size_t)4 * ch[l + 1] * 5 * ch[l], nrad = rad_partial_size(ch[l], dec);
     psum += ((rm * nmix + 15) & ~size_t(15)) + ((rr * nrad + 15) & ~size_t(15));
-    psum += ((size_t)mlp_partial_rows((int)BN, d.mlp_hidden_mul * 2 * ch[l + 1]) * mlp_psize(ch[l + 1], d.mlp_hidden_mul * 2 * ch[l + 1], d.mlp_nlin) + 15) & ~size_t(15);
+    psum += (mlp_part_rows(d, dec, l) * mlp_psize(ch[l + 1], d.mlp_hidden_mul * 2 * ch[l + 1], d.mlp_nlin) + 15) & ~size_t(15);
     w.tot[dec ? 1 : 0][l] = b.take(nrad + 16);
   }
   // input / output ends: decoder  B x (2 C_L) + B x (4 C_0 + 2 N Tin);  encoder  B x 2 (Ts + Tv) C_L + B x 4 C_0
@@ -871,7 +905,7 @@ NetScratch carve_scratch(const lgn_net_desc& d, bool dec, double* base) {
   if (dec) psum += (((size_t)d.B * 2 * ch[L] + 15) & ~size_t(15)) + (((size_t)d.B * (4 * ch[0] + 2 * (size_t)d.N * Tin) + 15) & ~size_t(15));
   else {
     int rm0, rr0;                                          // input-stage partial rows: one per workgroup of the first level's backward
-    level_bwd_partial_rows(d.B, d.N, 0, &rm0, &rr0);
+    level_bwd_partial_rows(d.B, d.N, 0, d.flags, &rm0, &rr0);
     if (rm0 < d.B) rm0 = d.B;
     psum += (((size_t)d.B * 2 * (Ts + Tv) * ch[L] + 15) & ~size_t(15)) + (((size_t)rm0 * 4 * ch[0] + 15) & ~size_t(15));
   }
@@ -1138,7 +1172,7 @@ int lgn_step_fwd_bwd_f64(const lgn_net_desc* d, const double* params, double* gr
   {
     DQ_NEW(part, (size_t)B * 2 * cd[L]);
     const LossStage ls{params + dec_off[S.out0(true) + 1], target, 1.0, recon, loss_part, w.gv[cur], part};
-    const bool rides = level_fwd_carries_loss(N);
+    const bool rides = level_fwd_carries_loss(N, d->flags);
     LGN_TRY(levels_fwd(*d, true, cd, params, dec_off, w.dec, w.pdec, nullptr, st, nullptr, rides ? &ls : nullptr));
     if (!rides)
       LGN_TRY(dec_output_loss(B, N, cd[L], w.dec.v[L], ls.wo1, target, 1.0, recon, loss_part, w.gv[cur], part, st));

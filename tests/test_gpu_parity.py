@@ -179,6 +179,162 @@ def _level_case(dev, O, decoder, C, CO, N, B):
     U.assert_close(wm1.grad, P["lgn_cg.node_levels.0.cat_mix.mix_reps.weights.(1, 1)"].grad, GRAD_TOL, "g_wm1")
 
 
+def _level_mlp_inputs(O, decoder, C, CO, N, B, act, g, seed):
+    """Random level + CGMLP parameters (every parameter O(1)), a jet batch and cotangents; returns what both sides need."""
+    cfg = O.NetConfig(num_channels=(C, CO), activation=act)
+    P = {}
+    torch.manual_seed(seed)
+    O._init_radial(P, cfg, decoder)
+    plans = O.build_level_plans(cfg, {(0, 0): C, (1, 1): C})
+    O._init_levels(P, cfg, plans)
+    for k in P:
+        if "cat_mix" in k:
+            P[k] = torch.randn(P[k].shape, dtype=torch.float64, generator=g) * 0.3
+    node = {(1, 1): torch.randn(2, B, N, C, 4, dtype=torch.float64, generator=g),
+            (0, 0): torch.randn(2, B, N, C, 1, dtype=torch.float64, generator=g)}
+    if decoder:
+        p, mask = torch.randn(2, B, N, 4, dtype=torch.float64, generator=g), None
+    else:
+        p, mask = O.synthetic_jets(B, N, seed=seed, pad=N > 4)
+    cot = {(0, 0): torch.randn(2, B, N, CO, 1, dtype=torch.float64, generator=g),
+           (1, 1): torch.randn(2, B, N, CO, 4, dtype=torch.float64, generator=g)}
+    return cfg, plans, P, node, p, mask, cot
+
+
+_RAD_NAMES = ["a", "b", "c", "linear.0.weight", "linear.0.bias", "linear.1.weight", "linear.1.bias"]
+_MIX = "lgn_cg.node_levels.0.cat_mix.mix_reps.weights."
+
+
+def _level_mlp_native(dev, decoder, act, P, node, p, mask, cot):
+    """level + CGMLP through ops.LevelMlpFn (ONE native call per direction); returns outputs and every gradient on the CPU."""
+    from lgn import ops, _native as Nn
+    d = lambda t: t.detach().to(dev).requires_grad_(True)  # noqa: E731
+    s_in, v_in, pd = d(node[(0, 0)].squeeze(-1)), d(node[(1, 1)]), d(p)
+    radp = [d(P["rad_funcs.rad_funcs.0." + n]) for n in _RAD_NAMES]
+    wm0, wm1 = d(P[_MIX + "(0, 0)"]), d(P[_MIX + "(1, 1)"])
+    flat = []
+    for i in range(7):
+        flat += [d(P[f"lgn_cg.mlp_levels.0.linear.{i}.weight"]), d(P[f"lgn_cg.mlp_levels.0.linear.{i}.bias"])]
+    s_out, v_out = ops.LevelMlpFn.apply(decoder, Nn.activation_id(act), s_in, v_in, pd, None if mask is None else mask.to(dev), *radp,
+                                        wm0, wm1, *flat)
+    ((s_out.unsqueeze(-1) * cot[(0, 0)].to(dev)).sum() + (v_out * cot[(1, 1)].to(dev)).sum()).backward()
+    z = lambda t: torch.zeros_like(t) if t.grad is None else t.grad  # noqa: E731
+    grads = {"s_in": s_in.grad.unsqueeze(-1), "v_in": v_in.grad, "p": pd.grad if decoder else None, "wm0": wm0.grad, "wm1": wm1.grad}
+    grads.update({"rad." + n: z(t) for n, t in zip(_RAD_NAMES, radp)})
+    for i in range(7):
+        grads[f"mlp.{i}.weight"], grads[f"mlp.{i}.bias"] = flat[2 * i].grad, flat[2 * i + 1].grad
+    return s_out.unsqueeze(-1), v_out, grads
+
+
+def _level_mlp_oracle(O, decoder, cfg, plans, P, node, p, mask, cot):
+    P = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    node = {k: v.clone().requires_grad_(True) for k, v in node.items()}
+    p = p.clone().requires_grad_(True) if decoder else p
+    B, N = node[(0, 0)].shape[1:3]
+    if decoder:
+        zonal, norms, _ = O.zonal_rel(p, p, "canonical")
+        emask = torch.zeros(2, B, N, N, dtype=torch.float64)
+    else:
+        zonal, norms, _ = O.zonal_rel(p, p, "cartesian")
+        emask = (mask.unsqueeze(1) * mask.unsqueeze(2)) * (norms != 0).byte()
+    rad = O.radial_filters(P, cfg, 0, norms, emask, decoder)
+    edge = {k: O.scalar_times_irrep(rad[k], zonal[k]) for k in rad}
+    out = O.cg_mlp(P, cfg, 0, O.node_level(P, O.get_cg(2), cfg, 0, plans[0], node, edge))
+    sum((out[k] * cot[k]).sum() for k in out).backward()
+    z = lambda t: torch.zeros_like(t) if t.grad is None else t.grad  # noqa: E731
+    grads = {"s_in": node[(0, 0)].grad, "v_in": node[(1, 1)].grad, "p": p.grad if decoder else None,
+             "wm0": P[_MIX + "(0, 0)"].grad, "wm1": P[_MIX + "(1, 1)"].grad}
+    grads.update({"rad." + n: z(P["rad_funcs.rad_funcs.0." + n]) for n in _RAD_NAMES})
+    for i in range(7):
+        grads[f"mlp.{i}.weight"] = P[f"lgn_cg.mlp_levels.0.linear.{i}.weight"].grad
+        grads[f"mlp.{i}.bias"] = P[f"lgn_cg.mlp_levels.0.linear.{i}.bias"].grad
+    return out[(0, 0)], out[(1, 1)], grads
+
+
+def _assert_grads(got, ref, tol, tag=""):
+    for k, r in ref.items():
+        if r is None:
+            continue
+        if r.abs().max() == 0:
+            assert got[k].abs().max() == 0, f"{tag}{k} must have exactly zero gradient"
+        else:
+            U.assert_close(got[k], r, tol, tag + "g_" + k)
+
+
+@pytest.mark.parametrize("decoder", [False, True])
+@pytest.mark.parametrize("C,CO,N,B", [(3, 3, 30, 3), (3, 4, 30, 2), (4, 4, 30, 2), (4, 3, 30, 2),      # the four BASELINE level shapes
+                                      (4, 4, 7, 2), (3, 4, 7, 1), (4, 3, 33, 2), (3, 3, 33, 1),          # one tile; two passes
+                                      (4, 4, 16, 2), (4, 4, 17, 1), (3, 3, 32, 2), (4, 4, 40, 1),        # tile / pass boundaries
+                                      (2, 2, 30, 2), (1, 1, 5, 1), (4, 2, 13, 3), (2, 4, 30, 1),         # narrow MLPs (H = 12, 24)
+                                      (5, 4, 30, 2), (4, 5, 30, 1), (4, 4, 48, 1)])                      # outside the fused range
+def test_level_mlp_fwd_bwd(dev, O, decoder, C, CO, N, B):
+    """LGNNodeLevel + CGMLP behind one call per direction (lgn_level_mlp_fwd/bwd_f64) against the oracle.  For N <= 40, C <= 4,
+    C_out <= 4 (H <= 48) the CGMLP rides on the level kernels (csrc/mlp_dev.hpp; small B: the jet is split over several workgroups,
+    each running the forward MLP on its rows and the backward chain on all rows); the other shapes run the separate launches."""
+    from lgn import _native as Nn
+    g = torch.Generator().manual_seed(1000 * C + 100 * CO + N + int(decoder))
+    cfg, plans, P, node, p, mask, cot = _level_mlp_inputs(O, decoder, C, CO, N, B, "leakyrelu", g, seed=N + 7 * C)
+    H = P["lgn_cg.mlp_levels.0.linear.0.weight"].shape[0]
+    fused = Nn.level_mlp_fused(N, C, CO, H, 7, 0, decoder)
+    assert fused == (3 if (N <= 40 and C <= 4 and CO <= 4) else 0), "which shapes ride on the level kernels"
+    s_ref, v_ref, g_ref = _level_mlp_oracle(O, decoder, cfg, plans, P, node, p, mask, cot)
+    s_out, v_out, g_got = _level_mlp_native(dev, decoder, "leakyrelu", P, node, p, mask, cot)
+    U.assert_close(s_out, s_ref, FWD_TOL, "s_out (after the MLP)")
+    U.assert_close(v_out, v_ref, FWD_TOL, "v_out")
+    _assert_grads(g_got, g_ref, GRAD_TOL)
+
+
+@pytest.mark.parametrize("decoder", [False, True])
+@pytest.mark.parametrize("act", ["leakyrelu", "relu", "elu", "sigmoid", "logsigmoid", "atan"])
+def test_level_mlp_activations(dev, O, decoder, act):
+    """Every activation of get_activation_fn through the level + CGMLP call.  LeakyReLU (the reference default) rides on the level
+    kernels; the others keep the separate CGMLP kernels behind the same call (level.hpp: level_mlp_fusable says why)."""
+    from lgn import _native as Nn
+    C, CO, N, B = 4, 3, 30, 2
+    g = torch.Generator().manual_seed(77 + int(decoder))
+    cfg, plans, P, node, p, mask, cot = _level_mlp_inputs(O, decoder, C, CO, N, B, act, g, seed=11)
+    assert Nn.level_mlp_fused(N, C, CO, 36, 7, Nn.activation_id(act), decoder) == (3 if act == "leakyrelu" else 0)
+    s_ref, v_ref, g_ref = _level_mlp_oracle(O, decoder, cfg, plans, P, node, p, mask, cot)
+    s_out, v_out, g_got = _level_mlp_native(dev, decoder, act, P, node, p, mask, cot)
+    U.assert_close(s_out, s_ref, FWD_TOL, f"{act} s_out")
+    U.assert_close(v_out, v_ref, FWD_TOL, f"{act} v_out")
+    _assert_grads(g_got, g_ref, GRAD_TOL, act + " ")
+
+
+@pytest.mark.parametrize("decoder", [False, True])
+@pytest.mark.parametrize("C,CO", [(3, 4), (4, 4), (4, 3)])
+def test_level_mlp_full_batch_matches_small_batches_and_unfused(dev, O, monkeypatch, decoder, C, CO):
+    """B = 512 (one workgroup per jet, two per CU: the BASELINE launch shape) cannot be held by the oracle.  Properties instead:
+    (1) jets of the 512-batch equal the same jets run in a batch of 3 (the jet-split launch shape, which the oracle pins in
+    test_level_mlp_fwd_bwd); (2) every output and gradient of the riding CGMLP equals the separate-launch path
+    (LGN_AMD_NO_FUSED_MLP=1) to rounding; (3) the run is bitwise reproducible."""
+    from lgn import _native as Nn
+    N, B = 30, 512
+    g = torch.Generator().manual_seed(5 + C + int(decoder))
+    cfg, plans, P, node, p, mask, cot = _level_mlp_inputs(O, decoder, C, CO, N, B, "leakyrelu", g, seed=3)
+    assert Nn.level_mlp_fused(N, C, CO, 12 * CO, 7, 0, decoder) == 3
+    s1, v1, g1 = _level_mlp_native(dev, decoder, "leakyrelu", P, node, p, mask, cot)
+    s2, v2, g2 = _level_mlp_native(dev, decoder, "leakyrelu", P, node, p, mask, cot)
+    assert torch.equal(s1, s2) and torch.equal(v1, v2) and all(torch.equal(g1[k], g2[k]) for k in g1 if g1[k] is not None)
+    sl = [0, 255, 511]
+    sub = lambda t, ax: t.index_select(ax, torch.tensor(sl)).contiguous()  # noqa: E731
+    node3 = {k: sub(v, 1) for k, v in node.items()}
+    cot3 = {k: sub(v, 1) for k, v in cot.items()}
+    p3, m3 = (sub(p, 1), None) if decoder else (sub(p, 0), sub(mask, 0))
+    s3, v3, g3 = _level_mlp_native(dev, decoder, "leakyrelu", P, node3, p3, m3, cot3)
+    idx = torch.tensor(sl, device=dev)
+    U.assert_close(s1.index_select(1, idx), s3, 1e-13, "jets of the full batch: s_out")
+    U.assert_close(v1.index_select(1, idx), v3, 1e-13, "jets of the full batch: v_out")
+    U.assert_close(g1["s_in"].index_select(1, idx), g3["s_in"], 1e-12, "jets of the full batch: g_s_in")
+    U.assert_close(g1["v_in"].index_select(1, idx), g3["v_in"], 1e-12, "jets of the full batch: g_v_in")
+    monkeypatch.setenv("LGN_AMD_NO_FUSED_MLP", "1")
+    assert Nn.level_mlp_fused(N, C, CO, 12 * CO, 7, 0, decoder) == 0
+    su, vu, gu = _level_mlp_native(dev, decoder, "leakyrelu", P, node, p, mask, cot)
+    U.assert_close(s1, su, 1e-13, "fused vs separate: s_out")
+    U.assert_close(v1, vu, 1e-13, "fused vs separate: v_out")
+    _assert_grads(g1, gu, 1e-11, "fused vs separate: ")
+
+
 @pytest.mark.parametrize("act", ["relu", "elu", "sigmoid", "logsigmoid", "atan"])
 def test_cgmlp_activations_vs_reference_golden(dev, act):
     """The CGMLP kernels with every non-default activation against vectors of the reference's CGMLP (g9)."""
