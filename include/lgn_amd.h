@@ -78,9 +78,11 @@ int lgn_level_bwd_f64(int B, int N, int C, int CO, int decoder,
 
 /* ---- level + its CGMLP in one launch per direction -----------------------------------------------
  * LGNNodeLevel followed by CGMLP on the level's scalars, the pair of lgn/models/lgn_cg.py:164-172.  For jets of up to 40
- * particles, C <= 4, hidden width H <= 48, 7 Linear layers and LeakyReLU (lgn_level_mlp_fused says so) the CGMLP is a phase
- * of the level kernel: the forward's tail, the backward's head (csrc/mlp_dev.hpp).  Every other shape runs the level and the
- * CGMLP launches back to back behind the same call -- same results.
+ * particles, C <= 4, hidden width H <= 48, 7 Linear layers and LeakyReLU the CGMLP can run as a phase of the level kernel: the
+ * forward's tail (LGN_AMD_FUSED_MLP=1), the backward's head (LGN_AMD_FUSED_MLP_BWD=1) -- csrc/mlp_dev.hpp; lgn_level_mlp_fused
+ * says which of the two this call would take (bit 0 forward, bit 1 backward).  Measured slower than the separate launches at
+ * every batch size on MI355X, hence opt-in.  Otherwise, and for every other shape, the level and the CGMLP
+ * launches run back to back behind the same call -- same results.
  *  mlp_params: the CGMLP's parameters as ONE block (linear.0.weight, linear.0.bias, linear.1.weight, ...), nn.Linear layouts.
  *  forward : s_pre [2][B][N][CO] = scalars before the MLP (kept for the backward), s_out = after it.
  *  backward: g_s_out = gradient w.r.t. s_out; part_mlp [lgn_level_mlp_partial_rows][psize] (psize = the block's length,
@@ -252,8 +254,10 @@ typedef struct lgn_net_desc {
  * and the workspace sizing can never disagree): */
 #define LGN_NET_DEC_PAIRWISE 2   /* LGN_AMD_DEC_PAIRWISE=1: decoder levels as O(N^2) pair sweeps instead of the separable form */
 #define LGN_NET_LEVEL_V2 4       /* LGN_AMD_LEVEL_V2=1: three-kernel level backward also for N <= 40 */
-#define LGN_NET_NO_FUSED_MLP 8   /* LGN_AMD_NO_FUSED_MLP=1: every CGMLP as its own launches */
+#define LGN_NET_FUSED_MLP_FWD 8  /* LGN_AMD_FUSED_MLP=1: the CGMLP forward rides on the level forward kernel (csrc/mlp_dev.hpp; off by
+                                    default: measured slower than the separate launches on MI355X) */
 #define LGN_NET_MOMENTS_V1 16    /* LGN_AMD_MOMENTS_V1=1: component-chunked moments kernels (with LGN_NET_NO_STATIC) */
+#define LGN_NET_FUSED_MLP_BWD 32 /* LGN_AMD_FUSED_MLP_BWD=1: the CGMLP backward rides on the level backward kernel (off by default) */
 
 int lgn_step_param_slots(const lgn_net_desc* d, int decoder);
 long long lgn_step_workspace_doubles(const lgn_net_desc* d);

@@ -27,8 +27,9 @@ namespace lgn {
 // -- every launcher and every sizing helper below receives them as an argument and none reads the environment itself.
 constexpr int LVL_DEC_PAIRWISE = 2;    // decoder levels as O(N^2) pair sweeps instead of the separable form
 constexpr int LVL_LEVEL_V2 = 4;        // three-kernel level backward also for N <= 40
-constexpr int LVL_NO_FUSED_MLP = 8;    // CGMLP as separate launches even where it could ride on the level kernels
+constexpr int LVL_FUSED_MLP_FWD = 8;   // CGMLP forward as the tail of the level forward kernel (mlp_dev.hpp; off by default: measured slower)
 constexpr int LVL_MOMENTS_V1 = 16;     // table-driven levels: component-chunked moments kernels
+constexpr int LVL_FUSED_MLP_BWD = 32;  // CGMLP backward as the head of the one-kernel level backward (off by default: measured slower)
 int level_flags_from_env();
 
 // The level's CGMLP (lgn/models/lgn_levels.py:191-227) riding on the level kernel (mlp_dev.hpp): forward as the tail of

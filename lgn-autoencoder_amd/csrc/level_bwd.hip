@@ -435,7 +435,7 @@ static bool use_v3(int N, int flags) { return !(flags & LVL_LEVEL_V2) && level_b
 // does the level backward for N-particle jets run as the one kernel that can carry the input stage's backward (LevelBwdArgs::part_in0)?
 bool level_bwd_carries_input(int N, int flags) { return use_v3(N, flags); }
 bool level_bwd_fuses_mlp(int N, int C, int CO, int H, int nlin, int act, int decoder, int flags) {
-  return use_v3(N, flags) && level_mlp_fusable(N, C, CO, H, nlin, act) && !(flags & LVL_NO_FUSED_MLP) && !(decoder && dec_pairwise(flags));
+  return (flags & LVL_FUSED_MLP_BWD) && use_v3(N, flags) && level_mlp_fusable(N, C, CO, H, nlin, act) && !(decoder && dec_pairwise(flags));
 }
 
 // number of partial rows the backward launch writes (host side must size the workspace with these)

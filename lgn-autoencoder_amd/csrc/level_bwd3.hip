@@ -55,6 +55,7 @@ constexpr int TS = 18;
 LGN_STAMP_DECL
 }  // namespace
 LGN_STAMP_READER(lgn_debug_stamps_bwd3)
+FM_STAMP_READER(lgn_debug_stamps_fm_bwd)
 
 // NWV = waves per workgroup (4; 8 was measured for small batches: 31 -> 28.5 us at 64 jets -- a lone workgroup already keeps
 // its CU's SIMDs two thirds busy, the idle CUs are what a small batch wastes: level_jet_split spreads a jet over several CUs)
@@ -90,8 +91,11 @@ struct Bwd3 {
 //   outputs   node gradient, position gradient and bias gradients from O(N C) closed forms.
 // gsx_off (with a.mlp.wb): offset in doubles of the [N][2 CO] block that receives the CGMLP phase's result -- the level's upstream
 // scalar gradient -- behind both the level's LDS and the phase's (mlp_dev.hpp: bwd_doubles).
-template <int C, bool DEC, bool SEP, int NWV>
-__global__ __launch_bounds__(64 * NWV) void level_bwd3_kernel(LevelBwdArgs<double> a, int gsx_off) {
+// (amdgpu_waves_per_eu(2): two workgroups per CU is what the 77 KB of LDS are sized for; without the bound the register allocator
+// takes accumulation registers beyond 256 for the CGMLP phase -- 396 in total -- and the launch silently runs one workgroup per CU)
+// MLP: the instantiation that carries the CGMLP backward as its head -- a kernel of its own (the plain kernel pays nothing for it).
+template <int C, bool DEC, bool SEP, int NWV, bool MLP>
+__global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2))) void level_bwd3_kernel(LevelBwdArgs<double> a, int gsx_off) {
   using F = Bwd3<C, DEC, NWV>;
   constexpr int BLK = F::BLK;
   using G = GA3<C>;
@@ -115,8 +119,8 @@ __global__ __launch_bounds__(64 * NWV) void level_bwd3_kernel(LevelBwdArgs<doubl
   double* agl = wm + 4 * CO * K;                               //              N * 2C * 10 aggregate [n][q*C+c][s2|v8]
   double* sm = tr + F::scratch(N, CO);                         // decoder: 50 C jet-level sums
   // the CGMLP's backward as the head of this kernel (mlp_dev.hpp): its LDS aliases everything above, its result stays in gsx
-  constexpr bool MLP_OK = C <= 4 && (!DEC || SEP) && NWV == 4;
-  const bool has_mlp = MLP_OK && a.mlp.wb != nullptr;
+  constexpr bool MLP_OK = MLP;
+  constexpr bool has_mlp = MLP;
   double* gsx = reinterpret_cast<double*>(smem_raw) + gsx_off;  // [N][2 CO], feature k = 2o + z
   uint8_t* mk = has_mlp ? reinterpret_cast<uint8_t*>(gsx + ((N * 2 * CO + 1) & ~1)) : reinterpret_cast<uint8_t*>(sm + F::SEPSZ);
   __shared__ int fm_ids[4];
@@ -998,7 +1002,10 @@ static int launch_bwd3_w(const LevelBwdArgs<double>& a, int split, hipStream_t s
   }
   LGN_CHECK_ARG(smem <= 160 * 1024, "level_bwd: N=%d C=%d needs %zu B of LDS", a.N, a.C, smem);
   LGN_CHECK_ARG(a.CO <= 8, "level_bwd: C_out=%d unsupported (1..8)", a.CO);
-  auto kern = level_bwd3_kernel<C, DEC, SEP, NWV>;
+  auto kern = level_bwd3_kernel<C, DEC, SEP, NWV, false>;
+  if constexpr (C <= 4 && (!DEC || SEP) && NWV == 4) {
+    if (a.mlp.wb) kern = level_bwd3_kernel<C, DEC, SEP, NWV, true>;
+  }
   if (smem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   hipLaunchKernelGGL(kern, dim3(a.B, split), dim3(64 * NWV), smem, stream, a, gsx_off);
   LGN_CHECK_LAUNCH();

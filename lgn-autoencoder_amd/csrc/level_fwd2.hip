@@ -27,6 +27,7 @@ namespace lgn {
 typedef double v4d __attribute__((ext_vector_type(4)));
 LGN_STAMP_DECL
 LGN_STAMP_READER(lgn_debug_stamps_fwd2)
+FM_STAMP_READER(lgn_debug_stamps_fm_fwd)
 
 __device__ __forceinline__ double dpp_quad(double v, int ctrl_is_xor2) {
   // quad_perm [1,0,3,2] = 0xB1 (xor 1), [2,3,0,1] = 0x4E (xor 2)
@@ -69,8 +70,10 @@ struct Fwd2 {
 //   A1_i = e0 sum_j v_j            A2_i = R1 (p_i sum_j s_j - sum_j s_j p_j)
 //   A4_i = e0 sum_j s_j            A3_i = R1 (<sum_j v_j, p_i> - sum_j <v_j, p_j>) / 2
 // O(N C) instead of O(N^2 C) work per jet, same values up to summation order.  SEP = false keeps the pair sweep.
-// mlp_off (with a.mlp.wb): offset in doubles of the CGMLP phase's own LDS (first-layer image | MLP input rows) behind the level's.
-template <int C, bool DEC, bool SEP>
+// MLP: the instantiation that carries the level's CGMLP as its tail (a.mlp, mlp_dev.hpp) -- a kernel of its own, so that the plain
+// level kernel pays nothing for it (measured: 0.4 - 1.2 us per launch when the phase was a run-time branch of one kernel).
+// mlp_off (MLP): offset in doubles of the CGMLP phase's own LDS (images of the first two layers | MLP input rows) behind the level's.
+template <int C, bool DEC, bool SEP, bool MLP>
 __global__ __launch_bounds__(2 * BLOCK) void level_fwd2_kernel(LevelArgs<double> a, int chunk, int mlp_off) {
   using F = Fwd2<C, DEC>;
   constexpr int NG = F::NG;
@@ -86,18 +89,21 @@ __global__ __launch_bounds__(2 * BLOCK) void level_fwd2_kernel(LevelArgs<double>
   double* sums = agl + chunk * F::AGS;                                // 20 C: jet-level sums of the separable form
   uint8_t* mk = reinterpret_cast<uint8_t*>(sums + 20 * C);            // N
   // the level's CGMLP as the tail of this kernel (mlp_dev.hpp; the host launches it for one-chunk, four-wave shapes only)
-  constexpr bool MLP_OK = C <= 4 && (!DEC || SEP);
-  const bool has_mlp = MLP_OK && a.mlp.wb != nullptr;
+  constexpr bool MLP_OK = MLP;
+  constexpr bool has_mlp = MLP;
   double* fimg0 = reinterpret_cast<double*>(smem_raw) + mlp_off;       // first-layer image
-  double* fx0 = fimg0 + fm::IMG0;                                      // MLP input rows [row][S0]
+  double* fimg1 = fimg0 + fm::IMG0;                                    // second-layer image
+  double* fx0 = fimg1 + fm::IMG;                                       // MLP input rows [row][S0]
   __shared__ int fm_ids[4];
   fm::W0Regs<4> fw0;
+  fm::WRegs<4> fw1;
   const fm::Dims md = fm::make_dims(2 * CO, a.mlp.H);
 
   STAMP(0);
   if constexpr (MLP_OK) {
     if (has_mlp) {
       fm::stage0_issue<4>(a.mlp.wb, md, wave, lane, fw0);
+      fm::stage_issue<4>(a.mlp.wb, 1, md, wave, lane, fw1);
       fm::role_publish(fm_ids, wave, lane);
       for (int e = tid; e < fm::passes(N) * fm::ROWS * fm::S0; e += nthr) fx0[e] = 0.0;
     }
@@ -198,7 +204,10 @@ __global__ __launch_bounds__(2 * BLOCK) void level_fwd2_kernel(LevelArgs<double>
     }
   }
   if constexpr (MLP_OK) {
-    if (has_mlp) fm::stage0_commit<4>(fimg0, wave, lane, fw0);
+    if (has_mlp) {
+      fm::stage0_commit<4>(fimg0, wave, lane, fw0);
+      fm::stage_commit<4>(fimg1, 1, wave, lane, fw1);
+    }
   }
   __syncthreads();
   STAMP(1);
@@ -262,6 +271,81 @@ __global__ __launch_bounds__(2 * BLOCK) void level_fwd2_kernel(LevelArgs<double>
   // in chunks of `chunk` rows (a multiple of 16; all of them when they fit the LDS budget)
   const int ngroups = (N + 3) >> 2, gper = (ngroups + (int)gridDim.y - 1) / (int)gridDim.y;
   const int rlo = min(N, 4 * (int)blockIdx.y * gper), rhi = min(N, rlo + 4 * gper);
+  // ---- power + CatMix.  A lane owns one row's scalar (wave 0) or one (row, component m) of the vectors (waves 1-3):
+  // it builds that item's cat vector x[k] once in registers and runs all out channels over it; the weights are
+  // wave-uniform reads.  Cat order per irrep: [aggregate (2C), node (C), power (2C)]; power (0,0) = [<v,v>, s*s],
+  // (1,1) = [v*s, s*v]
+  auto catmix = [&](int c0, int c1) {
+    constexpr int K = 5 * C;
+    const int nr = c1 - c0;
+    const size_t plo = (size_t)B * N * CO;
+    if (wave == 0) {
+      for (int rl = lane; rl < nr; rl += 64) {
+        const int r = c0 + rl;
+        const double* st = agl + rl * F::AGS;
+        const double* ni = nd + r * F::NS;
+        cx<double> x[K];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          const cx<double> sc = {ni[c * 10], ni[c * 10 + 1]};
+          cx<double> v[4];
+#pragma unroll
+          for (int mm = 0; mm < 4; ++mm) v[mm] = {ni[c * 10 + 2 + mm], ni[c * 10 + 6 + mm]};
+          cx<double> vv = bil2(v, v);
+          vv.r *= 0.5;  vv.i *= 0.5;
+          x[c] = {st[F::A3 + 2 * c], st[F::A3 + 2 * c + 1]};
+          x[C + c] = {st[F::A4 + 2 * c], st[F::A4 + 2 * c + 1]};
+          x[2 * C + c] = sc;
+          x[3 * C + c] = vv;
+          x[4 * C + c] = cmul(sc, sc);
+        }
+#pragma unroll 2
+        for (int o = 0; o < CO; ++o) {
+          const double* wr = wm + (0 * CO + o) * K;
+          const double* wi = wm + (1 * CO + o) * K;
+          cx<double> acc = {0, 0};
+#pragma unroll
+          for (int k = 0; k < K; ++k) cfma(acc, cx<double>{wr[k], wi[k]}, x[k]);
+          const size_t e = ((size_t)b * N + r) * CO + o;
+          a.s_out[e] = acc.r;
+          a.s_out[plo + e] = acc.i;
+          if constexpr (MLP_OK) {
+            if (has_mlp) {                                    // the MLP's input row, feature k = 2o + z
+              fx0[rl * fm::S0 + 2 * o] = acc.r;
+              fx0[rl * fm::S0 + 2 * o + 1] = acc.i;
+            }
+          }
+        }
+      }
+    } else {
+      for (int it = lane + 64 * (wave - 1); it < nr * 4; it += 64 * (nw - 1)) {
+        const int rl = it >> 2, m = it & 3, r = c0 + rl;
+        const double* st = agl + rl * F::AGS;
+        const double* ni = nd + r * F::NS;
+        cx<double> x[K];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          const cx<double> sc = {ni[c * 10], ni[c * 10 + 1]};
+          const cx<double> v = {ni[c * 10 + 2 + m], ni[c * 10 + 6 + m]};
+          x[c] = {st[F::A1 + (c * 4 + m) * 2], st[F::A1 + (c * 4 + m) * 2 + 1]};
+          x[C + c] = {st[F::A2 + (c * 4 + m) * 2], st[F::A2 + (c * 4 + m) * 2 + 1]};
+          x[2 * C + c] = v;
+          x[3 * C + c] = x[4 * C + c] = cmul(v, sc);
+        }
+#pragma unroll 2
+        for (int o = 0; o < CO; ++o) {
+          const double* wr = wm + 2 * CO * K + (0 * CO + o) * K;
+          const double* wi = wm + 2 * CO * K + (1 * CO + o) * K;
+          cx<double> acc = {0, 0};
+#pragma unroll
+          for (int k = 0; k < K; ++k) cfma(acc, cx<double>{wr[k], wi[k]}, x[k]);
+          const size_t e = ((size_t)b * N + r) * CO + o;
+          a.v_out[e * 4 + m] = acc.r;
+          a.v_out[plo * 4 + e * 4 + m] = acc.i;
+        }
+      }
+    }
+    };
   for (int c0 = rlo; c0 < rhi; c0 += chunk) {
   const int c1 = min(rhi, c0 + chunk);
   if constexpr (DEC && SEP) {
@@ -473,95 +557,27 @@ __global__ __launch_bounds__(2 * BLOCK) void level_fwd2_kernel(LevelArgs<double>
   }
   STAMP(21);
 
-  // ---- power + CatMix.  A lane owns one row's scalar (wave 0) or one (row, component m) of the vectors (waves 1-3):
-  // it builds that item's cat vector x[k] once in registers and runs all out channels over it; the weights are
-  // wave-uniform reads.  Cat order per irrep: [aggregate (2C), node (C), power (2C)]; power (0,0) = [<v,v>, s*s],
-  // (1,1) = [v*s, s*v]
-  {
-    constexpr int K = 5 * C;
-    const int nr = c1 - c0;
-    const size_t plo = (size_t)B * N * CO;
-    if (wave == 0) {
-      for (int rl = lane; rl < nr; rl += 64) {
-        const int r = c0 + rl;
-        const double* st = agl + rl * F::AGS;
-        const double* ni = nd + r * F::NS;
-        cx<double> x[K];
-#pragma unroll
-        for (int c = 0; c < C; ++c) {
-          const cx<double> sc = {ni[c * 10], ni[c * 10 + 1]};
-          cx<double> v[4];
-#pragma unroll
-          for (int mm = 0; mm < 4; ++mm) v[mm] = {ni[c * 10 + 2 + mm], ni[c * 10 + 6 + mm]};
-          cx<double> vv = bil2(v, v);
-          vv.r *= 0.5;  vv.i *= 0.5;
-          x[c] = {st[F::A3 + 2 * c], st[F::A3 + 2 * c + 1]};
-          x[C + c] = {st[F::A4 + 2 * c], st[F::A4 + 2 * c + 1]};
-          x[2 * C + c] = sc;
-          x[3 * C + c] = vv;
-          x[4 * C + c] = cmul(sc, sc);
-        }
-#pragma unroll 2
-        for (int o = 0; o < CO; ++o) {
-          const double* wr = wm + (0 * CO + o) * K;
-          const double* wi = wm + (1 * CO + o) * K;
-          cx<double> acc = {0, 0};
-#pragma unroll
-          for (int k = 0; k < K; ++k) cfma(acc, cx<double>{wr[k], wi[k]}, x[k]);
-          const size_t e = ((size_t)b * N + r) * CO + o;
-          a.s_out[e] = acc.r;
-          a.s_out[plo + e] = acc.i;
-          if constexpr (MLP_OK) {
-            if (has_mlp) {                                    // the MLP's input row, feature k = 2o + z
-              fx0[rl * fm::S0 + 2 * o] = acc.r;
-              fx0[rl * fm::S0 + 2 * o + 1] = acc.i;
-            }
-          }
-        }
-      }
-    } else {
-      for (int it = lane + 64 * (wave - 1); it < nr * 4; it += 64 * (nw - 1)) {
-        const int rl = it >> 2, m = it & 3, r = c0 + rl;
-        const double* st = agl + rl * F::AGS;
-        const double* ni = nd + r * F::NS;
-        cx<double> x[K];
-#pragma unroll
-        for (int c = 0; c < C; ++c) {
-          const cx<double> sc = {ni[c * 10], ni[c * 10 + 1]};
-          const cx<double> v = {ni[c * 10 + 2 + m], ni[c * 10 + 6 + m]};
-          x[c] = {st[F::A1 + (c * 4 + m) * 2], st[F::A1 + (c * 4 + m) * 2 + 1]};
-          x[C + c] = {st[F::A2 + (c * 4 + m) * 2], st[F::A2 + (c * 4 + m) * 2 + 1]};
-          x[2 * C + c] = v;
-          x[3 * C + c] = x[4 * C + c] = cmul(v, sc);
-        }
-#pragma unroll 2
-        for (int o = 0; o < CO; ++o) {
-          const double* wr = wm + 2 * CO * K + (0 * CO + o) * K;
-          const double* wi = wm + 2 * CO * K + (1 * CO + o) * K;
-          cx<double> acc = {0, 0};
-#pragma unroll
-          for (int k = 0; k < K; ++k) cfma(acc, cx<double>{wr[k], wi[k]}, x[k]);
-          const size_t e = ((size_t)b * N + r) * CO + o;
-          a.v_out[e * 4 + m] = acc.r;
-          a.v_out[plo * 4 + e * 4 + m] = acc.i;
-        }
-      }
-    }
+  if constexpr (MLP_OK) {
+    if (has_mlp) break;                                  // (one chunk) the CatMix runs below, with the CGMLP's weights in flight
   }
+  catmix(c0, c1);
   STAMP(22);
   if (c1 < rhi) __syncthreads();                         // the chunk's aggregate rows are reused
   }
   if constexpr (MLP_OK) {
     if (has_mlp) {     // (one chunk: local row = row - rlo.  Outside the chunk loop: inside it, every lane-derived address of the phase
                        //  is hoisted in front of the pair sweep as a loop invariant and spills there)
+      fm::WRegs<4> fw2, fw3;                             // W_2, W_3 arrive under the CatMix
+      fm::stage_issue<4>(a.mlp.wb, 2, md, wave, lane, fw2);
+      fm::stage_issue<4>(a.mlp.wb, 3, md, wave, lane, fw3);
+      catmix(rlo, rhi);
+      STAMP(22);
       __syncthreads();                                   // the MLP input rows are complete; the level's LDS is dead
       const int role = fm::role_resolve(fm_ids, wave);
-      fm::WRegs<4> fwr;
-      fm::stage_issue<4>(a.mlp.wb, 1, md, wave, lane, fwr);
       double* so = a.mlp.s_out + ((size_t)b * N + rlo) * CO;
       double* img = reinterpret_cast<double*>(smem_raw);
       const size_t plm = (size_t)B * N * CO;
-      fm::fwd_phase<false>(a.mlp.wb, md, 0, img, fimg0, fx0, rhi - rlo, fwr, role, so, plm, CO);   // (LeakyReLU: level_mlp_fusable)
+      fm::fwd_phase<false>(a.mlp.wb, md, 0, img, fimg0, fimg1, fx0, rhi - rlo, fw2, fw3, role, so, plm, CO);   // (LeakyReLU: level_mlp_fusable)
     }
   }
   STAMP(40);
@@ -609,7 +625,10 @@ static int launch_level_fwd2(const LevelArgs<double>& a, hipStream_t stream) {
     if (smem < dec_out_loss_bytes(a.N, a.CO)) smem = dec_out_loss_bytes(a.N, a.CO);
   }
   LGN_CHECK_ARG(smem <= 160 * 1024, "level_fwd: N=%d C=%d needs %zu B of LDS (> 160 KiB)", a.N, a.C, smem);
-  auto kern = level_fwd2_kernel<C, DEC, SEP>;
+  auto kern = level_fwd2_kernel<C, DEC, SEP, false>;
+  if constexpr (C <= 4 && (!DEC || SEP)) {
+    if (a.mlp.wb) kern = level_fwd2_kernel<C, DEC, SEP, true>;
+  }
   if (smem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
@@ -625,7 +644,7 @@ static int launch_level_fwd2(const LevelArgs<double>& a, hipStream_t stream) {
 
 bool level_fwd_carries_loss(int N, int flags) { return N <= 40 && !(flags & LVL_DEC_PAIRWISE); }
 bool level_fwd_fuses_mlp(int N, int C, int CO, int H, int nlin, int act, int decoder, int flags) {
-  return level_mlp_fusable(N, C, CO, H, nlin, act) && !(flags & LVL_NO_FUSED_MLP) && !(decoder && (flags & LVL_DEC_PAIRWISE));
+  return (flags & LVL_FUSED_MLP_FWD) && level_mlp_fusable(N, C, CO, H, nlin, act) && !(decoder && (flags & LVL_DEC_PAIRWISE));
 }
 
 template <>

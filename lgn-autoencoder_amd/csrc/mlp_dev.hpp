@@ -31,6 +31,27 @@ namespace fm {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
+// phase stamps of the debug build (make stamps; tools/kbench.py KB_STAMPS=lgn_debug_stamps_fm_*): lane 0 of every wave of workgroup
+// 0 records the shader clock at FM_STAMP(role, i) -> slot role * 32 + i
+#ifdef LGN_STAMPS
+static __device__ long long fm_stamps[128];
+#define FM_STAMP(role, i) do { if ((threadIdx.x & 63) == 0 && blockIdx.x == 0 && blockIdx.y == 0) fm_stamps[(role) * 32 + (i)] = clock64(); } while (0)
+#define FM_STAMP_READER(name) \
+  extern "C" int name(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(lgn::fm::fm_stamps), sizeof(long long) * 128); }
+#else
+#define FM_STAMP(role, i) do { } while (0)
+#define FM_STAMP_READER(name)
+#endif
+
+// Workgroup barrier that orders LDS only.  __syncthreads() also waits for every global access in flight (s_waitcnt vmcnt(0)): the
+// weight prefetch of the next layer and, in the backward, 100 KB of weight-gradient stores per workgroup -- measured: a backward layer
+// step waits 2 - 3 us for its own stores.  Nothing the phases exchange between waves goes through global memory.
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 constexpr int NT = 3;            // 16-neuron tiles of a hidden layer
 constexpr int HP = 16 * NT;      // padded hidden width
 constexpr int S = 50;            // row stride of hidden images and G / X tiles (== 2 mod 4: conflict-free ds_read_b64 of fragments)
@@ -47,7 +68,7 @@ __host__ __device__ constexpr int off_w(int l, int D, int H) { return l == 0 ? 0
 __host__ __device__ constexpr int psize(int D, int H) { return off_w(NLIN - 1, D, H) + D * H + D; }
 // LDS of the phase, in doubles
 __host__ __device__ constexpr int fwd_alias_doubles() { return 2 * IMG; }                                   // over the sweep's dead data
-__host__ __device__ constexpr int fwd_own_doubles(int rows) { return IMG0 + passes(rows) * ROWS * S0; }     // first-layer image | input rows
+__host__ __device__ constexpr int fwd_own_doubles(int rows) { return IMG0 + IMG + passes(rows) * ROWS * S0; }   // images of layers 0, 1 | input rows
 __host__ __device__ constexpr int bwd_doubles() { return 2 * IMG + IMG0 + ROWS * S0 + 2 * TILE; }           // images | W0 | X0 | G | X
 
 struct Dims {
@@ -91,36 +112,37 @@ struct WRegs {
   double w[NR];
   double b;
 };
-// layers 1 .. 6 (H input columns); the output layer fills 16 rows only
-template <int NSW>
-__device__ __forceinline__ void stage_issue(const double* __restrict__ wb, int l, const Dims& d, int sw, int lane, WRegs<NSW>& r) {
-  // (the weights are read-only, so nothing else stops the compiler from hoisting the loads of ALL layers to the top of the
-  // phase -- measured: 102 -> 255 registers)
+// layers 1 .. 6 (H input columns); the output layer (OUT) fills 16 rows only.  Straight-line code: every row index is compared with
+// compile-time bounds only, run-time tests (o < Hout, lane < H) select the ADDRESS (clamped) and the VALUE -- a branch around a load
+// would put the load and its s_waitcnt into a block of its own and serialise the twelve round trips (measured: 3 us per layer).
+template <int NSW, bool OUT>
+__device__ __forceinline__ void stage_issue_t(const double* __restrict__ wb, int l, const Dims& d, int sw, int lane, WRegs<NSW>& r) {
+  // (the weights are read-only: without this nothing stops the compiler from hoisting the loads of ALL layers to the top of the phase)
   asm volatile("" ::: "memory");
-  const int Hout = l == NLIN - 1 ? d.D : d.H, H = d.H;
+  const int Hout = OUT ? d.D : d.H, H = d.H;
   const double* W = wb + off_w(l, d.D, H);
-  const int rows = l == NLIN - 1 ? 16 : HP;
+  constexpr int rows = OUT ? 16 : HP;
   const bool kok = lane < H;
-  // one 32-bit byte offset per lane, advanced by a uniform step: scalar base + lane offset addressing, no per-row address registers
-  const char* base = reinterpret_cast<const char*>(W);
-  unsigned voff = (unsigned)(sw * H + (kok ? lane : 0)) * 8u;
-  const unsigned step = (unsigned)(NSW * H) * 8u;
+  // one 32-bit element offset per lane, advanced by a uniform step
+  unsigned voff = (unsigned)(sw * H + (kok ? lane : 0));
+  const unsigned step = (unsigned)(NSW * H);
 #pragma unroll
   for (int i = 0; i < WRegs<NSW>::NR; ++i) {
-    const int o = sw + NSW * i;                            // (wave uniform)
     r.w[i] = 0.0;
-    if (o < rows) {                                        // (compile time for all but the output layer)
-      const bool ok = kok && o < Hout;
-      const double v = *reinterpret_cast<const double*>(base + (o < Hout ? voff : 0u));
+    if (NSW * i < rows) {                                  // (compile time: sw < NSW)
+      const bool ok = kok && (sw + NSW * i) < Hout;
+      const double v = W[(sw + NSW * i) < Hout ? voff : 0u];
       r.w[i] = ok ? v : 0.0;
     }
     voff += step;
   }
-  r.b = 0.0;
-  if (sw == 0) {
-    const double bv = W[Hout * H + (lane < Hout ? lane : 0)];
-    r.b = lane < Hout ? bv : 0.0;
-  }
+  const double bv = W[Hout * H + (lane < Hout ? lane : 0)];
+  r.b = lane < Hout ? bv : 0.0;
+}
+template <int NSW>
+__device__ __forceinline__ void stage_issue(const double* __restrict__ wb, int l, const Dims& d, int sw, int lane, WRegs<NSW>& r) {
+  if (l == NLIN - 1) stage_issue_t<NSW, true>(wb, l, d, sw, lane, r);
+  else stage_issue_t<NSW, false>(wb, l, d, sw, lane, r);
 }
 template <int NSW>
 __device__ __forceinline__ void stage_commit(double* img, int l, int sw, int lane, const WRegs<NSW>& r) {
@@ -129,7 +151,7 @@ __device__ __forceinline__ void stage_commit(double* img, int l, int sw, int lan
     double* dst = img + sw * S + lane;
 #pragma unroll
     for (int i = 0; i < WRegs<NSW>::NR; ++i)
-      if (sw + NSW * i < rows) dst[NSW * i * S] = r.w[i];
+      if (NSW * i < rows) dst[NSW * i * S] = r.w[i];       // (compile time at every call site: l is a literal)
     if (sw == 0) img[lane * S + HP] = r.b;
   }
 }
@@ -150,11 +172,8 @@ __device__ __forceinline__ void stage0_issue(const double* __restrict__ wb, cons
     const double v = wb[ok ? o * d.D + k : 0];
     r.w[i] = ok ? v : 0.0;
   }
-  r.b = 0.0;
-  if (sw == 0) {
-    const double bv = wb[d.H * d.D + (lane < d.H ? lane : 0)];
-    r.b = lane < d.H ? bv : 0.0;
-  }
+  const double bv = wb[d.H * d.D + (lane < d.H ? lane : 0)];
+  r.b = lane < d.H ? bv : 0.0;
 }
 template <int NSW>
 __device__ __forceinline__ void stage0_commit(double* img0, int sw, int lane, const W0Regs<NSW>& r) {
@@ -226,44 +245,86 @@ __device__ __forceinline__ v4d layer_out(const double* img, bool full, int lane,
 }
 
 // ---- forward phase (tail of level_fwd2_kernel; every thread of the 256-thread workgroup calls it) ---------------------------
-//   img   : 2 * IMG doubles of LDS (may alias anything dead after the caller's last barrier)
-//   img0  : first-layer image, staged by the caller at kernel start (stage0_issue / stage0_commit) -- visible
+//   img   : 2 * IMG doubles of LDS, images A | B (may alias anything dead after the caller's last barrier)
+//   img0, img1 : images of the first two layers, staged by the caller at kernel start (stage0_* / stage_*<4>(.., 1, ..)) -- visible
 //   x0    : the workgroup's `nrows` MLP input rows [row][S0] (k = 2c + z, zero padded to 16 columns and to whole passes) -- visible
-//   wr    : registers holding W_1, issued by the caller (stage_issue<4>(wb, 1, ...))
+//   w2, w3 : registers with W_2, W_3, issued by the caller (all four waves, stage_issue<4>) BEFORE its last phase: a weight image is
+//            4 - 5 k cycles away (512 workgroups pull the same 18 KB through L2 at once), more than a layer lasts
 //   s_out : &out[plane 0][first row of this workgroup][channel 0]; plane = stride between re / im
-// The caller must put a barrier between this call and any reuse of img / x0.
+// Two programs with the same barrier sequence: the chain waves (roles 0, 1: one 16-row tile each) only compute, the other two waves
+// stream the weights, two layers ahead, from two register sets:
+//   chain   first      | 1 (img1) | 2 (A) | 3 (B)        | 4 (A)     | 5 (B)     | out (A)
+//   worker  ld W4, W5  | --       | --    | W4->A, ld W6 | W5->B     | W6->A     |
+// (W_2 -> A and W_3 -> B are committed by everybody at the start.)  The caller must put a barrier between this call and any reuse
+// of img / x0.
 template <bool GEN>
-__device__ __forceinline__ void fwd_phase(const double* wb, const Dims& d, int act, double* img, const double* img0,
-                                          const double* x0, int nrows, WRegs<4>& wr, int role, double* __restrict__ s_out, size_t plane, int CO) {
-  const int tid = threadIdx.x, lane = tid & 63, sw = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int c = lane & 15, g = lane >> 4;
+__device__ __forceinline__ void fwd_phase(const double* __restrict__ wb_in, const Dims& d, int act, double* img, const double* img0,
+                                          const double* img1, const double* x0, int nrows, WRegs<4>& w2, WRegs<4>& w3, int role,
+                                          double* __restrict__ s_out, size_t plane, int CO) {
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  double* imgA = img;
+  double* imgB = img + IMG;
   for (int p = 0; p * ROWS < nrows; ++p) {
-    // (an opaque copy of the pointer per pass: otherwise the address of every weight load of every layer -- 144 registers -- is
-    // hoisted out of this loop as an invariant)
-    asm volatile("" : "+s"(wb));
-    const int row0 = p * ROWS + 16 * role;                 // this chain wave's tile
-    const bool chain = role < 2 && row0 < nrows;
-    if (p > 0) stage_issue<4>(wb, 1, d, sw, lane, wr);
-    stage_commit<4>(img + IMG, 1, sw, lane, wr);
-    stage_issue<4>(wb, 2, d, sw, lane, wr);
-    v4d h[2][NT];
-    if (chain) layer_first<GEN>(img0, x0 + row0 * S0, lane, act, h[0]);
-    __syncthreads();
-#pragma unroll
-    for (int l = 1; l <= 5; ++l) {
-      stage_commit<4>(img + ((l + 1) & 1) * IMG, l + 1, sw, lane, wr);
-      if (l + 2 < NLIN) stage_issue<4>(wb, l + 2, d, sw, lane, wr);
-      if (chain) layer_hidden<GEN>(img + (l & 1) * IMG, d.full, lane, act, h[(l - 1) & 1], h[l & 1]);
-      __syncthreads();
+    // (opaque per pass: every lane-derived LDS address and every weight address of the pass is otherwise hoisted out of this loop
+    // as an invariant, all of them live at once -- hundreds of registers, spilled at the kernel's entry)
+    int lane = tid & 63, opaque0 = 0;
+    asm volatile("" : "+v"(lane), "+s"(opaque0));
+    const double* __restrict__ wb = wb_in + opaque0;
+    const int c = lane & 15, g = lane >> 4;
+    if (p > 0) {
+      stage_issue<4>(wb, 2, d, wave, lane, w2);
+      stage_issue<4>(wb, 3, d, wave, lane, w3);
     }
-    if (chain) {
-      const v4d o = layer_out(img, d.full, lane, h[1]);
+    stage_commit<4>(imgA, 2, wave, lane, w2);
+    stage_commit<4>(imgB, 3, wave, lane, w3);
+    if (role < 2) {
+      const int row0 = p * ROWS + 16 * role;               // this chain wave's tile
+      const bool chain = row0 < nrows;
+      v4d h[2][NT];
+      FM_STAMP(role, 0);
+      if (chain) layer_first<GEN>(img0, x0 + row0 * S0, lane, act, h[0]);
+      FM_STAMP(role, 1);
+      lds_barrier();
+      FM_STAMP(role, 2);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int k = g + 4 * r, row = row0 + c;
-        if (k < d.D && row < nrows) s_out[(size_t)(k & 1) * plane + (size_t)row * CO + (k >> 1)] = o[r];
+      for (int l = 1; l <= 5; ++l) {
+        if (chain) layer_hidden<GEN>(l == 1 ? img1 : ((l & 1) ? imgB : imgA), d.full, lane, act, h[(l - 1) & 1], h[l & 1]);
+        FM_STAMP(role, 2 + 3 * l);
+        lds_barrier();
+        FM_STAMP(role, 3 + 3 * l);
       }
+      if (chain) {
+        const v4d o = layer_out(imgA, d.full, lane, h[1]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int k = g + 4 * r, row = row0 + c;
+          if (k < d.D && row < nrows) s_out[(size_t)(k & 1) * plane + (size_t)row * CO + (k >> 1)] = o[r];
+        }
+      }
+      FM_STAMP(role, 19);
+    } else {
+      const int sw = role - 2;
+      WRegs<2> r0, r1;
+      FM_STAMP(role, 0);
+      stage_issue<2>(wb, 4, d, sw, lane, r0);
+      stage_issue<2>(wb, 5, d, sw, lane, r1);
+      FM_STAMP(role, 1);
+      lds_barrier();                                       // chain: first layer done
+      lds_barrier();                                       // layer 1 (img1)
+      lds_barrier();                                       // layer 2 (A)
+      FM_STAMP(role, 9);
+      stage_commit<2>(imgA, 4, sw, lane, r0);
+      stage_issue<2>(wb, 6, d, sw, lane, r0);
+      FM_STAMP(role, 10);
+      lds_barrier();                                       // layer 3 (B)
+      stage_commit<2>(imgB, 5, sw, lane, r1);
+      lds_barrier();                                       // layer 4 (A)
+      stage_commit<2>(imgA, 6, sw, lane, r0);
+      FM_STAMP(role, 17);
+      lds_barrier();                                       // layer 5 (B)
+      FM_STAMP(role, 18);
     }
+    if ((p + 1) * ROWS < nrows) lds_barrier();             // the next pass rewrites A while this pass's output layer may still read it
   }
 }
 
@@ -306,30 +367,48 @@ __device__ __forceinline__ void put_tile(double* tile16 /* the wave's 16 rows */
 #pragma unroll
     for (int r = 0; r < 4; ++r) tile16[c * S + 16 * u + g + 4 * r] = x[u][r];
 }
-// dW_l tiles q, q + Q, ... of this pass's 32 rows -> the partial row; worker Q - 1 also sums the bias gradient
-__device__ __forceinline__ void dw_tiles(int l, const double* Gt, const double* Xt /* l == 0: the input rows, stride S0 */, double* __restrict__ prow,
-                                         const Dims& d, int q, int Q, int lane) {
+// one 16 x 16 tile (o-tile u, k-tile uk) of dW_l over this pass's 32 rows, two accumulation chains; stored into the partial row
+__device__ __forceinline__ void dw_tile(const double* Gt, const double* Xt, int xs, int u, int uk, double* __restrict__ pW, int Hout, int Hin, int lane) {
   const int c = lane & 15, g = lane >> 4;
-  const int Hin = l == 0 ? d.D : d.H, Hout = l == NLIN - 1 ? d.D : d.H;
-  const int nto = (d.H + 15) >> 4;
-  const int nto_l = l == NLIN - 1 ? 1 : nto, ntk_l = l == 0 ? 1 : nto, total = nto_l * ntk_l;
-  const int xs = l == 0 ? S0 : S;
-  double* pW = prow + off_w(l, d.D, d.H);
-  for (int tix = q; tix < total; tix += Q) {
-    const int u = tix / ntk_l, uk = tix - u * ntk_l;
-    const double* ga = Gt + g * S + 16 * u + c;
-    const double* xb = Xt + g * xs + 16 * uk + c;
-    v4d a0 = v4d{0, 0, 0, 0}, a1 = v4d{0, 0, 0, 0};
+  const double* ga = Gt + g * S + 16 * u + c;
+  const double* xb = Xt + g * xs + 16 * uk + c;
+  v4d a0 = v4d{0, 0, 0, 0}, a1 = v4d{0, 0, 0, 0};
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ga[4 * t * S], xb[4 * t * xs], a0, 0, 0, 0);
-      a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ga[(16 + 4 * t) * S], xb[(16 + 4 * t) * xs], a1, 0, 0, 0);
+  for (int t = 0; t < 4; ++t) {
+    a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ga[4 * t * S], xb[4 * t * xs], a0, 0, 0, 0);
+    a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ga[(16 + 4 * t) * S], xb[(16 + 4 * t) * xs], a1, 0, 0, 0);
+  }
+  const int k = 16 * uk + c;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int o = 16 * u + g + 4 * r;
+    if (o < Hout && k < Hin) pW[o * Hin + k] = a0[r] + a1[r];
+  }
+}
+// dW_l tiles q, q + Q, ... of this pass's 32 rows -> the partial row; worker Q - 1 also sums the bias gradient.  L is a compile-time
+// layer index.  Q == 2 (the jet is not split): the worker's tiles are a compile-time list, so that the fragment reads of the next tile
+// are in flight under the matrix instructions of the current one.
+template <int L>
+__device__ __forceinline__ void dw_tiles(const double* Gt, const double* Xt /* L == 0: the input rows, stride S0 */, double* __restrict__ prow,
+                                         const Dims& d, int q, int Q, int lane) {
+  const int Hin = L == 0 ? d.D : d.H, Hout = L == NLIN - 1 ? d.D : d.H;
+  constexpr int xs = L == 0 ? S0 : S;
+  double* pW = prow + off_w(L, d.D, d.H);
+  if (Q == 2 && d.H > 32) {                    // three live tiles per side
+    constexpr int NU = L == NLIN - 1 ? 1 : NT, NK = L == 0 ? 1 : NT;
+    if (q == 0) {
+#pragma unroll
+      for (int tix = 0; tix < NU * NK; tix += 2) dw_tile(Gt, Xt, xs, tix / NK, tix % NK, pW, Hout, Hin, lane);
+    } else {
+#pragma unroll
+      for (int tix = 1; tix < NU * NK; tix += 2) dw_tile(Gt, Xt, xs, tix / NK, tix % NK, pW, Hout, Hin, lane);
     }
-    const int k = 16 * uk + c;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int o = 16 * u + g + 4 * r;
-      if (o < Hout && k < Hin) pW[o * Hin + k] = a0[r] + a1[r];
+  } else {
+    const int nto = (d.H + 15) >> 4;
+    const int nto_l = L == NLIN - 1 ? 1 : nto, ntk_l = L == 0 ? 1 : nto, total = nto_l * ntk_l;
+    for (int tix = q; tix < total; tix += Q) {
+      const int u = tix / ntk_l, uk = tix - u * ntk_l;
+      dw_tile(Gt, Xt, xs, u, uk, pW, Hout, Hin, lane);
     }
   }
   if (q == Q - 1 && lane < Hout) {
@@ -341,6 +420,22 @@ __device__ __forceinline__ void dw_tiles(int l, const double* Gt, const double* 
     }
     pW[Hout * Hin + lane] = s0 + s1;
   }
+}
+
+// one backward layer of the worker program (L compile time): barrier (A), the weight image two layers down, the layer's dW tiles,
+// barrier (B)
+template <int L>
+__device__ __forceinline__ void worker_bwd_layer(const double* __restrict__ wb, const Dims& d, double* img, const double* Gt, const double* Xt,
+                                                 const double* x0, double* __restrict__ prow, WRegs<2>& wr, int sw, int q, int Q, int lane, int role) {
+  lds_barrier();                                        // (A)
+  FM_STAMP(role, 8 + 2 * (NLIN - 1 - L));
+  // every chain wave is past layer L + 1: its image takes W_{L-1}
+  if (L <= 5 && L >= 2) stage_commit<2>(img + ((L - 1) & 1) * IMG, L - 1, sw, lane, wr);
+  if (L <= 5 && L >= 3) stage_issue<2>(wb, L - 2, d, sw, lane, wr);
+  dw_tiles<L>(Gt, L == 0 ? x0 : Xt, prow, d, q, Q, lane);
+  FM_STAMP(role, 22 + (NLIN - 1 - L));
+  lds_barrier();                                        // (B)
+  FM_STAMP(role, 9 + 2 * (NLIN - 1 - L));
 }
 
 // Everything the backward phase needs.
@@ -358,21 +453,29 @@ struct BwdIo {
 // 72 activation registers and the workers' 25 staging registers are never live in the same wave.
 template <bool GEN>
 __device__ __forceinline__ void bwd_phase(const BwdIo& io, double* lds, int* ids, double* gsx) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int c = lane & 15, g = lane >> 4;
+  const int tid = threadIdx.x, wave = tid >> 6;
   const Dims d = make_dims(2 * io.CO, io.H);
   double* img = lds;
   double* img0 = img + 2 * IMG;
   double* x0 = img0 + IMG0;
   double* Gt = x0 + ROWS * S0;
   double* Xt = Gt + TILE;
-  const int role = wave_role(ids, wave, lane);
+  const int role = wave_role(ids, wave, tid & 63);
   const size_t plane = (size_t)io.B * io.N * io.CO;
   const int np = passes(io.N), ps = psize(d.D, d.H);
-  const double* wb = io.wb;
   for (int p = 0; p < np; ++p) {
-    asm volatile("" : "+s"(wb));                           // (see fwd_phase)
-    // the pass's input rows (every thread: 2 of the 512 elements)
+    int opaque0 = 0, lane = tid & 63;
+    asm volatile("" : "+s"(opaque0), "+v"(lane));          // (see fwd_phase: nothing of the pass may be hoisted out of this loop)
+    const double* __restrict__ wb = io.wb + opaque0;
+    const int c = lane & 15, g = lane >> 4;
+    // Everything the pass needs from global memory is requested before anything is waited for (one round trip, ~5 k cycles, at the head
+    // of the kernel): the workers' first two weight images, then the pass's input rows (every thread: 2 of the 512 elements)
+    WRegs<2> wr;
+    W0Regs<2> w0;
+    if (role >= 2) {
+      if (p == 0) stage0_issue<2>(wb, d, role - 2, lane, w0);
+      stage_issue<2>(wb, 1, d, role - 2, lane, wr);
+    }
     {
       double xv[2];
 #pragma unroll
@@ -398,21 +501,26 @@ __device__ __forceinline__ void bwd_phase(const BwdIo& io, double* lds, int* ids
         const double v = io.g_out[ok ? (size_t)(k & 1) * plane + ((size_t)io.b * io.N + row) * io.CO + (k >> 1) : 0];
         gp[0][r] = ok ? v : 0.0;
       }
-      __syncthreads();                                      // x0, first-layer image
+      FM_STAMP(role, 0);
+      lds_barrier();                                      // x0, first-layer image
+      FM_STAMP(role, 1);
       v4d h[NLIN - 1][NT];
       layer_first<GEN>(img0, x0 + 16 * role * S0, lane, io.act, h[0]);
-      __syncthreads();
+      lds_barrier();
+      FM_STAMP(role, 2);
 #pragma unroll
       for (int l = 1; l <= 5; ++l) {
         layer_hidden<GEN>(img + (l & 1) * IMG, d.full, lane, io.act, h[l - 1], h[l]);
-        __syncthreads();
+        lds_barrier();
+        FM_STAMP(role, 2 + l);
       }
 #pragma unroll
       for (int l = NLIN - 1; l >= 0; --l) {
         if (l == NLIN - 1) put_tile<1>(Gt + 16 * role * S, lane, gp);
         else put_tile<NT>(Gt + 16 * role * S, lane, gp);
         if (l >= 1) put_tile<NT>(Xt + 16 * role * S, lane, h[l >= 1 ? l - 1 : 0]);
-        __syncthreads();                                    // (A) tiles of layer l published
+        lds_barrier();                                    // (A) tiles of layer l published
+        FM_STAMP(role, 8 + 2 * (NLIN - 1 - l));
         if (l >= 1) {
           v4d gh[NT];
           if (l == NLIN - 1) chain_gin_out(img + (l & 1) * IMG, lane, gp[0], gh);
@@ -429,41 +537,39 @@ __device__ __forceinline__ void bwd_phase(const BwdIo& io, double* lds, int* ids
             if (k < d.D && row < io.N) gsx[row * d.D + k] = gx[r];
           }
         }
-        __syncthreads();                                    // (B) tiles consumed
+        FM_STAMP(role, 22 + (NLIN - 1 - l));
+        lds_barrier();                                    // (B) tiles consumed
+        FM_STAMP(role, 9 + 2 * (NLIN - 1 - l));
       }
     } else {
       // ================= worker program: streams the weights, runs the weight-gradient GEMMs =================
       const int sw = role - 2;                             // staging wave 0 / 1
       const int q = io.share * 2 + (role - 2), Q = io.nshare * 2;
       double* prow = io.part + ((size_t)io.b * np + p) * ps;
-      WRegs<2> wr;
-      {
-        W0Regs<2> w0;
-        if (p == 0) stage0_issue<2>(wb, d, sw, lane, w0);
-        stage_issue<2>(wb, 1, d, sw, lane, wr);
-        if (p == 0) stage0_commit<2>(img0, sw, lane, w0);
-      }
-      __syncthreads();
+      if (p == 0) stage0_commit<2>(img0, sw, lane, w0);
+      FM_STAMP(role, 0);
+      lds_barrier();
+      FM_STAMP(role, 1);
       stage_commit<2>(img + IMG, 1, sw, lane, wr);
       stage_issue<2>(wb, 2, d, sw, lane, wr);
-      __syncthreads();
+      lds_barrier();
+      FM_STAMP(role, 2);
 #pragma unroll
       for (int l = 1; l <= 5; ++l) {
         // W_{l+1} into the image last read at layer l - 1; then the layer after it -- at l = 5 the first reload of the backward sweep
         stage_commit<2>(img + ((l + 1) & 1) * IMG, l + 1, sw, lane, wr);
         stage_issue<2>(wb, l + 2 < NLIN ? l + 2 : 4, d, sw, lane, wr);     // l = 4: W_6; l = 5: W_4
-        __syncthreads();
+        lds_barrier();
+        FM_STAMP(role, 2 + l);
       }
       // images now: [0] = W_6, [1] = W_5; registers: W_4
-#pragma unroll
-      for (int l = NLIN - 1; l >= 0; --l) {
-        __syncthreads();                                    // (A)
-        // every chain wave is past layer l + 1: its image takes W_{l-1}
-        if (l <= 5 && l >= 2) stage_commit<2>(img + ((l - 1) & 1) * IMG, l - 1, sw, lane, wr);
-        if (l <= 5 && l >= 3) stage_issue<2>(wb, l - 2, d, sw, lane, wr);
-        dw_tiles(l, Gt, l == 0 ? x0 : Xt, prow, d, q, Q, lane);
-        __syncthreads();                                    // (B)
-      }
+      worker_bwd_layer<6>(wb, d, img, Gt, Xt, x0, prow, wr, sw, q, Q, lane, role);
+      worker_bwd_layer<5>(wb, d, img, Gt, Xt, x0, prow, wr, sw, q, Q, lane, role);
+      worker_bwd_layer<4>(wb, d, img, Gt, Xt, x0, prow, wr, sw, q, Q, lane, role);
+      worker_bwd_layer<3>(wb, d, img, Gt, Xt, x0, prow, wr, sw, q, Q, lane, role);
+      worker_bwd_layer<2>(wb, d, img, Gt, Xt, x0, prow, wr, sw, q, Q, lane, role);
+      worker_bwd_layer<1>(wb, d, img, Gt, Xt, x0, prow, wr, sw, q, Q, lane, role);
+      worker_bwd_layer<0>(wb, d, img, Gt, Xt, x0, prow, wr, sw, q, Q, lane, role);
     }
   }
 }

@@ -267,11 +267,14 @@ def _assert_grads(got, ref, tol, tag=""):
                                       (4, 4, 16, 2), (4, 4, 17, 1), (3, 3, 32, 2), (4, 4, 40, 1),        # tile / pass boundaries
                                       (2, 2, 30, 2), (1, 1, 5, 1), (4, 2, 13, 3), (2, 4, 30, 1),         # narrow MLPs (H = 12, 24)
                                       (5, 4, 30, 2), (4, 5, 30, 1), (4, 4, 48, 1)])                      # outside the fused range
-def test_level_mlp_fwd_bwd(dev, O, decoder, C, CO, N, B):
-    """LGNNodeLevel + CGMLP behind one call per direction (lgn_level_mlp_fwd/bwd_f64) against the oracle.  For N <= 40, C <= 4,
-    C_out <= 4 (H <= 48) the CGMLP rides on the level kernels (csrc/mlp_dev.hpp; small B: the jet is split over several workgroups,
-    each running the forward MLP on its rows and the backward chain on all rows); the other shapes run the separate launches."""
+def test_level_mlp_fwd_bwd(dev, O, monkeypatch, decoder, C, CO, N, B):
+    """LGNNodeLevel + CGMLP behind one call per direction (lgn_level_mlp_fwd/bwd_f64) against the oracle.  With LGN_AMD_FUSED_MLP=1 /
+    LGN_AMD_FUSED_MLP_BWD=1 and N <= 40, C <= 4, C_out <= 4 (H <= 48) the CGMLP rides on the level kernels (csrc/mlp_dev.hpp; small B:
+    the jet is split over several workgroups, each running the forward MLP on its rows and the backward chain on all rows); the other
+    shapes run the separate launches."""
     from lgn import _native as Nn
+    monkeypatch.setenv("LGN_AMD_FUSED_MLP", "1")
+    monkeypatch.setenv("LGN_AMD_FUSED_MLP_BWD", "1")
     g = torch.Generator().manual_seed(1000 * C + 100 * CO + N + int(decoder))
     cfg, plans, P, node, p, mask, cot = _level_mlp_inputs(O, decoder, C, CO, N, B, "leakyrelu", g, seed=N + 7 * C)
     H = P["lgn_cg.mlp_levels.0.linear.0.weight"].shape[0]
@@ -286,10 +289,12 @@ def test_level_mlp_fwd_bwd(dev, O, decoder, C, CO, N, B):
 
 @pytest.mark.parametrize("decoder", [False, True])
 @pytest.mark.parametrize("act", ["leakyrelu", "relu", "elu", "sigmoid", "logsigmoid", "atan"])
-def test_level_mlp_activations(dev, O, decoder, act):
+def test_level_mlp_activations(dev, O, monkeypatch, decoder, act):
     """Every activation of get_activation_fn through the level + CGMLP call.  LeakyReLU (the reference default) rides on the level
-    kernels; the others keep the separate CGMLP kernels behind the same call (level.hpp: level_mlp_fusable says why)."""
+    kernels when asked to; the others keep the separate CGMLP kernels behind the same call (level.hpp: level_mlp_fusable says why)."""
     from lgn import _native as Nn
+    monkeypatch.setenv("LGN_AMD_FUSED_MLP", "1")
+    monkeypatch.setenv("LGN_AMD_FUSED_MLP_BWD", "1")
     C, CO, N, B = 4, 3, 30, 2
     g = torch.Generator().manual_seed(77 + int(decoder))
     cfg, plans, P, node, p, mask, cot = _level_mlp_inputs(O, decoder, C, CO, N, B, act, g, seed=11)
@@ -307,8 +312,10 @@ def test_level_mlp_full_batch_matches_small_batches_and_unfused(dev, O, monkeypa
     """B = 512 (one workgroup per jet, two per CU: the BASELINE launch shape) cannot be held by the oracle.  Properties instead:
     (1) jets of the 512-batch equal the same jets run in a batch of 3 (the jet-split launch shape, which the oracle pins in
     test_level_mlp_fwd_bwd); (2) every output and gradient of the riding CGMLP equals the separate-launch path
-    (LGN_AMD_NO_FUSED_MLP=1) to rounding; (3) the run is bitwise reproducible."""
+    (the default) to rounding; (3) the run is bitwise reproducible."""
     from lgn import _native as Nn
+    monkeypatch.setenv("LGN_AMD_FUSED_MLP", "1")
+    monkeypatch.setenv("LGN_AMD_FUSED_MLP_BWD", "1")
     N, B = 30, 512
     g = torch.Generator().manual_seed(5 + C + int(decoder))
     cfg, plans, P, node, p, mask, cot = _level_mlp_inputs(O, decoder, C, CO, N, B, "leakyrelu", g, seed=3)
@@ -327,7 +334,8 @@ def test_level_mlp_full_batch_matches_small_batches_and_unfused(dev, O, monkeypa
     U.assert_close(v1.index_select(1, idx), v3, 1e-13, "jets of the full batch: v_out")
     U.assert_close(g1["s_in"].index_select(1, idx), g3["s_in"], 1e-12, "jets of the full batch: g_s_in")
     U.assert_close(g1["v_in"].index_select(1, idx), g3["v_in"], 1e-12, "jets of the full batch: g_v_in")
-    monkeypatch.setenv("LGN_AMD_NO_FUSED_MLP", "1")
+    monkeypatch.delenv("LGN_AMD_FUSED_MLP")
+    monkeypatch.delenv("LGN_AMD_FUSED_MLP_BWD")
     assert Nn.level_mlp_fused(N, C, CO, 12 * CO, 7, 0, decoder) == 0
     su, vu, gu = _level_mlp_native(dev, decoder, "leakyrelu", P, node, p, mask, cot)
     U.assert_close(s1, su, 1e-13, "fused vs separate: s_out")

@@ -68,6 +68,33 @@ def test_native_step_matches_reference_golden(name, use_graph):
                 assert torch.equal(g.cpu(), lam * torch.sign(sd[k])), f"{pre}.{k}: dead parameter must get exactly the L1 term"
 
 
+@pytest.mark.parametrize("flags", [("LGN_AMD_FUSED_MLP",), ("LGN_AMD_FUSED_MLP", "LGN_AMD_FUSED_MLP_BWD"), ("LGN_AMD_FUSED_MLP_BWD",),
+                                   ("LGN_AMD_LEVEL_V2",), ("LGN_AMD_DEC_PAIRWISE",)])
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_native_step_maxdim2_alternative_kernels(flags, use_graph, monkeypatch):
+    """The kernel-selecting switches of the maxdim = 2 step, frozen into the descriptor when the step is created (lgn/_native.py:
+    net_flags): the CGMLPs riding on the level kernels (forward tail, backward head, both; csrc/mlp_dev.hpp: 24, 26 or 20 launches per
+    step instead of 30), the three-kernel level backward, the decoder as pair sweeps -- each against the reference's g1 gradients with
+    the strict per-tensor tolerance, and the number of launches the fused forms promise."""
+    from lgn.step import NativeTrainStep
+    for f in flags:
+        monkeypatch.setenv(f, "1")
+    z, m, enc, dec, batch = _golden_setup("g1_e2e_maxdim2.npz")
+    step = NativeTrainStep(enc, dec, batch_size=m["B"], l1_lambda=m["l1_lambda"], optimizer=False, use_graph=use_graph)
+    for f in flags:
+        monkeypatch.delenv(f)                # the switches live in the descriptor from here on
+    for _ in range(2):
+        total, recon = step.step(batch)
+    U.assert_close(total, z["loss_total"], 1e-11, "total loss")
+    U.assert_close(recon, z["recon"], 1e-11, "recon")
+    lam = m["l1_lambda"]
+    for pre, mod in (("enc", enc), ("dec", dec)):
+        sd = U.params_from(z, pre)
+        for k, g in mod.named_grads():
+            ref = torch.from_numpy(z[f"grad.{pre}.{k}"]) + lam * torch.sign(sd[k])
+            U.assert_close(g, ref, 1e-9, f"grad {pre}.{k}")
+
+
 @pytest.mark.parametrize("flag", ["LGN_AMD_NO_STATIC", "LGN_AMD_DEC_PAIRWISE", "LGN_AMD_MOMENTS_V1"])
 def test_native_step_maxdim3_alternative_kernels(flag, monkeypatch):
     """The table-driven (maxdim 3) native step through its cross-check kernels: run-time-table local kernels instead of the

@@ -53,6 +53,15 @@ def main():
         gs, gv = torch.randn_like(so), torch.randn_like(vo)
         gp = torch.zeros_like(p) if decoder else None
         fn = lambda: Nn.level_bwd(decoder, s, v, p, mask, rad, wm0, wm1, ag0, ag1, gs, gv, gp)  # noqa: E731
+    elif what.startswith("level_mlp_fwd"):        # level + CGMLP in one launch (csrc/mlp_dev.hpp)
+        block = torch.cat([t.reshape(-1) for pair in zip(ws, bs) for t in pair])
+        fn = lambda: Nn.level_mlp_fwd(decoder, s, v, p, mask, rad, wm0, wm1, block, ws[0].shape[0], 7, 0)   # noqa: E731
+    elif what.startswith("level_mlp_bwd"):
+        block = torch.cat([t.reshape(-1) for pair in zip(ws, bs) for t in pair])
+        ag0, ag1, spre, so, vo = Nn.level_mlp_fwd(decoder, s, v, p, mask, rad, wm0, wm1, block, ws[0].shape[0], 7, 0)
+        gs, gv = torch.randn_like(so), torch.randn_like(vo)
+        gp = torch.zeros_like(p) if decoder else None
+        fn = lambda: Nn.level_mlp_bwd(decoder, s, v, p, mask, rad, wm0, wm1, ag0, ag1, block, ws[0].shape[0], 7, 0, spre, gs, gv, gp)  # noqa: E731
     elif what == "mlp_fwd":
         fn = lambda: Nn.cgmlp_fwd(s_mlp, ws, bs)                                                 # noqa: E731
     elif what == "mlp_bwd":
@@ -72,14 +81,21 @@ def main():
     print(f"{what}: B={B} N={N} C={C}->{CO}  {e0.elapsed_time(e1) * 1e3 / reps:.1f} us per call")
     if stamps:
         import ctypes
-        buf = (ctypes.c_longlong * 64)()
+        n = 128 if "_fm_" in stamps else 64
+        buf = (ctypes.c_longlong * n)()
         rc = getattr(Nn.lib(), stamps)(buf)
         st = list(buf)
-        print(f"stamps ({stamps}, rc={rc}), s_memtime ticks relative to stamp 0:")
-        prev = st[0]
-        for i in range(1, 64):
-            if st[i] > st[0]:
-                print(f"  {i:3d}  t={st[i] - st[0]:8d}")
+        if n == 128:      # mlp_dev.hpp: slot = role * 32 + i, lane 0 of each wave of workgroup 0
+            t0 = min(x for x in st if x > 0)
+            print(f"stamps ({stamps}, rc={rc}), shader-clock ticks relative to the earliest stamp; one line per role (0, 1 chain; 2, 3 worker):")
+            for role in range(4):
+                row = st[role * 32: role * 32 + 32]
+                print(f"  role {role}: " + " ".join(f"{i}:{x - t0}" for i, x in enumerate(row) if x > 0))
+        else:
+            print(f"stamps ({stamps}, rc={rc}), s_memtime ticks relative to stamp 0:")
+            for i in range(1, 64):
+                if st[i] > st[0]:
+                    print(f"  {i:3d}  t={st[i] - st[0]:8d}")
 
 
 if __name__ == "__main__":
