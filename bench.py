@@ -83,25 +83,28 @@ def level_fwd_flops(N, C, CO, decoder):
     return edge + aggregate + power + catmix
 
 
-def _events_us(fn, reps):
+def _events_us(fn, reps, mode_out=None):
     """Average duration of fn's launches: `reps` of them captured into ONE HIP graph (back to back on the device, as in the
     step's graph: eager launches of a 10-50 us kernel add 3-5 us of dispatch gap each and make the host the pacer at 64 jets),
-    the replay bracketed by events on the stream it runs on.  Falls back to eager launches if the capture is refused."""
+    the replay bracketed by events on the stream it runs on.  If the CAPTURE is refused (a RuntimeError out of the capture; a failing
+    launch raises out of fn's own checks first, in the warm-up below, and is not caught) the launches are timed eagerly on a fresh
+    stream; mode_out (a dict) receives which of the two happened."""
     for _ in range(3):
-        fn()
+        fn()                                 # (launch errors surface here, uncaught)
     torch.cuda.synchronize()
     side = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
     try:
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.stream(side):
-            graph.capture_begin()
+        with torch.cuda.graph(graph, stream=side):       # (its __exit__ ends the capture also when fn raises)
             for _ in range(reps):
                 fn()
-            graph.capture_end()
-        run, per = graph.replay, reps
-    except Exception:          # noqa: BLE001
+        run, per, mode = graph.replay, reps, "graph of %d launches" % reps
+    except RuntimeError as exc:
         torch.cuda.synchronize()
-        run, per = fn, 1
+        side = torch.cuda.Stream()                       # the stream of the aborted capture is not reused
+        run, per, mode = fn, 1, "eager launches (capture refused: %s)" % str(exc).splitlines()[0][:120]
+    if mode_out is not None:
+        mode_out["timing"] = mode
     total, rounds = 0.0, 0
     with torch.cuda.stream(side):
         run()
@@ -150,7 +153,8 @@ def time_dominant_kernel(enc, batch, reps=20):
     def fwd():
         Nn._check(L.lgn_level_fwd_f64(*fargs, Nn.stream_ptr()), "lgn_level_fwd_f64")
 
-    us_fwd = _events_us(fwd, reps)
+    mode = {}
+    us_fwd = _events_us(fwd, reps, mode)
     gs = torch.randn(so.shape, dtype=torch.float64, generator=g).to(dev)
     gv = torch.randn(vo.shape, dtype=torch.float64, generator=g).to(dev)
     rm, rr = C.c_int(), C.c_int()
@@ -165,11 +169,12 @@ def time_dominant_kernel(enc, batch, reps=20):
     def bwd():
         Nn._check(L.lgn_level_bwd_f64(*bargs, Nn.stream_ptr()), "lgn_level_bwd_f64")
 
-    us_bwd = _events_us(bwd, reps)
+    us_bwd = _events_us(bwd, reps, mode)
     fwd_flops = B * level_fwd_flops(N, Cc, CO, False)
     single = N <= 40
     return {"kernel": f"level_bwd3_kernel<{Cc}, false, false, 4>" if single else "level_bwd (mix + nodes2 + rad2 kernels)",
             "level": lvl, "us": us_bwd, "flops": 2 * fwd_flops,          # backward = 2 x forward
+            "timing": mode.get("timing"),
             "forward": {"kernel": f"level_fwd2_kernel<{Cc}, false, false>", "us": us_fwd, "flops": fwd_flops}}
 
 
@@ -225,8 +230,9 @@ def time_dominant_kernel_generic(net, B, N, reps=10):
     def bwd():
         Nn._check(L.lgn_local_bwd_static_f64(*args, Nn.stream_ptr()), "lgn_local_bwd_static_f64")
 
-    us = _events_us(bwd, reps)
-    return {"kernel": f"local_bwd_static_kernel<Kind{kind}, {4 if CO <= 4 else 6 if CO <= 6 else 8}>", "level": lvl, "us": us,
+    mode = {}
+    us = _events_us(bwd, reps, mode)
+    return {"kernel": f"local_bwd_static_kernel<Kind{kind}, {4 if CO <= 4 else 6 if CO <= 6 else 8}>", "level": lvl, "us": us, "timing": mode.get("timing"),
             "flops": 2 * M * local_level_flops(net, lvl)}
 
 
@@ -546,7 +552,7 @@ def main():
                 "traffic_note": "bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction; an ESTIMATE: the guide "
                                 "calibrates the x2 on 16 B/lane loads, this kernel issues 8 B/lane), separate rocprofv3 "
                                 "--pmc passes recorded in profiles/r03_pmc_cfg2.json; 0.5 TB/s, HBM is not the bound",
-                "us_per_launch": dom["us"], "algorithmic_flops_per_launch": dom["flops"],
+                "us_per_launch": dom["us"], "timing": dom.get("timing"), "algorithmic_flops_per_launch": dom["flops"],
                 "forward_kernel": {"kernel": fw["kernel"], "us_per_launch": fw["us"], "algorithmic_flops_per_launch": fw["flops"],
                                    "achieved": fw["flops"] / (fw["us"] * 1e-6) / 1e12,
                                    "frac": fw["flops"] / (fw["us"] * 1e-6) / 1e12 / FP64_VECTOR_PEAK_TFLOPS},

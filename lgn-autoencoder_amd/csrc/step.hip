@@ -7,6 +7,7 @@
 // straight into the caller's flat gradient buffer at the same offsets as the parameters.
 #include <stdlib.h>
 
+#include <mutex>
 #include <vector>
 
 #include "net.hpp"
@@ -65,9 +66,15 @@ struct Deferred {
   // record / wait pairs become graph edges, i.e. a branch of the step's graph; eagerly they are ordinary events.  The
   // reductions move ~100 MB of CGMLP weight-gradient partials per cfg2 step (HBM-bound) beside kernels that are not.
   hipStream_t side = nullptr;
+  hipStream_t main_of_fork = nullptr; // the stream the open fork left from (joined back by the destructor on an error path)
   hipEvent_t* ev = nullptr;          // pool of >= 2 * MAX_FORKS events owned by the library (per device)
   int nfork = 0;
   bool forked = false;
+  // An error return between fork_flush() and join() must not leave the side branch dangling: under stream capture an unjoined branch
+  // makes capture_end fail with "unjoined work" and hides the error that caused it.  Best effort, the original error is kept.
+  ~Deferred() {
+    if (forked && main_of_fork && hipEventRecord(ev[MAX_FORKS], side) == hipSuccess) (void)hipStreamWaitEvent(main_of_fork, ev[MAX_FORKS], 0);
+  }
   static constexpr int MAX_FORKS = 6;
   int max_forks = MAX_FORKS;
   int fork_flush(hipStream_t main_st) {
@@ -77,6 +84,7 @@ struct Deferred {
     if (e != hipSuccess) { set_error("fork_flush: %s", hipGetErrorString(e)); return (int)e; }
     ++nfork;
     forked = true;
+    main_of_fork = main_st;
     return flush(side);
   }
   int join(hipStream_t main_st) {
@@ -101,16 +109,18 @@ struct Deferred {
 // events for Deferred::fork_flush, created on first use (outside any capture: NativeTrainStep warms the step up eagerly
 // before it captures) and kept for the life of the process
 hipEvent_t* fork_events() {
-  static hipEvent_t pool[16][Deferred::MAX_FORKS + 1];
-  static bool ready[16] = {};
+  constexpr int MAX_DEV = 64;
+  static hipEvent_t pool[MAX_DEV][Deferred::MAX_FORKS + 1];
+  static std::once_flag once[MAX_DEV];
+  static bool ready[MAX_DEV] = {};
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-  if (!ready[dev]) {
-    for (int i = 0; i <= Deferred::MAX_FORKS; ++i)
-      if (hipEventCreateWithFlags(&pool[dev][i], hipEventDisableTiming) != hipSuccess) return nullptr;
-    ready[dev] = true;
-  }
-  return pool[dev];
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return nullptr;
+  std::call_once(once[dev], [dev] {           // (two host threads may take their first step at the same time)
+    bool ok = true;
+    for (int i = 0; i <= Deferred::MAX_FORKS && ok; ++i) ok = hipEventCreateWithFlags(&pool[dev][i], hipEventDisableTiming) == hipSuccess;
+    ready[dev] = ok;
+  });
+  return ready[dev] ? pool[dev] : nullptr;
 }
 int attach_side(Deferred& dq, void* side_stream) {
   if (!side_stream) return 0;

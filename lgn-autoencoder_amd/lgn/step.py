@@ -167,6 +167,48 @@ class ReferenceLoopStep:
 from .ops import slot_tensors as _slot_tensors  # noqa: E402  (parameter slots of include/lgn_amd.h)
 
 
+def any_rank(flag: bool, group, device) -> bool:
+    """True on EVERY rank iff `flag` is true on ANY rank: one eager all-reduce(MAX) of a one-element tensor."""
+    t = torch.tensor([1.0 if flag else 0.0], device=device, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return t.item() != 0.0
+
+
+def agree_in_graph(try_capture, replay_matches, reset, group, device, strict: bool = False) -> bool:
+    """Shall the gradient all-reduce live INSIDE the step's graph?  The same answer on every rank of `group`.
+
+    try_capture() captures [fwd+bwd | all-reduce | L1 + Adam] into the step graph (may raise: the backend refuses to be captured);
+    replay_matches() replays that graph once and says whether it reproduced the eager step; reset() discards the graph.  Both
+    outcomes are LOCAL -- a capture can fail on one rank only (allocator state, a watchdog) -- and both are exchanged before anybody
+    acts on them: a rank that fell back by itself would pair its next gradient-sized eager all-reduce with the other ranks' replayed
+    in-graph all-reduce and their one-element flag all-reduce (collectives mismatched in size and order: a hang or silently wrong
+    gradients).  The sequence of collectives below is therefore identical on every rank whatever happens locally:
+        any_rank(capture failed)  ->  [all ranks captured: replay (one in-graph all-reduce each) -> any_rank(replay wrong)]
+    strict: raise instead of falling back (NativeTrainStep(graph_collective=True))."""
+    import warnings
+    err = None
+    try:
+        try_capture()
+    except Exception as exc:      # noqa: BLE001
+        err = exc
+    if any_rank(err is not None, group, device):
+        if strict:
+            raise RuntimeError("the all-reduce could not be captured in the step graph on every rank") from err
+        warnings.warn("all-reduce could not be captured in the step graph" +
+                      (f" ({type(err).__name__}: {err})" if err is not None else " on another rank") +
+                      "; every rank falls back to graph | all-reduce | graph")
+        reset()
+        return False
+    if any_rank(not replay_matches(), group, device):
+        if strict:
+            raise RuntimeError("the all-reduce captured in the step graph does not reproduce the eager step")
+        warnings.warn("the all-reduce captured in the step graph does not reproduce the eager step; "
+                      "every rank falls back to graph | all-reduce | graph")
+        reset()
+        return False
+    return True
+
+
 class NativeTrainStep:
     """Same step as TrainStep, executed by lgn_step_fwd_bwd_f64 / lgn_step_finalize_f64 (csrc/step.hip):
     no autograd graph, no PyTorch kernels, every buffer static.  With ``use_graph=True`` the two native calls
@@ -304,28 +346,21 @@ class NativeTrainStep:
         self._g1, self._g2, self._in_graph = torch.cuda.CUDAGraph(), None, False
         if self.collective and self.graph_collective is not False:
             # ONE graph: forward + backward | all-reduce(SUM) of gradients and loss terms | L1 + Adam.  RCCL enqueues its
-            # kernel on the capturing stream like any other launch; if this backend refuses, use the three-launch form below
-            try:
+            # kernel on the capturing stream like any other launch; if this backend refuses -- on ANY rank -- or the captured
+            # collective does not reproduce the eager step -- on ANY rank -- every rank uses the three-launch form below
+            # (agree_in_graph: the ranks exchange both outcomes, none decides from what it saw locally)
+            def try_capture():
                 with torch.cuda.graph(self._g1):
                     self._fwd_bwd()
                     dist.all_reduce(self.flat.grad_buf, op=dist.ReduceOp.SUM, group=self.group)
                     self._finalize(self.optimizer)
-                self._in_graph = True
-            except Exception as exc:      # noqa: BLE001  (every rank runs the same software: all of them land here together)
-                if self.graph_collective is True:
-                    raise
-                import warnings
-                warnings.warn(f"all-reduce could not be captured in the step graph ({type(exc).__name__}: {exc}); "
-                              "falling back to graph | all-reduce | graph")
+
+            def reset():
                 torch.cuda.synchronize()
                 self._g1 = torch.cuda.CUDAGraph()
-            if self._in_graph and not self._captured_collective_ok(snap, ref):
-                if self.graph_collective is True:
-                    raise RuntimeError("the all-reduce captured in the step graph does not reproduce the eager step")
-                import warnings
-                warnings.warn("the all-reduce captured in the step graph does not reproduce the eager step; "
-                              "falling back to graph | all-reduce | graph")
-                self._g1, self._in_graph = torch.cuda.CUDAGraph(), False
+
+            self._in_graph = agree_in_graph(try_capture, lambda: self._captured_collective_matches(snap, ref), reset, self.group,
+                                            self.flat.flat.device, strict=self.graph_collective is True)
         if self.collective and not self._in_graph:      # the gradient all-reduce sits between two graphs
             self._g2 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._g1):
@@ -340,20 +375,17 @@ class NativeTrainStep:
         with torch.no_grad():   # capture does not execute, but restore anyway in case a backend replays eagerly
             self.flat.flat.copy_(snap[0]); self.adam_m.copy_(snap[1]); self.adam_v.copy_(snap[2]); self.step_dev.copy_(snap[3])
 
-    def _captured_collective_ok(self, snap, ref) -> bool:
+    def _captured_collective_matches(self, snap, ref) -> bool:
         """One replay of the freshly captured [fwd+bwd | all-reduce | L1 + Adam] graph from the snapshotted state: the reduced
         gradient buffer (gradients + L1 sub-gradient | per-jet loss terms of ALL ranks) and the loss must be what the eager
         warm-up step produced from the same state -- a capture that silently dropped the collective would leave the local sums.
-        Every rank takes the same decision (MAX over ranks of the failure flag, through an eager all-reduce)."""
+        LOCAL verdict; agree_in_graph makes it every rank's."""
         with torch.no_grad():
             self.flat.flat.copy_(snap[0]); self.adam_m.copy_(snap[1]); self.adam_v.copy_(snap[2]); self.step_dev.copy_(snap[3])
         self._g1.replay()
         torch.cuda.synchronize()
         tol = dict(rtol=1e-11, atol=1e-300)       # same kernels; only the reduction order inside RCCL may differ
-        bad = not (torch.allclose(self.flat.grad_buf, ref[0], **tol) and torch.allclose(self._loss_buf[:3], ref[1], **tol))
-        flag = torch.tensor([1.0 if bad else 0.0], device=self.flat.flat.device, dtype=torch.float64)
-        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
-        return flag.item() == 0.0
+        return bool(torch.allclose(self.flat.grad_buf, ref[0], **tol) and torch.allclose(self._loss_buf[:3], ref[1], **tol))
 
     def load_batch(self, batch: Dict[str, torch.Tensor]):
         """Stage a batch into the static input buffers (device-to-device copy; labels/masks as in

@@ -106,6 +106,64 @@ def test_two_rank_data_parallel_equals_single_process():
     assert torch.equal(res[0][1], res[1][1]), "replicas diverged"
 
 
+def _agree_worker(rank, world, port, scenario, out):
+    sys.path.insert(0, os.path.join(ROOT, "lgn-autoencoder_amd"))
+    import warnings
+    from lgn.step import agree_in_graph
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    log = []
+
+    def try_capture():
+        log.append("capture")
+        if scenario == "capture_fails_on_rank1" and rank == 1:
+            raise RuntimeError("forced: capture refused on this rank only")
+
+    def replay_matches():
+        # stands for one replay of the captured graph: ONE gradient-sized all-reduce per rank (the in-graph collective)
+        t = torch.ones(1000, dtype=torch.float64)
+        dist.all_reduce(t)
+        log.append("replay")
+        return not (scenario == "replay_wrong_on_rank0" and rank == 0)
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        in_graph = agree_in_graph(try_capture, replay_matches, lambda: log.append("reset"), None, torch.device("cpu"))
+    # what NativeTrainStep derives from the answer, and the first step's collective: gradient-sized on every rank either way
+    launches = 1 if in_graph else 3
+    t = torch.full((1000,), float(rank + 1), dtype=torch.float64)
+    dist.all_reduce(t)
+    out[rank] = (launches, log, float(t[0]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("scenario,launches", [("all_good", 1), ("capture_fails_on_rank1", 3), ("replay_wrong_on_rank0", 3)])
+def test_in_graph_collective_decision_is_taken_by_all_ranks_together(scenario, launches):
+    """lgn/step.py: agree_in_graph.  A capture of the in-graph all-reduce that fails on ONE rank (or a replay that is wrong on one
+    rank) must send EVERY rank to the three-launch form, through the same sequence of collectives on every rank -- no hang, no
+    mismatched all-reduce sizes; the next gradient all-reduce pairs up (sum 1 + 2 on both ranks)."""
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        out = mgr.dict()
+        port = 31500 + (os.getpid() % 2000)
+        procs = [ctx.Process(target=_agree_worker, args=(r, 2, port, scenario, out)) for r in range(2)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(timeout=120)
+            assert p.exitcode == 0, "worker failed or hung"
+        res = dict(out)
+    assert res[0][0] == res[1][0] == launches, res
+    assert res[0][2] == res[1][2] == 3.0
+    if scenario == "capture_fails_on_rank1":
+        assert "replay" not in res[0][1] and "replay" not in res[1][1], "nobody may replay a graph another rank does not have"
+        assert res[0][1] == ["capture", "reset"]
+    if scenario == "replay_wrong_on_rank0":
+        assert res[0][1] == res[1][1] == ["capture", "replay", "reset"]
+
+
 def test_bench_self_spawn_world2_dry_run():
     """`python bench.py --gpus 2` without a launcher starts its two ranks itself (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*),
     they rendezvous (gloo stand-in for RCCL: LGN_BENCH_DRY=1 replaces the GPU step by a CPU all-reduce with the same

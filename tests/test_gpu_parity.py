@@ -544,17 +544,25 @@ def test_end_to_end_vs_reference_golden(dev, O, name, fused):
     loss = O.chamfer_loss(rec[0] + rec[1], p4.to(dev))
     U.assert_close(loss, z["loss_chamfer"], FWD_TOL, "chamfer")
     loss.backward()
-    # a gradient tensor 100x below the largest gradient of the step is held to that floor (g9 / ELU: the encoder's input
-    # mixing weight gets 5e-12 against 3e-9, the survivor of a cancellation whose rounding noise is absolute)
+    # Every gradient tensor is held to GRAD_TOL relative to ITS OWN largest entry.  The named exceptions are tensors whose gradient
+    # is the survivor of a cancellation -- rounding noise of the sums they come from is absolute: they are held to GRAD_TOL of the
+    # step's largest gradient / 100 instead.  (g9 / ELU: the encoder's input mixing weight gets 5e-12 against 3e-9.)
     floor = 1e-2 * max(float(abs(z[k]).max()) for k in z.files if k.startswith("grad."))
+    scaled = _SCALED_GRADS.get(name, ())
     for pre, mod in (("enc", enc), ("dec", dec)):
         assert [n for n, _ in mod.named_parameters()] == ["flat_params"]
         for k, got in mod.named_grads():
             ref = torch.from_numpy(z[f"grad.{pre}.{k}"])
             if ref.abs().max() == 0:
                 assert got.abs().max() == 0, f"{pre}.{k} must have exactly zero gradient"
-            else:
+            elif f"{pre}.{k}" in scaled:
                 U.assert_close_scaled(got, ref, GRAD_TOL, floor, f"grad {pre}.{k}")
+            else:
+                U.assert_close(got, ref, GRAD_TOL, f"grad {pre}.{k}")
+
+
+# gradient tensors checked against the step's gradient scale instead of their own (see test_end_to_end_vs_reference_golden)
+_SCALED_GRADS = {"g9_e2e_elu.npz": ("enc.input_func_node.weights.(0, 0)", "enc.input_func_node.weights.(1, 1)")}
 
 
 @pytest.mark.parametrize("name,B,N,maxdim,che,chd", [("cfg2", 512, 30, 2, (3, 3, 4, 4), (4, 4, 3, 3)),
@@ -712,9 +720,16 @@ def test_module_option_combinations_vs_oracle(dev, O, tag, kw):
     U.assert_close(rec, rec_o.detach(), FWD_TOL, f"{tag} recon")
     U.assert_close(loss.detach(), loss_o.detach(), FWD_TOL, f"{tag} loss")
     grads = [(f"{pre}.{k}", g, P[k].grad) for pre, mod, P in (("enc", enc, Pe), ("dec", dec, Pd)) for k, g in mod.named_grads()]
+    # strict per-tensor tolerance; the named cancellation survivors (see _SCALED_GRADS) against the step's gradient scale
     floor = 1e-2 * max(float(r.abs().max()) for _, _, r in grads if r is not None)
+    scaled = _SCALED_OPTION_GRADS.get(tag, ())
     for name, g, r in grads:
         if r is None or r.abs().max() == 0:
             assert g.abs().max() == 0, f"{tag} {name}: must have exactly zero gradient"
-        else:
+        elif name in scaled:
             U.assert_close_scaled(g, r, GRAD_TOL, floor, f"{tag} grad {name}")
+        else:
+            U.assert_close(g, r, GRAD_TOL, f"{tag} grad {name}")
+
+
+_SCALED_OPTION_GRADS = {}
