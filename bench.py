@@ -68,6 +68,14 @@ def synthetic_jets(B, N, seed):
     p4 = torch.cat([e, p3], -1)
     p4 = p4 / (p4.abs().amax(dim=-1, keepdim=True).amax(dim=-2, keepdim=True) + 1e-16)
     nobj = torch.randint(min(10, N), N + 1, (B,), generator=g)
+    order = os.environ.get("LGN_BENCH_JET_ORDER")       # experiment: which jets share a CU
+    if order and B % 2 == 0:
+        idx = torch.argsort(nobj, descending=True, stable=True)
+        if order == "pair":       # workgroup i: i-th heaviest jet, workgroup B/2 + i: i-th lightest
+            idx = torch.cat([idx[: B // 2], idx[B // 2:].flip(0)])
+        elif order == "interleave":   # heaviest, lightest, 2nd heaviest, 2nd lightest, ...
+            idx = torch.stack([idx[: B // 2], idx[B // 2:].flip(0)], 1).reshape(-1)
+        p4, nobj = p4[idx], nobj[idx]
     labels = (torch.arange(N).unsqueeze(0) < nobj.unsqueeze(1)).to(torch.uint8)
     return p4 * labels.unsqueeze(-1).to(p4.dtype), labels
 

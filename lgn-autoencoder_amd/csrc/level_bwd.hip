@@ -426,6 +426,7 @@ int level_bwd_rad2_dispatch(const LevelBwdArgs<double>& a, hipStream_t stream);
 
 int level_bwd3_dispatch(const LevelBwdArgs<double>& a, int decoder, hipStream_t stream);         // level_bwd3.hip
 int level_bwd_dec_sep_dispatch(const LevelBwdArgs<double>& a, hipStream_t stream);               // level_bwd_dec_sep.hip
+int level_bwd_sweep_enc_dispatch(const LevelBwdArgs<double>& a, hipStream_t stream);             // level_bwd2.hip
 static bool dec_pairwise(int flags) { return (flags & LVL_DEC_PAIRWISE) != 0; }   // the decoder on the O(N^2) pair sweeps
 bool level_bwd3_fits(int N);
 
@@ -471,6 +472,10 @@ static int launch_level_bwd(const LevelBwdArgs<T>& a, hipStream_t stream) {
   }
   if constexpr (DEC && std::is_same<T, double>::value) {
     if (!dec_pairwise(a.flags)) return level_bwd_dec_sep_dispatch(a, stream);   // 2+3. from jet-level sums, O(N C)
+  }
+  if constexpr (!DEC && std::is_same<T, double>::value) {
+    // 2+3. encoder: node gradients and radial sums in ONE pair sweep (level_bwd2.hip); LVL_LEVEL_V2 keeps the two sweeps below
+    if (!(a.flags & LVL_LEVEL_V2)) return level_bwd_sweep_enc_dispatch(a, stream);
   }
   if ((rc = level_bwd_nodes2_dispatch(a, DEC, stream))) return rc;        // 2. j-centric pass
   if (DEC) {  // 3b

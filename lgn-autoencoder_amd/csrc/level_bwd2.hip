@@ -474,6 +474,331 @@ __global__ __launch_bounds__(2 * BLOCK) void level_bwd_rad2_kernel(LevelBwdArgs<
   }
 }
 
+// =========================================================================================================
+// encoder, jets too large for level_bwd3: BOTH passes in ONE pair sweep (round 4; was nodes2 + rad2: two sweeps, each with its own
+// geometry, basis functions and radial Linear on the matrix cores: 190 + 298 us per level at N = 150)
+// =========================================================================================================
+// j-centric like level_bwd3's phase 2, whose per-tile arithmetic this is: a wave owns 4 source particles j and sweeps the receivers i
+// in tiles of 4; per pair (a) g_node_j += g_ag_i (x) conj(edge_ij) and (b) dL/d rad of the pair -> 16 x 16 LDS transposes -> the
+// T1 | T2 | S | dB GEMM on the matrix cores.  What level_bwd3 keeps in LDS for the whole jet does not fit here (N = 150, C = 4: the
+// gradient of the aggregate alone is 96 KB, beside 9 KB of transpose tiles per wave), so the receivers come in CHUNKS of `ichunk`
+// particles: the chunk's g_ag rows (written by level_bwd_mix_kernel) are staged, every wave sweeps its row groups over the chunk
+// and adds its share into the node gradient (which already holds the direct + power part from level_bwd_mix_kernel), next chunk.
+// The source particle's own features come from global memory (10 reals per lane and row group); the radial sums live in the
+// matrix-core accumulators across all chunks and leave as ONE partial row per jet, like level_bwd_rad2's.
+template <int C, int NWV>
+__global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2))) void level_bwd_sweep_enc_kernel(LevelBwdArgs<double> a, int ichunk) {
+  constexpr int NG = (C + 3) / 4;
+  using G = GA2<C>;
+  constexpr int TS = 18, BLK = 64 * NWV;
+  constexpr int TRW = (NG + 3) * 16 * TS > 64 * NG * 12 ? (NG + 3) * 16 * TS : 64 * NG * 12;   // per wave: transpose tiles, later the reduction rows
+  const int N = a.N, B = a.B;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  double* ga = reinterpret_cast<double*>(smem_raw);          // ichunk * 20C   gradient of the aggregate, receivers of the current chunk
+  double* pj = ga + (size_t)ichunk * G::SIZE;                // N * 4
+  double* tr = pj + N * 4;                                   // NWV * TRW
+  uint8_t* mk = reinterpret_cast<uint8_t*>(tr + NWV * TRW);  // N
+
+  {
+    const double* p0 = a.p + (size_t)b * N * 4;
+    for (int e = tid; e < N * 4; e += BLK) pj[e] = p0[e];
+    for (int e = tid; e < N; e += BLK) mk[e] = a.mask[(size_t)b * N + e];
+  }
+  const int pr = lane & 15, cg = lane >> 4;
+  const int tj = pr >> 2, ti = pr & 3;                      // which of the wave's 4 source particles j / slot in the i tile
+  double ak[5], bk[5], ck2[5], wf[NG][5], bias[NG][4];
+#pragma unroll
+  for (int s = 0; s < 5; ++s) {
+    const int k = 4 * s + cg;
+    ak[s] = a.ra[k];
+    bk[s] = a.rb[k];
+    const double c = a.rc[k];
+    ck2[s] = c * c;
+  }
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    const int rr = lane & 15, q = rr >> 2, ch = 4 * g + (rr & 3);
+    const double* w = (q >> 1) ? a.w1 : a.w0;
+#pragma unroll
+    for (int s = 0; s < 5; ++s) wf[g][s] = ch < C ? w[(2 * ch + (q & 1)) * NB + 4 * s + cg] : 0.0;
+    const int chl = 4 * g + cg;
+#pragma unroll
+    for (int q2 = 0; q2 < 4; ++q2) {
+      const double* bb = (q2 >> 1) ? a.b1 : a.b0;
+      bias[g][q2] = chl < C ? bb[2 * chl + (q2 & 1)] : 0.0;
+    }
+  }
+
+  double* trw = tr + wave * TRW;
+  v4d T[NG][3];
+#pragma unroll
+  for (int g = 0; g < NG; ++g)
+#pragma unroll
+    for (int t = 0; t < 3; ++t) T[g][t] = v4d{0, 0, 0, 0};
+  const size_t pls = (size_t)B * N * C;
+  const int ngroups = (N + 3) >> 2;
+
+  for (int ilo = 0; ilo < N; ilo += ichunk) {
+    const int ihi = min(N, ilo + ichunk);
+    __syncthreads();                                         // (first chunk: pj / mk staged; later: the previous chunk is swept)
+    {
+      const double* src = a.g_ag + ((size_t)b * N + ilo) * G::SIZE;
+      for (int e = tid; e < (ihi - ilo) * G::SIZE; e += BLK) ga[e] = src[e];
+    }
+    __syncthreads();
+    for (int rg = wave; rg < ngroups; rg += NWV) {
+      const int j = rg * 4 + tj;
+      const bool jok = j < N;
+      const int jj = jok ? j : N - 1;
+      double pme[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) pme[m] = pj[jj * 4 + m];
+      const bool mj = mk[jj] != 0;
+      cx<double> Gs[NG], Gv[NG][4];
+      cx<double> sj[NG], vj[NG][4], dvj[NG], svj[NG];       // own (source) node features; v_j[3] - v_j[1], v_j[1] + v_j[3]
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        Gs[g] = {0, 0};
+#pragma unroll
+        for (int m = 0; m < 4; ++m) Gv[g][m] = {0, 0};
+        const int ch = 4 * g + cg;
+        const size_t e = ((size_t)b * N + jj) * C + (ch < C ? ch : 0);
+        sj[g] = {a.s_in[e], a.s_in[pls + e]};
+#pragma unroll
+        for (int m = 0; m < 4; ++m) vj[g][m] = {a.v_in[e * 4 + m], a.v_in[pls * 4 + e * 4 + m]};
+        dvj[g] = {vj[g][3].r - vj[g][1].r, vj[g][3].i - vj[g][1].i};
+        svj[g] = {vj[g][1].r + vj[g][3].r, vj[g][1].i + vj[g][3].i};
+      }
+
+      for (int i0 = ilo; i0 < ihi; i0 += 4) {
+        const int i = i0 + ti;
+        const bool ok = jok && i < ihi;
+        const int ii = i < ihi ? i : ihi - 1;
+        const double* pii = pj + ii * 4;
+        v4d R[NG];
+        double rho[5];
+        const double d0 = pii[0] - pme[0], d1 = pii[1] - pme[1], d2 = pii[2] - pme[2], d3 = pii[3] - pme[3];
+        const double q0 = d0 * d0, q1 = d1 * d1, q2 = d2 * d2, q3 = d3 * d3;
+        const double nsq = (2.0 * q0 - (((q0 + q1) + q2) + q3)) + 1e-16;
+        const double an = fabs(nsq);
+        const bool on = ok && mj && (mk[ii] != 0) && (nsq != 0.0);
+        const double h = rsqrt2<double>();
+        const double qd0 = d0, qd3 = d3, qa = d1 * h, qb = d2 * h;   // q = [d0, a - ib, d3, -a - ib] (real momenta)
+        double beta[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < 5; ++s) rho[s] = 0.0;
+        if (on) {                                            // (EXEC-masked block: no per-value selects)
+#pragma unroll
+          for (int s = 0; s < 5; ++s) {
+            rho[s] = fast_rcp((1.0 + ck2[s] * an) + 1e-16);
+            beta[s] = __builtin_fma(bk[s], rho[s], ak[s]);
+          }
+        }
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          R[g] = v4d{bias[g][0], bias[g][1], bias[g][2], bias[g][3]};
+#pragma unroll
+          for (int s = 0; s < 5; ++s) R[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(wf[g][s], beta[s], R[g], 0, 0, 0);
+        }
+        // B-operand source of the radial GEMM: this lane's pair (row pr), columns k = 4s + cg
+        double* xb = trw + NG * 16 * TS;
+#pragma unroll
+        for (int s = 0; s < 5; ++s) {
+          const double x2 = an * rho[s] * rho[s];
+          if (s < 4) {
+            xb[pr * TS + 4 * s + cg] = rho[s];
+            xb[16 * TS + pr * TS + 4 * s + cg] = x2;
+          } else {
+            xb[32 * TS + pr * TS + cg] = rho[s];
+            xb[32 * TS + pr * TS + 4 + cg] = x2;
+          }
+        }
+        xb[32 * TS + pr * TS + 8 + 2 * cg] = cg == 0 ? (on ? 1.0 : 0.0) : 0.0;
+        xb[32 * TS + pr * TS + 9 + 2 * cg] = cg == 0 ? (ok ? 1.0 : 0.0) : 0.0;
+
+        const double* gi = ga + (size_t)(ii - ilo) * G::SIZE;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          const int ch = 4 * g + cg;
+          double G0r = 0, G0i = 0, G1r = 0, G1i = 0;
+          if (ok && ch < C) {
+            const cx<double> R0 = {R[g][0], R[g][1]}, R1 = {R[g][2], R[g][3]};
+            const cx<double> e0 = {R0.r - R0.i, R0.r + R0.i};
+            const cx<double> gA3 = {0.5 * gi[G::A3 + 2 * ch], 0.5 * gi[G::A3 + 2 * ch + 1]};
+            const cx<double> gA4 = {gi[G::A4 + 2 * ch], gi[G::A4 + 2 * ch + 1]};
+            cx<double> gA1[4], gA2[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+              gA1[m] = {gi[G::A1 + (ch * 4 + m) * 2], gi[G::A1 + (ch * 4 + m) * 2 + 1]};
+              gA2[m] = {gi[G::A2 + (ch * 4 + m) * 2], gi[G::A2 + (ch * 4 + m) * 2 + 1]};
+            }
+            cfmac(Gs[g], gA4, e0);
+            cx<double> ge0 = cmulc(gA4, sj[g]);
+            // the edge e1[m] = R1 q[m] enters through P2 = sum_m gA2[m] conj(q[m]), V = <v_j, q> and Z = gA3 conj(R1) only
+            // (level_bwd3.hip, phase 2)
+            const cx<double> dg = {gA2[1].r - gA2[3].r, gA2[1].i - gA2[3].i}, sg = {gA2[1].r + gA2[3].r, gA2[1].i + gA2[3].i};
+            cx<double> P2;
+            P2.r = __builtin_fma(gA2[0].r, qd0, __builtin_fma(gA2[2].r, qd3, __builtin_fma(qa, dg.r, -qb * sg.i)));
+            P2.i = __builtin_fma(gA2[0].i, qd0, __builtin_fma(gA2[2].i, qd3, __builtin_fma(qa, dg.i, qb * sg.r)));
+            cfmac(Gs[g], P2, R1);
+            const cx<double> Z = cmulc(gA3, R1);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+              cfmac(Gv[g][m], gA1[m], e0);
+              cfmac(ge0, gA1[m], vj[g][m]);
+            }
+            Gv[g][0].r = __builtin_fma(Z.r, qd0, Gv[g][0].r);   Gv[g][0].i = __builtin_fma(Z.i, qd0, Gv[g][0].i);
+            Gv[g][2].r = __builtin_fma(-Z.r, qd3, Gv[g][2].r);  Gv[g][2].i = __builtin_fma(-Z.i, qd3, Gv[g][2].i);
+            const double aZr = qa * Z.r, aZi = qa * Z.i, bZr = qb * Z.r, bZi = qb * Z.i;
+            Gv[g][1].r -= aZr + bZi;  Gv[g][1].i += bZr - aZi;   // Z (-a + ib)
+            Gv[g][3].r += aZr - bZi;  Gv[g][3].i += aZi + bZr;   // Z ( a + ib)
+            cx<double> V;
+            V.r = __builtin_fma(vj[g][0].r, qd0, __builtin_fma(-vj[g][2].r, qd3, __builtin_fma(qa, dvj[g].r, qb * svj[g].i)));
+            V.i = __builtin_fma(vj[g][0].i, qd0, __builtin_fma(-vj[g][2].i, qd3, __builtin_fma(qa, dvj[g].i, -qb * svj[g].r)));
+            cx<double> gR1 = cmulc(P2, sj[g]);
+            cfmac(gR1, gA3, V);
+            G0r = ge0.r + ge0.i;  G0i = ge0.i - ge0.r;        // e0 = R0 (1+i)  ->  G_R0 = G_e0 (1-i)
+            G1r = gR1.r;  G1i = gR1.i;
+          }
+          double* ta = trw + g * 16 * TS;                     // [pair][r' = cg + 4q]
+          ta[pr * TS + cg] = G0r;
+          ta[pr * TS + 4 + cg] = G0i;
+          ta[pr * TS + 8 + cg] = G1r;
+          ta[pr * TS + 12 + cg] = G1i;
+        }
+        wave_sync();
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const int prow = 4 * s + cg;
+          double bv[3];
+#pragma unroll
+          for (int t = 0; t < 3; ++t) bv[t] = xb[t * 16 * TS + prow * TS + pr];
+#pragma unroll
+          for (int g = 0; g < NG; ++g) {
+            const double av = trw[g * 16 * TS + prow * TS + pr];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) T[g][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[t], T[g][t], 0, 0, 0);
+          }
+        }
+        wave_sync();
+      }
+
+      // this chunk's share of the node gradient of the wave's 4 particles (quad sum over the i slots), added to what
+      // level_bwd_mix_kernel (direct + power part) and the earlier chunks left there.  The ten old values are all requested
+      // before the first store: written as ten "+=" the loads and stores alternate (the pointers may alias for all the compiler
+      // knows) and the flush is ten memory round trips -- measured: a third of the kernel at N = 150.
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        const int ch = 4 * g + cg;
+        const size_t e = ((size_t)b * N + jj) * C + (ch < C ? ch : 0);
+        const bool wr = jok && ti == 0 && ch < C;
+        double old[10];
+        if (wr) {
+          old[0] = a.g_s_in[e];
+          old[1] = a.g_s_in[pls + e];
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            old[2 + m] = a.g_v_in[e * 4 + m];
+            old[6 + m] = a.g_v_in[pls * 4 + e * 4 + m];
+          }
+        }
+        double add[10];
+        add[0] = quad_sum(Gs[g].r);
+        add[1] = quad_sum(Gs[g].i);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          add[2 + m] = quad_sum(Gv[g][m].r);
+          add[6 + m] = quad_sum(Gv[g][m].i);
+        }
+        if (wr) {
+          a.g_s_in[e] = old[0] + add[0];
+          a.g_s_in[pls + e] = old[1] + add[1];
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            a.g_v_in[e * 4 + m] = old[2 + m] + add[2 + m];
+            a.g_v_in[pls * 4 + e * 4 + m] = old[6 + m] + add[6 + m];
+          }
+        }
+      }
+    }
+  }
+
+  // ---- radial partial row of this jet: cross-wave sum of the accumulators (D layout: T[r' = (lane>>4) + 4q][col = lane & 15]) ----
+  __syncthreads();                                           // every wave is done with its transpose tiles (aliased by the rows below)
+  {
+    double* mine = tr + (size_t)(wave * 64 + lane) * NG * 12;
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) mine[(g * 3 + t) * 4 + q] = T[g][t][q];
+  }
+  __syncthreads();
+  if (wave == 0) {
+    constexpr int R = 4 * C;
+    double* part = a.part_rad + (size_t)blockIdx.x * rad_partial_size(C, false);
+    const int col = lane & 15;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const int ch = 4 * g + cg;
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int e = (g * 3 + t) * 4 + q;
+          double v = 0.0;
+          for (int w = 0; w < NWV; ++w) v += tr[(size_t)(w * 64 + lane) * NG * 12 + e];
+          if (ch >= C) continue;
+          const int r = (q >> 1) * 2 * C + 2 * ch + (q & 1);       // row of the partial layout: lin*2C + 2c + z
+          if (t == 0) part[r * NB + col] = v;
+          else if (t == 1) part[R * NB + r * NB + col] = v;
+          else {
+            if (col < 4) part[r * NB + 16 + col] = v;
+            else if (col < 8) part[R * NB + r * NB + 16 + (col - 4)] = v;
+            else if (col == 8) part[2 * R * NB + r] = v;
+            else if (col == 9) part[2 * R * NB + R + r] = v;
+          }
+        }
+    }
+  }
+}
+
+template <int C, int NWV>
+static int launch_sweep_enc_w(const LevelBwdArgs<double>& a, hipStream_t stream) {
+  constexpr int NG = (C + 3) / 4;
+  constexpr size_t TRW = (NG + 3) * 16 * 18 > 64 * NG * 12 ? (NG + 3) * 16 * 18 : 64 * NG * 12;
+  const size_t fixed = sizeof(double) * ((size_t)a.N * 4 + NWV * TRW) + a.N + 16, row = sizeof(double) * 20 * C;
+  // receivers per chunk: the whole jet when it fits, else the largest multiple of 4 that does; chunks of equal size
+  // (four waves: half the LDS, so that two workgroups share a CU -- unless not even four receivers fit then)
+  const size_t budget = (NWV == 4 && fixed + 4 * row <= 79 * 1024) ? 79 * 1024 : 160 * 1024;
+  LGN_CHECK_ARG(fixed + 4 * row <= budget, "level_bwd_sweep: N=%d C=%d does not fit the LDS", a.N, a.C);
+  int ichunk = (a.N + 3) & ~3;
+  if (fixed + ichunk * row > budget) {
+    const int cap = (int)((budget - fixed) / row) & ~3, nchunks = (a.N + cap - 1) / cap;
+    ichunk = (((a.N + nchunks - 1) / nchunks) + 3) & ~3;
+  }
+  const size_t smem = fixed + (size_t)ichunk * row;
+  auto kern = level_bwd_sweep_enc_kernel<C, NWV>;
+  if (smem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipLaunchKernelGGL(kern, dim3(a.B), dim3(64 * NWV), smem, stream, a, ichunk);
+  LGN_CHECK_LAUNCH();
+  return 0;
+}
+
+// encoder only; reads g_ag and adds into g_s_in / g_v_in (both written by level_bwd_mix_kernel), writes ONE radial partial row per jet
+int level_bwd_sweep_enc_dispatch(const LevelBwdArgs<double>& a, hipStream_t stream) {
+  // 8 waves per jet when the batch has no more jets than the chip has CUs (cfg4), else 4 (two workgroups per CU)
+#define LGN_CASE(CC) case CC: return (a.B <= 320 && a.N >= 64) ? launch_sweep_enc_w<CC, 8>(a, stream) : launch_sweep_enc_w<CC, 4>(a, stream);
+  switch (a.C) {
+    LGN_CASE(1) LGN_CASE(2) LGN_CASE(3) LGN_CASE(4) LGN_CASE(5) LGN_CASE(6) LGN_CASE(7) LGN_CASE(8)
+    default: set_error("level_bwd: C_in=%d unsupported (1..8)", a.C); return -1;
+  }
+#undef LGN_CASE
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // One workgroup per jet with 4 waves leaves a SIMD with a single wave when the batch has no more jets than the chip has
 // CUs (cfg4: 256 jets of 150 particles = 38 row groups each): run 8 waves per jet then.

@@ -28,6 +28,8 @@
 namespace lgn {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
+namespace { LGN_STAMP_DECL }
+LGN_STAMP_READER(lgn_debug_stamps_mlp)
 
 __host__ __device__ constexpr int pad4(int x) { return (x + 3) & ~3; }
 // smallest stride >= x with stride == 2 (mod 4): 16 rows x 2 k's of a ds_read_b64 group hit 32 distinct bank pairs
@@ -168,6 +170,7 @@ __global__ __launch_bounds__(64 * MT * NT) void mlp_fwd_mfma_kernel(MlpArgs<doub
   double* X0 = Xb + 2 * MT * G::TSIZE;                       // MT input tiles
 
   double regs[G::NPH], breg;
+  STAMP(0);
   prefetch_first<NT, MT>(a.w[0], a.b[0], H, D, regs, breg);
   load_input_tiles<NT, MT>(a.s_in, M, a.C, wg_row0, X0);
   commit_first<NT, MT>(Wl, regs, breg);
@@ -197,6 +200,7 @@ __global__ __launch_bounds__(64 * MT * NT) void mlp_fwd_mfma_kernel(MlpArgs<doub
       if (c < D && row < M) a.s_out[mlp_out_index(a, c & 1, row, c >> 1)] = acc[r];
     }
   }
+  STAMP(1);
 }
 
 template <int NT, int NH, int KSH, int MT, bool GEN>
@@ -218,6 +222,7 @@ __global__ __launch_bounds__(64 * MT * NT) void mlp_bwd_mfma_kernel(MlpArgs<doub
   double* part = a.part + (size_t)blockIdx.x * a.psize;
 
   // ---- h[l] = post-activation of hidden layer l, this wave's tile, D layout: read back from the forward's copy, or recomputed
+  STAMP(2);
   double regs[G::NPH], breg;
   v4d h[NH];
   if (a.h_saved) {
@@ -351,6 +356,7 @@ __global__ __launch_bounds__(64 * MT * NT) void mlp_bwd_mfma_kernel(MlpArgs<doub
       }
     }
   }
+  STAMP(3);
 }
 
 template <int NT, int KSH, int MT>

@@ -44,17 +44,20 @@ def _rand_level_params(O, C, CO, decoder, g):
 @pytest.mark.parametrize("decoder", [False, True])
 @pytest.mark.parametrize("C,CO,N,B", [(3, 3, 30, 3), (3, 4, 30, 2), (4, 4, 30, 2), (4, 3, 30, 2), (4, 4, 7, 2),
                                       (2, 5, 33, 2), (4, 4, 70, 1), (1, 1, 1, 1),
-                                      (4, 4, 48, 2), (3, 4, 50, 1), (4, 3, 41, 2), (2, 2, 63, 1)])   # 40 < N < 64
+                                      (4, 4, 48, 2), (3, 4, 50, 1), (4, 3, 41, 2), (2, 2, 63, 1),    # 40 < N < 64
+                                      (4, 4, 150, 1), (3, 3, 150, 2), (5, 6, 100, 1), (8, 8, 70, 1)])  # chunked receivers
 def test_level_fwd_bwd(dev, O, decoder, C, CO, N, B):
-    """N <= 40: one-kernel backward (level_bwd3); 40 < N < 64: three-kernel backward (mix + nodes2 + rad2, four waves per
-    jet) resp. mix + separable decoder backward; N >= 64 with a small batch: the 8-wave 'wide' sweeps."""
+    """N <= 40: one-kernel backward (level_bwd3); 40 < N: mix + ONE pair sweep for node gradients and radial sums
+    (level_bwd_sweep_enc: four waves per jet, receivers in chunks when the jet's g_ag does not fit beside a second workgroup)
+    resp. mix + separable decoder backward; N >= 64 with a small batch: the 8-wave 'wide' sweeps."""
     _level_case(dev, O, decoder, C, CO, N, B)
 
 
 @pytest.mark.parametrize("decoder", [False, True])
-@pytest.mark.parametrize("C,CO,N,B", [(4, 4, 30, 2), (3, 4, 30, 3), (4, 3, 7, 1), (2, 5, 33, 2)])
+@pytest.mark.parametrize("C,CO,N,B", [(4, 4, 30, 2), (3, 4, 30, 3), (4, 3, 7, 1), (2, 5, 33, 2), (4, 4, 48, 2), (3, 4, 70, 1)])
 def test_level_three_kernel_backward_small_jets(dev, O, monkeypatch, decoder, C, CO, N, B):
-    """LGN_AMD_LEVEL_V2=1 (read per call) forces the three-kernel backward of large jets onto small ones."""
+    """LGN_AMD_LEVEL_V2=1 (read per call) selects the three-kernel backward (mix + nodes2 + rad2: two pair sweeps) -- for small jets
+    instead of the one-kernel backward, for large encoder jets instead of mix + the one-sweep kernel (level_bwd_sweep_enc)."""
     monkeypatch.setenv("LGN_AMD_LEVEL_V2", "1")
     _level_case(dev, O, decoder, C, CO, N, B)
 

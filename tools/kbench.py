@@ -92,10 +92,26 @@ def main():
                 row = st[role * 32: role * 32 + 32]
                 print(f"  role {role}: " + " ".join(f"{i}:{x - t0}" for i, x in enumerate(row) if x > 0))
         else:
-            print(f"stamps ({stamps}, rc={rc}), s_memtime ticks relative to stamp 0:")
-            for i in range(1, 64):
-                if st[i] > st[0]:
-                    print(f"  {i:3d}  t={st[i] - st[0]:8d}")
+            n = 256
+            buf = (ctypes.c_longlong * n)()
+            rc = getattr(Nn.lib(), stamps)(buf)
+            st = list(buf)
+            w = [x for x in st[64:128] + st[192:256] if x > 0]
+            if w and any(x > 0 for x in st[192:256]):
+                w0 = min(w)
+                for nm, off in (("first", 64), ("last", 192)):
+                    ww = [x for x in st[off:off + 64] if x > 0]
+                    print(f"{nm} workgroup of the grid: alive from {(min(ww) - w0) / 100:.2f} to {(max(ww) - w0) / 100:.2f} us (100 MHz counter)")
+            first = min(i for i in range(64) if st[i] > 0)
+            print(f"stamps ({stamps}, rc={rc}), shader-clock cycles relative to stamp {first}: first workgroup | last workgroup of the grid")
+            for i in range(64):
+                if st[i] > st[first]:
+                    print(f"  {i:3d}  t={st[i] - st[first]:8d}  | {st[128 + i] - st[128 + first]:8d}")
+            last = max(range(64), key=lambda i: st[i])
+            cyc, wall = st[last] - st[first], st[64 + last] - st[64 + first]
+            if wall > 0:      # wall_clock64 ticks at 100 MHz on gfx9 (csrc/probes/clock_probe.hip calibrates it against the host clock)
+                print(f"effective shader clock of workgroup 0 between stamps {first} and {last}: {cyc} cycles / {wall} ticks of the 100 MHz "
+                      f"counter = {cyc / wall * 0.1:.3f} GHz")
 
 
 if __name__ == "__main__":
