@@ -34,10 +34,12 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 // phase stamps of the debug build (make stamps; tools/kbench.py KB_STAMPS=lgn_debug_stamps_fm_*): lane 0 of every wave of workgroup
 // 0 records the shader clock at FM_STAMP(role, i) -> slot role * 32 + i
 #ifdef LGN_STAMPS
-static __device__ long long fm_stamps[128];
-#define FM_STAMP(role, i) do { if ((threadIdx.x & 63) == 0 && blockIdx.x == 0 && blockIdx.y == 0) fm_stamps[(role) * 32 + (i)] = clock64(); } while (0)
+// (slots 128 .. 255: the same for the LAST workgroup of the grid)
+static __device__ long long fm_stamps[256];
+#define FM_STAMP(role, i) do { if ((threadIdx.x & 63) == 0 && blockIdx.y == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1)) \
+    fm_stamps[(blockIdx.x == 0 ? 0 : 128) + (role) * 32 + (i)] = clock64(); } while (0)
 #define FM_STAMP_READER(name) \
-  extern "C" int name(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(lgn::fm::fm_stamps), sizeof(long long) * 128); }
+  extern "C" int name(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(lgn::fm::fm_stamps), sizeof(long long) * 256); }
 #else
 #define FM_STAMP(role, i) do { } while (0)
 #define FM_STAMP_READER(name)
@@ -84,6 +86,9 @@ __device__ __forceinline__ Dims make_dims(int D, int H) { return Dims{D, H, H > 
 __device__ __forceinline__ void role_publish(int* ids, int wave, int lane) {
   const unsigned hw = __builtin_amdgcn_s_getreg((6 - 1) << 11 | 0 << 6 | 4);      // HW_REG_HW_ID bits [5:0]
   if (lane == 0) ids[wave] = (int)hw;
+#ifdef LGN_STAMPS
+  if (lane == 0 && blockIdx.y == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1)) fm_stamps[(blockIdx.x == 0 ? 0 : 128) + wave * 32 + 31] = 0x1000 + (long long)hw;
+#endif
 }
 // (after a barrier behind role_publish)
 __device__ __forceinline__ int role_resolve(const int* ids, int wave) {

@@ -81,16 +81,22 @@ def main():
     print(f"{what}: B={B} N={N} C={C}->{CO}  {e0.elapsed_time(e1) * 1e3 / reps:.1f} us per call")
     if stamps:
         import ctypes
-        n = 128 if "_fm_" in stamps else 64
+        n = 256 if "_fm_" in stamps else 64
         buf = (ctypes.c_longlong * n)()
         rc = getattr(Nn.lib(), stamps)(buf)
         st = list(buf)
-        if n == 128:      # mlp_dev.hpp: slot = role * 32 + i, lane 0 of each wave of workgroup 0
-            t0 = min(x for x in st if x > 0)
-            print(f"stamps ({stamps}, rc={rc}), shader-clock ticks relative to the earliest stamp; one line per role (0, 1 chain; 2, 3 worker):")
-            for role in range(4):
-                row = st[role * 32: role * 32 + 32]
-                print(f"  role {role}: " + " ".join(f"{i}:{x - t0}" for i, x in enumerate(row) if x > 0))
+        if n == 256:      # mlp_dev.hpp: slot = (last workgroup ? 128 : 0) + role * 32 + i, lane 0 of each wave
+            for nm, off in (("first", 0), ("last", 128)):
+                part = st[off: off + 128]
+                ids = [part[w * 32 + 31] - 0x1000 for w in range(4)]       # slot 31 of "role" w: HW_ID of WAVE w (wave slot [3:0], SIMD [5:4])
+                for w in range(4):
+                    part[w * 32 + 31] = 0
+                t0 = min(x for x in part if x > 0)
+                print(f"{nm} workgroup of the grid: waves 0..3 on (SIMD, slot) " + " ".join(f"({(x >> 4) & 3},{x & 15})" for x in ids) +
+                      "; shader-clock cycles relative to its earliest stamp, one line per role (0, 1 chain; 2, 3 worker):")
+                for role in range(4):
+                    row = part[role * 32: role * 32 + 32]
+                    print(f"  role {role}: " + " ".join(f"{i}:{x - t0}" for i, x in enumerate(row) if x > 0))
         else:
             n = 256
             buf = (ctypes.c_longlong * n)()

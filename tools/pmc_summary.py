@@ -8,14 +8,16 @@ Per kernel (mean over its dispatches; dispatches of the warm-up included -- they
                        count quad-cycles summed over the waves; SQ_VALU_MFMA_BUSY_CYCLES counts cycles; GRBM_GUI_ACTIVE is summed
                        over the 8 XCDs; FETCH_SIZE / WRITE_SIZE are KiB (FETCH_SIZE tallies 128-B requests at 64 B on gfx950)
   derived
-    clock_GHz          GRBM_GUI_ACTIVE / 8 / duration   (reads high for dispatches well under 0.3 ms -- the guide's caveat)
+    (no clock: GRBM_GUI_ACTIVE / duration reads 2.5 - 7 "GHz" for dispatches well under 0.3 ms -- the guide's caveat -- and is
+     not stored.  The measured clocks are in profiles/r04_clock.txt: 2.39 - 2.40 GHz sustained for any instruction mix
+     (csrc/probes/clock_probe.hip), 2.15 - 2.28 GHz inside the 10 - 50 us kernels of the step (s_memtime against s_memrealtime,
+     tools/kbench.py with the stamps build).)
     waves_per_simd     mean resident waves = SQ_WAVE_CYCLES * 4 / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs)
     wave_active_valu   SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES: share of a wave's lifetime spent issuing vector (incl. matrix) work
     wave_wait_any      SQ_WAIT_ANY / SQ_WAVE_CYCLES: parked on s_waitcnt / barriers
     wave_wait_inst     SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES: issue stalled (matrix-pipe / dependency)
     mfma_pipe_util     SQ_INSTS_MFMA * 64 cycles (v_mfma_f64_16x16x4: measured, csrc/probes) / (duration * 2.4 GHz * 1024 SIMDs):
-                       share of the NOMINAL-clock matrix-pipe time (the chip clocks lower under fp64 load, so the pipe is busier
-                       than this in its own cycles; the GRBM-derived clock is unusable for sub-0.3-ms dispatches)
+                       share of the matrix-pipe time at the nominal clock (the kernels run at 2.15 - 2.28 GHz: profiles/r04_clock.txt)
     valu_issue_util    (SQ_INSTS_VALU - SQ_INSTS_MFMA) * 4 cycles / (duration * 2.4 GHz * 1024 SIMDs)   (4 = best-case issue cost;
                        fp64 matrix and vector instructions share the datapath: the two shares add up against ONE budget)
     mfma_tflops        SQ_INSTS_VALU_MFMA_MOPS_F64 * 512 flops / duration (MOPS unit: 512 flops) -- executed, padding included
@@ -63,10 +65,8 @@ def main():
         gui = c.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
         d = {"dispatches": n, "duration_us": ns / 1e3, "counters": {x: round(v, 1) for x, v in sorted(c.items())}, "derived": {}}
         dv = d["derived"]
-        if gui > 0:
-            dv["clock_GHz"] = gui / ns
-            if "SQ_WAVE_CYCLES" in c:
-                dv["waves_per_simd"] = c["SQ_WAVE_CYCLES"] * 4 / (gui * 1024)
+        if gui > 0 and "SQ_WAVE_CYCLES" in c:
+            dv["waves_per_simd"] = c["SQ_WAVE_CYCLES"] * 4 / (gui * 1024)
         if "SQ_INSTS_MFMA" in c:
             nominal = ns * 2.4 * 1024                      # SIMD cycles at the nominal 2.4 GHz
             dv["mfma_pipe_util"] = c["SQ_INSTS_MFMA"] * 64 / nominal
@@ -86,10 +86,10 @@ def main():
     res = dict(sorted(res.items(), key=lambda kv: -kv[1]["duration_us"] * kv[1]["dispatches"]))
     with open(out, "w") as fh:
         json.dump({"_doc": __doc__.strip().splitlines()[0] + " -- see tools/pmc_summary.py for units and formulas", "kernels": res}, fh, indent=1)
-    print(f"{'kernel':58s} {'us':>7s} {'clk':>5s} {'w/simd':>6s} {'valu':>5s} {'wait':>5s} {'stall':>5s} {'mfma%':>6s} {'valu%':>6s} {'MB':>7s}")
+    print(f"{'kernel':58s} {'us':>7s} {'w/simd':>6s} {'valu':>5s} {'wait':>5s} {'stall':>5s} {'mfma%':>6s} {'valu%':>6s} {'MB':>7s}")
     for k, d in list(res.items())[:24]:
         v = d["derived"]
-        print(f"{k[:58]:58s} {d['duration_us']:7.1f} {v.get('clock_GHz', 0):5.2f} {v.get('waves_per_simd', 0):6.2f} {v.get('wave_active_valu', 0):5.2f} "
+        print(f"{k[:58]:58s} {d['duration_us']:7.1f} {v.get('waves_per_simd', 0):6.2f} {v.get('wave_active_valu', 0):5.2f} "
               f"{v.get('wave_wait_any', 0):5.2f} {v.get('wave_wait_inst', 0):5.2f} {100 * v.get('mfma_pipe_util', 0):6.1f} {100 * v.get('valu_issue_util', 0):6.1f} "
               f"{v.get('hbm_bytes', 0) / 1e6:7.1f}")
 
