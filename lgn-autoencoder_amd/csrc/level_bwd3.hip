@@ -596,6 +596,10 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2))) v
   double in0[NG][4];                                     // input-stage weight-gradient terms of this lane's nodes (LevelBwdArgs::part_in0)
 #pragma unroll
   for (int g = 0; g < NG; ++g) in0[g][0] = in0[g][1] = in0[g][2] = in0[g][3] = 0.0;
+  // (Two workgroups share a CU and the SIMD arbiter serves the OLDER wave first: the workgroup that arrived first runs 30 % ahead of
+  // the other -- 36 against 46 us at 512 jets, whatever the jets hold -- which then finishes alone.  s_setprio does move the
+  // advantage (priority 3 on the younger one swaps the two times exactly), but alternating it per tile only brought the two to
+  // 40.5 / 46.5 us and the kernel from 50.2 to 49.4 - 50.1 us: the makespan is the CU's total work, not the order.  Not kept.)
   for (int rg = glo + wave; rg < ghi; rg += NWV) {
     const int j = rg * 4 + tj;
     const bool jok = j < N;

@@ -24,6 +24,9 @@ def main():
     dev = torch.device("cuda:0")
     enc, dec = G._models(N, bench.CH_ENC, bench.CH_DEC, dev, seed=0)
     p4, labels = bench.synthetic_jets(B, N, seed=0)
+    if os.environ.get("KB_SAMEJET"):      # every workgroup gets the same jet: position effects without content effects
+        k = int(os.environ["KB_SAMEJET"])
+        p4, labels = p4[k:k + 1].expand(B, -1, -1).contiguous(), labels[k:k + 1].expand(B, -1).contiguous()
     p4, labels = p4.to(dev), labels.to(dev)
     g = torch.Generator().manual_seed(1)
     decoder = what.endswith("_dec")
