@@ -275,7 +275,8 @@ int lgn_step_fwd_bwd_f64(const lgn_net_desc* d, const double* params, double* gr
                          double* loss_part, void* stream, void* side_stream);
 /* grads += l1_lambda*sign(params) (utils/train.py:484-487); loss_out[0..2] = total, chamfer, sum|w|; optional Adam
  * (torch.optim.Adam defaults; the step counter lives on the device so that graph replays stay correct).
- * loss_out must hold 3 + LGN_FINALIZE_SCRATCH doubles: the results, then scratch for the per-workgroup |w| partials. */
+ * loss_out must hold 3 + LGN_FINALIZE_SCRATCH doubles: the results, then scratch for the per-workgroup |w| partials whose last
+ * slot is the finished-workgroup counter of the single launch -- the caller zero-fills the block ONCE, at allocation. */
 #define LGN_FINALIZE_SCRATCH 2048
 int lgn_step_finalize_f64(double* params, double* grads, long long n_params, const double* loss_part, int n_loss,
                           double l1_lambda, double* adam_m, double* adam_v, long long* step_dev,

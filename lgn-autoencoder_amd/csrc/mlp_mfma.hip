@@ -376,6 +376,8 @@ static int launch_mlp_mfma_mt(const MlpArgs<double>& a, bool backward, hipStream
 }
 template <int NT, int KSH>
 static int launch_mlp_mfma(const MlpArgs<double>& a, bool backward, hipStream_t stream) {
+  // (measured again in round 4 with today's staging: 32-row forward workgroups, two per CU with independent barrier domains --
+  // MT = 2, 68 KB of LDS -- take the cfg2 step from 0.568 to 0.584 ms)
   return mlp_rows_per_workgroup(a.M, a.H) == 16 ? launch_mlp_mfma_mt<NT, KSH, 1>(a, backward, stream)
                                                  : launch_mlp_mfma_mt<NT, KSH, 4>(a, backward, stream);
 }

@@ -781,10 +781,17 @@ __global__ __launch_bounds__(BLOCK) void dec_output_bwd_kernel(int B, int N, int
 // g += lambda * sign(w); Adam update (torch.optim.Adam defaults: no weight decay, no amsgrad).  The same pass adds up
 // |w| of the weights BEFORE the update (the L1 term of this step's loss) into one partial per workgroup.
 // The optimiser step counter lives on the device (graph replays stay correct): this step is number *step_dev + 1.
+// The LAST workgroup to finish (a counter in the scratch block, bumped behind a device-scope fence) also assembles the loss
+// -- loss_out[0] = chamfer + lambda * sum|w|, loss_out[1] = chamfer, loss_out[2] = sum|w| -- from the per-jet terms and the
+// per-workgroup |w| sums IN INDEX ORDER (the result does not depend on which workgroup that was), bumps the device-side step
+// counter (every workgroup read it at its start) and clears the counter for the next replay: one launch instead of two
+// (round 4; the second launch was 4 us of the 64-jet step for a 512-term sum).
 __global__ __launch_bounds__(BLOCK) void l1_adam_kernel(long n, double* w, double* g, double* m, double* v, double lambda, double lr,
-                                                       double beta1, double beta2, double eps, const long* step_dev, int do_adam,
-                                                       double* l1_part) {
+                                                       double beta1, double beta2, double eps, long* step_dev, int do_adam,
+                                                       double* l1_part, unsigned long long* done, const double* __restrict__ loss_part,
+                                                       int nB, double* loss_out) {
   __shared__ double red[4];
+  __shared__ int last;
   double bc1 = 1.0, bc2_sqrt = 1.0;
   if (do_adam) {
     const double t = (double)(*step_dev + 1);
@@ -807,15 +814,16 @@ __global__ __launch_bounds__(BLOCK) void l1_adam_kernel(long n, double* w, doubl
     }
   }
   l1 = block_sum(l1, red);
-  if (threadIdx.x == 0) l1_part[blockIdx.x] = l1;
-}
-
-// loss_out[0] = chamfer + lambda * sum|w|, loss_out[1] = chamfer, loss_out[2] = sum|w|; bumps the step counter.
-__global__ __launch_bounds__(BLOCK) void loss_final_kernel(const double* __restrict__ loss_part, int nB, const double* __restrict__ l1_part,
-                                                          int nblk, double lambda, double* loss_out, long* step_dev, int bump) {
-  __shared__ double red[4];
+  if (threadIdx.x == 0) {
+    l1_part[blockIdx.x] = l1;
+    __threadfence();                                       // this workgroup's |w| sum is visible device-wide before the count
+    last = atomicAdd(done, 1ull) == (unsigned long long)gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();                                         // ... and the others' are visible to this one
   double a = 0, l = 0;
-  for (int i = threadIdx.x; i < nblk; i += BLOCK) a += l1_part[i];
+  for (int i = threadIdx.x; i < (int)gridDim.x; i += BLOCK) a += __builtin_nontemporal_load(l1_part + i);
   for (int i = threadIdx.x; i < nB; i += BLOCK) l += loss_part[i];
   a = block_sum(a, red);
   l = block_sum(l, red);
@@ -823,7 +831,8 @@ __global__ __launch_bounds__(BLOCK) void loss_final_kernel(const double* __restr
     loss_out[0] = l + lambda * a;
     loss_out[1] = l;
     loss_out[2] = a;
-    if (bump) *step_dev += 1;
+    if (do_adam) *step_dev += 1;
+    *done = 0ull;
   }
 }
 
@@ -940,13 +949,14 @@ int junction_bwd(int B, int N, int C0, int Tin, const double* lat_v, const doubl
 // loss_out: 3 results followed by LGN_FINALIZE_SCRATCH doubles of scratch (per-workgroup |w| partials)
 int finalize_step(double* w, double* g, long n, const double* loss_part, int nB, double lambda, double* m, double* v, long* step_dev,
                   double lr, double beta1, double beta2, double eps, int do_adam, double* loss_out, hipStream_t st) {
+  // scratch behind the 3 results: [0, nblk) per-workgroup |w| sums, last slot = the finished-workgroup counter (zero between calls:
+  // the caller allocates the block zero-filled, the kernel clears it again)
   int nblk = grid_for((size_t)n);
-  if (nblk > LGN_FINALIZE_SCRATCH) nblk = LGN_FINALIZE_SCRATCH;
+  if (nblk > LGN_FINALIZE_SCRATCH - 1) nblk = LGN_FINALIZE_SCRATCH - 1;
   double* l1_part = loss_out + 3;
+  unsigned long long* done = reinterpret_cast<unsigned long long*>(loss_out + 3 + LGN_FINALIZE_SCRATCH - 1);
   hipLaunchKernelGGL(l1_adam_kernel, dim3(nblk), dim3(BLOCK), 0, st, n, w, g, m, v, lambda, lr, beta1, beta2, eps, step_dev, do_adam,
-                     l1_part);
-  LGN_CHECK_LAUNCH();
-  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(BLOCK), 0, st, loss_part, nB, l1_part, nblk, lambda, loss_out, step_dev, do_adam);
+                     l1_part, done, loss_part, nB, loss_out);
   LGN_CHECK_LAUNCH();
   return 0;
 }
