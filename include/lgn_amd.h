@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LGN_AMD_ABI_VERSION 11   /* bump on ANY struct or signature change (lgn/_native.py: ABI_VERSION) */
+#define LGN_AMD_ABI_VERSION 12   /* bump on ANY struct or signature change (lgn/_native.py: ABI_VERSION) */
 
 int lgn_abi_version(void);
 const char* lgn_last_error(void);
@@ -246,6 +246,10 @@ typedef struct lgn_net_desc {
    * a forward and its backward can never disagree. */
   int flags;
   int activation;          /* LGN_ACT_* of every CGMLP of both networks (the reference builds them from one --activation) */
+  int n_in_scalars;        /* encoder: input scalars per node, K (0 or 1: the mass alone).  K > 1 -- jet_features and / or
+                              data['scalars'], lgn/models/lgn_encoder.py:372-411: the mass, then K - 1 values per node the caller
+                              passes as in_scalars -- is served by lgn_encoder_fwd/bwd_f64; the whole-step call refuses it (its two
+                              networks share one particle count, jet_features gives the encoder one node more) */
 } lgn_net_desc;
 #define LGN_NET_NO_STATIC 1   /* table-driven levels: run-time-table kernels + node-major features (cross-check of the
                                  compile-time-table kernels; lgn/_native.py sets it from LGN_AMD_NO_STATIC at creation) */
@@ -288,16 +292,17 @@ int lgn_step_finalize_f64(double* params, double* grads, long long n_params, con
  * backward needs into `act` (lgn_net_workspace_doubles(d, decoder, 0) doubles, owned by the caller between the two
  * calls); *_bwd zero-fills `grads`, then writes every parameter gradient (dead parameters keep an exact 0) and uses
  * `scratch` (lgn_net_workspace_doubles(d, decoder, 1) doubles).
- *   encoder: p4 [B][N][4] (already scaled), mask [B][N] -> lat_s [2][B][2 tau_s], lat_v [2][B][2 tau_v][4] Cartesian
+ *   encoder: p4 [B][N][4] (already scaled), mask [B][N], in_scalars [B][N][K - 1] (NULL when d->n_in_scalars <= 1: the input
+ *            MixReps (0,0) weight is [2][C][K], slot 0) -> lat_s [2][B][2 tau_s], lat_v [2][B][2 tau_v][4] Cartesian
  *            ('min&max' pooling); g_lat_s may be NULL (no gradient on the latent scalars: the last level's scalar
  *            branch is then skipped, like autograd would).
  *   decoder: lat_v [2][B][Tin][4] (Tin = tau_v_in, or 2 tau_v when 0) -> recon [2][B][N][4] complex Cartesian;
  *            backward from g_recon [2][B][N][4] to g_lat_v (the latent scalars never reach the output). */
 long long lgn_net_workspace_doubles(const lgn_net_desc* d, int decoder, int which);
 int lgn_encoder_fwd_f64(const lgn_net_desc* d, const double* params, const int64_t* off, const double* p4, const uint8_t* mask,
-                        double* act, long long act_doubles, double* lat_s, double* lat_v, void* stream);
+                        const double* in_scalars, double* act, long long act_doubles, double* lat_s, double* lat_v, void* stream);
 int lgn_encoder_bwd_f64(const lgn_net_desc* d, const double* params, double* grads, long long n_params, const int64_t* off,
-                        const double* p4, const uint8_t* mask, const double* act, long long act_doubles,
+                        const double* p4, const uint8_t* mask, const double* in_scalars, const double* act, long long act_doubles,
                         const double* g_lat_s, const double* g_lat_v, double* scratch, long long scratch_doubles, void* stream);
 int lgn_decoder_fwd_f64(const lgn_net_desc* d, const double* params, const int64_t* off, const double* lat_v, double* act,
                         long long act_doubles, double* recon, void* stream);

@@ -5,8 +5,9 @@
 
 namespace lgn {
 // z1/z2 (optional): buffers zeroed by the same launch (the step folds its two memsets into this first kernel)
-int enc_input_fwd(int B, int N, int C, const double* p4, const double* w0, const double* w1, double* s, double* v, hipStream_t,
-                  double* z1 = nullptr, size_t n1 = 0, double* z2 = nullptr, size_t n2 = 0);
+// K input scalars per node: the mass, then xs [B][N][K-1] (K = 1: xs unused); w0 = MixReps weight [2][C][K]
+int enc_input_fwd(int B, int N, int C, int K, const double* p4, const double* xs, const double* w0, const double* w1, double* s, double* v,
+                  hipStream_t, double* z1 = nullptr, size_t n1 = 0, double* z2 = nullptr, size_t n2 = 0);
 // enc_latent_fwd + dec_input_fwd (resp. dec_input_bwd + enc_latent_bwd) of a jet in one launch
 int junction_fwd(int B, int N, int CL, int Ts, int Tv, const double* s, const double* v, const double* wl0, const double* wl1,
                  double* lat_s, double* lat_v, int* idx, int C0, const double* wg1, const double* w0, const double* w1, double* pdec,
@@ -15,7 +16,8 @@ int junction_bwd(int B, int N, int C0, int Tin, const double* lat_v, const doubl
                  const double* g_p, const double* g_s0, const double* g_v0, double* g_lat_v, double* part_dec, int CL, int Ts, int Tv,
                  const double* s, const double* v, const double* wl0, const double* wl1, const double* g_lat_s, const int* idx,
                  double* g_s, double* g_v, double* part_enc, hipStream_t);
-int enc_input_bwd(int B, int N, int C, const double* p4, const double* g_s, const double* g_v, double* part /*[B][4C]*/, hipStream_t);
+int enc_input_bwd(int B, int N, int C, int K, const double* p4, const double* xs, const double* g_s, const double* g_v,
+                  double* part /*[B][(2K + 2) C]: dW00 re [C][K], im [C][K] | dW11 re[C], im[C]*/, hipStream_t);
 int enc_latent_fwd(int B, int N, int C, int Ts, int Tv, const double* s, const double* v, const double* wl0, const double* wl1,
                    double* lat_s, double* lat_v, int* idx, hipStream_t);
 int enc_latent_bwd(int B, int N, int C, int Ts, int Tv, const double* s, const double* v, const double* wl0, const double* wl1,

@@ -57,9 +57,11 @@ __device__ __forceinline__ void cart_from_canon(const cx<double> (&c)[4], cx<dou
 // ============================================================================================
 // z1/z2: two buffers the step wants zeroed before anything later in the stream touches them (the flat gradient buffer and
 // the zero-initialised workspace block); folded into this first kernel instead of two memset launches.
-__global__ void enc_input_fwd_kernel(int B, int N, int C, const double* __restrict__ p4, const double* __restrict__ w0,
-                                     const double* __restrict__ w1, double* s, double* v, double* z1, size_t n1, double* z2,
-                                     size_t n2) {
+// K input scalars per node (MixReps weight w0 [2][C][K]): x_0 = the mass, x_1 .. x_{K-1} from xs [B][N][K-1] (jet_features: the
+// jet's un-rooted normsq4, then data['scalars']; lgn_encoder.py:372-411).  K = 1: xs unused.
+__global__ void enc_input_fwd_kernel(int B, int N, int C, int K, const double* __restrict__ p4, const double* __restrict__ xs,
+                                     const double* __restrict__ w0, const double* __restrict__ w1, double* s, double* v, double* z1,
+                                     size_t n1, double* z2, size_t n2) {
   const size_t total = (size_t)B * N * C, pl = total;
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n1; e += (size_t)gridDim.x * blockDim.x) z1[e] = 0.0;
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n2; e += (size_t)gridDim.x * blockDim.x) z2[e] = 0.0;
@@ -70,8 +72,14 @@ __global__ void enc_input_fwd_kernel(int B, int N, int C, const double* __restri
     const double mass = sqrt(fabs(minkowski_sq_ref(p)));
     cx<double> q[4];
     canon_real(p, q);
-    s[e] = w0[c] * mass;                  // W00[c] * (mass + 0i)
-    s[pl + e] = w0[C + c] * mass;
+    double sr = w0[c * K] * mass, si = w0[(C + c) * K] * mass;       // W00[c][0] * (mass + 0i)
+    for (int k = 1; k < K; ++k) {
+      const double x = xs[node * (K - 1) + (k - 1)];
+      sr = __builtin_fma(w0[c * K + k], x, sr);
+      si = __builtin_fma(w0[(C + c) * K + k], x, si);
+    }
+    s[e] = sr;
+    s[pl + e] = si;
     const cx<double> w = {w1[c], w1[C + c]};
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
@@ -82,13 +90,14 @@ __global__ void enc_input_fwd_kernel(int B, int N, int C, const double* __restri
   }
 }
 
-// partial rows [nblk][4C]: dW00 (re[C], im[C]) then dW11 (re[C], im[C]).  One workgroup per jet:
-// thread = (node, channel) writes its four terms to LDS, thread = (term, channel) adds them up in node order.
-__global__ __launch_bounds__(BLOCK) void enc_input_bwd_kernel(int B, int N, int C, const double* __restrict__ p4,
-                                                             const double* __restrict__ g_s, const double* __restrict__ g_v,
-                                                             double* part) {
+// partial rows [nblk][(2K + 2) C]: dW00 (re [C][K], im [C][K]) then dW11 (re[C], im[C]).  One workgroup per jet:
+// thread = (node, channel) writes its 2K + 2 terms to LDS, thread = (term, channel) adds them up in node order.
+__global__ __launch_bounds__(BLOCK) void enc_input_bwd_kernel(int B, int N, int C, int K, const double* __restrict__ p4,
+                                                             const double* __restrict__ xs, const double* __restrict__ g_s,
+                                                             const double* __restrict__ g_v, double* part) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
-  double* tmp = reinterpret_cast<double*>(smem_raw);    // [N*C][4]
+  double* tmp = reinterpret_cast<double*>(smem_raw);    // [N*C][2K + 2]: (g_s.r x_k)_k | (g_s.i x_k)_k | d1.r | d1.i
+  const int T = 2 * K + 2;
   const int b = blockIdx.x;
   const size_t pl = (size_t)B * N * C;
   for (int i = threadIdx.x; i < N * C; i += BLOCK) {
@@ -101,17 +110,33 @@ __global__ __launch_bounds__(BLOCK) void enc_input_bwd_kernel(int B, int N, int 
     cx<double> d1 = {0, 0};
 #pragma unroll
     for (int m = 0; m < 4; ++m) cfmac(d1, cx<double>{g_v[e * 4 + m], g_v[pl * 4 + e * 4 + m]}, q[m]);
-    tmp[i * 4 + 0] = g_s[e] * mass;
-    tmp[i * 4 + 1] = g_s[pl + e] * mass;
-    tmp[i * 4 + 2] = d1.r;
-    tmp[i * 4 + 3] = d1.i;
+    const double gr = g_s[e], gi = g_s[pl + e];
+    tmp[i * T + 0] = gr * mass;
+    tmp[i * T + K] = gi * mass;
+    for (int k = 1; k < K; ++k) {
+      const double x = xs[((size_t)b * N + n) * (K - 1) + (k - 1)];
+      tmp[i * T + k] = gr * x;
+      tmp[i * T + K + k] = gi * x;
+    }
+    tmp[i * T + 2 * K] = d1.r;
+    tmp[i * T + 2 * K + 1] = d1.i;
   }
   __syncthreads();
-  if ((int)threadIdx.x < 4 * C) {
-    const int k = threadIdx.x / C, c = threadIdx.x - k * C;
+  // output column o of the partial row: o < 2CK: (plane z, channel c, scalar k) = W00 layout; then dW11 re[C], im[C]
+  for (int o = threadIdx.x; o < T * C; o += BLOCK) {
+    int c, t;
+    if (o < 2 * C * K) {
+      const int z = o / (C * K), r = o - z * C * K;
+      c = r / K;
+      t = z * K + (r - c * K);
+    } else {
+      const int r = o - 2 * C * K, z = r / C;
+      c = r - z * C;
+      t = 2 * K + z;
+    }
     double acc = 0.0;
-    for (int n = 0; n < N; ++n) acc += tmp[(n * C + c) * 4 + k];
-    part[(size_t)b * 4 * C + k * C + c] = acc;
+    for (int n = 0; n < N; ++n) acc += tmp[(n * C + c) * T + t];
+    part[(size_t)b * T * C + o] = acc;
   }
 }
 
@@ -839,26 +864,31 @@ __global__ __launch_bounds__(BLOCK) void l1_adam_kernel(long n, double* w, doubl
 // ---------------------------------------------------------------------------------------------
 // host launchers
 // ---------------------------------------------------------------------------------------------
+#define LGN_LDS_LAUNCH(kernel, what, smem)                                                                            \
+  LGN_CHECK_ARG((smem) <= 160 * 1024, what ": needs %zu B of LDS", (size_t)(smem));                                    \
+  if ((smem) > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(smem))
 static int grid_for(size_t total) {
   size_t g = (total + BLOCK - 1) / BLOCK;
   return (int)(g < 2048 ? (g ? g : 1) : 2048);
 }
 
-int enc_input_fwd(int B, int N, int C, const double* p4, const double* w0, const double* w1, double* s, double* v, hipStream_t st,
-                  double* z1, size_t n1, double* z2, size_t n2) {
-  hipLaunchKernelGGL(enc_input_fwd_kernel, dim3(grid_for((size_t)B * N * C)), dim3(BLOCK), 0, st, B, N, C, p4, w0, w1, s, v, z1, n1,
-                     z2, n2);
+int enc_input_fwd(int B, int N, int C, int K, const double* p4, const double* xs, const double* w0, const double* w1, double* s, double* v,
+                  hipStream_t st, double* z1, size_t n1, double* z2, size_t n2) {
+  LGN_CHECK_ARG(K >= 1 && (K == 1 || xs), "enc_input: %d input scalars need the extra-scalar array", K);
+  hipLaunchKernelGGL(enc_input_fwd_kernel, dim3(grid_for((size_t)B * N * C)), dim3(BLOCK), 0, st, B, N, C, K, p4, xs, w0, w1, s, v, z1,
+                     n1, z2, n2);
   LGN_CHECK_LAUNCH();
   return 0;
 }
-int enc_input_bwd(int B, int N, int C, const double* p4, const double* g_s, const double* g_v, double* part, hipStream_t st) {
-  hipLaunchKernelGGL(enc_input_bwd_kernel, dim3(B), dim3(BLOCK), sizeof(double) * N * C * 4, st, B, N, C, p4, g_s, g_v, part);
+int enc_input_bwd(int B, int N, int C, int K, const double* p4, const double* xs, const double* g_s, const double* g_v, double* part,
+                  hipStream_t st) {
+  LGN_CHECK_ARG(K >= 1 && (K == 1 || xs), "enc_input: %d input scalars need the extra-scalar array", K);
+  const size_t smem = sizeof(double) * N * C * (2 * K + 2);
+  LGN_LDS_LAUNCH(enc_input_bwd_kernel, "enc_input_bwd", smem);
+  hipLaunchKernelGGL(enc_input_bwd_kernel, dim3(B), dim3(BLOCK), smem, st, B, N, C, K, p4, xs, g_s, g_v, part);
   LGN_CHECK_LAUNCH();
   return 0;
 }
-#define LGN_LDS_LAUNCH(kernel, what, smem)                                                                            \
-  LGN_CHECK_ARG((smem) <= 160 * 1024, what ": needs %zu B of LDS", (size_t)(smem));                                    \
-  if ((smem) > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(smem))
 int enc_latent_fwd(int B, int N, int C, int Ts, int Tv, const double* s, const double* v, const double* wl0, const double* wl1,
                    double* lat_s, double* lat_v, int* idx, hipStream_t st) {
   const size_t smem = sizeof(double) * lat_fwd_doubles(N, C, Ts, Tv);

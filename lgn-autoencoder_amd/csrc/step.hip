@@ -144,6 +144,8 @@ size_t mlp_part_rows(const lgn_net_desc& d, bool dec, int l) {
   return fuses_mlp(d, dec, l, true) ? (size_t)d.B * level_mlp_passes(d.N) : (size_t)mlp_partial_rows(d.B * d.N, d.mlp_hidden_mul * 2 * ch[l + 1]);
 }
 
+inline int in_K(const lgn_net_desc& d) { return d.n_in_scalars > 1 ? d.n_in_scalars : 1; }      // encoder input scalars per node
+
 int mlp_psize(int C, int H, int nlin) {
   const int D = 2 * C;
   return nlin == 1 ? D * D + D : (H * D + H) + (nlin - 2) * (H * H + H) + (D * H + D);
@@ -372,6 +374,7 @@ int check_desc(const lgn_net_desc* d) {
   LGN_CHECK_ARG(d->n_levels >= 1 && d->n_levels <= 4, "step: n_levels=%d unsupported (1..4)", d->n_levels);
   LGN_CHECK_ARG(d->mlp_nlin == 7, "step: mlp_depth must be 6 (7 Linear layers)");
   LGN_CHECK_ARG(d->tau_s >= 1 && d->tau_v >= 1 && d->tau_v_in >= 0, "step: latent multiplicities must be positive");
+  LGN_CHECK_ARG(d->n_in_scalars >= 0 && d->n_in_scalars <= 8, "step: n_in_scalars=%d unsupported (0..8)", d->n_in_scalars);
   for (int l = 0; l <= d->n_levels; ++l)
     LGN_CHECK_ARG(d->enc_channels[l] >= 1 && d->enc_channels[l] <= 8 && d->dec_channels[l] >= 1 && d->dec_channels[l] <= 8,
                   "step: channel counts must be in 1..8");
@@ -541,7 +544,7 @@ GenScratch carve_gen_scratch(const lgn_net_desc& d, bool dec, double* base) {
   }
   const int Tin = d.tau_v_in > 0 ? d.tau_v_in : 2 * d.tau_v;
   if (dec) psum += (((size_t)d.B * 2 * g.ch[L] + 15) & ~size_t(15)) + (((size_t)d.B * (4 * g.ch[0] + 2 * (size_t)d.N * Tin) + 15) & ~size_t(15));
-  else psum += (((size_t)d.B * 2 * (d.tau_s + d.tau_v) * g.ch[L] + 15) & ~size_t(15)) + (((size_t)d.B * 4 * g.ch[0] + 15) & ~size_t(15));
+  else psum += (((size_t)d.B * 2 * (d.tau_s + d.tau_v) * g.ch[L] + 15) & ~size_t(15)) + (((size_t)d.B * (2 * in_K(d) + 2) * g.ch[0] + 15) & ~size_t(15));
   s.parts = b.take(psum);
   s.parts_size = psum;
   s.total = b.off;
@@ -687,11 +690,11 @@ int net_unpack(const lgn_net_desc& d, bool dec, int l, const double* X, double* 
 
 // ---- one table-driven network, forward / backward (shared by the per-network API and the whole step) ----------------
 int gen_encoder_fwd(const lgn_net_desc& d, const double* P, const int64_t* off, const double* p4, const uint8_t* mask, GenAct& a,
-                    double* lat_s, double* lat_v, hipStream_t st) {
+                    double* lat_s, double* lat_v, hipStream_t st, const double* xs = nullptr) {
   const Slots S{d.n_levels, d.mlp_nlin};
   const GenGeom g = geom(d, false);
   const int L = d.n_levels;
-  LGN_TRY(enc_input_fwd(d.B, d.N, g.ch[0], p4, P + off[0], P + off[1], a.s0, a.v0, st));
+  LGN_TRY(enc_input_fwd(d.B, d.N, g.ch[0], in_K(d), p4, xs, P + off[0], P + off[1], a.s0, a.v0, st));
   LGN_TRY(net_pack(d, false, 0, a.s0, a.v0, a.X[0], st));
   LGN_TRY(gen_levels_fwd(d, false, P, off, a, p4, mask, st));
   LGN_TRY(net_unpack(d, false, L, a.X[L], a.sL, a.vL, st));
@@ -702,7 +705,8 @@ int gen_encoder_fwd(const lgn_net_desc& d, const double* P, const int64_t* off, 
 
 // the caller has zero-filled G and sc's zero block
 int gen_encoder_bwd(const lgn_net_desc& d, const double* P, double* G, const int64_t* off, const double* p4, const uint8_t* mask,
-                    const GenAct& a, const double* g_lat_s, const double* g_lat_v, GenScratch& sc, hipStream_t st) {
+                    const GenAct& a, const double* g_lat_s, const double* g_lat_v, GenScratch& sc, hipStream_t st,
+                    const double* xs = nullptr) {
   const Slots S{d.n_levels, d.mlp_nlin};
   const GenGeom g = geom(d, false);
   const int L = d.n_levels, B = d.B, N = d.N, Ts = d.tau_s, Tv = d.tau_v;
@@ -725,10 +729,11 @@ int gen_encoder_bwd(const lgn_net_desc& d, const double* P, double* G, const int
   {
     const int C0 = g.ch[0];
     LGN_TRY(net_unpack(d, false, 0, sc.gX[cur], sc.gs, sc.gv, st));
-    DQ_NEW(part, (size_t)B * 4 * C0);
-    LGN_TRY(enc_input_bwd(B, N, C0, p4, sc.gs, sc.gv, part, st));
-    dq.add(part, B, 4 * C0, 0, 2 * C0, G + off[0]);
-    dq.add(part, B, 4 * C0, 2 * C0, 2 * C0, G + off[1]);
+    const int K = in_K(d), row = (2 * K + 2) * C0;
+    DQ_NEW(part, (size_t)B * row);
+    LGN_TRY(enc_input_bwd(B, N, C0, K, p4, xs, sc.gs, sc.gv, part, st));
+    dq.add(part, B, row, 0, 2 * C0 * K, G + off[0]);
+    dq.add(part, B, row, 2 * C0 * K, 2 * C0, G + off[1]);
   }
   LGN_CHECK_ARG(dq.off <= dq.cap, "encoder_bwd: partial-row workspace overflow (%zu > %zu)", dq.off, dq.cap);
   LGN_TRY(dq.flush(st));
@@ -917,7 +922,7 @@ NetScratch carve_scratch(const lgn_net_desc& d, bool dec, double* base) {
     int rm0, rr0;                                          // input-stage partial rows: one per workgroup of the first level's backward
     level_bwd_partial_rows(d.B, d.N, 0, d.flags, &rm0, &rr0);
     if (rm0 < d.B) rm0 = d.B;
-    psum += (((size_t)d.B * 2 * (Ts + Tv) * ch[L] + 15) & ~size_t(15)) + (((size_t)rm0 * 4 * ch[0] + 15) & ~size_t(15));
+    psum += (((size_t)d.B * 2 * (Ts + Tv) * ch[L] + 15) & ~size_t(15)) + (((size_t)rm0 * (2 * in_K(d) + 2) * ch[0] + 15) & ~size_t(15));
   }
   w.parts = b.take(psum);
   w.parts_size = psum;
@@ -942,14 +947,15 @@ long long lgn_net_workspace_doubles(const lgn_net_desc* d, int decoder, int whic
 }
 
 int lgn_encoder_fwd_f64(const lgn_net_desc* d, const double* params, const int64_t* off, const double* p4, const uint8_t* mask,
-                        double* act, long long act_doubles, double* lat_s, double* lat_v, void* stream) {
+                        const double* in_scalars, double* act, long long act_doubles, double* lat_s, double* lat_v, void* stream) {
   if (int rc = check_desc(d)) return rc;
   LGN_CHECK_ARG(params && off && p4 && mask && act && lat_s && lat_v, "encoder_fwd: null pointer");
+  LGN_CHECK_ARG(d->n_in_scalars <= 1 || in_scalars, "encoder_fwd: %d input scalars per node, but in_scalars is NULL", d->n_in_scalars);
   if (is_generic(*d, false)) {
     if (int rc = check_generic(*d, false)) return rc;
     GenAct ga = carve_gen_act(*d, false, act);
     LGN_CHECK_ARG((long long)ga.total <= act_doubles, "encoder_fwd: activation buffer holds %lld doubles, needs %zu", act_doubles, ga.total);
-    return gen_encoder_fwd(*d, params, off, p4, mask, ga, lat_s, lat_v, (hipStream_t)stream);
+    return gen_encoder_fwd(*d, params, off, p4, mask, ga, lat_s, lat_v, (hipStream_t)stream, in_scalars);
   }
   NetAct a = carve_act(*d, false, act);
   LGN_CHECK_ARG((long long)a.total <= act_doubles, "encoder_fwd: activation buffer holds %lld doubles, needs %zu", act_doubles, a.total);
@@ -957,18 +963,24 @@ int lgn_encoder_fwd_f64(const lgn_net_desc* d, const double* params, const int64
   const Slots S{d->n_levels, d->mlp_nlin};
   const int L = d->n_levels;
   const int* ce = d->enc_channels;
-  const InputStage in0{params + off[0], params + off[1]};                 // (rides on the first level's kernel)
-  LGN_TRY(levels_fwd(*d, false, ce, params, off, a.n, p4, mask, st, &in0));
+  if (in_K(*d) > 1) {        // several input scalars: the input stage is its own launch
+    LGN_TRY(enc_input_fwd(d->B, d->N, ce[0], in_K(*d), p4, in_scalars, params + off[0], params + off[1], a.n.s[0], a.n.v[0], st));
+    LGN_TRY(levels_fwd(*d, false, ce, params, off, a.n, p4, mask, st));
+  } else {
+    const InputStage in0{params + off[0], params + off[1]};               // (rides on the first level's kernel)
+    LGN_TRY(levels_fwd(*d, false, ce, params, off, a.n, p4, mask, st, &in0));
+  }
   LGN_TRY(enc_latent_fwd(d->B, d->N, ce[L], d->tau_s, d->tau_v, a.n.s[L], a.n.v[L], params + off[S.out0(false)],
                          params + off[S.out0(false) + 1], lat_s, lat_v, a.idx, st));
   return 0;
 }
 
 int lgn_encoder_bwd_f64(const lgn_net_desc* d, const double* params, double* grads, long long n_params, const int64_t* off,
-                        const double* p4, const uint8_t* mask, const double* act, long long act_doubles, const double* g_lat_s,
-                        const double* g_lat_v, double* scratch, long long scratch_doubles, void* stream) {
+                        const double* p4, const uint8_t* mask, const double* in_scalars, const double* act, long long act_doubles,
+                        const double* g_lat_s, const double* g_lat_v, double* scratch, long long scratch_doubles, void* stream) {
   if (int rc = check_desc(d)) return rc;
   LGN_CHECK_ARG(params && grads && off && p4 && mask && act && g_lat_v && scratch && n_params > 0, "encoder_bwd: null pointer");
+  LGN_CHECK_ARG(d->n_in_scalars <= 1 || in_scalars, "encoder_bwd: %d input scalars per node, but in_scalars is NULL", d->n_in_scalars);
   if (is_generic(*d, false)) {
     if (int rc = check_generic(*d, false)) return rc;
     GenAct ga = carve_gen_act(*d, false, const_cast<double*>(act));
@@ -977,7 +989,7 @@ int lgn_encoder_bwd_f64(const lgn_net_desc* d, const double* params, double* gra
                   "encoder_bwd: buffers hold %lld / %lld doubles, need %zu / %zu", act_doubles, scratch_doubles, ga.total, gs.total);
     if (int rc = check_mlp_contiguous(*d, false, off)) return rc;
     LGN_TRY(zero_grads_and_block(grads, (size_t)n_params, gs.zero0, gs.zero_doubles, (hipStream_t)stream));
-    return gen_encoder_bwd(*d, params, grads, off, p4, mask, ga, g_lat_s, g_lat_v, gs, (hipStream_t)stream);
+    return gen_encoder_bwd(*d, params, grads, off, p4, mask, ga, g_lat_s, g_lat_v, gs, (hipStream_t)stream, in_scalars);
   }
   NetAct a = carve_act(*d, false, const_cast<double*>(act));
   NetScratch sc = carve_scratch(*d, false, scratch);
@@ -1006,14 +1018,15 @@ int lgn_encoder_bwd_f64(const lgn_net_desc* d, const double* params, double* gra
   // without an upstream gradient on the latent scalars the last level's scalars (and its CGMLP) receive none
   double* const in0_grads[2] = {grads + off[0], grads + off[1]};
   bool in0_done = false;
+  const int K = in_K(*d);      // (several input scalars: the input stage's backward is its own launch, nothing rides)
   LGN_TRY(levels_bwd(*d, false, ce, params, grads, off, a.n, p4, mask, w, dq, fin, cur, /*has_s_grad=*/g_lat_s != nullptr, st, false,
-                     in0_grads, &in0_done));
+                     K > 1 ? nullptr : in0_grads, &in0_done));
   if (!in0_done) {
-    const int C0 = ce[0];
-    DQ_NEW(part, (size_t)B * 4 * C0);
-    LGN_TRY(enc_input_bwd(B, N, C0, p4, w.gs[cur], w.gv[cur], part, st));
-    dq.add(part, B, 4 * C0, 0, 2 * C0, grads + off[0]);
-    dq.add(part, B, 4 * C0, 2 * C0, 2 * C0, grads + off[1]);
+    const int C0 = ce[0], row = (2 * K + 2) * C0;
+    DQ_NEW(part, (size_t)B * row);
+    LGN_TRY(enc_input_bwd(B, N, C0, K, p4, in_scalars, w.gs[cur], w.gv[cur], part, st));
+    dq.add(part, B, row, 0, 2 * C0 * K, grads + off[0]);
+    dq.add(part, B, row, 2 * C0 * K, 2 * C0, grads + off[1]);
   }
   LGN_CHECK_ARG(dq.off <= dq.cap, "encoder_bwd: partial-row workspace overflow (%zu > %zu)", dq.off, dq.cap);
   LGN_TRY(dq.flush(st));
@@ -1134,6 +1147,8 @@ int lgn_step_fwd_bwd_f64(const lgn_net_desc* d, const double* params, double* gr
   if (int rc = check_desc(d)) return rc;
   LGN_CHECK_ARG(params && grads && enc_off && dec_off && p4 && target && mask && workspace && recon && loss_part && n_params > 0,
                 "step_fwd_bwd: null pointer");
+  LGN_CHECK_ARG(d->n_in_scalars <= 1, "step_fwd_bwd: the whole-step call takes the mass as the only input scalar (n_in_scalars=%d): "
+                "use the per-network calls", d->n_in_scalars);
   hipStream_t st = (hipStream_t)stream;
   if (is_generic(*d, false) || is_generic(*d, true))
     return gen_step_fwd_bwd(*d, params, grads, n_params, enc_off, dec_off, p4, target, mask, workspace, workspace_doubles, recon,
@@ -1217,7 +1232,7 @@ int lgn_step_fwd_bwd_f64(const lgn_net_desc* d, const double* params, double* gr
   if (!in0_done) {      // (three-kernel level backward: N > 40, LGN_AMD_LEVEL_V2)
     const int C0 = ce[0];
     DQ_NEW(part, (size_t)B * 4 * C0);
-    LGN_TRY(enc_input_bwd(B, N, C0, p4, w.gs[cur], w.gv[cur], part, st));
+    LGN_TRY(enc_input_bwd(B, N, C0, 1, p4, nullptr, w.gs[cur], w.gv[cur], part, st));
     dq.add(part, B, 4 * C0, 0, 2 * C0, grads + enc_off[0]);
     dq.add(part, B, 4 * C0, 2 * C0, 2 * C0, grads + enc_off[1]);
   }

@@ -15,7 +15,7 @@ import torch  # imported before the .so so that the process-wide libamdhip64 is 
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LGN_AMD_LIB") or os.path.join(_HERE, "_lib", "liblgn_amd.so")   # LGN_AMD_LIB: debug builds (tools/)
-ABI_VERSION = 11
+ABI_VERSION = 12
 FINALIZE_SCRATCH = 2048      # include/lgn_amd.h: LGN_FINALIZE_SCRATCH
 
 _lib: Optional[C.CDLL] = None
@@ -62,7 +62,7 @@ class NetDesc(C.Structure):
                 ("enc_tables", _tp * 4), ("dec_tables", _tp * 4),
                 ("enc_Q", C.c_int * 5), ("enc_qs", C.c_int * 5), ("enc_qv", C.c_int * 5),
                 ("dec_Q", C.c_int * 5), ("dec_qs", C.c_int * 5), ("dec_qv", C.c_int * 5), ("flags", C.c_int),
-                ("activation", C.c_int)]
+                ("activation", C.c_int), ("n_in_scalars", C.c_int)]
 
     def __init__(self, *a, **kw):
         super().__init__(*a, **kw)
@@ -103,8 +103,8 @@ _SIGNATURES.update({
     "lgn_local_bwd_f64": [_i] * 5 + [_tp] + [_vp] * 8,
     "lgn_step_param_slots": [_dp, _i],
     "lgn_step_fwd_bwd_f64": [_dp, _vp, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _vp, _vp, _vp],
-    "lgn_encoder_fwd_f64": [_dp, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _vp, _vp],
-    "lgn_encoder_bwd_f64": [_dp, _vp, _vp, _ll, _vp, _vp, _vp, _vp, _ll, _vp, _vp, _vp, _ll, _vp],
+    "lgn_encoder_fwd_f64": [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _vp, _vp],
+    "lgn_encoder_bwd_f64": [_dp, _vp, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _vp, _vp, _ll, _vp],
     "lgn_decoder_fwd_f64": [_dp, _vp, _vp, _vp, _vp, _ll, _vp, _vp],
     "lgn_decoder_bwd_f64": [_dp, _vp, _vp, _ll, _vp, _vp, _vp, _ll, _vp, _vp, _vp, _ll, _vp],
     "lgn_step_finalize_f64": [_vp, _vp, _ll, _vp, _i, _d, _vp, _vp, _vp, _d, _d, _d, _d, _i, _vp, _vp],

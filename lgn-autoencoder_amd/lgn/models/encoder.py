@@ -85,7 +85,7 @@ class LGNEncoder(CGModule, LevelTablesMixin):
         node_ps, node_mask, scalars = self._prepare_input(data)
         if not covariance_test and self.use_fused and self._fused_ok():
             # the whole encoder is one native call (and one more for its backward): csrc/step.hip lgn_encoder_fwd/bwd_f64
-            lat_s, lat_v = ops.EncoderFn.apply(self, node_ps, node_mask, self.flat_params)
+            lat_s, lat_v = ops.EncoderFn.apply(self, node_ps, node_mask, self.flat_params, scalars)
             return GVec({(0, 0): lat_s, (1, 1): lat_v})
         # module / autograd path: one native call per operator (all irreps, every map_to_latent, internal features)
         self._bind(self._tracked_views())
@@ -96,8 +96,8 @@ class LGNEncoder(CGModule, LevelTablesMixin):
 
     def _fused_ok(self) -> bool:
         """True when a whole-network native implementation covers this configuration (lgn/ops.py: native_kind)."""
-        # the whole-network calls take the mass as the only input scalar: jet features / extra scalars run per operator
-        return ops.native_kind(self) is not None and self.tau_input_scalars == 1
+        # (jet features / extra input scalars included: lgn_net_desc.n_in_scalars, round 4)
+        return ops.native_kind(self) is not None and self.tau_input_scalars <= 8
 
     def _forward_modular(self, node_ps, node_mask, covariance_test, scalars=None):
         # input features: (0,0) = (sqrt|p^2| [, jet mass, extra scalars], 0), (1,1) = canonical(p)   (lgn_encoder.py:287-293,376)

@@ -367,6 +367,7 @@ def describe_network(d, net, decoder: bool):
         d.tau_v_in = net.tau_latent_vectors
     else:
         d.tau_s, d.tau_v = net.tau_latent[(0, 0)], net.tau_latent[(1, 1)]
+        d.n_in_scalars = net.tau_input_scalars      # > 1: jet_features / data['scalars'] (per-network calls only)
     if native_kind(net) == "generic":
         tabs = d.dec_tables if decoder else d.enc_tables
         Q, qs, qv = (d.dec_Q, d.dec_qs, d.dec_qv) if decoder else (d.enc_Q, d.enc_qs, d.enc_qv)
@@ -441,24 +442,30 @@ def _alloc(n: int, like: torch.Tensor) -> torch.Tensor:
 
 class EncoderFn(torch.autograd.Function):
     """LGNEncoder.forward (lgn/models/lgn_encoder.py:255-336; 'min&max' pooling) as ONE native call, and the backward
-    autograd would run through it as one more.  args: net, p4 (B,N,4) already scaled, mask (B,N) uint8, flat_params.
+    autograd would run through it as one more.  args: net, p4 (B,N,4) already scaled, mask (B,N) uint8, flat_params, and the
+    extra input scalars (B,N,K-1) or None (jet_features / data['scalars']: data, no gradient).
     One allocation per direction: forward = [latent scalars | latent vectors | activations kept for the backward],
     backward = [parameter gradients | scratch] (the native call zero-fills gradients + its zero block with one memset)."""
 
     @staticmethod
-    def forward(ctx, net, p4, mask, flat):
+    def forward(ctx, net, p4, mask, flat, scalars=None):
         B = p4.shape[0]
         h = net_handle(net, False, B)
+        K = h.desc.n_in_scalars
+        if (K > 1) != (scalars is not None) or (scalars is not None and tuple(scalars.shape) != (B, p4.shape[1], K - 1)):
+            raise ValueError(f"the encoder takes {K} input scalars per particle (the mass + {max(K, 1) - 1} given ones); got "
+                             f"{None if scalars is None else tuple(scalars.shape)}")
+        scalars = None if scalars is None else N.f64(scalars)
         Ts, Tv = h.desc.tau_s, h.desc.tau_v
         ns, nv = _r16(4 * B * Ts), _r16(16 * B * Tv)
         buf = _alloc(ns + nv + h.n_act, flat)
         lat_s = buf[:4 * B * Ts].view(2, B, 1, 2 * Ts, 1)
         lat_v = buf[ns:ns + 16 * B * Tv].view(2, B, 1, 2 * Tv, 4)
         base = buf.data_ptr()
-        rc = N.lib().lgn_encoder_fwd_f64(h.ref, flat.data_ptr(), h.off, N.ptr(p4), N.ptr(mask), base + 8 * (ns + nv), h.n_act,
-                                         base, base + 8 * ns, N.stream_ptr())
+        rc = N.lib().lgn_encoder_fwd_f64(h.ref, flat.data_ptr(), h.off, N.ptr(p4), N.ptr(mask), N.ptr(scalars), base + 8 * (ns + nv),
+                                         h.n_act, base, base + 8 * ns, N.stream_ptr())
         N._check(rc, "lgn_encoder_fwd_f64")
-        ctx.h, ctx.act_off = h, ns + nv
+        ctx.h, ctx.act_off, ctx.scalars = h, ns + nv, scalars
         ctx.save_for_backward(p4, mask, flat, buf)
         ctx.set_materialize_grads(False)
         return lat_s, lat_v
@@ -472,14 +479,14 @@ class EncoderFn(torch.autograd.Function):
         grads = out[:h.n_params]
         if g_v is None:
             if g_s is None:
-                return None, None, None, grads.zero_()
+                return None, None, None, grads.zero_(), None
             g_v = torch.zeros(2, h.desc.B, 1, 2 * h.desc.tau_v, 4, device=flat.device, dtype=flat.dtype)
         base = out.data_ptr()
-        rc = N.lib().lgn_encoder_bwd_f64(h.ref, flat.data_ptr(), base, h.n_params, h.off, N.ptr(p4), N.ptr(mask),
+        rc = N.lib().lgn_encoder_bwd_f64(h.ref, flat.data_ptr(), base, h.n_params, h.off, N.ptr(p4), N.ptr(mask), N.ptr(ctx.scalars),
                                          buf.data_ptr() + 8 * ctx.act_off, h.n_act, N.ptr(None if g_s is None else N.f64(g_s)),
                                          N.ptr(N.f64(g_v)), base + 8 * npar, h.n_scratch, N.stream_ptr())
         N._check(rc, "lgn_encoder_bwd_f64")
-        return None, None, None, grads
+        return None, None, None, grads, None
 
 
 class DecoderFn(torch.autograd.Function):

@@ -237,9 +237,10 @@ def test_native_step_refuses_configurations_it_does_not_implement():
     enc, dec = G._models(12, (3, 3, 4, 4), (4, 4, 3, 3), torch.device("cpu"), seed=0, map_to_latent="mean+max")
     with pytest.raises(NotImplementedError, match="min&max"):
         NativeTrainStep(enc, dec, batch_size=4)
-    # jet features / extra input scalars: module API only (the whole-step call takes the masses as the only input scalars)
+    # jet features / extra input scalars: the per-network native calls take them (lgn_net_desc.n_in_scalars, round 4), the whole-step
+    # call does not (its two networks share one particle count; the encoder has one node more here)
     enc, dec = G._models(12, (3, 3, 4, 4), (4, 4, 3, 3), torch.device("cpu"), seed=0, jet_features=True)
-    assert enc.num_input_particles == 13 and enc.tau_input_scalars == 2 and not enc._fused_ok()
+    assert enc.num_input_particles == 13 and enc.tau_input_scalars == 2 and enc._fused_ok()
     assert tuple(enc.input_func_node.weight((0, 0)).shape) == (2, 3, 2)
     with pytest.raises(NotImplementedError, match="jet_features"):
         NativeTrainStep(enc, dec, batch_size=4)
