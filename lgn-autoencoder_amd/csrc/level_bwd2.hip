@@ -49,7 +49,9 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
+LGN_STAMP_DECL
 }  // namespace
+LGN_STAMP_READER(lgn_debug_stamps_bwd2)
 
 // =========================================================================================================
 // j-centric pass
@@ -539,16 +541,21 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2))) v
     for (int t = 0; t < 3; ++t) T[g][t] = v4d{0, 0, 0, 0};
   const size_t pls = (size_t)B * N * C;
   const int ngroups = (N + 3) >> 2;
+  STAMP(0);
 
   for (int ilo = 0; ilo < N; ilo += ichunk) {
     const int ihi = min(N, ilo + ichunk);
     __syncthreads();                                         // (first chunk: pj / mk staged; later: the previous chunk is swept)
+    STAMP(ilo ? 10 : 1);
     {
       const double* src = a.g_ag + ((size_t)b * N + ilo) * G::SIZE;
       for (int e = tid; e < (ihi - ilo) * G::SIZE; e += BLK) ga[e] = src[e];
     }
     __syncthreads();
+    STAMP(ilo ? 11 : 2);
     for (int rg = wave; rg < ngroups; rg += NWV) {
+      if (rg == 0) STAMP(ilo ? 12 : 3);
+      if (rg == NWV) STAMP(ilo ? 15 : 6);
       const int j = rg * 4 + tj;
       const bool jok = j < N;
       const int jj = jok ? j : N - 1;
@@ -572,6 +579,7 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2))) v
         svj[g] = {vj[g][1].r + vj[g][3].r, vj[g][1].i + vj[g][3].i};
       }
 
+      if (rg == 0) STAMP(ilo ? 13 : 4);
       for (int i0 = ilo; i0 < ihi; i0 += 4) {
         const int i = i0 + ti;
         const bool ok = jok && i < ihi;
@@ -685,6 +693,7 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2))) v
         wave_sync();
       }
 
+      if (rg == 0) STAMP(ilo ? 14 : 5);
       // this chunk's share of the node gradient of the wave's 4 particles (quad sum over the i slots), added to what
       // level_bwd_mix_kernel (direct + power part) and the earlier chunks left there.  The ten old values are all requested
       // before the first store: written as ten "+=" the loads and stores alternate (the pointers may alias for all the compiler
@@ -726,7 +735,9 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2))) v
   }
 
   // ---- radial partial row of this jet: cross-wave sum of the accumulators (D layout: T[r' = (lane>>4) + 4q][col = lane & 15]) ----
+  STAMP(20);
   __syncthreads();                                           // every wave is done with its transpose tiles (aliased by the rows below)
+  STAMP(21);
   {
     double* mine = tr + (size_t)(wave * 64 + lane) * NG * 12;
 #pragma unroll
