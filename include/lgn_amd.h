@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LGN_AMD_ABI_VERSION 12   /* bump on ANY struct or signature change (lgn/_native.py: ABI_VERSION) */
+#define LGN_AMD_ABI_VERSION 13   /* bump on ANY struct or signature change (lgn/_native.py: ABI_VERSION) */
 
 int lgn_abi_version(void);
 const char* lgn_last_error(void);
@@ -250,7 +250,20 @@ typedef struct lgn_net_desc {
                               data['scalars'], lgn/models/lgn_encoder.py:372-411: the mass, then K - 1 values per node the caller
                               passes as in_scalars -- is served by lgn_encoder_fwd/bwd_f64; the whole-step call refuses it (its two
                               networks share one particle count, jet_features gives the encoder one node more) */
+  int latent_pool;         /* encoder: how the latent channels are pooled over the particles (aggregate(), lgn/models/
+                              lgn_encoder.py:419-496): 0 = 'min&max' (the reference default), else LGN_POOL(...).  With P output
+                              blocks (one per pooling under '&', one in all under '+') the latent space is lat_s [2][B][P tau_s],
+                              lat_v [2][B][P tau_v][4], and the decoder of a whole step takes Tin = P tau_v vectors */
 } lgn_net_desc;
+/* latent pooling code: n = 1..4 poolings o0..o3 (LGN_POOL_MIN / MAX / MEAN), avg = 0: concatenated ('a&b'), 1: averaged ('a+b').
+ * min / max pick ONE particle per (plane, channel) -- by the value itself (min) / its square (max) for scalars, by the Minkowski
+ * square of the Cartesian vector for vectors (get_min_features / get_max_features, lgn_encoder.py:538-583); mean = torch.mean over
+ * the particle axis, padded particles included.  ('sum' returns an extra axis in the reference and 'mix' is a different operator:
+ * both stay on the per-operator path.) */
+#define LGN_POOL_MIN 0
+#define LGN_POOL_MAX 1
+#define LGN_POOL_MEAN 2
+#define LGN_POOL(n, avg, o0, o1, o2, o3) ((n) | ((avg) << 3) | ((o0) << 4) | ((o1) << 6) | ((o2) << 8) | ((o3) << 10))
 #define LGN_NET_NO_STATIC 1   /* table-driven levels: run-time-table kernels + node-major features (cross-check of the
                                  compile-time-table kernels; lgn/_native.py sets it from LGN_AMD_NO_STATIC at creation) */
 /* kernel-selecting cross-check switches, frozen the same way (lgn/_native.py: net_flags; the partial-row counts, whether the loss
@@ -293,8 +306,8 @@ int lgn_step_finalize_f64(double* params, double* grads, long long n_params, con
  * calls); *_bwd zero-fills `grads`, then writes every parameter gradient (dead parameters keep an exact 0) and uses
  * `scratch` (lgn_net_workspace_doubles(d, decoder, 1) doubles).
  *   encoder: p4 [B][N][4] (already scaled), mask [B][N], in_scalars [B][N][K - 1] (NULL when d->n_in_scalars <= 1: the input
- *            MixReps (0,0) weight is [2][C][K], slot 0) -> lat_s [2][B][2 tau_s], lat_v [2][B][2 tau_v][4] Cartesian
- *            ('min&max' pooling); g_lat_s may be NULL (no gradient on the latent scalars: the last level's scalar
+ *            MixReps (0,0) weight is [2][C][K], slot 0) -> lat_s [2][B][P tau_s], lat_v [2][B][P tau_v][4] Cartesian
+ *            (P = 2 for the default 'min&max' pooling, see lgn_net_desc.latent_pool); g_lat_s may be NULL (no gradient on the latent scalars: the last level's scalar
  *            branch is then skipped, like autograd would).
  *   decoder: lat_v [2][B][Tin][4] (Tin = tau_v_in, or 2 tau_v when 0) -> recon [2][B][N][4] complex Cartesian;
  *            backward from g_recon [2][B][N][4] to g_lat_v (the latent scalars never reach the output). */

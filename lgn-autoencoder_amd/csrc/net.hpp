@@ -4,23 +4,35 @@
 #include "../../include/lgn_amd.h"
 
 namespace lgn {
+// latent pooling code of include/lgn_amd.h (LGN_POOL): 0 stands for min&max
+__host__ __device__ inline int pool_canon(int code) { return code ? code : LGN_POOL(2, 0, LGN_POOL_MIN, LGN_POOL_MAX, 0, 0); }
+__host__ __device__ inline int pool_n(int code) { return pool_canon(code) & 7; }
+__host__ __device__ inline int pool_avg(int code) { return (pool_canon(code) >> 3) & 1; }
+__host__ __device__ inline int pool_op(int code, int i) { return (pool_canon(code) >> (4 + 2 * i)) & 3; }
+__host__ __device__ inline int pool_blocks(int code) { return pool_avg(code) ? 1 : pool_n(code); }   // P: output blocks per channel
+inline bool pool_valid(int code) {
+  if (code < 0 || code >= (1 << 12) || pool_n(code) < 1 || pool_n(code) > 4) return false;
+  for (int i = 0; i < 4; ++i)
+    if (pool_op(code, i) > LGN_POOL_MEAN || (i >= pool_n(code) && pool_op(code, i) != 0)) return false;
+  return true;
+}
 // z1/z2 (optional): buffers zeroed by the same launch (the step folds its two memsets into this first kernel)
 // K input scalars per node: the mass, then xs [B][N][K-1] (K = 1: xs unused); w0 = MixReps weight [2][C][K]
 int enc_input_fwd(int B, int N, int C, int K, const double* p4, const double* xs, const double* w0, const double* w1, double* s, double* v,
                   hipStream_t, double* z1 = nullptr, size_t n1 = 0, double* z2 = nullptr, size_t n2 = 0);
 // enc_latent_fwd + dec_input_fwd (resp. dec_input_bwd + enc_latent_bwd) of a jet in one launch
-int junction_fwd(int B, int N, int CL, int Ts, int Tv, const double* s, const double* v, const double* wl0, const double* wl1,
+int junction_fwd(int B, int N, int CL, int Ts, int Tv, int pool, const double* s, const double* v, const double* wl0, const double* wl1,
                  double* lat_s, double* lat_v, int* idx, int C0, const double* wg1, const double* w0, const double* w1, double* pdec,
                  double* s0, double* v0, hipStream_t);
 int junction_bwd(int B, int N, int C0, int Tin, const double* lat_v, const double* wg1, const double* w1, const double* pdec,
                  const double* g_p, const double* g_s0, const double* g_v0, double* g_lat_v, double* part_dec, int CL, int Ts, int Tv,
-                 const double* s, const double* v, const double* wl0, const double* wl1, const double* g_lat_s, const int* idx,
+                 int pool, const double* s, const double* v, const double* wl0, const double* wl1, const double* g_lat_s, const int* idx,
                  double* g_s, double* g_v, double* part_enc, hipStream_t);
 int enc_input_bwd(int B, int N, int C, int K, const double* p4, const double* xs, const double* g_s, const double* g_v,
                   double* part /*[B][(2K + 2) C]: dW00 re [C][K], im [C][K] | dW11 re[C], im[C]*/, hipStream_t);
-int enc_latent_fwd(int B, int N, int C, int Ts, int Tv, const double* s, const double* v, const double* wl0, const double* wl1,
+int enc_latent_fwd(int B, int N, int C, int Ts, int Tv, int pool, const double* s, const double* v, const double* wl0, const double* wl1,
                    double* lat_s, double* lat_v, int* idx, hipStream_t);
-int enc_latent_bwd(int B, int N, int C, int Ts, int Tv, const double* s, const double* v, const double* wl0, const double* wl1,
+int enc_latent_bwd(int B, int N, int C, int Ts, int Tv, int pool, const double* s, const double* v, const double* wl0, const double* wl1,
                    const double* g_lat_s, const double* g_lat_v, const int* idx, double* g_s, double* g_v,
                    double* part /*[B][2(Ts+Tv)C]*/, hipStream_t);
 int dec_input_fwd(int B, int N, int C, int Tin, const double* lat_v, const double* wg1, const double* w0, const double* w1,

@@ -200,9 +200,12 @@ struct LatentStage {
 };
 // after enc_latent_fwd_stage + a barrier.  TO_LDS: lat_l (LDS [2Tv][8]: re[4] | im[4]) also receives the latent vectors.
 template <bool TO_LDS>
-__device__ __forceinline__ void enc_latent_fwd_body(int B, int N, int C, int Ts, int Tv, double* lat_s, double* lat_v, int* idx,
+__device__ __forceinline__ void enc_latent_fwd_body(int B, int N, int C, int Ts, int Tv, int pool, double* lat_s, double* lat_v, int* idx,
                                                     double* lds, double* lat_l) {
   const int b = blockIdx.x, TT = Ts + Tv;
+  const int P = pool_blocks(pool), PN = pool_n(pool);
+  bool need_mean = false;
+  for (int i = 0; i < PN; ++i) need_mean |= pool_op(pool, i) == LGN_POOL_MEAN;
   const int YS = 2 * Ts + 8 * Tv;                       // per-node stride
   double* y = lds;                                      // [n][t] : scalars 2 (re,im), vectors 8 (cart re[4], im[4])
   const double* sv = y + N * YS;
@@ -270,17 +273,48 @@ __device__ __forceinline__ void enc_latent_fwd_body(int B, int N, int C, int Ts,
     imin = __shfl(imin, 0, 8);        // (identical on all 8 lanes unless NaNs are present: lane 0 holds the sequential scan's answer)
     imax = __shfl(imax, 0, 8);
     if (l8 < 2) idx[(((size_t)b * 2 + z) * TT + t) * 2 + l8] = l8 ? imax : imin;
-    if (t < Ts) {
-      if (l8 < 2) lat_s[((size_t)z * B + b) * 2 * Ts + l8 * Ts + t] = y[(l8 ? imax : imin) * YS + 2 * t + z];
-    } else {
-      const int tv = t - Ts, kind = l8 >> 2, m = l8 & 3;
-      const double val = y[(kind ? imax : imin) * YS + 2 * Ts + 8 * tv + 4 * z + m];
-      lat_v[(((size_t)z * B + b) * 2 * Tv + kind * Tv + tv) * 4 + m] = val;
-      if constexpr (TO_LDS) lat_l[(kind * Tv + tv) * 8 + 4 * z + m] = val;
+    // the item's components in y: one (scalar channel) or four (vector channel), at y[n * YS + y0 + m]
+    const int nc = t < Ts ? 1 : 4, y0 = t < Ts ? 2 * t + z : 2 * Ts + 8 * (t - Ts) + 4 * z;
+    double mean[4] = {0, 0, 0, 0};     // torch.mean over the particle axis, padded particles included (lgn_encoder.py:450-452)
+    if (need_mean) {
+      for (int n = l8; n < N; n += 8)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          if (m < nc) mean[m] += y[n * YS + y0 + m];
+#pragma unroll
+      for (int off = 4; off; off >>= 1)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) mean[m] += __shfl_xor(mean[m], off, 8);      // (every lane ends with the same sum)
+#pragma unroll
+      for (int m = 0; m < 4; ++m) mean[m] /= (double)N;
+    }
+    // output blocks: '&' = one block per pooling, '+' = one block holding their average (lgn_encoder.py:454-496)
+    for (int k = l8; k < P * nc; k += 8) {
+      const int pb = k / nc, m = k - pb * nc;
+      auto pick = [&](int op) -> double {
+        if (op == LGN_POOL_MIN) return y[imin * YS + y0 + m];
+        if (op == LGN_POOL_MAX) return y[imax * YS + y0 + m];
+        return m == 0 ? mean[0] : (m == 1 ? mean[1] : (m == 2 ? mean[2] : mean[3]));
+      };
+      double val;
+      if (pool_avg(pool)) {
+        val = pick(pool_op(pool, 0));
+        for (int i = 1; i < PN; ++i) val += pick(pool_op(pool, i));
+        val /= (double)PN;
+      } else {
+        val = pick(pool_op(pool, pb));
+      }
+      if (t < Ts) {
+        lat_s[((size_t)z * B + b) * P * Ts + pb * Ts + t] = val;
+      } else {
+        const int tv = t - Ts;
+        lat_v[(((size_t)z * B + b) * P * Tv + pb * Tv + tv) * 4 + m] = val;
+        if constexpr (TO_LDS) lat_l[(pb * Tv + tv) * 8 + 4 * z + m] = val;
+      }
     }
   }
 }
-__global__ __launch_bounds__(BLOCK) void enc_latent_fwd_kernel(int B, int N, int C, int Ts, int Tv,
+__global__ __launch_bounds__(BLOCK) void enc_latent_fwd_kernel(int B, int N, int C, int Ts, int Tv, int pool,
                                                               const double* __restrict__ s, const double* __restrict__ v,
                                                               const double* __restrict__ wl0, const double* __restrict__ wl1,
                                                               double* lat_s, double* lat_v, int* idx) {
@@ -290,7 +324,7 @@ __global__ __launch_bounds__(BLOCK) void enc_latent_fwd_kernel(int B, int N, int
   st.issue(B, N, C, Ts, Tv, s, v, wl0, wl1);
   st.commit(lds, false);
   __syncthreads();
-  enc_latent_fwd_body<false>(B, N, C, Ts, Tv, lat_s, lat_v, idx, lds, nullptr);
+  enc_latent_fwd_body<false>(B, N, C, Ts, Tv, pool, lat_s, lat_v, idx, lds, nullptr);
 }
 
 // backward: scatter the latent gradient to the selected particles, undo rep_to_p and the MixReps.
@@ -305,23 +339,22 @@ __host__ __device__ inline size_t lat_bwd_doubles(int N, int C, int Ts, int Tv) 
 // `pre`: the pooling indices (and latent-scalar gradients) of this thread's (plane, channel), fetched with the staging loads
 struct LatentBwdPrefetch {
   int n[2];
-  double gs[2];
+  double gs[4];
   bool valid;
-  __device__ __forceinline__ void issue(int B, int Ts, int Tv, const int* __restrict__ idx, const double* __restrict__ g_lat_s) {
-    const int TT = Ts + Tv, e = threadIdx.x, b = blockIdx.x;
+  __device__ __forceinline__ void issue(int B, int Ts, int Tv, int pool, const int* __restrict__ idx, const double* __restrict__ g_lat_s) {
+    const int TT = Ts + Tv, e = threadIdx.x, b = blockIdx.x, P = pool_blocks(pool);
     valid = 2 * TT <= BLOCK;
     if (valid && e < 2 * TT) {
       const int z = e / TT, t = e - z * TT;
 #pragma unroll
-      for (int kind = 0; kind < 2; ++kind) {
-        n[kind] = idx[(((size_t)b * 2 + z) * TT + t) * 2 + kind];
-        gs[kind] = t < Ts ? g_lat_s[((size_t)z * B + b) * 2 * Ts + kind * Ts + t] : 0.0;
-      }
+      for (int kind = 0; kind < 2; ++kind) n[kind] = idx[(((size_t)b * 2 + z) * TT + t) * 2 + kind];
+#pragma unroll
+      for (int pb = 0; pb < 4; ++pb) gs[pb] = (t < Ts && pb < P) ? g_lat_s[((size_t)z * B + b) * P * Ts + pb * Ts + t] : 0.0;
     }
   }
 };
 template <bool FROM_LDS>
-__device__ __forceinline__ void enc_latent_bwd_body(int B, int N, int C, int Ts, int Tv, const double* __restrict__ g_lat_s,
+__device__ __forceinline__ void enc_latent_bwd_body(int B, int N, int C, int Ts, int Tv, int pool, const double* __restrict__ g_lat_s,
                                                     const double* __restrict__ g_lat_v, const double* g_lat_l,
                                                     const int* __restrict__ idx, double* g_s, double* g_v, double* part, double* lds,
                                                     const LatentBwdPrefetch& pre) {
@@ -334,21 +367,44 @@ __device__ __forceinline__ void enc_latent_bwd_body(int B, int N, int C, int Ts,
   double* red = const_cast<double*>(w1l) + 2 * Tv * C;  // [LAT_PARTS][TT*C][2]
   const size_t pl = (size_t)B * N * C;
   STAMP(14);
+  const int P = pool_blocks(pool), PN = pool_n(pool);
   for (int e = threadIdx.x; e < 2 * TT; e += BLOCK) {    // (plane, channel) owners: no write conflicts
     const int z = e / TT, t = e - z * TT;
+    int nmm[2];                                          // arg-min, arg-max of this (plane, channel)
 #pragma unroll
-    for (int kind = 0; kind < 2; ++kind) {
-      const int n = pre.valid ? pre.n[kind] : idx[(((size_t)b * 2 + z) * TT + t) * 2 + kind];
+    for (int kind = 0; kind < 2; ++kind) nmm[kind] = pre.valid ? pre.n[kind] : idx[(((size_t)b * 2 + z) * TT + t) * 2 + kind];
+    const int nc = t < Ts ? 1 : 4, y0 = t < Ts ? 2 * t + z : 2 * Ts + 8 * (t - Ts) + 4 * z;
+    // '&': block pb carries the gradient of pooling pb; '+': the one block's gradient / PN goes to every pooling
+    const int nscat = pool_avg(pool) ? PN : P;
+    for (int i = 0; i < nscat; ++i) {
+      const int pb = pool_avg(pool) ? 0 : i, op = pool_op(pool, i);
+      double g[4] = {0, 0, 0, 0};
       if (t < Ts) {
-        gy[n * YS + 2 * t + z] += pre.valid ? pre.gs[kind] : g_lat_s[((size_t)z * B + b) * 2 * Ts + kind * Ts + t];
+        g[0] = pre.valid ? (pb == 0 ? pre.gs[0] : (pb == 1 ? pre.gs[1] : (pb == 2 ? pre.gs[2] : pre.gs[3])))
+                         : g_lat_s[((size_t)z * B + b) * P * Ts + pb * Ts + t];
       } else {
         const int tv = t - Ts;
+#pragma unroll
         for (int m = 0; m < 4; ++m) {
-          double g;
-          if constexpr (FROM_LDS) g = g_lat_l[(kind * Tv + tv) * 8 + 4 * z + m];
-          else g = g_lat_v[(((size_t)z * B + b) * 2 * Tv + kind * Tv + tv) * 4 + m];
-          gy[n * YS + 2 * Ts + 8 * tv + 4 * z + m] += g;
+          if constexpr (FROM_LDS) g[m] = g_lat_l[(pb * Tv + tv) * 8 + 4 * z + m];
+          else g[m] = g_lat_v[(((size_t)z * B + b) * P * Tv + pb * Tv + tv) * 4 + m];
         }
+      }
+      if (pool_avg(pool))
+#pragma unroll
+        for (int m = 0; m < 4; ++m) g[m] /= (double)PN;
+      if (op == LGN_POOL_MEAN) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) g[m] /= (double)N;
+        for (int n = 0; n < N; ++n)
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+            if (m < nc) gy[n * YS + y0 + m] += g[m];
+      } else {
+        const int n = nmm[op == LGN_POOL_MAX];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          if (m < nc) gy[n * YS + y0 + m] += g[m];
       }
     }
   }
@@ -423,7 +479,7 @@ __device__ __forceinline__ void enc_latent_bwd_body(int B, int N, int C, int Ts,
     }
   }
 }
-__global__ __launch_bounds__(BLOCK) void enc_latent_bwd_kernel(int B, int N, int C, int Ts, int Tv,
+__global__ __launch_bounds__(BLOCK) void enc_latent_bwd_kernel(int B, int N, int C, int Ts, int Tv, int pool,
                                                               const double* __restrict__ s, const double* __restrict__ v,
                                                               const double* __restrict__ wl0, const double* __restrict__ wl1,
                                                               const double* __restrict__ g_lat_s, const double* __restrict__ g_lat_v,
@@ -433,10 +489,10 @@ __global__ __launch_bounds__(BLOCK) void enc_latent_bwd_kernel(int B, int N, int
   LatentStage st;
   LatentBwdPrefetch pre;
   st.issue(B, N, C, Ts, Tv, s, v, wl0, wl1);
-  pre.issue(B, Ts, Tv, idx, g_lat_s);
+  pre.issue(B, Ts, Tv, pool, idx, g_lat_s);
   st.commit(lds, true);                                  // same regions as the forward; gy takes y's place and starts at zero
   __syncthreads();
-  enc_latent_bwd_body<false>(B, N, C, Ts, Tv, g_lat_s, g_lat_v, nullptr, idx, g_s, g_v, part, lds, pre);
+  enc_latent_bwd_body<false>(B, N, C, Ts, Tv, pool, g_lat_s, g_lat_v, nullptr, idx, g_s, g_v, part, lds, pre);
 }
 
 // ============================================================================================
@@ -665,12 +721,12 @@ __global__ __launch_bounds__(BLOCK) void dec_input_bwd_kernel(int B, int N, int 
 __global__ __launch_bounds__(BLOCK) void junction_fwd_kernel(int B, int N, int CL, int Ts, int Tv, const double* s, const double* v,
                                                             const double* wl0, const double* wl1, double* lat_s, double* lat_v,
                                                             int* idx, int C0, const double* wg1, const double* w0, const double* w1,
-                                                            double* pdec, double* s0, double* v0, int overlap) {
+                                                            double* pdec, double* s0, double* v0, int overlap, int pool) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   double* lat_lds = reinterpret_cast<double*>(smem_raw);
   // overlap: behind the encoder stage's block; else over its sv / weight regions, which are dead once y is complete
   double* dec_lds = lat_lds + (overlap ? lat_fwd_doubles(N, CL, Ts, Tv) : (size_t)N * (2 * Ts + 8 * Tv));
-  const int Tin = 2 * Tv;
+  const int Tin = pool_blocks(pool) * Tv;
   STAMP(0);
   LatentStage ls;
   DecInFwdStage ds;
@@ -679,7 +735,7 @@ __global__ __launch_bounds__(BLOCK) void junction_fwd_kernel(int B, int N, int C
   ls.commit(lat_lds, false);
   if (overlap) ds.commit(dec_lds);
   __syncthreads();
-  enc_latent_fwd_body<true>(B, N, CL, Ts, Tv, lat_s, lat_v, idx, lat_lds, dec_lds + 2 * N * Tin);
+  enc_latent_fwd_body<true>(B, N, CL, Ts, Tv, pool, lat_s, lat_v, idx, lat_lds, dec_lds + 2 * N * Tin);
   if (!overlap) {
     ds.issue(B, N, C0, Tin, nullptr, wg1, w0, w1, false);
     ds.commit(dec_lds);
@@ -693,7 +749,8 @@ __global__ __launch_bounds__(BLOCK) void junction_bwd_kernel(int B, int N, int C
                                                             const double* g_s0, const double* g_v0, double* g_lat_v, double* part_dec,
                                                             int CL, int Ts, int Tv, const double* s, const double* v,
                                                             const double* wl0, const double* wl1, const double* g_lat_s,
-                                                            const int* idx, double* g_s, double* g_v, double* part_enc, int overlap) {
+                                                            const int* idx, double* g_s, double* g_v, double* part_enc, int overlap,
+                                                            int pool) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   double* dec_lds = reinterpret_cast<double*>(smem_raw);
   const size_t nd = dec_in_bwd_doubles(N, C0, Tin), nl = lat_bwd_doubles(N, CL, Ts, Tv);
@@ -704,7 +761,7 @@ __global__ __launch_bounds__(BLOCK) void junction_bwd_kernel(int B, int N, int C
   LatentStage ls;
   LatentBwdPrefetch pre;
   ds.issue(B, N, C0, Tin, lat_v, wg1, w1, pdec, g_p, g_s0, g_v0);
-  pre.issue(B, Ts, Tv, idx, g_lat_s);
+  pre.issue(B, Ts, Tv, pool, idx, g_lat_s);
   if (overlap) ls.issue(B, N, CL, Ts, Tv, s, v, wl0, wl1);
   ds.commit(dec_lds);
   if (overlap) ls.commit(lat_lds, true);
@@ -716,7 +773,7 @@ __global__ __launch_bounds__(BLOCK) void junction_bwd_kernel(int B, int N, int C
     ls.commit(lat_lds, true);
     __syncthreads();
   }
-  enc_latent_bwd_body<true>(B, N, CL, Ts, Tv, g_lat_s, nullptr, g_lat_l, idx, g_s, g_v, part_enc, lat_lds, pre);
+  enc_latent_bwd_body<true>(B, N, CL, Ts, Tv, pool, g_lat_s, nullptr, g_lat_l, idx, g_s, g_v, part_enc, lat_lds, pre);
   STAMP(19);
 }
 
@@ -889,20 +946,22 @@ int enc_input_bwd(int B, int N, int C, int K, const double* p4, const double* xs
   LGN_CHECK_LAUNCH();
   return 0;
 }
-int enc_latent_fwd(int B, int N, int C, int Ts, int Tv, const double* s, const double* v, const double* wl0, const double* wl1,
+int enc_latent_fwd(int B, int N, int C, int Ts, int Tv, int pool, const double* s, const double* v, const double* wl0, const double* wl1,
                    double* lat_s, double* lat_v, int* idx, hipStream_t st) {
+  LGN_CHECK_ARG(pool_valid(pool), "enc_latent_fwd: bad latent pooling code %d", pool);
   const size_t smem = sizeof(double) * lat_fwd_doubles(N, C, Ts, Tv);
   LGN_LDS_LAUNCH(enc_latent_fwd_kernel, "enc_latent_fwd", smem);
-  hipLaunchKernelGGL(enc_latent_fwd_kernel, dim3(B), dim3(BLOCK), smem, st, B, N, C, Ts, Tv, s, v, wl0, wl1, lat_s, lat_v, idx);
+  hipLaunchKernelGGL(enc_latent_fwd_kernel, dim3(B), dim3(BLOCK), smem, st, B, N, C, Ts, Tv, pool_canon(pool), s, v, wl0, wl1, lat_s, lat_v, idx);
   LGN_CHECK_LAUNCH();
   return 0;
 }
-int enc_latent_bwd(int B, int N, int C, int Ts, int Tv, const double* s, const double* v, const double* wl0, const double* wl1,
+int enc_latent_bwd(int B, int N, int C, int Ts, int Tv, int pool, const double* s, const double* v, const double* wl0, const double* wl1,
                    const double* g_lat_s, const double* g_lat_v, const int* idx, double* g_s, double* g_v, double* part,
                    hipStream_t st) {
+  LGN_CHECK_ARG(pool_valid(pool), "enc_latent_bwd: bad latent pooling code %d", pool);
   const size_t smem = sizeof(double) * lat_bwd_doubles(N, C, Ts, Tv);
   LGN_LDS_LAUNCH(enc_latent_bwd_kernel, "enc_latent_bwd", smem);
-  hipLaunchKernelGGL(enc_latent_bwd_kernel, dim3(B), dim3(BLOCK), smem, st, B, N, C, Ts, Tv, s, v, wl0, wl1, g_lat_s, g_lat_v, idx,
+  hipLaunchKernelGGL(enc_latent_bwd_kernel, dim3(B), dim3(BLOCK), smem, st, B, N, C, Ts, Tv, pool_canon(pool), s, v, wl0, wl1, g_lat_s, g_lat_v, idx,
                      g_s, g_v, part);
   LGN_CHECK_LAUNCH();
   return 0;
@@ -949,29 +1008,34 @@ int dec_output_bwd(int B, int N, int C, const double* v, const double* wo1, cons
 }
 // The two stages of a junction keep their LDS blocks side by side (all fetches up front) while that stays within 64 KB per
 // workgroup; larger jets run them in turn on shared LDS.
-int junction_fwd(int B, int N, int CL, int Ts, int Tv, const double* s, const double* v, const double* wl0, const double* wl1,
+int junction_fwd(int B, int N, int CL, int Ts, int Tv, int pool, const double* s, const double* v, const double* wl0, const double* wl1,
                  double* lat_s, double* lat_v, int* idx, int C0, const double* wg1, const double* w0, const double* w1, double* pdec,
                  double* s0, double* v0, hipStream_t st) {
-  const size_t nl = lat_fwd_doubles(N, CL, Ts, Tv), nd = dec_in_fwd_doubles(N, C0, 2 * Tv), ny = (size_t)N * (2 * Ts + 8 * Tv);
+  LGN_CHECK_ARG(pool_valid(pool), "junction_fwd: bad latent pooling code %d", pool);
+  pool = pool_canon(pool);
+  const size_t nl = lat_fwd_doubles(N, CL, Ts, Tv), nd = dec_in_fwd_doubles(N, C0, pool_blocks(pool) * Tv), ny = (size_t)N * (2 * Ts + 8 * Tv);
   const int overlap = sizeof(double) * (nl + nd) <= 64 * 1024;
   const size_t smem = sizeof(double) * (overlap ? nl + nd : ny + (nl - ny > nd ? nl - ny : nd));
   LGN_LDS_LAUNCH(junction_fwd_kernel, "junction_fwd", smem);
   hipLaunchKernelGGL(junction_fwd_kernel, dim3(B), dim3(BLOCK), smem, st, B, N, CL, Ts, Tv, s, v, wl0, wl1, lat_s, lat_v, idx, C0, wg1,
-                     w0, w1, pdec, s0, v0, overlap);
+                     w0, w1, pdec, s0, v0, overlap, pool);
   LGN_CHECK_LAUNCH();
   return 0;
 }
 int junction_bwd(int B, int N, int C0, int Tin, const double* lat_v, const double* wg1, const double* w1, const double* pdec,
                  const double* g_p, const double* g_s0, const double* g_v0, double* g_lat_v, double* part_dec, int CL, int Ts, int Tv,
-                 const double* s, const double* v, const double* wl0, const double* wl1, const double* g_lat_s, const int* idx,
+                 int pool, const double* s, const double* v, const double* wl0, const double* wl1, const double* g_lat_s, const int* idx,
                  double* g_s, double* g_v, double* part_enc, hipStream_t st) {
-  LGN_CHECK_ARG(Tin == 2 * Tv, "junction_bwd: the decoder takes the 2 Tv = %d pooled latent vectors, got Tin = %d", 2 * Tv, Tin);
+  LGN_CHECK_ARG(pool_valid(pool), "junction_bwd: bad latent pooling code %d", pool);
+  pool = pool_canon(pool);
+  LGN_CHECK_ARG(Tin == pool_blocks(pool) * Tv, "junction_bwd: the decoder takes the %d pooled latent vectors, got Tin = %d",
+                pool_blocks(pool) * Tv, Tin);
   const size_t nd = dec_in_bwd_doubles(N, C0, Tin), nl = lat_bwd_doubles(N, CL, Ts, Tv);
   const int overlap = sizeof(double) * (nd + nl + (size_t)Tin * 8) <= 64 * 1024;
   const size_t smem = sizeof(double) * ((overlap ? nd + nl : (nd > nl ? nd : nl)) + (size_t)Tin * 8);
   LGN_LDS_LAUNCH(junction_bwd_kernel, "junction_bwd", smem);
   hipLaunchKernelGGL(junction_bwd_kernel, dim3(B), dim3(BLOCK), smem, st, B, N, C0, Tin, lat_v, wg1, w1, pdec, g_p, g_s0, g_v0, g_lat_v,
-                     part_dec, CL, Ts, Tv, s, v, wl0, wl1, g_lat_s, idx, g_s, g_v, part_enc, overlap);
+                     part_dec, CL, Ts, Tv, s, v, wl0, wl1, g_lat_s, idx, g_s, g_v, part_enc, overlap, pool);
   LGN_CHECK_LAUNCH();
   return 0;
 }

@@ -176,10 +176,10 @@ Work carve(const lgn_net_desc& d, double* base) {
   };
   net(w.enc, d.enc_channels, false);
   net(w.dec, d.dec_channels, true);
-  const int Ts = d.tau_s, Tv = d.tau_v;
-  w.lat_s = b.take((size_t)2 * d.B * 2 * Ts);
-  w.lat_v = b.take((size_t)2 * d.B * 2 * Tv * 4);
-  w.g_lat_v = b.take((size_t)2 * d.B * 2 * Tv * 4);
+  const int Ts = d.tau_s, Tv = d.tau_v, PB = pool_blocks(d.latent_pool);
+  w.lat_s = b.take((size_t)2 * d.B * PB * Ts);
+  w.lat_v = b.take((size_t)2 * d.B * PB * Tv * 4);
+  w.g_lat_v = b.take((size_t)2 * d.B * PB * Tv * 4);
   w.pdec = b.take(8 * BN);
   for (int q = 0; q < 2; ++q) {
     w.gs[q] = b.take(2 * BN * cmax);
@@ -191,7 +191,7 @@ Work carve(const lgn_net_desc& d, double* base) {
     const size_t z0 = b.off;
     w.zeros_s = b.take(2 * BN * cmax);
     w.g_p = b.take(8 * BN);
-    w.g_lat_s = b.take((size_t)2 * d.B * 2 * d.tau_s);
+    w.g_lat_s = b.take((size_t)2 * d.B * PB * d.tau_s);
     w.zero_doubles = b.off - z0;
   }
   w.idx = reinterpret_cast<int*>(b.take(((size_t)d.B * 2 * (Ts + Tv) * 2 + 1) / 2 + 8));
@@ -208,7 +208,7 @@ Work carve(const lgn_net_desc& d, double* base) {
       w.tot[dec][l] = b.take(nrad + 16);
     }
   }
-  psum += 4 * (((size_t)d.B * (4 * cmax + 2 * (size_t)d.N * 2 * Tv + 2 * (Ts + Tv) * cmax) + 15) & ~size_t(15));
+  psum += 4 * (((size_t)d.B * (4 * cmax + 2 * (size_t)d.N * PB * Tv + 2 * (Ts + Tv) * cmax) + 15) & ~size_t(15));
   w.parts = b.take(psum);
   w.parts_size = psum;
   w.total = b.off;
@@ -375,6 +375,7 @@ int check_desc(const lgn_net_desc* d) {
   LGN_CHECK_ARG(d->mlp_nlin == 7, "step: mlp_depth must be 6 (7 Linear layers)");
   LGN_CHECK_ARG(d->tau_s >= 1 && d->tau_v >= 1 && d->tau_v_in >= 0, "step: latent multiplicities must be positive");
   LGN_CHECK_ARG(d->n_in_scalars >= 0 && d->n_in_scalars <= 8, "step: n_in_scalars=%d unsupported (0..8)", d->n_in_scalars);
+  LGN_CHECK_ARG(pool_valid(d->latent_pool), "step: latent_pool=%d is not an LGN_POOL(...) code", d->latent_pool);
   for (int l = 0; l <= d->n_levels; ++l)
     LGN_CHECK_ARG(d->enc_channels[l] >= 1 && d->enc_channels[l] <= 8 && d->dec_channels[l] >= 1 && d->dec_channels[l] <= 8,
                   "step: channel counts must be in 1..8");
@@ -520,7 +521,7 @@ GenScratch carve_gen_scratch(const lgn_net_desc& d, bool dec, double* base) {
     const size_t z0 = b.off;
     s.zero0 = b.take(2 * BN * cmax);
     s.g_p = b.take(dec ? 8 * BN : 0);
-    s.g_lat_s = b.take(dec ? 0 : (size_t)2 * d.B * 2 * d.tau_s);
+    s.g_lat_s = b.take(dec ? 0 : (size_t)2 * d.B * pool_blocks(d.latent_pool) * d.tau_s);
     s.zero_doubles = b.off - z0;
   }
   s.gs = b.take(2 * BN * cmax);
@@ -542,7 +543,7 @@ GenScratch carve_gen_scratch(const lgn_net_desc& d, bool dec, double* base) {
     psum += ((size_t)mlp_partial_rows((int)BN, d.mlp_hidden_mul * 2 * g.ch[l + 1]) * mlp_psize(g.ch[l + 1], d.mlp_hidden_mul * 2 * g.ch[l + 1], d.mlp_nlin) + 15) & ~size_t(15);
     s.tot[l] = b.take(nrad + 16);
   }
-  const int Tin = d.tau_v_in > 0 ? d.tau_v_in : 2 * d.tau_v;
+  const int Tin = d.tau_v_in > 0 ? d.tau_v_in : pool_blocks(d.latent_pool) * d.tau_v;
   if (dec) psum += (((size_t)d.B * 2 * g.ch[L] + 15) & ~size_t(15)) + (((size_t)d.B * (4 * g.ch[0] + 2 * (size_t)d.N * Tin) + 15) & ~size_t(15));
   else psum += (((size_t)d.B * 2 * (d.tau_s + d.tau_v) * g.ch[L] + 15) & ~size_t(15)) + (((size_t)d.B * (2 * in_K(d) + 2) * g.ch[0] + 15) & ~size_t(15));
   s.parts = b.take(psum);
@@ -698,7 +699,7 @@ int gen_encoder_fwd(const lgn_net_desc& d, const double* P, const int64_t* off, 
   LGN_TRY(net_pack(d, false, 0, a.s0, a.v0, a.X[0], st));
   LGN_TRY(gen_levels_fwd(d, false, P, off, a, p4, mask, st));
   LGN_TRY(net_unpack(d, false, L, a.X[L], a.sL, a.vL, st));
-  LGN_TRY(enc_latent_fwd(d.B, d.N, g.ch[L], d.tau_s, d.tau_v, a.sL, a.vL, P + off[S.out0(false)], P + off[S.out0(false) + 1], lat_s,
+  LGN_TRY(enc_latent_fwd(d.B, d.N, g.ch[L], d.tau_s, d.tau_v, d.latent_pool, a.sL, a.vL, P + off[S.out0(false)], P + off[S.out0(false) + 1], lat_s,
                          lat_v, a.idx, st));
   return 0;
 }
@@ -718,7 +719,7 @@ int gen_encoder_bwd(const lgn_net_desc& d, const double* P, double* G, const int
   {
     const int CL = g.ch[L], rowe = 2 * (Ts + Tv) * CL;
     DQ_NEW(parte, (size_t)B * rowe);
-    LGN_TRY(enc_latent_bwd(B, N, CL, Ts, Tv, a.sL, a.vL, P + off[S.out0(false)], P + off[S.out0(false) + 1],
+    LGN_TRY(enc_latent_bwd(B, N, CL, Ts, Tv, d.latent_pool, a.sL, a.vL, P + off[S.out0(false)], P + off[S.out0(false) + 1],
                            g_lat_s ? g_lat_s : sc.g_lat_s, g_lat_v, a.idx, sc.gs, sc.gv, parte, st));
     dq.add(parte, B, rowe, 0, 2 * Ts * CL, G + off[S.out0(false)]);
     dq.add(parte, B, rowe, 2 * Ts * CL, 2 * Tv * CL, G + off[S.out0(false) + 1]);
@@ -745,7 +746,7 @@ int gen_encoder_bwd(const lgn_net_desc& d, const double* P, double* G, const int
 // forward up to the unpacked last-level features (the caller applies dec_output_fwd or the fused output + loss kernel)
 int gen_decoder_fwd(const lgn_net_desc& d, const double* P, const int64_t* off, const double* lat_v, GenAct& a, hipStream_t st) {
   const GenGeom g = geom(d, true);
-  const int L = d.n_levels, Tin = d.tau_v_in > 0 ? d.tau_v_in : 2 * d.tau_v;
+  const int L = d.n_levels, Tin = d.tau_v_in > 0 ? d.tau_v_in : pool_blocks(d.latent_pool) * d.tau_v;
   LGN_TRY(dec_input_fwd(d.B, d.N, g.ch[0], Tin, lat_v, P + off[1], P + off[2], P + off[3], a.pdec, a.s0, a.v0, st));
   LGN_TRY(net_pack(d, true, 0, a.s0, a.v0, a.X[0], st));
   LGN_TRY(gen_levels_fwd(d, true, P, off, a, a.pdec, nullptr, st));
@@ -758,7 +759,7 @@ int gen_decoder_fwd(const lgn_net_desc& d, const double* P, const int64_t* off, 
 int gen_decoder_bwd(const lgn_net_desc& d, const double* P, double* G, const int64_t* off, const double* lat_v, const GenAct& a,
                     double* g_lat_v, GenScratch& sc, Deferred& dq, RadFinJob& fin, std::vector<UnpackJob>& post, hipStream_t st) {
   const GenGeom g = geom(d, true);
-  const int L = d.n_levels, B = d.B, N = d.N, Tin = d.tau_v_in > 0 ? d.tau_v_in : 2 * d.tau_v;
+  const int L = d.n_levels, B = d.B, N = d.N, Tin = d.tau_v_in > 0 ? d.tau_v_in : pool_blocks(d.latent_pool) * d.tau_v;
   int cur = 0;
   LGN_TRY(net_pack(d, true, L, sc.zero0, sc.gv, sc.gX[cur], st));
   LGN_TRY(gen_levels_bwd(d, true, P, G, off, a, a.pdec, nullptr, sc, dq, fin, post, cur, /*has_s_grad=*/false, st));
@@ -787,8 +788,8 @@ GenStep carve_gen_step(const lgn_net_desc& d, double* base) {
   g.da = carve_gen_act(d, true, at(off)); off += (g.da.total + 15) & ~size_t(15);
   g.es = carve_gen_scratch(d, false, at(off)); off += (g.es.total + 15) & ~size_t(15);
   g.ds = carve_gen_scratch(d, true, at(off)); off += (g.ds.total + 15) & ~size_t(15);
-  const int Tin = d.tau_v_in > 0 ? d.tau_v_in : 2 * d.tau_v;
-  g.lat_s = at(off); off += ((size_t)2 * d.B * 2 * d.tau_s + 15) & ~size_t(15);
+  const int Tin = d.tau_v_in > 0 ? d.tau_v_in : pool_blocks(d.latent_pool) * d.tau_v;
+  g.lat_s = at(off); off += ((size_t)2 * d.B * pool_blocks(d.latent_pool) * d.tau_s + 15) & ~size_t(15);
   g.lat_v = at(off); off += ((size_t)2 * d.B * Tin * 4 + 15) & ~size_t(15);
   g.g_lat_v = at(off); off += ((size_t)2 * d.B * Tin * 4 + 15) & ~size_t(15);
   g.total = off;
@@ -801,7 +802,8 @@ int gen_step_fwd_bwd(const lgn_net_desc& d, const double* params, double* grads,
   LGN_CHECK_ARG(is_generic(d, false) && is_generic(d, true), "step: encoder and decoder must both be table-driven (or both fused)");
   if (int rc = check_generic(d, false)) return rc;
   if (int rc = check_generic(d, true)) return rc;
-  LGN_CHECK_ARG(d.tau_v_in == 0 || d.tau_v_in == 2 * d.tau_v, "step: the decoder must consume the encoder's 2*tau_v latent vectors");
+  LGN_CHECK_ARG(d.tau_v_in == 0 || d.tau_v_in == pool_blocks(d.latent_pool) * d.tau_v,
+                "step: the decoder must consume the encoder's %d pooled latent vectors", pool_blocks(d.latent_pool) * d.tau_v);
   GenStep g = carve_gen_step(d, workspace);
   LGN_CHECK_ARG((long long)g.total <= workspace_doubles, "step: workspace holds %lld doubles, this configuration needs %zu",
                 workspace_doubles, g.total);
@@ -897,7 +899,7 @@ NetScratch carve_scratch(const lgn_net_desc& d, bool dec, double* base) {
     const size_t z0 = b.off;
     w.zeros_s = b.take(2 * BN * cmax);
     w.g_p = b.take(dec ? 8 * BN : 0);
-    w.g_lat_s = b.take(dec ? 0 : (size_t)2 * d.B * 2 * Ts);
+    w.g_lat_s = b.take(dec ? 0 : (size_t)2 * d.B * pool_blocks(d.latent_pool) * Ts);
     w.zero_doubles = b.off - z0;
   }
   for (int q = 0; q < 2; ++q) {
@@ -916,7 +918,7 @@ NetScratch carve_scratch(const lgn_net_desc& d, bool dec, double* base) {
     w.tot[dec ? 1 : 0][l] = b.take(nrad + 16);
   }
   // input / output ends: decoder  B x (2 C_L) + B x (4 C_0 + 2 N Tin);  encoder  B x 2 (Ts + Tv) C_L + B x 4 C_0
-  const int Tin = d.tau_v_in > 0 ? d.tau_v_in : 2 * Tv;
+  const int Tin = d.tau_v_in > 0 ? d.tau_v_in : pool_blocks(d.latent_pool) * Tv;
   if (dec) psum += (((size_t)d.B * 2 * ch[L] + 15) & ~size_t(15)) + (((size_t)d.B * (4 * ch[0] + 2 * (size_t)d.N * Tin) + 15) & ~size_t(15));
   else {
     int rm0, rr0;                                          // input-stage partial rows: one per workgroup of the first level's backward
@@ -970,7 +972,7 @@ int lgn_encoder_fwd_f64(const lgn_net_desc* d, const double* params, const int64
     const InputStage in0{params + off[0], params + off[1]};               // (rides on the first level's kernel)
     LGN_TRY(levels_fwd(*d, false, ce, params, off, a.n, p4, mask, st, &in0));
   }
-  LGN_TRY(enc_latent_fwd(d->B, d->N, ce[L], d->tau_s, d->tau_v, a.n.s[L], a.n.v[L], params + off[S.out0(false)],
+  LGN_TRY(enc_latent_fwd(d->B, d->N, ce[L], d->tau_s, d->tau_v, d->latent_pool, a.n.s[L], a.n.v[L], params + off[S.out0(false)],
                          params + off[S.out0(false) + 1], lat_s, lat_v, a.idx, st));
   return 0;
 }
@@ -1010,7 +1012,7 @@ int lgn_encoder_bwd_f64(const lgn_net_desc* d, const double* params, double* gra
   {
     const int CL = ce[L], rowe = 2 * (Ts + Tv) * CL;
     DQ_NEW(parte, (size_t)B * rowe);
-    LGN_TRY(enc_latent_bwd(B, N, CL, Ts, Tv, a.n.s[L], a.n.v[L], params + off[S.out0(false)], params + off[S.out0(false) + 1],
+    LGN_TRY(enc_latent_bwd(B, N, CL, Ts, Tv, d->latent_pool, a.n.s[L], a.n.v[L], params + off[S.out0(false)], params + off[S.out0(false) + 1],
                            g_lat_s ? g_lat_s : w.g_lat_s, g_lat_v, a.idx, w.gs[cur], w.gv[cur], parte, st));
     dq.add(parte, B, rowe, 0, 2 * Ts * CL, grads + off[S.out0(false)]);
     dq.add(parte, B, rowe, 2 * Ts * CL, 2 * Tv * CL, grads + off[S.out0(false) + 1]);
@@ -1050,7 +1052,7 @@ int lgn_decoder_fwd_f64(const lgn_net_desc* d, const double* params, const int64
   LGN_CHECK_ARG((long long)a.total <= act_doubles, "decoder_fwd: activation buffer holds %lld doubles, needs %zu", act_doubles, a.total);
   hipStream_t st = (hipStream_t)stream;
   const Slots S{d->n_levels, d->mlp_nlin};
-  const int L = d->n_levels, Tin = d->tau_v_in > 0 ? d->tau_v_in : 2 * d->tau_v;
+  const int L = d->n_levels, Tin = d->tau_v_in > 0 ? d->tau_v_in : pool_blocks(d->latent_pool) * d->tau_v;
   const int* cd = d->dec_channels;
   LGN_TRY(dec_input_fwd(d->B, d->N, cd[0], Tin, lat_v, params + off[1], params + off[2], params + off[3], a.pdec, a.n.s[0], a.n.v[0], st));
   LGN_TRY(levels_fwd(*d, true, cd, params, off, a.n, a.pdec, nullptr, st));
@@ -1095,7 +1097,7 @@ int lgn_decoder_bwd_f64(const lgn_net_desc* d, const double* params, double* gra
   hipStream_t st = (hipStream_t)stream;
   Work& w = sc.w;
   const Slots S{d->n_levels, d->mlp_nlin};
-  const int L = d->n_levels, B = d->B, N = d->N, Tin = d->tau_v_in > 0 ? d->tau_v_in : 2 * d->tau_v;
+  const int L = d->n_levels, B = d->B, N = d->N, Tin = d->tau_v_in > 0 ? d->tau_v_in : pool_blocks(d->latent_pool) * d->tau_v;
   const int* cd = d->dec_channels;
   LGN_TRY(zero_grads_and_block(grads, (size_t)n_params, w.zeros_s, w.zero_doubles, st));
   Deferred dq;
@@ -1189,7 +1191,7 @@ int lgn_step_fwd_bwd_f64(const lgn_net_desc* d, const double* params, double* gr
   // (the encoder's input stage and the two clears ride on the first level's kernel: levels_fwd / InputStage)
   const InputStage in0{params + enc_off[0], params + enc_off[1], grads, (size_t)n_params, w.zeros_s, w.zero_doubles};
   LGN_TRY(levels_fwd(*d, false, ce, params, enc_off, w.enc, p4, mask, st, &in0));
-  LGN_TRY(junction_fwd(B, N, ce[L], Ts, Tv, w.enc.s[L], w.enc.v[L], params + enc_off[S.out0(false)],
+  LGN_TRY(junction_fwd(B, N, ce[L], Ts, Tv, d->latent_pool, w.enc.s[L], w.enc.v[L], params + enc_off[S.out0(false)],
                        params + enc_off[S.out0(false) + 1], w.lat_s, w.lat_v, w.idx, cd[0], params + dec_off[1], params + dec_off[2],
                        params + dec_off[3], w.pdec, w.dec.s[0], w.dec.v[0], st));
   // ---------------- loss (and its backward), on the last decoder level's kernel when that is one workgroup per jet ----------
@@ -1208,7 +1210,7 @@ int lgn_step_fwd_bwd_f64(const lgn_net_desc* d, const double* params, double* gr
   LGN_TRY(levels_bwd(*d, true, cd, params, grads, dec_off, w.dec, w.pdec, nullptr, w, dq, fin, cur, /*has_s_grad=*/false, st,
                      /*fork_last=*/true));
   {
-    const int C0 = cd[0], Tin = 2 * Tv, row = 4 * C0 + 2 * N * Tin;
+    const int C0 = cd[0], Tin = pool_blocks(d->latent_pool) * Tv, row = 4 * C0 + 2 * N * Tin;
     const int CL = ce[L], rowe = 2 * (Ts + Tv) * CL;
     DQ_NEW(part, (size_t)B * row);
     DQ_NEW(parte, (size_t)B * rowe);
@@ -1217,7 +1219,7 @@ int lgn_step_fwd_bwd_f64(const lgn_net_desc* d, const double* params, double* gr
     const int rd = cur, wr = cur ^ 1;
     cur = wr;
     LGN_TRY(junction_bwd(B, N, C0, Tin, w.lat_v, params + dec_off[1], params + dec_off[3], w.pdec, w.g_p, w.gs[rd], w.gv[rd], w.g_lat_v, part,
-                         CL, Ts, Tv, w.enc.s[L], w.enc.v[L], params + enc_off[S.out0(false)], params + enc_off[S.out0(false) + 1],
+                         CL, Ts, Tv, d->latent_pool, w.enc.s[L], w.enc.v[L], params + enc_off[S.out0(false)], params + enc_off[S.out0(false) + 1],
                          w.g_lat_s, w.idx, w.gs[wr], w.gv[wr], parte, st));
     dq.add(part, B, row, 0, 2 * C0, grads + dec_off[2]);
     dq.add(part, B, row, 2 * C0, 2 * C0, grads + dec_off[3]);

@@ -15,7 +15,7 @@ import torch  # imported before the .so so that the process-wide libamdhip64 is 
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LGN_AMD_LIB") or os.path.join(_HERE, "_lib", "liblgn_amd.so")   # LGN_AMD_LIB: debug builds (tools/)
-ABI_VERSION = 12
+ABI_VERSION = 13
 FINALIZE_SCRATCH = 2048      # include/lgn_amd.h: LGN_FINALIZE_SCRATCH
 
 _lib: Optional[C.CDLL] = None
@@ -54,6 +54,33 @@ class LocalTables(C.Structure):
 _tp = C.POINTER(LocalTables)
 
 
+_POOL_OPS = {"min": 0, "max": 1, "mean": 2, "average": 2}
+
+
+def pool_code(map_to_latent: str):
+    """LGN_POOL(...) code of include/lgn_amd.h for a --map-to-latent string (aggregate(), lgn/models/lgn_encoder.py:419-496):
+    up to four of min / max / mean joined by '&' (concatenated) or '+' (averaged).  None: not a pooling the whole-network
+    kernels implement ('mix', 'sum' -- which returns an extra axis in the reference -- or mixed separators)."""
+    m = map_to_latent.lower()
+    if "&" in m and "+" in m:
+        return None
+    avg = "+" in m
+    ops = m.split("+") if avg else m.split("&")
+    if not 1 <= len(ops) <= 4 or any(o not in _POOL_OPS for o in ops):
+        return None
+    code = len(ops) | (int(avg) << 3)
+    for i, o in enumerate(ops):
+        code |= _POOL_OPS[o] << (4 + 2 * i)
+    return code
+
+
+def pool_blocks(code: int) -> int:
+    """Output blocks per latent channel: one per pooling under '&', one under '+' (0 = min&max)."""
+    if code == 0:
+        return 2
+    return 1 if (code >> 3) & 1 else code & 7
+
+
 class NetDesc(C.Structure):
     """lgn_net_desc of include/lgn_amd.h."""
     _fields_ = [("B", C.c_int), ("N", C.c_int), ("n_levels", C.c_int), ("enc_channels", C.c_int * 5),
@@ -62,7 +89,7 @@ class NetDesc(C.Structure):
                 ("enc_tables", _tp * 4), ("dec_tables", _tp * 4),
                 ("enc_Q", C.c_int * 5), ("enc_qs", C.c_int * 5), ("enc_qv", C.c_int * 5),
                 ("dec_Q", C.c_int * 5), ("dec_qs", C.c_int * 5), ("dec_qv", C.c_int * 5), ("flags", C.c_int),
-                ("activation", C.c_int), ("n_in_scalars", C.c_int)]
+                ("activation", C.c_int), ("n_in_scalars", C.c_int), ("latent_pool", C.c_int)]
 
     def __init__(self, *a, **kw):
         super().__init__(*a, **kw)

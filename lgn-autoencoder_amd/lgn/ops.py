@@ -295,7 +295,7 @@ def native_kind(net):
         from .plan import check_maxdim2_layout
         ok = (bool(net.mlp) and net.mlp_depth == 6 and net.num_basis_fn == 10 and 1 <= net.num_cg_levels <= 4
               and all(1 <= c <= 8 for c in net.num_channels) and net.mlp_width * 2 * max(net.num_channels[1:]) <= 96
-              and (not hasattr(net, "map_to_latent") or net.map_to_latent == "min&max"))
+              and (not hasattr(net, "map_to_latent") or N.pool_code(net.map_to_latent) is not None))
         kind = None
         if ok:
             fused = all(m == 2 for m in net.level_maxdim)
@@ -368,6 +368,7 @@ def describe_network(d, net, decoder: bool):
     else:
         d.tau_s, d.tau_v = net.tau_latent[(0, 0)], net.tau_latent[(1, 1)]
         d.n_in_scalars = net.tau_input_scalars      # > 1: jet_features / data['scalars'] (per-network calls only)
+        d.latent_pool = N.pool_code(net.map_to_latent) or 0
     if native_kind(net) == "generic":
         tabs = d.dec_tables if decoder else d.enc_tables
         Q, qs, qv = (d.dec_Q, d.dec_qs, d.dec_qv) if decoder else (d.enc_Q, d.enc_qs, d.enc_qv)
@@ -456,11 +457,11 @@ class EncoderFn(torch.autograd.Function):
             raise ValueError(f"the encoder takes {K} input scalars per particle (the mass + {max(K, 1) - 1} given ones); got "
                              f"{None if scalars is None else tuple(scalars.shape)}")
         scalars = None if scalars is None else N.f64(scalars)
-        Ts, Tv = h.desc.tau_s, h.desc.tau_v
-        ns, nv = _r16(4 * B * Ts), _r16(16 * B * Tv)
+        Ts, Tv, P = h.desc.tau_s, h.desc.tau_v, N.pool_blocks(h.desc.latent_pool)
+        ns, nv = _r16(2 * P * B * Ts), _r16(8 * P * B * Tv)
         buf = _alloc(ns + nv + h.n_act, flat)
-        lat_s = buf[:4 * B * Ts].view(2, B, 1, 2 * Ts, 1)
-        lat_v = buf[ns:ns + 16 * B * Tv].view(2, B, 1, 2 * Tv, 4)
+        lat_s = buf[:2 * P * B * Ts].view(2, B, 1, P * Ts, 1)
+        lat_v = buf[ns:ns + 8 * P * B * Tv].view(2, B, 1, P * Tv, 4)
         base = buf.data_ptr()
         rc = N.lib().lgn_encoder_fwd_f64(h.ref, flat.data_ptr(), h.off, N.ptr(p4), N.ptr(mask), N.ptr(scalars), base + 8 * (ns + nv),
                                          h.n_act, base, base + 8 * ns, N.stream_ptr())
@@ -480,7 +481,7 @@ class EncoderFn(torch.autograd.Function):
         if g_v is None:
             if g_s is None:
                 return None, None, None, grads.zero_(), None
-            g_v = torch.zeros(2, h.desc.B, 1, 2 * h.desc.tau_v, 4, device=flat.device, dtype=flat.dtype)
+            g_v = torch.zeros(2, h.desc.B, 1, N.pool_blocks(h.desc.latent_pool) * h.desc.tau_v, 4, device=flat.device, dtype=flat.dtype)
         base = out.data_ptr()
         rc = N.lib().lgn_encoder_bwd_f64(h.ref, flat.data_ptr(), base, h.n_params, h.off, N.ptr(p4), N.ptr(mask), N.ptr(ctx.scalars),
                                          buf.data_ptr() + 8 * ctx.act_off, h.n_act, N.ptr(None if g_s is None else N.f64(g_s)),

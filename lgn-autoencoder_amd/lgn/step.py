@@ -228,7 +228,7 @@ class NativeTrainStep:
             # layout -> refuse instead of computing garbage.
             raise NotImplementedError(
                 "the native step implements maxdim=2 / maxdim=3 networks (the same kind for encoder and decoder) with "
-                "map_to_latent='min&max', CGMLP levels (mlp_depth=6), num_basis_fn=10 and <= 8 channels; got encoder "
+                "map_to_latent = min / max / mean joined by '&' or '+', CGMLP levels (mlp_depth=6), num_basis_fn=10 and <= 8 channels; got encoder "
                 f"maxdim={encoder.level_maxdim} map_to_latent={encoder.map_to_latent!r} mlp={encoder.mlp} mlp_depth="
                 f"{encoder.mlp_depth}, decoder maxdim={decoder.level_maxdim} mlp={decoder.mlp}")
         if getattr(encoder, "tau_input_scalars", 1) != 1:
@@ -266,8 +266,9 @@ class NativeTrainStep:
                                       f"got {encoder.activation} / {decoder.activation}")
         d.activation = N.activation_id(encoder.activation)
         fused = native_kind(encoder) == "fused"
-        if decoder.tau_latent_vectors != 2 * d.tau_v or decoder.num_output_particles != d.N:
-            raise ValueError("decoder latent size / particle count does not match the encoder (min&max doubles tau)")
+        if decoder.tau_latent_vectors != N.pool_blocks(d.latent_pool) * d.tau_v or decoder.num_output_particles != d.N:
+            raise ValueError(f"decoder latent size / particle count does not match the encoder (map_to_latent={encoder.map_to_latent!r} "
+                             f"gives {N.pool_blocks(d.latent_pool)} x {d.tau_v} latent vectors, the decoder takes {decoder.tau_latent_vectors})")
         self.desc = d
         lib = N.lib()
         base = self.flat.flat.data_ptr()

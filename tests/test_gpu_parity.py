@@ -542,9 +542,9 @@ def test_end_to_end_vs_reference_golden(dev, O, name, fused):
     for i, rep in enumerate(nodes_all[n_enc:]):
         U.assert_rep_close(dict(rep.items()), U.rep_from(z, f"dec_nodes.{i}"), FWD_TOL, f"dec_nodes[{i}]")
 
-    if fused and name in ("g1_e2e_maxdim2.npz", "g3_e2e_n150.npz", "g2_e2e_maxdim3.npz", "g9_e2e_elu.npz", "g10_e2e_jetfeat.npz"):
-        # these configurations ARE covered by the whole-network native calls (g10: jet features + extra input scalars since round 4;
-        # g6 / g7: other latent maps, per-operator path) -- the training forward below must take them
+    if fused and name != "g6_e2e_mix.npz":
+        # these configurations ARE covered by the whole-network native calls (g10: jet features + extra input scalars, g7: mean+max
+        # pooling since round 4; g6: the learned 'mix' latent map, per-operator path) -- the training forward below must take them
         assert enc._fused_ok() and dec._fused_ok(), "expected the one-call-per-network native path"
     rec = dec(enc(batch))
     U.assert_close(rec, z["recon"], FWD_TOL, "recon")
@@ -569,7 +569,9 @@ def test_end_to_end_vs_reference_golden(dev, O, name, fused):
 
 
 # gradient tensors checked against the step's gradient scale instead of their own (see test_end_to_end_vs_reference_golden)
-_SCALED_GRADS = {"g9_e2e_elu.npz": ("enc.input_func_node.weights.(0, 0)", "enc.input_func_node.weights.(1, 1)")}
+# (g7 / mean+max: the encoder's input scalar weight gets 3e-13 against 3.7e-6 -- the whole-network calls sum it in another order)
+_SCALED_GRADS = {"g9_e2e_elu.npz": ("enc.input_func_node.weights.(0, 0)", "enc.input_func_node.weights.(1, 1)"),
+                 "g7_e2e_meanmax.npz": ("enc.input_func_node.weights.(0, 0)",)}
 
 
 @pytest.mark.parametrize("name,B,N,maxdim,che,chd", [("cfg2", 512, 30, 2, (3, 3, 4, 4), (4, 4, 3, 3)),

@@ -39,12 +39,12 @@ def _golden_setup(name="g1_e2e_maxdim2.npz"):
     z = U.load(name)
     m = U.meta(z)
     enc, dec = G._models(m["N"], m["ch_enc"], m["ch_dec"], dev, seed=m["seed"], maxdim=m.get("maxdim", 2),
-                         activation=m.get("activation", "leakyrelu"))
+                         activation=m.get("activation", "leakyrelu"), map_to_latent=m.get("map_to_latent", "min&max"))
     batch = {"p4": torch.from_numpy(z["p4"]).to(dev), "labels": torch.from_numpy(z["labels"]).to(dev)}
     return z, m, enc, dec, batch
 
 
-@pytest.mark.parametrize("name", ["g1_e2e_maxdim2.npz", "g3_e2e_n150.npz", "g2_e2e_maxdim3.npz", "g9_e2e_elu.npz"])
+@pytest.mark.parametrize("name", ["g1_e2e_maxdim2.npz", "g3_e2e_n150.npz", "g2_e2e_maxdim3.npz", "g9_e2e_elu.npz", "g7_e2e_meanmax.npz"])
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_native_step_matches_reference_golden(name, use_graph):
     """lgn_step_fwd_bwd_f64 + lgn_step_finalize_f64 (one native call each, optionally replayed from a HIP graph)
@@ -273,6 +273,47 @@ def test_module_api_training_loop_matches_native_step():
 
 
 WIDE = ((2, 4, 7, 8), (8, 6, 5, 3))
+@pytest.mark.parametrize("maxdim", [2, 3])
+@pytest.mark.parametrize("latent", ["mean", "max", "min", "mean&max", "max&min", "min+max", "mean&min&max", "mean+min+max",
+                                    "Mean&Max&Min&Mean"])
+def test_latent_poolings_native_calls_match_per_op_path(latent, maxdim):
+    """--map-to-latent variants (aggregate(), lgn/models/lgn_encoder.py:419-496; 'mean+max' is pinned by the reference fixture g7,
+    the pooling operators one by one by test_gpu_parity.py) through the three native routes -- whole step, one call per network
+    under autograd, junction kernels with the decoder taking P x tau_v latent vectors -- against the per-operator module path
+    on the same weights."""
+    import __graft_entry__ as G
+    from lgn.step import NativeTrainStep, TrainStep
+    from oracle import lgn_oracle as O
+    dev = torch.device("cuda:0")
+    N, B = 12, 5
+    chans = ((2, 3, 3, 4), (4, 3, 3, 2))
+    nets = [G._models(N, chans[0], chans[1], dev, seed=7, maxdim=maxdim, map_to_latent=latent) for _ in range(3)]
+    for enc, dec in nets[:2]:
+        assert enc._fused_ok() and dec._fused_ok()
+    nets[2][0].use_fused = nets[2][1].use_fused = False
+    p4, labels = O.synthetic_jets(B, N, seed=11, pad=True)
+    batch = {"p4": p4.to(dev), "labels": labels.to(dev)}
+    a = NativeTrainStep(*nets[0], batch_size=B, optimizer=False, use_graph=False)
+    b = TrainStep(*nets[1], optimizer=False)
+    c = TrainStep(*nets[2], optimizer=False)
+    la, ra = a.step(batch)
+    lb, rb = b.forward_backward(batch)
+    lc, rc = c.forward_backward(batch)
+    lat_b, lat_c = nets[1][0](batch), nets[2][0](batch)
+    for k in lat_c.keys():
+        assert lat_b[k].shape == lat_c[k].shape
+        U.assert_close(lat_b[k], lat_c[k], 1e-12, f"latent {k}")
+    for tag, (l, r, st) in {"whole step": (la, ra, a), "per-network calls": (lb, rb, b)}.items():
+        U.assert_close(l, lc, 1e-11, f"{tag}: loss")
+        U.assert_close(r, rc, 1e-11, f"{tag}: recon")
+        for (k, g), (_, ref) in zip(list(st.encoder.named_grads()) + list(st.decoder.named_grads()),
+                                    list(c.encoder.named_grads()) + list(c.decoder.named_grads())):
+            if ref.abs().max() == 0:
+                assert g.abs().max() == 0, f"{tag}: {k} must have exactly zero gradient"
+            else:
+                U.assert_close(g, ref, 1e-9, f"{tag}: grad {k}")
+
+
 CFG5 = ((4, 4, 6, 6), (6, 6, 4, 4))
 NARROW = ((3, 3, 4, 4), (4, 4, 3, 3))
 

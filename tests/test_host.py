@@ -234,9 +234,21 @@ def test_native_step_refuses_configurations_it_does_not_implement():
     enc.__dict__.pop("_native_kind", None)
     with pytest.raises(NotImplementedError, match="mlp_depth"):
         NativeTrainStep(enc, dec, batch_size=4)
+    # min / max / mean poolings and their '&' / '+' combinations are native (lgn_net_desc.latent_pool, round 4); the learned 'mix'
+    # map and 'sum' (an extra axis in the reference) are not
+    from lgn import _native as Nn
+    assert Nn.pool_code("min&max") == 2 | (1 << 6) and Nn.pool_blocks(0) == Nn.pool_blocks(Nn.pool_code("min&max")) == 2
+    assert Nn.pool_code("Mean+Max") == 2 | (1 << 3) | (2 << 4) | (1 << 6) and Nn.pool_blocks(Nn.pool_code("mean+max")) == 1
+    assert Nn.pool_blocks(Nn.pool_code("mean&min&max")) == 3
+    assert Nn.pool_code("mix") is None and Nn.pool_code("sum") is None and Nn.pool_code("mean&min+max") is None
+    assert Nn.pool_code("min&max&mean&min&max") is None
     enc, dec = G._models(12, (3, 3, 4, 4), (4, 4, 3, 3), torch.device("cpu"), seed=0, map_to_latent="mean+max")
-    with pytest.raises(NotImplementedError, match="min&max"):
-        NativeTrainStep(enc, dec, batch_size=4)
+    assert enc._fused_ok()
+    for latent in ("mix", "sum"):
+        enc, dec = G._models(12, (3, 3, 4, 4), (4, 4, 3, 3), torch.device("cpu"), seed=0, map_to_latent=latent)
+        assert not enc._fused_ok()
+        with pytest.raises(NotImplementedError, match="map_to_latent"):
+            NativeTrainStep(enc, dec, batch_size=4)
     # jet features / extra input scalars: the per-network native calls take them (lgn_net_desc.n_in_scalars, round 4), the whole-step
     # call does not (its two networks share one particle count; the encoder has one node more here)
     enc, dec = G._models(12, (3, 3, 4, 4), (4, 4, 3, 3), torch.device("cpu"), seed=0, jet_features=True)
