@@ -258,11 +258,13 @@ typedef struct lgn_net_desc {
 /* latent pooling code: n = 1..4 poolings o0..o3 (LGN_POOL_MIN / MAX / MEAN), avg = 0: concatenated ('a&b'), 1: averaged ('a+b').
  * min / max pick ONE particle per (plane, channel) -- by the value itself (min) / its square (max) for scalars, by the Minkowski
  * square of the Cartesian vector for vectors (get_min_features / get_max_features, lgn_encoder.py:538-583); mean = torch.mean over
- * the particle axis, padded particles included.  ('sum' returns an extra axis in the reference and 'mix' is a different operator:
- * both stay on the per-operator path.) */
+ * the particle axis, padded particles included.  ('sum' returns an extra axis in the reference: per-operator path only.) */
 #define LGN_POOL_MIN 0
 #define LGN_POOL_MAX 1
 #define LGN_POOL_MEAN 2
+#define LGN_POOL_MIX 3        /* only as LGN_POOL(1, 0, LGN_POOL_MIX, 0, 0, 0): map_to_latent = 'mix' -- no pooling, the latent MixReps
+                                 weights (encoder output slots) are [2][tau][N C] and act on all (particle, channel) pairs of a jet
+                                 (lgn_encoder.py:226-232,313-319); one output block */
 #define LGN_POOL(n, avg, o0, o1, o2, o3) ((n) | ((avg) << 3) | ((o0) << 4) | ((o1) << 6) | ((o2) << 8) | ((o3) << 10))
 #define LGN_NET_NO_STATIC 1   /* table-driven levels: run-time-table kernels + node-major features (cross-check of the
                                  compile-time-table kernels; lgn/_native.py sets it from LGN_AMD_NO_STATIC at creation) */

@@ -10,12 +10,17 @@ __host__ __device__ inline int pool_n(int code) { return pool_canon(code) & 7; }
 __host__ __device__ inline int pool_avg(int code) { return (pool_canon(code) >> 3) & 1; }
 __host__ __device__ inline int pool_op(int code, int i) { return (pool_canon(code) >> (4 + 2 * i)) & 3; }
 __host__ __device__ inline int pool_blocks(int code) { return pool_avg(code) ? 1 : pool_n(code); }   // P: output blocks per channel
+// 'mix': no pooling at all -- the latent MixReps acts on the N C (particle, channel) pairs of the jet (lgn_encoder.py:226-232,313-319)
+__host__ __device__ inline bool pool_is_mix(int code) { return code == LGN_POOL(1, 0, LGN_POOL_MIX, 0, 0, 0); }
 inline bool pool_valid(int code) {
+  if (pool_is_mix(code)) return true;
   if (code < 0 || code >= (1 << 12) || pool_n(code) < 1 || pool_n(code) > 4) return false;
   for (int i = 0; i < 4; ++i)
     if (pool_op(code, i) > LGN_POOL_MEAN || (i >= pool_n(code) && pool_op(code, i) != 0)) return false;
   return true;
 }
+// input channels of the latent MixReps weights: C, or N C under 'mix'
+__host__ __device__ inline int pool_mix_in(int code, int N, int C) { return pool_is_mix(code) ? N * C : C; }
 // z1/z2 (optional): buffers zeroed by the same launch (the step folds its two memsets into this first kernel)
 // K input scalars per node: the mass, then xs [B][N][K-1] (K = 1: xs unused); w0 = MixReps weight [2][C][K]
 int enc_input_fwd(int B, int N, int C, int K, const double* p4, const double* xs, const double* w0, const double* w1, double* s, double* v,

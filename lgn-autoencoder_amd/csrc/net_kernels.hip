@@ -165,8 +165,8 @@ __device__ __forceinline__ cx<double> canon_cplx_bwd_m(const double* g, int m) {
 //   lat_s [2][B][2Ts]  (min block, max block), lat_v [2][B][2Tv][4], idx [B][2][Ts+Tv][2] (plane, channel, min/max)
 // LDS: y [N][2Ts + 8Tv] | sv [N][C][10] | w0l [2][Ts][C] | w1l [2][Tv][C]
 // ============================================================================================
-__host__ __device__ inline size_t lat_fwd_doubles(int N, int C, int Ts, int Tv) {
-  return (size_t)N * (2 * Ts + 8 * Tv) + (size_t)N * C * 10 + 2 * (size_t)(Ts + Tv) * C;
+__host__ __device__ inline size_t lat_fwd_doubles(int N, int C, int Ts, int Tv, int pool = 0) {
+  return (size_t)N * (2 * Ts + 8 * Tv) + (size_t)N * C * 10 + 2 * (size_t)(Ts + Tv) * pool_mix_in(pool, N, C);
 }
 // node features of the jet -> sv [N][C][10] (s re, im, v re[4], im[4]) and the two mixing weights; zero_y: y / gy starts at zero
 struct LatentStage {
@@ -174,28 +174,28 @@ struct LatentStage {
   StageRegs<4> vr, vi;
   StageRegs<1> w0, w1;
   const double *s0, *s1, *v0, *v1, *wl0, *wl1;
-  int N, C, Ts, Tv;
+  int N, C, Ts, Tv, K;                                  // K: input channels of the two weights (C; N C under 'mix')
   __device__ __forceinline__ void issue(int B, int N_, int C_, int Ts_, int Tv_, const double* __restrict__ s, const double* __restrict__ v,
-                                        const double* __restrict__ wl0_, const double* __restrict__ wl1_) {
-    N = N_; C = C_; Ts = Ts_; Tv = Tv_; wl0 = wl0_; wl1 = wl1_;
+                                        const double* __restrict__ wl0_, const double* __restrict__ wl1_, int pool = 0) {
+    N = N_; C = C_; Ts = Ts_; Tv = Tv_; wl0 = wl0_; wl1 = wl1_; K = pool_mix_in(pool, N_, C_);
     const size_t pl = (size_t)B * N * C, j0 = (size_t)blockIdx.x * N * C;
     s0 = s + j0; s1 = s + pl + j0; v0 = v + j0 * 4; v1 = v + (pl + j0) * 4;
     vr.issue(v0, N * C * 4); vi.issue(v1, N * C * 4);
     sr.issue(s0, N * C); si.issue(s1, N * C);
-    w0.issue(wl0, 2 * Ts * C); w1.issue(wl1, 2 * Tv * C);
+    w0.issue(wl0, 2 * Ts * K); w1.issue(wl1, 2 * Tv * K);
   }
   __device__ __forceinline__ void commit(double* lds, bool zero_y) const {
     double* sv = lds + N * (2 * Ts + 8 * Tv);
     double* w0l = sv + N * C * 10;
-    double* w1l = w0l + 2 * Ts * C;
+    double* w1l = w0l + 2 * Ts * K;
     if (zero_y)
       for (int e = threadIdx.x; e < N * (2 * Ts + 8 * Tv); e += BLOCK) lds[e] = 0.0;
     vr.commit(v0, N * C * 4, [&](int e, double x) { sv[(e >> 2) * 10 + 2 + (e & 3)] = x; });
     vi.commit(v1, N * C * 4, [&](int e, double x) { sv[(e >> 2) * 10 + 6 + (e & 3)] = x; });
     sr.commit(s0, N * C, [&](int e, double x) { sv[e * 10] = x; });
     si.commit(s1, N * C, [&](int e, double x) { sv[e * 10 + 1] = x; });
-    w0.commit(wl0, 2 * Ts * C, [&](int e, double x) { w0l[e] = x; });
-    w1.commit(wl1, 2 * Tv * C, [&](int e, double x) { w1l[e] = x; });
+    w0.commit(wl0, 2 * Ts * K, [&](int e, double x) { w0l[e] = x; });
+    w1.commit(wl1, 2 * Tv * K, [&](int e, double x) { w1l[e] = x; });
   }
 };
 // after enc_latent_fwd_stage + a barrier.  TO_LDS: lat_l (LDS [2Tv][8]: re[4] | im[4]) also receives the latent vectors.
@@ -314,6 +314,45 @@ __device__ __forceinline__ void enc_latent_fwd_body(int B, int N, int C, int Ts,
     }
   }
 }
+// map_to_latent = 'mix': latent channel t = sum over ALL (particle, channel) pairs k = n C + c of W[t][k] x[k] (the reference reshapes
+// the node features to (2, B, 1, N C, d) before the MixReps, lgn_encoder.py:313-319), then rep_to_p.  8 lanes per latent channel.
+// LDS as for the pooled maps, the weights being w0l [2][Ts][N C] | w1l [2][Tv][N C]; the y block is unused.
+template <bool TO_LDS>
+__device__ __forceinline__ void enc_latent_mix_fwd_body(int B, int N, int C, int Ts, int Tv, double* lat_s, double* lat_v, double* lds,
+                                                        double* lat_l) {
+  const int b = blockIdx.x, TT = Ts + Tv, K = N * C;
+  const double* sv = lds + N * (2 * Ts + 8 * Tv);
+  const double* w0l = sv + K * 10;
+  const double* w1l = w0l + 2 * Ts * K;
+  const int l8 = threadIdx.x & 7;
+  for (int t = threadIdx.x >> 3; t < TT; t += BLOCK / 8) {
+    if (t < Ts) {
+      cx<double> acc = {0, 0};
+      for (int k = l8; k < K; k += 8) cfma(acc, cx<double>{w0l[t * K + k], w0l[Ts * K + t * K + k]}, cx<double>{sv[k * 10], sv[k * 10 + 1]});
+#pragma unroll
+      for (int off = 4; off; off >>= 1) { acc.r += __shfl_xor(acc.r, off, 8); acc.i += __shfl_xor(acc.i, off, 8); }
+      if (l8 < 2) lat_s[((size_t)l8 * B + b) * Ts + t] = l8 ? acc.i : acc.r;
+    } else {
+      const int tv = t - Ts;
+      cx<double> acc[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}}, pc[4];
+      for (int k = l8; k < K; k += 8) {
+        const cx<double> w = {w1l[tv * K + k], w1l[Tv * K + tv * K + k]};
+#pragma unroll
+        for (int m = 0; m < 4; ++m) cfma(acc[m], w, cx<double>{sv[k * 10 + 2 + m], sv[k * 10 + 6 + m]});
+      }
+#pragma unroll
+      for (int off = 4; off; off >>= 1)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) { acc[m].r += __shfl_xor(acc[m].r, off, 8); acc[m].i += __shfl_xor(acc[m].i, off, 8); }
+      cart_from_canon(acc, pc);
+      const int z = l8 >> 2, m = l8 & 3;
+      const cx<double> pm = m == 0 ? pc[0] : (m == 1 ? pc[1] : (m == 2 ? pc[2] : pc[3]));
+      const double val = z ? pm.i : pm.r;
+      lat_v[(((size_t)z * B + b) * Tv + tv) * 4 + m] = val;
+      if constexpr (TO_LDS) lat_l[tv * 8 + 4 * z + m] = val;
+    }
+  }
+}
 __global__ __launch_bounds__(BLOCK) void enc_latent_fwd_kernel(int B, int N, int C, int Ts, int Tv, int pool,
                                                               const double* __restrict__ s, const double* __restrict__ v,
                                                               const double* __restrict__ wl0, const double* __restrict__ wl1,
@@ -321,10 +360,11 @@ __global__ __launch_bounds__(BLOCK) void enc_latent_fwd_kernel(int B, int N, int
   extern __shared__ __align__(16) unsigned char smem_raw[];
   double* lds = reinterpret_cast<double*>(smem_raw);
   LatentStage st;
-  st.issue(B, N, C, Ts, Tv, s, v, wl0, wl1);
+  st.issue(B, N, C, Ts, Tv, s, v, wl0, wl1, pool);
   st.commit(lds, false);
   __syncthreads();
-  enc_latent_fwd_body<false>(B, N, C, Ts, Tv, pool, lat_s, lat_v, idx, lds, nullptr);
+  if (pool_is_mix(pool)) enc_latent_mix_fwd_body<false>(B, N, C, Ts, Tv, lat_s, lat_v, lds, nullptr);
+  else enc_latent_fwd_body<false>(B, N, C, Ts, Tv, pool, lat_s, lat_v, idx, lds, nullptr);
 }
 
 // backward: scatter the latent gradient to the selected particles, undo rep_to_p and the MixReps.
@@ -332,8 +372,8 @@ __global__ __launch_bounds__(BLOCK) void enc_latent_fwd_kernel(int B, int N, int
 // in LDS once; the weight gradient runs over (channel pair, node part) items whose parts meet in LDS in a fixed order.
 // LDS: gy [N][2Ts + 8Tv] | sv [N][C][10] | w0l | w1l | red [LAT_PARTS][TT*C][2]
 constexpr int LAT_PARTS = 6;
-__host__ __device__ inline size_t lat_bwd_doubles(int N, int C, int Ts, int Tv) {
-  return lat_fwd_doubles(N, C, Ts, Tv) + (size_t)LAT_PARTS * (Ts + Tv) * C * 2;
+__host__ __device__ inline size_t lat_bwd_doubles(int N, int C, int Ts, int Tv, int pool = 0) {
+  return lat_fwd_doubles(N, C, Ts, Tv, pool) + (pool_is_mix(pool) ? 0 : (size_t)LAT_PARTS * (Ts + Tv) * C * 2);
 }
 // FROM_LDS: the latent-vector gradient of this jet comes from g_lat_l (LDS, [2Tv][8]: re[4] | im[4]) instead of g_lat_v
 // `pre`: the pooling indices (and latent-scalar gradients) of this thread's (plane, channel), fetched with the staging loads
@@ -343,7 +383,7 @@ struct LatentBwdPrefetch {
   bool valid;
   __device__ __forceinline__ void issue(int B, int Ts, int Tv, int pool, const int* __restrict__ idx, const double* __restrict__ g_lat_s) {
     const int TT = Ts + Tv, e = threadIdx.x, b = blockIdx.x, P = pool_blocks(pool);
-    valid = 2 * TT <= BLOCK;
+    valid = 2 * TT <= BLOCK && !pool_is_mix(pool);
     if (valid && e < 2 * TT) {
       const int z = e / TT, t = e - z * TT;
 #pragma unroll
@@ -479,6 +519,68 @@ __device__ __forceinline__ void enc_latent_bwd_body(int B, int N, int C, int Ts,
     }
   }
 }
+// backward of the 'mix' map.  part row per jet: dWl0 [2][Ts][N C] then dWl1 [2][Tv][N C] -- every entry is one product, no sum
+// inside the jet.  The gradient of the latent channels (vectors: undone rep_to_p) sits in the first 2 Ts + 8 Tv doubles of the y block.
+template <bool FROM_LDS>
+__device__ __forceinline__ void enc_latent_mix_bwd_body(int B, int N, int C, int Ts, int Tv, const double* __restrict__ g_lat_s,
+                                                        const double* __restrict__ g_lat_v, const double* g_lat_l, double* g_s, double* g_v,
+                                                        double* part, double* lds) {
+  const int b = blockIdx.x, TT = Ts + Tv, K = N * C;
+  double* gy = lds;                                     // [2 Ts + 8 Tv]: scalars (re, im), vectors canonical re[4] | im[4]
+  const double* sv = lds + N * (2 * Ts + 8 * Tv);
+  const double* w0l = sv + K * 10;
+  const double* w1l = w0l + 2 * Ts * K;
+  const size_t pl = (size_t)B * K;
+  for (int t = threadIdx.x; t < TT; t += BLOCK) {
+    if (t < Ts) {
+      gy[2 * t] = g_lat_s ? g_lat_s[((size_t)0 * B + b) * Ts + t] : 0.0;
+      gy[2 * t + 1] = g_lat_s ? g_lat_s[((size_t)1 * B + b) * Ts + t] : 0.0;
+    } else {
+      const int tv = t - Ts;
+      cx<double> g[4], gc[4];
+      for (int m = 0; m < 4; ++m) {
+        if constexpr (FROM_LDS) g[m] = {g_lat_l[tv * 8 + m], g_lat_l[tv * 8 + 4 + m]};
+        else g[m] = {g_lat_v[(((size_t)0 * B + b) * Tv + tv) * 4 + m], g_lat_v[(((size_t)1 * B + b) * Tv + tv) * 4 + m]};
+      }
+      cart_from_canon_bwd(g, gc);
+      double* o = gy + 2 * Ts + 8 * tv;
+      for (int m = 0; m < 4; ++m) { o[m] = gc[m].r; o[4 + m] = gc[m].i; }
+    }
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < K; k += BLOCK) {         // gradient w.r.t. the last level's node features
+    cx<double> as = {0, 0}, av[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+    for (int t = 0; t < Ts; ++t) cfmac(as, cx<double>{gy[2 * t], gy[2 * t + 1]}, cx<double>{w0l[t * K + k], w0l[Ts * K + t * K + k]});
+    for (int t = 0; t < Tv; ++t) {
+      const cx<double> w = {w1l[t * K + k], w1l[Tv * K + t * K + k]};
+      const double* o = gy + 2 * Ts + 8 * t;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) cfmac(av[m], cx<double>{o[m], o[4 + m]}, w);
+    }
+    const size_t base = (size_t)b * K + k;
+    g_s[base] = as.r;
+    g_s[pl + base] = as.i;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) { g_v[base * 4 + m] = av[m].r; g_v[pl * 4 + base * 4 + m] = av[m].i; }
+  }
+  double* row = part + (size_t)b * 2 * TT * K;
+  for (int e = threadIdx.x; e < TT * K; e += BLOCK) {
+    const int t = e / K, k = e - t * K;
+    cx<double> acc = {0, 0};
+    if (t < Ts) {
+      cfmac(acc, cx<double>{gy[2 * t], gy[2 * t + 1]}, cx<double>{sv[k * 10], sv[k * 10 + 1]});
+      row[t * K + k] = acc.r;
+      row[Ts * K + t * K + k] = acc.i;
+    } else {
+      const int tv = t - Ts;
+      const double* o = gy + 2 * Ts + 8 * tv;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) cfmac(acc, cx<double>{o[m], o[4 + m]}, cx<double>{sv[k * 10 + 2 + m], sv[k * 10 + 6 + m]});
+      row[2 * Ts * K + tv * K + k] = acc.r;
+      row[2 * Ts * K + Tv * K + tv * K + k] = acc.i;
+    }
+  }
+}
 __global__ __launch_bounds__(BLOCK) void enc_latent_bwd_kernel(int B, int N, int C, int Ts, int Tv, int pool,
                                                               const double* __restrict__ s, const double* __restrict__ v,
                                                               const double* __restrict__ wl0, const double* __restrict__ wl1,
@@ -488,11 +590,12 @@ __global__ __launch_bounds__(BLOCK) void enc_latent_bwd_kernel(int B, int N, int
   double* lds = reinterpret_cast<double*>(smem_raw);
   LatentStage st;
   LatentBwdPrefetch pre;
-  st.issue(B, N, C, Ts, Tv, s, v, wl0, wl1);
+  st.issue(B, N, C, Ts, Tv, s, v, wl0, wl1, pool);
   pre.issue(B, Ts, Tv, pool, idx, g_lat_s);
   st.commit(lds, true);                                  // same regions as the forward; gy takes y's place and starts at zero
   __syncthreads();
-  enc_latent_bwd_body<false>(B, N, C, Ts, Tv, pool, g_lat_s, g_lat_v, nullptr, idx, g_s, g_v, part, lds, pre);
+  if (pool_is_mix(pool)) enc_latent_mix_bwd_body<false>(B, N, C, Ts, Tv, g_lat_s, g_lat_v, nullptr, g_s, g_v, part, lds);
+  else enc_latent_bwd_body<false>(B, N, C, Ts, Tv, pool, g_lat_s, g_lat_v, nullptr, idx, g_s, g_v, part, lds, pre);
 }
 
 // ============================================================================================
@@ -725,17 +828,18 @@ __global__ __launch_bounds__(BLOCK) void junction_fwd_kernel(int B, int N, int C
   extern __shared__ __align__(16) unsigned char smem_raw[];
   double* lat_lds = reinterpret_cast<double*>(smem_raw);
   // overlap: behind the encoder stage's block; else over its sv / weight regions, which are dead once y is complete
-  double* dec_lds = lat_lds + (overlap ? lat_fwd_doubles(N, CL, Ts, Tv) : (size_t)N * (2 * Ts + 8 * Tv));
+  double* dec_lds = lat_lds + (overlap ? lat_fwd_doubles(N, CL, Ts, Tv, pool) : (size_t)N * (2 * Ts + 8 * Tv));
   const int Tin = pool_blocks(pool) * Tv;
   STAMP(0);
   LatentStage ls;
   DecInFwdStage ds;
-  ls.issue(B, N, CL, Ts, Tv, s, v, wl0, wl1);
+  ls.issue(B, N, CL, Ts, Tv, s, v, wl0, wl1, pool);
   if (overlap) ds.issue(B, N, C0, Tin, nullptr, wg1, w0, w1, false);
   ls.commit(lat_lds, false);
   if (overlap) ds.commit(dec_lds);
   __syncthreads();
-  enc_latent_fwd_body<true>(B, N, CL, Ts, Tv, pool, lat_s, lat_v, idx, lat_lds, dec_lds + 2 * N * Tin);
+  if (pool_is_mix(pool)) enc_latent_mix_fwd_body<true>(B, N, CL, Ts, Tv, lat_s, lat_v, lat_lds, dec_lds + 2 * N * Tin);
+  else enc_latent_fwd_body<true>(B, N, CL, Ts, Tv, pool, lat_s, lat_v, idx, lat_lds, dec_lds + 2 * N * Tin);
   if (!overlap) {
     ds.issue(B, N, C0, Tin, nullptr, wg1, w0, w1, false);
     ds.commit(dec_lds);
@@ -753,7 +857,7 @@ __global__ __launch_bounds__(BLOCK) void junction_bwd_kernel(int B, int N, int C
                                                             int pool) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   double* dec_lds = reinterpret_cast<double*>(smem_raw);
-  const size_t nd = dec_in_bwd_doubles(N, C0, Tin), nl = lat_bwd_doubles(N, CL, Ts, Tv);
+  const size_t nd = dec_in_bwd_doubles(N, C0, Tin), nl = lat_bwd_doubles(N, CL, Ts, Tv, pool);
   double* g_lat_l = dec_lds + (overlap ? nd : (nd > nl ? nd : nl));      // [Tin][8], outside both stages' blocks
   double* lat_lds = overlap ? g_lat_l + Tin * 8 : dec_lds;
   STAMP(10);
@@ -762,18 +866,19 @@ __global__ __launch_bounds__(BLOCK) void junction_bwd_kernel(int B, int N, int C
   LatentBwdPrefetch pre;
   ds.issue(B, N, C0, Tin, lat_v, wg1, w1, pdec, g_p, g_s0, g_v0);
   pre.issue(B, Ts, Tv, pool, idx, g_lat_s);
-  if (overlap) ls.issue(B, N, CL, Ts, Tv, s, v, wl0, wl1);
+  if (overlap) ls.issue(B, N, CL, Ts, Tv, s, v, wl0, wl1, pool);
   ds.commit(dec_lds);
   if (overlap) ls.commit(lat_lds, true);
   __syncthreads();
   dec_input_bwd_body<true>(B, N, C0, Tin, g_lat_v, part_dec, dec_lds, g_lat_l);
   __syncthreads();                                       // this jet's latent-vector gradient is in LDS; the decoder stage's block is free
   if (!overlap) {
-    ls.issue(B, N, CL, Ts, Tv, s, v, wl0, wl1);
+    ls.issue(B, N, CL, Ts, Tv, s, v, wl0, wl1, pool);
     ls.commit(lat_lds, true);
     __syncthreads();
   }
-  enc_latent_bwd_body<true>(B, N, CL, Ts, Tv, pool, g_lat_s, nullptr, g_lat_l, idx, g_s, g_v, part_enc, lat_lds, pre);
+  if (pool_is_mix(pool)) enc_latent_mix_bwd_body<true>(B, N, CL, Ts, Tv, g_lat_s, nullptr, g_lat_l, g_s, g_v, part_enc, lat_lds);
+  else enc_latent_bwd_body<true>(B, N, CL, Ts, Tv, pool, g_lat_s, nullptr, g_lat_l, idx, g_s, g_v, part_enc, lat_lds, pre);
   STAMP(19);
 }
 
@@ -949,7 +1054,7 @@ int enc_input_bwd(int B, int N, int C, int K, const double* p4, const double* xs
 int enc_latent_fwd(int B, int N, int C, int Ts, int Tv, int pool, const double* s, const double* v, const double* wl0, const double* wl1,
                    double* lat_s, double* lat_v, int* idx, hipStream_t st) {
   LGN_CHECK_ARG(pool_valid(pool), "enc_latent_fwd: bad latent pooling code %d", pool);
-  const size_t smem = sizeof(double) * lat_fwd_doubles(N, C, Ts, Tv);
+  const size_t smem = sizeof(double) * lat_fwd_doubles(N, C, Ts, Tv, pool_canon(pool));
   LGN_LDS_LAUNCH(enc_latent_fwd_kernel, "enc_latent_fwd", smem);
   hipLaunchKernelGGL(enc_latent_fwd_kernel, dim3(B), dim3(BLOCK), smem, st, B, N, C, Ts, Tv, pool_canon(pool), s, v, wl0, wl1, lat_s, lat_v, idx);
   LGN_CHECK_LAUNCH();
@@ -959,7 +1064,7 @@ int enc_latent_bwd(int B, int N, int C, int Ts, int Tv, int pool, const double* 
                    const double* g_lat_s, const double* g_lat_v, const int* idx, double* g_s, double* g_v, double* part,
                    hipStream_t st) {
   LGN_CHECK_ARG(pool_valid(pool), "enc_latent_bwd: bad latent pooling code %d", pool);
-  const size_t smem = sizeof(double) * lat_bwd_doubles(N, C, Ts, Tv);
+  const size_t smem = sizeof(double) * lat_bwd_doubles(N, C, Ts, Tv, pool_canon(pool));
   LGN_LDS_LAUNCH(enc_latent_bwd_kernel, "enc_latent_bwd", smem);
   hipLaunchKernelGGL(enc_latent_bwd_kernel, dim3(B), dim3(BLOCK), smem, st, B, N, C, Ts, Tv, pool_canon(pool), s, v, wl0, wl1, g_lat_s, g_lat_v, idx,
                      g_s, g_v, part);
@@ -1013,7 +1118,7 @@ int junction_fwd(int B, int N, int CL, int Ts, int Tv, int pool, const double* s
                  double* s0, double* v0, hipStream_t st) {
   LGN_CHECK_ARG(pool_valid(pool), "junction_fwd: bad latent pooling code %d", pool);
   pool = pool_canon(pool);
-  const size_t nl = lat_fwd_doubles(N, CL, Ts, Tv), nd = dec_in_fwd_doubles(N, C0, pool_blocks(pool) * Tv), ny = (size_t)N * (2 * Ts + 8 * Tv);
+  const size_t nl = lat_fwd_doubles(N, CL, Ts, Tv, pool), nd = dec_in_fwd_doubles(N, C0, pool_blocks(pool) * Tv), ny = (size_t)N * (2 * Ts + 8 * Tv);
   const int overlap = sizeof(double) * (nl + nd) <= 64 * 1024;
   const size_t smem = sizeof(double) * (overlap ? nl + nd : ny + (nl - ny > nd ? nl - ny : nd));
   LGN_LDS_LAUNCH(junction_fwd_kernel, "junction_fwd", smem);
@@ -1030,7 +1135,7 @@ int junction_bwd(int B, int N, int C0, int Tin, const double* lat_v, const doubl
   pool = pool_canon(pool);
   LGN_CHECK_ARG(Tin == pool_blocks(pool) * Tv, "junction_bwd: the decoder takes the %d pooled latent vectors, got Tin = %d",
                 pool_blocks(pool) * Tv, Tin);
-  const size_t nd = dec_in_bwd_doubles(N, C0, Tin), nl = lat_bwd_doubles(N, CL, Ts, Tv);
+  const size_t nd = dec_in_bwd_doubles(N, C0, Tin), nl = lat_bwd_doubles(N, CL, Ts, Tv, pool);
   const int overlap = sizeof(double) * (nd + nl + (size_t)Tin * 8) <= 64 * 1024;
   const size_t smem = sizeof(double) * ((overlap ? nd + nl : (nd > nl ? nd : nl)) + (size_t)Tin * 8);
   LGN_LDS_LAUNCH(junction_bwd_kernel, "junction_bwd", smem);

@@ -208,7 +208,7 @@ Work carve(const lgn_net_desc& d, double* base) {
       w.tot[dec][l] = b.take(nrad + 16);
     }
   }
-  psum += 4 * (((size_t)d.B * (4 * cmax + 2 * (size_t)d.N * PB * Tv + 2 * (Ts + Tv) * cmax) + 15) & ~size_t(15));
+  psum += 4 * (((size_t)d.B * (4 * cmax + 2 * (size_t)d.N * PB * Tv + 2 * (size_t)(Ts + Tv) * pool_mix_in(d.latent_pool, d.N, cmax)) + 15) & ~size_t(15));
   w.parts = b.take(psum);
   w.parts_size = psum;
   w.total = b.off;
@@ -545,7 +545,7 @@ GenScratch carve_gen_scratch(const lgn_net_desc& d, bool dec, double* base) {
   }
   const int Tin = d.tau_v_in > 0 ? d.tau_v_in : pool_blocks(d.latent_pool) * d.tau_v;
   if (dec) psum += (((size_t)d.B * 2 * g.ch[L] + 15) & ~size_t(15)) + (((size_t)d.B * (4 * g.ch[0] + 2 * (size_t)d.N * Tin) + 15) & ~size_t(15));
-  else psum += (((size_t)d.B * 2 * (d.tau_s + d.tau_v) * g.ch[L] + 15) & ~size_t(15)) + (((size_t)d.B * (2 * in_K(d) + 2) * g.ch[0] + 15) & ~size_t(15));
+  else psum += (((size_t)d.B * 2 * (d.tau_s + d.tau_v) * pool_mix_in(d.latent_pool, d.N, g.ch[L]) + 15) & ~size_t(15)) + (((size_t)d.B * (2 * in_K(d) + 2) * g.ch[0] + 15) & ~size_t(15));
   s.parts = b.take(psum);
   s.parts_size = psum;
   s.total = b.off;
@@ -717,12 +717,12 @@ int gen_encoder_bwd(const lgn_net_desc& d, const double* P, double* G, const int
   RadFinJob fin{};
   int cur = 0;
   {
-    const int CL = g.ch[L], rowe = 2 * (Ts + Tv) * CL;
+    const int CL = g.ch[L], KL = pool_mix_in(d.latent_pool, N, CL), rowe = 2 * (Ts + Tv) * KL;
     DQ_NEW(parte, (size_t)B * rowe);
     LGN_TRY(enc_latent_bwd(B, N, CL, Ts, Tv, d.latent_pool, a.sL, a.vL, P + off[S.out0(false)], P + off[S.out0(false) + 1],
                            g_lat_s ? g_lat_s : sc.g_lat_s, g_lat_v, a.idx, sc.gs, sc.gv, parte, st));
-    dq.add(parte, B, rowe, 0, 2 * Ts * CL, G + off[S.out0(false)]);
-    dq.add(parte, B, rowe, 2 * Ts * CL, 2 * Tv * CL, G + off[S.out0(false) + 1]);
+    dq.add(parte, B, rowe, 0, 2 * Ts * KL, G + off[S.out0(false)]);
+    dq.add(parte, B, rowe, 2 * Ts * KL, 2 * Tv * KL, G + off[S.out0(false) + 1]);
     LGN_TRY(net_pack(d, false, L, g_lat_s ? sc.gs : sc.zero0, sc.gv, sc.gX[cur], st));
   }
   std::vector<UnpackJob> post;
@@ -924,7 +924,7 @@ NetScratch carve_scratch(const lgn_net_desc& d, bool dec, double* base) {
     int rm0, rr0;                                          // input-stage partial rows: one per workgroup of the first level's backward
     level_bwd_partial_rows(d.B, d.N, 0, d.flags, &rm0, &rr0);
     if (rm0 < d.B) rm0 = d.B;
-    psum += (((size_t)d.B * 2 * (Ts + Tv) * ch[L] + 15) & ~size_t(15)) + (((size_t)rm0 * (2 * in_K(d) + 2) * ch[0] + 15) & ~size_t(15));
+    psum += (((size_t)d.B * 2 * (Ts + Tv) * pool_mix_in(d.latent_pool, d.N, ch[L]) + 15) & ~size_t(15)) + (((size_t)rm0 * (2 * in_K(d) + 2) * ch[0] + 15) & ~size_t(15));
   }
   w.parts = b.take(psum);
   w.parts_size = psum;
@@ -1010,12 +1010,12 @@ int lgn_encoder_bwd_f64(const lgn_net_desc* d, const double* params, double* gra
   RadFinJob fin{};
   int cur = 0;
   {
-    const int CL = ce[L], rowe = 2 * (Ts + Tv) * CL;
+    const int CL = ce[L], KL = pool_mix_in(d->latent_pool, N, CL), rowe = 2 * (Ts + Tv) * KL;
     DQ_NEW(parte, (size_t)B * rowe);
     LGN_TRY(enc_latent_bwd(B, N, CL, Ts, Tv, d->latent_pool, a.n.s[L], a.n.v[L], params + off[S.out0(false)], params + off[S.out0(false) + 1],
                            g_lat_s ? g_lat_s : w.g_lat_s, g_lat_v, a.idx, w.gs[cur], w.gv[cur], parte, st));
-    dq.add(parte, B, rowe, 0, 2 * Ts * CL, grads + off[S.out0(false)]);
-    dq.add(parte, B, rowe, 2 * Ts * CL, 2 * Tv * CL, grads + off[S.out0(false) + 1]);
+    dq.add(parte, B, rowe, 0, 2 * Ts * KL, grads + off[S.out0(false)]);
+    dq.add(parte, B, rowe, 2 * Ts * KL, 2 * Tv * KL, grads + off[S.out0(false) + 1]);
   }
   // without an upstream gradient on the latent scalars the last level's scalars (and its CGMLP) receive none
   double* const in0_grads[2] = {grads + off[0], grads + off[1]};
@@ -1211,7 +1211,7 @@ int lgn_step_fwd_bwd_f64(const lgn_net_desc* d, const double* params, double* gr
                      /*fork_last=*/true));
   {
     const int C0 = cd[0], Tin = pool_blocks(d->latent_pool) * Tv, row = 4 * C0 + 2 * N * Tin;
-    const int CL = ce[L], rowe = 2 * (Ts + Tv) * CL;
+    const int CL = ce[L], KL = pool_mix_in(d->latent_pool, N, CL), rowe = 2 * (Ts + Tv) * KL;
     DQ_NEW(part, (size_t)B * row);
     DQ_NEW(parte, (size_t)B * rowe);
     // reads the gradient w.r.t. the decoder's level-0 features, writes the one w.r.t. the encoder's last level into the
@@ -1224,8 +1224,8 @@ int lgn_step_fwd_bwd_f64(const lgn_net_desc* d, const double* params, double* gr
     dq.add(part, B, row, 0, 2 * C0, grads + dec_off[2]);
     dq.add(part, B, row, 2 * C0, 2 * C0, grads + dec_off[3]);
     dq.add(part, B, row, 4 * C0, 2 * N * Tin, grads + dec_off[1]);
-    dq.add(parte, B, rowe, 0, 2 * Ts * CL, grads + enc_off[S.out0(false)]);
-    dq.add(parte, B, rowe, 2 * Ts * CL, 2 * Tv * CL, grads + enc_off[S.out0(false) + 1]);
+    dq.add(parte, B, rowe, 0, 2 * Ts * KL, grads + enc_off[S.out0(false)]);
+    dq.add(parte, B, rowe, 2 * Ts * KL, 2 * Tv * KL, grads + enc_off[S.out0(false) + 1]);
   }
   double* const in0_grads[2] = {grads + enc_off[0], grads + enc_off[1]};
   bool in0_done = false;

@@ -59,9 +59,12 @@ _POOL_OPS = {"min": 0, "max": 1, "mean": 2, "average": 2}
 
 def pool_code(map_to_latent: str):
     """LGN_POOL(...) code of include/lgn_amd.h for a --map-to-latent string (aggregate(), lgn/models/lgn_encoder.py:419-496):
-    up to four of min / max / mean joined by '&' (concatenated) or '+' (averaged).  None: not a pooling the whole-network
-    kernels implement ('mix', 'sum' -- which returns an extra axis in the reference -- or mixed separators)."""
+    up to four of min / max / mean joined by '&' (concatenated) or '+' (averaged), or 'mix' (no pooling: the latent MixReps takes
+    all N C (particle, channel) pairs).  None: not a map the whole-network kernels implement ('sum' -- which returns an extra axis
+    in the reference -- or mixed separators)."""
     m = map_to_latent.lower()
+    if m == "mix":
+        return 1 | (3 << 4)
     if "&" in m and "+" in m:
         return None
     avg = "+" in m

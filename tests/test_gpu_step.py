@@ -44,7 +44,7 @@ def _golden_setup(name="g1_e2e_maxdim2.npz"):
     return z, m, enc, dec, batch
 
 
-@pytest.mark.parametrize("name", ["g1_e2e_maxdim2.npz", "g3_e2e_n150.npz", "g2_e2e_maxdim3.npz", "g9_e2e_elu.npz", "g7_e2e_meanmax.npz"])
+@pytest.mark.parametrize("name", ["g1_e2e_maxdim2.npz", "g3_e2e_n150.npz", "g2_e2e_maxdim3.npz", "g9_e2e_elu.npz", "g7_e2e_meanmax.npz", "g6_e2e_mix.npz"])
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_native_step_matches_reference_golden(name, use_graph):
     """lgn_step_fwd_bwd_f64 + lgn_step_finalize_f64 (one native call each, optionally replayed from a HIP graph)
@@ -275,7 +275,7 @@ def test_module_api_training_loop_matches_native_step():
 WIDE = ((2, 4, 7, 8), (8, 6, 5, 3))
 @pytest.mark.parametrize("maxdim", [2, 3])
 @pytest.mark.parametrize("latent", ["mean", "max", "min", "mean&max", "max&min", "min+max", "mean&min&max", "mean+min+max",
-                                    "Mean&Max&Min&Mean"])
+                                    "Mean&Max&Min&Mean", "mix"])
 def test_latent_poolings_native_calls_match_per_op_path(latent, maxdim):
     """--map-to-latent variants (aggregate(), lgn/models/lgn_encoder.py:419-496; 'mean+max' is pinned by the reference fixture g7,
     the pooling operators one by one by test_gpu_parity.py) through the three native routes -- whole step, one call per network

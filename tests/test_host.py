@@ -234,17 +234,20 @@ def test_native_step_refuses_configurations_it_does_not_implement():
     enc.__dict__.pop("_native_kind", None)
     with pytest.raises(NotImplementedError, match="mlp_depth"):
         NativeTrainStep(enc, dec, batch_size=4)
-    # min / max / mean poolings and their '&' / '+' combinations are native (lgn_net_desc.latent_pool, round 4); the learned 'mix'
-    # map and 'sum' (an extra axis in the reference) are not
+    # min / max / mean poolings, their '&' / '+' combinations and the learned 'mix' map are native (lgn_net_desc.latent_pool, round 4);
+    # 'sum' (an extra axis in the reference) is not
     from lgn import _native as Nn
     assert Nn.pool_code("min&max") == 2 | (1 << 6) and Nn.pool_blocks(0) == Nn.pool_blocks(Nn.pool_code("min&max")) == 2
     assert Nn.pool_code("Mean+Max") == 2 | (1 << 3) | (2 << 4) | (1 << 6) and Nn.pool_blocks(Nn.pool_code("mean+max")) == 1
     assert Nn.pool_blocks(Nn.pool_code("mean&min&max")) == 3
-    assert Nn.pool_code("mix") is None and Nn.pool_code("sum") is None and Nn.pool_code("mean&min+max") is None
+    assert Nn.pool_code("mix") == 1 | (3 << 4) and Nn.pool_blocks(Nn.pool_code("mix")) == 1
+    assert Nn.pool_code("sum") is None and Nn.pool_code("mean&min+max") is None and Nn.pool_code("mix&max") is None
     assert Nn.pool_code("min&max&mean&min&max") is None
     enc, dec = G._models(12, (3, 3, 4, 4), (4, 4, 3, 3), torch.device("cpu"), seed=0, map_to_latent="mean+max")
     assert enc._fused_ok()
-    for latent in ("mix", "sum"):
+    enc, dec = G._models(12, (3, 3, 4, 4), (4, 4, 3, 3), torch.device("cpu"), seed=0, map_to_latent="mix")
+    assert enc._fused_ok() and tuple(enc.mix_reps.weight((1, 1)).shape) == (2, 8, 12 * 4)
+    for latent in ("sum",):
         enc, dec = G._models(12, (3, 3, 4, 4), (4, 4, 3, 3), torch.device("cpu"), seed=0, map_to_latent=latent)
         assert not enc._fused_ok()
         with pytest.raises(NotImplementedError, match="map_to_latent"):
