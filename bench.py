@@ -180,10 +180,10 @@ def time_dominant_kernel(enc, batch, reps=20):
     us_bwd = _events_us(bwd, reps, mode)
     fwd_flops = B * level_fwd_flops(N, Cc, CO, False)
     single = N <= 40
-    return {"kernel": f"level_bwd3_kernel<{Cc}, false, false, 4>" if single else "level_bwd (level_bwd_mix + level_bwd_sweep_enc kernels)",
+    return {"kernel": f"level_bwd3_kernel<{Cc}, false, false, 4, false>" if single else "level_bwd (level_bwd_mix + level_bwd_sweep_enc kernels)",
             "level": lvl, "us": us_bwd, "flops": 2 * fwd_flops,          # backward = 2 x forward
             "timing": mode.get("timing"),
-            "forward": {"kernel": f"level_fwd2_kernel<{Cc}, false, false>", "us": us_fwd, "flops": fwd_flops}}
+            "forward": {"kernel": f"level_fwd2_kernel<{Cc}, false, false, false>", "us": us_fwd, "flops": fwd_flops}}
 
 
 def local_level_flops(net, lvl):
@@ -546,7 +546,7 @@ def main():
             traffic = None          # HBM bytes per launch of the dominant kernel, from the PMC passes recorded under profiles/
             if args.config == "cfg2" and per_gpu == 512:
                 try:
-                    with open(os.path.join(ROOT, "profiles", "r03_pmc_cfg2.json")) as fh:
+                    with open(os.path.join(ROOT, "profiles", "r04_pmc_cfg2.json")) as fh:
                         traffic = json.load(fh)["kernels"]["lgn::" + dom["kernel"]]["derived"]["hbm_bytes"]
                 except (OSError, KeyError):
                     pass
@@ -559,7 +559,7 @@ def main():
                 "frac": achieved / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic,
                 "traffic_note": "bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction; an ESTIMATE: the guide "
                                 "calibrates the x2 on 16 B/lane loads, this kernel issues 8 B/lane), separate rocprofv3 "
-                                "--pmc passes recorded in profiles/r03_pmc_cfg2.json; 0.5 TB/s, HBM is not the bound",
+                                "--pmc passes recorded in profiles/r04_pmc_cfg2.json; 0.5 TB/s, HBM is not the bound",
                 "us_per_launch": dom["us"], "timing": dom.get("timing"), "algorithmic_flops_per_launch": dom["flops"],
                 "forward_kernel": {"kernel": fw["kernel"], "us_per_launch": fw["us"], "algorithmic_flops_per_launch": fw["flops"],
                                    "achieved": fw["flops"] / (fw["us"] * 1e-6) / 1e12,
@@ -575,7 +575,7 @@ def main():
             traffic = None
             if args.config == "cfg5" and per_gpu == 512 and dom is not None:
                 try:
-                    with open(os.path.join(ROOT, "profiles", "r03_pmc_cfg5.json")) as fh:
+                    with open(os.path.join(ROOT, "profiles", "r04_pmc_cfg5.json")) as fh:
                         ks = json.load(fh)["kernels"]
                     traffic = ks["lgn::" + dom["kernel"].replace("<Kind", "<lgn::cgs::Kind")]["derived"].get("hbm_bytes")
                 except (OSError, KeyError):
@@ -585,10 +585,10 @@ def main():
                 out["roofline"] = {"bound": "mfma", "pipe": "fp64 vector datapath (no matrix instructions in this kernel; schema has hbm|mfma only)",
                                    "kernel": dom["kernel"], "achieved": ach, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                                    "frac": ach / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic,
-                                   "traffic_note": "2 x FETCH_SIZE + WRITE_SIZE of the rocprofv3 --pmc passes in profiles/r03_pmc_cfg5.json",
+                                   "traffic_note": "2 x FETCH_SIZE + WRITE_SIZE of the rocprofv3 --pmc passes in profiles/r04_pmc_cfg5.json",
                                    "us_per_launch": dom["us"], "algorithmic_flops_per_launch": dom["flops"],
                                    "note": "us_per_launch is the C-ABI call (kernel + weight packing + partial-row reduction + unpacking); "
-                                           "the kernel alone: profiles/r03_cfg5_kernel_stats.csv",
+                                           "the kernel alone: profiles/r04_cfg5_kernel_stats.csv",
                                    "whole_step": {"achieved": ach_step, "frac": ach_step / FP64_VECTOR_PEAK_TFLOPS,
                                                   "algorithmic_flops_per_jet": flops_per_jet,
                                                   "note": "SURVEY 8(d) algorithmic flops per jet x measured jets/s"}}

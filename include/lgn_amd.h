@@ -325,6 +325,16 @@ int lgn_decoder_bwd_f64(const lgn_net_desc* d, const double* params, double* gra
                         const double* lat_v, const double* act, long long act_doubles, const double* g_recon, double* g_lat_v,
                         double* scratch, long long scratch_doubles, void* stream);
 
+/* ---- Chamfer loss on its own (module API: lgn/losses.py ChamferLoss, the drop-in of utils/losses/chamfer_loss/chamfer_loss.py:7-31;
+ * the whole-step call has the loss inside the decoder's last kernel).  x [B][N][4], y [B][M][4] real 4-vectors, cdist = sum of
+ * squared component differences (distance_sq.py:263-304, even p: no eps).
+ *   loss_part[b] = (sum_i min_j d_ij + sum_j min_i d_ij) / 2  [+ sum_mu (sum_i x - sum_j y)_mu^2 / (4 B) with jet_features: the
+ *                  nn.MSELoss() of the jet momenta, chamfer_loss.py:25-29];  the loss is the sum of loss_part over the batch
+ *   gx [B][N][4], gy [B][M][4] = d loss / d x, d loss / d y (first minimum on ties, as torch.min; gy may be needed for a target that
+ *                  requires grad -- always written) */
+int lgn_chamfer_f64(int B, int N, int M, const double* x, const double* y, int jet_features, double* loss_part, double* gx, double* gy,
+                    void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -163,6 +163,13 @@ int lgn_mixreps_fwd_f64(int rows, int Cin, int Cout, int d, const double* w, con
 
 int lgn_mixreps_partial_rows(int rows) { return mix_partial_rows(rows); }
 
+int lgn_chamfer_f64(int B, int N, int M, const double* x, const double* y, int jet_features, double* loss_part, double* gx, double* gy,
+                    void* stream) {
+  LGN_CHECK_ARG(B > 0 && N > 0 && M > 0, "chamfer: empty input (B=%d N=%d M=%d)", B, N, M);
+  LGN_CHECK_ARG(x && y && loss_part && gx && gy, "chamfer: null pointer");
+  return chamfer_fwd(B, N, M, x, y, jet_features, loss_part, gx, gy, (hipStream_t)stream);
+}
+
 int lgn_mixreps_bwd_f64(int rows, int Cin, int Cout, int d, const double* w, const double* x, const double* g_y, double* g_x,
                         double* part, void* stream) {
   LGN_CHECK_ARG(w && x && g_y && part, "mixreps_bwd: null pointer");

@@ -47,6 +47,9 @@ int dec_input_bwd(int B, int N, int C, int Tin, const double* lat_v, const doubl
                   double* part /*[B][4C + 2 N Tin]*/, hipStream_t);
 int dec_output_loss(int B, int N, int C, const double* v, const double* wo1, const double* target, double loss_scale, double* recon,
                     double* loss_part /*[B]*/, double* g_v, double* part /*[B][2C]*/, hipStream_t);
+// Chamfer loss per jet and its gradients (module API: lgn/losses.py); loss_part [B], gx [B][N][4], gy [B][M][4]
+int chamfer_fwd(int B, int N, int M, const double* x, const double* y, int jet_features, double* loss_part, double* gx, double* gy,
+                hipStream_t);
 // decoder output without the loss (module API): recon [2][B][N][4]; backward from g_recon, part [B][2C]
 int dec_output_fwd(int B, int N, int C, const double* v, const double* wo1, double* recon, hipStream_t);
 int dec_output_bwd(int B, int N, int C, const double* v, const double* wo1, const double* g_recon, double* g_v, double* part, hipStream_t);

@@ -919,6 +919,85 @@ __global__ __launch_bounds__(BLOCK) void dec_output_fwd_kernel(int B, int N, int
   }
 }
 // one workgroup per jet; g_v [2][B][N][C][4]; part row per jet: dWo1 [2][C]
+// ============================================================================================
+// Chamfer loss on its own (module API; the whole step has it inside dec_output_loss): ChamferLoss.forward of
+// utils/losses/chamfer_loss/chamfer_loss.py:16-31 with cdist = sum over the 4 components of (x_i - y_j)^2 (distance_sq.py:263-304,
+// even p: no eps).  One workgroup per jet computes the jet's term
+//     (sum_i min_j d_ij + sum_j min_i d_ij) / 2   [+ sum_mu (sum_i x_i - sum_j y_j)_mu^2 / (4 B): the jet_features MSE term]
+// and, in the same pass, its gradient w.r.t. x and y (first minimum on ties, as torch.min); autograd scales them by the upstream
+// scalar.  LDS: x [N][4] | y [M][4] | rarg [N] | carg [M] (ints) | red [2 * BLOCK / 64 + 8]
+// ============================================================================================
+__global__ __launch_bounds__(BLOCK) void chamfer_kernel(int B, int N, int M, const double* __restrict__ x, const double* __restrict__ y,
+                                                        int jet_features, double* loss_part, double* gx, double* gy) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  double* xl = reinterpret_cast<double*>(smem_raw);
+  double* yl = xl + N * 4;
+  double* red = yl + M * 4;                             // [BLOCK / 64] wave sums, then [8] jet sums
+  int* rarg = reinterpret_cast<int*>(red + BLOCK / 64 + 8);
+  int* carg = rarg + N;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  for (int e = tid; e < N * 4; e += BLOCK) xl[e] = x[(size_t)b * N * 4 + e];
+  for (int e = tid; e < M * 4; e += BLOCK) yl[e] = y[(size_t)b * M * 4 + e];
+  __syncthreads();
+  auto dist = [&](int i, int j) {
+    const double d0 = xl[i * 4] - yl[j * 4], d1 = xl[i * 4 + 1] - yl[j * 4 + 1], d2 = xl[i * 4 + 2] - yl[j * 4 + 2],
+                 d3 = xl[i * 4 + 3] - yl[j * 4 + 3];
+    return ((d0 * d0 + d1 * d1) + d2 * d2) + d3 * d3;   // torch.sum over the last axis of 4: sequential
+  };
+  double mine = 0.0;
+  for (int e = tid; e < N + M; e += BLOCK) {
+    double best = 0.0;
+    int arg = 0;
+    if (e < N) {
+      for (int j = 0; j < M; ++j) { const double d = dist(e, j); if (j == 0 || d < best) { best = d; arg = j; } }
+      rarg[e] = arg;
+    } else {
+      const int j = e - N;
+      for (int i = 0; i < N; ++i) { const double d = dist(i, j); if (i == 0 || d < best) { best = d; arg = i; } }
+      carg[j] = arg;
+    }
+    mine += 0.5 * best;
+  }
+  if (jet_features && tid < 8) {                         // jet sums of x (tid 0..3) and y (4..7), component tid & 3
+    const int m = tid & 3;
+    double s = 0.0;
+    if (tid < 4) for (int i = 0; i < N; ++i) s += xl[i * 4 + m];
+    else for (int j = 0; j < M; ++j) s += yl[j * 4 + m];
+    red[BLOCK / 64 + tid] = s;
+  }
+  mine = group_sum<64>(mine);
+  if ((tid & 63) == 0) red[tid >> 6] = mine;
+  __syncthreads();
+  const double* js = red + BLOCK / 64;
+  const double jscale = 1.0 / (4.0 * (double)B);         // nn.MSELoss(): mean over the (B, 4) jet momenta
+  if (tid == 0) {
+    double s = 0.0;
+    for (int w = 0; w < BLOCK / 64; ++w) s += red[w];
+    if (jet_features)
+      for (int m = 0; m < 4; ++m) { const double d = js[m] - js[4 + m]; s += d * d * jscale; }
+    loss_part[b] = s;
+  }
+  // gradients: row-minimum term of the own particle + every column (row) minimum that picked it, in index order
+  for (int e = tid; e < (N + M) * 4; e += BLOCK) {
+    const int p = e >> 2, m = e & 3;
+    double g = 0.0;
+    if (p < N) {
+      const double xi = xl[p * 4 + m];
+      g = xi - yl[rarg[p] * 4 + m];
+      for (int j = 0; j < M; ++j) if (carg[j] == p) g += xi - yl[j * 4 + m];
+      if (jet_features) g += 2.0 * jscale * (js[m] - js[4 + m]);
+      gx[((size_t)b * N + p) * 4 + m] = g;
+    } else {
+      const int j = p - N;
+      const double yj = yl[j * 4 + m];
+      g = yj - xl[carg[j] * 4 + m];
+      for (int i = 0; i < N; ++i) if (rarg[i] == j) g += yj - xl[i * 4 + m];
+      if (jet_features) g -= 2.0 * jscale * (js[m] - js[4 + m]);
+      gy[((size_t)b * M + j) * 4 + m] = g;
+    }
+  }
+}
+
 __global__ __launch_bounds__(BLOCK) void dec_output_bwd_kernel(int B, int N, int C, const double* __restrict__ v,
                                                               const double* __restrict__ wo1, const double* __restrict__ g_recon,
                                                               double* g_v, double* part) {
@@ -1099,6 +1178,14 @@ int dec_output_loss(int B, int N, int C, const double* v, const double* wo1, con
 }
 int dec_output_fwd(int B, int N, int C, const double* v, const double* wo1, double* recon, hipStream_t st) {
   hipLaunchKernelGGL(dec_output_fwd_kernel, dim3(grid_for((size_t)B * N)), dim3(BLOCK), 0, st, B, N, C, v, wo1, recon);
+  LGN_CHECK_LAUNCH();
+  return 0;
+}
+int chamfer_fwd(int B, int N, int M, const double* x, const double* y, int jet_features, double* loss_part, double* gx, double* gy,
+                hipStream_t st) {
+  const size_t smem = sizeof(double) * ((size_t)(N + M) * 4 + BLOCK / 64 + 8) + sizeof(int) * (size_t)(N + M);
+  LGN_LDS_LAUNCH(chamfer_kernel, "chamfer", smem);
+  hipLaunchKernelGGL(chamfer_kernel, dim3(B), dim3(BLOCK), smem, st, B, N, M, x, y, jet_features, loss_part, gx, gy);
   LGN_CHECK_LAUNCH();
   return 0;
 }

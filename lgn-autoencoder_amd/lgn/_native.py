@@ -38,6 +38,7 @@ _SIGNATURES = {
     "lgn_cgmlp_partial_rows": [_i, _i],
     "lgn_cgmlp_bwd_f64": [_i] * 5 + [_vp] * 6 + [_i, _vp],
     "lgn_mixreps_fwd_f64": [_i] * 4 + [_vp] * 4,
+    "lgn_chamfer_f64": [_i] * 3 + [_vp] * 2 + [_i] + [_vp] * 4,
     "lgn_mixreps_partial_rows": [_i],
     "lgn_mixreps_bwd_f64": [_i] * 4 + [_vp] * 6,
 }
@@ -375,6 +376,17 @@ def cgmlp_bwd(s_in, ws, bs, g_out, act: int = 0):
         gws.append(flat[off: off + w.numel()].view_as(w)); off += w.numel()
         gbs.append(flat[off: off + b.numel()].view_as(b)); off += b.numel()
     return g_in, gws, gbs
+
+
+def chamfer(x, y, jet_features=False):
+    """x (B,N,4), y (B,M,4) real 4-vectors -> per-jet loss terms (B,), d loss / d x, d loss / d y (lgn_chamfer_f64)."""
+    x, y = f64(x), f64(y)
+    B, Np, M = x.shape[0], x.shape[1], y.shape[1]
+    out = torch.empty(B + 4 * B * (Np + M), device=x.device, dtype=x.dtype)       # one allocation: [loss_part | gx | gy]
+    part, gx, gy = out[:B], out[B:B + 4 * B * Np].view(B, Np, 4), out[B + 4 * B * Np:].view(B, M, 4)
+    _check(lib().lgn_chamfer_f64(B, Np, M, ptr(x), ptr(y), int(bool(jet_features)), ptr(part), ptr(gx), ptr(gy), stream_ptr()),
+           "lgn_chamfer_f64")
+    return part, gx, gy
 
 
 def mixreps_fwd(w, x):

@@ -420,6 +420,58 @@ def test_mixreps(dev, O, rows, Ci, Co, d):
     U.assert_close(xd.grad, x.grad, GRAD_TOL, "mix g_x")
 
 
+@pytest.mark.parametrize("B,N,M", [(2, 7, 19), (1, 1, 5), (3, 40, 9)])
+def test_chamfer_kernel_unequal_sets(dev, B, N, M):
+    """lgn_chamfer_f64 with N != M (the module refuses it like the reference, whose elementwise sum of the two minima arrays needs
+    N == M): sum_i min_j + sum_j min_i, halved, and its gradients, against torch."""
+    from lgn import _native as Nn
+    from lgn.losses import ChamferLoss
+    g = torch.Generator().manual_seed(N + M)
+    x = torch.randn(B, N, 4, dtype=torch.float64, generator=g).requires_grad_(True)
+    y = torch.randn(B, M, 4, dtype=torch.float64, generator=g).requires_grad_(True)
+    d = ((x.unsqueeze(-2) - y.unsqueeze(-3)) ** 2).sum(-1)
+    ref = 0.5 * (d.min(dim=-1).values.sum(-1) + d.min(dim=-2).values.sum(-1))
+    ref.sum().backward()
+    part, gx, gy = Nn.chamfer(x.detach().to(dev), y.detach().to(dev))
+    U.assert_close(part, ref, 1e-13, "per-jet terms")
+    U.assert_close(gx, x.grad, 1e-12, "d / d x")
+    U.assert_close(gy, y.grad, 1e-12, "d / d y")
+    with pytest.raises(RuntimeError, match="must match the size"):
+        ChamferLoss(device=dev)(x.detach().to(dev), y.detach().to(dev))
+
+
+@pytest.mark.parametrize("B,N,M,jet", [(4, 30, 30, False), (3, 12, 12, True), (2, 150, 150, True), (1, 1, 1, False), (300, 30, 30, False)])
+def test_chamfer_loss_module(dev, O, B, N, M, jet):
+    """lgn.losses.ChamferLoss (one kernel: loss + both gradients) against the reference's formula restated in torch fp64
+    (oracle: chamfer_loss; utils/losses/chamfer_loss/chamfer_loss.py:16-31), including zero-padded rows (exact ties: first minimum),
+    the jet_features MSE term, and the gradient w.r.t. the target."""
+    from lgn.losses import ChamferLoss
+    g = torch.Generator().manual_seed(100 * N + M + B)
+    x = torch.randn(B, N, 4, dtype=torch.float64, generator=g)
+    y = torch.randn(B, M, 4, dtype=torch.float64, generator=g)
+    if N > 4 and M > 4:
+        x[0, N - 2:] = 0.0                  # padded particles: identical rows -> tied distances
+        y[0, M - 3:] = 0.0
+        y[-1, 0] = x[-1, 1]                 # an exact zero distance
+    xr, yr = x.clone().requires_grad_(True), y.clone().requires_grad_(True)
+    ref = O.chamfer_loss(xr, yr)
+    if jet:
+        ref = ref + torch.nn.MSELoss()(xr.sum(dim=-2), yr.sum(dim=-2))
+    (3.0 * ref).backward()
+    xd, yd = x.to(dev).requires_grad_(True), y.to(dev).requires_grad_(True)
+    loss = ChamferLoss(device=dev)(xd, yd, jet_features=jet)
+    (3.0 * loss).backward()
+    U.assert_close(loss, ref, 1e-13, "chamfer")
+    U.assert_close(xd.grad, xr.grad, 1e-12, "d loss / d x")
+    U.assert_close(yd.grad, yr.grad, 1e-12, "d loss / d y")
+    with torch.no_grad():                    # no graph: forward only, target without gradient
+        U.assert_close(ChamferLoss(device=dev)(x.to(dev), y.to(dev), jet), ref, 1e-13, "chamfer (no grad)")
+    # leading batch axes are flattened as the reference's broadcasting cdist would treat them
+    if B % 2 == 0:
+        l2 = ChamferLoss(device=dev)(x.to(dev).view(2, B // 2, N, 4), y.to(dev).view(2, B // 2, M, 4))
+        U.assert_close(l2, O.chamfer_loss(x, y), 1e-13, "chamfer, two batch axes")
+
+
 def _build(meta, dev):
     import __graft_entry__ as G
     enc, dec = G._models(meta["N"], meta["ch_enc"], meta["ch_dec"], dev, seed=meta["seed"], maxdim=meta["maxdim"],

@@ -272,6 +272,22 @@ def test_module_api_training_loop_matches_native_step():
     U.assert_close(torch.cat([enc.flat_params.detach(), dec.flat_params.detach()]), ref.flat.flat, 1e-9, "parameters after 3 steps")
 
 
+@pytest.mark.parametrize("native_loss", [True, False])
+def test_reference_loop_step_matches_native_step(native_loss):
+    """lgn.step.ReferenceLoopStep (the loop body of utils/train.py:283-343 on the module API, with lgn.losses.ChamferLoss or the
+    torch restatement of the reference's loss) against the native graph-replayed step: same losses, same parameters after 3 steps."""
+    from lgn.step import NativeTrainStep, ReferenceLoopStep
+    z, m, enc, dec, batch = _golden_setup()
+    _, _, enc2, dec2, _ = _golden_setup()
+    ref = NativeTrainStep(enc2, dec2, batch_size=m["B"], lr=5e-4, l1_lambda=1e-8, use_graph=True)
+    loop = ReferenceLoopStep(enc, dec, lr=5e-4, l1_lambda=1e-8, native_loss=native_loss)
+    for it in range(3):
+        loss, _ = loop.step(batch)
+        lr, _ = ref.step(batch)
+        U.assert_close(loss, lr, 1e-10, f"loss at step {it}")
+    U.assert_close(torch.cat([enc.flat_params.detach(), dec.flat_params.detach()]), ref.flat.flat, 1e-9, "parameters after 3 steps")
+
+
 WIDE = ((2, 4, 7, 8), (8, 6, 5, 3))
 @pytest.mark.parametrize("maxdim", [2, 3])
 @pytest.mark.parametrize("latent", ["mean", "max", "min", "mean&max", "max&min", "min+max", "mean&min&max", "mean+min+max",

@@ -261,6 +261,21 @@ def test_native_step_refuses_configurations_it_does_not_implement():
         NativeTrainStep(enc, dec, batch_size=4)
 
 
+def test_chamfer_loss_module_has_no_cpu_path():
+    """lgn.losses.ChamferLoss keeps the reference's constructor / forward signature (utils/losses/chamfer_loss/chamfer_loss.py:7-16)
+    and fails loudly without a GPU instead of computing on the host."""
+    import inspect
+    from lgn.losses import ChamferLoss
+    assert list(inspect.signature(ChamferLoss.__init__).parameters) == ["self", "device"]
+    assert list(inspect.signature(ChamferLoss.forward).parameters) == ["self", "x", "y", "jet_features"]
+    loss = ChamferLoss(device=torch.device("cpu"))
+    x = torch.randn(2, 5, 4, dtype=torch.float64)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        loss(x, x)
+    with pytest.raises(ValueError, match="4-vectors"):
+        loss(x[..., :3], x[..., :3])
+
+
 def test_generated_static_tables_are_up_to_date_and_match_the_runtime_matcher():
     """csrc/cg_static_tables.hpp is generated from lgn.plan.build_local_tables (tools/gen_static_tables.py); the committed
     file must equal a fresh rendering, and plan.static_kind must recognise exactly the levels it was generated from."""
