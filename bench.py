@@ -449,7 +449,7 @@ def main():
     ap.add_argument("--weak", action="store_true", help="weak scaling as the primary figure: the config's batch on every GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the module_api and decoder_pairwise legs")
-    ap.add_argument("--harness", choices=["native", "native-nograph", "module", "modular"], default=None,
+    ap.add_argument("--harness", choices=["native", "native-nograph", "module", "modular", "captured"], default=None,
                     help="native: one C call per step replayed from a HIP graph (default); module: the reference's loop on the "
                          "nn.Module API")
     args = ap.parse_args()
@@ -485,12 +485,14 @@ def main():
     harness = "module" if harness == "modular" else harness
 
     import __graft_entry__ as G
-    from lgn.step import NativeTrainStep, ReferenceLoopStep
+    from lgn.step import CapturedModuleStep, NativeTrainStep, ReferenceLoopStep
 
     def build(which, jets=None):
         enc, dec = G._models(N, cfg["ch_enc"], cfg["ch_dec"], dev, seed=0, maxdim=cfg["maxdim"])   # identical replicas on every rank
         if which == "module":
             return enc, ReferenceLoopStep(enc, dec, lr=5e-4, l1_lambda=1e-8)
+        if which == "captured":
+            return enc, CapturedModuleStep(enc, dec, batch_size=jets or per_gpu, lr=5e-4, l1_lambda=1e-8)
         return enc, NativeTrainStep(enc, dec, batch_size=jets or per_gpu, lr=5e-4, l1_lambda=1e-8, use_graph=which == "native")
 
     def timed(tr, b):
@@ -536,7 +538,9 @@ def main():
                        "parallelism": f"dp{world}" + (" (one RCCL all-reduce of the flat gradient per step)" if world > 1 else ""),
                        "harness": {"native": "NativeTrainStep: lgn_step_fwd_bwd_f64 + lgn_step_finalize_f64 replayed from a HIP graph",
                                    "native-nograph": "NativeTrainStep without graph capture",
-                                   "module": "ReferenceLoopStep: reference loop on the nn.Module API"}[harness]},
+                                   "module": "ReferenceLoopStep: reference loop on the nn.Module API",
+                                   "captured": "CapturedModuleStep: module API + ChamferLoss under autograd + native L1 / Adam, "
+                                               "captured into one HIP graph (what configurations outside the whole-step call get)"}[harness]},
         }
         if weak is not None:
             out["weak_scaling"] = weak
@@ -602,10 +606,17 @@ def main():
                 _, mod = build("module")
                 e2 = _time_steps(mod, batch, args.steps, args.warmup, 1)
                 out["module_api"] = {"value": per_gpu * args.steps / e2, "unit": "jets/s", "ms_per_step": 1e3 * e2 / args.steps,
-                                     "harness": "ReferenceLoopStep (lgn/step.py): enc(batch) -> dec(latent) -> torch Chamfer + "
+                                     "harness": "ReferenceLoopStep (lgn/step.py): enc(batch) -> dec(latent) -> lgn.losses.ChamferLoss + "
                                                 "l1_norm() -> loss.backward() -> 2 x torch.optim.Adam, fused whole-network "
                                                 "native calls under autograd, no graph capture"}
                 del mod
+                _, cap = build("captured")
+                e3 = _time_steps(cap, batch, args.steps, args.warmup, 1)
+                out["module_api_captured"] = {"value": per_gpu * args.steps / e3, "unit": "jets/s", "ms_per_step": 1e3 * e3 / args.steps,
+                                              "harness": "CapturedModuleStep (lgn/step.py): the same module-API step (ChamferLoss, backward(), "
+                                                         "native L1 + Adam) captured into one HIP graph -- the route of configurations "
+                                                         "the whole-step call does not take (jet_features, extra scalars, ...)"}
+                del cap
             if harness == "native" and cfg["maxdim"] == 2:
                 os.environ["LGN_AMD_DEC_PAIRWISE"] = "1"
                 try:

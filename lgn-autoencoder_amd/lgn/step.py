@@ -240,7 +240,8 @@ class NativeTrainStep:
                 f"{encoder.mlp_depth}, decoder maxdim={decoder.level_maxdim} mlp={decoder.mlp}")
         if getattr(encoder, "tau_input_scalars", 1) != 1:
             raise NotImplementedError("the native step takes the particle masses as the only input scalars: jet_features / extra "
-                                      "input scalars run through the module API (per-operator path)")
+                                      "input scalars run through the module API (CapturedModuleStep / native_train_step capture that "
+                                      "step into one graph)")
         encoder._require_gpu()
         self.encoder, self.decoder = encoder, decoder
         self.l1_lambda, self.lr, self.betas, self.eps = l1_lambda, lr, betas, eps
@@ -434,3 +435,137 @@ class NativeTrainStep:
                 dist.all_reduce(self.flat.grad_buf, op=dist.ReduceOp.SUM, group=self.group)
             self._finalize(self.optimizer)
         return self.loss_out[0], self.recon
+
+
+class CapturedModuleStep:
+    """The training step for every configuration the MODULES run but lgn_step_fwd_bwd_f64 refuses -- ``jet_features`` / extra
+    input scalars (the encoder has one node more than the decoder), ``--chamfer-jet-features``, mixed maxdim-2 / maxdim-3 networks,
+    ``map_to_latent='sum'``, levels without CGMLP: ``encoder(batch) -> decoder(latent) -> lgn.losses.ChamferLoss -> backward()``
+    under autograd (one native call per network and direction where the configuration allows it, per operator otherwise), then
+    lgn_step_finalize_f64 (L1 sub-gradient, loss assembly, Adam) -- all of it, input preparation included, captured ONCE into a
+    HIP graph on static buffers and replayed (``use_graph``), so that no Python / autograd work is left in the step.  Same
+    interface as NativeTrainStep (``load_batch``, ``step``, ``loss_out``, ``flat``); under data parallelism the flat gradient buffer
+    (gradients | this rank's Chamfer term) is all-reduced between two graphs."""
+
+    def __init__(self, encoder, decoder, batch_size: int, lr: float = 5e-4, l1_lambda: float = 1e-8, betas=(0.9, 0.999),
+                 eps: float = 1e-8, process_group=None, optimizer: bool = True, use_graph: bool = True, get_real_method: str = "sum",
+                 chamfer_jet_features: bool = False, extra_scalars: int = 0):
+        from . import _native as N
+        from .losses import ChamferLoss
+        self.N = N
+        encoder._require_gpu()
+        self.encoder, self.decoder = encoder, decoder
+        self.l1_lambda, self.lr, self.betas, self.eps = l1_lambda, lr, betas, eps
+        self.get_real_method, self.chamfer_jet_features = get_real_method, chamfer_jet_features
+        self.flat = FlatParams(encoder, decoder, grad_tail=1)             # gradients | this rank's Chamfer term
+        self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        self.group, self.optimizer, self.use_graph = process_group, optimizer, use_graph
+        dev, dt = self.flat.flat.device, self.flat.flat.dtype
+        n_in = encoder.num_input_particles - (1 if getattr(encoder, "jet_features", False) else 0)    # particles per jet in the batch
+        self.batch = {"p4": torch.zeros(batch_size, n_in, 4, device=dev, dtype=dt),
+                      "labels": torch.zeros(batch_size, n_in, device=dev, dtype=torch.uint8)}
+        if extra_scalars:
+            self.batch["scalars"] = torch.zeros(batch_size, encoder.num_input_particles, extra_scalars, device=dev, dtype=dt)
+        self.loss_fn = ChamferLoss(device=dev)
+        self.loss_part = self.flat.tail
+        self._loss_buf = torch.zeros(3 + N.FINALIZE_SCRATCH, device=dev, dtype=dt)
+        self.loss_out = self._loss_buf[:3]
+        self.adam_m, self.adam_v = torch.zeros_like(self.flat.flat), torch.zeros_like(self.flat.flat)
+        self.step_dev = torch.zeros(1, device=dev, dtype=torch.int64)
+        self.recon = None
+        self._g1 = self._g2 = None
+        self.launches_per_step = None
+
+    def _fwd_bwd(self):
+        self.flat.grad_buf.zero_()
+        recon = self.decoder(self.encoder(self.batch))
+        loss = self.loss_fn(get_real(recon, self.get_real_method), self.batch["p4"], jet_features=self.chamfer_jet_features)
+        loss.backward()                                   # accumulates into the views of flat.grad the parameters hold
+        self.loss_part.copy_(loss.detach().reshape(1))
+        self.recon = recon.detach()
+
+    def _finalize(self, do_adam: bool):
+        N = self.N
+        rc = N.lib().lgn_step_finalize_f64(N.ptr(self.flat.flat), N.ptr(self.flat.grad), self.flat.flat.numel(), N.ptr(self.loss_part), 1,
+                                           float(self.l1_lambda), N.ptr(self.adam_m), N.ptr(self.adam_v), N.ptr(self.step_dev),
+                                           float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), int(do_adam),
+                                           N.ptr(self._loss_buf), N.stream_ptr())
+        N._check(rc, "lgn_step_finalize_f64")
+
+    def _capture(self):
+        snap = (self.flat.flat.clone(), self.adam_m.clone(), self.adam_v.clone(), self.step_dev.clone())
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):                        # warm-up: lazy loads, autograd's first-use set-up, allocator state
+            for _ in range(2):
+                self._fwd_bwd()
+                self._finalize(False)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        self._g1 = torch.cuda.CUDAGraph()
+        if self.world > 1:
+            self._g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._g1):
+                self._fwd_bwd()
+            with torch.cuda.graph(self._g2, pool=self._g1.pool()):
+                self._finalize(self.optimizer)
+        else:
+            with torch.cuda.graph(self._g1):
+                self._fwd_bwd()
+                self._finalize(self.optimizer)
+        self.launches_per_step = 3 if self._g2 is not None else 1
+        with torch.no_grad():
+            self.flat.flat.copy_(snap[0]); self.adam_m.copy_(snap[1]); self.adam_v.copy_(snap[2]); self.step_dev.copy_(snap[3])
+
+    def load_batch(self, batch: Dict[str, torch.Tensor]):
+        """Stage a batch into the static input tensors the captured graph reads (the encoder's own input preparation -- scale,
+        jet node, masks: lgn/models/lgn_encoder.py:338-412 -- is part of the graph)."""
+        p4 = batch["p4"]
+        if tuple(p4.shape) != tuple(self.batch["p4"].shape):
+            raise ValueError(f"CapturedModuleStep was built for batches of shape {tuple(self.batch['p4'].shape)}, got {tuple(p4.shape)}")
+        self.batch["p4"].copy_(p4)
+        for key in ("labels", "masks", "mask"):
+            if key in batch:
+                self.batch["labels"].copy_(batch[key].to(torch.uint8))
+                break
+        else:
+            self.batch["labels"].copy_((p4[..., 0] != 0).to(torch.uint8))
+        if ("scalars" in batch) != ("scalars" in self.batch):
+            raise ValueError("CapturedModuleStep: data['scalars'] must be present exactly when the step was built with extra_scalars")
+        if "scalars" in batch:
+            self.batch["scalars"].copy_(batch["scalars"])
+
+    def step(self, batch: Optional[Dict[str, torch.Tensor]] = None):
+        """One step on `batch` (or on the staged static buffers).  Returns (total loss (device scalar), reconstruction)."""
+        if batch is not None:
+            self.load_batch(batch)
+        if self.use_graph and self._g1 is None:
+            self._capture()
+        if self.use_graph:
+            self._g1.replay()
+            if self._g2 is not None:
+                dist.all_reduce(self.flat.grad_buf, op=dist.ReduceOp.SUM, group=self.group)
+                self._g2.replay()
+        else:
+            self._fwd_bwd()
+            if self.world > 1:
+                dist.all_reduce(self.flat.grad_buf, op=dist.ReduceOp.SUM, group=self.group)
+            self._finalize(self.optimizer)
+        return self.loss_out[0], self.recon
+
+
+def native_train_step(encoder, decoder, batch_size: int, **kw):
+    """NativeTrainStep where lgn_step_fwd_bwd_f64 covers the configuration (one native call per step), else CapturedModuleStep
+    (the module-API step captured into one graph).  Keyword arguments the two do not share go to the one that takes them."""
+    import inspect
+
+    def only(cls):
+        return {k: v for k, v in kw.items() if k in inspect.signature(cls.__init__).parameters}
+
+    needs_modules = bool(kw.get("chamfer_jet_features") or kw.get("extra_scalars") or kw.get("get_real_method", "sum") != "sum")
+    if not needs_modules:
+        try:
+            return NativeTrainStep(encoder, decoder, batch_size, **only(NativeTrainStep))
+        except NotImplementedError:
+            pass
+    return CapturedModuleStep(encoder, decoder, batch_size, **only(CapturedModuleStep))

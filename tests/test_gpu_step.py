@@ -288,6 +288,65 @@ def test_reference_loop_step_matches_native_step(native_loss):
     U.assert_close(torch.cat([enc.flat_params.detach(), dec.flat_params.detach()]), ref.flat.flat, 1e-9, "parameters after 3 steps")
 
 
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_captured_module_step_jet_features_matches_reference_golden(use_graph):
+    """CapturedModuleStep -- enc(batch) -> dec -> ChamferLoss -> backward() -> native L1 + Adam, captured into one HIP graph -- on the
+    configuration the whole-step call refuses (g10: jet_features, one more encoder node, two extra input scalars): the reference's
+    loss, reconstruction and gradients, eager and replayed."""
+    import __graft_entry__ as G
+    from lgn.step import CapturedModuleStep, NativeTrainStep, native_train_step
+    dev = torch.device("cuda:0")
+    z = U.load("g10_e2e_jetfeat.npz")
+    m = U.meta(z)
+    enc, dec = G._models(m["N"], m["ch_enc"], m["ch_dec"], dev, seed=m["seed"], maxdim=m.get("maxdim", 2), jet_features=True,
+                         tau_input_scalars=1 + m.get("extra_scalars", 0))
+    enc.load_state_dict(U.params_from(z, "enc")); dec.load_state_dict(U.params_from(z, "dec"))
+    with pytest.raises(NotImplementedError, match="jet_features"):
+        NativeTrainStep(enc, dec, batch_size=m["B"])
+    batch = {"p4": torch.from_numpy(z["p4"]).to(dev), "labels": torch.from_numpy(z["labels"]).to(dev)}
+    if "scalars" in z.files:
+        batch["scalars"] = torch.from_numpy(z["scalars"]).to(dev)
+    step = native_train_step(enc, dec, m["B"], l1_lambda=m["l1_lambda"], optimizer=False, use_graph=use_graph,
+                             extra_scalars=m.get("extra_scalars", 0))
+    assert isinstance(step, CapturedModuleStep)
+    for _ in range(3):
+        total, recon = step.step(batch)
+    U.assert_close(total, z["loss_total"], 1e-11, "total loss")
+    U.assert_close(step.loss_out[1], z["loss_chamfer"], 1e-11, "chamfer")
+    U.assert_close(recon, z["recon"], 1e-11, "recon")
+    lam = m["l1_lambda"]
+    for pre, mod in (("enc", enc), ("dec", dec)):
+        sd = U.params_from(z, pre)
+        for k, g in mod.named_grads():
+            U.assert_close(g, torch.from_numpy(z[f"grad.{pre}.{k}"]) + lam * torch.sign(sd[k]), 1e-9, f"grad {pre}.{k}")
+    assert step.launches_per_step == (1 if use_graph else None)
+
+
+@pytest.mark.parametrize("jet_loss", [False, True])
+def test_captured_module_step_trains_like_the_native_step(jet_loss):
+    """Three Adam steps of CapturedModuleStep (graph replay) against NativeTrainStep on a configuration both cover; with
+    --chamfer-jet-features (utils/train.py:432: the MSE of the summed momenta inside ChamferLoss) against the eager module loop."""
+    from lgn.step import CapturedModuleStep, NativeTrainStep, ReferenceLoopStep, native_train_step
+    z, m, enc, dec, batch = _golden_setup()
+    _, _, enc2, dec2, _ = _golden_setup()
+    a = CapturedModuleStep(enc, dec, batch_size=m["B"], lr=5e-4, l1_lambda=1e-8, use_graph=True, chamfer_jet_features=jet_loss)
+    if jet_loss:
+        b = ReferenceLoopStep(enc2, dec2, lr=5e-4, l1_lambda=1e-8)
+        loss_fn = b.loss_fn
+        b.loss_fn = lambda x, y: loss_fn(x, y, jet_features=True)
+        flat_b = lambda: torch.cat([enc2.flat_params.detach(), dec2.flat_params.detach()])      # noqa: E731
+    else:
+        b = native_train_step(enc2, dec2, m["B"], lr=5e-4, l1_lambda=1e-8, use_graph=True)
+        assert isinstance(b, NativeTrainStep)
+        flat_b = lambda: b.flat.flat                                                               # noqa: E731
+    for it in range(3):
+        la, _ = a.step(batch)
+        lb, _ = b.step(batch)
+        U.assert_close(la, lb, 1e-10, f"loss at step {it}")
+    U.assert_close(a.flat.flat, flat_b(), 1e-9, "parameters after 3 Adam steps")
+    assert int(a.step_dev.item()) == 3
+
+
 WIDE = ((2, 4, 7, 8), (8, 6, 5, 3))
 @pytest.mark.parametrize("maxdim", [2, 3])
 @pytest.mark.parametrize("latent", ["mean", "max", "min", "mean&max", "max&min", "min+max", "mean&min&max", "mean+min+max",
