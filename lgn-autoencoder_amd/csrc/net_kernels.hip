@@ -165,8 +165,12 @@ __device__ __forceinline__ cx<double> canon_cplx_bwd_m(const double* g, int m) {
 //   lat_s [2][B][2Ts]  (min block, max block), lat_v [2][B][2Tv][4], idx [B][2][Ts+Tv][2] (plane, channel, min/max)
 // LDS: y [N][2Ts + 8Tv] | sv [N][C][10] | w0l [2][Ts][C] | w1l [2][Tv][C]
 // ============================================================================================
+// the y / gy block: the latent channels of every particle -- under 'mix' there is no particle axis left, one row
+__host__ __device__ inline size_t lat_y_doubles(int N, int Ts, int Tv, int pool = 0) {
+  return (size_t)(pool_is_mix(pool) ? 1 : N) * (2 * Ts + 8 * Tv);
+}
 __host__ __device__ inline size_t lat_fwd_doubles(int N, int C, int Ts, int Tv, int pool = 0) {
-  return (size_t)N * (2 * Ts + 8 * Tv) + (size_t)N * C * 10 + 2 * (size_t)(Ts + Tv) * pool_mix_in(pool, N, C);
+  return lat_y_doubles(N, Ts, Tv, pool) + (size_t)N * C * 10 + 2 * (size_t)(Ts + Tv) * pool_mix_in(pool, N, C);
 }
 // node features of the jet -> sv [N][C][10] (s re, im, v re[4], im[4]) and the two mixing weights; zero_y: y / gy starts at zero
 struct LatentStage {
@@ -174,10 +178,10 @@ struct LatentStage {
   StageRegs<4> vr, vi;
   StageRegs<1> w0, w1;
   const double *s0, *s1, *v0, *v1, *wl0, *wl1;
-  int N, C, Ts, Tv, K;                                  // K: input channels of the two weights (C; N C under 'mix')
+  int N, C, Ts, Tv, K, NY;                              // K: input channels of the two weights (C; N C under 'mix'); NY: y block
   __device__ __forceinline__ void issue(int B, int N_, int C_, int Ts_, int Tv_, const double* __restrict__ s, const double* __restrict__ v,
                                         const double* __restrict__ wl0_, const double* __restrict__ wl1_, int pool = 0) {
-    N = N_; C = C_; Ts = Ts_; Tv = Tv_; wl0 = wl0_; wl1 = wl1_; K = pool_mix_in(pool, N_, C_);
+    N = N_; C = C_; Ts = Ts_; Tv = Tv_; wl0 = wl0_; wl1 = wl1_; K = pool_mix_in(pool, N_, C_); NY = (int)lat_y_doubles(N_, Ts_, Tv_, pool);
     const size_t pl = (size_t)B * N * C, j0 = (size_t)blockIdx.x * N * C;
     s0 = s + j0; s1 = s + pl + j0; v0 = v + j0 * 4; v1 = v + (pl + j0) * 4;
     vr.issue(v0, N * C * 4); vi.issue(v1, N * C * 4);
@@ -185,11 +189,11 @@ struct LatentStage {
     w0.issue(wl0, 2 * Ts * K); w1.issue(wl1, 2 * Tv * K);
   }
   __device__ __forceinline__ void commit(double* lds, bool zero_y) const {
-    double* sv = lds + N * (2 * Ts + 8 * Tv);
+    double* sv = lds + NY;
     double* w0l = sv + N * C * 10;
     double* w1l = w0l + 2 * Ts * K;
     if (zero_y)
-      for (int e = threadIdx.x; e < N * (2 * Ts + 8 * Tv); e += BLOCK) lds[e] = 0.0;
+      for (int e = threadIdx.x; e < NY; e += BLOCK) lds[e] = 0.0;
     vr.commit(v0, N * C * 4, [&](int e, double x) { sv[(e >> 2) * 10 + 2 + (e & 3)] = x; });
     vi.commit(v1, N * C * 4, [&](int e, double x) { sv[(e >> 2) * 10 + 6 + (e & 3)] = x; });
     sr.commit(s0, N * C, [&](int e, double x) { sv[e * 10] = x; });
@@ -321,7 +325,7 @@ template <bool TO_LDS>
 __device__ __forceinline__ void enc_latent_mix_fwd_body(int B, int N, int C, int Ts, int Tv, double* lat_s, double* lat_v, double* lds,
                                                         double* lat_l) {
   const int b = blockIdx.x, TT = Ts + Tv, K = N * C;
-  const double* sv = lds + N * (2 * Ts + 8 * Tv);
+  const double* sv = lds + (2 * Ts + 8 * Tv);
   const double* w0l = sv + K * 10;
   const double* w1l = w0l + 2 * Ts * K;
   const int l8 = threadIdx.x & 7;
@@ -527,7 +531,7 @@ __device__ __forceinline__ void enc_latent_mix_bwd_body(int B, int N, int C, int
                                                         double* part, double* lds) {
   const int b = blockIdx.x, TT = Ts + Tv, K = N * C;
   double* gy = lds;                                     // [2 Ts + 8 Tv]: scalars (re, im), vectors canonical re[4] | im[4]
-  const double* sv = lds + N * (2 * Ts + 8 * Tv);
+  const double* sv = lds + (2 * Ts + 8 * Tv);
   const double* w0l = sv + K * 10;
   const double* w1l = w0l + 2 * Ts * K;
   const size_t pl = (size_t)B * K;
@@ -828,7 +832,7 @@ __global__ __launch_bounds__(BLOCK) void junction_fwd_kernel(int B, int N, int C
   extern __shared__ __align__(16) unsigned char smem_raw[];
   double* lat_lds = reinterpret_cast<double*>(smem_raw);
   // overlap: behind the encoder stage's block; else over its sv / weight regions, which are dead once y is complete
-  double* dec_lds = lat_lds + (overlap ? lat_fwd_doubles(N, CL, Ts, Tv, pool) : (size_t)N * (2 * Ts + 8 * Tv));
+  double* dec_lds = lat_lds + (overlap ? lat_fwd_doubles(N, CL, Ts, Tv, pool) : lat_y_doubles(N, Ts, Tv, pool));
   const int Tin = pool_blocks(pool) * Tv;
   STAMP(0);
   LatentStage ls;
@@ -838,11 +842,22 @@ __global__ __launch_bounds__(BLOCK) void junction_fwd_kernel(int B, int N, int C
   ls.commit(lat_lds, false);
   if (overlap) ds.commit(dec_lds);
   __syncthreads();
-  if (pool_is_mix(pool)) enc_latent_mix_fwd_body<true>(B, N, CL, Ts, Tv, lat_s, lat_v, lat_lds, dec_lds + 2 * N * Tin);
-  else enc_latent_fwd_body<true>(B, N, CL, Ts, Tv, pool, lat_s, lat_v, idx, lat_lds, dec_lds + 2 * N * Tin);
+  // 'mix' reads the node features and weights WHILE it writes the latent vectors: when the stages share LDS they go to a spare
+  // row behind both blocks first (the pooled maps write them after their last read of anything the decoder block overlays)
+  const bool spare = pool_is_mix(pool) && !overlap;
+  double* lat_l = dec_lds + 2 * N * Tin;
+  if (spare) {
+    const size_t nl = lat_fwd_doubles(N, CL, Ts, Tv, pool), nyd = lat_y_doubles(N, Ts, Tv, pool) + dec_in_fwd_doubles(N, C0, Tin);
+    lat_l = lat_lds + (nl > nyd ? nl : nyd);
+  }
+  if (pool_is_mix(pool)) enc_latent_mix_fwd_body<true>(B, N, CL, Ts, Tv, lat_s, lat_v, lat_lds, lat_l);
+  else enc_latent_fwd_body<true>(B, N, CL, Ts, Tv, pool, lat_s, lat_v, idx, lat_lds, lat_l);
   if (!overlap) {
+    if (spare) __syncthreads();                          // every thread is done with the encoder stage's operands
     ds.issue(B, N, C0, Tin, nullptr, wg1, w0, w1, false);
     ds.commit(dec_lds);
+    if (spare)
+      for (int e = threadIdx.x; e < Tin * 8; e += BLOCK) dec_lds[2 * N * Tin + e] = lat_l[e];
   }
   __syncthreads();                                       // the latent vectors of the jet are in the decoder stage's LDS block
   dec_input_fwd_body(B, N, C0, Tin, pdec, s0, v0, dec_lds);
@@ -1205,9 +1220,10 @@ int junction_fwd(int B, int N, int CL, int Ts, int Tv, int pool, const double* s
                  double* s0, double* v0, hipStream_t st) {
   LGN_CHECK_ARG(pool_valid(pool), "junction_fwd: bad latent pooling code %d", pool);
   pool = pool_canon(pool);
-  const size_t nl = lat_fwd_doubles(N, CL, Ts, Tv, pool), nd = dec_in_fwd_doubles(N, C0, pool_blocks(pool) * Tv), ny = (size_t)N * (2 * Ts + 8 * Tv);
+  const size_t nl = lat_fwd_doubles(N, CL, Ts, Tv, pool), nd = dec_in_fwd_doubles(N, C0, pool_blocks(pool) * Tv), ny = lat_y_doubles(N, Ts, Tv, pool);
   const int overlap = sizeof(double) * (nl + nd) <= 64 * 1024;
-  const size_t smem = sizeof(double) * (overlap ? nl + nd : ny + (nl - ny > nd ? nl - ny : nd));
+  const size_t smem = sizeof(double) * (overlap ? nl + nd : ny + (nl - ny > nd ? nl - ny : nd) +
+                                                            (pool_is_mix(pool) ? (size_t)pool_blocks(pool) * Tv * 8 : 0));
   LGN_LDS_LAUNCH(junction_fwd_kernel, "junction_fwd", smem);
   hipLaunchKernelGGL(junction_fwd_kernel, dim3(B), dim3(BLOCK), smem, st, B, N, CL, Ts, Tv, s, v, wl0, wl1, lat_s, lat_v, idx, C0, wg1,
                      w0, w1, pdec, s0, v0, overlap, pool);

@@ -352,6 +352,32 @@ WIDE = ((2, 4, 7, 8), (8, 6, 5, 3))
 @pytest.mark.parametrize("latent", ["mean", "max", "min", "mean&max", "max&min", "min+max", "mean&min&max", "mean+min+max",
                                     "Mean&Max&Min&Mean", "mix"])
 def test_latent_poolings_native_calls_match_per_op_path(latent, maxdim):
+    _latent_case(latent, maxdim, 12, 5)
+
+
+@pytest.mark.parametrize("N,B", [(30, 3), (150, 2), (7, 4)])
+@pytest.mark.parametrize("latent", ["mix", "mean&min&max", "min+max"])
+def test_latent_poolings_other_jet_sizes(latent, N, B):
+    """The same at jet sizes where the particle loops of the pooling kernels run partial rounds (7, 30) and where the junction's
+    two stages share their LDS (150: with 'mix' the latent weights alone are 86 KB)."""
+    if latent == "mean&min&max" and N == 150:
+        # three pooled blocks of 8 latent vectors for 150 particles: the decoder's input stage would need 165 KB of LDS -- the calls
+        # come back with an explicit error naming the limit (as for oversized maxdim-3 jets); the per-operator path remains
+        import __graft_entry__ as G
+        from lgn.step import NativeTrainStep
+        from oracle import lgn_oracle as O
+        dev = torch.device("cuda:0")
+        enc, dec = G._models(N, (2, 3, 3, 4), (4, 3, 3, 2), dev, seed=7, map_to_latent=latent)
+        p4, labels = O.synthetic_jets(B, N, seed=11, pad=True)
+        a = NativeTrainStep(enc, dec, batch_size=B, optimizer=False, use_graph=False)
+        with pytest.raises(RuntimeError, match="of LDS"):
+            a.step({"p4": p4.to(dev), "labels": labels.to(dev)})
+        torch.cuda.synchronize()
+        return
+    _latent_case(latent, 2, N, B)
+
+
+def _latent_case(latent, maxdim, N, B):
     """--map-to-latent variants (aggregate(), lgn/models/lgn_encoder.py:419-496; 'mean+max' is pinned by the reference fixture g7,
     the pooling operators one by one by test_gpu_parity.py) through the three native routes -- whole step, one call per network
     under autograd, junction kernels with the decoder taking P x tau_v latent vectors -- against the per-operator module path
@@ -360,7 +386,6 @@ def test_latent_poolings_native_calls_match_per_op_path(latent, maxdim):
     from lgn.step import NativeTrainStep, TrainStep
     from oracle import lgn_oracle as O
     dev = torch.device("cuda:0")
-    N, B = 12, 5
     chans = ((2, 3, 3, 4), (4, 3, 3, 2))
     nets = [G._models(N, chans[0], chans[1], dev, seed=7, maxdim=maxdim, map_to_latent=latent) for _ in range(3)]
     for enc, dec in nets[:2]:
