@@ -526,6 +526,8 @@ class CapturedModuleStep:
         self.batch["p4"].copy_(p4)
         for key in ("labels", "masks", "mask"):
             if key in batch:
+                if tuple(batch[key].shape) != tuple(self.batch["labels"].shape):
+                    raise ValueError(f"mask shape {tuple(batch[key].shape)} != {tuple(self.batch['labels'].shape)}")
                 self.batch["labels"].copy_(batch[key].to(torch.uint8))
                 break
         else:

@@ -1,7 +1,7 @@
 """Worker of tests/test_gpu_step.py::test_native_step_two_ranks_match_single_process: one rank of a 2-rank
 data-parallel NativeTrainStep.  Both ranks share the one GPU of the test box and talk over gloo (RCCL refuses two ranks
 on one device); the code path is the one bench.py runs under torch.distributed.run with RCCL.
-    python _dist_native_worker.py RANK WORLD PORT OUTDIR JETS_PER_RANK STEPS"""
+    python _dist_native_worker.py RANK WORLD PORT OUTDIR JETS_PER_RANK STEPS [native|captured]"""
 import os
 import sys
 
@@ -20,10 +20,11 @@ def main():
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import bench
     import __graft_entry__ as G
-    from lgn.step import NativeTrainStep
+    from lgn.step import CapturedModuleStep, NativeTrainStep
+    cls = CapturedModuleStep if (len(sys.argv) > 7 and sys.argv[7] == "captured") else NativeTrainStep
     dev = torch.device("cuda:0")
     enc, dec = G._models(bench.N_PART, bench.CH_ENC, bench.CH_DEC, dev, seed=0)
-    step = NativeTrainStep(enc, dec, batch_size=per_rank, lr=5e-4, l1_lambda=1e-8, use_graph=True)
+    step = cls(enc, dec, batch_size=per_rank, lr=5e-4, l1_lambda=1e-8, use_graph=True)
     p4, labels = bench.synthetic_jets(per_rank * world, bench.N_PART, seed=5)
     sl = slice(rank * per_rank, (rank + 1) * per_rank)
     batch = {"p4": p4[sl].to(dev), "labels": labels[sl].to(dev)}

@@ -157,7 +157,8 @@ def test_native_step_full_size_properties(name, B, N, maxdim, che, chd):
     assert torch.isfinite(a.flat.grad).all()
 
 
-def test_native_step_two_ranks_match_single_process(tmp_path):
+@pytest.mark.parametrize("which", ["native", "captured"])
+def test_native_step_two_ranks_match_single_process(tmp_path, which):
     dev = torch.device("cuda:0")
     """2 ranks x 8 jets (one all-reduce of gradients | loss terms between the two captured graphs) must reproduce the
     single-process 16-jet step: the loss is a SUM over jets, gradients are summed, the L1 term is added once."""
@@ -172,7 +173,7 @@ def test_native_step_two_ranks_match_single_process(tmp_path):
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_dist_native_worker.py")
-    procs = [subprocess.Popen([_sys.executable, worker, str(r), str(world), str(port), str(tmp_path), str(per_rank), str(steps)],
+    procs = [subprocess.Popen([_sys.executable, worker, str(r), str(world), str(port), str(tmp_path), str(per_rank), str(steps), which],
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
     outs = [p.communicate(timeout=600)[0].decode(errors="replace") for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
