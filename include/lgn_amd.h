@@ -276,6 +276,8 @@ typedef struct lgn_net_desc {
 #define LGN_NET_FUSED_MLP_FWD 8  /* LGN_AMD_FUSED_MLP=1: the CGMLP forward rides on the level forward kernel (csrc/mlp_dev.hpp; off by
                                     default: measured slower than the separate launches on MI355X) */
 #define LGN_NET_MOMENTS_V1 16    /* LGN_AMD_MOMENTS_V1=1: component-chunked moments kernels (with LGN_NET_NO_STATIC) */
+#define LGN_NET_BWD_ORDERED 64   /* LGN_AMD_BWD_ORDERED=1: the encoder level backward runs its radial-gradient GEMM per ordered pair tile
+                                    (the form before round 4's symmetric sweep; cross-check) */
 #define LGN_NET_FUSED_MLP_BWD 32 /* LGN_AMD_FUSED_MLP_BWD=1: the CGMLP backward rides on the level backward kernel (off by default) */
 
 int lgn_step_param_slots(const lgn_net_desc* d, int decoder);

@@ -29,6 +29,7 @@ constexpr int LVL_DEC_PAIRWISE = 2;    // decoder levels as O(N^2) pair sweeps i
 constexpr int LVL_LEVEL_V2 = 4;        // three-kernel level backward also for N <= 40
 constexpr int LVL_FUSED_MLP_FWD = 8;   // CGMLP forward as the tail of the level forward kernel (mlp_dev.hpp; off by default: measured slower)
 constexpr int LVL_MOMENTS_V1 = 16;     // table-driven levels: component-chunked moments kernels
+constexpr int LVL_BWD_ORDERED = 64;    // encoder level backward (N <= 40): radial-gradient GEMM per ORDERED pair tile (cross-check of the symmetric sweep)
 constexpr int LVL_FUSED_MLP_BWD = 32;  // CGMLP backward as the head of the one-kernel level backward (off by default: measured slower)
 int level_flags_from_env();
 

@@ -94,8 +94,16 @@ struct Bwd3 {
 // (amdgpu_waves_per_eu(2): two workgroups per CU is what the 77 KB of LDS are sized for; without the bound the register allocator
 // takes accumulation registers beyond 256 for the CGMLP phase -- 396 in total -- and the launch silently runs one workgroup per CU)
 // MLP: the instantiation that carries the CGMLP backward as its head -- a kernel of its own (the plain kernel pays nothing for it).
-template <int C, bool DEC, bool SEP, int NWV, bool MLP>
+// SYM (encoder, whole jet in one workgroup): the radial network sees a pair only through |p_i - p_j|^2 and the masks, so R(i, j) =
+// R(j, i) and the gradient w.r.t. the pair's radial values is the SUM of what the two directed edges i <- j and j <- i send back.
+// The wave that owns the source group J therefore adds, on its tiles with receiver group I < J, the reverse edge's share (receiver
+// j, source i: a second, shorter pass over the same lanes) before the radial-parameter GEMM, and skips that GEMM -- 12 of a tile's 17
+// matrix instructions, with the basis rows and transposes that feed it -- on its tiles with I > J, whose share the owner of I adds.
+// 36 instead of 64 radial GEMM tiles per 30-particle jet; waves own the groups in pairs (p, G - 1 - p) so that each gets the same
+// number of them.  Node gradients flow exactly as before (every ordered tile still evaluates R and its edge).
+template <int C, bool DEC, bool SEP, int NWV, bool MLP, bool SYM = false>
 __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2))) void level_bwd3_kernel(LevelBwdArgs<double> a, int gsx_off) {
+  static_assert(!SYM || (!DEC && !MLP), "the symmetric sweep is the encoder's");
   using F = Bwd3<C, DEC, NWV>;
   constexpr int BLK = F::BLK;
   using G = GA3<C>;
@@ -600,7 +608,17 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2))) v
   // the other -- 36 against 46 us at 512 jets, whatever the jets hold -- which then finishes alone.  s_setprio does move the
   // advantage (priority 3 on the younger one swaps the two times exactly), but alternating it per tile only brought the two to
   // 40.5 / 46.5 us and the kernel from 50.2 to 49.4 - 50.1 us: the makespan is the CU's total work, not the order.  Not kept.)
-  for (int rg = glo + wave; rg < ghi; rg += NWV) {
+  for (int u = 0;; ++u) {
+    int rg;
+    if constexpr (SYM) {                                   // groups in pairs (p, G - 1 - p): u = 2 k -> p, 2 k + 1 -> its partner
+      const int p = wave + NWV * (u >> 1);
+      if (p >= (ngroups + 1) >> 1) break;
+      rg = (u & 1) ? ngroups - 1 - p : p;
+      if ((u & 1) && rg == p) continue;
+    } else {
+      rg = glo + wave + NWV * u;
+      if (rg >= ghi) break;
+    }
     const int j = rg * 4 + tj;
     const bool jok = j < N;
     const int jj = jok ? j : N - 1;
@@ -630,6 +648,9 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2))) v
 
     for (int i0 = 0; i0 < N; i0 += 4) {
       if (rg == glo && i0 < 32) STAMP(16 + (i0 >> 2) * 4);
+      // SYM: 2 = receiver group below the source group (this tile also carries the reverse edges' radial gradient), 1 = diagonal
+      // tile (both directions are lanes of the tile), 0 = above (radial gradient left to the owner of the other group)
+      const int kind = SYM ? ((i0 >> 2) < rg ? 2 : ((i0 >> 2) == rg ? 1 : 0)) : 1;
       const int i = i0 + ti;
       const bool ok = jok && i < N;
       const int ii = i < N ? i : N - 1;
@@ -673,20 +694,22 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2))) v
           for (int s = 0; s < 5; ++s) R[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(wf[g][s], beta[s], R[g], 0, 0, 0);
         }
         // B-operand source of the radial GEMM: this lane's pair (row pr), columns k = 4s + cg
-        double* xb = trw + NG * 16 * TS;
+        if (kind != 0) {
+          double* xb = trw + NG * 16 * TS;
 #pragma unroll
-        for (int s = 0; s < 5; ++s) {
-          const double x2 = an * rho[s] * rho[s];
-          if (s < 4) {
-            xb[pr * TS + 4 * s + cg] = rho[s];
-            xb[16 * TS + pr * TS + 4 * s + cg] = x2;
-          } else {
-            xb[32 * TS + pr * TS + cg] = rho[s];
-            xb[32 * TS + pr * TS + 4 + cg] = x2;
+          for (int s = 0; s < 5; ++s) {
+            const double x2 = an * rho[s] * rho[s];
+            if (s < 4) {
+              xb[pr * TS + 4 * s + cg] = rho[s];
+              xb[16 * TS + pr * TS + 4 * s + cg] = x2;
+            } else {
+              xb[32 * TS + pr * TS + cg] = rho[s];
+              xb[32 * TS + pr * TS + 4 + cg] = x2;
+            }
           }
+          xb[32 * TS + pr * TS + 8 + 2 * cg] = cg == 0 ? (on ? 1.0 : 0.0) : 0.0;
+          xb[32 * TS + pr * TS + 9 + 2 * cg] = cg == 0 ? (ok ? 1.0 : 0.0) : 0.0;
         }
-        xb[32 * TS + pr * TS + 8 + 2 * cg] = cg == 0 ? (on ? 1.0 : 0.0) : 0.0;
-        xb[32 * TS + pr * TS + 9 + 2 * cg] = cg == 0 ? (ok ? 1.0 : 0.0) : 0.0;
       }
       if (rg == glo && i0 < 32) STAMP(17 + (i0 >> 2) * 4);
       const double* gi = ga + ii * G::SIZE;
@@ -718,22 +741,58 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2))) v
             cfmac(Gs[g], P2, R1);                              // sum_m gA2[m] conj(e1[m]) = conj(R1) P2
             const cx<double> Z = cmulc(gA3, R1);              // gA3 conj(e1t[m]) = Z conj(qt[m])
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-              cfmac(Gv[g][m], gA1[m], e0);
-              cfmac(ge0, gA1[m], vj[g][m]);
-            }
+            for (int m = 0; m < 4; ++m) cfmac(Gv[g][m], gA1[m], e0);
             Gv[g][0].r = __builtin_fma(Z.r, qd0, Gv[g][0].r);   Gv[g][0].i = __builtin_fma(Z.i, qd0, Gv[g][0].i);
             Gv[g][2].r = __builtin_fma(-Z.r, qd3, Gv[g][2].r);  Gv[g][2].i = __builtin_fma(-Z.i, qd3, Gv[g][2].i);
             const double aZr = qa * Z.r, aZi = qa * Z.i;
             const double bZr = qb * Z.r, bZi = qb * Z.i;
             Gv[g][1].r -= aZr + bZi;  Gv[g][1].i += bZr - aZi;   // Z (-a + ib)
             Gv[g][3].r += aZr - bZi;  Gv[g][3].i += aZi + bZr;   // Z ( a + ib)
-            // V = <v_j, q> = v0 d0 - v2 d3 + a (v3 - v1) - ib (v1 + v3)
-            cx<double> V;
-            V.r = __builtin_fma(vj[g][0].r, qd0, __builtin_fma(-vj[g][2].r, qd3, __builtin_fma(qa, dvj[g].r, qb * svj[g].i)));
-            V.i = __builtin_fma(vj[g][0].i, qd0, __builtin_fma(-vj[g][2].i, qd3, __builtin_fma(qa, dvj[g].i, -qb * svj[g].r)));
-            gR1 = cmulc(P2, sj[g]);                            // sum_m ge1[m] conj(q[m]) = conj(s_j) P2 + gA3 conj(V)
-            cfmac(gR1, gA3, V);
+            gR1 = {0, 0};
+            if (kind != 0) {                                   // (b) gradient w.r.t. the radial values of this pair
+#pragma unroll
+              for (int m = 0; m < 4; ++m) cfmac(ge0, gA1[m], vj[g][m]);
+              // V = <v_j, q> = v0 d0 - v2 d3 + a (v3 - v1) - ib (v1 + v3)
+              cx<double> V;
+              V.r = __builtin_fma(vj[g][0].r, qd0, __builtin_fma(-vj[g][2].r, qd3, __builtin_fma(qa, dvj[g].r, qb * svj[g].i)));
+              V.i = __builtin_fma(vj[g][0].i, qd0, __builtin_fma(-vj[g][2].i, qd3, __builtin_fma(qa, dvj[g].i, -qb * svj[g].r)));
+              gR1 = cmulc(P2, sj[g]);                          // sum_m ge1[m] conj(q[m]) = conj(s_j) P2 + gA3 conj(V)
+              cfmac(gR1, gA3, V);
+            }
+            if constexpr (SYM) {
+              if (kind == 2) {
+                // the reverse edge (receiver j, source i, momentum difference -q): the same two gradients with the roles swapped --
+                // the upstream gradient of j's aggregate, i's features; P2 and V change sign with q
+                const double* gj = ga + jj * G::SIZE;
+                const double* ni = nd + ii * NS + ch * 10;
+                const cx<double> si = {ni[0], ni[1]};
+                cx<double> vi[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) vi[m] = {ni[2 + m], ni[6 + m]};
+                const cx<double> hA3 = {0.5 * gj[G::A3 + 2 * ch], 0.5 * gj[G::A3 + 2 * ch + 1]};
+                const cx<double> hA4 = {gj[G::A4 + 2 * ch], gj[G::A4 + 2 * ch + 1]};
+                cx<double> he0 = cmulc(hA4, si);
+                cx<double> hA2[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                  const cx<double> hA1 = {gj[G::A1 + (ch * 4 + m) * 2], gj[G::A1 + (ch * 4 + m) * 2 + 1]};
+                  hA2[m] = {gj[G::A2 + (ch * 4 + m) * 2], gj[G::A2 + (ch * 4 + m) * 2 + 1]};
+                  cfmac(he0, hA1, vi[m]);
+                }
+                const cx<double> hd = {hA2[1].r - hA2[3].r, hA2[1].i - hA2[3].i}, hs = {hA2[1].r + hA2[3].r, hA2[1].i + hA2[3].i};
+                cx<double> Q2;                                 // sum_m hA2[m] conj(q[m]) (the reverse edge's is its negative)
+                Q2.r = __builtin_fma(hA2[0].r, qd0, __builtin_fma(hA2[2].r, qd3, __builtin_fma(qa, hd.r, -qb * hs.i)));
+                Q2.i = __builtin_fma(hA2[0].i, qd0, __builtin_fma(hA2[2].i, qd3, __builtin_fma(qa, hd.i, qb * hs.r)));
+                const cx<double> dvi = {vi[3].r - vi[1].r, vi[3].i - vi[1].i}, svi = {vi[1].r + vi[3].r, vi[1].i + vi[3].i};
+                cx<double> W;                                  // <v_i, q>
+                W.r = __builtin_fma(vi[0].r, qd0, __builtin_fma(-vi[2].r, qd3, __builtin_fma(qa, dvi.r, qb * svi.i)));
+                W.i = __builtin_fma(vi[0].i, qd0, __builtin_fma(-vi[2].i, qd3, __builtin_fma(qa, dvi.i, -qb * svi.r)));
+                cx<double> hR1 = cmulc(Q2, si);
+                cfmac(hR1, hA3, W);
+                ge0.r += he0.r;  ge0.i += he0.i;
+                gR1.r -= hR1.r;  gR1.i -= hR1.i;
+              }
+            }
           } else {
             cx<double> e1[4], e1t[4];
 #pragma unroll
@@ -760,7 +819,7 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2))) v
         if (DEC) {
           dB0[g] += G0r + G0i;                              // R0 = b0 (1+i): d b0 = Re G_R0 + Im G_R0
           dB1[g] += G1r + G1i;
-        } else {
+        } else if (kind != 0) {
           double* ta = trw + g * 16 * TS;                   // [pair][r' = cg + 4q]
           ta[pr * TS + cg] = G0r;
           ta[pr * TS + 4 + cg] = G0i;
@@ -769,7 +828,7 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2))) v
         }
       }
       if (rg == glo && i0 < 32) STAMP(18 + (i0 >> 2) * 4);
-      if (!DEC) {
+      if (!DEC && kind != 0) {
         wave_sync();
         const double* xb = trw + NG * 16 * TS;
 #pragma unroll
@@ -1009,6 +1068,9 @@ static int launch_bwd3_w(const LevelBwdArgs<double>& a, int split, hipStream_t s
   auto kern = level_bwd3_kernel<C, DEC, SEP, NWV, false>;
   if constexpr (C <= 4 && (!DEC || SEP) && NWV == 4) {
     if (a.mlp.wb) kern = level_bwd3_kernel<C, DEC, SEP, NWV, true>;
+  }
+  if constexpr (!DEC) {       // whole jets per workgroup: the sweep that uses R(i, j) = R(j, i) (LVL_BWD_ORDERED: the plain one)
+    if (!a.mlp.wb && split == 1 && !(a.flags & LVL_BWD_ORDERED)) kern = level_bwd3_kernel<C, DEC, SEP, NWV, false, true>;
   }
   if (smem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   hipLaunchKernelGGL(kern, dim3(a.B, split), dim3(64 * NWV), smem, stream, a, gsx_off);

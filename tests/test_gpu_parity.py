@@ -53,6 +53,19 @@ def test_level_fwd_bwd(dev, O, decoder, C, CO, N, B):
     _level_case(dev, O, decoder, C, CO, N, B)
 
 
+@pytest.mark.parametrize("ordered", [False, True])
+@pytest.mark.parametrize("C,CO,N,B", [(4, 4, 30, 260), (3, 4, 30, 260), (3, 3, 33, 260), (2, 5, 40, 257), (4, 3, 7, 300), (1, 2, 1, 513),
+                                      (5, 6, 26, 260), (8, 8, 13, 260)])
+def test_level_backward_whole_jet_workgroups(dev, O, monkeypatch, ordered, C, CO, N, B):
+    """Batches of more than 256 jets give every jet ONE workgroup, and the encoder's one-kernel backward then runs its
+    radial-parameter GEMM once per UNORDERED pair tile (R(i, j) = R(j, i): the owner of the higher group adds both directed edges'
+    gradients; level_bwd3.hip, SYM) -- 8, 9 and 10 groups of 4 particles (even / odd counts, partly empty last groups), 1 and 2
+    groups, a single particle.  LGN_AMD_BWD_ORDERED=1: the per-ordered-tile form on the same launch shape."""
+    if ordered:
+        monkeypatch.setenv("LGN_AMD_BWD_ORDERED", "1")
+    _level_case(dev, O, False, C, CO, N, B)
+
+
 @pytest.mark.parametrize("decoder", [False, True])
 @pytest.mark.parametrize("C,CO,N,B", [(4, 4, 30, 2), (3, 4, 30, 3), (4, 3, 7, 1), (2, 5, 33, 2), (4, 4, 48, 2), (3, 4, 70, 1)])
 def test_level_three_kernel_backward_small_jets(dev, O, monkeypatch, decoder, C, CO, N, B):

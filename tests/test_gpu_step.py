@@ -69,7 +69,7 @@ def test_native_step_matches_reference_golden(name, use_graph):
 
 
 @pytest.mark.parametrize("flags", [("LGN_AMD_FUSED_MLP",), ("LGN_AMD_FUSED_MLP", "LGN_AMD_FUSED_MLP_BWD"), ("LGN_AMD_FUSED_MLP_BWD",),
-                                   ("LGN_AMD_LEVEL_V2",), ("LGN_AMD_DEC_PAIRWISE",)])
+                                   ("LGN_AMD_LEVEL_V2",), ("LGN_AMD_DEC_PAIRWISE",), ("LGN_AMD_BWD_ORDERED",)])
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_native_step_maxdim2_alternative_kernels(flags, use_graph, monkeypatch):
     """The kernel-selecting switches of the maxdim = 2 step, frozen into the descriptor when the step is created (lgn/_native.py:
