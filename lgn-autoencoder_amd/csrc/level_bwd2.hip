@@ -488,8 +488,9 @@ __global__ __launch_bounds__(2 * BLOCK) void level_bwd_rad2_kernel(LevelBwdArgs<
 // and adds its share into the node gradient (which already holds the direct + power part from level_bwd_mix_kernel), next chunk.
 // The source particle's own features come from global memory (10 reals per lane and row group); the radial sums live in the
 // matrix-core accumulators across all chunks and leave as ONE partial row per jet, like level_bwd_rad2's.
-template <int C, int NWV>
+template <int C, int NWV, bool SYM>
 __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2))) void level_bwd_sweep_enc_kernel(LevelBwdArgs<double> a, int ichunk) {
+  constexpr bool sym = SYM;
   constexpr int NG = (C + 3) / 4;
   using G = GA2<C>;
   constexpr int TS = 18, BLK = 64 * NWV;
@@ -499,9 +500,11 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2))) v
 
   extern __shared__ __align__(16) unsigned char smem_raw[];
   double* ga = reinterpret_cast<double*>(smem_raw);          // ichunk * 20C   gradient of the aggregate, receivers of the current chunk
-  double* pj = ga + (size_t)ichunk * G::SIZE;                // N * 4
+  double* xn = ga + (size_t)ichunk * G::SIZE;                // ichunk * 10C   (sym) their node features [i][c][s2 | v8]
+  double* pj = xn + (sym ? (size_t)ichunk * 10 * C : 0);     // N * 4
   double* tr = pj + N * 4;                                   // NWV * TRW
-  uint8_t* mk = reinterpret_cast<uint8_t*>(tr + NWV * TRW);  // N
+  double* gaj = tr + NWV * TRW;                              // (sym) NWV * 4 * 20C: g_ag rows of each wave's own 4 particles
+  uint8_t* mk = reinterpret_cast<uint8_t*>(gaj + (sym ? NWV * 4 * G::SIZE : 0));  // N
 
   {
     const double* p0 = a.p + (size_t)b * N * 4;
@@ -511,6 +514,10 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2))) v
   const int pr = lane & 15, cg = lane >> 4;
   const int tj = pr >> 2, ti = pr & 3;                      // which of the wave's 4 source particles j / slot in the i tile
   double ak[5], bk[5], ck2[5], wf[NG][5], bias[NG][4];
+  // sym: the 15 bell constants of the lane's five basis functions live in LDS (one row per lane group, read per tile) -- with them
+  // in registers the second pass of the tiles below the diagonal spills into the hot loop
+  __shared__ double rkt[4][16];
+  const double* rkl = rkt[cg];
 #pragma unroll
   for (int s = 0; s < 5; ++s) {
     const int k = 4 * s + cg;
@@ -518,6 +525,11 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2))) v
     bk[s] = a.rb[k];
     const double c = a.rc[k];
     ck2[s] = c * c;
+    if (sym && pr == 0) {
+      rkt[cg][s] = ak[s];
+      rkt[cg][5 + s] = bk[s];
+      rkt[cg][10 + s] = ck2[s];
+    }
   }
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
@@ -541,6 +553,28 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2))) v
     for (int t = 0; t < 3; ++t) T[g][t] = v4d{0, 0, 0, 0};
   const size_t pls = (size_t)B * N * C;
   const int ngroups = (N + 3) >> 2;
+  // Which source groups this wave owns.  sym (R(i, j) = R(j, i): the radial-parameter GEMM runs once per UNORDERED tile, as in
+  // level_bwd3.hip): a group's cost grows with its index -- tiles with receiver group I < J carry both directions' radial
+  // gradient, tiles with I > J none -- so the groups are dealt by longest-processing-time-first on that cost model (every wave runs
+  // the same few hundred scalar steps); else round robin.
+  unsigned long long mine = 0;
+  if (sym) {
+    int load[NWV];
+#pragma unroll
+    for (int w = 0; w < NWV; ++w) load[w] = 0;
+    for (int g = ngroups - 1; g >= 0; --g) {
+      int best = 0, bestv = load[0];
+#pragma unroll
+      for (int w = 1; w < NWV; ++w)
+        if (load[w] < bestv) { bestv = load[w]; best = w; }
+#pragma unroll
+      for (int w = 0; w < NWV; ++w)
+        if (w == best) load[w] += 27 * g + 11 * (ngroups - 1 - g) + 23;      // ~cycles / 100 of a full / light / diagonal tile
+      if (best == wave) mine |= 1ull << g;
+    }
+  } else {
+    for (int g = wave; g < ngroups; g += NWV) mine |= 1ull << g;
+  }
   STAMP(0);
 
   for (int ilo = 0; ilo < N; ilo += ichunk) {
@@ -550,12 +584,31 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2))) v
     {
       const double* src = a.g_ag + ((size_t)b * N + ilo) * G::SIZE;
       for (int e = tid; e < (ihi - ilo) * G::SIZE; e += BLK) ga[e] = src[e];
+      if (sym) {
+        for (int e = tid; e < (ihi - ilo) * C; e += BLK) {
+          const size_t ge = ((size_t)b * N + ilo) * C + e;
+          double* x = xn + (size_t)e * 10;
+          x[0] = a.s_in[ge];
+          x[1] = a.s_in[pls + ge];
+#pragma unroll
+          for (int m = 0; m < 4; ++m) { x[2 + m] = a.v_in[ge * 4 + m]; x[6 + m] = a.v_in[pls * 4 + ge * 4 + m]; }
+        }
+      }
     }
     __syncthreads();
     STAMP(ilo ? 11 : 2);
-    for (int rg = wave; rg < ngroups; rg += NWV) {
+    for (int rg = 0; rg < ngroups; ++rg) {
+      if (!((mine >> rg) & 1)) continue;
       if (rg == 0) STAMP(ilo ? 12 : 3);
       if (rg == NWV) STAMP(ilo ? 15 : 6);
+      double* gajw = gaj + wave * 4 * G::SIZE;
+      if (sym) {                                             // the upstream gradient of the own particles' aggregates (reverse edges)
+        for (int e = lane; e < 4 * G::SIZE; e += 64) {
+          const int r = e / G::SIZE, jr = min(rg * 4 + r, N - 1);
+          gajw[e] = a.g_ag[((size_t)b * N + jr) * G::SIZE + (e - r * G::SIZE)];
+        }
+        wave_sync();
+      }
       const int j = rg * 4 + tj;
       const bool jok = j < N;
       const int jj = jok ? j : N - 1;
@@ -581,6 +634,9 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2))) v
 
       if (rg == 0) STAMP(ilo ? 13 : 4);
       for (int i0 = ilo; i0 < ihi; i0 += 4) {
+        // 2: receiver group below the source group (the tile also carries the reverse edges' radial gradient), 1: diagonal tile,
+        // 0: above (the owner of the other group adds this tile's radial gradient to its own)
+        const int kind = sym ? ((i0 >> 2) < rg ? 2 : ((i0 >> 2) == rg ? 1 : 0)) : 1;
         const int i = i0 + ti;
         const bool ok = jok && i < ihi;
         const int ii = i < ihi ? i : ihi - 1;
@@ -600,8 +656,8 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2))) v
         if (on) {                                            // (EXEC-masked block: no per-value selects)
 #pragma unroll
           for (int s = 0; s < 5; ++s) {
-            rho[s] = fast_rcp((1.0 + ck2[s] * an) + 1e-16);
-            beta[s] = __builtin_fma(bk[s], rho[s], ak[s]);
+            rho[s] = fast_rcp((1.0 + (sym ? rkl[10 + s] : ck2[s]) * an) + 1e-16);
+            beta[s] = __builtin_fma(sym ? rkl[5 + s] : bk[s], rho[s], sym ? rkl[s] : ak[s]);
           }
         }
 #pragma unroll
@@ -612,19 +668,21 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2))) v
         }
         // B-operand source of the radial GEMM: this lane's pair (row pr), columns k = 4s + cg
         double* xb = trw + NG * 16 * TS;
+        if (kind != 0) {
 #pragma unroll
-        for (int s = 0; s < 5; ++s) {
-          const double x2 = an * rho[s] * rho[s];
-          if (s < 4) {
-            xb[pr * TS + 4 * s + cg] = rho[s];
-            xb[16 * TS + pr * TS + 4 * s + cg] = x2;
-          } else {
-            xb[32 * TS + pr * TS + cg] = rho[s];
-            xb[32 * TS + pr * TS + 4 + cg] = x2;
+          for (int s = 0; s < 5; ++s) {
+            const double x2 = an * rho[s] * rho[s];
+            if (s < 4) {
+              xb[pr * TS + 4 * s + cg] = rho[s];
+              xb[16 * TS + pr * TS + 4 * s + cg] = x2;
+            } else {
+              xb[32 * TS + pr * TS + cg] = rho[s];
+              xb[32 * TS + pr * TS + 4 + cg] = x2;
+            }
           }
+          xb[32 * TS + pr * TS + 8 + 2 * cg] = cg == 0 ? (on ? 1.0 : 0.0) : 0.0;
+          xb[32 * TS + pr * TS + 9 + 2 * cg] = cg == 0 ? (ok ? 1.0 : 0.0) : 0.0;
         }
-        xb[32 * TS + pr * TS + 8 + 2 * cg] = cg == 0 ? (on ? 1.0 : 0.0) : 0.0;
-        xb[32 * TS + pr * TS + 9 + 2 * cg] = cg == 0 ? (ok ? 1.0 : 0.0) : 0.0;
 
         const double* gi = ga + (size_t)(ii - ilo) * G::SIZE;
 #pragma unroll
@@ -653,44 +711,81 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2))) v
             cfmac(Gs[g], P2, R1);
             const cx<double> Z = cmulc(gA3, R1);
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-              cfmac(Gv[g][m], gA1[m], e0);
-              cfmac(ge0, gA1[m], vj[g][m]);
-            }
+            for (int m = 0; m < 4; ++m) cfmac(Gv[g][m], gA1[m], e0);
             Gv[g][0].r = __builtin_fma(Z.r, qd0, Gv[g][0].r);   Gv[g][0].i = __builtin_fma(Z.i, qd0, Gv[g][0].i);
             Gv[g][2].r = __builtin_fma(-Z.r, qd3, Gv[g][2].r);  Gv[g][2].i = __builtin_fma(-Z.i, qd3, Gv[g][2].i);
             const double aZr = qa * Z.r, aZi = qa * Z.i, bZr = qb * Z.r, bZi = qb * Z.i;
             Gv[g][1].r -= aZr + bZi;  Gv[g][1].i += bZr - aZi;   // Z (-a + ib)
             Gv[g][3].r += aZr - bZi;  Gv[g][3].i += aZi + bZr;   // Z ( a + ib)
-            cx<double> V;
-            V.r = __builtin_fma(vj[g][0].r, qd0, __builtin_fma(-vj[g][2].r, qd3, __builtin_fma(qa, dvj[g].r, qb * svj[g].i)));
-            V.i = __builtin_fma(vj[g][0].i, qd0, __builtin_fma(-vj[g][2].i, qd3, __builtin_fma(qa, dvj[g].i, -qb * svj[g].r)));
-            cx<double> gR1 = cmulc(P2, sj[g]);
-            cfmac(gR1, gA3, V);
+            cx<double> gR1 = {0, 0};
+            if (kind != 0) {                                   // gradient w.r.t. the radial values of this pair
+#pragma unroll
+              for (int m = 0; m < 4; ++m) cfmac(ge0, gA1[m], vj[g][m]);
+              cx<double> V;
+              V.r = __builtin_fma(vj[g][0].r, qd0, __builtin_fma(-vj[g][2].r, qd3, __builtin_fma(qa, dvj[g].r, qb * svj[g].i)));
+              V.i = __builtin_fma(vj[g][0].i, qd0, __builtin_fma(-vj[g][2].i, qd3, __builtin_fma(qa, dvj[g].i, -qb * svj[g].r)));
+              gR1 = cmulc(P2, sj[g]);
+              cfmac(gR1, gA3, V);
+            }
+            if (kind == 2) {
+              // the reverse edge (receiver j, source i, momentum difference -q): level_bwd3.hip, SYM
+              const double* gj = gajw + tj * G::SIZE;
+              const double* ni = xn + ((size_t)(ii - ilo) * C + ch) * 10;
+              const cx<double> si = {ni[0], ni[1]};
+              cx<double> vi[4];
+#pragma unroll
+              for (int m = 0; m < 4; ++m) vi[m] = {ni[2 + m], ni[6 + m]};
+              const cx<double> hA3 = {0.5 * gj[G::A3 + 2 * ch], 0.5 * gj[G::A3 + 2 * ch + 1]};
+              const cx<double> hA4 = {gj[G::A4 + 2 * ch], gj[G::A4 + 2 * ch + 1]};
+              cx<double> he0 = cmulc(hA4, si);
+              cx<double> hA2[4];
+#pragma unroll
+              for (int m = 0; m < 4; ++m) {
+                const cx<double> hA1 = {gj[G::A1 + (ch * 4 + m) * 2], gj[G::A1 + (ch * 4 + m) * 2 + 1]};
+                hA2[m] = {gj[G::A2 + (ch * 4 + m) * 2], gj[G::A2 + (ch * 4 + m) * 2 + 1]};
+                cfmac(he0, hA1, vi[m]);
+              }
+              const cx<double> hd = {hA2[1].r - hA2[3].r, hA2[1].i - hA2[3].i}, hs = {hA2[1].r + hA2[3].r, hA2[1].i + hA2[3].i};
+              cx<double> Q2;
+              Q2.r = __builtin_fma(hA2[0].r, qd0, __builtin_fma(hA2[2].r, qd3, __builtin_fma(qa, hd.r, -qb * hs.i)));
+              Q2.i = __builtin_fma(hA2[0].i, qd0, __builtin_fma(hA2[2].i, qd3, __builtin_fma(qa, hd.i, qb * hs.r)));
+              const cx<double> dvi = {vi[3].r - vi[1].r, vi[3].i - vi[1].i}, svi = {vi[1].r + vi[3].r, vi[1].i + vi[3].i};
+              cx<double> W;
+              W.r = __builtin_fma(vi[0].r, qd0, __builtin_fma(-vi[2].r, qd3, __builtin_fma(qa, dvi.r, qb * svi.i)));
+              W.i = __builtin_fma(vi[0].i, qd0, __builtin_fma(-vi[2].i, qd3, __builtin_fma(qa, dvi.i, -qb * svi.r)));
+              cx<double> hR1 = cmulc(Q2, si);
+              cfmac(hR1, hA3, W);
+              ge0.r += he0.r;  ge0.i += he0.i;
+              gR1.r -= hR1.r;  gR1.i -= hR1.i;
+            }
             G0r = ge0.r + ge0.i;  G0i = ge0.i - ge0.r;        // e0 = R0 (1+i)  ->  G_R0 = G_e0 (1-i)
             G1r = gR1.r;  G1i = gR1.i;
           }
-          double* ta = trw + g * 16 * TS;                     // [pair][r' = cg + 4q]
-          ta[pr * TS + cg] = G0r;
-          ta[pr * TS + 4 + cg] = G0i;
-          ta[pr * TS + 8 + cg] = G1r;
-          ta[pr * TS + 12 + cg] = G1i;
-        }
-        wave_sync();
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const int prow = 4 * s + cg;
-          double bv[3];
-#pragma unroll
-          for (int t = 0; t < 3; ++t) bv[t] = xb[t * 16 * TS + prow * TS + pr];
-#pragma unroll
-          for (int g = 0; g < NG; ++g) {
-            const double av = trw[g * 16 * TS + prow * TS + pr];
-#pragma unroll
-            for (int t = 0; t < 3; ++t) T[g][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[t], T[g][t], 0, 0, 0);
+          if (kind != 0) {
+            double* ta = trw + g * 16 * TS;                   // [pair][r' = cg + 4q]
+            ta[pr * TS + cg] = G0r;
+            ta[pr * TS + 4 + cg] = G0i;
+            ta[pr * TS + 8 + cg] = G1r;
+            ta[pr * TS + 12 + cg] = G1i;
           }
         }
-        wave_sync();
+        if (kind != 0) {
+          wave_sync();
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const int prow = 4 * s + cg;
+            double bv[3];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) bv[t] = xb[t * 16 * TS + prow * TS + pr];
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+              const double av = trw[g * 16 * TS + prow * TS + pr];
+#pragma unroll
+              for (int t = 0; t < 3; ++t) T[g][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[t], T[g][t], 0, 0, 0);
+            }
+          }
+          wave_sync();
+        }
       }
 
       if (rg == 0) STAMP(ilo ? 14 : 5);
@@ -781,7 +876,12 @@ template <int C, int NWV>
 static int launch_sweep_enc_w(const LevelBwdArgs<double>& a, hipStream_t stream) {
   constexpr int NG = (C + 3) / 4;
   constexpr size_t TRW = (NG + 3) * 16 * 18 > 64 * NG * 12 ? (NG + 3) * 16 * 18 : 64 * NG * 12;
-  const size_t fixed = sizeof(double) * ((size_t)a.N * 4 + NWV * TRW) + a.N + 16, row = sizeof(double) * 20 * C;
+  // sym (level_bwd3.hip: R(i, j) = R(j, i), the radial-parameter GEMM once per unordered tile): the chunk also holds the receivers'
+  // node features, every wave the g_ag rows of its own four particles
+  // (C <= 4: with two lane groups of channels the second pass does not fit the register file beside the first)
+  const bool sym = !(a.flags & LVL_BWD_ORDERED) && C <= 4;
+  const size_t fixed = sizeof(double) * ((size_t)a.N * 4 + NWV * TRW + (sym ? NWV * 4 * 20 * C : 0)) + a.N + 16,
+               row = sizeof(double) * (sym ? 30 : 20) * C;
   // receivers per chunk: the whole jet when it fits, else the largest multiple of 4 that does; chunks of equal size
   // (four waves: half the LDS, so that two workgroups share a CU -- unless not even four receivers fit then)
   const size_t budget = (NWV == 4 && fixed + 4 * row <= 79 * 1024) ? 79 * 1024 : 160 * 1024;
@@ -792,7 +892,10 @@ static int launch_sweep_enc_w(const LevelBwdArgs<double>& a, hipStream_t stream)
     ichunk = (((a.N + nchunks - 1) / nchunks) + 3) & ~3;
   }
   const size_t smem = fixed + (size_t)ichunk * row;
-  auto kern = level_bwd_sweep_enc_kernel<C, NWV>;
+  auto kern = level_bwd_sweep_enc_kernel<C, NWV, false>;
+  if constexpr (C <= 4) {
+    if (sym) kern = level_bwd_sweep_enc_kernel<C, NWV, true>;
+  }
   if (smem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   hipLaunchKernelGGL(kern, dim3(a.B), dim3(64 * NWV), smem, stream, a, ichunk);
   LGN_CHECK_LAUNCH();

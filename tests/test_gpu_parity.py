@@ -66,6 +66,16 @@ def test_level_backward_whole_jet_workgroups(dev, O, monkeypatch, ordered, C, CO
     _level_case(dev, O, False, C, CO, N, B)
 
 
+@pytest.mark.parametrize("C,CO,N,B", [(4, 4, 150, 1), (3, 3, 150, 2), (4, 4, 48, 2), (3, 4, 50, 1), (4, 3, 41, 2), (2, 2, 63, 1), (4, 4, 70, 1),
+                                      (5, 6, 100, 1)])
+def test_level_backward_large_jets_ordered_pair_tiles(dev, O, monkeypatch, C, CO, N, B):
+    """N > 40: the one-sweep backward with LGN_AMD_BWD_ORDERED=1 -- the radial-parameter GEMM per ordered pair tile, round-robin
+    group ownership -- beside the default symmetric sweep that test_level_fwd_bwd runs (unordered tiles, groups dealt by cost;
+    C > 4 always takes the ordered form)."""
+    monkeypatch.setenv("LGN_AMD_BWD_ORDERED", "1")
+    _level_case(dev, O, False, C, CO, N, B)
+
+
 @pytest.mark.parametrize("decoder", [False, True])
 @pytest.mark.parametrize("C,CO,N,B", [(4, 4, 30, 2), (3, 4, 30, 3), (4, 3, 7, 1), (2, 5, 33, 2), (4, 4, 48, 2), (3, 4, 70, 1)])
 def test_level_three_kernel_backward_small_jets(dev, O, monkeypatch, decoder, C, CO, N, B):
