@@ -879,7 +879,7 @@ static int launch_sweep_enc_w(const LevelBwdArgs<double>& a, hipStream_t stream)
   // sym (level_bwd3.hip: R(i, j) = R(j, i), the radial-parameter GEMM once per unordered tile): the chunk also holds the receivers'
   // node features, every wave the g_ag rows of its own four particles
   // (C <= 4: with two lane groups of channels the second pass does not fit the register file beside the first)
-  const bool sym = !(a.flags & LVL_BWD_ORDERED) && C <= 4;
+  const bool sym = !(a.flags & LVL_BWD_ORDERED) && C <= 4 && (a.N + 3) / 4 <= 64;     // (group ownership is a 64-bit mask)
   const size_t fixed = sizeof(double) * ((size_t)a.N * 4 + NWV * TRW + (sym ? NWV * 4 * 20 * C : 0)) + a.N + 16,
                row = sizeof(double) * (sym ? 30 : 20) * C;
   // receivers per chunk: the whole jet when it fits, else the largest multiple of 4 that does; chunks of equal size
