@@ -180,7 +180,9 @@ def time_dominant_kernel(enc, batch, reps=20):
     us_bwd = _events_us(bwd, reps, mode)
     fwd_flops = B * level_fwd_flops(N, Cc, CO, False)
     single = N <= 40
-    return {"kernel": f"level_bwd3_kernel<{Cc}, false, false, 4, false>" if single else "level_bwd (level_bwd_mix + level_bwd_sweep_enc kernels)",
+    # (batches of more than 256 jets: one workgroup per jet, the symmetric radial-gradient sweep -- the last template argument)
+    sym = "true" if (B > 256 and os.environ.get("LGN_AMD_BWD_ORDERED") != "1") else "false"
+    return {"kernel": f"level_bwd3_kernel<{Cc}, false, false, 4, false, {sym}>" if single else "level_bwd (level_bwd_mix + level_bwd_sweep_enc kernels)",
             "level": lvl, "us": us_bwd, "flops": 2 * fwd_flops,          # backward = 2 x forward
             "timing": mode.get("timing"),
             "forward": {"kernel": f"level_fwd2_kernel<{Cc}, false, false, false>", "us": us_fwd, "flops": fwd_flops}}
