@@ -884,7 +884,8 @@ static int launch_sweep_enc_w(const LevelBwdArgs<double>& a, hipStream_t stream)
                row = sizeof(double) * (sym ? 30 : 20) * C;
   // receivers per chunk: the whole jet when it fits, else the largest multiple of 4 that does; chunks of equal size
   // (four waves: half the LDS, so that two workgroups share a CU -- unless not even four receivers fit then)
-  const size_t budget = (NWV == 4 && fixed + 4 * row <= 79 * 1024) ? 79 * 1024 : 160 * 1024;
+  // (1 KB below the CU's 160 KB / half of it: the kernel also has a few hundred bytes of static LDS)
+  const size_t budget = (NWV == 4 && fixed + 4 * row <= 79 * 1024) ? 79 * 1024 : 159 * 1024;
   LGN_CHECK_ARG(fixed + 4 * row <= budget, "level_bwd_sweep: N=%d C=%d does not fit the LDS", a.N, a.C);
   int ichunk = (a.N + 3) & ~3;
   if (fixed + ichunk * row > budget) {
