@@ -721,12 +721,47 @@ __global__ __launch_bounds__(BLOCK) void moments_rad_reduce2_kernel(GenArgs a, c
   for (int g = 0; g < NG; ++g)
 #pragma unroll
     for (int t = 0; t < 3; ++t) T[g][t] = v4d{0, 0, 0, 0};
-  const int npairs = N * N;
-  for (int p0 = wave * 4; p0 < npairs; p0 += 16) {             // 4 pairs per MFMA step, waves interleaved
-    const int p = p0 + kq;                                     // this lane's pair for the B operand and the A operand
-    const bool ok = p < npairs;
-    const int pp = ok ? p : npairs - 1;
-    const int i = pp / N, j = pp - i * N;
+  // The basis functions see a pair only through |p_i - p_j|^2 and the two masks: rho(i, j) = rho(j, i), so the sum over ORDERED pairs
+  // of G(i, j) rho(i, j) is the sum over UNORDERED pairs {i <= j} of (G(i, j) + G(j, i)) rho -- half the basis evaluations and matrix
+  // instructions (level_bwd3.hip uses the same symmetry inside its sweep).  The pair gradients of the next step are requested before
+  // this step's matrix instructions (the loop is a chain of global round trips otherwise).
+  const int npairs = N * N, nuno = N * (N + 1) / 2;
+  auto decode = [&](int u, int& i, int& j, bool& ok) {         // u -> (i <= j), row-major over the lower triangle of (j, i)
+    ok = u < nuno;
+    const int uu = ok ? u : nuno - 1;
+    int r = (int)((sqrt(8.0 * (double)uu + 1.0) - 1.0) * 0.5);
+    while ((r + 1) * (r + 2) / 2 <= uu) ++r;
+    while (r * (r + 1) / 2 > uu) --r;
+    j = r;
+    i = uu - r * (r + 1) / 2;
+  };
+  auto fetch = [&](int i, int j, bool ok, double (&av)[NG]) {
+    const double* g1 = Gbuf + ((size_t)b * npairs + (size_t)i * N + j) * C * 4;
+    const double* g2 = Gbuf + ((size_t)b * npairs + (size_t)j * N + i) * C * 4;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const int rr = lane & 15, quant = rr >> 2, ch = 4 * g + (rr & 3);
+      const bool live = ok && ch < C;
+      const double x1 = live ? g1[ch * 4 + quant] : 0.0;
+      const double x2 = (live && i != j) ? g2[ch * 4 + quant] : 0.0;
+      av[g] = x1 + x2;
+    }
+  };
+  int ci, cj;
+  bool cok;
+  double cav[NG];
+  decode(wave * 4 + kq, ci, cj, cok);
+  fetch(ci, cj, cok, cav);
+  for (int u0 = wave * 4; u0 < nuno; u0 += 16) {               // 4 pairs per MFMA step, waves interleaved
+    const int i = ci, j = cj;
+    const bool ok = cok;
+    double av[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) av[g] = cav[g];
+    if (u0 + 16 < nuno) {                                      // next step's operands
+      decode(u0 + 16 + kq, ci, cj, cok);
+      fetch(ci, cj, cok, cav);
+    }
     const double* pi = pj + i * 4;
     const double* pq = pj + j * 4;
     const double d0 = pi[0] - pq[0], d1 = pi[1] - pq[1], d2 = pi[2] - pq[2], d3 = pi[3] - pq[3];
@@ -741,14 +776,10 @@ __global__ __launch_bounds__(BLOCK) void moments_rad_reduce2_kernel(GenArgs a, c
     bv[0] = rho0;
     bv[1] = an * rho0 * rho0;
     bv[2] = col < 4 ? rho2 : (col < 8 ? an * rho2 * rho2 : (col == 8 ? (on ? 1.0 : 0.0) : (col == 9 ? (ok ? 1.0 : 0.0) : 0.0)));
-    const double* gp = Gbuf + ((size_t)b * npairs + pp) * C * 4;
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
-      const int rr = lane & 15, quant = rr >> 2, ch = 4 * g + (rr & 3);
-      const double av = (ok && ch < C) ? gp[ch * 4 + quant] : 0.0;
+    for (int g = 0; g < NG; ++g)
 #pragma unroll
-      for (int t = 0; t < 3; ++t) T[g][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[t], T[g][t], 0, 0, 0);
-    }
+      for (int t = 0; t < 3; ++t) T[g][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[g], bv[t], T[g][t], 0, 0, 0);
   }
   // D fragment: lane holds rows (lane >> 4) + 4 * reg = channel cc = lane >> 4 of group g, quantity reg; column lane & 15
   {
