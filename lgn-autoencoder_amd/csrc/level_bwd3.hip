@@ -1069,7 +1069,8 @@ static int launch_bwd3_w(const LevelBwdArgs<double>& a, int split, hipStream_t s
   if constexpr (C <= 4 && (!DEC || SEP) && NWV == 4) {
     if (a.mlp.wb) kern = level_bwd3_kernel<C, DEC, SEP, NWV, true>;
   }
-  if constexpr (!DEC) {       // whole jets per workgroup: the sweep that uses R(i, j) = R(j, i) (LVL_BWD_ORDERED: the plain one)
+  if constexpr (!DEC && C <= 4) {       // whole jets per workgroup: the sweep that uses R(i, j) = R(j, i) (LVL_BWD_ORDERED: the plain one;
+                                        // C > 4: two lane groups of channels, the second pass would double the spills)
     if (!a.mlp.wb && split == 1 && !(a.flags & LVL_BWD_ORDERED)) kern = level_bwd3_kernel<C, DEC, SEP, NWV, false, true>;
   }
   if (smem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
