@@ -323,6 +323,37 @@ def test_captured_module_step_jet_features_matches_reference_golden(use_graph):
     assert step.launches_per_step == (1 if use_graph else None)
 
 
+@pytest.mark.parametrize("case", ["sum", "mixed_maxdim"])
+def test_native_train_step_chooser_covers_module_only_configurations(case):
+    """native_train_step falls back to CapturedModuleStep for what the whole-step call refuses -- the 'sum' latent map (an extra axis
+    in the reference), an encoder with maxdim 3 feeding a decoder with maxdim 2 -- and the replayed graph reproduces the eager
+    module-API step (TrainStep: per-network calls under autograd) on the same weights."""
+    import __graft_entry__ as G
+    from lgn.step import CapturedModuleStep, TrainStep, native_train_step
+    from oracle import lgn_oracle as O
+    dev = torch.device("cuda:0")
+    N, B, chans = 12, 4, ((2, 3, 3, 4), (4, 3, 3, 2))
+
+    def build():
+        if case == "sum":
+            return G._models(N, chans[0], chans[1], dev, seed=7, map_to_latent="sum")
+        enc, _ = G._models(N, chans[0], chans[1], dev, seed=7, maxdim=3)
+        _, dec = G._models(N, chans[0], chans[1], dev, seed=7, maxdim=2)
+        return enc, dec
+
+    p4, labels = O.synthetic_jets(B, N, seed=11, pad=True)
+    batch = {"p4": p4.to(dev), "labels": labels.to(dev)}
+    a = native_train_step(*build(), B, optimizer=False, use_graph=True)
+    assert isinstance(a, CapturedModuleStep)
+    b = TrainStep(*build(), optimizer=False)
+    for _ in range(2):
+        la, ra = a.step(batch)
+    lb, rb = b.forward_backward(batch)
+    U.assert_close(la, lb, 1e-11, "loss")
+    U.assert_close(ra, rb, 1e-11, "recon")
+    U.assert_close(a.flat.grad, b.flat.grad, 1e-9, "flat gradient")
+
+
 @pytest.mark.parametrize("jet_loss", [False, True])
 def test_captured_module_step_trains_like_the_native_step(jet_loss):
     """Three Adam steps of CapturedModuleStep (graph replay) against NativeTrainStep on a configuration both cover; with
