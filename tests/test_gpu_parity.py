@@ -66,6 +66,47 @@ def test_level_backward_whole_jet_workgroups(dev, O, monkeypatch, ordered, C, CO
     _level_case(dev, O, False, C, CO, N, B)
 
 
+def test_level_backward_symmetric_and_ordered_sweeps_agree_on_random_shapes(dev, O, monkeypatch):
+    """The two forms of the encoder level backward (unordered pair tiles with both directed edges' radial gradient / one GEMM per
+    ordered tile) on the same inputs, over random jet sizes 2 .. 150, channel counts 1 .. 4 and paddings: every output to 1e-11 of
+    its own scale (the forms differ in summation order only)."""
+    from lgn import _native as Nn
+    g = torch.Generator().manual_seed(12345)
+    for trial in range(14):
+        N = int(torch.randint(2, 41, (1,), generator=g)) if trial < 10 else int(torch.randint(41, 151, (1,), generator=g))
+        C = int(torch.randint(1, 5, (1,), generator=g)); CO = int(torch.randint(1, 7, (1,), generator=g))
+        B = 257 + int(torch.randint(0, 40, (1,), generator=g)) if N <= 40 else int(torch.randint(1, 4, (1,), generator=g))
+        cfg, plans, P = _rand_level_params(O, C, CO, False, g)
+        pre = "rad_funcs.rad_funcs.0."
+        rad = tuple(P[pre + n].to(dev).contiguous() for n in ["a", "b", "c", "linear.0.weight", "linear.0.bias", "linear.1.weight", "linear.1.bias"])
+        wm0 = P["lgn_cg.node_levels.0.cat_mix.mix_reps.weights.(0, 0)"].to(dev).contiguous()
+        wm1 = P["lgn_cg.node_levels.0.cat_mix.mix_reps.weights.(1, 1)"].to(dev).contiguous()
+        s = torch.randn(2, B, N, C, dtype=torch.float64, generator=g).to(dev)
+        v = torch.randn(2, B, N, C, 4, dtype=torch.float64, generator=g).to(dev)
+        gs = torch.randn(2, B, N, CO, dtype=torch.float64, generator=g).to(dev)
+        gv = torch.randn(2, B, N, CO, 4, dtype=torch.float64, generator=g).to(dev)
+        p4, labels = O.synthetic_jets(B, N, seed=100 + trial, pad=N > 3)
+        p, mask = p4.to(dev), labels.to(dev)
+        ag0, ag1, so, vo = Nn.level_fwd(False, s, v, p, mask, rad, wm0, wm1)
+        outs = []
+        for ordered in (False, True):
+            if ordered:
+                monkeypatch.setenv("LGN_AMD_BWD_ORDERED", "1")
+            else:
+                monkeypatch.delenv("LGN_AMD_BWD_ORDERED", raising=False)
+            outs.append(Nn.level_bwd(False, s, v, p, mask, rad, wm0, wm1, ag0, ag1, gs, gv, None))
+        monkeypatch.delenv("LGN_AMD_BWD_ORDERED", raising=False)
+        (g_s, g_v, g_w0, g_w1, rg), (h_s, h_v, h_w0, h_w1, rh) = outs
+        what = f"trial {trial}: N={N} C={C} CO={CO} B={B}"
+        for x, y, name in ((g_s, h_s, "g_s"), (g_v, h_v, "g_v"), (g_w0, h_w0, "g_wm0"), (g_w1, h_w1, "g_wm1")):
+            U.assert_close(x, y, 1e-11, f"{what} {name}")
+        for x, y in zip(rg, rh):
+            if y.abs().max() > 0:
+                U.assert_close(x, y, 1e-10, f"{what} radial gradient")
+            else:
+                assert x.abs().max() == 0
+
+
 @pytest.mark.parametrize("C,CO,N,B", [(4, 4, 150, 1), (3, 3, 150, 2), (4, 4, 48, 2), (3, 4, 50, 1), (4, 3, 41, 2), (2, 2, 63, 1), (4, 4, 70, 1),
                                       (5, 6, 100, 1)])
 def test_level_backward_large_jets_ordered_pair_tiles(dev, O, monkeypatch, C, CO, N, B):
