@@ -24,7 +24,8 @@ int mlp_dispatch(const MlpArgs<T>& a, bool backward, hipStream_t stream) {
   LGN_CHECK_ARG(a.act >= 0 && a.act < LGN_ACT_COUNT, "cgmlp: unknown activation id %d (LGN_ACT_*)", a.act);
   LGN_CHECK_ARG(a.H >= 2 * a.C && a.H <= 96, "cgmlp: hidden width %d unsupported (2C..96)", a.H);
   if (backward) LGN_CHECK_ARG((size_t)a.psize == mlp_param_count(a.C, a.H, a.nlin), "cgmlp: psize mismatch");
-  int rc = mlp_mfma_dispatch(a, backward, stream);
+  int rc = mlp_chain_dispatch(a, backward, stream);
+  if (rc == -2) rc = mlp_mfma_dispatch(a, backward, stream);
   if (rc == -2) rc = mlp_mfma_wide_dispatch(a, backward, stream);
   if (rc == -2) { set_error("cgmlp: shape C=%d H=%d not covered", a.C, a.H); return -1; }
   return rc;

@@ -1,0 +1,600 @@
+// lgn-autoencoder_amd/csrc/mlp_chain.hip -- CGMLP forward / backward for large batches: one wave carries a 16-row tile through
+// ALL layers out of registers (round 5).
+//
+// Same operator as mlp_mfma.hip (reference: CGMLP.forward, lgn/models/lgn_levels.py:191-227), for the reference widths
+// H = 6 * 2C, C <= 4, and batches that give every CU a 64-row workgroup.  Layers are computed TRANSPOSED,
+//     h_l^T [H x rows] = W_l [H x Hin] . h_{l-1}^T [Hin x rows],
+// with v_mfma_f64_16x16x4_f64 (D(16x16) += A(16x4) B(4x16)):
+//   A: lane l holds A[i = l&15][k = l>>4]      B: lane l holds B[k = l>>4][j = l&15]
+//   D: lane l, register r holds D[i = (l>>4) + 4r][j = l&15]
+// With c = l&15, g = l>>4: the D register r of output tile u, D[neuron 16u + 4r + g][row c], IS the B operand of the next
+// layer's k-step (u, r) (k = 16u + 4r + g): activations never leave the registers, the A operands are fragments of the weight
+// image W[o][k] in LDS, one ds_read_b64 per matrix instruction.  A wave owns 16 rows; a workgroup = 4 waves = 64 rows shares
+// the weight images (double buffered, staged through registers one layer ahead: ONE barrier per layer, and no wave ever waits
+// for another wave's activations).  In mlp_mfma.hip a wave owns one 16 x 16 tile of every layer and the whole workgroup
+// exchanges activations through LDS at every layer: thirteen latency-exposed layer steps in the backward.
+//
+// Backward, layer l (weights W_l [Hout x Hin], g_pre = d loss / d pre-activation, transposed like everything else):
+//   g_in^T = W_l^T g_pre^T    A = fragments of the SAME image read transposed, B = the D registers of g_pre^T: registers only
+//   dW_l   = g_pre^T h_in     K = rows: both operands have the row index on l&15, where a matrix instruction never contracts,
+//                             so each wave publishes its 16 columns of g_pre^T and h_in^T into two LDS tiles [neuron][64 rows]
+//                             (double buffered) and the tile rows of dW_l are dealt to the waves (owner = (t + l) mod 4, three
+//                             16 x 16 tiles that share their A fragment): K = 64 rows per matrix chain, one partial row per
+//                             64-row workgroup as before.  dW_l runs one step BEHIND the chain (after the barrier that follows
+//                             the publication), so the one barrier per layer also covers the tiles.
+//   db_l   = row sums of g_pre^T: the owner of a tile row adds up the A fragments it loads anyway (16 adds + 2 shuffles).
+// The hidden activations are recomputed (six more layer steps at the head of the kernel) and stay in registers: 72 doubles.
+#include "ops.hpp"
+
+namespace lgn {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+namespace { LGN_STAMP_DECL }
+LGN_STAMP_READER(lgn_debug_stamps_mlp_chain)
+
+namespace chain {
+
+__host__ __device__ constexpr int stride2mod4(int x) { return x + ((6 - (x & 3)) & 3); }   // smallest >= x with == 2 (mod 4)
+
+// LDS-only barrier: __syncthreads() also drains the global loads of the weight prefetch and the dW stores
+// It is also a fence for the instruction scheduler, which would otherwise hoist the NEXT step's image commit (and the wait for its
+// global loads) above this step's matrix instructions.
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+  __builtin_amdgcn_sched_barrier(0);
+}
+// A block of N matrix instructions whose A operands come from LDS, one ds_read per instruction, as an explicit software pipeline:
+// P reads ahead of the instruction that consumes them, order pinned (one wave per SIMD: nobody else hides the LDS latency, and
+// left alone the scheduler sinks every read to just above its use).
+// side(i) runs in the shadow of matrix instruction i (64 cycles of the pipe each; the wave keeps issuing): everything a step has
+// to do besides its matrix work -- image commits and requests, activations of finished tiles, tile publication, gradient
+// stores -- is cut into pieces and dealt to the items, because with one wave per SIMD whatever is issued between two streams
+// leaves the matrix pipe idle (measured: 1 200 - 2 200 cycles per step before this, for 2 300 - 5 400 cycles of pipe time).
+template <int N, int P, class LoadF, class MmaF, class SideF>
+__device__ __forceinline__ void mfma_stream(LoadF load, MmaF mma, SideF side) {
+  double q[N];
+#pragma unroll
+  for (int i = 0; i < (P < N ? P : N); ++i) q[i] = load(i);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    if (i + P < N) q[i + P] = load(i + P);
+    mma(i, q[i]);
+    side(i);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+constexpr int LOOKAHEAD = 9;
+// pieces [i T / N, (i + 1) T / N) of a list of T pieces, for item i of N
+template <int N, int T, class F>
+__device__ __forceinline__ void deal(int i, F piece) {
+#pragma unroll
+  for (int j = 0; j < T; ++j)
+    if (j * N >= i * T && j * N < (i + 1) * T) piece(j);
+}
+// keeps a value's computation on this side of the next scheduling fence (instruction selection places unchained arithmetic freely)
+__device__ __forceinline__ void pin(double& x) { asm volatile("" : "+v"(x)); }
+
+#ifndef LGN_DBG_NOSTAGE
+#define LGN_DBG_NOSTAGE 0
+#endif
+#ifndef LGN_DBG_NOACT
+#define LGN_DBG_NOACT 0
+#endif
+template <bool GEN>
+__device__ __forceinline__ double act_t(double x, int act) {
+  if (LGN_DBG_NOACT) return x;
+  if constexpr (GEN) return act_apply(x, act);
+  else return fmax(x, 0.01 * x);     // (probes/mfma_issue_probe: 165 cycles per 36-instruction layer; multiply + compare + select: 250 - 300)
+}
+template <int H_, int D_>
+struct Geo {
+  static constexpr int H = H_, D = D_, NH = 6;
+  static constexpr int NT = (H + 15) / 16, HP = 16 * NT;   // hidden tiles
+  static constexpr int KSH = H / 4;                         // k-steps over a hidden layer's inputs
+  static constexpr int KS0 = (D + 3) / 4;                   // k-steps over the MLP's inputs (2C features, zero padded to 4 KS0)
+  static constexpr int S = stride2mod4(HP + 1);             // row stride of a weight image; column HP holds the bias
+  static constexpr int WSIZE = HP * S;
+  static constexpr int SR = 66;                             // row stride of the [neuron][64 rows] tiles of the backward
+  static constexpr int TSIZE = HP * SR;
+  static constexpr int NREG = (HP * 4 * KSH + 255) / 256;   // staging registers per thread for a hidden image
+  static_assert(H % 4 == 0 && D <= 16 && D <= H && H <= 48, "chain kernels: H = 12 .. 48 (multiple of 4), 2C <= 16");
+  static constexpr size_t fwd_bytes() { return sizeof(double) * 2 * WSIZE; }
+  static constexpr size_t bwd_bytes() { return sizeof(double) * (2 * WSIZE + 4 * TSIZE); }
+  // offsets of (W_l, b_l) in a partial row / parameter block: concat_l (W_l, b_l)
+  static constexpr int off_w(int l) { return l == 0 ? 0 : (H * D + H) + (l - 1) * (H * H + H); }
+  static constexpr int hout(int l) { return l == NH ? D : H; }
+  static constexpr int hin(int l) { return l == 0 ? D : H; }
+  static constexpr int off_b(int l) { return off_w(l) + hout(l) * hin(l); }
+  static constexpr int psize() { return off_b(NH) + D; }
+};
+
+// ---- weight images ---------------------------------------------------------------------------------
+// Image of Linear l in LDS: W_l[o][k] at Wl[o * S + k], zero padded to RP x CP (what the matrix instructions read; beyond it a
+// tile's unused rows / columns may hold anything: a row of A only reaches the same row of D), bias at Wl[o * S + HP].
+template <class G, int L>
+struct Img {
+  static constexpr int HO = G::hout(L), HI = G::hin(L);
+  static constexpr int RP = L == G::NH ? 16 : G::HP;                       // rows read: a full tile of outputs
+  static constexpr int CP = L == 0 ? 4 * G::KS0 : 4 * G::KSH;              // columns read by the k-steps
+  static constexpr int NP = (RP * CP + 255) / 256;
+  static_assert(NP <= G::NREG, "staging registers");
+};
+template <class G>
+struct WRegs {
+  double v[G::NREG];
+  double b;
+};
+template <class G, int L>
+__device__ __forceinline__ void issue_image(const MlpArgs<double>& a, WRegs<G>& wr, int tid) {
+  using I = Img<G, L>;
+  const double* __restrict__ W = a.w[L];
+#pragma unroll
+  for (int i = 0; i < I::NP; ++i) {
+    const int e = tid + 256 * i, o = e / I::CP, k = e - o * I::CP;
+    const bool ok = o < I::HO && k < I::HI;
+    const double x = W[ok ? o * I::HI + k : 0];                            // clamped address + select: no branch around the load
+    wr.v[i] = ok ? x : 0.0;
+  }
+  const double bb = a.b[L][tid < I::HO ? tid : 0];
+  wr.b = tid < I::HO ? bb : 0.0;
+}
+template <class G, int L>
+__device__ __forceinline__ void commit_image(double* Wl, const WRegs<G>& wr, int tid) {
+  using I = Img<G, L>;
+#pragma unroll
+  for (int i = 0; i < I::NP; ++i) {
+    const int e = tid + 256 * i, o = e / I::CP, k = e - o * I::CP;
+    if (I::RP * I::CP % 256 == 0 || e < I::RP * I::CP) Wl[o * G::S + k] = wr.v[i];
+  }
+  if (tid < I::RP) Wl[tid * G::S + G::HP] = wr.b;
+}
+
+// one register of an image (j < NP) or its bias (j == NP): the same work as issue_image / commit_image, piece by piece
+template <class G, int L>
+__device__ __forceinline__ void issue_piece(const MlpArgs<double>& a, WRegs<G>& wr, int tid, int j) {
+  using I = Img<G, L>;
+  if (j < I::NP) {
+    const int e = tid + 256 * j, o = e / I::CP, k = e - o * I::CP;
+    const bool ok = o < I::HO && k < I::HI;
+    const double x = a.w[L][ok ? o * I::HI + k : 0];
+    wr.v[j] = ok ? x : 0.0;
+  } else if (j == I::NP) {
+    const double bb = a.b[L][tid < I::HO ? tid : 0];
+    wr.b = tid < I::HO ? bb : 0.0;
+  }
+}
+template <class G, int L>
+__device__ __forceinline__ void commit_piece(double* Wl, const WRegs<G>& wr, int tid, int j) {
+  using I = Img<G, L>;
+  if (j < I::NP) {
+    const int e = tid + 256 * j, o = e / I::CP, k = e - o * I::CP;
+    if (I::RP * I::CP % 256 == 0 || e < I::RP * I::CP) Wl[o * G::S + k] = wr.v[j];
+  } else if (j == I::NP) {
+    if (tid < I::RP) Wl[tid * G::S + G::HP] = wr.b;
+  }
+}
+// Step q of a kernel reads the image of Linear seq(q) from buffer q & 1.  The images travel global -> registers -> LDS two steps
+// ahead of their use (two register sets, images alternate between them): with one set, i.e. one layer of lead, every step waited
+// for its successor's weights -- an L2 round trip under load is longer than the ~1 us a layer computes.
+template <class G, bool BWD>
+__host__ __device__ constexpr int seq(int q) { return BWD && q > G::NH ? 2 * G::NH - q : q; }
+// a step's staging as pieces: 2 (NREG + 1) of them -- commit of the next step's image first (it frees the register set), then
+// the request for the image two steps further on
+template <class G>
+constexpr int stage_pieces() { return 2 * (G::NREG + 1); }
+template <class G, bool BWD, int Q>
+__device__ __forceinline__ void stage_piece(const MlpArgs<double>& a, double* Wl, WRegs<G>& wrA, WRegs<G>& wrB, int tid, int j) {
+  constexpr int LAST = BWD ? 2 * G::NH : G::NH, n1 = Q + 1, n3 = Q + 3;
+  WRegs<G>& wr = (n1 & 1) ? wrB : wrA;
+  if (j <= G::NREG) {
+    if constexpr (n1 <= LAST) commit_piece<G, seq<G, BWD>(n1 <= LAST ? n1 : 0)>(Wl + (n1 & 1) * G::WSIZE, wr, tid, j);
+  } else {
+    if constexpr (n3 <= LAST) issue_piece<G, seq<G, BWD>(n3 <= LAST ? n3 : 0)>(a, wr, tid, j - G::NREG - 1);
+  }
+}
+template <class G, bool BWD>
+__device__ __forceinline__ void stage_prologue(const MlpArgs<double>& a, double* Wl, WRegs<G>& wrA, WRegs<G>& wrB, int tid) {
+  issue_image<G, 0>(a, wrA, tid);
+  issue_image<G, 1>(a, wrB, tid);
+  commit_image<G, 0>(Wl, wrA, tid);
+  issue_image<G, 2>(a, wrA, tid);
+}
+
+// ---- one layer of the chain ---------------------------------------------------------------------------
+// hidden layer: hout^T = act(W hin^T + b).  KS = k-steps over the inputs (hin[u][r] <-> k = 16u + 4r + g).  Tile-major: tile t is
+// complete after item (t + 1) KS - 1 and its activation runs two items later, under the next tile's matrix instructions; the
+// bias of tile t + 1 is read while tile t computes.  ext(i) = the step's other work for item i.
+template <class G, int KS, int NTI, bool GEN, int DBG = 0, class ExtF>
+__device__ __forceinline__ void layer_fwd(const double* Wc, const v4d (&hin)[NTI], v4d (&hout)[G::NT], int c, int g, int act, ExtF ext) {
+  constexpr int S = G::S, NT = G::NT;
+  const double* wa = Wc + c * S + g;
+  const double* wbias = Wc + g * S + G::HP;
+  v4d acc[NT];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc[0][r] = wbias[4 * r * S];
+  if (DBG) STAMP(30);
+  mfma_stream<KS * NT, LOOKAHEAD>(
+      [&](int i) { return wa[16 * (i / KS) * S + 4 * (i % KS)]; },
+      [&](int i, double av) {
+        const int t = i / KS, ks = i % KS;
+        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, hin[ks >> 2][ks & 3], acc[t], 0, 0, 0);
+      },
+      [&](int i) {
+        const int t = i / KS, ks = i % KS;
+        if (ks == 0 && t + 1 < NT) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[t + 1 < NT ? t + 1 : 0][r] = wbias[(16 * (t + 1) + 4 * r) * S];
+        }
+        constexpr int k1 = KS > 6 ? 5 : KS > 1 ? 1 : 0, k2 = KS > 6 ? 6 : KS > 2 ? 2 : k1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)                          // tile t - 1 finished a few items ago (its results have left the pipe)
+          if (t > 0 && ks == (r < 2 ? k1 : k2)) {
+            double y = act_t<GEN>(acc[t > 0 ? t - 1 : 0][r], act);
+            pin(y);
+            hout[t > 0 ? t - 1 : 0][r] = y;
+          }
+        ext(i);
+        if (DBG && (i == 0 || i == 1 || i == 2 || i == 11 || i == 12 || i == 23 || i == 34 || i == 35)) STAMP(31 + i);
+      });
+  if (DBG) STAMP(28);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) hout[NT - 1][r] = act_t<GEN>(acc[NT - 1][r], act);
+  if (DBG) { double z_ = hout[NT - 1][3]; pin(z_); hout[NT - 1][3] = z_; STAMP(29); }
+}
+// output layer (one tile of 2C <= 16 neurons, no activation)
+template <class G>
+__device__ __forceinline__ v4d layer_out(const double* Wc, const v4d (&hin)[G::NT], int c, int g) {
+  constexpr int S = G::S;
+  const double* wa = Wc + c * S + g;
+  v4d acc;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc[r] = Wc[(4 * r + g) * S + G::HP];
+  mfma_stream<G::KSH, LOOKAHEAD>([&](int ks) { return wa[4 * ks]; },
+                                 [&](int ks, double av) { acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, hin[ks >> 2][ks & 3], acc, 0, 0, 0); },
+                                 [&](int) {});
+  return acc;
+}
+// backward through a Linear: gin^T [NTO tiles of inputs] = W^T gpre^T.  KS = k-steps over the layer's OUTPUT neurons
+// (gpre[t][r] <-> o = 16t + 4r + g); A fragment (i = input 16u + c, k = o): the image read transposed.  Tile-major over the
+// input tiles u; fin(u, r) consumes gin[u][r] of a finished tile (activation slope) two items after the tile's last matrix
+// instruction -- except the last tile, which the caller finishes under whatever it issues next.
+template <class G, int KS, int NTO, int NTG, class FinF, class ExtF>
+__device__ __forceinline__ void layer_bwd(const double* Wc, const v4d (&gpre)[NTG], v4d (&gin)[NTO], int c, int g, FinF fin, ExtF ext) {
+  constexpr int S = G::S;
+  const double* wa = Wc + g * S + c;
+#pragma unroll
+  for (int u = 0; u < NTO; ++u) gin[u] = v4d{0, 0, 0, 0};
+  mfma_stream<KS * NTO, LOOKAHEAD>(
+      [&](int i) { return wa[4 * (i % KS) * S + 16 * (i / KS)]; },
+      [&](int i, double av) {
+        const int u = i / KS, ks = i % KS;
+        gin[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, gpre[ks >> 2][ks & 3], gin[u], 0, 0, 0);
+      },
+      [&](int i) {
+        const int u = i / KS, ks = i % KS;
+        constexpr int k1 = KS > 6 ? 5 : KS > 1 ? 1 : 0, k2 = KS > 6 ? 6 : KS > 2 ? 2 : k1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (u > 0 && ks == (r < 2 ? k1 : k2)) fin(u > 0 ? u - 1 : 0, r);
+        ext(i);
+      });
+}
+
+// Hidden activations kept for the backward (MlpArgs::h_saved; the step keeps them below mlp_save_max_rows() rows): an opaque
+// register image, [64-row block][wave][layer][tile][register][lane] -- every store / load is one 512-byte run -- of exactly
+// mlp_saved_doubles(M, H, 7) doubles.  Written and read by these kernels only (same H, same lane mapping).
+template <class G>
+__device__ __forceinline__ double* saved_ptr(const MlpArgs<double>& a, int wave, int lane) {
+  return a.h_saved + ((size_t)blockIdx.x * 4 + wave) * (G::NH * G::NT * 4 * 64) + lane;
+}
+template <class G>
+__device__ __forceinline__ void save_layer(double* hs, int l, const v4d (&h)[G::NT]) {
+#pragma unroll
+  for (int t = 0; t < G::NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) __builtin_nontemporal_store(h[t][r], &hs[((l * G::NT + t) * 4 + r) * 64]);
+}
+template <class G, int NTI>
+__device__ __forceinline__ void save_piece(double* hs, int l, const v4d (&h)[NTI], int j) {
+  __builtin_nontemporal_store(h[j >> 2][j & 3], &hs[(l * G::NT * 4 + j) * 64]);
+}
+template <class G>
+__device__ __forceinline__ void load_layer(const double* hs, int l, v4d (&h)[G::NT]) {
+#pragma unroll
+  for (int t = 0; t < G::NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) h[t][r] = __builtin_nontemporal_load(&hs[((l * G::NT + t) * 4 + r) * 64]);
+}
+
+// MLP input rows in B layout: xb[r] = x[row0 + c][feature 4r + g], feature f = 2 ch + z of the planar [2][M][C] scalars
+template <class G>
+__device__ __forceinline__ void load_x(const MlpArgs<double>& a, int row, int g, v4d (&xb)[1]) {
+  const bool rok = row < a.M;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int f = 4 * r + g;
+    const bool ok = r < G::KS0 && rok && f < G::D;
+    const double x = a.s_in[ok ? (size_t)(f & 1) * a.M * a.C + (size_t)row * a.C + (f >> 1) : 0];
+    xb[0][r] = ok ? x : 0.0;
+  }
+}
+
+template <int H, int D, bool GEN, bool SAVE>
+__global__ __launch_bounds__(256) void mlp_chain_fwd_kernel(MlpArgs<double> a) {
+  using G = Geo<H, D>;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, g = lane >> 4;
+  const int row = blockIdx.x * 64 + wave * 16 + c;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  double* Wl = reinterpret_cast<double*>(smem_raw);          // 2 weight images
+  WRegs<G> wrA, wrB;
+  STAMP(0);
+  v4d xb[1];
+  load_x<G>(a, row, g, xb);
+  stage_prologue<G, false>(a, Wl, wrA, wrB, tid);
+  lds_barrier();
+  STAMP(1);
+  v4d h0[G::NT], h1[G::NT];
+  double* hs = SAVE ? saved_ptr<G>(a, wave, lane) : nullptr;
+  // step q: commit the image of layer q + 1 (loaded during step q - 1), request layer q + 2, compute layer q
+  // (SAVE: the activations of layer q - 1 are stored under layer q's matrix instructions)
+#define LGN_CHAIN_STEP(Q, HIN, HOUT, KS, NTI)                                                                        \
+  layer_fwd<G, KS, NTI, GEN, (Q == 3)>(Wl + (Q & 1) * G::WSIZE, HIN, HOUT, c, g, a.act, [&](int i) {               \
+    if (!LGN_DBG_NOSTAGE) deal<KS * G::NT, stage_pieces<G>()>(i, [&](int j) { stage_piece<G, false, Q>(a, Wl, wrA, wrB, tid, j); });      \
+    if (SAVE && Q > 0) deal<KS * G::NT, 4 * NTI>(i, [&](int j) { save_piece<G>(hs, Q - 1, HIN, j); });              \
+  });                                                                                                                \
+  lds_barrier();                                                                                                     \
+  STAMP(2 + Q);
+  LGN_CHAIN_STEP(0, xb, h0, G::KS0, 1)
+  LGN_CHAIN_STEP(1, h0, h1, G::KSH, G::NT)
+  LGN_CHAIN_STEP(2, h1, h0, G::KSH, G::NT)
+  LGN_CHAIN_STEP(3, h0, h1, G::KSH, G::NT)
+  LGN_CHAIN_STEP(4, h1, h0, G::KSH, G::NT)
+  LGN_CHAIN_STEP(5, h0, h1, G::KSH, G::NT)
+#undef LGN_CHAIN_STEP
+  if (SAVE) save_layer<G>(hs, G::NH - 1, h1);
+  const v4d y = layer_out<G>(Wl + (G::NH & 1) * G::WSIZE, h1, c, g);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int o = 4 * r + g;
+    if (o < D && row < a.M) a.s_out[mlp_out_index(a, o & 1, row, o >> 1)] = y[r];
+  }
+  STAMP(8);
+}
+
+// one register (piece j = 4t + r) of this wave's columns 16 w .. 16 w + 15 of a [neuron][64 rows] tile: D layout, neuron
+// 16t + 4r + g, row c
+template <class G, int NTI>
+__device__ __forceinline__ void publish_piece(double* T, const v4d (&v)[NTI], int wave, int c, int g, int j) {
+  T[(4 * j + g) * G::SR + 16 * wave + c] = v[j >> 2][j & 3];
+}
+// dW tiles (t, u0 .. u0 + NU - 1) of Linear L over the workgroup's 64 rows, and (u0 == 0) the bias gradient of tile row t.
+// Tile-major: the 16 A fragments (g_pre^T, shared by the NU tiles) are read during the first tile and kept; a finished tile is
+// stored under the next tile's matrix instructions.  side(i): the caller's work for item i of 16 NU.
+template <class G, int L, int NU, class SideF>
+__device__ __forceinline__ void dw_unit(const double* Gt, const double* Xt, double* part, int t, int u0, int c, int g, SideF side) {
+  constexpr int SR = G::SR, HO = G::hout(L), HI = G::hin(L), N = 16 * NU, P = 6;
+  const double* ga = Gt + (16 * t + c) * SR + g;
+  const double* xb = Xt + (16 * u0 + c) * SR + g;
+  double* pW = part + G::off_w(L);
+  v4d acc[NU];
+#pragma unroll
+  for (int u = 0; u < NU; ++u) acc[u] = v4d{0, 0, 0, 0};
+  double dbs = 0.0, qa[16], qx[N];
+  auto load = [&](int i) {
+    qx[i] = xb[16 * (i >> 4) * SR + 4 * (i & 15)];
+    if (i < 16) qa[i] = ga[4 * i];
+  };
+  auto store = [&](int u, int r) {
+    const int o = 16 * t + 4 * r + g, k = 16 * (u0 + u) + c;
+    if (o < HO && k < HI) __builtin_nontemporal_store(acc[u][r], &pW[o * HI + k]);
+  };
+#pragma unroll
+  for (int i = 0; i < P; ++i) load(i);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const int u = i >> 4, sk = i & 15;
+    if (i + P < N) load(i + P);
+    acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[sk], qx[i], acc[u], 0, 0, 0);
+    if (u == 0) dbs += qa[sk];
+    if (u > 0 && sk >= 1 && sk <= 4) store(u > 0 ? u - 1 : 0, sk - 1);
+    side(i);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) store(NU - 1, r);
+  if (u0 == 0) {
+    dbs += shfl_xor(dbs, 16);
+    dbs += shfl_xor(dbs, 32);
+    if (g == 0 && 16 * t + c < HO) __builtin_nontemporal_store(dbs, &part[G::off_b(L) + 16 * t + c]);
+  }
+}
+// the weight gradient of Linear L from the tiles published one step earlier: hidden layers deal their tile ROWS to the waves
+// (three tiles that share the A fragment; the owner rotates with the layer), the two end layers their single row / column of
+// tiles.  Returns whether this wave had a unit (side ran); a wave without one runs side's work itself.
+template <class G, int L, class SideF>
+__device__ __forceinline__ bool dw_layer(const double* Gt, const double* Xt, double* part, int wave, int c, int g, SideF side) {
+  if (L == G::NH) {
+    if (wave < G::NT) { dw_unit<G, L, 1>(Gt, Xt, part, 0, wave, c, g, side); return true; }
+  } else if (L == 0) {
+    if (wave < G::NT) { dw_unit<G, L, 1>(Gt, Xt, part, wave, 0, c, g, side); return true; }
+  } else {
+    const int t = (wave + L) & 3;
+    if (t < G::NT) { dw_unit<G, L, G::NT>(Gt, Xt, part, t, 0, c, g, side); return true; }
+  }
+  return false;
+}
+
+template <int H, int D, bool GEN, bool SAVE>
+__global__ __launch_bounds__(256) void mlp_chain_bwd_kernel(MlpArgs<double> a) {
+  using G = Geo<H, D>;
+  constexpr int NT = G::NT, NH = G::NH;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, g = lane >> 4;
+  const int row = blockIdx.x * 64 + wave * 16 + c;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  double* Wl = reinterpret_cast<double*>(smem_raw);          // 2 weight images
+  double* Gt = Wl + 2 * G::WSIZE;                            // 2 g_pre tiles [neuron][64 rows]
+  double* Xt = Gt + 2 * G::TSIZE;                            // 2 layer-input tiles
+  double* part = a.part + (size_t)blockIdx.x * a.psize;
+  WRegs<G> wrA, wrB;
+  STAMP(10);
+  v4d xb[1];
+  load_x<G>(a, row, g, xb);
+  v4d gout[1];                                               // upstream gradient, D layout of the output tile (o = 4r + g, row c)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int o = 4 * r + g;
+    const bool ok = o < D && row < a.M;
+    const double x = a.g_out[ok ? mlp_out_index(a, o & 1, row, o >> 1) : 0];
+    gout[0][r] = ok ? x : 0.0;
+  }
+  v4d h[NH][NT];
+  if constexpr (SAVE) {
+    // the forward's copy: the six recompute steps go away; the images start at the output layer (steps NH, NH + 1, ...: the same
+    // buffers and register sets as in the recompute form)
+    const double* hs = saved_ptr<G>(a, wave, lane);
+    issue_image<G, NH>(a, wrA, tid);
+    issue_image<G, NH - 1>(a, wrB, tid);
+#pragma unroll
+    for (int l = NH - 1; l >= 0; --l) load_layer<G>(hs, l, h[l]);
+    commit_image<G, NH>(Wl, wrA, tid);
+    issue_image<G, NH - 2>(a, wrA, tid);
+    lds_barrier();
+    STAMP(11);
+  } else {
+    stage_prologue<G, true>(a, Wl, wrA, wrB, tid);
+    lds_barrier();
+    STAMP(11);
+    // ---- recompute the hidden activations: steps q = 0 .. 5, image q in buffer q & 1
+#define LGN_CHAIN_STEP(Q, HIN, KS, NTI)                                                                              \
+  layer_fwd<G, KS, NTI, GEN>(Wl + (Q & 1) * G::WSIZE, HIN, h[Q], c, g, a.act, [&](int i) {                          \
+    deal<KS * NT, stage_pieces<G>()>(i, [&](int j) { stage_piece<G, true, Q>(a, Wl, wrA, wrB, tid, j); });          \
+  });                                                                                                                \
+  lds_barrier();                                                                                                     \
+  STAMP(12 + Q);
+    LGN_CHAIN_STEP(0, xb, G::KS0, 1)
+    LGN_CHAIN_STEP(1, h[0], G::KSH, NT)
+    LGN_CHAIN_STEP(2, h[1], G::KSH, NT)
+    LGN_CHAIN_STEP(3, h[2], G::KSH, NT)
+    LGN_CHAIN_STEP(4, h[3], G::KSH, NT)
+    LGN_CHAIN_STEP(5, h[4], G::KSH, NT)
+#undef LGN_CHAIN_STEP
+  }
+  // ---- backward sweep: step q = 6 .. 12 handles Linear l = 12 - q (image in buffer q & 1), tiles of parity l & 1.  The g_pre of
+  // successive layers alternate between two register arrays: the running stream still reads the old one as its B operands.
+  v4d gpA[NT], gpB[NT], gin[NT];
+  {  // q = 6, l = 6: the output layer
+    constexpr int NI = G::KS0 * NT, NPC = 4 + 4 * NT + stage_pieces<G>();
+    auto fin = [&](int u, int r) {
+      double y = gin[u][r] * act_slope_t<GEN>(h[NH - 1][u][r], a.act);
+      pin(y);
+      gpA[u][r] = y;
+    };
+    layer_bwd<G, G::KS0, NT, 1>(Wl + 0 * G::WSIZE, gout, gin, c, g, fin, [&](int i) {
+      deal<NI, NPC>(i, [&](int j) {
+        if (j < 4) publish_piece<G, 1>(Gt, gout, wave, c, g, j);
+        else if (j < 4 + 4 * NT) publish_piece<G, NT>(Xt, h[NH - 1], wave, c, g, j - 4);
+        else stage_piece<G, true, NH>(a, Wl, wrA, wrB, tid, j - 4 - 4 * NT);
+      });
+    });
+#pragma unroll
+    for (int r = 0; r < 4; ++r) fin(NT - 1, r);
+    lds_barrier();
+    STAMP(18);
+  }
+#define LGN_CHAIN_BSTEP(L, GP, GN)                                                                                   \
+  {                                                                                                                  \
+    constexpr int q_ = 2 * NH - (L), NI = G::KSH * NT, NPC = 8 * NT + stage_pieces<G>();                             \
+    auto fin = [&](int u, int r) {                                                                                   \
+      double y = gin[u][r] * act_slope_t<GEN>(h[(L) - 1][u][r], a.act);                                              \
+      pin(y);                                                                                                        \
+      GN[u][r] = y;                                                                                                  \
+    };                                                                                                               \
+    layer_bwd<G, G::KSH, NT, NT>(Wl + (q_ & 1) * G::WSIZE, GP, gin, c, g, fin, [&](int i) {                          \
+      deal<NI, NPC>(i, [&](int j) {                                                                                  \
+        if (j < 4 * NT) publish_piece<G, NT>(Gt + ((L) & 1) * G::TSIZE, GP, wave, c, g, j);                          \
+        else if (j < 8 * NT) publish_piece<G, NT>(Xt + ((L) & 1) * G::TSIZE, h[(L) - 1], wave, c, g, j - 4 * NT);    \
+        else stage_piece<G, true, q_>(a, Wl, wrA, wrB, tid, j - 8 * NT);                                             \
+      });                                                                                                            \
+    });                                                                                                              \
+    auto tail = [&](int i) {                                                                                         \
+      if (i == 1) { fin(NT - 1, 0); fin(NT - 1, 1); }                                                                \
+      if (i == 2) { fin(NT - 1, 2); fin(NT - 1, 3); }                                                                \
+    };                                                                                                               \
+    if (!dw_layer<G, (L) + 1>(Gt + (((L) + 1) & 1) * G::TSIZE, Xt + (((L) + 1) & 1) * G::TSIZE, part, wave, c, g, tail)) {   \
+      tail(1);                                                                                                       \
+      tail(2);                                                                                                       \
+    }                                                                                                                \
+    lds_barrier();                                                                                                   \
+    STAMP(12 + q_);                                                                                                  \
+  }
+  LGN_CHAIN_BSTEP(5, gpA, gpB)
+  LGN_CHAIN_BSTEP(4, gpB, gpA)
+  LGN_CHAIN_BSTEP(3, gpA, gpB)
+  LGN_CHAIN_BSTEP(2, gpB, gpA)
+  LGN_CHAIN_BSTEP(1, gpA, gpB)
+#undef LGN_CHAIN_BSTEP
+  {  // q = 12, l = 0: the first layer; its input tile holds the MLP's input rows (k-steps beyond KS0 never stored or read)
+    v4d gx[1];
+    layer_bwd<G, G::KSH, 1, NT>(Wl + 0 * G::WSIZE, gpB, gx, c, g, [&](int, int) {}, [&](int i) {
+      deal<G::KSH, 4 * NT + 4>(i, [&](int j) {
+        if (j < 4 * NT) publish_piece<G, NT>(Gt, gpB, wave, c, g, j);
+        else publish_piece<G, 1>(Xt, xb, wave, c, g, j - 4 * NT);
+      });
+    });
+    auto tail = [&](int i) {                                 // D layout of the input tile: feature f = 4r + g, row c
+      if (i >= 1 && i <= 4) {
+        const int f = 4 * (i - 1) + g;
+        if (f < D && row < a.M) a.g_in[mlp_out_index(a, f & 1, row, f >> 1)] = gx[0][i - 1];
+      }
+    };
+    if (!dw_layer<G, 1>(Gt + G::TSIZE, Xt + G::TSIZE, part, wave, c, g, tail)) {
+#pragma unroll
+      for (int i = 1; i <= 4; ++i) tail(i);
+    }
+    lds_barrier();
+    STAMP(25);
+  }
+  dw_layer<G, 0>(Gt, Xt, part, wave, c, g, [&](int) {});
+  STAMP(26);
+}
+
+template <int H, int D>
+static int launch(const MlpArgs<double>& a, bool backward, hipStream_t stream) {
+  using G = Geo<H, D>;
+  const int nblk = cdiv(a.M, 64);
+  const size_t smem = backward ? G::bwd_bytes() : G::fwd_bytes();
+  static_assert(G::bwd_bytes() <= 160 * 1024, "LDS budget");
+  if (backward) LGN_CHECK_ARG(a.psize == G::psize(), "cgmlp: psize %d, expected %d", a.psize, G::psize());
+  LGN_CHECK_ARG(!a.h_saved || a.h_rows >= nblk * 64, "cgmlp: the saved-activation buffer has %d rows per layer, %d rows need %d",
+                a.h_rows, a.M, nblk * 64);
+  auto kern = a.h_saved ? (a.act == 0 ? (backward ? mlp_chain_bwd_kernel<H, D, false, true> : mlp_chain_fwd_kernel<H, D, false, true>)
+                                      : (backward ? mlp_chain_bwd_kernel<H, D, true, true> : mlp_chain_fwd_kernel<H, D, true, true>))
+                        : (a.act == 0 ? (backward ? mlp_chain_bwd_kernel<H, D, false, false> : mlp_chain_fwd_kernel<H, D, false, false>)
+                                      : (backward ? mlp_chain_bwd_kernel<H, D, true, false> : mlp_chain_fwd_kernel<H, D, true, false>));
+  if (smem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), smem, stream, a);
+  LGN_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // namespace chain
+
+// The reference widths H = 6 * 2C (C = 1 .. 4) at batches that run 64-row workgroups, activations recomputed; -2 = not this kernel's shape.
+int mlp_chain_dispatch(const MlpArgs<double>& a, bool backward, hipStream_t stream) {
+  static const bool off = [] { const char* e = getenv("LGN_AMD_MLP_V1"); return e && e[0] == '1'; }();
+  if (off || a.nlin != 7 || mlp_rows_per_workgroup(a.M, a.H) != 64) return -2;
+  if (a.H == 48 && a.C == 4) return chain::launch<48, 8>(a, backward, stream);
+  if (a.H == 36 && a.C == 3) return chain::launch<36, 6>(a, backward, stream);
+  if (a.H == 24 && a.C == 2) return chain::launch<24, 4>(a, backward, stream);
+  if (a.H == 12 && a.C == 1) return chain::launch<12, 2>(a, backward, stream);
+  return -2;
+}
+
+}  // namespace lgn

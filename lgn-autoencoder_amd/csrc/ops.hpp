@@ -87,6 +87,7 @@ __host__ __device__ inline size_t mlp_out_index(const MlpArgs<T>& a, int z, int 
 }
 template <typename T> int mlp_dispatch(const MlpArgs<T>&, bool backward, hipStream_t);
 int mlp_mfma_dispatch(const MlpArgs<double>&, bool backward, hipStream_t);
+int mlp_chain_dispatch(const MlpArgs<double>&, bool backward, hipStream_t);   // H = 6 * 2C <= 48, 64-row workgroups (mlp_chain.hip)
 int mlp_mfma_wide_dispatch(const MlpArgs<double>&, bool backward, hipStream_t);   // 48 < H <= 96 (mlp_mfma_wide.hip)
 // rows a CGMLP workgroup (= a partial row of its weight gradients) covers: 64, or 16 for H <= 48 when the batch would give
 // fewer than 128 64-row workgroups (small batches: more, shorter workgroups; mlp_mfma.hip)
