@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LGN_AMD_ABI_VERSION 13   /* bump on ANY struct or signature change (lgn/_native.py: ABI_VERSION) */
+#define LGN_AMD_ABI_VERSION 14   /* bump on ANY struct or signature change (lgn/_native.py: ABI_VERSION) */
 
 int lgn_abi_version(void);
 const char* lgn_last_error(void);
@@ -75,37 +75,6 @@ int lgn_level_bwd_f64(int B, int N, int C, int CO, int decoder,
                       const double* g_s_out, const double* g_v_out,
                       double* g_ag, double* g_s_in, double* g_v_in, double* g_p,
                       double* part_mix, double* part_rad, void* stream);
-
-/* ---- level + its CGMLP in one launch per direction -----------------------------------------------
- * LGNNodeLevel followed by CGMLP on the level's scalars, the pair of lgn/models/lgn_cg.py:164-172.  For jets of up to 40
- * particles, C <= 4, hidden width H <= 48, 7 Linear layers and LeakyReLU the CGMLP can run as a phase of the level kernel: the
- * forward's tail (LGN_AMD_FUSED_MLP=1), the backward's head (LGN_AMD_FUSED_MLP_BWD=1) -- csrc/mlp_dev.hpp; lgn_level_mlp_fused
- * says which of the two this call would take (bit 0 forward, bit 1 backward).  Measured slower than the separate launches at
- * every batch size on MI355X, hence opt-in.  Otherwise, and for every other shape, the level and the CGMLP
- * launches run back to back behind the same call -- same results.
- *  mlp_params: the CGMLP's parameters as ONE block (linear.0.weight, linear.0.bias, linear.1.weight, ...), nn.Linear layouts.
- *  forward : s_pre [2][B][N][CO] = scalars before the MLP (kept for the backward), s_out = after it.
- *  backward: g_s_out = gradient w.r.t. s_out; part_mlp [lgn_level_mlp_partial_rows][psize] (psize = the block's length,
- *            block layout), mlp_scratch [2][B][N][CO] (used by the unfused shapes only; may be NULL when fused);
- *            everything else as lgn_level_bwd_f64. */
-int lgn_level_mlp_fused(int N, int C, int CO, int H, int nlin, int activation, int decoder);
-int lgn_level_mlp_partial_rows(int B, int N, int C, int CO, int H, int nlin, int activation, int decoder);
-int lgn_level_mlp_fwd_f64(int B, int N, int C, int CO, int decoder,
-                          const double* s_in, const double* v_in, const double* p, const uint8_t* mask,
-                          const double* ra, const double* rb, const double* rc,
-                          const double* w0, const double* b0, const double* w1, const double* b1,
-                          const double* wm0, const double* wm1,
-                          const double* mlp_params, int H, int nlin, int activation,
-                          double* ag0, double* ag1, double* s_pre, double* s_out, double* v_out, void* stream);
-int lgn_level_mlp_bwd_f64(int B, int N, int C, int CO, int decoder,
-                          const double* s_in, const double* v_in, const double* p, const uint8_t* mask,
-                          const double* ra, const double* rb, const double* rc,
-                          const double* w0, const double* b0, const double* w1, const double* b1,
-                          const double* wm0, const double* wm1, const double* ag0, const double* ag1,
-                          const double* mlp_params, int H, int nlin, int activation, const double* s_pre,
-                          const double* g_s_out, const double* g_v_out,
-                          double* g_ag, double* g_s_in, double* g_v_in, double* g_p,
-                          double* part_mix, double* part_rad, double* part_mlp, double* mlp_scratch, void* stream);
 
 /* out[n] = (accumulate ? out[n] : 0) + sum_r part[r][n], fixed summation order. */
 int lgn_reduce_partials_f64(const double* part, int rows, int n, double* out, int accumulate, void* stream);
@@ -269,16 +238,26 @@ typedef struct lgn_net_desc {
 #define LGN_NET_NO_STATIC 1   /* table-driven levels: run-time-table kernels + node-major features (cross-check of the
                                  compile-time-table kernels; lgn/_native.py sets it from LGN_AMD_NO_STATIC at creation) */
 /* kernel-selecting cross-check switches, frozen the same way (lgn/_native.py: net_flags; the partial-row counts, whether the loss
- * rides on the last decoder level, whether the CGMLPs ride on the level kernels all follow from them -- a forward, its backward
+ * rides on the last decoder level all follow from them -- a forward, its backward
  * and the workspace sizing can never disagree): */
 #define LGN_NET_DEC_PAIRWISE 2   /* LGN_AMD_DEC_PAIRWISE=1: decoder levels as O(N^2) pair sweeps instead of the separable form */
 #define LGN_NET_LEVEL_V2 4       /* LGN_AMD_LEVEL_V2=1: three-kernel level backward also for N <= 40 */
-#define LGN_NET_FUSED_MLP_FWD 8  /* LGN_AMD_FUSED_MLP=1: the CGMLP forward rides on the level forward kernel (csrc/mlp_dev.hpp; off by
-                                    default: measured slower than the separate launches on MI355X) */
+#define LGN_NET_MLP_V1 8         /* LGN_AMD_MLP_V1=1: the CGMLP keeps the 12-wave kernels (csrc/mlp_mfma.hip) where the chain kernels
+                                    (csrc/mlp_chain.hip: large batches, H = 6 x 2C <= 48) would run; cross-check */
+/* (bit 32, and bit 8 before ABI 14: round 4's CGMLP-inside-the-level-kernels switches; measured slower in every regime, removed) */
 #define LGN_NET_MOMENTS_V1 16    /* LGN_AMD_MOMENTS_V1=1: component-chunked moments kernels (with LGN_NET_NO_STATIC) */
 #define LGN_NET_BWD_ORDERED 64   /* LGN_AMD_BWD_ORDERED=1: the encoder level backward runs its radial-gradient GEMM per ordered pair tile
                                     (the form before round 4's symmetric sweep; cross-check) */
-#define LGN_NET_FUSED_MLP_BWD 32 /* LGN_AMD_FUSED_MLP_BWD=1: the CGMLP backward rides on the level backward kernel (off by default) */
+
+/* Plan-time fit queries: bytes of LDS the largest per-jet end stage needs (one workgroup per jet; the limit is LGN_LDS_LIMIT).
+ * encoder: input-stage backward (K input scalars, C0 = first channel count) and the latent stage (CL = last channel count,
+ * Ts / Tv latent multiplicities, pool = LGN_POOL code); decoder: its input stage (Tin latent vectors) and output / loss stage;
+ * junction: the fused encoder-latent + decoder-input kernels of the whole-step call.  -1: bad pooling code.  A caller whose
+ * shape does not fit takes the per-operator path instead (lgn/models/*.py: _fused_ok, lgn/step.py: NativeTrainStep). */
+#define LGN_LDS_LIMIT (160 * 1024)
+long long lgn_encoder_end_lds_bytes(int N, int C0, int K, int CL, int Ts, int Tv, int pool);
+long long lgn_decoder_end_lds_bytes(int N, int C0, int Tin, int CL);
+long long lgn_junction_lds_bytes(int N, int CL, int Ts, int Tv, int pool, int C0);
 
 int lgn_step_param_slots(const lgn_net_desc* d, int decoder);
 long long lgn_step_workspace_doubles(const lgn_net_desc* d);
@@ -296,8 +275,12 @@ int lgn_step_fwd_bwd_f64(const lgn_net_desc* d, const double* params, double* gr
                          double* loss_part, void* stream, void* side_stream);
 /* grads += l1_lambda*sign(params) (utils/train.py:484-487); loss_out[0..2] = total, chamfer, sum|w|; optional Adam
  * (torch.optim.Adam defaults; the step counter lives on the device so that graph replays stay correct).
- * loss_out must hold 3 + LGN_FINALIZE_SCRATCH doubles: the results, then scratch for the per-workgroup |w| partials whose last
- * slot is the finished-workgroup counter of the single launch -- the caller zero-fills the block ONCE, at allocation. */
+ * loss_out must hold 3 + LGN_FINALIZE_SCRATCH doubles: the results, then scratch -- the per-workgroup |w| partials, the cached
+ * bias-correction powers {t, beta1^t, beta2^t} of the next odd / even step (checked against the step counter before use: a
+ * restored counter or changed betas just recompute them) and, in the last slot, the finished-workgroup counter of the single
+ * launch.  The caller zero-fills the block ONCE, at allocation; the kernel leaves the counter at zero.  A launch that died
+ * part-way (device fault) leaves it dirty: zero the block again before reusing it -- with a non-zero counter no workgroup
+ * recognises itself as the last one, loss_out[0..2] stay stale and the step counter is not advanced. */
 #define LGN_FINALIZE_SCRATCH 2048
 int lgn_step_finalize_f64(double* params, double* grads, long long n_params, const double* loss_part, int n_loss,
                           double l1_lambda, double* adam_m, double* adam_v, long long* step_dev,

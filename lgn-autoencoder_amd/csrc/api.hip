@@ -38,79 +38,6 @@ int lgn_level_bwd_f64(int B, int N, int C, int CO, int decoder, const double* s_
   return level_bwd_dispatch<double>(a, decoder, (hipStream_t)stream);
 }
 
-// ---- level + CGMLP -------------------------------------------------------------------------------------------------
-static int mlp_block_args(MlpArgs<double>& m, int M, int C, int H, int nlin, int activation, const double* blk) {
-  LGN_CHECK_ARG(nlin >= 2 && nlin <= MLP_MAX_LIN && blk, "level_mlp: bad CGMLP (nlin=%d)", nlin);
-  m.M = M; m.C = C; m.H = H; m.nlin = nlin; m.act = activation;
-  const int D = 2 * C;
-  size_t off = 0;
-  for (int l = 0; l < nlin; ++l) {
-    const int hin = l == 0 ? D : H, hout = l == nlin - 1 ? D : H;
-    m.w[l] = blk + off; off += (size_t)hin * hout;
-    m.b[l] = blk + off; off += hout;
-  }
-  m.psize = (int)off;
-  return 0;
-}
-
-int lgn_level_mlp_fused(int N, int C, int CO, int H, int nlin, int activation, int decoder) {
-  const int f = level_flags_from_env();
-  return (level_fwd_fuses_mlp(N, C, CO, H, nlin, activation, decoder, f) ? 1 : 0) |
-         (level_bwd_fuses_mlp(N, C, CO, H, nlin, activation, decoder, f) ? 2 : 0);
-}
-
-int lgn_level_mlp_partial_rows(int B, int N, int C, int CO, int H, int nlin, int activation, int decoder) {
-  return level_bwd_fuses_mlp(N, C, CO, H, nlin, activation, decoder, level_flags_from_env()) ? B * level_mlp_passes(N)
-                                                                                           : mlp_partial_rows(B * N, H);
-}
-
-int lgn_level_mlp_fwd_f64(int B, int N, int C, int CO, int decoder, const double* s_in, const double* v_in, const double* p,
-                          const uint8_t* mask, const double* ra, const double* rb, const double* rc, const double* w0,
-                          const double* b0, const double* w1, const double* b1, const double* wm0, const double* wm1,
-                          const double* mlp_params, int H, int nlin, int activation, double* ag0, double* ag1, double* s_pre,
-                          double* s_out, double* v_out, void* stream) {
-  LGN_CHECK_ARG(s_in && v_in && p && b0 && b1 && wm0 && wm1 && ag0 && ag1 && s_pre && s_out && v_out && mlp_params, "level_mlp_fwd: null pointer");
-  LGN_CHECK_ARG(decoder || (mask && ra && rb && rc && w0 && w1), "level_mlp_fwd: encoder needs mask and radial parameters");
-  LevelArgs<double> a{B, N, C, CO, s_in, v_in, p, mask, ra, rb, rc, w0, b0, w1, b1, wm0, wm1, ag0, ag1, s_pre, v_out};
-  a.flags = level_flags_from_env();
-  MlpArgs<double> m{};
-  if (int rc2 = mlp_block_args(m, B * N, CO, H, nlin, activation, mlp_params)) return rc2;
-  if (level_fwd_fuses_mlp(N, C, CO, H, nlin, activation, decoder, a.flags)) {
-    a.mlp.wb = mlp_params; a.mlp.H = H; a.mlp.act = activation; a.mlp.s_out = s_out;
-    return level_fwd_dispatch<double>(a, decoder, (hipStream_t)stream);
-  }
-  if (int rc2 = level_fwd_dispatch<double>(a, decoder, (hipStream_t)stream)) return rc2;
-  m.s_in = s_pre; m.s_out = s_out;
-  return mlp_dispatch<double>(m, false, (hipStream_t)stream);
-}
-
-int lgn_level_mlp_bwd_f64(int B, int N, int C, int CO, int decoder, const double* s_in, const double* v_in, const double* p,
-                          const uint8_t* mask, const double* ra, const double* rb, const double* rc, const double* w0,
-                          const double* b0, const double* w1, const double* b1, const double* wm0, const double* wm1,
-                          const double* ag0, const double* ag1, const double* mlp_params, int H, int nlin, int activation,
-                          const double* s_pre, const double* g_s_out, const double* g_v_out, double* g_ag, double* g_s_in,
-                          double* g_v_in, double* g_p, double* part_mix, double* part_rad, double* part_mlp, double* mlp_scratch,
-                          void* stream) {
-  LGN_CHECK_ARG(s_in && v_in && p && b0 && b1 && wm0 && wm1 && ag0 && ag1 && s_pre && g_s_out && g_v_out && g_ag && g_s_in &&
-                    g_v_in && part_mix && part_rad && part_mlp && mlp_params, "level_mlp_bwd: null pointer");
-  LGN_CHECK_ARG(decoder ? (g_p != nullptr) : (mask && ra && rb && rc && w0 && w1), "level_mlp_bwd: missing decoder g_p / encoder radial parameters");
-  LevelBwdArgs<double> a{B, N, C, CO, s_in, v_in, p, mask, ra, rb, rc, w0, b0, w1, b1, wm0, wm1, ag0, ag1,
-                         g_s_out, g_v_out, g_ag, g_s_in, g_v_in, g_p, part_mix, part_rad};
-  a.flags = level_flags_from_env();
-  MlpArgs<double> m{};
-  if (int rc2 = mlp_block_args(m, B * N, CO, H, nlin, activation, mlp_params)) return rc2;
-  if (level_bwd_fuses_mlp(N, C, CO, H, nlin, activation, decoder, a.flags)) {
-    a.mlp.wb = mlp_params; a.mlp.H = H; a.mlp.act = activation; a.mlp.s_pre = s_pre; a.mlp.g_out = g_s_out; a.mlp.part = part_mlp;
-    a.g_s_out = nullptr;
-    return level_bwd_dispatch<double>(a, decoder, (hipStream_t)stream);
-  }
-  LGN_CHECK_ARG(mlp_scratch, "level_mlp_bwd: this shape runs the CGMLP backward as its own launch and needs mlp_scratch");
-  m.s_in = s_pre; m.g_out = g_s_out; m.g_in = mlp_scratch; m.part = part_mlp;
-  if (int rc2 = mlp_dispatch<double>(m, true, (hipStream_t)stream)) return rc2;
-  a.g_s_out = mlp_scratch;
-  return level_bwd_dispatch<double>(a, decoder, (hipStream_t)stream);
-}
-
 int lgn_reduce_partials_f64(const double* part, int rows, int n, double* out, int accumulate, void* stream) {
   LGN_CHECK_ARG(part && out && rows > 0 && n >= 0, "reduce_partials: bad arguments");
   return reduce_partials<double>(part, rows, n, out, accumulate, (hipStream_t)stream);
@@ -141,6 +68,7 @@ int lgn_cgmlp_fwd_f64(int M, int C, int H, int nlin, int activation, const doubl
   if (int rc = fill_mlp(a, M, C, H, nlin, activation, w, b)) return rc;
   LGN_CHECK_ARG(s_in && s_out, "cgmlp_fwd: null pointer");
   a.s_in = s_in; a.s_out = s_out;
+  a.flags = level_flags_from_env();
   return mlp_dispatch<double>(a, false, (hipStream_t)stream);
 }
 
@@ -152,6 +80,7 @@ int lgn_cgmlp_bwd_f64(int M, int C, int H, int nlin, int activation, const doubl
   if (int rc = fill_mlp(a, M, C, H, nlin, activation, w, b)) return rc;
   LGN_CHECK_ARG(s_in && g_out && g_in && part, "cgmlp_bwd: null pointer");
   a.s_in = s_in; a.g_out = g_out; a.g_in = g_in; a.part = part; a.psize = psize;
+  a.flags = level_flags_from_env();
   return mlp_dispatch<double>(a, true, (hipStream_t)stream);
 }
 

@@ -27,32 +27,11 @@ namespace lgn {
 // -- every launcher and every sizing helper below receives them as an argument and none reads the environment itself.
 constexpr int LVL_DEC_PAIRWISE = 2;    // decoder levels as O(N^2) pair sweeps instead of the separable form
 constexpr int LVL_LEVEL_V2 = 4;        // three-kernel level backward also for N <= 40
-constexpr int LVL_FUSED_MLP_FWD = 8;   // CGMLP forward as the tail of the level forward kernel (mlp_dev.hpp; off by default: measured slower)
+constexpr int LVL_MLP_V1 = 8;          // CGMLP: the 12-wave kernels of mlp_mfma.hip also where the chain kernels (mlp_chain.hip) apply
+// (8 and 32 were round 4's switches of the CGMLP riding on the level kernels: built, measured slower in every regime, removed in round 5)
 constexpr int LVL_MOMENTS_V1 = 16;     // table-driven levels: component-chunked moments kernels
 constexpr int LVL_BWD_ORDERED = 64;    // encoder level backward (N <= 40): radial-gradient GEMM per ORDERED pair tile (cross-check of the symmetric sweep)
-constexpr int LVL_FUSED_MLP_BWD = 32;  // CGMLP backward as the head of the one-kernel level backward (off by default: measured slower)
 int level_flags_from_env();
-
-// The level's CGMLP (lgn/models/lgn_levels.py:191-227) riding on the level kernel (mlp_dev.hpp): forward as the tail of
-// level_fwd2_kernel, backward as the head of level_bwd3_kernel.  wb == nullptr: no CGMLP on this launch.
-template <typename T>
-struct LevelMlpArgs {
-  const T* wb = nullptr;     // the MLP's parameter block (W_0, b_0, W_1, b_1, ... W_6, b_6), contiguous (nn.Linear layouts)
-  int H = 0;                 // hidden width
-  int act = 0;               // LGN_ACT_*
-  T* s_out = nullptr;        // forward: [2][B][N][CO] scalars after the MLP (LevelArgs::s_out keeps the scalars before it)
-  const T* s_pre = nullptr;  // backward: [2][B][N][CO] scalars before the MLP (what the forward left in LevelArgs::s_out)
-  const T* g_out = nullptr;  // backward: [2][B][N][CO] gradient w.r.t. the MLP output; LevelBwdArgs::g_s_out is then not read
-  T* part = nullptr;         // backward: [B * level_mlp_passes(N)][psize] partial rows of the parameter gradients, block layout
-};
-// rows of LevelMlpArgs::part per jet: one per pass of 32 particles
-inline int level_mlp_passes(int N) { return (N + 31) / 32; }
-// Shapes the fused phase covers: one workgroup per jet (share), four waves, LeakyReLU (the reference default; the other
-// activations of get_activation_fn inline twelve transcendental branches per layer into the chain -- hundreds of spilled
-// registers -- and keep the separate CGMLP kernels, as does everything else outside this range).
-inline bool level_mlp_fusable(int N, int C, int CO, int H, int nlin, int act) {
-  return N <= 40 && C <= 4 && 2 * CO <= 16 && H >= 1 && H <= 48 && nlin == 7 && act == 0;
-}
 
 template <typename T>
 struct LevelArgs {
@@ -97,7 +76,6 @@ struct LevelArgs {
   T* loss_gv = nullptr;            // [2][B][N][CO][4] gradient w.r.t. v_out
   T* loss_wpart = nullptr;         // [B][2 CO]
   int flags = 0;                   // LVL_*
-  LevelMlpArgs<T> mlp;             // optional: the level's CGMLP as the tail of the kernel (N <= 40: level_mlp_fusable)
 };
 
 template <typename T>
@@ -125,7 +103,6 @@ struct LevelBwdArgs {
   // arithmetic) rides on this kernel, one partial row [4C] = (dW00 re, im, dW11 re, im) per workgroup like part_mix.
   T* part_in0 = nullptr;
   int flags = 0;             // LVL_*
-  LevelMlpArgs<T> mlp;       // optional: the CGMLP's backward as the head of the one-kernel backward (level_mlp_fusable)
 };
 
 // Per-node stride (in scalars) of the node tile kept in LDS: [c][ s_r s_i v_r[4] v_i[4] ] + 2 pad.

@@ -435,9 +435,6 @@ static bool use_v3(int N, int flags) { return !(flags & LVL_LEVEL_V2) && level_b
 
 // does the level backward for N-particle jets run as the one kernel that can carry the input stage's backward (LevelBwdArgs::part_in0)?
 bool level_bwd_carries_input(int N, int flags) { return use_v3(N, flags); }
-bool level_bwd_fuses_mlp(int N, int C, int CO, int H, int nlin, int act, int decoder, int flags) {
-  return (flags & LVL_FUSED_MLP_BWD) && use_v3(N, flags) && level_mlp_fusable(N, C, CO, H, nlin, act) && !(decoder && dec_pairwise(flags));
-}
 
 // number of partial rows the backward launch writes (host side must size the workspace with these)
 void level_bwd_partial_rows(int B, int N, int decoder, int flags, int* rows_mix, int* rows_rad) {
@@ -462,7 +459,6 @@ static int launch_level_bwd(const LevelBwdArgs<T>& a, hipStream_t stream) {
   const int N = a.N, CO = a.CO, tiles = cdiv(N, 32);
   int rc;
   if (use_v3(N, a.flags)) return level_bwd3_dispatch(a, DEC, stream);
-  LGN_CHECK_ARG(!a.mlp.wb, "level_bwd: the CGMLP rides on the one-kernel backward only");
   {  // 1. CatMix / power
     auto kern = level_bwd_mix_kernel<T, C>;
     size_t smem = sizeof(T) * (4 * CO * 5 * C + 32 * (5 * C * 10) + 32 * CO * 10);

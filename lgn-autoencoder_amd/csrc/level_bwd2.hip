@@ -572,8 +572,6 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2))) v
         if (w == best) load[w] += 27 * g + 11 * (ngroups - 1 - g) + 23;      // ~cycles / 100 of a full / light / diagonal tile
       if (best == wave) mine |= 1ull << g;
     }
-  } else {
-    for (int g = wave; g < ngroups; g += NWV) mine |= 1ull << g;
   }
   STAMP(0);
 
@@ -598,7 +596,8 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2))) v
     __syncthreads();
     STAMP(ilo ? 11 : 2);
     for (int rg = 0; rg < ngroups; ++rg) {
-      if (!((mine >> rg) & 1)) continue;
+      // (ordered form: round robin, computed -- not through the 64-bit mask, which only covers the 64 groups of sym's N <= 256)
+      if (sym ? !((mine >> rg) & 1) : (rg % NWV != wave)) continue;
       if (rg == 0) STAMP(ilo ? 12 : 3);
       if (rg == NWV) STAMP(ilo ? 15 : 6);
       double* gajw = gaj + wave * 4 * G::SIZE;

@@ -11,7 +11,6 @@
 //            16x16 LDS transposes -> T1|T2|S|dB GEMM on the matrix cores; decoder: bias sums and d p_j
 //   phase 3  decoder only: i-centric sweep for d p_i
 #include "level_dev.hpp"
-#include "mlp_dev.hpp"
 #include "ops.hpp"
 #include "wave_sum.hpp"
 
@@ -55,7 +54,6 @@ constexpr int TS = 18;
 LGN_STAMP_DECL
 }  // namespace
 LGN_STAMP_READER(lgn_debug_stamps_bwd3)
-FM_STAMP_READER(lgn_debug_stamps_fm_bwd)
 
 // NWV = waves per workgroup (4; 8 was measured for small batches: 31 -> 28.5 us at 64 jets -- a lone workgroup already keeps
 // its CU's SIMDs two thirds busy, the idle CUs are what a small batch wastes: level_jet_split spreads a jet over several CUs)
@@ -89,11 +87,7 @@ struct Bwd3 {
 //   stage 1   per (node, channel): the node's terms of S, VS, SP, VP (forward) and of the sums of g_ag (backward)
 //   stage 2   per (channel, term): sum over the nodes in node order
 //   outputs   node gradient, position gradient and bias gradients from O(N C) closed forms.
-// gsx_off (with a.mlp.wb): offset in doubles of the [N][2 CO] block that receives the CGMLP phase's result -- the level's upstream
-// scalar gradient -- behind both the level's LDS and the phase's (mlp_dev.hpp: bwd_doubles).
-// (amdgpu_waves_per_eu(2): two workgroups per CU is what the 77 KB of LDS are sized for; without the bound the register allocator
-// takes accumulation registers beyond 256 for the CGMLP phase -- 396 in total -- and the launch silently runs one workgroup per CU)
-// MLP: the instantiation that carries the CGMLP backward as its head -- a kernel of its own (the plain kernel pays nothing for it).
+// (amdgpu_waves_per_eu(2): two workgroups per CU is what the 77 KB of LDS are sized for)
 // SYM (encoder, whole jet in one workgroup): the radial network sees a pair only through |p_i - p_j|^2 and the masks, so R(i, j) =
 // R(j, i) and the gradient w.r.t. the pair's radial values is the SUM of what the two directed edges i <- j and j <- i send back.
 // The wave that owns the source group J therefore adds, on its tiles with receiver group I < J, the reverse edge's share (receiver
@@ -101,9 +95,9 @@ struct Bwd3 {
 // matrix instructions, with the basis rows and transposes that feed it -- on its tiles with I > J, whose share the owner of I adds.
 // 36 instead of 64 radial GEMM tiles per 30-particle jet; waves own the groups in pairs (p, G - 1 - p) so that each gets the same
 // number of them.  Node gradients flow exactly as before (every ordered tile still evaluates R and its edge).
-template <int C, bool DEC, bool SEP, int NWV, bool MLP, bool SYM = false>
-__global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2))) void level_bwd3_kernel(LevelBwdArgs<double> a, int gsx_off) {
-  static_assert(!SYM || (!DEC && !MLP), "the symmetric sweep is the encoder's");
+template <int C, bool DEC, bool SEP, int NWV, bool SYM = false>
+__global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2))) void level_bwd3_kernel(LevelBwdArgs<double> a) {
+  static_assert(!SYM || !DEC, "the symmetric sweep is the encoder's");
   using F = Bwd3<C, DEC, NWV>;
   constexpr int BLK = F::BLK;
   using G = GA3<C>;
@@ -126,18 +120,7 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2))) v
   double* wm = go + N * 10 * CO;                               //              4 * CO * K CatMix weights
   double* agl = wm + 4 * CO * K;                               //              N * 2C * 10 aggregate [n][q*C+c][s2|v8]
   double* sm = tr + F::scratch(N, CO);                         // decoder: 50 C jet-level sums
-  // the CGMLP's backward as the head of this kernel (mlp_dev.hpp): its LDS aliases everything above, its result stays in gsx
-  constexpr bool MLP_OK = MLP;
-  constexpr bool has_mlp = MLP;
-  double* gsx = reinterpret_cast<double*>(smem_raw) + gsx_off;  // [N][2 CO], feature k = 2o + z
-  uint8_t* mk = has_mlp ? reinterpret_cast<uint8_t*>(gsx + ((N * 2 * CO + 1) & ~1)) : reinterpret_cast<uint8_t*>(sm + F::SEPSZ);
-  __shared__ int fm_ids[4];
-  if constexpr (MLP_OK) {
-    if (has_mlp) {
-      const fm::BwdIo io{a.mlp.wb, a.mlp.s_pre, a.mlp.g_out, a.mlp.part, B, N, CO, a.mlp.H, b, 0, (int)blockIdx.y, (int)gridDim.y};
-      fm::bwd_phase<false>(io, reinterpret_cast<double*>(smem_raw), fm_ids, gsx);       // (LeakyReLU: level_mlp_fusable)
-    }
-  }
+  uint8_t* mk = reinterpret_cast<uint8_t*>(sm + F::SEPSZ);
 
   // ---------------- staging ----------------------------------------------------------------------------
   STAMP(0);
@@ -150,13 +133,8 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2))) v
     const int eg = tid < N * CO ? tid : 0, ea_ = tid < N * 2 * C ? tid : 0, ew = tid < 2 * CO * K ? tid : 0;
     const size_t ig = (size_t)b * N * CO + eg, ia = (size_t)b * N * 2 * C + ea_;
     double rg[10], ra[10];
-    if (has_mlp) {                                             // gsx[n][2o + z] = gsx[2 (n CO + o) + z]
-      rg[0] = gsx[2 * eg];
-      rg[1] = gsx[2 * eg + 1];
-    } else {
-      rg[0] = a.g_s_out[ig];
-      rg[1] = a.g_s_out[plo + ig];
-    }
+    rg[0] = a.g_s_out[ig];
+    rg[1] = a.g_s_out[plo + ig];
     ra[0] = a.ag0[ia];
     ra[1] = a.ag0[pa + ia];
 #pragma unroll
@@ -188,8 +166,8 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2))) v
     for (int e = tid + BLK; e < N * CO; e += BLK) {
       const size_t idx = (size_t)b * N * CO + e;
       double* g = go + e * 10;
-      g[0] = has_mlp ? gsx[2 * e] : a.g_s_out[idx];
-      g[1] = has_mlp ? gsx[2 * e + 1] : a.g_s_out[plo + idx];
+      g[0] = a.g_s_out[idx];
+      g[1] = a.g_s_out[plo + idx];
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
         g[2 + m] = a.g_v_out[idx * 4 + m];
@@ -1052,29 +1030,15 @@ bool level_bwd3_fits(int N) { return N <= 40; }
 template <int C, bool DEC, bool SEP, int NWV>
 static int launch_bwd3_w(const LevelBwdArgs<double>& a, int split, hipStream_t stream) {
   size_t smem = Bwd3<C, DEC, NWV>::smem(a.N, a.CO);
-  int gsx_off = 0;
-  if (a.mlp.wb) {
-    constexpr bool MLP_OK = C <= 4 && (!DEC || SEP) && NWV == 4;
-    LGN_CHECK_ARG(MLP_OK && level_mlp_fusable(a.N, C, a.CO, a.mlp.H, 7, a.mlp.act) && a.mlp.s_pre && a.mlp.g_out && a.mlp.part,
-                  "level_bwd: the CGMLP does not ride on this shape (N=%d C=%d CO=%d H=%d)", a.N, C, a.CO, a.mlp.H);
-    // [level data | ...] with the node mask (N bytes) last: the gradient block goes in front of the mask, behind both layouts
-    size_t lvl = (smem - a.N - 16) / sizeof(double);
-    if (lvl < (size_t)fm::bwd_doubles()) lvl = fm::bwd_doubles();
-    gsx_off = (int)((lvl + 1) & ~size_t(1));
-    smem = sizeof(double) * ((size_t)gsx_off + (((size_t)a.N * 2 * a.CO + 1) & ~size_t(1))) + a.N + 16;
-  }
   LGN_CHECK_ARG(smem <= 160 * 1024, "level_bwd: N=%d C=%d needs %zu B of LDS", a.N, a.C, smem);
   LGN_CHECK_ARG(a.CO <= 8, "level_bwd: C_out=%d unsupported (1..8)", a.CO);
-  auto kern = level_bwd3_kernel<C, DEC, SEP, NWV, false>;
-  if constexpr (C <= 4 && (!DEC || SEP) && NWV == 4) {
-    if (a.mlp.wb) kern = level_bwd3_kernel<C, DEC, SEP, NWV, true>;
-  }
+  auto kern = level_bwd3_kernel<C, DEC, SEP, NWV>;
   if constexpr (!DEC && C <= 4) {       // whole jets per workgroup: the sweep that uses R(i, j) = R(j, i) (LVL_BWD_ORDERED: the plain one;
                                         // C > 4: two lane groups of channels, the second pass would double the spills)
-    if (!a.mlp.wb && split == 1 && !(a.flags & LVL_BWD_ORDERED)) kern = level_bwd3_kernel<C, DEC, SEP, NWV, false, true>;
+    if (split == 1 && !(a.flags & LVL_BWD_ORDERED)) kern = level_bwd3_kernel<C, DEC, SEP, NWV, true>;
   }
   if (smem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  hipLaunchKernelGGL(kern, dim3(a.B, split), dim3(64 * NWV), smem, stream, a, gsx_off);
+  hipLaunchKernelGGL(kern, dim3(a.B, split), dim3(64 * NWV), smem, stream, a);
   LGN_CHECK_LAUNCH();
   return 0;
 }

@@ -17,7 +17,6 @@
 //  * the aggregate of the whole jet is collected in LDS; after one barrier all 256 threads write it out (it is saved
 //    for the backward) and run CatMix over the items (row, out channel, component).
 #include "level_dev.hpp"
-#include "mlp_dev.hpp"
 #include "net_dev.hpp"
 #include "ops.hpp"
 #include "wave_sum.hpp"
@@ -27,7 +26,6 @@ namespace lgn {
 typedef double v4d __attribute__((ext_vector_type(4)));
 LGN_STAMP_DECL
 LGN_STAMP_READER(lgn_debug_stamps_fwd2)
-FM_STAMP_READER(lgn_debug_stamps_fm_fwd)
 
 __device__ __forceinline__ double dpp_quad(double v, int ctrl_is_xor2) {
   // quad_perm [1,0,3,2] = 0xB1 (xor 1), [2,3,0,1] = 0x4E (xor 2)
@@ -70,11 +68,8 @@ struct Fwd2 {
 //   A1_i = e0 sum_j v_j            A2_i = R1 (p_i sum_j s_j - sum_j s_j p_j)
 //   A4_i = e0 sum_j s_j            A3_i = R1 (<sum_j v_j, p_i> - sum_j <v_j, p_j>) / 2
 // O(N C) instead of O(N^2 C) work per jet, same values up to summation order.  SEP = false keeps the pair sweep.
-// MLP: the instantiation that carries the level's CGMLP as its tail (a.mlp, mlp_dev.hpp) -- a kernel of its own, so that the plain
-// level kernel pays nothing for it (measured: 0.4 - 1.2 us per launch when the phase was a run-time branch of one kernel).
-// mlp_off (MLP): offset in doubles of the CGMLP phase's own LDS (images of the first two layers | MLP input rows) behind the level's.
-template <int C, bool DEC, bool SEP, bool MLP>
-__global__ __launch_bounds__(2 * BLOCK) void level_fwd2_kernel(LevelArgs<double> a, int chunk, int mlp_off) {
+template <int C, bool DEC, bool SEP>
+__global__ __launch_bounds__(2 * BLOCK) void level_fwd2_kernel(LevelArgs<double> a, int chunk) {
   using F = Fwd2<C, DEC>;
   constexpr int NG = F::NG;
   const int N = a.N, B = a.B, CO = a.CO;
@@ -88,26 +83,8 @@ __global__ __launch_bounds__(2 * BLOCK) void level_fwd2_kernel(LevelArgs<double>
   double* agl = wm + 4 * CO * 5 * C;                                  // chunk rows * AGS: aggregate of a chunk of rows
   double* sums = agl + chunk * F::AGS;                                // 20 C: jet-level sums of the separable form
   uint8_t* mk = reinterpret_cast<uint8_t*>(sums + 20 * C);            // N
-  // the level's CGMLP as the tail of this kernel (mlp_dev.hpp; the host launches it for one-chunk, four-wave shapes only)
-  constexpr bool MLP_OK = MLP;
-  constexpr bool has_mlp = MLP;
-  double* fimg0 = reinterpret_cast<double*>(smem_raw) + mlp_off;       // first-layer image
-  double* fimg1 = fimg0 + fm::IMG0;                                    // second-layer image
-  double* fx0 = fimg1 + fm::IMG;                                       // MLP input rows [row][S0]
-  __shared__ int fm_ids[4];
-  fm::W0Regs<4> fw0;
-  fm::WRegs<4> fw1;
-  const fm::Dims md = fm::make_dims(2 * CO, a.mlp.H);
 
   STAMP(0);
-  if constexpr (MLP_OK) {
-    if (has_mlp) {
-      fm::stage0_issue<4>(a.mlp.wb, md, wave, lane, fw0);
-      fm::stage_issue<4>(a.mlp.wb, 1, md, wave, lane, fw1);
-      fm::role_publish(fm_ids, wave, lane);
-      for (int e = tid; e < fm::passes(N) * fm::ROWS * fm::S0; e += nthr) fx0[e] = 0.0;
-    }
-  }
   if (!DEC && a.in_w0) {
     // first encoder level of a fused network: input features from the momenta (see LevelArgs::in_w0), buffers to clear
     {
@@ -201,12 +178,6 @@ __global__ __launch_bounds__(2 * BLOCK) void level_fwd2_kernel(LevelArgs<double>
     for (int q = 0; q < 4; ++q) {
       const double* bb = (q >> 1) ? a.b1 : a.b0;
       bias[g][q] = ch < C ? (DEC ? bb[ch] : bb[2 * ch + (q & 1)]) : 0.0;
-    }
-  }
-  if constexpr (MLP_OK) {
-    if (has_mlp) {
-      fm::stage0_commit<4>(fimg0, wave, lane, fw0);
-      fm::stage_commit<4>(fimg1, 1, wave, lane, fw1);
     }
   }
   __syncthreads();
@@ -309,12 +280,6 @@ __global__ __launch_bounds__(2 * BLOCK) void level_fwd2_kernel(LevelArgs<double>
           const size_t e = ((size_t)b * N + r) * CO + o;
           a.s_out[e] = acc.r;
           a.s_out[plo + e] = acc.i;
-          if constexpr (MLP_OK) {
-            if (has_mlp) {                                    // the MLP's input row, feature k = 2o + z
-              fx0[rl * fm::S0 + 2 * o] = acc.r;
-              fx0[rl * fm::S0 + 2 * o + 1] = acc.i;
-            }
-          }
         }
       }
     } else {
@@ -557,28 +522,9 @@ __global__ __launch_bounds__(2 * BLOCK) void level_fwd2_kernel(LevelArgs<double>
   }
   STAMP(21);
 
-  if constexpr (MLP_OK) {
-    if (has_mlp) break;                                  // (one chunk) the CatMix runs below, with the CGMLP's weights in flight
-  }
   catmix(c0, c1);
   STAMP(22);
   if (c1 < rhi) __syncthreads();                         // the chunk's aggregate rows are reused
-  }
-  if constexpr (MLP_OK) {
-    if (has_mlp) {     // (one chunk: local row = row - rlo.  Outside the chunk loop: inside it, every lane-derived address of the phase
-                       //  is hoisted in front of the pair sweep as a loop invariant and spills there)
-      fm::WRegs<4> fw2, fw3;                             // W_2, W_3 arrive under the CatMix
-      fm::stage_issue<4>(a.mlp.wb, 2, md, wave, lane, fw2);
-      fm::stage_issue<4>(a.mlp.wb, 3, md, wave, lane, fw3);
-      catmix(rlo, rhi);
-      STAMP(22);
-      __syncthreads();                                   // the MLP input rows are complete; the level's LDS is dead
-      const int role = fm::role_resolve(fm_ids, wave);
-      double* so = a.mlp.s_out + ((size_t)b * N + rlo) * CO;
-      double* img = reinterpret_cast<double*>(smem_raw);
-      const size_t plm = (size_t)B * N * CO;
-      fm::fwd_phase<false>(a.mlp.wb, md, 0, img, fimg0, fimg1, fx0, rhi - rlo, fw2, fw3, role, so, plm, CO);   // (LeakyReLU: level_mlp_fusable)
-    }
   }
   STAMP(40);
   if constexpr (DEC) {
@@ -608,27 +554,13 @@ static int launch_level_fwd2(const LevelArgs<double>& a, hipStream_t stream) {
     if (chunk < 16) chunk = 16;
   }
   size_t smem = fixed + chunk * row;
-  // the CGMLP phase: two weight images over the level's (then dead) data, first-layer image + input rows behind them
-  int mlp_off = 0;
-  if (a.mlp.wb) {
-    constexpr bool MLP_OK = C <= 4 && (!DEC || SEP);
-    LGN_CHECK_ARG(MLP_OK && level_mlp_fusable(a.N, C, a.CO, a.mlp.H, 7, a.mlp.act) && chunk == full && !wide && a.mlp.s_out,
-                  "level_fwd: the CGMLP does not ride on this shape (N=%d C=%d CO=%d H=%d)", a.N, C, a.CO, a.mlp.H);
-    size_t base = (smem + 15) & ~size_t(15);
-    if (base < sizeof(double) * fm::fwd_alias_doubles()) base = sizeof(double) * fm::fwd_alias_doubles();
-    mlp_off = (int)(base / sizeof(double));
-    smem = base + sizeof(double) * fm::fwd_own_doubles(a.N);
-  }
   if (a.loss_wo1) {
     LGN_CHECK_ARG(DEC && SEP && a.N <= 40 && !wide && a.loss_target && a.loss_recon && a.loss_part && a.loss_gv && a.loss_wpart,
                   "level_fwd: the loss rides on the separable decoder forward of jets of <= 40 particles only");
     if (smem < dec_out_loss_bytes(a.N, a.CO)) smem = dec_out_loss_bytes(a.N, a.CO);
   }
   LGN_CHECK_ARG(smem <= 160 * 1024, "level_fwd: N=%d C=%d needs %zu B of LDS (> 160 KiB)", a.N, a.C, smem);
-  auto kern = level_fwd2_kernel<C, DEC, SEP, false>;
-  if constexpr (C <= 4 && (!DEC || SEP)) {
-    if (a.mlp.wb) kern = level_fwd2_kernel<C, DEC, SEP, true>;
-  }
+  auto kern = level_fwd2_kernel<C, DEC, SEP>;
   if (smem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
@@ -637,15 +569,12 @@ static int launch_level_fwd2(const LevelArgs<double>& a, hipStream_t stream) {
   const int nthreads = wide ? 2 * BLOCK : BLOCK;
   // small batches of small jets: several workgroups per jet, each with its own rows (level.hpp: level_jet_split)
   const int split = (SEP || a.N > 40) ? 1 : level_jet_split(a.B, a.N);
-  hipLaunchKernelGGL(kern, dim3(a.B, split), dim3(nthreads), smem, stream, a, chunk, mlp_off);
+  hipLaunchKernelGGL(kern, dim3(a.B, split), dim3(nthreads), smem, stream, a, chunk);
   LGN_CHECK_LAUNCH();
   return 0;
 }
 
 bool level_fwd_carries_loss(int N, int flags) { return N <= 40 && !(flags & LVL_DEC_PAIRWISE); }
-bool level_fwd_fuses_mlp(int N, int C, int CO, int H, int nlin, int act, int decoder, int flags) {
-  return (flags & LVL_FUSED_MLP_FWD) && level_mlp_fusable(N, C, CO, H, nlin, act) && !(decoder && (flags & LVL_DEC_PAIRWISE));
-}
 
 template <>
 int level_fwd_dispatch<double>(const LevelArgs<double>& a, int decoder, hipStream_t stream) {

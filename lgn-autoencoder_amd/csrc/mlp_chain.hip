@@ -588,8 +588,7 @@ static int launch(const MlpArgs<double>& a, bool backward, hipStream_t stream) {
 
 // The reference widths H = 6 * 2C (C = 1 .. 4) at batches that run 64-row workgroups, activations recomputed; -2 = not this kernel's shape.
 int mlp_chain_dispatch(const MlpArgs<double>& a, bool backward, hipStream_t stream) {
-  static const bool off = [] { const char* e = getenv("LGN_AMD_MLP_V1"); return e && e[0] == '1'; }();
-  if (off || a.nlin != 7 || mlp_rows_per_workgroup(a.M, a.H) != 64) return -2;
+  if ((a.flags & LVL_MLP_V1) || a.nlin != 7 || mlp_rows_per_workgroup(a.M, a.H) != 64) return -2;
   if (a.H == 48 && a.C == 4) return chain::launch<48, 8>(a, backward, stream);
   if (a.H == 36 && a.C == 3) return chain::launch<36, 6>(a, backward, stream);
   if (a.H == 24 && a.C == 2) return chain::launch<24, 4>(a, backward, stream);

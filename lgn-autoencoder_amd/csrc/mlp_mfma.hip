@@ -330,7 +330,7 @@ __global__ __launch_bounds__(64 * MT * NT) void mlp_bwd_mfma_kernel(MlpArgs<doub
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int o = 16 * t + g + 4 * r;
-          if (o < Hout && k < Hin) pW[o * Hin + k] = acc0[r] + acc1[r];
+          if (o < Hout && k < Hin) __builtin_nontemporal_store(acc0[r] + acc1[r], &pW[o * Hin + k]);   // (read once, by the reduction at the end of the step)
         }
       }
       const double* dq = dbw + q * MT * HP;
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(64 * MT * NT) void mlp_bwd_mfma_kernel(MlpArgs<doub
         double v = dq[tid];
 #pragma unroll
         for (int w = 1; w < MT; ++w) v += dq[w * HP + tid];
-        pB[tid] = v;
+        __builtin_nontemporal_store(v, &pB[tid]);
       }
     }
     // next layer down

@@ -306,7 +306,7 @@ __global__ __launch_bounds__(64 * MT * NT) void mlp_bwd_wide_kernel(MlpArgs<doub
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int o = 16 * t + g + 4 * r;
-          if (o < Hout && k < Hin) pW[o * Hin + k] = acc0[r] + acc1[r];
+          if (o < Hout && k < Hin) __builtin_nontemporal_store(acc0[r] + acc1[r], &pW[o * Hin + k]);
         }
       }
       if (tid < Hout) pB[tid] = (dbw[tid] + dbw[HP + tid]) + (dbw[2 * HP + tid] + dbw[3 * HP + tid]);

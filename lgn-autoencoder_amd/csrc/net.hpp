@@ -53,6 +53,10 @@ int chamfer_fwd(int B, int N, int M, const double* x, const double* y, int jet_f
 // decoder output without the loss (module API): recon [2][B][N][4]; backward from g_recon, part [B][2C]
 int dec_output_fwd(int B, int N, int C, const double* v, const double* wo1, double* recon, hipStream_t);
 int dec_output_bwd(int B, int N, int C, const double* v, const double* wo1, const double* g_recon, double* g_v, double* part, hipStream_t);
+// LDS bytes of the largest per-jet end stage (plan-time fit queries; net_kernels.hip)
+size_t encoder_end_lds_bytes(int N, int C0, int K, int CL, int Ts, int Tv, int pool);
+size_t decoder_end_lds_bytes(int N, int C0, int Tin, int CL);
+size_t junction_lds_bytes(int N, int CL, int Ts, int Tv, int pool, int C0);
 int finalize_step(double* w, double* g, long n, const double* loss_part, int nB, double lambda, double* m, double* v, long* step_dev,
                   double lr, double beta1, double beta2, double eps, int do_adam, double* loss_out, hipStream_t st);
 // LocalArgs from the C-ABI table struct (shared by api.hip and step.hip)

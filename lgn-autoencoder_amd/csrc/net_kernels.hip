@@ -1061,24 +1061,41 @@ __global__ __launch_bounds__(BLOCK) void dec_output_bwd_kernel(int B, int N, int
 // ============================================================================================
 // g += lambda * sign(w); Adam update (torch.optim.Adam defaults: no weight decay, no amsgrad).  The same pass adds up
 // |w| of the weights BEFORE the update (the L1 term of this step's loss) into one partial per workgroup.
-// The optimiser step counter lives on the device (graph replays stay correct): this step is number *step_dev + 1.
+// The optimiser step counter lives on the device (graph replays stay correct): this step is number t = *step_dev + 1.
 // The LAST workgroup to finish (a counter in the scratch block, bumped behind a device-scope fence) also assembles the loss
 // -- loss_out[0] = chamfer + lambda * sum|w|, loss_out[1] = chamfer, loss_out[2] = sum|w| -- from the per-jet terms and the
 // per-workgroup |w| sums IN INDEX ORDER (the result does not depend on which workgroup that was), bumps the device-side step
-// counter (every workgroup read it at its start) and clears the counter for the next replay: one launch instead of two
-// (round 4; the second launch was 4 us of the 64-jet step for a 512-term sum).
+// counter (every workgroup read it at its start) and clears the counter for the next replay: one launch instead of two.
+// Round 5 (the kernel took 11.7 us for 63 k parameters at ANY batch): the bias corrections 1 - beta^t were two fp64 pow() per
+// THREAD; now one thread per workgroup takes beta1^t, beta2^t from the scratch block, where the previous step's last workgroup
+// left them (slot t & 1 = {t, beta1^t, beta2^t}: written during step t - 1, read during step t, so no workgroup of a launch can
+// see its own launch's update), and falls back to pow() when the slot does not name this step (first step, restored counter);
+// four parameters per thread, a quarter of the workgroups at the counter.
+constexpr int ADAM_PER_THREAD = 4;
 __global__ __launch_bounds__(BLOCK) void l1_adam_kernel(long n, double* w, double* g, double* m, double* v, double lambda, double lr,
                                                        double beta1, double beta2, double eps, long* step_dev, int do_adam,
-                                                       double* l1_part, unsigned long long* done, const double* __restrict__ loss_part,
-                                                       int nB, double* loss_out) {
+                                                       double* l1_part, double* powers, unsigned long long* done,
+                                                       const double* __restrict__ loss_part, int nB, double* loss_out) {
   __shared__ double red[4];
+  __shared__ double bc[4];
   __shared__ int last;
-  double bc1 = 1.0, bc2_sqrt = 1.0;
-  if (do_adam) {
-    const double t = (double)(*step_dev + 1);
-    bc1 = 1.0 - pow(beta1, t);
-    bc2_sqrt = sqrt(1.0 - pow(beta2, t));
+  if (threadIdx.x == 0) {
+    bc[0] = bc[1] = bc[2] = bc[3] = 1.0;
+    if (do_adam) {
+      const long ti = *step_dev + 1;
+      const double t = (double)ti;
+      const double* slot = powers + 3 * (ti & 1);
+      double p1, p2;
+      if (slot[0] == t) { p1 = slot[1]; p2 = slot[2]; }
+      else { p1 = pow(beta1, t); p2 = pow(beta2, t); }
+      bc[0] = 1.0 - p1;
+      bc[1] = sqrt(1.0 - p2);
+      bc[2] = p1;
+      bc[3] = p2;
+    }
   }
+  __syncthreads();
+  const double bc1 = bc[0], bc2_sqrt = bc[1];
   double l1 = 0.0;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const double wi = w[i];
@@ -1112,7 +1129,14 @@ __global__ __launch_bounds__(BLOCK) void l1_adam_kernel(long n, double* w, doubl
     loss_out[0] = l + lambda * a;
     loss_out[1] = l;
     loss_out[2] = a;
-    if (do_adam) *step_dev += 1;
+    if (do_adam) {
+      const long tn = *step_dev + 2;                       // the NEXT step's number and powers, into the slot it will read
+      double* slot = powers + 3 * (tn & 1);
+      slot[1] = bc[2] * beta1;
+      slot[2] = bc[3] * beta2;
+      slot[0] = (double)tn;
+      *step_dev += 1;
+    }
     *done = 0ull;
   }
 }
@@ -1204,6 +1228,37 @@ int chamfer_fwd(int B, int N, int M, const double* x, const double* y, int jet_f
   LGN_CHECK_LAUNCH();
   return 0;
 }
+// Plan-time fit queries (lgn_encoder_end_lds_bytes / lgn_decoder_end_lds_bytes / lgn_junction_lds_bytes): the LDS the per-jet end
+// stages of a network need, from the same expressions as the launchers above -- so that the callers choose the per-operator path
+// BEFORE the first launch instead of failing at it (a jet's latent stage is one workgroup: N C (Ts + Tv) grows past 160 KiB for
+// 150-particle jets with three pooled blocks).
+size_t encoder_end_lds_bytes(int N, int C0, int K, int CL, int Ts, int Tv, int pool) {
+  pool = pool_canon(pool);
+  size_t m = sizeof(double) * (size_t)N * C0 * (2 * K + 2);                                   // enc_input_bwd
+  const size_t f = sizeof(double) * lat_fwd_doubles(N, CL, Ts, Tv, pool), b = sizeof(double) * lat_bwd_doubles(N, CL, Ts, Tv, pool);
+  m = f > m ? f : m;
+  return b > m ? b : m;
+}
+size_t decoder_end_lds_bytes(int N, int C0, int Tin, int CL) {
+  size_t m = sizeof(double) * dec_in_fwd_doubles(N, C0, Tin);
+  const size_t b = sizeof(double) * dec_in_bwd_doubles(N, C0, Tin), o = dec_out_loss_bytes(N, CL),
+               ob = sizeof(double) * ((size_t)N * 8 + (size_t)N * CL * 2);
+  m = b > m ? b : m;
+  m = o > m ? o : m;
+  return ob > m ? ob : m;
+}
+size_t junction_lds_bytes(int N, int CL, int Ts, int Tv, int pool, int C0) {
+  pool = pool_canon(pool);
+  const int Tin = pool_blocks(pool) * Tv;
+  const size_t nl = lat_fwd_doubles(N, CL, Ts, Tv, pool), nd = dec_in_fwd_doubles(N, C0, Tin), ny = lat_y_doubles(N, Ts, Tv, pool);
+  const bool ov = sizeof(double) * (nl + nd) <= 64 * 1024;
+  const size_t fwd = sizeof(double) * (ov ? nl + nd : ny + (nl - ny > nd ? nl - ny : nd) + (pool_is_mix(pool) ? (size_t)Tin * 8 : 0));
+  const size_t bd = dec_in_bwd_doubles(N, C0, Tin), bl = lat_bwd_doubles(N, CL, Ts, Tv, pool);
+  const bool ovb = sizeof(double) * (bd + bl + (size_t)Tin * 8) <= 64 * 1024;
+  const size_t bwd = sizeof(double) * ((ovb ? bd + bl : (bd > bl ? bd : bl)) + (size_t)Tin * 8);
+  return fwd > bwd ? fwd : bwd;
+}
+
 int dec_output_bwd(int B, int N, int C, const double* v, const double* wo1, const double* g_recon, double* g_v, double* part,
                    hipStream_t st) {
   const size_t smem = sizeof(double) * ((size_t)N * 8 + (size_t)N * C * 2);
@@ -1251,14 +1306,16 @@ int junction_bwd(int B, int N, int C0, int Tin, const double* lat_v, const doubl
 // loss_out: 3 results followed by LGN_FINALIZE_SCRATCH doubles of scratch (per-workgroup |w| partials)
 int finalize_step(double* w, double* g, long n, const double* loss_part, int nB, double lambda, double* m, double* v, long* step_dev,
                   double lr, double beta1, double beta2, double eps, int do_adam, double* loss_out, hipStream_t st) {
-  // scratch behind the 3 results: [0, nblk) per-workgroup |w| sums, last slot = the finished-workgroup counter (zero between calls:
-  // the caller allocates the block zero-filled, the kernel clears it again)
-  int nblk = grid_for((size_t)n);
-  if (nblk > LGN_FINALIZE_SCRATCH - 1) nblk = LGN_FINALIZE_SCRATCH - 1;
+  // scratch behind the 3 results: [0, nblk) per-workgroup |w| sums; the last slot = the finished-workgroup counter (zero between
+  // calls: the caller allocates the block zero-filled, the kernel clears it again -- a launch that faulted part-way leaves it dirty:
+  // re-zero the block before reusing it); the six slots before it = {t, beta1^t, beta2^t} for the next odd / even step
+  int nblk = grid_for(((size_t)n + ADAM_PER_THREAD - 1) / ADAM_PER_THREAD);
+  if (nblk > LGN_FINALIZE_SCRATCH - 8) nblk = LGN_FINALIZE_SCRATCH - 8;
   double* l1_part = loss_out + 3;
+  double* powers = loss_out + 3 + LGN_FINALIZE_SCRATCH - 7;
   unsigned long long* done = reinterpret_cast<unsigned long long*>(loss_out + 3 + LGN_FINALIZE_SCRATCH - 1);
   hipLaunchKernelGGL(l1_adam_kernel, dim3(nblk), dim3(BLOCK), 0, st, n, w, g, m, v, lambda, lr, beta1, beta2, eps, step_dev, do_adam,
-                     l1_part, done, loss_part, nB, loss_out);
+                     l1_part, powers, done, loss_part, nB, loss_out);
   LGN_CHECK_LAUNCH();
   return 0;
 }

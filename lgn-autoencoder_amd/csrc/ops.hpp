@@ -34,8 +34,6 @@ bool level_bwd_carries_input(int N, int flags);   // the encoder's first level m
 bool level_fwd_carries_loss(int N, int flags);    // the decoder's last level may take LevelArgs::loss_* (separable one-workgroup-per-jet forward)
 // does the level's CGMLP ride on the level kernel (LevelArgs::mlp / LevelBwdArgs::mlp)?  The forward and the backward decide
 // independently (the forward always leaves the scalars before AND after the MLP)
-bool level_fwd_fuses_mlp(int N, int C, int CO, int H, int nlin, int act, int decoder, int flags);
-bool level_bwd_fuses_mlp(int N, int C, int CO, int H, int nlin, int act, int decoder, int flags);
 
 // ---- CGMLP (mlp.hip / mlp_mfma.hip) ------------------------------------------------------------------
 constexpr int MLP_MAX_LIN = 8;
@@ -66,6 +64,7 @@ struct MlpArgs {
   T* h_saved = nullptr;
   int h_rows = 0;
   int act = 0;      // LGN_ACT_* (include/lgn_amd.h): activation after all but the last Linear
+  int flags = 0;    // LVL_* (level.hpp): LVL_MLP_V1 keeps the 12-wave kernels
 };
 inline int mlp_saved_rows(int M) { return (M + 63) & ~63; }
 inline size_t mlp_saved_doubles(int M, int H, int nlin) {

@@ -131,17 +131,10 @@ int attach_side(Deferred& dq, void* side_stream) {
   return 0;
 }
 
-// does level l's CGMLP ride on the level kernels (forward tail / backward head; mlp_dev.hpp)?  One answer per descriptor.
-bool fuses_mlp(const lgn_net_desc& d, bool dec, int l, bool backward) {
-  const int* ch = dec ? d.dec_channels : d.enc_channels;
-  const int H = d.mlp_hidden_mul * 2 * ch[l + 1];
-  return backward ? level_bwd_fuses_mlp(d.N, ch[l], ch[l + 1], H, d.mlp_nlin, d.activation, dec, d.flags)
-                  : level_fwd_fuses_mlp(d.N, ch[l], ch[l + 1], H, d.mlp_nlin, d.activation, dec, d.flags);
-}
-// partial rows of level l's CGMLP weight gradients: one per jet and pass when it rides on the level backward
+// partial rows of level l's CGMLP weight gradients
 size_t mlp_part_rows(const lgn_net_desc& d, bool dec, int l) {
   const int* ch = dec ? d.dec_channels : d.enc_channels;
-  return fuses_mlp(d, dec, l, true) ? (size_t)d.B * level_mlp_passes(d.N) : (size_t)mlp_partial_rows(d.B * d.N, d.mlp_hidden_mul * 2 * ch[l + 1]);
+  return (size_t)mlp_partial_rows(d.B * d.N, d.mlp_hidden_mul * 2 * ch[l + 1]);
 }
 
 inline int in_K(const lgn_net_desc& d) { return d.n_in_scalars > 1 ? d.n_in_scalars : 1; }      // encoder input scalars per node
@@ -169,7 +162,7 @@ Work carve(const lgn_net_desc& d, double* base) {
       n.ag1[l] = b.take(16 * BN * ch[l]);
       // the last level's scalars never reach the loss: its CGMLP has no backward
       // (a CGMLP that rides on the level kernels recomputes: nothing kept)
-      const size_t hs = l + 1 < L && BN <= mlp_save_max_rows() && !fuses_mlp(d, dec, l, false)
+      const size_t hs = l + 1 < L && BN <= mlp_save_max_rows()
                             ? mlp_saved_doubles((int)BN, d.mlp_hidden_mul * 2 * ch[l + 1], d.mlp_nlin) : 0;
       n.hsave[l] = hs ? b.take(hs) : nullptr;
     }
@@ -272,14 +265,9 @@ int levels_fwd(const lgn_net_desc& d, bool dec, const int* ch, const double* P, 
       a.loss_part = loss->loss_part; a.loss_gv = loss->g_v; a.loss_wpart = loss->wpart;
     }
     a.flags = d.flags;
-    if (fuses_mlp(d, dec, l, false)) {        // the CGMLP is the tail of the level kernel (parameters contiguous: checked at plan time)
-      a.mlp.wb = p(S.mlp(dec, l, 0)); a.mlp.H = d.mlp_hidden_mul * 2 * ch[l + 1]; a.mlp.act = d.activation; a.mlp.s_out = n.s[l + 1];
-      LGN_TRY(level_fwd_dispatch<double>(a, dec, st));
-      continue;
-    }
     LGN_TRY(level_fwd_dispatch<double>(a, dec, st));
     MlpArgs<double> m{};
-    m.M = d.B * d.N; m.C = ch[l + 1]; m.H = d.mlp_hidden_mul * 2 * ch[l + 1]; m.nlin = d.mlp_nlin; m.act = d.activation;
+    m.M = d.B * d.N; m.C = ch[l + 1]; m.H = d.mlp_hidden_mul * 2 * ch[l + 1]; m.nlin = d.mlp_nlin; m.act = d.activation; m.flags = d.flags;
     for (int q = 0; q < d.mlp_nlin; ++q) { m.w[q] = p(S.mlp(dec, l, 2 * q)); m.b[q] = p(S.mlp(dec, l, 2 * q + 1)); }
     m.s_in = n.smix[l]; m.s_out = n.s[l + 1];
     m.h_saved = n.hsave[l]; m.h_rows = mlp_saved_rows(m.M);
@@ -304,13 +292,12 @@ int levels_bwd(const lgn_net_desc& d, bool dec, const int* ch, const double* P, 
     auto g = [&](int slot) { return G + off[slot]; };
     const int C = ch[l], CO = ch[l + 1];
     const double* g_smix = w.zeros_s;
-    const bool ride = has_s_grad && fuses_mlp(d, dec, l, true);
-    if (has_s_grad && !ride) {
+    if (has_s_grad) {
       MlpArgs<double> m{};
-      m.M = BN; m.C = CO; m.H = d.mlp_hidden_mul * 2 * CO; m.nlin = d.mlp_nlin; m.act = d.activation;
+      m.M = BN; m.C = CO; m.H = d.mlp_hidden_mul * 2 * CO; m.nlin = d.mlp_nlin; m.act = d.activation; m.flags = d.flags;
       for (int q = 0; q < d.mlp_nlin; ++q) { m.w[q] = p(S.mlp(dec, l, 2 * q)); m.b[q] = p(S.mlp(dec, l, 2 * q + 1)); }
       m.s_in = n.smix[l]; m.g_out = w.gs[cur]; m.g_in = w.gsmix;
-      m.h_saved = fuses_mlp(d, dec, l, false) ? nullptr : n.hsave[l];     // (a riding forward keeps no hidden activations)
+      m.h_saved = n.hsave[l];
       m.h_rows = mlp_saved_rows(BN);
       m.psize = mlp_psize(CO, m.H, m.nlin);
       DQ_TAKE(m.part, (size_t)mlp_partial_rows(BN, m.H) * m.psize);
@@ -332,14 +319,6 @@ int levels_bwd(const lgn_net_desc& d, bool dec, const int* ch, const double* P, 
     const bool carry_in0 = !dec && l == 0 && in0_grads && level_bwd_carries_input(d.N, d.flags);
     if (carry_in0) { DQ_TAKE(a.part_in0, (size_t)rm * 4 * C); }
     a.flags = d.flags;
-    if (ride) {          // the CGMLP's backward is the head of the level kernel: gs[cur] is the gradient w.r.t. the MLP OUTPUT
-      const int H = d.mlp_hidden_mul * 2 * CO, psz = mlp_psize(CO, H, d.mlp_nlin);
-      const size_t rows = mlp_part_rows(d, dec, l);
-      a.mlp.wb = p(S.mlp(dec, l, 0)); a.mlp.H = H; a.mlp.act = d.activation; a.mlp.s_pre = n.smix[l]; a.mlp.g_out = w.gs[cur];
-      DQ_TAKE(a.mlp.part, rows * psz);
-      a.g_s_out = nullptr;
-      dq.add(a.mlp.part, (int)rows, psz, 0, psz, g(S.mlp(dec, l, 0)));
-    }
     LGN_TRY(level_bwd_dispatch<double>(a, dec, st));
     if (carry_in0) {
       dq.add(a.part_in0, rm, 4 * C, 0, 2 * C, in0_grads[0]);
@@ -597,7 +576,7 @@ int gen_levels_fwd(const lgn_net_desc& d, bool dec, const double* P, const int64
       LGN_TRY(local_fwd(la, st));
     }
     MlpArgs<double> mm{};
-    mm.M = BN; mm.C = g.ch[l + 1]; mm.H = d.mlp_hidden_mul * 2 * g.ch[l + 1]; mm.nlin = d.mlp_nlin; mm.act = d.activation;
+    mm.M = BN; mm.C = g.ch[l + 1]; mm.H = d.mlp_hidden_mul * 2 * g.ch[l + 1]; mm.nlin = d.mlp_nlin; mm.act = d.activation; mm.flags = d.flags;
     for (int q = 0; q < d.mlp_nlin; ++q) { mm.w[q] = P + off[S.mlp(dec, l, 2 * q)]; mm.b[q] = P + off[S.mlp(dec, l, 2 * q + 1)]; }
     mm.s_in = a.smix[l];
     if (tb) { mm.s_out = a.X[l + 1] + (size_t)g.qs[l + 1] * 128; mm.tbQ = g.Q[l + 1]; }
@@ -626,7 +605,7 @@ int gen_levels_bwd(const lgn_net_desc& d, bool dec, const double* P, double* G, 
     const int C = g.ch[l], CO = g.ch[l + 1];
     if (has_s_grad) {     // CGMLP backward, in place on the scalar column of the gradient
       MlpArgs<double> m{};
-      m.M = BN; m.C = CO; m.H = d.mlp_hidden_mul * 2 * CO; m.nlin = d.mlp_nlin; m.act = d.activation;
+      m.M = BN; m.C = CO; m.H = d.mlp_hidden_mul * 2 * CO; m.nlin = d.mlp_nlin; m.act = d.activation; m.flags = d.flags;
       for (int q = 0; q < d.mlp_nlin; ++q) { m.w[q] = P + off[S.mlp(dec, l, 2 * q)]; m.b[q] = P + off[S.mlp(dec, l, 2 * q + 1)]; }
       m.s_in = a.smix[l];
       if (tb) { m.g_out = sc.gX[cur] + (size_t)g.qs[l + 1] * 128; m.g_in = sc.gX[cur] + (size_t)g.qs[l + 1] * 128; m.tbQ = g.Q[l + 1]; }
@@ -872,7 +851,7 @@ NetAct carve_act(const lgn_net_desc& d, bool dec, double* base) {
     a.n.ag0[l] = b.take(4 * BN * ch[l]);
     a.n.ag1[l] = b.take(16 * BN * ch[l]);
     // (the caller's upstream gradient may reach every level)
-    const size_t hs = BN <= mlp_save_max_rows() && !fuses_mlp(d, dec, l, false)
+    const size_t hs = BN <= mlp_save_max_rows()
                           ? mlp_saved_doubles((int)BN, d.mlp_hidden_mul * 2 * ch[l + 1], d.mlp_nlin) : 0;
     a.n.hsave[l] = hs ? b.take(hs) : nullptr;
   }
@@ -1132,6 +1111,14 @@ extern "C" {
 int lgn_step_param_slots(const lgn_net_desc* d, int decoder) {
   if (check_desc(d)) return -1;
   return Slots{d->n_levels, d->mlp_nlin}.count(decoder != 0);
+}
+
+long long lgn_encoder_end_lds_bytes(int N, int C0, int K, int CL, int Ts, int Tv, int pool) {
+  return pool_valid(pool) ? (long long)encoder_end_lds_bytes(N, C0, K < 1 ? 1 : K, CL, Ts, Tv, pool) : -1;
+}
+long long lgn_decoder_end_lds_bytes(int N, int C0, int Tin, int CL) { return (long long)decoder_end_lds_bytes(N, C0, Tin, CL); }
+long long lgn_junction_lds_bytes(int N, int CL, int Ts, int Tv, int pool, int C0) {
+  return pool_valid(pool) ? (long long)junction_lds_bytes(N, CL, Ts, Tv, pool, C0) : -1;
 }
 
 long long lgn_step_workspace_doubles(const lgn_net_desc* d) {

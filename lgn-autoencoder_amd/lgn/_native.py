@@ -15,7 +15,7 @@ import torch  # imported before the .so so that the process-wide libamdhip64 is 
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LGN_AMD_LIB") or os.path.join(_HERE, "_lib", "liblgn_amd.so")   # LGN_AMD_LIB: debug builds (tools/)
-ABI_VERSION = 13
+ABI_VERSION = 14
 FINALIZE_SCRATCH = 2048      # include/lgn_amd.h: LGN_FINALIZE_SCRATCH
 
 _lib: Optional[C.CDLL] = None
@@ -28,10 +28,6 @@ _SIGNATURES = {
     "lgn_level_bwd_partial_rows": [_i, _i, _i, _ip, _ip],
     "lgn_level_rad_partial_len": [_i, _i],
     "lgn_level_bwd_f64": [_i] * 5 + [_vp] * 24,
-    "lgn_level_mlp_fused": [_i] * 7,
-    "lgn_level_mlp_partial_rows": [_i] * 8,
-    "lgn_level_mlp_fwd_f64": [_i] * 5 + [_vp] * 14 + [_i, _i, _i] + [_vp] * 6,
-    "lgn_level_mlp_bwd_f64": [_i] * 5 + [_vp] * 16 + [_i, _i, _i] + [_vp] * 12,
     "lgn_reduce_partials_f64": [_vp, _i, _i, _vp, _i, _vp],
     "lgn_radial_finalize_f64": [_vp, _i] + [_vp] * 13,
     "lgn_cgmlp_fwd_f64": [_i] * 5 + [_vp] * 5,
@@ -78,6 +74,29 @@ def pool_code(map_to_latent: str):
     return code
 
 
+def end_stages_fit(encoder=None, decoder=None, junction: bool = False) -> bool:
+    """Plan-time fit query (lgn_*_lds_bytes): do the per-jet end stages of the whole-network calls -- input / latent stage of the
+    encoder, input / output stage of the decoder, with `junction` also the fused encoder-latent + decoder-input kernels of the
+    whole-step call -- fit the 160 KiB of LDS of a CU?  A jet is one workgroup there; e.g. 'mean&min&max' at N = 150 does not fit
+    and takes the per-operator path."""
+    L = lib()
+    need = 0
+    if encoder is not None:
+        code = pool_code(encoder.map_to_latent)
+        if code is None:
+            return False
+        n = encoder.num_input_particles + int(bool(getattr(encoder, "jet_features", False)))
+        ch = encoder.num_channels
+        ts, tv = encoder.tau_latent[(0, 0)], encoder.tau_latent[(1, 1)]
+        need = max(need, L.lgn_encoder_end_lds_bytes(n, ch[0], max(1, encoder.tau_input_scalars), ch[-1], ts, tv, code))
+        if junction and decoder is not None:
+            need = max(need, L.lgn_junction_lds_bytes(n, ch[-1], ts, tv, code, decoder.num_channels[0]))
+    if decoder is not None:
+        ch = decoder.num_channels
+        need = max(need, L.lgn_decoder_end_lds_bytes(decoder.num_output_particles, ch[0], decoder.tau_latent_vectors, ch[-1]))
+    return 0 <= need <= LDS_LIMIT
+
+
 def pool_blocks(code: int) -> int:
     """Output blocks per latent channel: one per pooling under '&', one under '+' (0 = min&max)."""
     if code == 0:
@@ -102,8 +121,8 @@ class NetDesc(C.Structure):
 
 NET_NO_STATIC = 1
 # kernel-selecting cross-check switches -> LGN_NET_* bits of include/lgn_amd.h
-_NET_FLAG_ENV = {"LGN_AMD_NO_STATIC": 1, "LGN_AMD_DEC_PAIRWISE": 2, "LGN_AMD_LEVEL_V2": 4, "LGN_AMD_FUSED_MLP": 8,
-                 "LGN_AMD_MOMENTS_V1": 16, "LGN_AMD_FUSED_MLP_BWD": 32, "LGN_AMD_BWD_ORDERED": 64}
+_NET_FLAG_ENV = {"LGN_AMD_NO_STATIC": 1, "LGN_AMD_DEC_PAIRWISE": 2, "LGN_AMD_LEVEL_V2": 4, "LGN_AMD_MLP_V1": 8,
+                 "LGN_AMD_MOMENTS_V1": 16, "LGN_AMD_BWD_ORDERED": 64}
 # LGN_ACT_* of include/lgn_amd.h: the names get_activation_fn accepts (lgn/nn/generic_levels.py:119-135)
 ACTIVATIONS = {"leakyrelu": 0, "relu": 1, "elu": 2, "sigmoid": 3, "logsigmoid": 4, "atan": 5}
 
@@ -140,8 +159,17 @@ _SIGNATURES.update({
     "lgn_decoder_bwd_f64": [_dp, _vp, _vp, _ll, _vp, _vp, _vp, _ll, _vp, _vp, _vp, _ll, _vp],
     "lgn_step_finalize_f64": [_vp, _vp, _ll, _vp, _i, _d, _vp, _vp, _vp, _d, _d, _d, _d, _i, _vp, _vp],
 })
-EXPORTED_SYMBOLS = ["lgn_abi_version", "lgn_last_error", "lgn_step_workspace_doubles", "lgn_net_workspace_doubles",
-                    "lgn_moments_scratch_doubles", "lgn_local_static_packed_doubles"] + list(_SIGNATURES)
+_LL_SIGNATURES = {          # entry points that return a long long
+    "lgn_step_workspace_doubles": [_dp],
+    "lgn_net_workspace_doubles": [_dp, _i, _i],
+    "lgn_moments_scratch_doubles": [_i, _i, _i, _i],
+    "lgn_local_static_packed_doubles": [_i, _i, _i],
+    "lgn_encoder_end_lds_bytes": [_i] * 7,
+    "lgn_decoder_end_lds_bytes": [_i] * 4,
+    "lgn_junction_lds_bytes": [_i] * 6,
+}
+LDS_LIMIT = 160 * 1024      # LGN_LDS_LIMIT of include/lgn_amd.h
+EXPORTED_SYMBOLS = ["lgn_abi_version", "lgn_last_error"] + list(_LL_SIGNATURES) + list(_SIGNATURES)
 
 
 def lib() -> C.CDLL:
@@ -162,14 +190,10 @@ def lib() -> C.CDLL:
             fn = getattr(l, name)
             fn.argtypes = argtypes
             fn.restype = C.c_int
-        l.lgn_step_workspace_doubles.argtypes = [_dp]
-        l.lgn_step_workspace_doubles.restype = C.c_longlong
-        l.lgn_net_workspace_doubles.argtypes = [_dp, _i, _i]
-        l.lgn_net_workspace_doubles.restype = C.c_longlong
-        l.lgn_moments_scratch_doubles.argtypes = [_i, _i, _i, _i]
-        l.lgn_moments_scratch_doubles.restype = C.c_longlong
-        l.lgn_local_static_packed_doubles.argtypes = [_i, _i, _i]
-        l.lgn_local_static_packed_doubles.restype = C.c_longlong
+        for name, argtypes in _LL_SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.argtypes = argtypes
+            fn.restype = C.c_longlong
         _lib = l
     return _lib
 
@@ -270,75 +294,6 @@ def level_bwd(decoder, s_in, v_in, p, mask, rad, wm0, wm1, ag0, ag1, g_s_out, g_
                "lgn_radial_finalize_f64")
         rad_grads = (g_a, g_b, g_c, g_w0, g_b0, g_w1, g_b1)
     return g_s_in, g_v_in, g_wm0, g_wm1, rad_grads
-
-
-def level_mlp_fused(N, Cc, CO, H, nlin, act, decoder) -> int:
-    """bit 0: the CGMLP rides on the level forward kernel; bit 1: on the level backward kernel (csrc/mlp_dev.hpp)."""
-    return lib().lgn_level_mlp_fused(N, Cc, CO, H, nlin, act, int(decoder))
-
-
-def level_mlp_fwd(decoder, s_in, v_in, p, mask, rad, wm0, wm1, mlp_block, H, nlin, act):
-    """LGNNodeLevel + CGMLP (one launch where the shape allows).  mlp_block: the CGMLP's parameters (W_0, b_0, W_1, ...) as one
-    flat tensor.  Returns (ag0, ag1, s_pre, s_out, v_out)."""
-    _, B, N, Cc = s_in.shape
-    CO = wm0.shape[1]
-    dev, dt = s_in.device, s_in.dtype
-    ag0 = torch.empty(2, B, N, 2 * Cc, device=dev, dtype=dt)
-    ag1 = torch.empty(2, B, N, 2 * Cc, 4, device=dev, dtype=dt)
-    s_pre = torch.empty(2, B, N, CO, device=dev, dtype=dt)
-    s_out = torch.empty(2, B, N, CO, device=dev, dtype=dt)
-    v_out = torch.empty(2, B, N, CO, 4, device=dev, dtype=dt)
-    a, b, c, w0, b0, w1, b1 = rad
-    rc = lib().lgn_level_mlp_fwd_f64(B, N, Cc, CO, int(decoder), ptr(s_in), ptr(v_in), ptr(p), ptr(mask),
-                                     ptr(a), ptr(b), ptr(c), ptr(w0), ptr(b0), ptr(w1), ptr(b1), ptr(wm0), ptr(wm1),
-                                     ptr(mlp_block), H, nlin, act, ptr(ag0), ptr(ag1), ptr(s_pre), ptr(s_out), ptr(v_out), stream_ptr())
-    _check(rc, "lgn_level_mlp_fwd_f64")
-    return ag0, ag1, s_pre, s_out, v_out
-
-
-def level_mlp_bwd(decoder, s_in, v_in, p, mask, rad, wm0, wm1, ag0, ag1, mlp_block, H, nlin, act, s_pre, g_s_out, g_v_out, g_p=None):
-    """Backward of level_mlp_fwd.  Returns (g_s_in, g_v_in, g_wm0, g_wm1, rad_grads, g_mlp_block)."""
-    _, B, N, Cc = s_in.shape
-    CO = wm0.shape[1]
-    dev, dt = s_in.device, s_in.dtype
-    L = lib()
-    rm, rr = C.c_int(), C.c_int()
-    _check(L.lgn_level_bwd_partial_rows(B, N, int(decoder), C.byref(rm), C.byref(rr)), "lgn_level_bwd_partial_rows")
-    nmix = 4 * CO * 5 * Cc
-    nrad = L.lgn_level_rad_partial_len(Cc, int(decoder))
-    rows_mlp = L.lgn_level_mlp_partial_rows(B, N, Cc, CO, H, nlin, act, int(decoder))
-    part_mix = torch.empty(rm.value, nmix, device=dev, dtype=dt)
-    part_rad = torch.empty(rr.value, nrad, device=dev, dtype=dt)
-    part_mlp = torch.empty(rows_mlp, mlp_block.numel(), device=dev, dtype=dt)
-    scratch = torch.empty(2, B, N, CO, device=dev, dtype=dt)
-    g_ag = torch.empty(B, N, 20 * Cc, device=dev, dtype=dt)
-    g_s_in = torch.empty_like(s_in)
-    g_v_in = torch.empty_like(v_in)
-    a, b, c, w0, b0, w1, b1 = rad
-    rc = L.lgn_level_mlp_bwd_f64(B, N, Cc, CO, int(decoder), ptr(s_in), ptr(v_in), ptr(p), ptr(mask),
-                                 ptr(a), ptr(b), ptr(c), ptr(w0), ptr(b0), ptr(w1), ptr(b1), ptr(wm0), ptr(wm1),
-                                 ptr(ag0), ptr(ag1), ptr(mlp_block), H, nlin, act, ptr(s_pre), ptr(g_s_out), ptr(g_v_out),
-                                 ptr(g_ag), ptr(g_s_in), ptr(g_v_in), ptr(g_p), ptr(part_mix), ptr(part_rad), ptr(part_mlp),
-                                 ptr(scratch), stream_ptr())
-    _check(rc, "lgn_level_mlp_bwd_f64")
-    g_mix = torch.empty(nmix, device=dev, dtype=dt)
-    reduce_partials(part_mix, g_mix)
-    g_wm0 = g_mix[: nmix // 2].view(2, CO, 5 * Cc)
-    g_wm1 = g_mix[nmix // 2:].view(2, CO, 5 * Cc)
-    g_mlp = torch.empty_like(mlp_block)
-    reduce_partials(part_mlp, g_mlp)
-    tot = torch.empty(nrad, device=dev, dtype=dt)
-    reduce_partials(part_rad, tot)
-    if decoder:
-        rad_grads = (tot[:Cc], tot[Cc:])
-    else:
-        g_a, g_b, g_c = (torch.empty_like(x) for x in (a, b, c))
-        g_w0, g_b0, g_w1, g_b1 = (torch.empty_like(x) for x in (w0, b0, w1, b1))
-        _check(L.lgn_radial_finalize_f64(ptr(tot), Cc, ptr(a), ptr(b), ptr(c), ptr(w0), ptr(w1), ptr(g_a), ptr(g_b),
-                                         ptr(g_c), ptr(g_w0), ptr(g_b0), ptr(g_w1), ptr(g_b1), stream_ptr()),
-               "lgn_radial_finalize_f64")
-        rad_grads = (g_a, g_b, g_c, g_w0, g_b0, g_w1, g_b1)
-    return g_s_in, g_v_in, g_wm0, g_wm1, rad_grads, g_mlp
 
 
 def _ptr_array(ts: Sequence[torch.Tensor]):

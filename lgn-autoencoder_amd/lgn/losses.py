@@ -45,6 +45,8 @@ class ChamferLoss(nn.Module):
         if x.device.type != "cuda":
             raise RuntimeError("lgn (MI355X build): ChamferLoss runs only in the HIP kernels of liblgn_amd.so on a GPU device; "
                                f"got tensors on '{x.device}'. There is no CPU fallback.")
+        if x.dim() == 2 and y.dim() == 2:                       # one unbatched jet (N, 4): the reference's formula takes it as it is
+            x, y = x.unsqueeze(0), y.unsqueeze(0)
         if x.shape[:-2] != y.shape[:-2] or x.dim() < 3:
             raise ValueError(f"x {tuple(x.shape)} and y {tuple(y.shape)} must share their batch shape")
         if x.shape[-2] != y.shape[-2]:

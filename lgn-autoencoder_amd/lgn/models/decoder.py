@@ -84,7 +84,13 @@ class LGNDecoder(CGModule, LevelTablesMixin):
 
     def _fused_ok(self) -> bool:
         """True when a whole-network native implementation covers this configuration (lgn/ops.py: native_kind)."""
-        return ops.native_kind(self) is not None
+        # (and its per-jet end stages fit a CU's LDS: plan-time query, lgn/_native.py: end_stages_fit)
+        if ops.native_kind(self) is None:
+            return False
+        fit = self.__dict__.get("_end_fit")
+        if fit is None:
+            fit = self.__dict__["_end_fit"] = ops.N.end_stages_fit(decoder=self)
+        return fit
 
     def _forward_modular(self, lat_v, covariance_test, nodes_all):
         B = lat_v.shape[1]

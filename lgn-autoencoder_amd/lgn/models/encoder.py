@@ -97,7 +97,13 @@ class LGNEncoder(CGModule, LevelTablesMixin):
     def _fused_ok(self) -> bool:
         """True when a whole-network native implementation covers this configuration (lgn/ops.py: native_kind)."""
         # (jet features / extra input scalars included: lgn_net_desc.n_in_scalars, round 4)
-        return ops.native_kind(self) is not None and self.tau_input_scalars <= 8
+        # (and its per-jet end stages fit a CU's LDS: plan-time query, lgn/_native.py: end_stages_fit)
+        if ops.native_kind(self) is None or self.tau_input_scalars > 8:
+            return False
+        fit = self.__dict__.get("_end_fit")
+        if fit is None:
+            fit = self.__dict__["_end_fit"] = ops.N.end_stages_fit(encoder=self)
+        return fit
 
     def _forward_modular(self, node_ps, node_mask, covariance_test, scalars=None):
         # input features: (0,0) = (sqrt|p^2| [, jet mass, extra scalars], 0), (1,1) = canonical(p)   (lgn_encoder.py:287-293,376)

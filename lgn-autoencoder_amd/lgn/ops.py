@@ -57,55 +57,6 @@ class LevelFn(torch.autograd.Function):
         return (None, g_s_in, g_v_in, g_p, None) + g_rad + (g_wm0, g_wm1)
 
 
-class LevelMlpFn(torch.autograd.Function):
-    """LGNNodeLevel + its CGMLP -- the pair of lgn/models/lgn_cg.py:164-172 -- behind ONE native call per direction
-    (lgn_level_mlp_fwd/bwd_f64; the CGMLP rides on the level kernels where the shape allows, csrc/mlp_dev.hpp).
-    args: decoder, activation id, s_in, v_in, p, mask, 7 radial parameters, wm0, wm1, w_0, b_0, ..., w_L, b_L."""
-
-    @staticmethod
-    def forward(ctx, decoder, act, s_in, v_in, p, mask, ra, rb, rc, w0, b0, w1, b1, wm0, wm1, *wb):
-        s_in, v_in, p = N.f64(s_in), N.f64(v_in), N.f64(p)
-        rad = tuple(N.f64(t.detach()) for t in (ra, rb, rc, w0, b0, w1, b1))
-        if decoder:
-            rad = (None, None, None, None, rad[4], None, rad[6])
-        wm0c, wm1c = N.f64(wm0.detach()), N.f64(wm1.detach())
-        block = torch.cat([N.f64(t.detach()).reshape(-1) for t in wb])
-        ctx.H, ctx.nlin, ctx.act = wb[0].shape[0], len(wb) // 2, int(act)
-        ag0, ag1, s_pre, s_out, v_out = N.level_mlp_fwd(decoder, s_in, v_in, p, mask, rad, wm0c, wm1c, block, ctx.H, ctx.nlin, ctx.act)
-        ctx.decoder, ctx.mask = decoder, mask
-        ctx.rad_full = (ra, rb, rc, w0, b0, w1, b1)
-        ctx.wb_shapes = [t.shape for t in wb]
-        ctx.save_for_backward(s_in, v_in, p, wm0c, wm1c, ag0, ag1, block, s_pre, *[t for t in rad if t is not None])
-        return s_out, v_out
-
-    @staticmethod
-    def backward(ctx, g_s, g_v):
-        s_in, v_in, p, wm0, wm1, ag0, ag1, block, s_pre, *radl = ctx.saved_tensors
-        decoder = ctx.decoder
-        if decoder:
-            rad = (None, None, None, None, radl[0], None, radl[1])
-            g_p = torch.zeros_like(p)
-        else:
-            rad = tuple(radl)
-            g_p = None
-        g_s_in, g_v_in, g_wm0, g_wm1, rg, g_block = N.level_mlp_bwd(decoder, s_in, v_in, p, ctx.mask, rad, wm0, wm1, ag0, ag1, block,
-                                                                    ctx.H, ctx.nlin, ctx.act, s_pre, N.f64(g_s), N.f64(g_v), g_p)
-        ra, rb, rc, w0, b0, w1, b1 = ctx.rad_full
-        if decoder:
-            g_rad = (torch.zeros_like(ra), torch.zeros_like(rb), torch.zeros_like(rc), torch.zeros_like(w0),
-                     rg[0].view_as(b0), torch.zeros_like(w1), rg[1].view_as(b1))
-        else:
-            g_rad = (rg[0].view_as(ra), rg[1].view_as(rb), rg[2].view_as(rc), rg[3], rg[4], rg[5], rg[6])
-        g_wb, off = [], 0
-        for shp in ctx.wb_shapes:
-            n = 1
-            for x in shp:
-                n *= x
-            g_wb.append(g_block[off: off + n].view(shp))
-            off += n
-        return (None, None, g_s_in, g_v_in, g_p, None) + g_rad + (g_wm0, g_wm1) + tuple(g_wb)
-
-
 class CGMLPFn(torch.autograd.Function):
     """CGMLP on the scalar irrep (csrc/mlp.hip).  args: activation id (N.ACTIVATIONS), s_in, w_0, b_0, ..., w_L, b_L."""
 

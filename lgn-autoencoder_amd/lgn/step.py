@@ -243,6 +243,12 @@ class NativeTrainStep:
                                       "input scalars run through the module API (CapturedModuleStep / native_train_step capture that "
                                       "step into one graph)")
         encoder._require_gpu()
+        if not N.end_stages_fit(encoder, decoder, junction=True):
+            # a jet's latent / junction stage is ONE workgroup: refused here, at plan time, so that native_train_step (and any caller
+            # catching NotImplementedError) takes the module route instead of failing at the first launch
+            raise NotImplementedError(
+                f"the per-jet latent stage of map_to_latent={encoder.map_to_latent!r} at {encoder.num_input_particles} particles needs "
+                "more than the 160 KiB of LDS of a CU; this configuration runs through the module API (per-operator path)")
         self.encoder, self.decoder = encoder, decoder
         self.l1_lambda, self.lr, self.betas, self.eps = l1_lambda, lr, betas, eps
         self.flat = FlatParams(encoder, decoder, grad_tail=batch_size)   # gradients | per-jet Chamfer terms
@@ -560,9 +566,14 @@ def native_train_step(encoder, decoder, batch_size: int, **kw):
     """NativeTrainStep where lgn_step_fwd_bwd_f64 covers the configuration (one native call per step), else CapturedModuleStep
     (the module-API step captured into one graph).  Keyword arguments the two do not share go to the one that takes them."""
     import inspect
+    import warnings
+    takes = {cls: set(inspect.signature(cls.__init__).parameters) - {"self"} for cls in (NativeTrainStep, CapturedModuleStep)}
+    unknown = set(kw) - takes[NativeTrainStep] - takes[CapturedModuleStep]
+    if unknown:
+        raise TypeError(f"native_train_step: unknown keyword argument(s) {sorted(unknown)}")
 
     def only(cls):
-        return {k: v for k, v in kw.items() if k in inspect.signature(cls.__init__).parameters}
+        return {k: v for k, v in kw.items() if k in takes[cls]}
 
     needs_modules = bool(kw.get("chamfer_jet_features") or kw.get("extra_scalars") or kw.get("get_real_method", "sum") != "sum")
     if not needs_modules:
@@ -570,4 +581,7 @@ def native_train_step(encoder, decoder, batch_size: int, **kw):
             return NativeTrainStep(encoder, decoder, batch_size, **only(NativeTrainStep))
         except NotImplementedError:
             pass
+    dropped = sorted(k for k in kw if k not in takes[CapturedModuleStep])
+    if dropped:
+        warnings.warn(f"native_train_step: this configuration runs as CapturedModuleStep, which does not take {dropped}; ignored")
     return CapturedModuleStep(encoder, decoder, batch_size, **only(CapturedModuleStep))

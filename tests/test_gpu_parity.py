@@ -45,7 +45,8 @@ def _rand_level_params(O, C, CO, decoder, g):
 @pytest.mark.parametrize("C,CO,N,B", [(3, 3, 30, 3), (3, 4, 30, 2), (4, 4, 30, 2), (4, 3, 30, 2), (4, 4, 7, 2),
                                       (2, 5, 33, 2), (4, 4, 70, 1), (1, 1, 1, 1),
                                       (4, 4, 48, 2), (3, 4, 50, 1), (4, 3, 41, 2), (2, 2, 63, 1),    # 40 < N < 64
-                                      (4, 4, 150, 1), (3, 3, 150, 2), (5, 6, 100, 1), (8, 8, 70, 1)])  # chunked receivers
+                                      (4, 4, 150, 1), (3, 3, 150, 2), (5, 6, 100, 1), (8, 8, 70, 1),   # chunked receivers
+                                      (2, 3, 270, 1), (4, 4, 30, 66)])   # N > 256 (symmetric sweep off: > 64 groups); jet split 4
 def test_level_fwd_bwd(dev, O, decoder, C, CO, N, B):
     """N <= 40: one-kernel backward (level_bwd3); 40 < N: mix + ONE pair sweep for node gradients and radial sums
     (level_bwd_sweep_enc: four waves per jet, receivers in chunks when the jet's g_ag does not fit beside a second workgroup)
@@ -108,7 +109,7 @@ def test_level_backward_symmetric_and_ordered_sweeps_agree_on_random_shapes(dev,
 
 
 @pytest.mark.parametrize("C,CO,N,B", [(4, 4, 150, 1), (3, 3, 150, 2), (4, 4, 48, 2), (3, 4, 50, 1), (4, 3, 41, 2), (2, 2, 63, 1), (4, 4, 70, 1),
-                                      (5, 6, 100, 1)])
+                                      (5, 6, 100, 1), (2, 2, 260, 1)])      # (N > 256: more than 64 groups of four particles)
 def test_level_backward_large_jets_ordered_pair_tiles(dev, O, monkeypatch, C, CO, N, B):
     """N > 40: the one-sweep backward with LGN_AMD_BWD_ORDERED=1 -- the radial-parameter GEMM per ordered pair tile, round-robin
     group ownership -- beside the default symmetric sweep that test_level_fwd_bwd runs (unordered tiles, groups dealt by cost;
@@ -273,7 +274,8 @@ _MIX = "lgn_cg.node_levels.0.cat_mix.mix_reps.weights."
 
 
 def _level_mlp_native(dev, decoder, act, P, node, p, mask, cot):
-    """level + CGMLP through ops.LevelMlpFn (ONE native call per direction); returns outputs and every gradient on the CPU."""
+    """level, then its CGMLP (ops.LevelFn, ops.CGMLPFn: the pair of lgn/models/lgn_cg.py:164-172); returns outputs and every gradient on
+    the CPU."""
     from lgn import ops, _native as Nn
     d = lambda t: t.detach().to(dev).requires_grad_(True)  # noqa: E731
     s_in, v_in, pd = d(node[(0, 0)].squeeze(-1)), d(node[(1, 1)]), d(p)
@@ -282,8 +284,8 @@ def _level_mlp_native(dev, decoder, act, P, node, p, mask, cot):
     flat = []
     for i in range(7):
         flat += [d(P[f"lgn_cg.mlp_levels.0.linear.{i}.weight"]), d(P[f"lgn_cg.mlp_levels.0.linear.{i}.bias"])]
-    s_out, v_out = ops.LevelMlpFn.apply(decoder, Nn.activation_id(act), s_in, v_in, pd, None if mask is None else mask.to(dev), *radp,
-                                        wm0, wm1, *flat)
+    s_pre, v_out = ops.LevelFn.apply(decoder, s_in, v_in, pd, None if mask is None else mask.to(dev), *radp, wm0, wm1)
+    s_out = ops.CGMLPFn.apply(Nn.activation_id(act), s_pre, *flat)
     ((s_out.unsqueeze(-1) * cot[(0, 0)].to(dev)).sum() + (v_out * cot[(1, 1)].to(dev)).sum()).backward()
     z = lambda t: torch.zeros_like(t) if t.grad is None else t.grad  # noqa: E731
     grads = {"s_in": s_in.grad.unsqueeze(-1), "v_in": v_in.grad, "p": pd.grad if decoder else None, "wm0": wm0.grad, "wm1": wm1.grad}
@@ -333,20 +335,13 @@ def _assert_grads(got, ref, tol, tag=""):
                                       (4, 4, 7, 2), (3, 4, 7, 1), (4, 3, 33, 2), (3, 3, 33, 1),          # one tile; two passes
                                       (4, 4, 16, 2), (4, 4, 17, 1), (3, 3, 32, 2), (4, 4, 40, 1),        # tile / pass boundaries
                                       (2, 2, 30, 2), (1, 1, 5, 1), (4, 2, 13, 3), (2, 4, 30, 1),         # narrow MLPs (H = 12, 24)
-                                      (5, 4, 30, 2), (4, 5, 30, 1), (4, 4, 48, 1)])                      # outside the fused range
-def test_level_mlp_fwd_bwd(dev, O, monkeypatch, decoder, C, CO, N, B):
-    """LGNNodeLevel + CGMLP behind one call per direction (lgn_level_mlp_fwd/bwd_f64) against the oracle.  With LGN_AMD_FUSED_MLP=1 /
-    LGN_AMD_FUSED_MLP_BWD=1 and N <= 40, C <= 4, C_out <= 4 (H <= 48) the CGMLP rides on the level kernels (csrc/mlp_dev.hpp; small B:
-    the jet is split over several workgroups, each running the forward MLP on its rows and the backward chain on all rows); the other
-    shapes run the separate launches."""
-    from lgn import _native as Nn
-    monkeypatch.setenv("LGN_AMD_FUSED_MLP", "1")
-    monkeypatch.setenv("LGN_AMD_FUSED_MLP_BWD", "1")
+                                      (5, 4, 30, 2), (4, 5, 30, 1), (4, 4, 48, 1),                       # C > 4, N > 40
+                                      (4, 4, 30, 66), (3, 3, 30, 70)])                                  # jet split 4 (65 .. 128 jets)
+def test_level_mlp_fwd_bwd(dev, O, decoder, C, CO, N, B):
+    """LGNNodeLevel followed by its CGMLP against the oracle, over the level shapes of the BASELINE configs, tile / pass boundaries of
+    the level kernels, narrow CGMLPs and channel counts on either side of the C <= 4 kernels (small B: jets split over workgroups)."""
     g = torch.Generator().manual_seed(1000 * C + 100 * CO + N + int(decoder))
     cfg, plans, P, node, p, mask, cot = _level_mlp_inputs(O, decoder, C, CO, N, B, "leakyrelu", g, seed=N + 7 * C)
-    H = P["lgn_cg.mlp_levels.0.linear.0.weight"].shape[0]
-    fused = Nn.level_mlp_fused(N, C, CO, H, 7, 0, decoder)
-    assert fused == (3 if (N <= 40 and C <= 4 and CO <= 4) else 0), "which shapes ride on the level kernels"
     s_ref, v_ref, g_ref = _level_mlp_oracle(O, decoder, cfg, plans, P, node, p, mask, cot)
     s_out, v_out, g_got = _level_mlp_native(dev, decoder, "leakyrelu", P, node, p, mask, cot)
     U.assert_close(s_out, s_ref, FWD_TOL, "s_out (after the MLP)")
@@ -356,16 +351,11 @@ def test_level_mlp_fwd_bwd(dev, O, monkeypatch, decoder, C, CO, N, B):
 
 @pytest.mark.parametrize("decoder", [False, True])
 @pytest.mark.parametrize("act", ["leakyrelu", "relu", "elu", "sigmoid", "logsigmoid", "atan"])
-def test_level_mlp_activations(dev, O, monkeypatch, decoder, act):
-    """Every activation of get_activation_fn through the level + CGMLP call.  LeakyReLU (the reference default) rides on the level
-    kernels when asked to; the others keep the separate CGMLP kernels behind the same call (level.hpp: level_mlp_fusable says why)."""
-    from lgn import _native as Nn
-    monkeypatch.setenv("LGN_AMD_FUSED_MLP", "1")
-    monkeypatch.setenv("LGN_AMD_FUSED_MLP_BWD", "1")
+def test_level_mlp_activations(dev, O, decoder, act):
+    """Every activation of get_activation_fn through the level + CGMLP pair."""
     C, CO, N, B = 4, 3, 30, 2
     g = torch.Generator().manual_seed(77 + int(decoder))
     cfg, plans, P, node, p, mask, cot = _level_mlp_inputs(O, decoder, C, CO, N, B, act, g, seed=11)
-    assert Nn.level_mlp_fused(N, C, CO, 36, 7, Nn.activation_id(act), decoder) == (3 if act == "leakyrelu" else 0)
     s_ref, v_ref, g_ref = _level_mlp_oracle(O, decoder, cfg, plans, P, node, p, mask, cot)
     s_out, v_out, g_got = _level_mlp_native(dev, decoder, act, P, node, p, mask, cot)
     U.assert_close(s_out, s_ref, FWD_TOL, f"{act} s_out")
@@ -375,18 +365,14 @@ def test_level_mlp_activations(dev, O, monkeypatch, decoder, act):
 
 @pytest.mark.parametrize("decoder", [False, True])
 @pytest.mark.parametrize("C,CO", [(3, 4), (4, 4), (4, 3)])
-def test_level_mlp_full_batch_matches_small_batches_and_unfused(dev, O, monkeypatch, decoder, C, CO):
-    """B = 512 (one workgroup per jet, two per CU: the BASELINE launch shape) cannot be held by the oracle.  Properties instead:
-    (1) jets of the 512-batch equal the same jets run in a batch of 3 (the jet-split launch shape, which the oracle pins in
-    test_level_mlp_fwd_bwd); (2) every output and gradient of the riding CGMLP equals the separate-launch path
-    (the default) to rounding; (3) the run is bitwise reproducible."""
-    from lgn import _native as Nn
-    monkeypatch.setenv("LGN_AMD_FUSED_MLP", "1")
-    monkeypatch.setenv("LGN_AMD_FUSED_MLP_BWD", "1")
+def test_level_mlp_full_batch_matches_small_batches_and_v1(dev, O, monkeypatch, decoder, C, CO):
+    """B = 512 (one workgroup per jet, two per CU; the CGMLP on the chain kernels of mlp_chain.hip: the BASELINE launch shapes) cannot be
+    held by the oracle.  Properties instead: (1) jets of the 512-batch equal the same jets run in a batch of 3 (the jet-split level
+    launch and the 16-row CGMLP workgroups, which the oracle pins in test_level_mlp_fwd_bwd); (2) every output and gradient equals the
+    12-wave CGMLP kernels' (LGN_AMD_MLP_V1=1) to rounding; (3) the run is bitwise reproducible."""
     N, B = 30, 512
     g = torch.Generator().manual_seed(5 + C + int(decoder))
     cfg, plans, P, node, p, mask, cot = _level_mlp_inputs(O, decoder, C, CO, N, B, "leakyrelu", g, seed=3)
-    assert Nn.level_mlp_fused(N, C, CO, 12 * CO, 7, 0, decoder) == 3
     s1, v1, g1 = _level_mlp_native(dev, decoder, "leakyrelu", P, node, p, mask, cot)
     s2, v2, g2 = _level_mlp_native(dev, decoder, "leakyrelu", P, node, p, mask, cot)
     assert torch.equal(s1, s2) and torch.equal(v1, v2) and all(torch.equal(g1[k], g2[k]) for k in g1 if g1[k] is not None)
@@ -401,13 +387,11 @@ def test_level_mlp_full_batch_matches_small_batches_and_unfused(dev, O, monkeypa
     U.assert_close(v1.index_select(1, idx), v3, 1e-13, "jets of the full batch: v_out")
     U.assert_close(g1["s_in"].index_select(1, idx), g3["s_in"], 1e-12, "jets of the full batch: g_s_in")
     U.assert_close(g1["v_in"].index_select(1, idx), g3["v_in"], 1e-12, "jets of the full batch: g_v_in")
-    monkeypatch.delenv("LGN_AMD_FUSED_MLP")
-    monkeypatch.delenv("LGN_AMD_FUSED_MLP_BWD")
-    assert Nn.level_mlp_fused(N, C, CO, 12 * CO, 7, 0, decoder) == 0
+    monkeypatch.setenv("LGN_AMD_MLP_V1", "1")
     su, vu, gu = _level_mlp_native(dev, decoder, "leakyrelu", P, node, p, mask, cot)
-    U.assert_close(s1, su, 1e-13, "fused vs separate: s_out")
-    U.assert_close(v1, vu, 1e-13, "fused vs separate: v_out")
-    _assert_grads(g1, gu, 1e-11, "fused vs separate: ")
+    U.assert_close(s1, su, 1e-13, "chain vs 12-wave CGMLP kernels: s_out")
+    U.assert_close(v1, vu, 1e-13, "chain vs 12-wave CGMLP kernels: v_out")
+    _assert_grads(g1, gu, 1e-11, "chain vs 12-wave CGMLP kernels: ")
 
 
 @pytest.mark.parametrize("act", ["relu", "elu", "sigmoid", "logsigmoid", "atan"])

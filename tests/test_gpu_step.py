@@ -68,14 +68,14 @@ def test_native_step_matches_reference_golden(name, use_graph):
                 assert torch.equal(g.cpu(), lam * torch.sign(sd[k])), f"{pre}.{k}: dead parameter must get exactly the L1 term"
 
 
-@pytest.mark.parametrize("flags", [("LGN_AMD_FUSED_MLP",), ("LGN_AMD_FUSED_MLP", "LGN_AMD_FUSED_MLP_BWD"), ("LGN_AMD_FUSED_MLP_BWD",),
-                                   ("LGN_AMD_LEVEL_V2",), ("LGN_AMD_DEC_PAIRWISE",), ("LGN_AMD_BWD_ORDERED",)])
+@pytest.mark.parametrize("flags", [("LGN_AMD_LEVEL_V2",), ("LGN_AMD_DEC_PAIRWISE",), ("LGN_AMD_BWD_ORDERED",), ("LGN_AMD_MLP_V1",),
+                                   ("LGN_AMD_LEVEL_V2", "LGN_AMD_DEC_PAIRWISE")])
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_native_step_maxdim2_alternative_kernels(flags, use_graph, monkeypatch):
     """The kernel-selecting switches of the maxdim = 2 step, frozen into the descriptor when the step is created (lgn/_native.py:
-    net_flags): the CGMLPs riding on the level kernels (forward tail, backward head, both; csrc/mlp_dev.hpp: 24, 26 or 20 launches per
-    step instead of 30), the three-kernel level backward, the decoder as pair sweeps -- each against the reference's g1 gradients with
-    the strict per-tensor tolerance, and the number of launches the fused forms promise."""
+    net_flags): the three-kernel level backward, the decoder as pair sweeps, the ordered radial-gradient sweep, the 12-wave CGMLP
+    kernels -- each against the reference's g1 gradients with the strict per-tensor tolerance.  (At g1's 4 jets the CGMLP runs its
+    16-row workgroups either way; test_native_step_batch_regimes covers the chain kernels against the 12-wave ones at 512 jets.)"""
     from lgn.step import NativeTrainStep
     for f in flags:
         monkeypatch.setenv(f, "1")
@@ -155,6 +155,40 @@ def test_native_step_full_size_properties(name, B, N, maxdim, che, chd):
     U.assert_close(ra, rb, 1e-12, "recon")
     U.assert_close(a.flat.grad, b.flat.grad, 1e-9, "flat gradient")
     assert torch.isfinite(a.flat.grad).all()
+
+
+@pytest.mark.parametrize("B", [64, 100, 128, 256, 300, 512])
+def test_native_step_batch_regimes(B, monkeypatch):
+    """cfg2 shapes at the batch sizes that change the launch geometry: the level kernels split a jet over 8 / 4 / 2 / 1 workgroups
+    (level.hpp: level_jet_split: 64 / 65 .. 128 / 129 .. 256 / more jets), the CGMLP runs 16-row workgroups with kept activations
+    (<= 4 096 rows), without them, or the chain kernels of mlp_chain.hip (>= 8 129 rows: 300 and 512 jets).  The graph-replayed
+    native step against the module / autograd path on the same weights, and at the chain-kernel sizes also against the same step
+    on the 12-wave CGMLP kernels (LGN_AMD_MLP_V1=1)."""
+    import __graft_entry__ as G
+    from lgn.step import NativeTrainStep, TrainStep
+    from oracle import lgn_oracle as O
+    dev = torch.device("cuda:0")
+    N, che, chd = 30, (3, 3, 4, 4), (4, 4, 3, 3)
+    enc, dec = G._models(N, che, chd, dev, seed=5)
+    enc2, dec2 = G._models(N, che, chd, dev, seed=5)
+    p4, labels = O.synthetic_jets(B, N, seed=B, pad=True)
+    batch = {"p4": p4.to(dev), "labels": labels.to(dev)}
+    a = NativeTrainStep(enc, dec, batch_size=B, optimizer=False, use_graph=True)
+    b = TrainStep(enc2, dec2, optimizer=False)
+    la, ra = a.step(batch)
+    la, ra = a.step(batch)                  # (the replay)
+    lb, rb = b.forward_backward(batch)
+    U.assert_close(la, lb, 1e-12, "loss")
+    U.assert_close(ra, rb, 1e-12, "recon")
+    U.assert_close(a.flat.grad, b.flat.grad, 1e-9, "flat gradient")
+    if B * N >= 8129:
+        enc3, dec3 = G._models(N, che, chd, dev, seed=5)
+        monkeypatch.setenv("LGN_AMD_MLP_V1", "1")
+        c = NativeTrainStep(enc3, dec3, batch_size=B, optimizer=False, use_graph=True)
+        monkeypatch.delenv("LGN_AMD_MLP_V1")
+        lc, rc = c.step(batch)
+        U.assert_close(la, lc, 1e-13, "loss, chain vs 12-wave CGMLP kernels")
+        U.assert_close(a.flat.grad, c.flat.grad, 1e-10, "flat gradient, chain vs 12-wave CGMLP kernels")
 
 
 @pytest.mark.parametrize("which", ["native", "captured"])
@@ -393,18 +427,27 @@ def test_latent_poolings_other_jet_sizes(latent, N, B):
     """The same at jet sizes where the particle loops of the pooling kernels run partial rounds (7, 30) and where the junction's
     two stages share their LDS (150: with 'mix' the latent weights alone are 86 KB)."""
     if latent == "mean&min&max" and N == 150:
-        # three pooled blocks of 8 latent vectors for 150 particles: the decoder's input stage would need 165 KB of LDS -- the calls
-        # come back with an explicit error naming the limit (as for oversized maxdim-3 jets); the per-operator path remains
+        # three pooled blocks of 8 latent vectors for 150 particles: the decoder's input stage would need 165 KB of LDS.  Decided at
+        # PLAN time (lgn_*_lds_bytes, lgn/_native.py: end_stages_fit): the whole-step class refuses with NotImplementedError, the chooser
+        # falls back to the captured module step, the modules take the per-operator path -- nothing fails at a launch.
         import __graft_entry__ as G
-        from lgn.step import NativeTrainStep
+        from lgn.step import CapturedModuleStep, NativeTrainStep, TrainStep, native_train_step
         from oracle import lgn_oracle as O
         dev = torch.device("cuda:0")
         enc, dec = G._models(N, (2, 3, 3, 4), (4, 3, 3, 2), dev, seed=7, map_to_latent=latent)
+        enc2, dec2 = G._models(N, (2, 3, 3, 4), (4, 3, 3, 2), dev, seed=7, map_to_latent=latent)
         p4, labels = O.synthetic_jets(B, N, seed=11, pad=True)
-        a = NativeTrainStep(enc, dec, batch_size=B, optimizer=False, use_graph=False)
-        with pytest.raises(RuntimeError, match="of LDS"):
-            a.step({"p4": p4.to(dev), "labels": labels.to(dev)})
-        torch.cuda.synchronize()
+        batch = {"p4": p4.to(dev), "labels": labels.to(dev)}
+        assert enc._fused_ok() and not dec._fused_ok()          # (the encoder's latent stage fits, the decoder's input stage does not)
+        with pytest.raises(NotImplementedError, match="LDS"):
+            NativeTrainStep(enc, dec, batch_size=B, optimizer=False, use_graph=False)
+        a = native_train_step(enc, dec, B, optimizer=False, use_graph=False)
+        assert isinstance(a, CapturedModuleStep)
+        la, ra = a.step(batch)
+        enc2.use_fused = dec2.use_fused = False                 # every operator on its own native call
+        lb, rb = TrainStep(enc2, dec2, optimizer=False).forward_backward(batch)
+        U.assert_close(la, lb, 1e-11, "loss")
+        U.assert_close(ra, rb, 1e-11, "recon")
         return
     _latent_case(latent, 2, N, B)
 

@@ -24,8 +24,8 @@ stats cfg2_module_api --config cfg2 --harness module --no-extras
 stats cfg4 --config cfg4 --no-extras
 stats cfg5 --config cfg5 --no-extras
 stats b64 --config cfg2 --batch 64 --no-extras
-# the opt-in level + CGMLP kernels (csrc/mlp_dev.hpp), for the comparison in DESIGN.md 5.0
-LGN_AMD_FUSED_MLP=1 LGN_AMD_FUSED_MLP_BWD=1 stats cfg2_fused --config cfg2 --no-extras
+# the 12-wave CGMLP kernels (csrc/mlp_mfma.hip) in place of the chain kernels, for the comparison in DESIGN.md
+LGN_AMD_MLP_V1=1 stats cfg2_mlp_v1 --config cfg2 --no-extras
 cd "$ROOT"
 for cfg in cfg2 cfg5; do
   echo "[evidence] pmc passes $cfg"

@@ -56,15 +56,6 @@ def main():
         gs, gv = torch.randn_like(so), torch.randn_like(vo)
         gp = torch.zeros_like(p) if decoder else None
         fn = lambda: Nn.level_bwd(decoder, s, v, p, mask, rad, wm0, wm1, ag0, ag1, gs, gv, gp)  # noqa: E731
-    elif what.startswith("level_mlp_fwd"):        # level + CGMLP in one launch (csrc/mlp_dev.hpp)
-        block = torch.cat([t.reshape(-1) for pair in zip(ws, bs) for t in pair])
-        fn = lambda: Nn.level_mlp_fwd(decoder, s, v, p, mask, rad, wm0, wm1, block, ws[0].shape[0], 7, 0)   # noqa: E731
-    elif what.startswith("level_mlp_bwd"):
-        block = torch.cat([t.reshape(-1) for pair in zip(ws, bs) for t in pair])
-        ag0, ag1, spre, so, vo = Nn.level_mlp_fwd(decoder, s, v, p, mask, rad, wm0, wm1, block, ws[0].shape[0], 7, 0)
-        gs, gv = torch.randn_like(so), torch.randn_like(vo)
-        gp = torch.zeros_like(p) if decoder else None
-        fn = lambda: Nn.level_mlp_bwd(decoder, s, v, p, mask, rad, wm0, wm1, ag0, ag1, block, ws[0].shape[0], 7, 0, spre, gs, gv, gp)  # noqa: E731
     elif what == "mlp_fwd":
         fn = lambda: Nn.cgmlp_fwd(s_mlp, ws, bs)                                                 # noqa: E731
     elif what == "mlp_bwd":
@@ -84,23 +75,7 @@ def main():
     print(f"{what}: B={B} N={N} C={C}->{CO}  {e0.elapsed_time(e1) * 1e3 / reps:.1f} us per call")
     if stamps:
         import ctypes
-        n = 256 if "_fm_" in stamps else 64
-        buf = (ctypes.c_longlong * n)()
-        rc = getattr(Nn.lib(), stamps)(buf)
-        st = list(buf)
-        if n == 256:      # mlp_dev.hpp: slot = (last workgroup ? 128 : 0) + role * 32 + i, lane 0 of each wave
-            for nm, off in (("first", 0), ("last", 128)):
-                part = st[off: off + 128]
-                ids = [part[w * 32 + 31] - 0x1000 for w in range(4)]       # slot 31 of "role" w: HW_ID of WAVE w (wave slot [3:0], SIMD [5:4])
-                for w in range(4):
-                    part[w * 32 + 31] = 0
-                t0 = min(x for x in part if x > 0)
-                print(f"{nm} workgroup of the grid: waves 0..3 on (SIMD, slot) " + " ".join(f"({(x >> 4) & 3},{x & 15})" for x in ids) +
-                      "; shader-clock cycles relative to its earliest stamp, one line per role (0, 1 chain; 2, 3 worker):")
-                for role in range(4):
-                    row = part[role * 32: role * 32 + 32]
-                    print(f"  role {role}: " + " ".join(f"{i}:{x - t0}" for i, x in enumerate(row) if x > 0))
-        else:
+        if True:
             n = 256
             buf = (ctypes.c_longlong * n)()
             rc = getattr(Nn.lib(), stamps)(buf)
