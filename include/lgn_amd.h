@@ -253,7 +253,7 @@ typedef struct lgn_net_desc {
  * encoder: input-stage backward (K input scalars, C0 = first channel count) and the latent stage (CL = last channel count,
  * Ts / Tv latent multiplicities, pool = LGN_POOL code); decoder: its input stage (Tin latent vectors) and output / loss stage;
  * junction: the fused encoder-latent + decoder-input kernels of the whole-step call.  -1: bad pooling code.  A caller whose
- * shape does not fit takes the per-operator path instead (lgn/models/*.py: _fused_ok, lgn/step.py: NativeTrainStep). */
+ * shape does not fit takes the per-operator path instead (_fused_ok of lgn/models/encoder.py and decoder.py, NativeTrainStep of lgn/step.py). */
 #define LGN_LDS_LIMIT (160 * 1024)
 long long lgn_encoder_end_lds_bytes(int N, int C0, int K, int CL, int Ts, int Tv, int pool);
 long long lgn_decoder_end_lds_bytes(int N, int C0, int Tin, int CL);

@@ -1113,15 +1113,21 @@ __global__ __launch_bounds__(BLOCK) void l1_adam_kernel(long n, double* w, doubl
   }
   l1 = block_sum(l1, red);
   if (threadIdx.x == 0) {
-    l1_part[blockIdx.x] = l1;
-    __threadfence();                                       // this workgroup's |w| sum is visible device-wide before the count
-    last = atomicAdd(done, 1ull) == (unsigned long long)gridDim.x - 1;
+    // The partial goes out as a device-scope atomic exchange (performed at the coherent level; its return is awaited, so it is
+    // complete before the count below is issued) and the last workgroup reads the partials back with device-scope atomic loads:
+    // no __threadfence() -- on this multi-XCD part a device-scope release / acquire pair writes back and invalidates the whole L2 of
+    // the XCD, 3.5 of this kernel's 9 us.
+    unsigned long long old = __hip_atomic_exchange(reinterpret_cast<unsigned long long*>(l1_part) + blockIdx.x,
+                                                   (unsigned long long)__double_as_longlong(l1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(old) : : "memory");       // the exchange has been performed before the count is issued
+    last = __hip_atomic_fetch_add(done, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned long long)gridDim.x - 1;
   }
   __syncthreads();
   if (!last) return;
-  __threadfence();                                         // ... and the others' are visible to this one
   double a = 0, l = 0;
-  for (int i = threadIdx.x; i < (int)gridDim.x; i += BLOCK) a += __builtin_nontemporal_load(l1_part + i);
+  for (int i = threadIdx.x; i < (int)gridDim.x; i += BLOCK)
+    a += __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(l1_part) + i, __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_AGENT));
   for (int i = threadIdx.x; i < nB; i += BLOCK) l += loss_part[i];
   a = block_sum(a, red);
   l = block_sum(l, red);
