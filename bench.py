@@ -58,6 +58,9 @@ CONFIGS = {
 }
 N_PART, BATCH, CH_ENC, CH_DEC = 30, 512, (3, 3, 4, 4), (4, 4, 3, 3)      # cfg2 (used by the tests' workers)
 FP64_VECTOR_PEAK_TFLOPS = 78.6     # MI355X fp64 vector == fp64 matrix peak (MI355X_MICROARCH.md: FP32 157.3 / 2)
+# algorithmic flops per jet of one training step (forward + backward = 3 x forward), decoder levels as pair sweeps
+WHOLE_STEP_FLOPS_PER_JET = {"cfg1": 31.2e6, "cfg2": 31.2e6, "cfg4": 533.7e6, "cfg5": 109.9e6}
+PROFILE_ROUND = "r05"              # profiles/<round>_pmc_<cfg>.json: the PMC passes the `traffic` figures come from
 
 
 def synthetic_jets(B, N, seed):
@@ -128,34 +131,33 @@ def _events_us(fn, reps, mode_out=None):
     return total / rounds
 
 
-def time_dominant_kernel(enc, batch, reps=20):
-    """Average duration of the dominant kernel -- the fused BACKWARD of the widest encoder level, the largest single
-    launch of the step (profiles/) -- and of the matching fused forward, measured with events on the stream they are
-    launched on (torch's current stream).  Both go through the C ABI with preallocated buffers; for N <= 40 the
-    backward is ONE kernel (level_bwd3_kernel), its partial-row reductions are separate launches and not timed here.
-    (maxdim = 2 levels only.)"""
+def _time_level(net, decoder, lvl, batch, reps=20):
+    """Average duration of the fused forward and backward kernels of maxdim = 2 level `lvl` of a network, through the C ABI with
+    preallocated buffers and pre-marshalled arguments (the loop's host time per call stays below the kernel's duration), measured
+    with events on the stream they are launched on.  For N <= 40 the backward is ONE kernel (level_bwd3_kernel); its partial-row
+    reductions are separate launches and not timed here.  Returns (us_fwd, us_bwd, timing mode)."""
     import ctypes as C
     from lgn import _native as Nn
-    lvl = max(range(enc.num_cg_levels), key=lambda l: enc.num_channels[l] * enc.num_channels[l + 1])
-    Cc, CO = enc.num_channels[lvl], enc.num_channels[lvl + 1]
-    dev = enc.device
+    Cc, CO = net.num_channels[lvl], net.num_channels[lvl + 1]
+    dev = net.device
     B, N = batch["p4"].shape[:2]
-    g = torch.Generator(device="cpu").manual_seed(1)
+    g = torch.Generator(device="cpu").manual_seed(1 + lvl + 10 * int(decoder))
     s = torch.randn(2, B, N, Cc, dtype=torch.float64, generator=g).to(dev)
     v = torch.randn(2, B, N, Cc, 4, dtype=torch.float64, generator=g).to(dev)
-    rad = tuple(t.detach().contiguous() for t in enc.rad_funcs.rad_funcs[lvl].flat_params())
-    mix = enc.lgn_cg.node_levels[lvl].cat_mix.mix_reps
+    rad = tuple(t.detach().contiguous() for t in net.rad_funcs.rad_funcs[lvl].flat_params())
+    mix = net.lgn_cg.node_levels[lvl].cat_mix.mix_reps
     wm0, wm1 = mix.weight((0, 0)).detach().contiguous(), mix.weight((1, 1)).detach().contiguous()
-    p = batch["p4"].to(dev).contiguous()
-    mask = batch["labels"].to(dev).contiguous()
-
-    # forward and backward through the C ABI on preallocated buffers with pre-marshalled arguments: the loop's host time per
-    # call stays below the kernel's duration (at 64 jets the kernels take < 20 us)
+    if decoder:        # complex canonical momenta, every edge masked: only the two Linear biases of the radial network are read
+        rad = (None, None, None, None, rad[4], None, rad[6])
+        p, mask = torch.randn(2, B, N, 4, dtype=torch.float64, generator=g).to(dev), None
+    else:
+        p, mask = batch["p4"].to(dev).contiguous(), batch["labels"].to(dev).contiguous()
     L = Nn.lib()
     a, b, c, w0, b0, w1, b1 = rad
     P = Nn.ptr
-    ag0, ag1, so, vo = Nn.level_fwd(False, s, v, p, mask, rad, wm0, wm1)
-    fargs = (B, N, Cc, CO, 0, P(s), P(v), P(p), P(mask), P(a), P(b), P(c), P(w0), P(b0), P(w1), P(b1), P(wm0), P(wm1),
+    dec = int(decoder)
+    ag0, ag1, so, vo = Nn.level_fwd(decoder, s, v, p, mask, rad, wm0, wm1)
+    fargs = (B, N, Cc, CO, dec, P(s), P(v), P(p), P(mask), P(a), P(b), P(c), P(w0), P(b0), P(w1), P(b1), P(wm0), P(wm1),
              P(ag0), P(ag1), P(so), P(vo))
 
     def fwd():
@@ -166,26 +168,126 @@ def time_dominant_kernel(enc, batch, reps=20):
     gs = torch.randn(so.shape, dtype=torch.float64, generator=g).to(dev)
     gv = torch.randn(vo.shape, dtype=torch.float64, generator=g).to(dev)
     rm, rr = C.c_int(), C.c_int()
-    Nn._check(L.lgn_level_bwd_partial_rows(B, N, 0, C.byref(rm), C.byref(rr)), "lgn_level_bwd_partial_rows")
+    Nn._check(L.lgn_level_bwd_partial_rows(B, N, dec, C.byref(rm), C.byref(rr)), "lgn_level_bwd_partial_rows")
     part_mix = torch.empty(rm.value, 4 * CO * 5 * Cc, device=dev, dtype=torch.float64)
-    part_rad = torch.empty(rr.value, L.lgn_level_rad_partial_len(Cc, 0), device=dev, dtype=torch.float64)
+    part_rad = torch.empty(rr.value, L.lgn_level_rad_partial_len(Cc, dec), device=dev, dtype=torch.float64)
     g_ag = torch.empty(B, N, 20 * Cc, device=dev, dtype=torch.float64)
     g_s_in, g_v_in = torch.empty_like(s), torch.empty_like(v)
-    bargs = (B, N, Cc, CO, 0, P(s), P(v), P(p), P(mask), P(a), P(b), P(c), P(w0), P(b0), P(w1), P(b1), P(wm0), P(wm1), P(ag0), P(ag1),
-             P(gs), P(gv), P(g_ag), P(g_s_in), P(g_v_in), P(None), P(part_mix), P(part_rad))
+    g_p = torch.zeros_like(p) if decoder else None
+    bargs = (B, N, Cc, CO, dec, P(s), P(v), P(p), P(mask), P(a), P(b), P(c), P(w0), P(b0), P(w1), P(b1), P(wm0), P(wm1), P(ag0), P(ag1),
+             P(gs), P(gv), P(g_ag), P(g_s_in), P(g_v_in), P(g_p), P(part_mix), P(part_rad))
 
     def bwd():
         Nn._check(L.lgn_level_bwd_f64(*bargs, Nn.stream_ptr()), "lgn_level_bwd_f64")
 
     us_bwd = _events_us(bwd, reps, mode)
+    return us_fwd, us_bwd, mode.get("timing")
+
+
+def _level_kernel_names(B, N, Cc, decoder):
+    """Names of the level kernels a launch of this shape runs (N <= 40), from the library's own launch geometry (lgn_level_jet_split)
+    and the switches the per-operator entry points read -- not rebuilt by hand (round 4's label was wrong for C > 4)."""
+    from lgn import _native as Nn
+    sep = decoder and os.environ.get("LGN_AMD_DEC_PAIRWISE") != "1"
+    split = 1 if sep else Nn.lib().lgn_level_jet_split(B, N)
+    sym = (not decoder) and Cc <= 4 and split == 1 and os.environ.get("LGN_AMD_BWD_ORDERED") != "1"
+    t = lambda x: "true" if x else "false"          # noqa: E731
+    return (f"level_fwd2_kernel<{Cc}, {t(decoder)}, {t(sep)}>",
+            f"level_bwd3_kernel<{Cc}, {t(decoder)}, {t(sep)}, 4, {t(sym)}>")
+
+
+def time_dominant_kernel(enc, batch, reps=20):
+    """The dominant kernel -- the fused BACKWARD of the widest encoder level, the largest single launch of the step (profiles/) --
+    and the matching fused forward (maxdim = 2 levels only)."""
+    lvl = max(range(enc.num_cg_levels), key=lambda l: enc.num_channels[l] * enc.num_channels[l + 1])
+    Cc, CO = enc.num_channels[lvl], enc.num_channels[lvl + 1]
+    B, N = batch["p4"].shape[:2]
+    us_fwd, us_bwd, timing = _time_level(enc, False, lvl, batch, reps)
     fwd_flops = B * level_fwd_flops(N, Cc, CO, False)
+    kf, kb = _level_kernel_names(B, N, Cc, False)
     single = N <= 40
-    # (batches of more than 256 jets: one workgroup per jet, the symmetric radial-gradient sweep -- the last template argument)
-    sym = "true" if (B > 256 and os.environ.get("LGN_AMD_BWD_ORDERED") != "1") else "false"
-    return {"kernel": f"level_bwd3_kernel<{Cc}, false, false, 4, false, {sym}>" if single else "level_bwd (level_bwd_mix + level_bwd_sweep_enc kernels)",
+    return {"kernel": kb if single else "level_bwd (level_bwd_mix + level_bwd_sweep_enc kernels)",
             "level": lvl, "us": us_bwd, "flops": 2 * fwd_flops,          # SURVEY 8(d): backward = 2 x forward
-            "timing": mode.get("timing"),
-            "forward": {"kernel": f"level_fwd2_kernel<{Cc}, false, false, false>", "us": us_fwd, "flops": fwd_flops}}
+            "timing": timing, "forward": {"kernel": kf, "us": us_fwd, "flops": fwd_flops}}
+
+
+def cgmlp_fwd_flops(M, C, H):
+    """CGMLP forward, 2 (2C W + 5 W^2 + W 2C) flops per row."""
+    return 2 * M * (2 * C * H + 5 * H * H + H * 2 * C)
+
+
+def _time_cgmlp(net, lvl, M, reps=20):
+    """The CGMLP of level `lvl` at M rows through lgn_cgmlp_fwd/bwd_f64 (kernel only: the partial rows are reduced elsewhere)."""
+    from lgn import _native as Nn
+    dev = net.device
+    mlp = net.lgn_cg.mlp_levels[lvl]
+    ws = [l.weight.detach().contiguous() for l in mlp.linear]
+    bs = [l.bias.detach().contiguous() for l in mlp.linear]
+    C, H = net.num_channels[lvl + 1], ws[0].shape[0]
+    g = torch.Generator(device="cpu").manual_seed(3 + lvl)
+    s_in = torch.randn(2, M, C, dtype=torch.float64, generator=g).to(dev)
+    s_out, g_out, g_in = torch.empty_like(s_in), torch.randn(2, M, C, dtype=torch.float64, generator=g).to(dev), torch.empty_like(s_in)
+    L = Nn.lib()
+    wp, bp = Nn._ptr_array(ws), Nn._ptr_array(bs)
+    psize = sum(w.numel() + b.numel() for w, b in zip(ws, bs))
+    part = torch.empty(L.lgn_cgmlp_partial_rows(M, H), psize, device=dev, dtype=torch.float64)
+    P = Nn.ptr
+
+    def fwd():
+        Nn._check(L.lgn_cgmlp_fwd_f64(M, C, H, len(ws), 0, wp, bp, P(s_in), P(s_out), Nn.stream_ptr()), "lgn_cgmlp_fwd_f64")
+
+    def bwd():
+        Nn._check(L.lgn_cgmlp_bwd_f64(M, C, H, len(ws), 0, wp, bp, P(s_in), P(g_out), P(g_in), P(part), psize, Nn.stream_ptr()), "lgn_cgmlp_bwd_f64")
+
+    us_f, us_b = _events_us(fwd, reps), _events_us(bwd, reps)
+    chain = M >= 8129 and H in (12, 24, 36, 48) and H == 12 * C and os.environ.get("LGN_AMD_MLP_V1") != "1"
+    name = ("mlp_chain_{}_kernel<%d, %d, false, false>" % (H, 2 * C)) if chain else ("mlp_{}_mfma_kernel (H = %d)" % H)
+    return C, H, us_f, us_b, name
+
+
+def price_step_kernels(enc, dec, batch, ms_per_step):
+    """roofline.kernels: every kernel family of the maxdim = 2 step that takes >= 3 % of it, timed live in isolation (graph of 20
+    launches, events on the launch stream) and priced with SURVEY 8(d)'s algorithmic flops -- launches per step from the step's own
+    structure: every level forward and its CGMLP once, every level backward once, the CGMLP backward of all but each network's
+    last level (whose scalars never reach the loss).  Decoder levels run the separable O(N C) form but are priced with the pair
+    sweep's flops SURVEY counts (`note`); their `frac` therefore overstates the executed work."""
+    B, N = batch["p4"].shape[:2]
+    M = B * N
+    step_us = ms_per_step * 1e3
+    rows = []
+
+    def add(kernel, what, launches, us, flops, note=None):
+        ach = flops / (us * 1e-6) / 1e12
+        r = {"kernel": kernel, "what": what, "launches_per_step": launches, "us_per_launch": us, "share_of_step": launches * us / step_us,
+             "algorithmic_flops_per_launch": flops, "achieved": ach, "frac": ach / FP64_VECTOR_PEAK_TFLOPS}
+        if note:
+            r["note"] = note
+        rows.append(r)
+
+    for net, decoder, tag in ((enc, False, "encoder"), (dec, True, "decoder")):
+        L = net.num_cg_levels
+        shapes = {}
+        for lvl in range(L):
+            shapes.setdefault((net.num_channels[lvl], net.num_channels[lvl + 1]), []).append(lvl)
+        for (Cc, CO), lvls in shapes.items():
+            us_f, us_b, _ = _time_level(net, decoder, lvls[0], batch)
+            kf, kb = _level_kernel_names(B, N, Cc, decoder)
+            fl = B * level_fwd_flops(N, Cc, CO, decoder)
+            note = "separable O(N C) form executed; flops of the reference's pair-sweep formulation" if decoder else None
+            add(kf, f"{tag} level forward, C {Cc} -> {CO}", len(lvls), us_f, fl, note)
+            add(kb, f"{tag} level backward, C {Cc} -> {CO}", len(lvls), us_b, 2 * fl, note)
+        mshapes = {}
+        for lvl in range(L):
+            mshapes.setdefault(net.num_channels[lvl + 1], []).append(lvl)
+        for Cm, lvls in mshapes.items():
+            C, H, us_f, us_b, name = _time_cgmlp(net, lvls[0], M)
+            nb = sum(1 for l in lvls if l + 1 < L)
+            add(name.format("fwd"), f"{tag} CGMLP forward, H = {H}", len(lvls), us_f, cgmlp_fwd_flops(M, C, H))
+            if nb:
+                add(name.format("bwd"), f"{tag} CGMLP backward, H = {H}", nb, us_b, 2 * cgmlp_fwd_flops(M, C, H),
+                    "the hidden activations are recomputed: 3 x the forward's matrix work executed for 2 x counted")
+    rows.sort(key=lambda r: -r["share_of_step"])
+    return [r for r in rows if r["share_of_step"] >= 0.03], sum(r["share_of_step"] for r in rows)
 
 
 def local_level_flops(net, lvl):
@@ -549,14 +651,18 @@ def main():
         if cfg["maxdim"] == 2:
             dom = time_dominant_kernel(enc, batch)
             achieved = dom["flops"] / (dom["us"] * 1e-6) / 1e12
-            traffic = None          # HBM bytes per launch of the dominant kernel, from the PMC passes recorded under profiles/
+            traffic, traffic_src = None, None   # HBM bytes per launch of the dominant kernel, from the PMC passes recorded under profiles/
             if args.config == "cfg2" and per_gpu == 512:
+                traffic_src = f"profiles/{PROFILE_ROUND}_pmc_cfg2.json"
                 try:
-                    with open(os.path.join(ROOT, "profiles", "r04_pmc_cfg2.json")) as fh:
+                    with open(os.path.join(ROOT, traffic_src)) as fh:
                         traffic = json.load(fh)["kernels"]["lgn::" + dom["kernel"]]["derived"]["hbm_bytes"]
-                except (OSError, KeyError):
-                    pass
+                except (OSError, KeyError) as exc:
+                    print(f"bench.py: no PMC record of {dom['kernel']} in {traffic_src} ({type(exc).__name__}: {exc}); traffic = null",
+                          file=sys.stderr)
             fw = dom["forward"]
+            step_flops = WHOLE_STEP_FLOPS_PER_JET[args.config]
+            ach_step = out["value"] * step_flops / 1e12
             out["roofline"] = {
                 "bound": "mfma", "pipe": "fp64 datapath: v_fma_f64 and v_mfma_f64 share it on MI355X (measured, "
                                          "csrc/probes/mfma_rate_probe.hip: an MFMA wave and an FMA wave on one SIMD take the SUM "
@@ -565,13 +671,21 @@ def main():
                 "frac": achieved / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic,
                 "traffic_note": "bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction; an ESTIMATE: the guide "
                                 "calibrates the x2 on 16 B/lane loads, this kernel issues 8 B/lane), separate rocprofv3 "
-                                "--pmc passes recorded in profiles/r04_pmc_cfg2.json; 0.5 TB/s, HBM is not the bound",
+                                f"--pmc passes recorded in {traffic_src}; HBM is not the bound",
                 "us_per_launch": dom["us"], "timing": dom.get("timing"), "algorithmic_flops_per_launch": dom["flops"],
                 "forward_kernel": {"kernel": fw["kernel"], "us_per_launch": fw["us"], "algorithmic_flops_per_launch": fw["flops"],
                                    "achieved": fw["flops"] / (fw["us"] * 1e-6) / 1e12,
                                    "frac": fw["flops"] / (fw["us"] * 1e-6) / 1e12 / FP64_VECTOR_PEAK_TFLOPS},
                 "note": "the decoder levels run the separable O(N C) form (SURVEY a-14: an algorithmic change, "
-                        "not counted as roofline gain); this kernel is an encoder level and is unaffected"}
+                        "not counted as roofline gain); this kernel is an encoder level and is unaffected",
+                "whole_step": {"achieved": ach_step, "frac": ach_step / FP64_VECTOR_PEAK_TFLOPS, "algorithmic_flops_per_jet": step_flops,
+                               "note": "SURVEY 8(d) algorithmic flops per jet (decoder counted as pair sweeps, which the default "
+                                       "step does not execute) x measured jets/s; the honest figure is decoder_pairwise.whole_step"}}
+            if N <= 40 and world == 1 and getattr(trainer, "decoder", None) is not None:
+                ks, covered = price_step_kernels(enc, trainer.decoder, batch, out["ms_per_step"])
+                out["roofline"]["kernels"] = ks
+                out["roofline"]["kernels_note"] = (f"every kernel family >= 3 % of the step, timed in isolation (graph of 20 launches) and "
+                                                   f"priced with SURVEY 8(d) flops; level + CGMLP kernels together = {covered:.2f} of the step")
         if cfg["maxdim"] != 2:
             # table-driven levels: the dominant launch (per-node backward of the widest level) priced with SURVEY 8(d)'s counting
             # rules, and the whole-step algorithmic rate (cfg5 fwd+bwd = 109.9 MFLOP per jet) next to it
@@ -581,20 +695,21 @@ def main():
             traffic = None
             if args.config == "cfg5" and per_gpu == 512 and dom is not None:
                 try:
-                    with open(os.path.join(ROOT, "profiles", "r04_pmc_cfg5.json")) as fh:
+                    with open(os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_pmc_cfg5.json")) as fh:
                         ks = json.load(fh)["kernels"]
                     traffic = ks["lgn::" + dom["kernel"].replace("<Kind", "<lgn::cgs::Kind")]["derived"].get("hbm_bytes")
-                except (OSError, KeyError):
-                    pass
+                except (OSError, KeyError) as exc:
+                    print(f"bench.py: no PMC record of {dom['kernel']} in profiles/{PROFILE_ROUND}_pmc_cfg5.json ({type(exc).__name__}: "
+                          f"{exc}); traffic = null", file=sys.stderr)
             if dom is not None:
                 ach = dom["flops"] / (dom["us"] * 1e-6) / 1e12
                 out["roofline"] = {"bound": "mfma", "pipe": "fp64 vector datapath (no matrix instructions in this kernel; schema has hbm|mfma only)",
                                    "kernel": dom["kernel"], "achieved": ach, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                                    "frac": ach / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic,
-                                   "traffic_note": "2 x FETCH_SIZE + WRITE_SIZE of the rocprofv3 --pmc passes in profiles/r04_pmc_cfg5.json",
+                                   "traffic_note": "2 x FETCH_SIZE + WRITE_SIZE of the rocprofv3 --pmc passes in profiles/r05_pmc_cfg5.json",
                                    "us_per_launch": dom["us"], "algorithmic_flops_per_launch": dom["flops"],
                                    "note": "us_per_launch is the C-ABI call (kernel + weight packing + partial-row reduction + unpacking); "
-                                           "the kernel alone: profiles/r04_cfg5_kernel_stats.csv",
+                                           "the kernel alone: profiles/r05_cfg5_kernel_stats.csv",
                                    "whole_step": {"achieved": ach_step, "frac": ach_step / FP64_VECTOR_PEAK_TFLOPS,
                                                   "algorithmic_flops_per_jet": flops_per_jet,
                                                   "note": "SURVEY 8(d) algorithmic flops per jet x measured jets/s"}}
@@ -627,13 +742,35 @@ def main():
                 try:
                     _, pw = build("native")
                     e3 = _time_steps(pw, batch, args.steps, args.warmup, 1)
+                    pw_rate = per_gpu * args.steps / e3
                     out["roofline"]["decoder_pairwise"] = {
-                        "value": per_gpu * args.steps / e3, "unit": "jets/s", "ms_per_step": 1e3 * e3 / args.steps,
+                        "value": pw_rate, "unit": "jets/s", "ms_per_step": 1e3 * e3 / args.steps,
+                        "whole_step": {"achieved": pw_rate * WHOLE_STEP_FLOPS_PER_JET[args.config] / 1e12,
+                                       "frac": pw_rate * WHOLE_STEP_FLOPS_PER_JET[args.config] / 1e12 / FP64_VECTOR_PEAK_TFLOPS},
                         "note": "same step with LGN_AMD_DEC_PAIRWISE=1: decoder levels as O(N^2) pair sweeps, the reference's "
                                 "formulation whose flops SURVEY 8(d) counts"}
                     del pw
                 finally:
                     del os.environ["LGN_AMD_DEC_PAIRWISE"]
+        if world == 1 and not args.no_extras and args.config == "cfg2" and harness == "native" and per_gpu == cfg["B"]:
+            # the other single-GPU BASELINE configs, 20 timed steps each of the same native step (< 0.2 s of GPU time): driver-timed
+            # figures for cfg4 / cfg5 next to the headline (python bench.py --config cfgN gives the full line of each)
+            out["configs"] = {}
+            for name in ("cfg4", "cfg5"):
+                c2 = CONFIGS[name]
+                try:
+                    e2, d2 = G._models(c2["N"], c2["ch_enc"], c2["ch_dec"], dev, seed=0, maxdim=c2["maxdim"])
+                    t2 = NativeTrainStep(e2, d2, batch_size=c2["B"], lr=5e-4, l1_lambda=1e-8, use_graph=True)
+                    q4, l4 = synthetic_jets(c2["B"], c2["N"], seed=0)
+                    el = _time_steps(t2, {"p4": q4.to(dev), "labels": l4.to(dev)}, 20, 5, 1)
+                    rate = c2["B"] * 20 / el
+                    ach = rate * WHOLE_STEP_FLOPS_PER_JET[name] / 1e12
+                    out["configs"][name] = {"value": rate, "unit": "jets/s", "ms_per_step": 1e3 * el / 20, "steps": 20, "warmup": 5,
+                                            "workload": c2["text"], "whole_step": {"achieved": ach, "frac": ach / FP64_VECTOR_PEAK_TFLOPS,
+                                                                                   "algorithmic_flops_per_jet": WHOLE_STEP_FLOPS_PER_JET[name]}}
+                    del t2, e2, d2
+                except RuntimeError as exc:
+                    out["configs"][name] = {"value": None, "error": f"{type(exc).__name__}: {exc}"[:300]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out), flush=True)

@@ -58,6 +58,9 @@ int lgn_level_fwd_f64(int B, int N, int C, int CO, int decoder,
  * (row length 4*CO*5C) and for the radial network (row length lgn_level_rad_partial_len). */
 int lgn_level_bwd_partial_rows(int B, int N, int decoder, int* rows_mix, int* rows_rad);
 int lgn_level_rad_partial_len(int C, int decoder);
+/* Workgroups per jet of the pair-sweep level kernels at this batch (jets of <= 40 particles; small batches split a jet's row groups
+ * over several workgroups; 1 otherwise): what decides the partial-row counts above and which backward instantiation runs. */
+int lgn_level_jet_split(int B, int N);
 
 /* Backward of lgn_level_fwd_f64 (autograd of the same reference functions).  Edges are recomputed.
  *  in : forward inputs + ag0/ag1 + g_s_out [2][B][N][CO], g_v_out [2][B][N][CO][4]

@@ -23,6 +23,7 @@ int lgn_level_bwd_partial_rows(int B, int N, int decoder, int* rows_mix, int* ro
 }
 
 int lgn_level_rad_partial_len(int C, int decoder) { return rad_partial_size(C, decoder != 0); }
+int lgn_level_jet_split(int B, int N) { return N <= 40 ? level_jet_split(B, N) : 1; }
 
 int lgn_level_bwd_f64(int B, int N, int C, int CO, int decoder, const double* s_in, const double* v_in, const double* p,
                       const uint8_t* mask, const double* ra, const double* rb, const double* rc, const double* w0,
