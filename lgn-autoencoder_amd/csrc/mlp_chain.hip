@@ -100,7 +100,7 @@ struct Geo {
   static constexpr int WSIZE = HP * S;
   static constexpr int SR = 66;                             // row stride of the [neuron][64 rows] tiles of the backward
   static constexpr int TSIZE = HP * SR;
-  static constexpr int NREG = (HP * 4 * KSH + 255) / 256;   // staging registers per thread for a hidden image
+  static constexpr int NREG = (HP * 2 * KSH + 255) / 256;   // staging registers (PAIRS of doubles) per thread for a hidden image
   static_assert(H % 4 == 0 && D <= 16 && D <= H && H <= 48, "chain kernels: H = 12 .. 48 (multiple of 4), 2C <= 16");
   static constexpr size_t fwd_bytes() { return sizeof(double) * 2 * WSIZE; }
   static constexpr size_t bwd_bytes() { return sizeof(double) * (2 * WSIZE + 4 * TSIZE); }
@@ -120,48 +120,27 @@ struct Img {
   static constexpr int HO = G::hout(L), HI = G::hin(L);
   static constexpr int RP = L == G::NH ? 16 : G::HP;                       // rows read: a full tile of outputs
   static constexpr int CP = L == 0 ? 4 * G::KS0 : 4 * G::KSH;              // columns read by the k-steps
-  static constexpr int NP = (RP * CP + 255) / 256;
-  static_assert(NP <= G::NREG, "staging registers");
+  static constexpr int CP2 = CP / 2;                                       // ... in pairs: the images travel 16 bytes per lane
+  static constexpr int NP = (RP * CP2 + 255) / 256;                        // (a lone wave pays ~40 cycles of issue per global load)
+  static_assert(NP <= G::NREG && HI % 2 == 0, "staging registers; rows of an even number of doubles");
 };
+typedef double v2d __attribute__((ext_vector_type(2)));
 template <class G>
 struct WRegs {
-  double v[G::NREG];
+  v2d v[G::NREG];
   double b;
 };
-template <class G, int L>
-__device__ __forceinline__ void issue_image(const MlpArgs<double>& a, WRegs<G>& wr, int tid) {
-  using I = Img<G, L>;
-  const double* __restrict__ W = a.w[L];
-#pragma unroll
-  for (int i = 0; i < I::NP; ++i) {
-    const int e = tid + 256 * i, o = e / I::CP, k = e - o * I::CP;
-    const bool ok = o < I::HO && k < I::HI;
-    const double x = W[ok ? o * I::HI + k : 0];                            // clamped address + select: no branch around the load
-    wr.v[i] = ok ? x : 0.0;
-  }
-  const double bb = a.b[L][tid < I::HO ? tid : 0];
-  wr.b = tid < I::HO ? bb : 0.0;
-}
-template <class G, int L>
-__device__ __forceinline__ void commit_image(double* Wl, const WRegs<G>& wr, int tid) {
-  using I = Img<G, L>;
-#pragma unroll
-  for (int i = 0; i < I::NP; ++i) {
-    const int e = tid + 256 * i, o = e / I::CP, k = e - o * I::CP;
-    if (I::RP * I::CP % 256 == 0 || e < I::RP * I::CP) Wl[o * G::S + k] = wr.v[i];
-  }
-  if (tid < I::RP) Wl[tid * G::S + G::HP] = wr.b;
-}
-
-// one register of an image (j < NP) or its bias (j == NP): the same work as issue_image / commit_image, piece by piece
+// (a row of W_l holds an even number of doubles and every block of the parameter buffer starts on an even offset or not -- global
+// loads only need 4-byte alignment; the LDS side, (o S + k) * 8 bytes with S and k even, is 16-byte aligned as ds_write_b128 requires)
+// one register (a pair of doubles) of an image (j < NP) or its bias (j == NP)
 template <class G, int L>
 __device__ __forceinline__ void issue_piece(const MlpArgs<double>& a, WRegs<G>& wr, int tid, int j) {
   using I = Img<G, L>;
   if (j < I::NP) {
-    const int e = tid + 256 * j, o = e / I::CP, k = e - o * I::CP;
+    const int e = tid + 256 * j, o = e / I::CP2, k = 2 * (e - o * I::CP2);
     const bool ok = o < I::HO && k < I::HI;
-    const double x = a.w[L][ok ? o * I::HI + k : 0];
-    wr.v[j] = ok ? x : 0.0;
+    const v2d x = *reinterpret_cast<const v2d*>(a.w[L] + (ok ? o * I::HI + k : 0));   // clamped address + select: no branch around the load
+    wr.v[j] = ok ? x : v2d{0.0, 0.0};
   } else if (j == I::NP) {
     const double bb = a.b[L][tid < I::HO ? tid : 0];
     wr.b = tid < I::HO ? bb : 0.0;
@@ -171,11 +150,23 @@ template <class G, int L>
 __device__ __forceinline__ void commit_piece(double* Wl, const WRegs<G>& wr, int tid, int j) {
   using I = Img<G, L>;
   if (j < I::NP) {
-    const int e = tid + 256 * j, o = e / I::CP, k = e - o * I::CP;
-    if (I::RP * I::CP % 256 == 0 || e < I::RP * I::CP) Wl[o * G::S + k] = wr.v[j];
+    const int e = tid + 256 * j, o = e / I::CP2, k = 2 * (e - o * I::CP2);
+    if (I::RP * I::CP2 % 256 == 0 || e < I::RP * I::CP2) *reinterpret_cast<v2d*>(Wl + o * G::S + k) = wr.v[j];
   } else if (j == I::NP) {
     if (tid < I::RP) Wl[tid * G::S + G::HP] = wr.b;
   }
+}
+template <class G, int L>
+__device__ __forceinline__ void issue_image(const MlpArgs<double>& a, WRegs<G>& wr, int tid) {
+  using I = Img<G, L>;
+#pragma unroll
+  for (int i = 0; i < I::NP + 1; ++i) issue_piece<G, L>(a, wr, tid, i);
+}
+template <class G, int L>
+__device__ __forceinline__ void commit_image(double* Wl, const WRegs<G>& wr, int tid) {
+  using I = Img<G, L>;
+#pragma unroll
+  for (int i = 0; i < I::NP + 1; ++i) commit_piece<G, L>(Wl, wr, tid, i);
 }
 // Step q of a kernel reads the image of Linear seq(q) from buffer q & 1.  The images travel global -> registers -> LDS two steps
 // ahead of their use (two register sets, images alternate between them): with one set, i.e. one layer of lead, every step waited
