@@ -19,7 +19,7 @@ static size_t mlp_param_count(int C, int H, int nlin) {
 template <typename T>
 int mlp_dispatch(const MlpArgs<T>& a, bool backward, hipStream_t stream) {
   LGN_CHECK_ARG(a.M > 0 && a.C > 0, "cgmlp: empty input (M=%d C=%d)", a.M, a.C);
-  LGN_CHECK_ARG(a.nlin == 7, "cgmlp: only mlp_depth=6 (7 Linear layers) is built, got %d", a.nlin);
+  LGN_CHECK_ARG(a.nlin >= 4 && a.nlin <= 7, "cgmlp: mlp_depth 3 .. 6 (4 .. 7 Linear layers) are built, got %d layers", a.nlin);
   LGN_CHECK_ARG(a.C <= 8, "cgmlp: %d channels unsupported (1..8)", a.C);
   LGN_CHECK_ARG(a.act >= 0 && a.act < LGN_ACT_COUNT, "cgmlp: unknown activation id %d (LGN_ACT_*)", a.act);
   LGN_CHECK_ARG(a.H >= 2 * a.C && a.H <= 96, "cgmlp: hidden width %d unsupported (2C..96)", a.H);

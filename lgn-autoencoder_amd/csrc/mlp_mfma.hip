@@ -359,34 +359,48 @@ __global__ __launch_bounds__(64 * MT * NT) void mlp_bwd_mfma_kernel(MlpArgs<doub
   STAMP(3);
 }
 
-template <int NT, int KSH, int MT>
+template <int NT, int KSH, int MT, int NH>
 static int launch_mlp_mfma_mt(const MlpArgs<double>& a, bool backward, hipStream_t stream) {
   using G = Geo<NT, MT>;
-  constexpr int NH = 6;
   const int nblk = cdiv(a.M, 16 * MT);
   const size_t smem = sizeof(double) * (backward ? G::bwd_doubles() : G::fwd_doubles());
   static_assert(sizeof(double) * G::bwd_doubles() <= 160 * 1024, "LDS budget");
   // (LeakyReLU, the reference default, has its own instantiation: common.hpp act_apply_t)
-  auto kern = a.act == 0 ? (backward ? mlp_bwd_mfma_kernel<NT, NH, KSH, MT, false> : mlp_fwd_mfma_kernel<NT, NH, KSH, MT, false>)
-                         : (backward ? mlp_bwd_mfma_kernel<NT, NH, KSH, MT, true> : mlp_fwd_mfma_kernel<NT, NH, KSH, MT, true>);
+  // (the other depths -- mlp_depth 3 .. 5, round 5 -- share the instantiation with the activation switch)
+  auto kern = backward ? mlp_bwd_mfma_kernel<NT, NH, KSH, MT, true> : mlp_fwd_mfma_kernel<NT, NH, KSH, MT, true>;
+  if constexpr (NH == 6) {
+    if (a.act == 0) kern = backward ? mlp_bwd_mfma_kernel<NT, NH, KSH, MT, false> : mlp_fwd_mfma_kernel<NT, NH, KSH, MT, false>;
+  }
   if (smem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   hipLaunchKernelGGL(kern, dim3(nblk), dim3(G::THREADS), smem, stream, a);
   LGN_CHECK_LAUNCH();
   return 0;
 }
-template <int NT, int KSH>
+template <int NT, int KSH, int NH = 6>
 static int launch_mlp_mfma(const MlpArgs<double>& a, bool backward, hipStream_t stream) {
   // (measured again in round 4 with today's staging: 32-row forward workgroups, two per CU with independent barrier domains --
   // MT = 2, 68 KB of LDS -- take the cfg2 step from 0.568 to 0.584 ms)
-  return mlp_rows_per_workgroup(a.M, a.H) == 16 ? launch_mlp_mfma_mt<NT, KSH, 1>(a, backward, stream)
-                                                 : launch_mlp_mfma_mt<NT, KSH, 4>(a, backward, stream);
+  return mlp_rows_per_workgroup(a.M, a.H) == 16 ? launch_mlp_mfma_mt<NT, KSH, 1, NH>(a, backward, stream)
+                                                 : launch_mlp_mfma_mt<NT, KSH, 4, NH>(a, backward, stream);
 }
 
-// H <= 48, 2C <= 16, 7 Linear layers.  Returns -2 if the shape is outside this kernel's range.
+// the depths besides the reference default (mlp_depth 3 .. 5 = 4 .. 6 Linear layers): run-time k-loops
+template <int NH>
+static int launch_mlp_mfma_depth(const MlpArgs<double>& a, bool backward, hipStream_t stream) {
+  const int nt = (a.H + 15) / 16;
+  if (nt == 1) return launch_mlp_mfma<1, 0, NH>(a, backward, stream);
+  if (nt == 2) return launch_mlp_mfma<2, 0, NH>(a, backward, stream);
+  return launch_mlp_mfma<3, 0, NH>(a, backward, stream);
+}
+
+// H <= 48, 2C <= 16, 4 .. 7 Linear layers (mlp_depth 3 .. 6).  Returns -2 if the shape is outside this kernel's range.
 int mlp_mfma_dispatch(const MlpArgs<double>& a, bool backward, hipStream_t stream) {
-  if (a.nlin != 7 || a.H > 48 || 2 * a.C > 16 || a.H < 2 * a.C) return -2;
+  if (a.nlin < 4 || a.nlin > 7 || a.H > 48 || 2 * a.C > 16 || a.H < 2 * a.C) return -2;
   LGN_CHECK_ARG(!a.h_saved || a.h_rows >= mlp_saved_rows(a.M), "CGMLP: the saved-activation buffer has %d rows per layer, %d rows need %d",
                 a.h_rows, a.M, mlp_saved_rows(a.M));
+  if (a.nlin == 4) return launch_mlp_mfma_depth<3>(a, backward, stream);
+  if (a.nlin == 5) return launch_mlp_mfma_depth<4>(a, backward, stream);
+  if (a.nlin == 6) return launch_mlp_mfma_depth<5>(a, backward, stream);
   const int nt = (a.H + 15) / 16;
   // fully unrolled k-loops for the widths of the reference configs (H = 6 * 2C); anything else keeps the run-time loop
   if (a.H == 48) return launch_mlp_mfma<3, 12>(a, backward, stream);

@@ -465,17 +465,18 @@ __global__ __launch_bounds__(64 * MT * NT) void mlp_bwd_wide_2pass_kernel(MlpArg
   }
 }
 
-template <int NT>
+template <int NT, int NH = 6>
 static int launch(const MlpArgs<double>& a, bool backward, hipStream_t stream) {
   using G = Geo<NT>;
-  constexpr int NH = 6;
   const size_t smem = sizeof(double) * (backward ? (G::ONE_PASS ? G::bwd_doubles() : G::bwd2p_doubles()) : G::fwd_doubles());
   static_assert(sizeof(double) * G::bwd2p_doubles() <= 160 * 1024 && sizeof(double) * G::fwd_doubles() <= 160 * 1024, "LDS budget");
   // (LeakyReLU, the reference default, has its own instantiation: common.hpp act_apply_t)
-  void (*kern)(MlpArgs<double>) = a.act == 0 ? mlp_fwd_wide_kernel<NT, NH, false> : mlp_fwd_wide_kernel<NT, NH, true>;
+  // (mlp_depth 3 .. 5 share the instantiation with the activation switch)
+  constexpr bool DEF = NH == 6;
+  void (*kern)(MlpArgs<double>) = (DEF && a.act == 0) ? mlp_fwd_wide_kernel<NT, NH, !DEF> : mlp_fwd_wide_kernel<NT, NH, true>;
   if (backward) {
-    if constexpr (G::ONE_PASS) kern = a.act == 0 ? mlp_bwd_wide_kernel<NT, NH, false> : mlp_bwd_wide_kernel<NT, NH, true>;
-    else kern = a.act == 0 ? mlp_bwd_wide_2pass_kernel<NT, NH, false> : mlp_bwd_wide_2pass_kernel<NT, NH, true>;
+    if constexpr (G::ONE_PASS) kern = (DEF && a.act == 0) ? mlp_bwd_wide_kernel<NT, NH, !DEF> : mlp_bwd_wide_kernel<NT, NH, true>;
+    else kern = (DEF && a.act == 0) ? mlp_bwd_wide_2pass_kernel<NT, NH, !DEF> : mlp_bwd_wide_2pass_kernel<NT, NH, true>;
   }
   if (smem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   const int nblk = backward ? cdiv(a.M, 64) : cdiv(a.M, 16 * MT);
@@ -486,13 +487,20 @@ static int launch(const MlpArgs<double>& a, bool backward, hipStream_t stream) {
 
 }  // namespace wide
 
-// 48 < H <= 96, 2C <= 16, 7 Linear layers.  Returns -2 if the shape is outside this kernel's range.
-int mlp_mfma_wide_dispatch(const MlpArgs<double>& a, bool backward, hipStream_t stream) {
-  if (a.nlin != 7 || a.H <= 48 || a.H > 96 || 2 * a.C > 16 || a.H < 2 * a.C) return -2;
+template <int NH>
+static int wide_launch_depth(const MlpArgs<double>& a, bool backward, hipStream_t stream) {
   const int nt = (a.H + 15) / 16;
-  if (nt == 4) return wide::launch<4>(a, backward, stream);
-  if (nt == 5) return wide::launch<5>(a, backward, stream);
-  return wide::launch<6>(a, backward, stream);
+  if (nt == 4) return wide::launch<4, NH>(a, backward, stream);
+  if (nt == 5) return wide::launch<5, NH>(a, backward, stream);
+  return wide::launch<6, NH>(a, backward, stream);
+}
+// 48 < H <= 96, 2C <= 16, 4 .. 7 Linear layers (mlp_depth 3 .. 6).  Returns -2 if the shape is outside this kernel's range.
+int mlp_mfma_wide_dispatch(const MlpArgs<double>& a, bool backward, hipStream_t stream) {
+  if (a.nlin < 4 || a.nlin > 7 || a.H <= 48 || a.H > 96 || 2 * a.C > 16 || a.H < 2 * a.C) return -2;
+  if (a.nlin == 4) return wide_launch_depth<3>(a, backward, stream);
+  if (a.nlin == 5) return wide_launch_depth<4>(a, backward, stream);
+  if (a.nlin == 6) return wide_launch_depth<5>(a, backward, stream);
+  return wide_launch_depth<6>(a, backward, stream);
 }
 
 }  // namespace lgn

@@ -68,7 +68,7 @@ struct MlpArgs {
 };
 inline int mlp_saved_rows(int M) { return (M + 63) & ~63; }
 inline size_t mlp_saved_doubles(int M, int H, int nlin) {
-  return H <= 48 && nlin == 7 ? (size_t)(nlin - 1) * mlp_saved_rows(M) * ((H + 15) & ~15) : 0;
+  return H <= 48 && nlin >= 4 && nlin <= 7 ? (size_t)(nlin - 1) * mlp_saved_rows(M) * ((H + 15) & ~15) : 0;
 }
 // Worth it only for small batches: the copy is 6 x M x 48 doubles per CGMLP (35 MB at 512 x 30 rows: measured, the step got
 // 26 us SLOWER -- writing and re-reading it costs more than the six recomputed layers), while at 64 x 30 rows (4.4 MB) the

@@ -351,7 +351,7 @@ int check_desc(const lgn_net_desc* d) {
   LGN_CHECK_ARG(d, "step: null descriptor");
   LGN_CHECK_ARG(d->B > 0 && d->N > 0, "step: empty batch (B=%d N=%d)", d->B, d->N);
   LGN_CHECK_ARG(d->n_levels >= 1 && d->n_levels <= 4, "step: n_levels=%d unsupported (1..4)", d->n_levels);
-  LGN_CHECK_ARG(d->mlp_nlin == 7, "step: mlp_depth must be 6 (7 Linear layers)");
+  LGN_CHECK_ARG(d->mlp_nlin >= 4 && d->mlp_nlin <= 7, "step: mlp_depth must be 3 .. 6 (4 .. 7 Linear layers), got %d layers", d->mlp_nlin);
   LGN_CHECK_ARG(d->tau_s >= 1 && d->tau_v >= 1 && d->tau_v_in >= 0, "step: latent multiplicities must be positive");
   LGN_CHECK_ARG(d->n_in_scalars >= 0 && d->n_in_scalars <= 8, "step: n_in_scalars=%d unsupported (0..8)", d->n_in_scalars);
   LGN_CHECK_ARG(pool_valid(d->latent_pool), "step: latent_pool=%d is not an LGN_POOL(...) code", d->latent_pool);

@@ -235,7 +235,7 @@ class NativeTrainStep:
             # layout -> refuse instead of computing garbage.
             raise NotImplementedError(
                 "the native step implements maxdim=2 / maxdim=3 networks (the same kind for encoder and decoder) with "
-                "map_to_latent = min / max / mean joined by '&' or '+', CGMLP levels (mlp_depth=6), num_basis_fn=10 and <= 8 channels; got encoder "
+                "map_to_latent = min / max / mean joined by '&' or '+', CGMLP levels (mlp_depth 3 .. 6), num_basis_fn=10 and <= 8 channels; got encoder "
                 f"maxdim={encoder.level_maxdim} map_to_latent={encoder.map_to_latent!r} mlp={encoder.mlp} mlp_depth="
                 f"{encoder.mlp_depth}, decoder maxdim={decoder.level_maxdim} mlp={decoder.mlp}")
         if getattr(encoder, "tau_input_scalars", 1) != 1:

@@ -24,6 +24,8 @@ Fixtures
   g9_e2e_elu.npz      end-to-end, B=3 N=12 maxdim=2 ch 2233/3322, activation='elu'
   g10_e2e_jetfeat.npz end-to-end, B=3 N=12 maxdim=2 ch 2233/3322, jet_features=True (13th node = jet momentum, second input scalar)
                       plus one extra input scalar per node through data['scalars']
+  g11_e2e_mlpdepth4.npz / g11_e2e_mlpdepth3_maxdim3.npz  end-to-end with --mlp-depth 4 (maxdim 2, B=3 N=12 ch 2344/4432) and 3 (maxdim 3,
+                      B=2 N=10 ch 246/642): CGMLPs of 5 / 4 Linear layers (round 5)
   g8_harness.npz      the reference's own equivariance harness (lgn/models/autotest/lgn_tests.py:292-423) run on the g1 weights
                       (maxdim 2) and the g2 weights (maxdim 3): gamma / theta grids, output and internal-feature deviation
                       tables, permutation results, on fixed zero-padded jets (SURVEY 8c "G6 harness")
@@ -80,10 +82,11 @@ def jets(B, N, seed, pad_rows=()):
     return p4, labels
 
 
-def build(N, maxdim, ch_enc, ch_dec, seed, map_to_latent="min&max", activation="leakyrelu", jet_features=False, tau_input_scalars=1):
+def build(N, maxdim, ch_enc, ch_dec, seed, map_to_latent="min&max", activation="leakyrelu", jet_features=False, tau_input_scalars=1,
+          mlp_depth=6):
     torch.manual_seed(seed)
     common = dict(maxdim=[maxdim], max_zf=[1], weight_init="randn", level_gain=[1.0], num_basis_fn=10,
-                  activation=activation, mlp=True, mlp_depth=6, mlp_width=6, device=CPU, dtype=F64)
+                  activation=activation, mlp=True, mlp_depth=mlp_depth, mlp_width=6, device=CPU, dtype=F64)
     enc = LGNEncoder(num_input_particles=N, tau_input_scalars=tau_input_scalars, tau_input_vectors=1, map_to_latent=map_to_latent,
                      tau_latent_scalars=1, tau_latent_vectors=8, num_channels=list(ch_enc), scale=1.0,
                      jet_features=jet_features, **common)
@@ -94,14 +97,16 @@ def build(N, maxdim, ch_enc, ch_dec, seed, map_to_latent="min&max", activation="
 
 
 def e2e(name, B, N, maxdim, ch_enc, ch_dec, seed, pad_rows=(), map_to_latent="min&max", activation="leakyrelu", jet_features=False,
-        extra_scalars=0):
-    enc, dec = build(N, maxdim, ch_enc, ch_dec, seed, map_to_latent, activation, jet_features, 1 + extra_scalars)
+        extra_scalars=0, mlp_depth=6):
+    enc, dec = build(N, maxdim, ch_enc, ch_dec, seed, map_to_latent, activation, jet_features, 1 + extra_scalars, mlp_depth)
     p4, labels = jets(B, N, seed + 100, pad_rows)
     meta = dict(B=B, N=N, maxdim=maxdim, ch_enc=list(ch_enc), ch_dec=list(ch_dec), seed=seed, l1_lambda=1e-8, map_to_latent=map_to_latent)
     if activation != "leakyrelu":
         meta["activation"] = activation
     if jet_features or extra_scalars:
         meta["jet_features"], meta["extra_scalars"] = bool(jet_features), extra_scalars
+    if mlp_depth != 6:
+        meta["mlp_depth"] = mlp_depth
     store = {"p4": npy(p4), "labels": npy(labels), "meta": np.array(json.dumps(meta))}
     for k, v in enc.state_dict().items():
         store["enc." + k] = npy(v)
@@ -331,5 +336,9 @@ if __name__ == "__main__":
     if want("g9"):
         activations()
         e2e("g9_e2e_elu.npz", 3, 12, 2, (2, 2, 3, 3), (3, 3, 2, 2), seed=5, pad_rows=((1, 7),), activation="elu")
+    if want("g11"):       # --mlp-depth other than the default 6 (lgn/models/lgn_levels.py:151-176): 5 Linear layers at maxdim 2 (H <= 48
+        # kernels), 4 at maxdim 3 (H = 72: the wide kernels)
+        e2e("g11_e2e_mlpdepth4.npz", 3, 12, 2, (2, 3, 4, 4), (4, 4, 3, 2), seed=7, pad_rows=((1, 8),), mlp_depth=4)
+        e2e("g11_e2e_mlpdepth3_maxdim3.npz", 2, 10, 3, (2, 4, 6), (6, 4, 2), seed=8, pad_rows=((0, 7),), mlp_depth=3)
     if want("g10"):
         e2e("g10_e2e_jetfeat.npz", 3, 12, 2, (2, 2, 3, 3), (3, 3, 2, 2), seed=6, pad_rows=((2, 9),), jet_features=True, extra_scalars=1)

@@ -524,7 +524,8 @@ def _build(meta, dev):
     import __graft_entry__ as G
     enc, dec = G._models(meta["N"], meta["ch_enc"], meta["ch_dec"], dev, seed=meta["seed"], maxdim=meta["maxdim"],
                          map_to_latent=meta.get("map_to_latent", "min&max"), activation=meta.get("activation", "leakyrelu"),
-                         jet_features=meta.get("jet_features", False), tau_input_scalars=1 + meta.get("extra_scalars", 0))
+                         jet_features=meta.get("jet_features", False), tau_input_scalars=1 + meta.get("extra_scalars", 0),
+                         mlp_depth=meta.get("mlp_depth", 6))
     return enc, dec
 
 
@@ -615,7 +616,8 @@ def _generic_level_case(dev, O, decoder, maxdim, full, C, CO, N, B):
 
 
 @pytest.mark.parametrize("name", ["g1_e2e_maxdim2.npz", "g3_e2e_n150.npz", "g2_e2e_maxdim3.npz", "g6_e2e_mix.npz",
-                                  "g7_e2e_meanmax.npz", "g9_e2e_elu.npz", "g10_e2e_jetfeat.npz"])
+                                  "g7_e2e_meanmax.npz", "g9_e2e_elu.npz", "g10_e2e_jetfeat.npz", "g11_e2e_mlpdepth4.npz",
+                                  "g11_e2e_mlpdepth3_maxdim3.npz"])
 @pytest.mark.parametrize("fused", [True, False])
 def test_end_to_end_vs_reference_golden(dev, O, name, fused):
     """Full encoder -> decoder -> Chamfer forward/backward against vectors captured from the reference, through the

@@ -230,7 +230,7 @@ def test_native_step_refuses_configurations_it_does_not_implement():
     with pytest.raises(NotImplementedError, match="same kind"):       # mixed fused / table-driven networks
         NativeTrainStep(enc, dec, batch_size=4)
     enc, dec = G._models(30, (3, 3, 4, 4), (4, 4, 3, 3), torch.device("cpu"), seed=0)
-    enc.mlp_depth = 5                                                   # the native CGMLP is the 7-Linear stack only
+    enc.mlp_depth = 2                                                   # the native CGMLP kernels are built for mlp_depth 3 .. 6
     enc.__dict__.pop("_native_kind", None)
     with pytest.raises(NotImplementedError, match="mlp_depth"):
         NativeTrainStep(enc, dec, batch_size=4)
