@@ -106,7 +106,7 @@ struct LevelBwdArgs {
 };
 
 // Per-node stride (in scalars) of the node tile kept in LDS: [c][ s_r s_i v_r[4] v_i[4] ] + 2 pad.
-__host__ __device__ constexpr int node_stride(int C) { return 10 * C + 2; }
+__host__ __device__ constexpr int node_stride(int C) { return 10 * C + 4; }
 
 // encoder radial partial layout: T1[4C][20] | T2[4C][20] | S[4C] | dB[4C]
 // decoder: dB0[C] | dB1[C]

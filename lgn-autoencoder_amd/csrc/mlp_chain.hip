@@ -71,9 +71,9 @@ constexpr int LOOKAHEAD = 9;
 // pieces [i T / N, (i + 1) T / N) of a list of T pieces, for item i of N
 template <int N, int T, class F>
 __device__ __forceinline__ void deal(int i, F piece) {
+  const int j0 = (i * T + N - 1) / N, j1 = ((i + 1) * T + N - 1) / N;       // (constants once the item loop is unrolled)
 #pragma unroll
-  for (int j = 0; j < T; ++j)
-    if (j * N >= i * T && j * N < (i + 1) * T) piece(j);
+  for (int j = j0; j < j1; ++j) piece(j);
 }
 // keeps a value's computation on this side of the next scheduling fence (instruction selection places unchained arithmetic freely)
 __device__ __forceinline__ void pin(double& x) { asm volatile("" : "+v"(x)); }
@@ -101,7 +101,7 @@ struct Geo {
   static constexpr int SR = 66;                             // row stride of the [neuron][64 rows] tiles of the backward
   static constexpr int TSIZE = HP * SR;
   static constexpr int NREG = (HP * 2 * KSH + 255) / 256;   // staging registers (PAIRS of doubles) per thread for a hidden image
-  static_assert(H % 4 == 0 && D <= 16 && D <= H && H <= 48, "chain kernels: H = 12 .. 48 (multiple of 4), 2C <= 16");
+  static_assert(H % 4 == 0 && D <= 16 && D <= H && H <= 96, "chain kernels: H = 12 .. 96 (multiple of 4; the backward: H <= 48), 2C <= 16");
   static constexpr size_t fwd_bytes() { return sizeof(double) * 2 * WSIZE; }
   static constexpr size_t bwd_bytes() { return sizeof(double) * (2 * WSIZE + 4 * TSIZE); }
   // offsets of (W_l, b_l) in a partial row / parameter block: concat_l (W_l, b_l)
@@ -556,6 +556,19 @@ __global__ __launch_bounds__(256) void mlp_chain_bwd_kernel(MlpArgs<double> a) {
   STAMP(26);
 }
 
+// 48 < H <= 96 (C = 5 .. 8): the FORWARD chain only -- its two weight images (up to 150 KB) and ping-ponged activations fit; the
+// backward's tiles and six kept activations do not (LDS 274 KB, > 512 registers), it stays with mlp_mfma_wide.hip
+template <int H, int D>
+static int launch_fwd(const MlpArgs<double>& a, hipStream_t stream) {
+  using G = Geo<H, D>;
+  static_assert(G::fwd_bytes() <= 160 * 1024, "LDS budget");
+  auto kern = a.act == 0 ? mlp_chain_fwd_kernel<H, D, false, false> : mlp_chain_fwd_kernel<H, D, true, false>;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::fwd_bytes());
+  hipLaunchKernelGGL(kern, dim3(cdiv(a.M, 64)), dim3(256), G::fwd_bytes(), stream, a);
+  LGN_CHECK_LAUNCH();
+  return 0;
+}
+
 template <int H, int D>
 static int launch(const MlpArgs<double>& a, bool backward, hipStream_t stream) {
   using G = Geo<H, D>;
@@ -584,6 +597,12 @@ int mlp_chain_dispatch(const MlpArgs<double>& a, bool backward, hipStream_t stre
   if (a.H == 36 && a.C == 3) return chain::launch<36, 6>(a, backward, stream);
   if (a.H == 24 && a.C == 2) return chain::launch<24, 4>(a, backward, stream);
   if (a.H == 12 && a.C == 1) return chain::launch<12, 2>(a, backward, stream);
+  if (!backward && !a.h_saved) {
+    if (a.H == 60 && a.C == 5) return chain::launch_fwd<60, 10>(a, stream);
+    if (a.H == 72 && a.C == 6) return chain::launch_fwd<72, 12>(a, stream);
+    if (a.H == 84 && a.C == 7) return chain::launch_fwd<84, 14>(a, stream);
+    if (a.H == 96 && a.C == 8) return chain::launch_fwd<96, 16>(a, stream);
+  }
   return -2;
 }
 

@@ -416,7 +416,9 @@ def test_cgmlp_activations_vs_reference_golden(dev, act):
 @pytest.mark.parametrize("C,B,N,act", [(3, 2, 30, "leakyrelu"), (4, 3, 30, "leakyrelu"), (4, 1, 150, "leakyrelu"), (2, 1, 5, "leakyrelu"),
                                        (6, 1, 40, "leakyrelu"), (6, 3, 37, "leakyrelu"), (5, 2, 30, "leakyrelu"), (8, 1, 70, "leakyrelu"),
                                        # >= 8192 rows: 64-row workgroups (fewer rows: 16-row ones, H <= 48)
-                                       (4, 300, 30, "leakyrelu"), (3, 275, 30, "leakyrelu"),
+                                       (4, 300, 30, "leakyrelu"), (3, 275, 30, "leakyrelu"), (2, 280, 30, "leakyrelu"), (1, 300, 30, "relu"),
+                                       # ... and 48 < H <= 96: the chain forward, the wide backward
+                                       (6, 300, 30, "leakyrelu"), (5, 275, 30, "leakyrelu"), (8, 280, 30, "elu"), (7, 272, 30, "leakyrelu"),
                                        # the other activations through every kernel family: 16-row and 64-row H <= 48, one-pass and
                                        # two-pass wide
                                        (4, 3, 30, "elu"), (4, 300, 30, "sigmoid"), (6, 3, 37, "atan"), (5, 2, 30, "logsigmoid"),
