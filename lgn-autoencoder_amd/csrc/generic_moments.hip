@@ -161,17 +161,20 @@ __device__ __forceinline__ void load_pos(const GenArgs& a, int b, double* pj, ui
 // =========================================================================================================
 // forward:  U[b][i][c][q][k][z]
 // =========================================================================================================
-template <int C, bool DEC>
+// XL: the jet's packed features are staged in LDS (N C Q 16 bytes); XL = false (round 5: jets whose features do not fit -- 150
+// particles at maxdim 3 are 288 KB -- used to be refused) reads them from global memory instead, every source row from L1 / L2.
+template <int C, bool DEC, bool XL>
 __global__ __launch_bounds__(BLOCK) void moments_fwd_kernel(GenArgs a) {
   constexpr int NG = (C + 3) / 4;
   constexpr int PS = DEC ? 8 : 4;
   const int N = a.N, B = a.B, Q = a.Q;
   const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   extern __shared__ __align__(16) unsigned char smem_raw[];
-  double* xs = reinterpret_cast<double*>(smem_raw);           // N * C * Q * 2
-  double* pj = xs + (size_t)N * C * Q * 2;                    // N * PS
+  double* xs = reinterpret_cast<double*>(smem_raw);           // N * C * Q * 2 (XL)
+  double* pj = xs + (XL ? (size_t)N * C * Q * 2 : 0);         // N * PS
   uint8_t* mk = reinterpret_cast<uint8_t*>(pj + N * PS);
-  load_packed(a.X, B, N, C, Q, b, xs);
+  const size_t xplane = (size_t)B * N * C * Q;
+  if (XL) load_packed(a.X, B, N, C, Q, b, xs);
   load_pos<DEC>(a, b, pj, mk);
   RadConst<C, DEC> rc;
   rc.load(a, lane);
@@ -215,10 +218,11 @@ __global__ __launch_bounds__(BLOCK) void moments_fwd_kernel(GenArgs a) {
 #pragma unroll
               for (int m = 0; m < 4; ++m) e[1 + m] = cmul(R1, q[m]);
               const double* xj = xs + ((size_t)jj * C + ch) * Q * 2;
+              const double* xg = a.X + (((size_t)b * N + jj) * C + ch) * Q;
 #pragma unroll
               for (int x = 0; x < QC; ++x) {
                 if (q0 + x < Q) {
-                  const cx<double> xv = {xj[(q0 + x) * 2], xj[(q0 + x) * 2 + 1]};
+                  const cx<double> xv = XL ? cx<double>{xj[(q0 + x) * 2], xj[(q0 + x) * 2 + 1]} : cx<double>{xg[q0 + x], xg[xplane + q0 + x]};
 #pragma unroll
                   for (int k = 0; k < 5; ++k) cfma(acc[g][x][k], xv, e[k]);
                 }
@@ -361,7 +365,7 @@ __global__ __launch_bounds__(BLOCK) void moments_bwd_nodes_kernel(GenArgs a) {
 // backward, i-centric: radial parameter gradient sums (encoder: T1|T2|S|dB as in level_bwd2; decoder: bias sums)
 // and the decoder's d p_i.   G_e_k[c] = sum_q gU[i][c][q][k] conj(X_j[c][q])
 // =========================================================================================================
-template <int C, bool DEC>
+template <int C, bool DEC, bool XL>
 __global__ __launch_bounds__(BLOCK) void moments_bwd_rad_kernel(GenArgs a) {
   constexpr int NG = (C + 3) / 4;
   constexpr int PS = DEC ? 8 : 4;
@@ -369,12 +373,13 @@ __global__ __launch_bounds__(BLOCK) void moments_bwd_rad_kernel(GenArgs a) {
   const int N = a.N, B = a.B, Q = a.Q;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   extern __shared__ __align__(16) unsigned char smem_raw[];
-  double* xs = reinterpret_cast<double*>(smem_raw);           // N * C * Q * 2
-  double* pj = xs + (size_t)N * C * Q * 2;                    // N * PS
+  double* xs = reinterpret_cast<double*>(smem_raw);           // N * C * Q * 2 (XL; else read from global memory, see moments_fwd_kernel)
+  double* pj = xs + (XL ? (size_t)N * C * Q * 2 : 0);         // N * PS
+  const size_t xplane = (size_t)B * N * C * Q;
   double* tr = pj + N * PS;                                   // 4 waves * (NG + 3) * 16 * TS   (also the final reduction buffer)
   constexpr int TRSZ = 4 * (NG + 3) * 16 * TS > 4 * 64 * NG * 12 ? 4 * (NG + 3) * 16 * TS : 4 * 64 * NG * 12;
   uint8_t* mk = reinterpret_cast<uint8_t*>(tr + TRSZ);
-  load_packed(a.X, B, N, C, Q, b, xs);
+  if (XL) load_packed(a.X, B, N, C, Q, b, xs);
   load_pos<DEC>(a, b, pj, mk);
   RadConst<C, DEC> rc;
   rc.load(a, lane);
@@ -433,10 +438,11 @@ __global__ __launch_bounds__(BLOCK) void moments_bwd_rad_kernel(GenArgs a) {
         double G0r = 0, G0i = 0, G1r = 0, G1i = 0;
         if (ok && ch < C) {
           const double* xj = xs + ((size_t)jj * C + ch) * Q * 2;
+          const double* xg = a.X + (((size_t)b * N + jj) * C + ch) * Q;
           const double* gu = a.gU + (((size_t)b * N + ii) * C + ch) * Q * 10;
           cx<double> ge[5] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}};
           for (int x = 0; x < Q; ++x) {
-            const cx<double> xv = {xj[2 * x], xj[2 * x + 1]};
+            const cx<double> xv = XL ? cx<double>{xj[2 * x], xj[2 * x + 1]} : cx<double>{xg[x], xg[xplane + x]};
 #pragma unroll
             for (int k = 0; k < 5; ++k) cfmac(ge[k], cx<double>{gu[x * 10 + 2 * k], gu[x * 10 + 2 * k + 1]}, xv);
           }
@@ -577,17 +583,20 @@ static int launch_moments(const GenArgs& a, int which, hipStream_t st) {
   const size_t xs = sizeof(double) * (size_t)a.N * C * a.Q * 2, pos = sizeof(double) * (size_t)a.N * PS + a.N + 16;
   int rc;
   if (which == 0) {
-    auto k = moments_fwd_kernel<C, DEC>;
-    if ((rc = set_smem(k, xs + pos, "moments_fwd"))) return rc;
-    hipLaunchKernelGGL(k, dim3(a.B), dim3(BLOCK), xs + pos, st, a);
+    const bool xl = xs + pos <= 160 * 1024;          // (jets whose features do not fit read them from global memory)
+    auto k = xl ? moments_fwd_kernel<C, DEC, true> : moments_fwd_kernel<C, DEC, false>;
+    const size_t smem = (xl ? xs : 0) + pos;
+    if ((rc = set_smem(k, smem, "moments_fwd"))) return rc;
+    hipLaunchKernelGGL(k, dim3(a.B), dim3(BLOCK), smem, st, a);
   } else if (which == 1) {
     auto k = moments_bwd_nodes_kernel<C, DEC>;
     if ((rc = set_smem(k, pos, "moments_bwd_nodes"))) return rc;
     hipLaunchKernelGGL(k, dim3(a.B), dim3(BLOCK), pos, st, a);
   } else {
     constexpr int TRSZ = 4 * (NG + 3) * 16 * 18 > 4 * 64 * NG * 12 ? 4 * (NG + 3) * 16 * 18 : 4 * 64 * NG * 12;
-    auto k = moments_bwd_rad_kernel<C, DEC>;
-    const size_t smem = xs + pos + sizeof(double) * TRSZ;
+    const bool xl = xs + pos + sizeof(double) * TRSZ <= 160 * 1024;
+    auto k = xl ? moments_bwd_rad_kernel<C, DEC, true> : moments_bwd_rad_kernel<C, DEC, false>;
+    const size_t smem = (xl ? xs : 0) + pos + sizeof(double) * TRSZ;
     if ((rc = set_smem(k, smem, "moments_bwd_rad"))) return rc;
     hipLaunchKernelGGL(k, dim3(a.B), dim3(BLOCK), smem, st, a);
   }

@@ -26,6 +26,7 @@ Fixtures
                       plus one extra input scalar per node through data['scalars']
   g11_e2e_mlpdepth4.npz / g11_e2e_mlpdepth3_maxdim3.npz  end-to-end with --mlp-depth 4 (maxdim 2, B=3 N=12 ch 2344/4432) and 3 (maxdim 3,
                       B=2 N=10 ch 246/642): CGMLPs of 5 / 4 Linear layers (round 5)
+  g12_e2e_n150_maxdim3.npz  end-to-end, B=1 N=150 maxdim=3 ch 4466/6644 (round 5: jets beyond the LDS-resident kernels)
   g8_harness.npz      the reference's own equivariance harness (lgn/models/autotest/lgn_tests.py:292-423) run on the g1 weights
                       (maxdim 2) and the g2 weights (maxdim 3): gamma / theta grids, output and internal-feature deviation
                       tables, permutation results, on fixed zero-padded jets (SURVEY 8c "G6 harness")
@@ -340,5 +341,7 @@ if __name__ == "__main__":
         # kernels), 4 at maxdim 3 (H = 72: the wide kernels)
         e2e("g11_e2e_mlpdepth4.npz", 3, 12, 2, (2, 3, 4, 4), (4, 4, 3, 2), seed=7, pad_rows=((1, 8),), mlp_depth=4)
         e2e("g11_e2e_mlpdepth3_maxdim3.npz", 2, 10, 3, (2, 4, 6), (6, 4, 2), seed=8, pad_rows=((0, 7),), mlp_depth=3)
+    if want("g12"):       # 150 particles at maxdim 3 (the product of two BASELINE axes; the jet's packed features exceed a CU's LDS)
+        e2e("g12_e2e_n150_maxdim3.npz", 1, 150, 3, (4, 4, 6, 6), (6, 6, 4, 4), seed=9, pad_rows=((0, 137),))
     if want("g10"):
         e2e("g10_e2e_jetfeat.npz", 3, 12, 2, (2, 2, 3, 3), (3, 3, 2, 2), seed=6, pad_rows=((2, 9),), jet_features=True, extra_scalars=1)

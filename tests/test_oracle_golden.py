@@ -19,7 +19,7 @@ def _cfgs(m):
 
 @pytest.mark.parametrize("name", ["g1_e2e_maxdim2.npz", "g2_e2e_maxdim3.npz", "g3_e2e_n150.npz", "g6_e2e_mix.npz",
                                   "g7_e2e_meanmax.npz", "g9_e2e_elu.npz", "g10_e2e_jetfeat.npz", "g11_e2e_mlpdepth4.npz",
-                                  "g11_e2e_mlpdepth3_maxdim3.npz"])
+                                  "g11_e2e_mlpdepth3_maxdim3.npz", "g12_e2e_n150_maxdim3.npz"])
 def test_end_to_end_forward_backward(name):
     z = U.load(name)
     m = U.meta(z)
