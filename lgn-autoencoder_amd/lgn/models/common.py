@@ -253,7 +253,7 @@ def run_levels(module, decoder: bool, feats, p, mask):
     out = [feats]
     for lvl, plan in enumerate(plans):
         mix = lgn_cg.node_levels[lvl].cat_mix.mix_reps
-        radp = rad_funcs.rad_funcs[lvl].flat_params()
+        radp = rad_funcs.rad_funcs[lvl].kernel_params()       # (zero-padded to the kernels' 20 bells when num_basis_fn < 10)
         if _is_fused_layout(plan, module.level_maxdim[lvl]):
             s, v = ops.LevelFn.apply(decoder, feats[(0, 0)].squeeze(-1), feats[(1, 1)], p, mask, *radp,
                                      mix.weight((0, 0)), mix.weight((1, 1)))

@@ -125,6 +125,9 @@ class RadPolyTrig(nn.Module):
             raise ValueError("Input basis can only be 'cartesian' or 'canonical'!")
         if not (mix is True or mix == "cplx"):
             raise NotImplementedError("the native radial network implements mix='cplx' (the only mode the autoencoder uses)")
+        if not 1 <= num_basis_fn <= self.KERNEL_BELLS // 2:
+            raise NotImplementedError(f"the native radial network evaluates up to {self.KERNEL_BELLS} Lorentzian bells (num_basis_fn <= "
+                                      f"{self.KERNEL_BELLS // 2}); got num_basis_fn={num_basis_fn}")
         self.max_zf, self.num_basis_fn, self.num_channels, self.input_basis = max_zf, num_basis_fn, num_channels, input_basis
         nb = 2 * num_basis_fn
         # drawn in the default dtype on the CPU, then cast/moved, like the reference (position_levels.py:67-73)
@@ -135,8 +138,22 @@ class RadPolyTrig(nn.Module):
         self.linear = nn.ModuleList([nn.Linear(nb, out).to(device=device, dtype=dtype) for _ in range(max_zf + 1)])
         self.radial_types = (num_channels,) * max_zf
 
+    KERNEL_BELLS = 20          # csrc/common.hpp: NB -- the width the level / moments kernels read (2 * num_basis_fn of the default 10)
+
     def flat_params(self):
         return [self.a, self.b, self.c, self.linear[0].weight, self.linear[0].bias, self.linear[1].weight, self.linear[1].bias]
+
+    def kernel_params(self):
+        """flat_params() in the width the kernels read.  Fewer than 20 bells (num_basis_fn < 10, lgn/nn/position_levels.py:44-64) are
+        embedded by zero padding: a bell with a = b = c = 0 and zero Linear weights evaluates to 0 and feeds nothing, its gradient
+        slots are sliced away by autograd (the padding is a differentiable op).  The whole-network calls read the parameters in
+        place and keep requiring num_basis_fn = 10 (lgn/ops.py: native_kind); the per-operator path takes these."""
+        pad = self.KERNEL_BELLS - 2 * self.num_basis_fn
+        if pad == 0:
+            return self.flat_params()
+        a, b, c, w0, b0, w1, b1 = self.flat_params()
+        P = torch.nn.functional.pad
+        return [P(a, (0, pad)), P(b, (0, pad)), P(c, (0, pad)), P(w0, (0, pad)), b0, P(w1, (0, pad)), b1]
 
 
 class RadialFilters(nn.Module):

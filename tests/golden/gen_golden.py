@@ -26,6 +26,7 @@ Fixtures
                       plus one extra input scalar per node through data['scalars']
   g11_e2e_mlpdepth4.npz / g11_e2e_mlpdepth3_maxdim3.npz  end-to-end with --mlp-depth 4 (maxdim 2, B=3 N=12 ch 2344/4432) and 3 (maxdim 3,
                       B=2 N=10 ch 246/642): CGMLPs of 5 / 4 Linear layers (round 5)
+  g13_e2e_basis5.npz / g13_e2e_basis5_maxdim3.npz  end-to-end with --num-basis-fn 5 (10 bells), maxdim 2 (B=3 N=12) and 3 (B=2 N=10)
   g12_e2e_n150_maxdim3.npz  end-to-end, B=1 N=150 maxdim=3 ch 4466/6644 (round 5: jets beyond the LDS-resident kernels)
   g8_harness.npz      the reference's own equivariance harness (lgn/models/autotest/lgn_tests.py:292-423) run on the g1 weights
                       (maxdim 2) and the g2 weights (maxdim 3): gamma / theta grids, output and internal-feature deviation
@@ -84,9 +85,9 @@ def jets(B, N, seed, pad_rows=()):
 
 
 def build(N, maxdim, ch_enc, ch_dec, seed, map_to_latent="min&max", activation="leakyrelu", jet_features=False, tau_input_scalars=1,
-          mlp_depth=6):
+          mlp_depth=6, num_basis_fn=10):
     torch.manual_seed(seed)
-    common = dict(maxdim=[maxdim], max_zf=[1], weight_init="randn", level_gain=[1.0], num_basis_fn=10,
+    common = dict(maxdim=[maxdim], max_zf=[1], weight_init="randn", level_gain=[1.0], num_basis_fn=num_basis_fn,
                   activation=activation, mlp=True, mlp_depth=mlp_depth, mlp_width=6, device=CPU, dtype=F64)
     enc = LGNEncoder(num_input_particles=N, tau_input_scalars=tau_input_scalars, tau_input_vectors=1, map_to_latent=map_to_latent,
                      tau_latent_scalars=1, tau_latent_vectors=8, num_channels=list(ch_enc), scale=1.0,
@@ -98,8 +99,8 @@ def build(N, maxdim, ch_enc, ch_dec, seed, map_to_latent="min&max", activation="
 
 
 def e2e(name, B, N, maxdim, ch_enc, ch_dec, seed, pad_rows=(), map_to_latent="min&max", activation="leakyrelu", jet_features=False,
-        extra_scalars=0, mlp_depth=6):
-    enc, dec = build(N, maxdim, ch_enc, ch_dec, seed, map_to_latent, activation, jet_features, 1 + extra_scalars, mlp_depth)
+        extra_scalars=0, mlp_depth=6, num_basis_fn=10):
+    enc, dec = build(N, maxdim, ch_enc, ch_dec, seed, map_to_latent, activation, jet_features, 1 + extra_scalars, mlp_depth, num_basis_fn)
     p4, labels = jets(B, N, seed + 100, pad_rows)
     meta = dict(B=B, N=N, maxdim=maxdim, ch_enc=list(ch_enc), ch_dec=list(ch_dec), seed=seed, l1_lambda=1e-8, map_to_latent=map_to_latent)
     if activation != "leakyrelu":
@@ -108,6 +109,8 @@ def e2e(name, B, N, maxdim, ch_enc, ch_dec, seed, pad_rows=(), map_to_latent="mi
         meta["jet_features"], meta["extra_scalars"] = bool(jet_features), extra_scalars
     if mlp_depth != 6:
         meta["mlp_depth"] = mlp_depth
+    if num_basis_fn != 10:
+        meta["num_basis_fn"] = num_basis_fn
     store = {"p4": npy(p4), "labels": npy(labels), "meta": np.array(json.dumps(meta))}
     for k, v in enc.state_dict().items():
         store["enc." + k] = npy(v)
@@ -341,6 +344,9 @@ if __name__ == "__main__":
         # kernels), 4 at maxdim 3 (H = 72: the wide kernels)
         e2e("g11_e2e_mlpdepth4.npz", 3, 12, 2, (2, 3, 4, 4), (4, 4, 3, 2), seed=7, pad_rows=((1, 8),), mlp_depth=4)
         e2e("g11_e2e_mlpdepth3_maxdim3.npz", 2, 10, 3, (2, 4, 6), (6, 4, 2), seed=8, pad_rows=((0, 7),), mlp_depth=3)
+    if want("g13"):       # --num-basis-fn 5 (lgn/nn/position_levels.py:44-64): 10 Lorentzian bells instead of 20, maxdim 2 and maxdim 3
+        e2e("g13_e2e_basis5.npz", 3, 12, 2, (2, 3, 4, 4), (4, 3, 3, 2), seed=10, pad_rows=((2, 9),), num_basis_fn=5)
+        e2e("g13_e2e_basis5_maxdim3.npz", 2, 10, 3, (2, 3, 4), (4, 3, 2), seed=11, pad_rows=((1, 6),), num_basis_fn=5)
     if want("g12"):       # 150 particles at maxdim 3 (the product of two BASELINE axes; the jet's packed features exceed a CU's LDS)
         e2e("g12_e2e_n150_maxdim3.npz", 1, 150, 3, (4, 4, 6, 6), (6, 6, 4, 4), seed=9, pad_rows=((0, 137),))
     if want("g10"):

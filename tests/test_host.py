@@ -230,6 +230,15 @@ def test_native_step_refuses_configurations_it_does_not_implement():
     with pytest.raises(NotImplementedError, match="same kind"):       # mixed fused / table-driven networks
         NativeTrainStep(enc, dec, batch_size=4)
     enc, dec = G._models(30, (3, 3, 4, 4), (4, 4, 3, 3), torch.device("cpu"), seed=0)
+    from lgn.nn import RadPolyTrig
+    with pytest.raises(NotImplementedError, match="num_basis_fn"):      # more Lorentzian bells than the kernels evaluate
+        RadPolyTrig(1, 11, 3)
+    r5 = RadPolyTrig(1, 5, 3)                                           # fewer: zero-padded to the kernels' 20 on the per-operator path
+    kp = r5.kernel_params()
+    assert [tuple(t.shape) for t in kp] == [(1, 1, 1, 20)] * 3 + [(6, 20), (6,), (6, 20), (6,)]
+    assert all(float(t[..., 10:].abs().max()) == 0 for t in (kp[0], kp[1], kp[2], kp[3], kp[5]))
+    kp[3].sum().backward()                                              # the padding is differentiable: gradients reach the 10 real columns
+    assert tuple(r5.linear[0].weight.grad.shape) == (6, 10)
     enc.mlp_depth = 2                                                   # the native CGMLP kernels are built for mlp_depth 3 .. 6
     enc.__dict__.pop("_native_kind", None)
     with pytest.raises(NotImplementedError, match="mlp_depth"):
