@@ -79,6 +79,19 @@ int lgn_level_bwd_f64(int B, int N, int C, int CO, int decoder,
                       double* g_ag, double* g_s_in, double* g_v_in, double* g_p,
                       double* part_mix, double* part_rad, void* stream);
 
+/* ---- Clebsch-Gordan product of two irreps, standalone (lgn/cg_lib/cg_ops.py:135-218: cg_product; :221-297: complex_kron_product) --
+ * Per channel: out = H (x1 (x) x2), H = the stacked Clebsch-Gordan matrix [DO][D1 * D2] of the irrep pair in CSR form (device arrays
+ * row_ptr [DO + 1], col [nnz] = m1 * D2 + m2, coef [nnz]).  mode 0: x1 [2][R][C][D1], x2 [2][R][C][D2].  Aggregate (sum over the
+ * neighbour index before H, cg_ops.py:281-291), rows R = B * N: mode 1: x1 [2][B][N][N][C][D1] edge-like, x2 [2][B][N][C][D2];
+ * mode 2: the operands the other way round.  out [2][R][C][DO].  Backward: g_x1 / g_x2 are ACCUMULATED into (zero-filled by the
+ * caller).  What lgn.cg_lib.cg_product / CGProduct bind, one call per pair of irreps; inside the networks the product is fused into
+ * the level kernels and never materialised. */
+int lgn_cg_product_fwd_f64(int R, int N, int C, int D1, int D2, int DO, int mode, int nnz, const int* row_ptr, const int* col,
+                           const double* coef, const double* x1, const double* x2, double* out, void* stream);
+int lgn_cg_product_bwd_f64(int R, int N, int C, int D1, int D2, int DO, int mode, int nnz, const int* row_ptr, const int* col,
+                           const double* coef, const double* x1, const double* x2, const double* g_out, double* g_x1, double* g_x2,
+                           void* stream);
+
 /* out[n] = (accumulate ? out[n] : 0) + sum_r part[r][n], fixed summation order. */
 int lgn_reduce_partials_f64(const double* part, int rows, int n, double* out, int accumulate, void* stream);
 

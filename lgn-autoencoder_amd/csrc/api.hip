@@ -39,6 +39,16 @@ int lgn_level_bwd_f64(int B, int N, int C, int CO, int decoder, const double* s_
   return level_bwd_dispatch<double>(a, decoder, (hipStream_t)stream);
 }
 
+int lgn_cg_product_fwd_f64(int R, int N, int C, int D1, int D2, int DO, int mode, int nnz, const int* row_ptr, const int* col,
+                           const double* coef, const double* x1, const double* x2, double* out, void* stream) {
+  return cg_product_fwd(R, N, C, D1, D2, DO, mode, nnz, row_ptr, col, coef, x1, x2, out, (hipStream_t)stream);
+}
+int lgn_cg_product_bwd_f64(int R, int N, int C, int D1, int D2, int DO, int mode, int nnz, const int* row_ptr, const int* col,
+                           const double* coef, const double* x1, const double* x2, const double* g_out, double* g_x1, double* g_x2,
+                           void* stream) {
+  return cg_product_bwd(R, N, C, D1, D2, DO, mode, nnz, row_ptr, col, coef, x1, x2, g_out, g_x1, g_x2, (hipStream_t)stream);
+}
+
 int lgn_reduce_partials_f64(const double* part, int rows, int n, double* out, int accumulate, void* stream) {
   LGN_CHECK_ARG(part && out && rows > 0 && n >= 0, "reduce_partials: bad arguments");
   return reduce_partials<double>(part, rows, n, out, accumulate, (hipStream_t)stream);

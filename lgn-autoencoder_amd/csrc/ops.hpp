@@ -85,6 +85,11 @@ __host__ __device__ inline size_t mlp_out_index(const MlpArgs<T>& a, int z, int 
   return ((size_t)z * a.M * a.C + (size_t)row * a.C + ch) * a.ld;
 }
 template <typename T> int mlp_dispatch(const MlpArgs<T>&, bool backward, hipStream_t);
+// standalone Clebsch-Gordan product (cg_product.hip)
+int cg_product_fwd(int R, int N, int C, int D1, int D2, int DO, int mode, int nnz, const int* row_ptr, const int* col, const double* coef,
+                   const double* x1, const double* x2, double* out, hipStream_t st);
+int cg_product_bwd(int R, int N, int C, int D1, int D2, int DO, int mode, int nnz, const int* row_ptr, const int* col, const double* coef,
+                   const double* x1, const double* x2, const double* g_out, double* g_x1, double* g_x2, hipStream_t st);
 int mlp_mfma_dispatch(const MlpArgs<double>&, bool backward, hipStream_t);
 int mlp_chain_dispatch(const MlpArgs<double>&, bool backward, hipStream_t);   // H = 6 * 2C <= 48, 64-row workgroups (mlp_chain.hip)
 int mlp_mfma_wide_dispatch(const MlpArgs<double>&, bool backward, hipStream_t);   // 48 < H <= 96 (mlp_mfma_wide.hip)

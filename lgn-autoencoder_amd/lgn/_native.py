@@ -28,6 +28,8 @@ _SIGNATURES = {
     "lgn_level_bwd_partial_rows": [_i, _i, _i, _ip, _ip],
     "lgn_level_rad_partial_len": [_i, _i],
     "lgn_level_jet_split": [_i, _i],
+    "lgn_cg_product_fwd_f64": [_i] * 8 + [_vp] * 7,
+    "lgn_cg_product_bwd_f64": [_i] * 8 + [_vp] * 9,
     "lgn_level_bwd_f64": [_i] * 5 + [_vp] * 24,
     "lgn_reduce_partials_f64": [_vp, _i, _i, _vp, _i, _vp],
     "lgn_radial_finalize_f64": [_vp, _i] + [_vp] * 13,

@@ -148,5 +148,7 @@ class CGDict:
 
 
 from .zonal_functions import p_to_rep, p_cplx_to_rep, rep_to_p, normsq, normsq4, repdot  # noqa: E402  (cg_lib/__init__.py:13-23)
+from .product import CGProduct, cg_product, cg_product_tau  # noqa: E402  (cg_lib/__init__.py:8-11)
 
-__all__ = ["CGDict", "lorentz_cg", "su2_cg", "p_to_rep", "p_cplx_to_rep", "rep_to_p", "normsq", "normsq4", "repdot"]
+__all__ = ["CGDict", "lorentz_cg", "su2_cg", "p_to_rep", "p_cplx_to_rep", "rep_to_p", "normsq", "normsq4", "repdot", "CGProduct",
+           "cg_product", "cg_product_tau"]

@@ -452,6 +452,72 @@ def test_cgmlp(dev, O, C, B, N, act):
         U.assert_close(flat[2 * i + 1].grad, P[f"lgn_cg.mlp_levels.0.linear.{i}.bias"].grad, GRAD_TOL, f"g_b{i}")
 
 
+@pytest.mark.parametrize("tag,maxdim", [("cg2_2", 2), ("cg3_5", 3), ("cg3_2", 3)])
+def test_cg_product_vs_reference_golden(dev, O, tag, maxdim):
+    """lgn.cg_lib.cg_product / CGProduct (lgn_cg_product_fwd/bwd_f64, csrc/cg_product.hip) against the reference's own vectors (g4:
+    aggregate = node (x) edge summed over neighbours, power = node (x) node; values, key order, channel order) and -- gradients --
+    against the oracle's autograd on the same inputs, aggregate with the edge-like operand on either side."""
+    from lgn.cg_lib import CGDict, CGProduct, cg_product
+    z = U.load("g4_ops.npz")
+    cg = CGDict(maxdim=maxdim, device=dev)
+    node, edge = U.rep_from(z, tag + ".node"), U.rep_from(z, tag + ".edge")
+    gn = {k: v.to(dev).requires_grad_(True) for k, v in node.items()}
+    ge = {k: v.to(dev).requires_grad_(True) for k, v in edge.items()}
+    agg = cg_product(cg, gn, ge, maxdim, aggregate=True)
+    U.assert_rep_close(dict(agg.items()), U.rep_from(z, tag + ".aggregate"), FWD_TOL, "aggregate")
+    power = CGProduct(maxdim=maxdim, cg_dict=cg)(U_gvec(gn), U_gvec(gn))
+    pref = U.rep_from(z, tag + ".power")
+    assert list(power.keys()) == list(pref.keys())
+    for k, ref in pref.items():          # ((1,1) (x) (1,1) -> (0,2), (2,0) is antisymmetric: v (x) v gives rounding noise there, 1e-17 in the reference)
+        if ref.abs().max() < 1e-13:
+            assert power[k].abs().max() < 1e-13, f"power {k} must vanish"
+        else:
+            U.assert_close(power[k], ref, FWD_TOL, f"power {k}")
+    agg2 = cg_product(cg, ge, gn, maxdim, aggregate=True)            # edge-like operand first
+    # gradients of one scalar of all three products, against the oracle's autograd
+    g = torch.Generator().manual_seed(len(tag) + maxdim)
+    on = {k: v.clone().requires_grad_(True) for k, v in node.items()}
+    oe = {k: v.clone().requires_grad_(True) for k, v in edge.items()}
+    ocg = O.get_cg(maxdim)
+    refs = [O.cg_product(ocg, on, oe, maxdim, aggregate=True), O.cg_product(ocg, on, on, maxdim, aggregate=False),
+            _cg_product_edge_first(CGDict(maxdim=maxdim), oe, on, maxdim)]
+    U.assert_rep_close(dict(agg2.items()), dict(refs[2].items()), FWD_TOL, "aggregate, edge-like operand first")
+    tot_ref, tot = 0.0, 0.0
+    for got, ref in zip((agg, power, agg2), refs):
+        for k in ref.keys():
+            cot = torch.randn(ref[k].shape, dtype=torch.float64, generator=g)
+            tot_ref = tot_ref + (ref[k] * cot).sum()
+            tot = tot + (got[k] * cot.to(dev)).sum()
+    tot_ref.backward()
+    tot.backward()
+    for k in node:
+        U.assert_close(gn[k].grad, on[k].grad, GRAD_TOL, f"d node {k}")
+    for k in edge:
+        U.assert_close(ge[k].grad, oe[k].grad, GRAD_TOL, f"d edge {k}")
+
+
+def _cg_product_edge_first(cg, edge, node, maxdim):
+    """cg_product(edge, node, aggregate=True) written out in torch (the oracle takes the node-like operand first only):
+    z[b,i,c,m1 d2 + m2] = sum_j edge[b,i,j,c,m1] node[b,j,c,m2] (complex), then the pair's stacked CG matrix."""
+    out = {}
+    for (k1, n1), e in edge.items():
+        for (k2, n2), x in node.items():
+            keys = [(k, n) for k in range(abs(k1 - k2), min(maxdim, k1 + k2 + 1), 2) for n in range(abs(n1 - n2), min(maxdim, n1 + n2 + 1), 2)]
+            mat = torch.cat([cg[((k1, n1), (k2, n2))][key] for key in keys], -2)
+            er, ei, xr, xi = e[0], e[1], x[0].unsqueeze(1), x[1].unsqueeze(1)             # e (B,N,N,C,d1); x (B,1,N,C,d2)
+            zr = (er.unsqueeze(-1) * xr.unsqueeze(-2) - ei.unsqueeze(-1) * xi.unsqueeze(-2)).sum(2).flatten(-2)
+            zi = (er.unsqueeze(-1) * xi.unsqueeze(-2) + ei.unsqueeze(-1) * xr.unsqueeze(-2)).sum(2).flatten(-2)
+            dec = torch.stack([zr @ mat.t(), zi @ mat.t()])
+            for key, piece in zip(keys, torch.split(dec, [(k + 1) * (n + 1) for k, n in keys], dim=-1)):
+                out.setdefault(key, []).append(piece)
+    return {key: torch.cat(v, dim=-2) for key, v in out.items()}
+
+
+def U_gvec(rep):
+    from lgn.g_lib import GVec
+    return GVec(rep)
+
+
 @pytest.mark.parametrize("rows,Ci,Co,d", [((2, 30), 1, 3, 4), ((2, 30), 4, 8, 4), ((5, 1), 16, 30, 4), ((3, 7), 4, 1, 1),
                                           ((700,), 3, 2, 4)])
 def test_mixreps(dev, O, rows, Ci, Co, d):
