@@ -48,7 +48,8 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 template <int C> struct GA3 {
-  static constexpr int A3 = 0, A4 = 2 * C, A1 = 4 * C, A2 = 12 * C, SIZE = 20 * C;
+  // (+ 2: rows of 20 C doubles put every second node of C = 4 on the same LDS banks -- the pair sweep reads four nodes' rows at once)
+  static constexpr int A3 = 0, A4 = 2 * C, A1 = 4 * C, A2 = 12 * C, SIZE = 20 * C + 2;
 };
 constexpr int TS = 18;
 LGN_STAMP_DECL
@@ -77,7 +78,7 @@ struct Bwd3 {
   static constexpr int SMS = 52;                         // 50 jet-level sums per channel (+ 2 of padding: 16 + 16 + 12 + 8 lane sums)
   static constexpr int SEPSZ = DEC ? SMS * C : 0;        // jet-level sums of the separable decoder form
   static size_t smem(int N, int CO) {
-    return sizeof(double) * ((((size_t)N * NS + 1) & ~size_t(1)) + (size_t)N * 20 * C + (size_t)N * 10 * C + (size_t)N * PS +
+    return sizeof(double) * ((((size_t)N * NS + 1) & ~size_t(1)) + (size_t)N * (20 * C + 2) + (size_t)N * 10 * C + (size_t)N * PS +
                              scratch(N, CO) + SEPSZ) + N + 16;
   }
 };
