@@ -392,7 +392,6 @@ __device__ __forceinline__ void dw_unit(const double* Gt, const double* Xt, doub
     const int u = i >> 4, sk = i & 15;
     if (i + P < N) load(i + P);
     acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[sk], qx[i], acc[u], 0, 0, 0);
-    if (u == 0) dbs += qa[sk];
     if (u > 0 && sk >= 1 && sk <= 4) store(u > 0 ? u - 1 : 0, sk - 1);
     side(i);
     __builtin_amdgcn_sched_barrier(0);
@@ -400,6 +399,13 @@ __device__ __forceinline__ void dw_unit(const double* Gt, const double* Xt, doub
 #pragma unroll
   for (int r = 0; r < 4; ++r) store(NU - 1, r);
   if (u0 == 0) {
+    // the bias gradient: row sums of g_pre^T = the sum of the 16 A fragments, which are still in registers -- added up HERE, in one
+    // burst (an fp64 vector instruction between two matrix instructions costs ~19 cycles of the shared datapath for the first of
+    // a burst and 4 for each further one: probes/mfma_issue_probe)
+    double d4[4] = {0.0, 0.0, 0.0, 0.0};                     // (four chains: the adds are 8-cycle-latency instructions)
+#pragma unroll
+    for (int sk = 0; sk < 16; ++sk) d4[sk & 3] += qa[sk];
+    dbs = (d4[0] + d4[1]) + (d4[2] + d4[3]);
     dbs += shfl_xor(dbs, 16);
     dbs += shfl_xor(dbs, 32);
     if (g == 0 && 16 * t + c < HO) __builtin_nontemporal_store(dbs, &part[G::off_b(L) + 16 * t + c]);
