@@ -640,7 +640,8 @@ def main():
                        "name": args.config, "jets_per_gpu": per_gpu, "global_batch": per_gpu * world, "particles": N,
                        "maxdim": cfg["maxdim"],
                        "parallelism": f"dp{world}" + (" (one RCCL all-reduce of the flat gradient per step)" if world > 1 else ""),
-                       "harness": {"native": "NativeTrainStep: lgn_step_fwd_bwd_f64 + lgn_step_finalize_f64 replayed from a HIP graph",
+                       "harness": {"native": "NativeTrainStep: lgn_step_train_f64 (one process) or lgn_step_fwd_bwd_f64 | all-reduce | "
+                                             "lgn_step_finalize_f64 (data parallel), replayed from a HIP graph",
                                    "native-nograph": "NativeTrainStep without graph capture",
                                    "module": "ReferenceLoopStep: reference loop on the nn.Module API",
                                    "captured": "CapturedModuleStep: module API + ChamferLoss under autograd + native L1 / Adam, "

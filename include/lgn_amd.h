@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LGN_AMD_ABI_VERSION 14   /* bump on ANY struct or signature change (lgn/_native.py: ABI_VERSION) */
+#define LGN_AMD_ABI_VERSION 15   /* bump on ANY struct or signature change (lgn/_native.py: ABI_VERSION) */
 
 int lgn_abi_version(void);
 const char* lgn_last_error(void);
@@ -301,6 +301,19 @@ int lgn_step_fwd_bwd_f64(const lgn_net_desc* d, const double* params, double* gr
 int lgn_step_finalize_f64(double* params, double* grads, long long n_params, const double* loss_part, int n_loss,
                           double l1_lambda, double* adam_m, double* adam_v, long long* step_dev,
                           double lr, double beta1, double beta2, double eps, int do_adam, double* loss_out, void* stream);
+/* The whole training step of ONE process in one call: lgn_step_fwd_bwd_f64 followed by lgn_step_finalize_f64 (same arguments, same
+ * results: gradients incl. the L1 sub-gradient in `grads`, loss terms in loss_out[0..2], Adam applied when do_adam).  With nothing
+ * to do between the gradients and the optimiser (no all-reduce) the tail of the step -- the deferred reductions of all partial
+ * rows, the radial-gradient finalisation, L1 + Adam, the loss assembly: three dependent launches above -- is ONE launch
+ * (csrc/step_tail.hip; bit-identical results; LGN_AMD_SPLIT_TAIL=1 keeps the three launches).  The table-driven (maxdim 3) step
+ * and steps that do not fit the fused form take the three launches by themselves.  loss_out as for lgn_step_finalize_f64; the
+ * scratch slots -11 .. -8 of the block are the per-level counters of the fused launch (zero between calls, like the last slot).
+ * Data-parallel training keeps the two calls above: the gradient all-reduce sits between them. */
+int lgn_step_train_f64(const lgn_net_desc* d, double* params, double* grads, long long n_params, const int64_t* enc_off,
+                       const int64_t* dec_off, const double* p4, const double* target, const uint8_t* mask, double* workspace,
+                       long long workspace_doubles, double* recon, double* loss_part, int n_loss, double l1_lambda,
+                       double* adam_m, double* adam_v, long long* step_dev, double lr, double beta1, double beta2, double eps,
+                       int do_adam, double* loss_out, void* stream);
 
 /* ---- one network at a time, maxdim = 2: what LGNEncoder.forward / LGNDecoder.forward (lgn/models/lgn_encoder.py:255-336,
  * lgn_decoder.py:218-303) and autograd's backward of them become under the module API.  Same parameter-slot layout as

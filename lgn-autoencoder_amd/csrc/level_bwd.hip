@@ -18,6 +18,7 @@
 #include "level_dev.hpp"
 #include <type_traits>
 #include "ops.hpp"
+#include "tail_dev.hpp"
 
 namespace lgn {
 
@@ -238,23 +239,16 @@ __global__ __launch_bounds__(256) void rad_finalize_batch_kernel(RadFinJob job) 
   for (int e = threadIdx.x; e < R * NB; e += blockDim.x) {
     int r = e / NB, k = e - r * NB;
     int lin = r / F, f = r - lin * F;
-    (lin ? it.g_w1 : it.g_w0)[f * NB + k] = it.rb[k] * T1[e] + it.ra[k] * S[r];
+    (lin ? it.g_w1 : it.g_w0)[f * NB + k] = radfin_weight(it.rb[k], T1[e], it.ra[k], S[r]);
   }
   for (int r = threadIdx.x; r < R; r += blockDim.x) {
     int lin = r / F, f = r - lin * F;
     (lin ? it.g_b1 : it.g_b0)[f] = dB[r];
   }
   for (int k = threadIdx.x; k < NB; k += blockDim.x) {
-    double da = 0, db = 0, dc = 0;
-    for (int r = 0; r < R; ++r) {
-      const double wv = w[r * NB + k];
-      da += wv * S[r];
-      db += wv * T1[r * NB + k];
-      dc += wv * T2[r * NB + k];
-    }
-    it.g_a[k] = da;
-    it.g_b[k] = db;
-    it.g_c[k] = -2.0 * it.rb[k] * it.rc[k] * dc;
+    it.g_a[k] = radfin_dot(w + k, NB, S, 1, R);
+    it.g_b[k] = radfin_dot(w + k, NB, T1 + k, NB, R);
+    it.g_c[k] = radfin_c(it.rb[k], it.rc[k], radfin_dot(w + k, NB, T2 + k, NB, R));
   }
 }
 

@@ -333,18 +333,14 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2))) v
     STAMP(50);
     __syncthreads();
     STAMP(51);
-    for (int e = tid; e < OK; e += BLK) {
-      double v[4];
+    // thread = (entry e = o K + k, component x): the parts in index order, as before, but 4 OK threads at work instead of OK
+    // (partial row: [x][o][k], x = re / im of the (0,0) weights, re / im of the (1,1) weights)
+    for (int ex = tid; ex < 4 * OK; ex += BLK) {
+      const int e = ex >> 2, x = ex & 3;
+      double v = red[ex];
 #pragma unroll
-      for (int x = 0; x < 4; ++x) v[x] = red[e * 4 + x];
-      for (int pp = 1; pp < NPART; ++pp)
-#pragma unroll
-        for (int x = 0; x < 4; ++x) v[x] += red[(pp * OK + e) * 4 + x];
-      const int o = e / K, kk = e - o * K;
-      part[(0 * CO + o) * K + kk] = v[0];
-      part[(1 * CO + o) * K + kk] = v[1];
-      part[2 * CO * K + (0 * CO + o) * K + kk] = v[2];
-      part[2 * CO * K + (1 * CO + o) * K + kk] = v[3];
+      for (int pp = 1; pp < NPART; ++pp) v += red[pp * OK * 4 + ex];
+      part[x * OK + e] = v;
     }
   }
 
@@ -993,7 +989,10 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2))) v
           for (int q = 0; q < 4; ++q) mine[(g * 3 + t) * 4 + q] = T[g][t][q];
     }
     __syncthreads();
-    if (wave == 0) {
+    // the 12 NG sums of a lane position are dealt to the first four waves by q (every wave reads LDS only: one wave doing all of them
+    // was 4 000 cycles of the kernel's tail with the other waves idle)
+    const int wq = __builtin_amdgcn_readfirstlane(wave);
+    if (wq < 4) {
       constexpr int R = 4 * C;
       const int col = lane & 15;
 #pragma unroll
@@ -1003,6 +1002,7 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2))) v
         for (int t = 0; t < 3; ++t)
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
+            if (q != wq) continue;
             const int e = (g * 3 + t) * 4 + q;
             double v = (red[(size_t)(0 * 64 + lane) * NG * 12 + e] + red[(size_t)(1 * 64 + lane) * NG * 12 + e]) +
                        (red[(size_t)(2 * 64 + lane) * NG * 12 + e] + red[(size_t)(3 * 64 + lane) * NG * 12 + e]);

@@ -8,6 +8,7 @@
 // Each forward/backward pair is one workgroup per jet; weight-gradient partials are one row per jet.
 #include "net.hpp"
 #include "net_dev.hpp"
+#include "tail_dev.hpp"
 
 namespace lgn {
 
@@ -1100,15 +1101,12 @@ __global__ __launch_bounds__(BLOCK) void l1_adam_kernel(long n, double* w, doubl
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const double wi = w[i];
     l1 += fabs(wi);
-    const double gi = g[i] + lambda * ((wi > 0.0) - (wi < 0.0));
-    g[i] = gi;
+    const AdamOut o = l1_adam_one(wi, g[i], do_adam ? m[i] : 0.0, do_adam ? v[i] : 0.0, lambda, lr, beta1, beta2, eps, bc1, bc2_sqrt);
+    g[i] = o.g;
     if (do_adam) {
-      const double mi = m[i] + (gi - m[i]) * (1.0 - beta1);
-      const double vi = v[i] * beta2 + (1.0 - beta2) * gi * gi;
-      m[i] = mi;
-      v[i] = vi;
-      const double denom = sqrt(vi) / bc2_sqrt + eps;
-      w[i] = wi - (lr / bc1) * (mi / denom);
+      m[i] = o.m;
+      v[i] = o.v;
+      w[i] = o.w;
     }
   }
   l1 = block_sum(l1, red);
@@ -1316,7 +1314,7 @@ int finalize_step(double* w, double* g, long n, const double* loss_part, int nB,
   // calls: the caller allocates the block zero-filled, the kernel clears it again -- a launch that faulted part-way leaves it dirty:
   // re-zero the block before reusing it); the six slots before it = {t, beta1^t, beta2^t} for the next odd / even step
   int nblk = grid_for(((size_t)n + ADAM_PER_THREAD - 1) / ADAM_PER_THREAD);
-  if (nblk > LGN_FINALIZE_SCRATCH - 8) nblk = LGN_FINALIZE_SCRATCH - 8;
+  if (nblk > LGN_FINALIZE_SCRATCH - 12) nblk = LGN_FINALIZE_SCRATCH - 12;     // (slots -11 .. -8: the level counters of step_tail.hip)
   double* l1_part = loss_out + 3;
   double* powers = loss_out + 3 + LGN_FINALIZE_SCRATCH - 7;
   unsigned long long* done = reinterpret_cast<unsigned long long*>(loss_out + 3 + LGN_FINALIZE_SCRATCH - 1);

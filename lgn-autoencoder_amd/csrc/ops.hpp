@@ -1,6 +1,7 @@
 // lgn-autoencoder_amd/csrc/ops.hpp -- argument blocks and host entry points shared between translation units.
 #pragma once
 #include <cstdlib>
+#include <vector>
 #include "level.hpp"
 
 namespace lgn {
@@ -11,7 +12,7 @@ template <typename T> int level_bwd_dispatch(const LevelBwdArgs<T>&, int decoder
 template <typename T> int reduce_partials(const T* part, int rows, int n, T* out, int accumulate, hipStream_t);
 template <typename T> int reduce_partials_strided(const T* part, int rows, int stride, int col0, int n, T* out, hipStream_t);
 // one launch reducing up to RED_MAX_SEG column ranges (a whole cfg2 step has ~30):  seg.out[c] = sum_r seg.part[r*stride + col0 + c]
-constexpr int RED_MAX_SEG = 48;
+constexpr int RED_MAX_SEG = 64;
 template <typename T> struct RedSeg { const T* part; int rows, stride, col0, n; T* out; };
 template <typename T> struct RedJob {
   int nseg;
@@ -29,6 +30,20 @@ struct RadFinJob {
   struct Item { const double* tot; int C; const double *ra, *rb, *rc, *w0, *w1; double *g_a, *g_b, *g_c, *g_w0, *g_b0, *g_w1, *g_b1; } it[4];
 };
 int rad_finalize_batch(const RadFinJob& job, hipStream_t);
+// the tail of a single-process training step -- deferred reductions, radial finalisation, L1 + Adam, loss assembly -- in ONE launch
+// (step_tail.hip); -2 = this step does not fit the fused form, take reduce_segments + rad_finalize_batch + finalize_step
+struct StepTailArgs {
+  double *w, *g;
+  long n;
+  double *m, *v;
+  long* step_dev;
+  double lambda, lr, beta1, beta2, eps;
+  int do_adam;
+  const double* loss_part;
+  int nB;
+  double* loss_out;             // 3 results + LGN_FINALIZE_SCRATCH doubles (include/lgn_amd.h)
+};
+int step_tail(const std::vector<RedSeg<double>>& segs, const RadFinJob& fin, const StepTailArgs& ta, hipStream_t st);
 void level_bwd_partial_rows(int B, int N, int decoder, int flags, int* rows_mix, int* rows_rad);
 bool level_bwd_carries_input(int N, int flags);   // the encoder's first level may take LevelBwdArgs::part_in0 (one-kernel backward, N <= 40)
 bool level_fwd_carries_loss(int N, int flags);    // the decoder's last level may take LevelArgs::loss_* (separable one-workgroup-per-jet forward)

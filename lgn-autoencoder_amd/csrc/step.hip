@@ -1130,18 +1130,27 @@ long long lgn_step_workspace_doubles(const lgn_net_desc* d) {
   return (long long)carve(*d, nullptr).total;
 }
 
-int lgn_step_fwd_bwd_f64(const lgn_net_desc* d, const double* params, double* grads, long long n_params, const int64_t* enc_off,
-                         const int64_t* dec_off, const double* p4, const double* target, const uint8_t* mask, double* workspace,
-                         long long workspace_doubles, double* recon, double* loss_part, void* stream, void* side_stream) {
+}  // extern "C"
+// forward + backward of a training step; with `tail` (single process: nothing sits between the gradients and the optimiser) the
+// deferred reductions, the radial finalisation, L1 + Adam and the loss assembly are ONE launch (step_tail.hip) instead of three
+static int step_fwd_bwd(const lgn_net_desc* d, const double* params, double* grads, long long n_params, const int64_t* enc_off,
+                        const int64_t* dec_off, const double* p4, const double* target, const uint8_t* mask, double* workspace,
+                        long long workspace_doubles, double* recon, double* loss_part, void* stream, void* side_stream,
+                        const StepTailArgs* tail, bool fuse_tail) {
   if (int rc = check_desc(d)) return rc;
   LGN_CHECK_ARG(params && grads && enc_off && dec_off && p4 && target && mask && workspace && recon && loss_part && n_params > 0,
                 "step_fwd_bwd: null pointer");
   LGN_CHECK_ARG(d->n_in_scalars <= 1, "step_fwd_bwd: the whole-step call takes the mass as the only input scalar (n_in_scalars=%d): "
                 "use the per-network calls", d->n_in_scalars);
   hipStream_t st = (hipStream_t)stream;
-  if (is_generic(*d, false) || is_generic(*d, true))
-    return gen_step_fwd_bwd(*d, params, grads, n_params, enc_off, dec_off, p4, target, mask, workspace, workspace_doubles, recon,
-                            loss_part, st, side_stream);
+  if (is_generic(*d, false) || is_generic(*d, true)) {
+    LGN_TRY(gen_step_fwd_bwd(*d, params, grads, n_params, enc_off, dec_off, p4, target, mask, workspace, workspace_doubles, recon,
+                             loss_part, st, side_stream));
+    if (tail)        // (the table-driven step unpacks gradients after its reductions: it keeps the separate launches)
+      LGN_TRY(finalize_step(tail->w, tail->g, tail->n, tail->loss_part, tail->nB, tail->lambda, tail->m, tail->v, tail->step_dev, tail->lr,
+                            tail->beta1, tail->beta2, tail->eps, tail->do_adam, tail->loss_out, st));
+    return 0;
+  }
   Work w = carve(*d, workspace);
   // the layout depends on run-time switches (LGN_AMD_DEC_PAIRWISE / LGN_AMD_LEVEL_V2 change the partial-row counts):
   // refuse before anything is enqueued if the caller sized the workspace under different settings
@@ -1226,10 +1235,41 @@ int lgn_step_fwd_bwd_f64(const lgn_net_desc* d, const double* params, double* gr
     dq.add(part, B, 4 * C0, 2 * C0, 2 * C0, grads + enc_off[1]);
   }
   LGN_CHECK_ARG(dq.off <= dq.cap, "step: partial-row workspace overflow (%zu > %zu)", dq.off, dq.cap);
+  if (tail && fuse_tail && !dq.forked) {
+    const int rc = step_tail(dq.segs, fin, *tail, st);
+    if (rc == 0) return 0;
+    if (rc != -2) return rc;                   // -2: does not fit the fused form -> the three launches below
+  }
   LGN_TRY(dq.flush(st));                       // what the last level and the input layer produced (all of it without a side stream)
   LGN_TRY(dq.join(st));
   LGN_TRY(rad_finalize_batch(fin, st));
+  if (tail)
+    LGN_TRY(finalize_step(tail->w, tail->g, tail->n, tail->loss_part, tail->nB, tail->lambda, tail->m, tail->v, tail->step_dev, tail->lr,
+                          tail->beta1, tail->beta2, tail->eps, tail->do_adam, tail->loss_out, st));
   return 0;
+}
+extern "C" {
+
+int lgn_step_fwd_bwd_f64(const lgn_net_desc* d, const double* params, double* grads, long long n_params, const int64_t* enc_off,
+                         const int64_t* dec_off, const double* p4, const double* target, const uint8_t* mask, double* workspace,
+                         long long workspace_doubles, double* recon, double* loss_part, void* stream, void* side_stream) {
+  return step_fwd_bwd(d, params, grads, n_params, enc_off, dec_off, p4, target, mask, workspace, workspace_doubles, recon, loss_part,
+                      stream, side_stream, nullptr, false);
+}
+
+int lgn_step_train_f64(const lgn_net_desc* d, double* params, double* grads, long long n_params, const int64_t* enc_off,
+                       const int64_t* dec_off, const double* p4, const double* target, const uint8_t* mask, double* workspace,
+                       long long workspace_doubles, double* recon, double* loss_part, int n_loss, double l1_lambda, double* adam_m,
+                       double* adam_v, long long* step_dev, double lr, double beta1, double beta2, double eps, int do_adam,
+                       double* loss_out, void* stream) {
+  LGN_CHECK_ARG(loss_out && n_loss > 0, "step_train: null pointer");
+  LGN_CHECK_ARG(!do_adam || (adam_m && adam_v && step_dev), "step_train: Adam state missing");
+  const StepTailArgs tail{params, grads, (long)n_params, adam_m, adam_v, reinterpret_cast<long*>(step_dev), l1_lambda, lr, beta1, beta2,
+                          eps, do_adam, loss_part, n_loss, loss_out};
+  // LGN_AMD_SPLIT_TAIL=1: the three separate launches (reduce_segments, rad_finalize_batch, l1_adam) -- the A/B switch of the fused tail
+  const char* split = getenv("LGN_AMD_SPLIT_TAIL");
+  return step_fwd_bwd(d, params, grads, n_params, enc_off, dec_off, p4, target, mask, workspace, workspace_doubles, recon, loss_part,
+                      stream, nullptr, &tail, !(split && split[0] == '1'));
 }
 
 int lgn_step_finalize_f64(double* params, double* grads, long long n_params, const double* loss_part, int n_loss, double l1_lambda,

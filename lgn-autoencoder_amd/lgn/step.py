@@ -345,16 +345,36 @@ class NativeTrainStep:
                                            float(self.eps), int(do_adam), N.ptr(self._loss_buf), N.stream_ptr())
         N._check(rc, "lgn_step_finalize_f64")
 
+    def _train(self, do_adam: bool):
+        """Single process: the whole step in ONE native call (lgn_step_train_f64) -- with no all-reduce between the gradients and the
+        optimiser, the reductions, the radial finalisation, L1 + Adam and the loss assembly are one launch (csrc/step_tail.hip)
+        instead of three; same results bit for bit (LGN_AMD_SPLIT_TAIL=1 or LGN_AMD_FORK=1: the separate calls)."""
+        if self._side is not None:
+            self._fwd_bwd()
+            self._finalize(do_adam)
+            return
+        import ctypes as C
+        N = self.N
+        rc = N.lib().lgn_step_train_f64(C.byref(self.desc), N.ptr(self.flat.flat), N.ptr(self.flat.grad), self.flat.flat.numel(),
+                                        self.enc_off, self.dec_off, N.ptr(self.p4), N.ptr(self.target), N.ptr(self.mask),
+                                        N.ptr(self.workspace), self.workspace.numel(), N.ptr(self.recon), N.ptr(self.loss_part),
+                                        self.loss_part.numel(), float(self.l1_lambda), N.ptr(self.adam_m), N.ptr(self.adam_v),
+                                        N.ptr(self.step_dev), float(self.lr), float(self.betas[0]), float(self.betas[1]),
+                                        float(self.eps), int(do_adam), N.ptr(self._loss_buf), N.stream_ptr())
+        N._check(rc, "lgn_step_train_f64")
+
     def _capture(self):
         # warm up on a side stream (lazy module loads, hipFuncSetAttribute), then capture
         snap = (self.flat.flat.clone(), self.adam_m.clone(), self.adam_v.clone(), self.step_dev.clone())
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
-            self._fwd_bwd()
             if self.collective:       # communicator / algorithm set-up of this message size happens outside the capture
+                self._fwd_bwd()
                 dist.all_reduce(self.flat.grad_buf, op=dist.ReduceOp.SUM, group=self.group)
-            self._finalize(False)
+                self._finalize(False)
+            else:
+                self._train(False)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         ref = (self.flat.grad_buf.clone(), self._loss_buf[:3].clone())     # the eager step's reduced gradients | loss terms, loss
@@ -384,8 +404,7 @@ class NativeTrainStep:
                 self._finalize(self.optimizer)
         elif not self.collective:     # single process: the whole step is ONE graph launch
             with torch.cuda.graph(self._g1):
-                self._fwd_bwd()
-                self._finalize(self.optimizer)
+                self._train(self.optimizer)
         self.launches_per_step = 3 if self._g2 is not None else 1
         with torch.no_grad():   # capture does not execute, but restore anyway in case a backend replays eagerly
             self.flat.flat.copy_(snap[0]); self.adam_m.copy_(snap[1]); self.adam_v.copy_(snap[2]); self.step_dev.copy_(snap[3])
@@ -435,11 +454,12 @@ class NativeTrainStep:
             if self._g2 is not None:    # ONE collective per step: gradients and the per-jet loss terms share a buffer
                 dist.all_reduce(self.flat.grad_buf, op=dist.ReduceOp.SUM, group=self.group)
                 self._g2.replay()
-        else:
+        elif self.collective:
             self._fwd_bwd()
-            if self.collective:
-                dist.all_reduce(self.flat.grad_buf, op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_reduce(self.flat.grad_buf, op=dist.ReduceOp.SUM, group=self.group)
             self._finalize(self.optimizer)
+        else:
+            self._train(self.optimizer)
         return self.loss_out[0], self.recon
 
 

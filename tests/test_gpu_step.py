@@ -203,6 +203,43 @@ def test_native_step_batch_regimes(B, monkeypatch):
         U.assert_close(a.flat.grad, c.flat.grad, 1e-10, "flat gradient, chain vs 12-wave CGMLP kernels")
 
 
+@pytest.mark.parametrize("B,N,use_graph", [(512, 30, True), (64, 30, True), (7, 30, False), (5, 70, True), (3, 150, False)])
+def test_native_step_fused_tail_is_bit_identical_to_the_three_launches(B, N, use_graph, monkeypatch):
+    """lgn_step_train_f64 (csrc/step_tail.hip: deferred reductions + radial finalisation + L1 + Adam + loss assembly in ONE launch)
+    against the same step with LGN_AMD_SPLIT_TAIL=1 (reduce_segments, rad_finalize_batch, l1_adam as three launches): four Adam
+    steps from the same weights -- gradients, moments, weights and the device-side step counter agree BIT FOR BIT (the loss VALUE
+    to rounding: its scalar sums run over different partitions), at the launch geometries of 512 / 64 jets, at a handful of jets, and at the jet sizes that take the other level-backward kernels."""
+    import __graft_entry__ as G
+    from lgn.step import NativeTrainStep
+    from oracle import lgn_oracle as O
+    dev = torch.device("cuda:0")
+    che, chd = (3, 3, 4, 4), (4, 4, 3, 3)
+    p4, labels = O.synthetic_jets(B, N, seed=B + N, pad=True)
+    batch = {"p4": p4.to(dev), "labels": labels.to(dev)}
+    runs = []
+    for split in (False, True):
+        enc, dec = G._models(N, che, chd, dev, seed=21)
+        if split:
+            monkeypatch.setenv("LGN_AMD_SPLIT_TAIL", "1")
+        st = NativeTrainStep(enc, dec, batch_size=B, lr=1e-3, l1_lambda=1e-6, use_graph=use_graph)
+        losses = [st.step(batch)[0].clone() for _ in range(4)]       # (the graph is captured while the switch is set)
+        if split:
+            monkeypatch.delenv("LGN_AMD_SPLIT_TAIL")
+        torch.cuda.synchronize()
+        runs.append((torch.stack(losses), st.loss_out.clone(), st.flat.grad.clone(), st.adam_m.clone(), st.adam_v.clone(),
+                     st.flat.flat.clone(), st.step_dev.clone(), st._loss_buf[-12:].clone(), st._loss_buf[3:-12].clone()))
+    names = ("losses of the four steps", "loss terms", "gradients (with the L1 term)", "Adam m", "Adam v", "weights", "step counter",
+             "counters and cached powers at the end of the scratch block")
+    for what, x, y in zip(names, *runs):
+        if what.startswith("loss"):     # the scalar sums (chamfer terms, |w|) are added up over different partitions: equal to rounding
+            U.assert_close(x, y, 1e-13, what)
+            continue
+        assert torch.equal(x, y), f"{what}: fused tail != three launches (max diff {(x.double() - y.double()).abs().max().item():.3e})"
+    assert int(runs[0][6].item()) == 4 and torch.isfinite(runs[0][5]).all()
+    assert float(runs[0][7][:4].abs().sum()) == 0.0 and float(runs[0][7][-1]) == 0.0, "the launch left its counters non-zero"
+    assert float(runs[0][8].abs().sum()) == 0.0, "the fused launch left |w| slots behind (they mark 'not yet written' for the next one)"
+
+
 @pytest.mark.parametrize("which", ["native", "captured"])
 def test_native_step_two_ranks_match_single_process(tmp_path, which):
     dev = torch.device("cuda:0")

@@ -1,5 +1,6 @@
 #!/bin/bash
-# kernel SEQUENCE of one step (rocprofv3 --kernel-trace): names and durations of the launches between two l1_adam kernels.
+# kernel SEQUENCE of one step (rocprofv3 --kernel-trace): names and durations of the launches between two step-closing kernels
+# (l1_adam, or step_tail of the single-process step).
 #   bash tools/kseq.sh NAME -- python3 bench.py --config cfg5 --no-cpu-baseline --no-extras --steps 3 --warmup 1
 NAME=$1; shift; shift
 ROOT=$(pwd); OUT=$ROOT/gpurun_out; mkdir -p "$OUT"
@@ -11,7 +12,7 @@ python3 - "$OUT/ks_$NAME" <<'PY'
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "l1_adam" in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(rows) if "l1_adam" in r["Kernel_Name"] or "step_tail" in r["Kernel_Name"]]
 a, b = idx[-2] + 1, idx[-1] + 1
 t0 = int(rows[a]["Start_Timestamp"])
 prev_end = None
