@@ -1083,11 +1083,16 @@ __global__ __launch_bounds__(BLOCK) void l1_adam_kernel(long n, double* w, doubl
   if (threadIdx.x == 0) {
     bc[0] = bc[1] = bc[2] = bc[3] = 1.0;
     if (do_adam) {
+      // counter and BOTH slots in one memory round trip (counter, then its slot, was two -- with every other thread at the barrier)
+      double pw[6];
+#pragma unroll
+      for (int q = 0; q < 6; ++q) pw[q] = powers[q];
       const long ti = *step_dev + 1;
       const double t = (double)ti;
-      const double* slot = powers + 3 * (ti & 1);
+      const int odd = (int)(ti & 1);
+      const double sl0 = odd ? pw[3] : pw[0], sl1 = odd ? pw[4] : pw[1], sl2 = odd ? pw[5] : pw[2];
       double p1, p2;
-      if (slot[0] == t) { p1 = slot[1]; p2 = slot[2]; }
+      if (sl0 == t) { p1 = sl1; p2 = sl2; }
       else { p1 = pow(beta1, t); p2 = pow(beta2, t); }
       bc[0] = 1.0 - p1;
       bc[1] = sqrt(1.0 - p2);

@@ -42,6 +42,10 @@ struct StepTailArgs {
   const double* loss_part;
   int nB;
   double* loss_out;             // 3 results + LGN_FINALIZE_SCRATCH doubles (include/lgn_amd.h)
+  // reduce_only: the reductions and the radial finalisation only (the data-parallel step: the gradient all-reduce follows) -- w / g / n
+  // describe the gradient buffer, `counters` are 4 zeroed 64-bit words (the step's zero block: cleared by its first kernel)
+  int reduce_only;
+  unsigned long long* counters;
 };
 int step_tail(const std::vector<RedSeg<double>>& segs, const RadFinJob& fin, const StepTailArgs& ta, hipStream_t st);
 void level_bwd_partial_rows(int B, int N, int decoder, int flags, int* rows_mix, int* rows_rad);

@@ -41,7 +41,8 @@ struct Work {
   double* tot[2][4];           // reduced radial sums per (network, level)
   int* idx;
   size_t total;
-  size_t zero_doubles;         // zeros_s | g_p | g_lat_s are contiguous: one memset
+  double* tail_cnt;            // 4 counters of the fused reduction (step_tail.hip, reduce_only), inside the zero block
+  size_t zero_doubles;         // zeros_s | g_p | g_lat_s | tail_cnt are contiguous: one memset
 };
 
 // deferred reductions: producers register their column ranges, one or two launches at the end reduce everything
@@ -185,6 +186,7 @@ Work carve(const lgn_net_desc& d, double* base) {
     w.zeros_s = b.take(2 * BN * cmax);
     w.g_p = b.take(8 * BN);
     w.g_lat_s = b.take((size_t)2 * d.B * PB * d.tau_s);
+    w.tail_cnt = b.take(8);
     w.zero_doubles = b.off - z0;
   }
   w.idx = reinterpret_cast<int*>(b.take(((size_t)d.B * 2 * (Ts + Tv) * 2 + 1) / 2 + 8));
@@ -1235,10 +1237,21 @@ static int step_fwd_bwd(const lgn_net_desc* d, const double* params, double* gra
     dq.add(part, B, 4 * C0, 2 * C0, 2 * C0, grads + enc_off[1]);
   }
   LGN_CHECK_ARG(dq.off <= dq.cap, "step: partial-row workspace overflow (%zu > %zu)", dq.off, dq.cap);
+  const char* split_env = getenv("LGN_AMD_SPLIT_TAIL");
   if (tail && fuse_tail && !dq.forked) {
     const int rc = step_tail(dq.segs, fin, *tail, st);
     if (rc == 0) return 0;
     if (rc != -2) return rc;                   // -2: does not fit the fused form -> the three launches below
+  } else if (!tail && !dq.forked && !(split_env && split_env[0] == '1')) {
+    // data-parallel step (the all-reduce follows): reductions + radial finalisation as one launch
+    StepTailArgs ro{};
+    ro.g = grads;
+    ro.n = (long)n_params;
+    ro.reduce_only = 1;
+    ro.counters = reinterpret_cast<unsigned long long*>(w.tail_cnt);
+    const int rc = step_tail(dq.segs, fin, ro, st);
+    if (rc == 0) return 0;
+    if (rc != -2) return rc;
   }
   LGN_TRY(dq.flush(st));                       // what the last level and the input layer produced (all of it without a side stream)
   LGN_TRY(dq.join(st));
@@ -1265,7 +1278,7 @@ int lgn_step_train_f64(const lgn_net_desc* d, double* params, double* grads, lon
   LGN_CHECK_ARG(loss_out && n_loss > 0, "step_train: null pointer");
   LGN_CHECK_ARG(!do_adam || (adam_m && adam_v && step_dev), "step_train: Adam state missing");
   const StepTailArgs tail{params, grads, (long)n_params, adam_m, adam_v, reinterpret_cast<long*>(step_dev), l1_lambda, lr, beta1, beta2,
-                          eps, do_adam, loss_part, n_loss, loss_out};
+                          eps, do_adam, loss_part, n_loss, loss_out, 0, nullptr};
   // LGN_AMD_SPLIT_TAIL=1: the three separate launches (reduce_segments, rad_finalize_batch, l1_adam) -- the A/B switch of the fused tail
   const char* split = getenv("LGN_AMD_SPLIT_TAIL");
   return step_fwd_bwd(d, params, grads, n_params, enc_off, dec_off, p4, target, mask, workspace, workspace_doubles, recon, loss_part,

@@ -53,6 +53,7 @@ struct TailDev {
   int ntiles, nlev;
   int lev_seg[TAIL_MAX_LEV];                 // index (in the job) of the level's `tot` segment
   int lev_tiles[TAIL_MAX_LEV];
+  int reduce_only;                           // sums and radial finalisation only: no L1, no Adam, no loss (the data-parallel step)
   RadFinJob fin;
 };
 
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void step_tail_kernel(RedJob<double> 
   const bool owner = rg < cp && mycol < sg.n;
   const long pidx = (long)(sg.out - t.g) + mycol;
   double wi = 0.0, mi = 0.0, vi = 0.0, g0 = 0.0;
-  if (owner && is_param) {
+  if (owner && is_param && !t.reduce_only) {
     wi = t.w[pidx];
     if (t.do_adam) { mi = t.m[pidx]; vi = t.v[pidx]; }
   }
@@ -197,7 +198,8 @@ __global__ __launch_bounds__(TAIL_THREADS) void step_tail_kernel(RedJob<double> 
 #pragma unroll
       for (int q = 0; q < TAIL_RG; ++q) s += red[rg][q][cl];
     }
-    if (is_param) l1 = finish_param(t, pidx, s, wi, mi, vi, bc1, bc2_sqrt);
+    if (is_param && t.reduce_only) t.g[pidx] = s;
+    else if (is_param) l1 = finish_param(t, pidx, s, wi, mi, vi, bc1, bc2_sqrt);
     else if (lev >= 0) put_shared(sg.out + mycol, s);
     else sg.out[mycol] = s;
   }
@@ -237,7 +239,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void step_tail_kernel(RedJob<double> 
       }
       const long pi = gp ? (long)(gp - t.g) : 0;
       double pw_ = 0.0, pm_ = 0.0, pv_ = 0.0;
-      if (gp) {
+      if (gp && !t.reduce_only) {
         pw_ = t.w[pi];
         if (t.do_adam) { pm_ = t.m[pi]; pv_ = t.v[pi]; }
       }
@@ -258,8 +260,10 @@ __global__ __launch_bounds__(TAIL_THREADS) void step_tail_kernel(RedJob<double> 
           const double d = radfin_dot(w + kk, NB, X, which == 0 ? 1 : NB, R);
           gsum = which == 2 ? radfin_c(rb[kk], rc[kk], d) : d;
         }
-        l1r = finish_param(t, pi, gsum, pw_, pm_, pv_, bc1, bc2_sqrt);
+        if (t.reduce_only) t.g[pi] = gsum;
+        else l1r = finish_param(t, pi, gsum, pw_, pm_, pv_, bc1, bc2_sqrt);
       }
+      if (t.reduce_only) return;               // (the counters are cleared by the next step's first kernel)
       l1r = tail_block_sum(l1r, sred);
       if (tid == 0) {
         post_sum(t.l1_part + t.ntiles + lev, l1r);
@@ -267,6 +271,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void step_tail_kernel(RedJob<double> 
       }
     }
   }
+  if (t.reduce_only) return;
   // ---- |w| of this tile; the last workgroup assembles the loss ----
   l1 = tail_block_sum(l1, sred);
   if (tid == 0) {
@@ -344,10 +349,10 @@ int step_tail(const std::vector<RedSeg<double>>& segs, const RadFinJob& fin, con
   long at = 0;
   for (const auto& r : cover) {
     if (r.lo < at || r.hi > ta.n) return -2;                  // two producers of one gradient: not a case of this kernel
-    if (r.lo > at) order.push_back(RedSeg<double>{nullptr, 0, 0, 0, (int)(r.lo - at), ta.g + at});
+    if (r.lo > at && !ta.reduce_only) order.push_back(RedSeg<double>{nullptr, 0, 0, 0, (int)(r.lo - at), ta.g + at});
     at = r.hi;
   }
-  if (at < ta.n) order.push_back(RedSeg<double>{nullptr, 0, 0, 0, (int)(ta.n - at), ta.g + at});
+  if (at < ta.n && !ta.reduce_only) order.push_back(RedSeg<double>{nullptr, 0, 0, 0, (int)(ta.n - at), ta.g + at});
   if ((int)order.size() > RED_MAX_SEG) return -2;
   int tiles = 0;
   for (const auto& s : order) {
@@ -357,13 +362,19 @@ int step_tail(const std::vector<RedSeg<double>>& segs, const RadFinJob& fin, con
     ++job.nseg;
   }
   job.tile0[job.nseg] = tiles;
-  if (tiles + fin.n > LGN_FINALIZE_SCRATCH - 12) return -2;
   t.ntiles = tiles;
-  double* scratch = ta.loss_out + 3;
-  t.l1_part = scratch;
-  t.lev_done = reinterpret_cast<unsigned long long*>(scratch + LGN_FINALIZE_SCRATCH - 11);
-  t.powers = scratch + LGN_FINALIZE_SCRATCH - 7;
-  t.done = reinterpret_cast<unsigned long long*>(scratch + LGN_FINALIZE_SCRATCH - 1);
+  t.reduce_only = ta.reduce_only;
+  if (ta.reduce_only) {
+    if (!ta.counters) return -2;
+    t.lev_done = ta.counters;
+  } else {
+    if (tiles + fin.n > LGN_FINALIZE_SCRATCH - 12) return -2;
+    double* scratch = ta.loss_out + 3;
+    t.l1_part = scratch;
+    t.lev_done = reinterpret_cast<unsigned long long*>(scratch + LGN_FINALIZE_SCRATCH - 11);
+    t.powers = scratch + LGN_FINALIZE_SCRATCH - 7;
+    t.done = reinterpret_cast<unsigned long long*>(scratch + LGN_FINALIZE_SCRATCH - 1);
+  }
   hipLaunchKernelGGL(step_tail_kernel, dim3(tiles), dim3(TAIL_THREADS), 0, st, job, t);
   LGN_CHECK_LAUNCH();
   return 0;

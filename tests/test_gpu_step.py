@@ -324,7 +324,9 @@ def test_native_step_rccl_collective_branch_single_rank():
             la, _ = a.step(batch)
             lb, _ = b.step(batch)
             lc, _ = c.step(batch)
-            assert float(la) == float(lb) == float(lc), f"step {it}: {float(la)!r} vs {float(lb)!r} vs {float(lc)!r}"
+            # (a and c assemble the loss in l1_adam, b in the fused tail of lgn_step_train_f64: the same terms over another partition)
+            assert float(la) == float(lc), f"step {it}: {float(la)!r} vs {float(lc)!r}"
+            assert abs(float(la) - float(lb)) <= 1e-13 * abs(float(lb)), f"step {it}: {float(la)!r} vs {float(lb)!r}"
         assert b._g2 is None and b.launches_per_step == 1
         assert c._g2 is not None and c.launches_per_step == 3
         print(f"all-reduce inside the step graph: {a._in_graph} (launches per step: {a.launches_per_step})")
