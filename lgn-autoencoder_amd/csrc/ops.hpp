@@ -43,7 +43,7 @@ struct StepTailArgs {
   int nB;
   double* loss_out;             // 3 results + LGN_FINALIZE_SCRATCH doubles (include/lgn_amd.h)
   // reduce_only: the reductions and the radial finalisation only (the data-parallel step: the gradient all-reduce follows) -- w / g / n
-  // describe the gradient buffer, `counters` are 4 zeroed 64-bit words (the step's zero block: cleared by its first kernel)
+  // describe the gradient buffer, `counters` are 4 64-bit words that are zero before the first launch (the kernel leaves them zero)
   int reduce_only;
   unsigned long long* counters;
 };

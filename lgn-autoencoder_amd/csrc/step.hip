@@ -7,6 +7,7 @@
 // straight into the caller's flat gradient buffer at the same offsets as the parameters.
 #include <stdlib.h>
 
+#include <algorithm>
 #include <mutex>
 #include <vector>
 
@@ -42,6 +43,7 @@ struct Work {
   int* idx;
   size_t total;
   double* tail_cnt;            // 4 counters of the fused reduction (step_tail.hip, reduce_only), inside the zero block
+  double* zero0() const { return tail_cnt < zeros_s ? tail_cnt : zeros_s; }     // start of the zero block
   size_t zero_doubles;         // zeros_s | g_p | g_lat_s | tail_cnt are contiguous: one memset
 };
 
@@ -130,6 +132,27 @@ int attach_side(Deferred& dq, void* side_stream) {
   dq.side = (hipStream_t)side_stream;
   if (const char* e = getenv("LGN_AMD_MAX_FORKS")) dq.max_forks = atoi(e) < Deferred::MAX_FORKS ? atoi(e) : Deferred::MAX_FORKS;
   return 0;
+}
+
+// The end of a backward whose gradients go on to somebody else (the all-reduce of a data-parallel step, autograd under the module
+// API): every deferred reduction and the radial finalisation as ONE launch (step_tail.hip, reduce_only) -- `counters`: 4 words of the
+// caller's zero block -- or, when that form does not fit (or LGN_AMD_SPLIT_TAIL=1, or reductions were forked), as reduce_segments +
+// rad_finalize_batch.
+int finish_reductions(Deferred& dq, const RadFinJob& fin, double* grads, long long n_params, double* counters, hipStream_t st) {
+  const char* split_env = getenv("LGN_AMD_SPLIT_TAIL");
+  if (!dq.forked && counters && !(split_env && split_env[0] == '1')) {
+    StepTailArgs ro{};
+    ro.g = grads;
+    ro.n = (long)n_params;
+    ro.reduce_only = 1;
+    ro.counters = reinterpret_cast<unsigned long long*>(counters);
+    const int rc = step_tail(dq.segs, fin, ro, st);
+    if (rc == 0) { dq.segs.clear(); return 0; }
+    if (rc != -2) return rc;
+  }
+  if (int rc = dq.flush(st)) return rc;
+  if (int rc = dq.join(st)) return rc;
+  return rad_finalize_batch(fin, st);
 }
 
 // partial rows of level l's CGMLP weight gradients
@@ -370,15 +393,30 @@ int check_desc(const lgn_net_desc* d) {
 
 namespace lgn {
 namespace {
-// grads [n] and the zero block [nz]: one memset when the caller laid them out back to back (lgn/ops.py does)
-int zero_grads_and_block(double* grads, size_t n, double* zeros, size_t nz, hipStream_t st) {
-  if (zeros >= grads + n && zeros <= grads + n + 16) {
-    HIPOK(hipMemsetAsync(grads, 0, sizeof(double) * (size_t)((zeros + nz) - grads), st));
-  } else {
-    HIPOK(hipMemsetAsync(grads, 0, sizeof(double) * n, st));
-    HIPOK(hipMemsetAsync(zeros, 0, sizeof(double) * nz, st));
-  }
+// Zero-fill of up to three ranges in ONE launch of our own.  NOT hipMemsetAsync: under stream capture (ROCm 7.2, torch 2.10) the
+// memset node of a replayed graph fills its range with a stale 16-byte pattern -- two pointer-like words, i.e. denormals ~7e-310 --
+// from the second replay on (tools/graph_memset_check.py).  As gradients of dead parameters and "zero" upstream gradients that
+// went unnoticed numerically; as counters it does not.
+struct ZeroJob { double* p[3]; size_t n[3]; };
+__global__ __launch_bounds__(BLOCK) void zero_ranges_kernel(ZeroJob job) {
+  const size_t stride = (size_t)gridDim.x * BLOCK;
+#pragma unroll
+  for (int q = 0; q < 3; ++q)
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < job.n[q]; i += stride) job.p[q][i] = 0.0;
+}
+int zero_ranges(double* a, size_t na, double* b, size_t nb, double* c, size_t nc, hipStream_t st) {
+  const ZeroJob job{{a, b, c}, {a ? na : 0, b ? nb : 0, c ? nc : 0}};
+  const size_t most = std::max(job.n[0], std::max(job.n[1], job.n[2]));
+  if (!most) return 0;
+  const int blocks = (int)std::min<size_t>((most + BLOCK - 1) / BLOCK, 1024);
+  hipLaunchKernelGGL(zero_ranges_kernel, dim3(blocks), dim3(BLOCK), 0, st, job);
+  LGN_CHECK_LAUNCH();
   return 0;
+}
+// grads [n] and the zero block [nz]: one range when the caller laid them out back to back (lgn/ops.py does)
+int zero_grads_and_block(double* grads, size_t n, double* zeros, size_t nz, hipStream_t st) {
+  if (zeros >= grads + n && zeros <= grads + n + 16) return zero_ranges(grads, (size_t)((zeros + nz) - grads), nullptr, 0, nullptr, 0, st);
+  return zero_ranges(grads, n, zeros, nz, nullptr, 0, st);
 }
 
 int check_mlp_contiguous(const lgn_net_desc& d, bool dec, const int64_t* off) {
@@ -792,9 +830,7 @@ int gen_step_fwd_bwd(const lgn_net_desc& d, const double* params, double* grads,
   if (int rc = check_mlp_contiguous(d, true, dec_off)) return rc;
   const Slots S{d.n_levels, d.mlp_nlin};
   const int L = d.n_levels, B = d.B, N = d.N, CL = d.dec_channels[L];
-  HIPOK(hipMemsetAsync(grads, 0, sizeof(double) * (size_t)n_params, st));
-  HIPOK(hipMemsetAsync(g.es.zero0, 0, sizeof(double) * g.es.zero_doubles, st));
-  HIPOK(hipMemsetAsync(g.ds.zero0, 0, sizeof(double) * g.ds.zero_doubles, st));
+  LGN_TRY(zero_ranges(grads, (size_t)n_params, g.es.zero0, g.es.zero_doubles, g.ds.zero0, g.ds.zero_doubles, st));
   LGN_TRY(gen_encoder_fwd(d, params, enc_off, p4, mask, g.ea, g.lat_s, g.lat_v, st));
   LGN_TRY(gen_decoder_fwd(d, params, dec_off, g.lat_v, g.da, st));
   Deferred dq;
@@ -878,6 +914,7 @@ NetScratch carve_scratch(const lgn_net_desc& d, bool dec, double* base) {
   for (int l = 0; l <= L; ++l) cmax = cmax > ch[l] ? cmax : ch[l];
   {  // zero-initialised block FIRST: a caller that places `grads` right in front of the scratch gets one memset for both
     const size_t z0 = b.off;
+    w.tail_cnt = b.take(8);
     w.zeros_s = b.take(2 * BN * cmax);
     w.g_p = b.take(dec ? 8 * BN : 0);
     w.g_lat_s = b.take(dec ? 0 : (size_t)2 * d.B * pool_blocks(d.latent_pool) * Ts);
@@ -984,7 +1021,7 @@ int lgn_encoder_bwd_f64(const lgn_net_desc* d, const double* params, double* gra
   const Slots S{d->n_levels, d->mlp_nlin};
   const int L = d->n_levels, B = d->B, N = d->N, Ts = d->tau_s, Tv = d->tau_v;
   const int* ce = d->enc_channels;
-  LGN_TRY(zero_grads_and_block(grads, (size_t)n_params, w.zeros_s, w.zero_doubles, st));
+  LGN_TRY(zero_grads_and_block(grads, (size_t)n_params, w.zero0(), w.zero_doubles, st));
   Deferred dq;
   dq.parts = w.parts;
   dq.cap = w.parts_size;
@@ -1012,8 +1049,8 @@ int lgn_encoder_bwd_f64(const lgn_net_desc* d, const double* params, double* gra
     dq.add(part, B, row, 2 * C0 * K, 2 * C0, grads + off[1]);
   }
   LGN_CHECK_ARG(dq.off <= dq.cap, "encoder_bwd: partial-row workspace overflow (%zu > %zu)", dq.off, dq.cap);
-  LGN_TRY(dq.flush(st));
-  LGN_TRY(rad_finalize_batch(fin, st));
+  // (measured at cfg2, captured module step: the one-launch form is 3 us SLOWER for the encoder alone -- 0.5966 against 0.5937 ms)
+  LGN_TRY(finish_reductions(dq, fin, grads, n_params, nullptr, st));
   return 0;
 }
 
@@ -1080,7 +1117,7 @@ int lgn_decoder_bwd_f64(const lgn_net_desc* d, const double* params, double* gra
   const Slots S{d->n_levels, d->mlp_nlin};
   const int L = d->n_levels, B = d->B, N = d->N, Tin = d->tau_v_in > 0 ? d->tau_v_in : pool_blocks(d->latent_pool) * d->tau_v;
   const int* cd = d->dec_channels;
-  LGN_TRY(zero_grads_and_block(grads, (size_t)n_params, w.zeros_s, w.zero_doubles, st));
+  LGN_TRY(zero_grads_and_block(grads, (size_t)n_params, w.zero0(), w.zero_doubles, st));
   Deferred dq;
   dq.parts = w.parts;
   dq.cap = w.parts_size;
@@ -1237,25 +1274,13 @@ static int step_fwd_bwd(const lgn_net_desc* d, const double* params, double* gra
     dq.add(part, B, 4 * C0, 2 * C0, 2 * C0, grads + enc_off[1]);
   }
   LGN_CHECK_ARG(dq.off <= dq.cap, "step: partial-row workspace overflow (%zu > %zu)", dq.off, dq.cap);
-  const char* split_env = getenv("LGN_AMD_SPLIT_TAIL");
   if (tail && fuse_tail && !dq.forked) {
     const int rc = step_tail(dq.segs, fin, *tail, st);
     if (rc == 0) return 0;
-    if (rc != -2) return rc;                   // -2: does not fit the fused form -> the three launches below
-  } else if (!tail && !dq.forked && !(split_env && split_env[0] == '1')) {
-    // data-parallel step (the all-reduce follows): reductions + radial finalisation as one launch
-    StepTailArgs ro{};
-    ro.g = grads;
-    ro.n = (long)n_params;
-    ro.reduce_only = 1;
-    ro.counters = reinterpret_cast<unsigned long long*>(w.tail_cnt);
-    const int rc = step_tail(dq.segs, fin, ro, st);
-    if (rc == 0) return 0;
-    if (rc != -2) return rc;
+    if (rc != -2) return rc;                   // -2: does not fit the fused form -> the separate launches below
   }
-  LGN_TRY(dq.flush(st));                       // what the last level and the input layer produced (all of it without a side stream)
-  LGN_TRY(dq.join(st));
-  LGN_TRY(rad_finalize_batch(fin, st));
+  // (data-parallel step: the all-reduce follows -- reductions + radial finalisation as one launch where that fits)
+  LGN_TRY(finish_reductions(dq, fin, grads, n_params, tail ? nullptr : w.tail_cnt, st));
   if (tail)
     LGN_TRY(finalize_step(tail->w, tail->g, tail->n, tail->loss_part, tail->nB, tail->lambda, tail->m, tail->v, tail->step_dev, tail->lr,
                           tail->beta1, tail->beta2, tail->eps, tail->do_adam, tail->loss_out, st));

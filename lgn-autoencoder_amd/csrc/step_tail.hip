@@ -263,12 +263,11 @@ __global__ __launch_bounds__(TAIL_THREADS) void step_tail_kernel(RedJob<double> 
         if (t.reduce_only) t.g[pi] = gsum;
         else l1r = finish_param(t, pi, gsum, pw_, pm_, pv_, bc1, bc2_sqrt);
       }
-      if (t.reduce_only) return;               // (the counters are cleared by the next step's first kernel)
+      // the level's counter back to zero for the next launch (nobody counts on it again in this one)
+      if (tid == 0) __hip_atomic_store(t.lev_done + lev, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (t.reduce_only) return;
       l1r = tail_block_sum(l1r, sred);
-      if (tid == 0) {
-        post_sum(t.l1_part + t.ntiles + lev, l1r);
-        t.lev_done[lev] = 0ull;               // (nobody counts on it again in this launch)
-      }
+      if (tid == 0) post_sum(t.l1_part + t.ntiles + lev, l1r);
     }
   }
   if (t.reduce_only) return;
