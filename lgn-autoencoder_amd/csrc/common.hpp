@@ -91,10 +91,21 @@ __device__ __forceinline__ T group_sum(T v) {
 #define STAMP(i) do { if (threadIdx.x == 0 && blockIdx.y == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1)) { \
     const int o_ = blockIdx.x == 0 ? 0 : 128; g_stamps[o_ + (i)] = clock64(); g_stamps[o_ + 64 + (i)] = wall_clock64(); } } while (0)
 #define LGN_STAMP_READER(name) \
-  extern "C" int name(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(long long) * 256); }
+  extern "C" int name(long long* out) {                                                                              \
+    const int rc_ = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(long long) * 256);                      \
+    const long long zero_ = 0;                       /* slot 63 starts over with every read */                        \
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &zero_, sizeof(long long), 63 * sizeof(long long));                   \
+    return rc_;                                                                                                        \
+  }
+// slot 63: the LONGEST lifetime of any workgroup (ticks of the constant-rate counter, over all launches since the library was loaded)
+#define STAMP_LIFE_BEGIN() const long long life0_ = wall_clock64()
+#define STAMP_LIFE_END() do { if (threadIdx.x == 0) atomicMax(reinterpret_cast<unsigned long long*>(&g_stamps[63]), \
+                                                           (unsigned long long)(wall_clock64() - life0_)); } while (0)
 #else
 #define LGN_STAMP_DECL
 #define STAMP(i) do { } while (0)
+#define STAMP_LIFE_BEGIN() do { } while (0)
+#define STAMP_LIFE_END() do { } while (0)
 #define LGN_STAMP_READER(name)
 #endif
 

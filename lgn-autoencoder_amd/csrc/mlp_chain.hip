@@ -324,6 +324,7 @@ __global__ __launch_bounds__(256) void mlp_chain_fwd_kernel(MlpArgs<double> a) {
   double* Wl = reinterpret_cast<double*>(smem_raw);          // 2 weight images
   WRegs<G> wrA, wrB;
   STAMP(0);
+  STAMP_LIFE_BEGIN();
   v4d xb[1];
   load_x<G>(a, row, g, xb);
   stage_prologue<G, false>(a, Wl, wrA, wrB, tid);
@@ -355,6 +356,7 @@ __global__ __launch_bounds__(256) void mlp_chain_fwd_kernel(MlpArgs<double> a) {
     if (o < D && row < a.M) a.s_out[mlp_out_index(a, o & 1, row, o >> 1)] = y[r];
   }
   STAMP(8);
+  STAMP_LIFE_END();
 }
 
 // one register (piece j = 4t + r) of this wave's columns 16 w .. 16 w + 15 of a [neuron][64 rows] tile: D layout, neuron

@@ -67,6 +67,9 @@ def main():
         fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if stamps:      # (reading resets the longest-lifetime slot: the warm-up launches do not count)
+        import ctypes
+        getattr(Nn.lib(), stamps)((ctypes.c_longlong * 256)())
     e0.record()
     for _ in range(reps):
         fn()
@@ -86,6 +89,9 @@ def main():
                 for nm, off in (("first", 64), ("last", 192)):
                     ww = [x for x in st[off:off + 64] if x > 0]
                     print(f"{nm} workgroup of the grid: alive from {(min(ww) - w0) / 100:.2f} to {(max(ww) - w0) / 100:.2f} us (100 MHz counter)")
+            if 0 < st[63] < 10 ** 9:       # STAMP_LIFE_END: longest lifetime of ANY workgroup over all launches so far
+                print(f"longest workgroup lifetime: {st[63] / 100:.2f} us")
+                st[63] = 0
             first = min(i for i in range(64) if st[i] > 0)
             print(f"stamps ({stamps}, rc={rc}), shader-clock cycles relative to stamp {first}: first workgroup | last workgroup of the grid")
             for i in range(64):
