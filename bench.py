@@ -686,7 +686,10 @@ def main():
                 ks, covered = price_step_kernels(enc, trainer.decoder, batch, out["ms_per_step"])
                 out["roofline"]["kernels"] = ks
                 out["roofline"]["kernels_note"] = (f"every kernel family >= 3 % of the step, timed in isolation (graph of 20 launches) and "
-                                                   f"priced with SURVEY 8(d) flops; level + CGMLP kernels together = {covered:.2f} of the step")
+                                                   f"priced with SURVEY 8(d) flops; level + CGMLP kernels together = {covered:.2f} of the step.  "
+                                                   f"Not a flops kernel and not in the list: the step's tail (step_tail_kernel: every deferred "
+                                                   f"reduction -- ~107 MB of partial rows at 512 jets, HBM-bound -- radial finalisation, L1 + Adam, "
+                                                   f"loss: one launch, ~5 % of the step; its duration is in profiles/{PROFILE_ROUND}_cfg2_kernel_stats.csv)")
         if cfg["maxdim"] != 2:
             # table-driven levels: the dominant launch (per-node backward of the widest level) priced with SURVEY 8(d)'s counting
             # rules, and the whole-step algorithmic rate (cfg5 fwd+bwd = 109.9 MFLOP per jet) next to it

@@ -26,7 +26,18 @@ stats cfg5 --config cfg5 --no-extras
 stats b64 --config cfg2 --batch 64 --no-extras
 # the 12-wave CGMLP kernels (csrc/mlp_mfma.hip) in place of the chain kernels, for the comparison in DESIGN.md
 LGN_AMD_MLP_V1=1 stats cfg2_mlp_v1 --config cfg2 --no-extras
+# the step's tail as three launches (reduce_segments, rad_finalize_batch, l1_adam) instead of step_tail_kernel
+LGN_AMD_SPLIT_TAIL=1 stats cfg2_split_tail --config cfg2 --no-extras
 cd "$ROOT"
+# fused against split tail, and the data-parallel branch on one rank (tools/ab.sh, tools/dp_bench.py)
+echo "[evidence] A/B of the step tail"
+bash tools/ab.sh "$OUT/ab_tail" LGN_AMD_SPLIT_TAIL=1 - -- --config cfg2 --no-extras > /dev/null 2>&1
+bash tools/ab.sh "$OUT/ab_tail64" LGN_AMD_SPLIT_TAIL=1 - -- --config cfg2 --batch 64 --no-extras > /dev/null 2>&1
+{ echo "== 512 jets (bench.py --config cfg2): three launches (LGN_AMD_SPLIT_TAIL=1) | one launch (-)"; cat "$OUT/ab_tail/ab.txt";
+  echo "== 64 jets"; cat "$OUT/ab_tail64/ab.txt";
+  echo "== data-parallel branch on one rank (tools/dp_bench.py 64 300): one-launch reductions, then LGN_AMD_SPLIT_TAIL=1";
+  python3 tools/dp_bench.py 64 300 2>&1 | grep jets; LGN_AMD_SPLIT_TAIL=1 python3 tools/dp_bench.py 64 300 2>&1 | grep jets; } > "$OUT/step_tail.txt"
+
 for cfg in cfg2 cfg5; do
   echo "[evidence] pmc passes $cfg"
   bash tools/pmc_passes.sh $cfg "$OUT/pmc_$cfg" > "$OUT/pmc_$cfg.log" 2>&1

@@ -10,7 +10,7 @@ src, tag = sys.argv[1], sys.argv[2]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 prof = os.path.join(root, "profiles")
 shutil.copy(os.path.join(src, "bench.jsonl"), os.path.join(prof, f"{tag}_bench.jsonl"))
-for name in ("cfg2", "cfg2_module_api", "cfg4", "cfg5", "b64", "cfg2_mlp_v1"):
+for name in ("cfg2", "cfg2_module_api", "cfg4", "cfg5", "b64", "cfg2_mlp_v1", "cfg2_split_tail"):
     f = os.path.join(src, f"{name}_kernel_stats.csv")
     if os.path.exists(f):
         shutil.copy(f, os.path.join(prof, f"{tag}_{name}_kernel_stats.csv"))
@@ -22,3 +22,6 @@ for cfg in ("cfg2", "cfg5"):
         subprocess.check_call([sys.executable, os.path.join(root, "tools", "pmc_summary.py"), d, os.path.join(prof, f"{tag}_pmc_{cfg}.json")])
     else:
         print("missing", d)
+f = os.path.join(src, "step_tail.txt")
+if os.path.exists(f):
+    shutil.copy(f, os.path.join(prof, f"{tag}_step_tail.txt"))

@@ -16,7 +16,7 @@ from lgn import _native as Nn  # noqa: E402
 def main():
     stamps = os.environ.get("KB_STAMPS")          # name of a stamp reader of the debug build, e.g. lgn_debug_stamps_bwd3
     if stamps:
-        Nn.LIB_PATH = Nn.LIB_PATH.replace("liblgn_amd.so", "liblgn_amd_stamps.so")
+        Nn.LIB_PATH = Nn.LIB_PATH.replace("liblgn_amd.so", os.environ.get("KB_STAMPS_LIB", "liblgn_amd_stamps.so"))
     what = sys.argv[1] if len(sys.argv) > 1 else "level_fwd_enc"
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
     B = int(os.environ.get("KB_BATCH", "512"))
