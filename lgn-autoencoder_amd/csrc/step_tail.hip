@@ -57,6 +57,8 @@ struct TailDev {
   RadFinJob fin;
 };
 
+static_assert(sizeof(RedJob<double>) + sizeof(TailDev) <= 4096, "step_tail_kernel: both argument blocks travel by value (4 KB of kernel arguments)");
+
 __device__ __forceinline__ void put_shared(double* p, double x) {        // visible to every XCD once the return value is there
   unsigned long long old = __hip_atomic_exchange(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(x),
                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
