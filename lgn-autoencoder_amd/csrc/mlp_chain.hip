@@ -275,30 +275,29 @@ __device__ __forceinline__ void layer_bwd(const double* Wc, const v4d (&gpre)[NT
       });
 }
 
-// Hidden activations kept for the backward (MlpArgs::h_saved; the step keeps them below mlp_save_max_rows() rows): an opaque
-// register image, [64-row block][wave][layer][tile][register][lane] -- every store / load is one 512-byte run -- of exactly
-// mlp_saved_doubles(M, H, 7) doubles.  Written and read by these kernels only (same H, same lane mapping).
+// Hidden activations kept for the backward (MlpArgs::h_saved): an opaque register image,
+// [64-row block][wave][layer][tile][lane][register] -- a lane's four registers of a tile are 32 contiguous bytes, moved as two
+// 16-byte pieces, a wave's piece = every other 16 bytes of a 2 KB run -- of exactly mlp_saved_doubles(M, H, 7) doubles.  Written and
+// read by these kernels only (same H, same lane mapping).  The forward stores layer q - 1 under layer q's matrix instructions; the
+// backward requests layer l - 1 TWO steps before the step that needs it (as it does for the weight images): loaded all at once in
+// the prologue, the 35 MB of a 512-jet batch were a burst of ~6 us in front of every backward -- what the six recomputed layers cost.
 template <class G>
 __device__ __forceinline__ double* saved_ptr(const MlpArgs<double>& a, int wave, int lane) {
-  return a.h_saved + ((size_t)blockIdx.x * 4 + wave) * (G::NH * G::NT * 4 * 64) + lane;
+  return a.h_saved + ((size_t)blockIdx.x * 4 + wave) * (G::NH * G::NT * 256) + lane * 4;
 }
 template <class G>
-__device__ __forceinline__ void save_layer(double* hs, int l, const v4d (&h)[G::NT]) {
-#pragma unroll
-  for (int t = 0; t < G::NT; ++t)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) __builtin_nontemporal_store(h[t][r], &hs[((l * G::NT + t) * 4 + r) * 64]);
-}
+constexpr int saved_pieces() { return 2 * G::NT; }
+// piece j of layer l: tile j >> 1, registers 2 (j & 1) and 2 (j & 1) + 1
 template <class G, int NTI>
 __device__ __forceinline__ void save_piece(double* hs, int l, const v4d (&h)[NTI], int j) {
-  __builtin_nontemporal_store(h[j >> 2][j & 3], &hs[(l * G::NT * 4 + j) * 64]);
+  const v2d v = {h[j >> 1][2 * (j & 1)], h[j >> 1][2 * (j & 1) + 1]};
+  __builtin_nontemporal_store(v, reinterpret_cast<v2d*>(hs + (l * G::NT + (j >> 1)) * 256 + 2 * (j & 1)));
 }
 template <class G>
-__device__ __forceinline__ void load_layer(const double* hs, int l, v4d (&h)[G::NT]) {
-#pragma unroll
-  for (int t = 0; t < G::NT; ++t)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) h[t][r] = __builtin_nontemporal_load(&hs[((l * G::NT + t) * 4 + r) * 64]);
+__device__ __forceinline__ void load_piece(const double* hs, int l, v4d (&h)[G::NT], int j) {
+  const v2d v = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(hs + (l * G::NT + (j >> 1)) * 256 + 2 * (j & 1)));
+  h[j >> 1][2 * (j & 1)] = v[0];
+  h[j >> 1][2 * (j & 1) + 1] = v[1];
 }
 
 // MLP input rows in B layout: xb[r] = x[row0 + c][feature 4r + g], feature f = 2 ch + z of the planar [2][M][C] scalars
@@ -337,7 +336,7 @@ __global__ __launch_bounds__(256) void mlp_chain_fwd_kernel(MlpArgs<double> a) {
 #define LGN_CHAIN_STEP(Q, HIN, HOUT, KS, NTI)                                                                        \
   layer_fwd<G, KS, NTI, GEN, (Q == 3)>(Wl + (Q & 1) * G::WSIZE, HIN, HOUT, c, g, a.act, [&](int i) {               \
     if (!LGN_DBG_NOSTAGE) deal<KS * G::NT, stage_pieces<G>()>(i, [&](int j) { stage_piece<G, false, Q>(a, Wl, wrA, wrB, tid, j); });      \
-    if (SAVE && Q > 0) deal<KS * G::NT, 4 * NTI>(i, [&](int j) { save_piece<G>(hs, Q - 1, HIN, j); });              \
+    if (SAVE && Q > 0) deal<KS * G::NT, 2 * NTI>(i, [&](int j) { save_piece<G>(hs, Q - 1, HIN, j); });              \
   });                                                                                                                \
   lds_barrier();                                                                                                     \
   STAMP(2 + Q);
@@ -348,7 +347,10 @@ __global__ __launch_bounds__(256) void mlp_chain_fwd_kernel(MlpArgs<double> a) {
   LGN_CHAIN_STEP(4, h1, h0, G::KSH, G::NT)
   LGN_CHAIN_STEP(5, h0, h1, G::KSH, G::NT)
 #undef LGN_CHAIN_STEP
-  if (SAVE) save_layer<G>(hs, G::NH - 1, h1);
+  if (SAVE) {
+#pragma unroll
+    for (int j = 0; j < saved_pieces<G>(); ++j) save_piece<G>(hs, G::NH - 1, h1, j);
+  }
   const v4d y = layer_out<G>(Wl + (G::NH & 1) * G::WSIZE, h1, c, g);
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -454,14 +456,16 @@ __global__ __launch_bounds__(256) void mlp_chain_bwd_kernel(MlpArgs<double> a) {
     gout[0][r] = ok ? x : 0.0;
   }
   v4d h[NH][NT];
+  const double* hs = SAVE ? saved_ptr<G>(a, wave, lane) : nullptr;
   if constexpr (SAVE) {
     // the forward's copy: the six recompute steps go away; the images start at the output layer (steps NH, NH + 1, ...: the same
     // buffers and register sets as in the recompute form)
-    const double* hs = saved_ptr<G>(a, wave, lane);
     issue_image<G, NH>(a, wrA, tid);
     issue_image<G, NH - 1>(a, wrB, tid);
 #pragma unroll
-    for (int l = NH - 1; l >= 0; --l) load_layer<G>(hs, l, h[l]);
+    for (int j = 0; j < saved_pieces<G>(); ++j) load_piece<G>(hs, NH - 1, h[NH - 1], j);      // needed by the first two steps; the
+#pragma unroll
+    for (int j = 0; j < saved_pieces<G>(); ++j) load_piece<G>(hs, NH - 2, h[NH - 2], j);      // others follow two steps ahead of their use
     commit_image<G, NH>(Wl, wrA, tid);
     issue_image<G, NH - 2>(a, wrA, tid);
     lds_barrier();
@@ -489,7 +493,7 @@ __global__ __launch_bounds__(256) void mlp_chain_bwd_kernel(MlpArgs<double> a) {
   // successive layers alternate between two register arrays: the running stream still reads the old one as its B operands.
   v4d gpA[NT], gpB[NT], gin[NT];
   {  // q = 6, l = 6: the output layer
-    constexpr int NI = G::KS0 * NT, NPC = 4 + 4 * NT + stage_pieces<G>();
+    constexpr int NI = G::KS0 * NT, NSV = SAVE && NH >= 3 ? saved_pieces<G>() : 0, NPC = 4 + 4 * NT + stage_pieces<G>() + NSV;
     auto fin = [&](int u, int r) {
       double y = gin[u][r] * act_slope_t<GEN>(h[NH - 1][u][r], a.act);
       pin(y);
@@ -499,7 +503,8 @@ __global__ __launch_bounds__(256) void mlp_chain_bwd_kernel(MlpArgs<double> a) {
       deal<NI, NPC>(i, [&](int j) {
         if (j < 4) publish_piece<G, 1>(Gt, gout, wave, c, g, j);
         else if (j < 4 + 4 * NT) publish_piece<G, NT>(Xt, h[NH - 1], wave, c, g, j - 4);
-        else stage_piece<G, true, NH>(a, Wl, wrA, wrB, tid, j - 4 - 4 * NT);
+        else if (j < 4 + 4 * NT + stage_pieces<G>()) stage_piece<G, true, NH>(a, Wl, wrA, wrB, tid, j - 4 - 4 * NT);
+        else if constexpr (NSV > 0) load_piece<G>(hs, NH - 3, h[NH >= 3 ? NH - 3 : 0], j - 4 - 4 * NT - stage_pieces<G>());
       });
     });
 #pragma unroll
@@ -509,7 +514,8 @@ __global__ __launch_bounds__(256) void mlp_chain_bwd_kernel(MlpArgs<double> a) {
   }
 #define LGN_CHAIN_BSTEP(L, GP, GN)                                                                                   \
   {                                                                                                                  \
-    constexpr int q_ = 2 * NH - (L), NI = G::KSH * NT, NPC = 8 * NT + stage_pieces<G>();                             \
+    constexpr int q_ = 2 * NH - (L), NI = G::KSH * NT, NSV = SAVE && (L) >= 3 ? saved_pieces<G>() : 0,               \
+                  NPC = 8 * NT + stage_pieces<G>() + NSV;                                                            \
     auto fin = [&](int u, int r) {                                                                                   \
       double y = gin[u][r] * act_slope_t<GEN>(h[(L) - 1][u][r], a.act);                                              \
       pin(y);                                                                                                        \
@@ -519,7 +525,8 @@ __global__ __launch_bounds__(256) void mlp_chain_bwd_kernel(MlpArgs<double> a) {
       deal<NI, NPC>(i, [&](int j) {                                                                                  \
         if (j < 4 * NT) publish_piece<G, NT>(Gt + ((L) & 1) * G::TSIZE, GP, wave, c, g, j);                          \
         else if (j < 8 * NT) publish_piece<G, NT>(Xt + ((L) & 1) * G::TSIZE, h[(L) - 1], wave, c, g, j - 4 * NT);    \
-        else stage_piece<G, true, q_>(a, Wl, wrA, wrB, tid, j - 8 * NT);                                             \
+        else if (j < 8 * NT + stage_pieces<G>()) stage_piece<G, true, q_>(a, Wl, wrA, wrB, tid, j - 8 * NT);         \
+        else if constexpr (NSV > 0) load_piece<G>(hs, (L) - 3, h[(L) >= 3 ? (L) - 3 : 0], j - 8 * NT - stage_pieces<G>()); \
       });                                                                                                            \
     });                                                                                                              \
     auto tail = [&](int i) {                                                                                         \

@@ -92,6 +92,8 @@ inline size_t mlp_saved_doubles(int M, int H, int nlin) {
 // Worth it only for small batches: the copy is 6 x M x 48 doubles per CGMLP (35 MB at 512 x 30 rows: measured, the step got
 // 26 us SLOWER -- writing and re-reading it costs more than the six recomputed layers), while at 64 x 30 rows (4.4 MB) the
 // backward drops from 24 to 17 us.  The step keeps the copy when the batch has at most this many rows.
+// (Round 5, chain kernels at 512 x 30 rows, the copy moved 16 bytes per lane and re-read two steps ahead of its use: backward
+// 33.5 -> 27.7 us, forward 11.5 -> 19.2 us -- a 12 us forward cannot absorb 35 MB of stores.  Recomputation stays.)
 constexpr int MLP_SAVE_MAX_ROWS = 4096;
 inline size_t mlp_save_max_rows() {          // LGN_AMD_MLP_SAVE_ROWS overrides the threshold (tuning; read once)
   static const long v = [] { const char* e = getenv("LGN_AMD_MLP_SAVE_ROWS"); return e ? atol(e) : (long)MLP_SAVE_MAX_ROWS; }();
