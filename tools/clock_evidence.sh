@@ -5,7 +5,8 @@
 #                  cfg2 shape: lifetime of the first / last workgroup of the grid on the 100 MHz counter and the shader-clock cycles
 #                  between its stamps (tools/kbench.py with the stamps build of the library)
 # probes.txt       what one wave per SIMD keeps up beside a stream of fp64 matrix instructions (csrc/probes/mfma_issue_probe.hip) and
-#                  the issue rates of csrc/probes/mfma_rate_probe.hip / mfma_chain_probe.hip
+#                  the issue rates of csrc/probes/mfma_rate_probe.hip / mfma_chain_probe.hip; what a kernel node of a replayed graph
+#                  costs beside its work (csrc/probes/launch_overhead_probe.hip)
 # placement.txt    which workgroups share a CU (csrc/probes/placement_probe.hip)
 set -e
 OUT=${1:-gpurun_out/clk}
@@ -24,7 +25,7 @@ for spec in "lgn_debug_stamps_bwd3 level_bwd_enc" "lgn_debug_stamps_fwd2 level_f
 done
 kb lgn_debug_stamps_bwd2 level_bwd_enc KB_BATCH=256 KB_N=150 >> "$OUT/clock.txt"
 echo "[clock] mfma probes"
-for pr in mfma_rate_probe mfma_chain_probe mfma_issue_probe; do
+for pr in mfma_rate_probe mfma_chain_probe mfma_issue_probe launch_overhead_probe; do
   echo "== $pr" >> "$OUT/probes.txt"
   timeout -k 5 120 ./$P/$pr.probe >> "$OUT/probes.txt" 2>&1
 done
