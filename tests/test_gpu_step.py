@@ -439,6 +439,28 @@ def test_native_train_step_chooser_covers_module_only_configurations(case):
     U.assert_close(a.flat.grad, b.flat.grad, 1e-9, "flat gradient")
 
 
+@pytest.mark.parametrize("which", ["captured", "native_maxdim3"])
+def test_replayed_graphs_clear_gradients_to_exact_zero(which):
+    """The gradient buffer and the zero blocks are cleared by a kernel of the library, not by hipMemsetAsync: on this stack the memset
+    node of a REPLAYED graph fills its range with a stale pattern (denormals ~7e-310, tools/graph_memset_check.py) -- numerically
+    invisible, but dead parameters (the decoder's radial bells and weights, the last levels' CGMLPs) must keep an EXACT zero
+    gradient on every replay, with the L1 term switched off."""
+    from lgn.step import CapturedModuleStep, NativeTrainStep
+    if which == "captured":
+        z, m, enc, dec, batch = _golden_setup()
+        st = CapturedModuleStep(enc, dec, batch_size=m["B"], lr=5e-4, l1_lambda=0.0, optimizer=False, use_graph=True)
+    else:
+        z, m, enc, dec, batch = _golden_setup("g2_e2e_maxdim3.npz")
+        st = NativeTrainStep(enc, dec, batch_size=m["B"], lr=5e-4, l1_lambda=0.0, optimizer=False, use_graph=True)
+    for _ in range(4):
+        st.step(batch)
+    torch.cuda.synchronize()
+    g = st.flat.grad
+    tiny = (g != 0) & (g.abs() < 1e-200)
+    assert int(tiny.sum()) == 0, f"{int(tiny.sum())} gradient entries hold denormal garbage, e.g. {g[tiny][:3].tolist()}"
+    assert int((g == 0).sum()) > 100, "expected dead parameters with an exact zero gradient"
+
+
 @pytest.mark.parametrize("jet_loss", [False, True])
 def test_captured_module_step_trains_like_the_native_step(jet_loss):
     """Three Adam steps of CapturedModuleStep (graph replay) against NativeTrainStep on a configuration both cover; with
