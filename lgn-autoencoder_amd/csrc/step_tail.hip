@@ -79,6 +79,7 @@ __device__ __forceinline__ double take_sum(double* p) {
     __builtin_amdgcn_s_sleep(1);
   }
   __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (!b) return __longlong_as_double(0x7ff8000000000000LL);      // gave up (a store that never landed): a NaN loss, not a wrong one
   return -__longlong_as_double((long long)b);
 }
 __device__ __forceinline__ double get_shared(const double* p) {
