@@ -657,10 +657,10 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2))) v
         for (int s = 0; s < 5; ++s) rho[s] = 0.0;
         if (on) {                                            // (EXEC-masked block: no per-value selects)
 #pragma unroll
-          for (int s = 0; s < 5; ++s) {
-            rho[s] = fast_rcp((1.0 + ck2[s] * an) + 1e-16);
-            beta[s] = __builtin_fma(bk[s], rho[s], ak[s]);
-          }
+          for (int s = 0; s < 5; ++s) beta[s] = (1.0 + ck2[s] * an) + 1e-16;
+          rcp5(beta, rho);
+#pragma unroll
+          for (int s = 0; s < 5; ++s) beta[s] = __builtin_fma(bk[s], rho[s], ak[s]);
         }
 #pragma unroll
         for (int g = 0; g < NG; ++g) {

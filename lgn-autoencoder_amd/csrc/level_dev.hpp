@@ -218,4 +218,23 @@ __device__ __forceinline__ void metric_perm(const cx<T> (&x)[4], cx<T> (&y)[4]) 
   y[3] = x[1];
 }
 
+// Five reciprocals for the price of one: 1 / u_s from the reciprocal of the product (prefix products up, suffix products down).
+// The five Lorentzian bells of a lane are 1 / (1 + c_s^2 |n|^2 + 1e-16), u_s >= 1 and far from overflow in the product; v_rcp_f64
+// runs at a quarter of the fp64 rate and each refined reciprocal is 32 cycles of the datapath the pair sweeps are bound by:
+// 5 x 32 -> 32 + 12 multiplies = 80 cycles per lane and tile.  Each result carries three or four roundings instead of one (a few
+// 1e-16 relative).
+__device__ __forceinline__ void rcp5(const double (&u)[5], double (&r)[5]) {
+  const double p1 = u[0] * u[1], p2 = p1 * u[2], p3 = p2 * u[3], p4 = p3 * u[4];
+  double t = __builtin_amdgcn_rcp(p4);
+  double e = __builtin_fma(-p4, t, 1.0);
+  t = __builtin_fma(t, e, t);
+  e = __builtin_fma(-p4, t, 1.0);
+  t = __builtin_fma(t, e, t);                  // 1 / (u0 u1 u2 u3 u4)
+  r[4] = t * p3;  t *= u[4];                   // t = 1 / (u0 .. u3)
+  r[3] = t * p2;  t *= u[3];
+  r[2] = t * p1;  t *= u[2];                   // t = 1 / (u0 u1)
+  r[1] = t * u[0];
+  r[0] = t * u[1];
+}
+
 }  // namespace lgn

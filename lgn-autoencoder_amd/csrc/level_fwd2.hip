@@ -396,7 +396,11 @@ __global__ __launch_bounds__(2 * BLOCK) void level_fwd2_kernel(LevelArgs<double>
         double beta[5] = {0.0, 0.0, 0.0, 0.0, 0.0};          // masked edge: basis zeroed, Linear bias survives
         if (on) {                                            // (EXEC-masked block: no per-value selects)
 #pragma unroll
-          for (int s = 0; s < 5; ++s) beta[s] = __builtin_fma(bk[s], fast_rcp((1.0 + ck2[s] * an) + 1e-16), ak[s]);
+          for (int s = 0; s < 5; ++s) beta[s] = (1.0 + ck2[s] * an) + 1e-16;
+          double rho5[5];
+          rcp5(beta, rho5);
+#pragma unroll
+          for (int s = 0; s < 5; ++s) beta[s] = __builtin_fma(bk[s], rho5[s], ak[s]);
         }
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
