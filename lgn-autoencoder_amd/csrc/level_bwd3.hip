@@ -657,7 +657,7 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2))) v
         for (int s = 0; s < 5; ++s) rho[s] = 0.0;
         if (on) {                                            // (EXEC-masked block: no per-value selects)
 #pragma unroll
-          for (int s = 0; s < 5; ++s) beta[s] = (1.0 + ck2[s] * an) + 1e-16;
+          for (int s = 0; s < 5; ++s) beta[s] = 1.0 + ck2[s] * an;      // (+ 1e-16 of position_levels.py:146: absorbed, the sum is >= 1)
           rcp5(beta, rho);
 #pragma unroll
           for (int s = 0; s < 5; ++s) beta[s] = __builtin_fma(bk[s], rho[s], ak[s]);

@@ -396,7 +396,7 @@ __global__ __launch_bounds__(2 * BLOCK) void level_fwd2_kernel(LevelArgs<double>
         double beta[5] = {0.0, 0.0, 0.0, 0.0, 0.0};          // masked edge: basis zeroed, Linear bias survives
         if (on) {                                            // (EXEC-masked block: no per-value selects)
 #pragma unroll
-          for (int s = 0; s < 5; ++s) beta[s] = (1.0 + ck2[s] * an) + 1e-16;
+          for (int s = 0; s < 5; ++s) beta[s] = 1.0 + ck2[s] * an;      // (+ 1e-16 of position_levels.py:146: absorbed, the sum is >= 1)
           double rho5[5];
           rcp5(beta, rho5);
 #pragma unroll
