@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LGN_AMD_ABI_VERSION 15   /* bump on ANY struct or signature change (lgn/_native.py: ABI_VERSION) */
+#define LGN_AMD_ABI_VERSION 16   /* bump on ANY struct or signature change (lgn/_native.py: ABI_VERSION) */
 
 int lgn_abi_version(void);
 const char* lgn_last_error(void);
@@ -84,7 +84,7 @@ int lgn_level_bwd_f64(int B, int N, int C, int CO, int decoder,
  * row_ptr [DO + 1], col [nnz] = m1 * D2 + m2, coef [nnz]).  mode 0: x1 [2][R][C][D1], x2 [2][R][C][D2].  Aggregate (sum over the
  * neighbour index before H, cg_ops.py:281-291), rows R = B * N: mode 1: x1 [2][B][N][N][C][D1] edge-like, x2 [2][B][N][C][D2];
  * mode 2: the operands the other way round.  out [2][R][C][DO].  Backward: g_x1 / g_x2 are ACCUMULATED into (zero-filled by the
- * caller).  What lgn.cg_lib.cg_product / CGProduct bind, one call per pair of irreps; inside the networks the product is fused into
+ * caller); either may be NULL (that operand is data: its gradient is not computed).  What lgn.cg_lib.cg_product / CGProduct bind, one call per pair of irreps; inside the networks the product is fused into
  * the level kernels and never materialised. */
 int lgn_cg_product_fwd_f64(int R, int N, int C, int D1, int D2, int DO, int mode, int nnz, const int* row_ptr, const int* col,
                            const double* coef, const double* x1, const double* x2, double* out, void* stream);
@@ -264,6 +264,8 @@ typedef struct lgn_net_desc {
 #define LGN_NET_MOMENTS_V1 16    /* LGN_AMD_MOMENTS_V1=1: component-chunked moments kernels (with LGN_NET_NO_STATIC) */
 #define LGN_NET_BWD_ORDERED 64   /* LGN_AMD_BWD_ORDERED=1: the encoder level backward runs its radial-gradient GEMM per ordered pair tile
                                     (the form before round 4's symmetric sweep; cross-check) */
+#define LGN_NET_SPLIT_TAIL 128   /* LGN_AMD_SPLIT_TAIL=1: the tail of a step (deferred reductions, radial finalisation, L1 + Adam) as the
+                                    three separate launches instead of csrc/step_tail.hip's one (cross-check; bit-identical) */
 
 /* Plan-time fit queries: bytes of LDS the largest per-jet end stage needs (one workgroup per jet; the limit is LGN_LDS_LIMIT).
  * encoder: input-stage backward (K input scalars, C0 = first channel count) and the latent stage (CL = last channel count,
@@ -281,20 +283,19 @@ long long lgn_step_workspace_doubles(const lgn_net_desc* d);
  * target [B][N][4] the UNscaled batch the reconstruction is compared with (utils/train.py:285-292; may alias p4 when
  * scale == 1); mask [B][N]; recon [2][B][N][4]; loss_part [B].  workspace_doubles = capacity of `workspace`: the call
  * fails before enqueuing anything if the current configuration needs more (lgn_step_workspace_doubles).
- * side_stream (may be NULL): a second stream of the same device on which the batch reductions of the parameter gradients run
- * beside the backward kernels on `stream` (forked and joined with events the library owns; under stream capture these become
- * a branch of the captured graph).  On return every side-stream launch is ordered before whatever is enqueued on `stream`
- * next.  NULL: all reductions run on `stream` after the backward. */
+ * (ABI 16: the side_stream argument of the forked gradient reductions is gone with that path -- measured slower in every regime.) */
 int lgn_step_fwd_bwd_f64(const lgn_net_desc* d, const double* params, double* grads, long long n_params,
                          const int64_t* enc_off, const int64_t* dec_off, const double* p4, const double* target,
                          const uint8_t* mask, double* workspace, long long workspace_doubles, double* recon,
-                         double* loss_part, void* stream, void* side_stream);
+                         double* loss_part, void* stream);
 /* grads += l1_lambda*sign(params) (utils/train.py:484-487); loss_out[0..2] = total, chamfer, sum|w|; optional Adam
  * (torch.optim.Adam defaults; the step counter lives on the device so that graph replays stay correct).
  * loss_out must hold 3 + LGN_FINALIZE_SCRATCH doubles: the results, then scratch -- the per-workgroup |w| partials, the cached
  * bias-correction powers {t, beta1^t, beta2^t} of the next odd / even step (checked against the step counter before use: a
  * restored counter or changed betas just recompute them) and, in the last slot, the finished-workgroup counter of the single
- * launch.  The caller zero-fills the block ONCE, at allocation; the kernel leaves the counter at zero.  A launch that died
+ * launch.  The caller zero-fills the block ONCE, at allocation; every kernel that uses it (this call's, lgn_step_train_f64's fused
+ * tail) leaves the counters AND the |w| partial slots at zero -- the fused tail reads "zero = not yet written in this launch", so
+ * the two calls may be mixed on one block.  A launch that died
  * part-way (device fault) leaves it dirty: zero the block again before reusing it -- with a non-zero counter no workgroup
  * recognises itself as the last one, loss_out[0..2] stay stale and the step counter is not advanced. */
 #define LGN_FINALIZE_SCRATCH 2048
@@ -305,7 +306,7 @@ int lgn_step_finalize_f64(double* params, double* grads, long long n_params, con
  * results: gradients incl. the L1 sub-gradient in `grads`, loss terms in loss_out[0..2], Adam applied when do_adam).  With nothing
  * to do between the gradients and the optimiser (no all-reduce) the tail of the step -- the deferred reductions of all partial
  * rows, the radial-gradient finalisation, L1 + Adam, the loss assembly: three dependent launches above -- is ONE launch
- * (csrc/step_tail.hip; bit-identical results; LGN_AMD_SPLIT_TAIL=1 keeps the three launches).  The table-driven (maxdim 3) step
+ * (csrc/step_tail.hip; bit-identical results; LGN_NET_SPLIT_TAIL in d->flags keeps the three launches).  The table-driven (maxdim 3) step
  * and steps that do not fit the fused form take the three launches by themselves.  loss_out as for lgn_step_finalize_f64; the
  * scratch slots -11 .. -8 of the block are the per-level counters of the fused launch (zero between calls, like the last slot).
  * Data-parallel training keeps the two calls above: the gradient all-reduce sits between them. */

@@ -78,12 +78,12 @@ __global__ __launch_bounds__(BLOCK) void cg_product_bwd_own_kernel(CgArgs a) {
         const size_t i1 = a.mode == 1 ? edge_at(a, r, j, c, a.D1, m1) : node_at(a, a.mode == 2 ? b0 + j : r, c, a.D1, m1);
         const size_t i2 = a.mode == 2 ? edge_at(a, r, j, c, a.D2, m2) : node_at(a, a.mode == 1 ? b0 + j : r, c, a.D2, m2);
         const double gr = a.coef[t] * gr0, gi = a.coef[t] * gi0;
-        if (a.mode != 2) {                                      // x1 is indexed by this thread's row: it owns g_x1 there
+        if (a.mode != 2 && a.g_x1) {                            // x1 is indexed by this thread's row: it owns g_x1 there
           const double br = a.x2[i2], bi = a.x2[p2 + i2];
           a.g_x1[i1] += gr * br + gi * bi;
           a.g_x1[p1 + i1] += gi * br - gr * bi;
         }
-        if (a.mode != 1) {
+        if (a.mode != 1 && a.g_x2) {
           const double ar = a.x1[i1], ai = a.x1[p1 + i1];
           a.g_x2[i2] += gr * ar + gi * ai;
           a.g_x2[p2 + i2] += gi * ar - gr * ai;
@@ -123,12 +123,16 @@ __global__ __launch_bounds__(BLOCK) void cg_product_bwd_src_kernel(CgArgs a) {
   }
 }
 
+// one thread per (row, channel): the product in size_t (edge-like batches reach 2^31 / C rows before they reach the memory limit)
+unsigned grid_of(int R, int C) { return (unsigned)(((size_t)R * C + BLOCK - 1) / BLOCK); }
+
 int check(const CgArgs& a, int nnz) {
   LGN_CHECK_ARG(a.R > 0 && a.C > 0 && a.D1 > 0 && a.D2 > 0 && a.DO > 0 && nnz >= 0, "cg_product: empty operand (R=%d C=%d D1=%d D2=%d DO=%d)",
                 a.R, a.C, a.D1, a.D2, a.DO);
   LGN_CHECK_ARG(a.mode >= 0 && a.mode <= 2, "cg_product: mode %d (0 plain, 1 / 2 aggregate with the first / second operand edge-like)", a.mode);
   LGN_CHECK_ARG(a.mode == 0 || (a.N > 0 && a.R % a.N == 0), "cg_product: aggregate needs rows = B * N (R=%d N=%d)", a.R, a.N);
   LGN_CHECK_ARG(a.row_ptr && a.col && a.coef && a.x1 && a.x2, "cg_product: null pointer");
+  LGN_CHECK_ARG(((size_t)a.R * a.C + BLOCK - 1) / BLOCK <= 0x7fffffffu, "cg_product: %d rows x %d channels exceed one launch", a.R, a.C);
   return 0;
 }
 
@@ -139,20 +143,26 @@ int cg_product_fwd(int R, int N, int C, int D1, int D2, int DO, int mode, int nn
   CgArgs a{R, N, C, D1, D2, DO, mode, row_ptr, col, coef, x1, x2, out, nullptr, nullptr, nullptr};
   if (int rc = check(a, nnz)) return rc;
   LGN_CHECK_ARG(out, "cg_product: null output");
-  hipLaunchKernelGGL(cg_product_fwd_kernel, dim3(cdiv(R * C, BLOCK)), dim3(BLOCK), 0, st, a);
+  hipLaunchKernelGGL(cg_product_fwd_kernel, dim3(grid_of(R, C)), dim3(BLOCK), 0, st, a);
   LGN_CHECK_LAUNCH();
   return 0;
 }
-// g_x1 / g_x2 are ACCUMULATED into (the caller zero-fills them; either may be null: that operand is data)
+// g_x1 / g_x2 are ACCUMULATED into (the caller zero-fills them); either may be null -- that operand is data, its gradient is not
+// computed (the launch that would only produce it is skipped)
 int cg_product_bwd(int R, int N, int C, int D1, int D2, int DO, int mode, int nnz, const int* row_ptr, const int* col, const double* coef,
                    const double* x1, const double* x2, const double* g_out, double* g_x1, double* g_x2, hipStream_t st) {
   CgArgs a{R, N, C, D1, D2, DO, mode, row_ptr, col, coef, x1, x2, nullptr, g_out, g_x1, g_x2};
   if (int rc = check(a, nnz)) return rc;
-  LGN_CHECK_ARG(g_out && g_x1 && g_x2, "cg_product_bwd: null pointer");
-  hipLaunchKernelGGL(cg_product_bwd_own_kernel, dim3(cdiv(R * C, BLOCK)), dim3(BLOCK), 0, st, a);
-  LGN_CHECK_LAUNCH();
-  if (mode) {
-    hipLaunchKernelGGL(cg_product_bwd_src_kernel, dim3(cdiv(R * C, BLOCK)), dim3(BLOCK), 0, st, a);
+  LGN_CHECK_ARG(g_out && (g_x1 || g_x2), "cg_product_bwd: null pointer (g_out, and at least one of g_x1 / g_x2)");
+  const unsigned grid = grid_of(R, C);
+  // receiver side: g_x1 (modes 0, 1) / g_x2 (modes 0, 2); source side of an aggregate: the other operand
+  const bool own = (mode != 2 && g_x1) || (mode != 1 && g_x2), src = mode && (mode == 1 ? g_x2 : g_x1);
+  if (own) {
+    hipLaunchKernelGGL(cg_product_bwd_own_kernel, dim3(grid), dim3(BLOCK), 0, st, a);
+    LGN_CHECK_LAUNCH();
+  }
+  if (src) {
+    hipLaunchKernelGGL(cg_product_bwd_src_kernel, dim3(grid), dim3(BLOCK), 0, st, a);
     LGN_CHECK_LAUNCH();
   }
   return 0;

@@ -222,9 +222,16 @@ __device__ __forceinline__ void metric_perm(const cx<T> (&x)[4], cx<T> (&y)[4]) 
 // The five Lorentzian bells of a lane are 1 / (1 + c_s^2 |n|^2 + 1e-16), u_s >= 1 and far from overflow in the product; v_rcp_f64
 // runs at a quarter of the fp64 rate and each refined reciprocal is 32 cycles of the datapath the pair sweeps are bound by:
 // 5 x 32 -> 32 + 12 multiplies = 80 cycles per lane and tile.  Each result carries three or four roundings instead of one (a few
-// 1e-16 relative).
+// 1e-16 relative).  A product that leaves the range (each u_s around 1e60: unnormalised momenta times a large c; or a NaN input)
+// takes the five divisions one by one -- a branch no realistic jet enters; without it the overflow turned five values that
+// should be ~0 into NaN (inf * 0 in the Newton step).
 __device__ __forceinline__ void rcp5(const double (&u)[5], double (&r)[5]) {
   const double p1 = u[0] * u[1], p2 = p1 * u[2], p3 = p2 * u[3], p4 = p3 * u[4];
+  if (__builtin_expect(!(p4 < 0x1p+1000), 0)) {
+#pragma unroll
+    for (int s = 0; s < 5; ++s) r[s] = 1.0 / u[s];
+    return;
+  }
   double t = __builtin_amdgcn_rcp(p4);
   double e = __builtin_fma(-p4, t, 1.0);
   t = __builtin_fma(t, e, t);

@@ -1128,9 +1128,13 @@ __global__ __launch_bounds__(BLOCK) void l1_adam_kernel(long n, double* w, doubl
   __syncthreads();
   if (!last) return;
   double a = 0, l = 0;
-  for (int i = threadIdx.x; i < (int)gridDim.x; i += BLOCK)
+  for (int i = threadIdx.x; i < (int)gridDim.x; i += BLOCK) {
     a += __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(l1_part) + i, __ATOMIC_RELAXED,
                                                            __HIP_MEMORY_SCOPE_AGENT));
+    // the slots go back to zero: step_tail.hip shares them and reads "zero = not yet written in this launch" (lgn_amd.h: the scratch
+    // block is zero between calls, whichever of the two kernels ran last)
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(l1_part) + i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   for (int i = threadIdx.x; i < nB; i += BLOCK) l += loss_part[i];
   a = block_sum(a, red);
   l = block_sum(l, red);

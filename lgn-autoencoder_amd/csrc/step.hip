@@ -64,40 +64,6 @@ struct Deferred {
   void add(const double* part, int rows, int stride, int col0, int n, double* out) {
     if (n > 0) segs.push_back(RedSeg<double>{part, rows, stride, col0, n, out});
   }
-  // Forked reductions.  The partial rows of a finished producer are reduced on `side` while `main` goes on with the next
-  // level: main --record--> side waits --> reduce on side ... join(): side --record--> main waits.  Under stream capture the
-  // record / wait pairs become graph edges, i.e. a branch of the step's graph; eagerly they are ordinary events.  The
-  // reductions move ~100 MB of CGMLP weight-gradient partials per cfg2 step (HBM-bound) beside kernels that are not.
-  hipStream_t side = nullptr;
-  hipStream_t main_of_fork = nullptr; // the stream the open fork left from (joined back by the destructor on an error path)
-  hipEvent_t* ev = nullptr;          // pool of >= 2 * MAX_FORKS events owned by the library (per device)
-  int nfork = 0;
-  bool forked = false;
-  // An error return between fork_flush() and join() must not leave the side branch dangling: under stream capture an unjoined branch
-  // makes capture_end fail with "unjoined work" and hides the error that caused it.  Best effort, the original error is kept.
-  ~Deferred() {
-    if (forked && main_of_fork && hipEventRecord(ev[MAX_FORKS], side) == hipSuccess) (void)hipStreamWaitEvent(main_of_fork, ev[MAX_FORKS], 0);
-  }
-  static constexpr int MAX_FORKS = 6;
-  int max_forks = MAX_FORKS;
-  int fork_flush(hipStream_t main_st) {
-    if (!side || segs.empty() || nfork >= max_forks) return 0;        // (no side stream: everything waits for flush())
-    hipError_t e = hipEventRecord(ev[nfork], main_st);
-    if (e == hipSuccess) e = hipStreamWaitEvent(side, ev[nfork], 0);
-    if (e != hipSuccess) { set_error("fork_flush: %s", hipGetErrorString(e)); return (int)e; }
-    ++nfork;
-    forked = true;
-    main_of_fork = main_st;
-    return flush(side);
-  }
-  int join(hipStream_t main_st) {
-    if (!forked) return 0;
-    hipError_t e = hipEventRecord(ev[MAX_FORKS], side);
-    if (e == hipSuccess) e = hipStreamWaitEvent(main_st, ev[MAX_FORKS], 0);
-    if (e != hipSuccess) { set_error("join: %s", hipGetErrorString(e)); return (int)e; }
-    forked = false;
-    return 0;
-  }
   int flush(hipStream_t st) {
     for (size_t i = 0; i < segs.size(); i += RED_MAX_SEG) {
       RedJob<double> job{};
@@ -109,38 +75,11 @@ struct Deferred {
   }
 };
 
-// events for Deferred::fork_flush, created on first use (outside any capture: NativeTrainStep warms the step up eagerly
-// before it captures) and kept for the life of the process
-hipEvent_t* fork_events() {
-  constexpr int MAX_DEV = 64;
-  static hipEvent_t pool[MAX_DEV][Deferred::MAX_FORKS + 1];
-  static std::once_flag once[MAX_DEV];
-  static bool ready[MAX_DEV] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return nullptr;
-  std::call_once(once[dev], [dev] {           // (two host threads may take their first step at the same time)
-    bool ok = true;
-    for (int i = 0; i <= Deferred::MAX_FORKS && ok; ++i) ok = hipEventCreateWithFlags(&pool[dev][i], hipEventDisableTiming) == hipSuccess;
-    ready[dev] = ok;
-  });
-  return ready[dev] ? pool[dev] : nullptr;
-}
-int attach_side(Deferred& dq, void* side_stream) {
-  if (!side_stream) return 0;
-  dq.ev = fork_events();
-  LGN_CHECK_ARG(dq.ev, "step: could not create the events of the forked reductions");
-  dq.side = (hipStream_t)side_stream;
-  if (const char* e = getenv("LGN_AMD_MAX_FORKS")) dq.max_forks = atoi(e) < Deferred::MAX_FORKS ? atoi(e) : Deferred::MAX_FORKS;
-  return 0;
-}
-
 // The end of a backward whose gradients go on to somebody else (the all-reduce of a data-parallel step, autograd under the module
 // API): every deferred reduction and the radial finalisation as ONE launch (step_tail.hip, reduce_only) -- `counters`: 4 words of the
-// caller's zero block -- or, when that form does not fit (or LGN_AMD_SPLIT_TAIL=1, or reductions were forked), as reduce_segments +
-// rad_finalize_batch.
-int finish_reductions(Deferred& dq, const RadFinJob& fin, double* grads, long long n_params, double* counters, hipStream_t st) {
-  const char* split_env = getenv("LGN_AMD_SPLIT_TAIL");
-  if (!dq.forked && counters && !(split_env && split_env[0] == '1')) {
+// caller's zero block -- or, when that form does not fit (or with LGN_NET_SPLIT_TAIL), as reduce_segments + rad_finalize_batch.
+int finish_reductions(Deferred& dq, const RadFinJob& fin, double* grads, long long n_params, double* counters, int flags, hipStream_t st) {
+  if (counters && !(flags & LGN_NET_SPLIT_TAIL)) {
     StepTailArgs ro{};
     ro.g = grads;
     ro.n = (long)n_params;
@@ -151,7 +90,6 @@ int finish_reductions(Deferred& dq, const RadFinJob& fin, double* grads, long lo
     if (rc != -2) return rc;
   }
   if (int rc = dq.flush(st)) return rc;
-  if (int rc = dq.join(st)) return rc;
   return rad_finalize_batch(fin, st);
 }
 
@@ -309,7 +247,7 @@ int levels_fwd(const lgn_net_desc& d, bool dec, const int* ch, const double* P, 
 // launches enc_input_bwd.
 int levels_bwd(const lgn_net_desc& d, bool dec, const int* ch, const double* P, double* G, const int64_t* off, const NetBuf& n,
                const double* pos, const uint8_t* mask, Work& w, Deferred& dq, RadFinJob& fin, int& cur, bool has_s_grad,
-               hipStream_t st, bool fork_last = false, double* const* in0_grads = nullptr, bool* in0_done = nullptr) {
+               hipStream_t st, double* const* in0_grads = nullptr, bool* in0_done = nullptr) {
   const Slots S{d.n_levels, d.mlp_nlin};
   const int BN = d.B * d.N;
   for (int l = d.n_levels - 1; l >= 0; --l) {
@@ -365,9 +303,6 @@ int levels_bwd(const lgn_net_desc& d, bool dec, const int* ch, const double* P, 
     }
     cur = nxt;
     has_s_grad = true;       // the level input scalars do carry gradient
-    // this level's partial rows (and whatever was pending) are reduced on the side stream while the next level runs; the
-    // very last level of the step keeps its rows for the closing flush on the main stream
-    if (l > 0 || fork_last) LGN_TRY(dq.fork_flush(st));
   }
   return 0;
 }
@@ -817,7 +752,7 @@ GenStep carve_gen_step(const lgn_net_desc& d, double* base) {
 
 int gen_step_fwd_bwd(const lgn_net_desc& d, const double* params, double* grads, long long n_params, const int64_t* enc_off,
                      const int64_t* dec_off, const double* p4, const double* target, const uint8_t* mask, double* workspace,
-                     long long workspace_doubles, double* recon, double* loss_part, hipStream_t st, void* side_stream) {
+                     long long workspace_doubles, double* recon, double* loss_part, hipStream_t st) {
   LGN_CHECK_ARG(is_generic(d, false) && is_generic(d, true), "step: encoder and decoder must both be table-driven (or both fused)");
   if (int rc = check_generic(d, false)) return rc;
   if (int rc = check_generic(d, true)) return rc;
@@ -836,7 +771,6 @@ int gen_step_fwd_bwd(const lgn_net_desc& d, const double* params, double* grads,
   Deferred dq;
   dq.parts = g.ds.parts;
   dq.cap = g.ds.parts_size;
-  LGN_TRY(attach_side(dq, side_stream));
   RadFinJob fin{};
   {
     DQ_NEW(part, (size_t)B * 2 * CL);
@@ -846,17 +780,10 @@ int gen_step_fwd_bwd(const lgn_net_desc& d, const double* params, double* grads,
   std::vector<UnpackJob> post;
   LGN_TRY(gen_decoder_bwd(d, params, grads, dec_off, g.lat_v, g.da, g.g_lat_v, g.ds, dq, fin, post, st));
   LGN_CHECK_ARG(dq.off <= dq.cap, "step: partial-row workspace overflow (%zu > %zu)", dq.off, dq.cap);
-  // the decoder's reductions (+ the unpacking of its packed CatMix gradients) run on the side stream beside the encoder backward
-  if (dq.side) {
-    LGN_TRY(dq.fork_flush(st));
-    LGN_TRY(run_unpack_jobs(post, dq.side));
-  } else {
-    LGN_TRY(dq.flush(st));
-    LGN_TRY(run_unpack_jobs(post, st));
-  }
+  LGN_TRY(dq.flush(st));
+  LGN_TRY(run_unpack_jobs(post, st));
   // the decoder never reads the latent scalars: no gradient on them
   LGN_TRY(gen_encoder_bwd(d, params, grads, enc_off, p4, mask, g.ea, nullptr, g.g_lat_v, g.es, st));
-  LGN_TRY(dq.join(st));
   return 0;
 }
 
@@ -1039,7 +966,7 @@ int lgn_encoder_bwd_f64(const lgn_net_desc* d, const double* params, double* gra
   double* const in0_grads[2] = {grads + off[0], grads + off[1]};
   bool in0_done = false;
   const int K = in_K(*d);      // (several input scalars: the input stage's backward is its own launch, nothing rides)
-  LGN_TRY(levels_bwd(*d, false, ce, params, grads, off, a.n, p4, mask, w, dq, fin, cur, /*has_s_grad=*/g_lat_s != nullptr, st, false,
+  LGN_TRY(levels_bwd(*d, false, ce, params, grads, off, a.n, p4, mask, w, dq, fin, cur, /*has_s_grad=*/g_lat_s != nullptr, st,
                      K > 1 ? nullptr : in0_grads, &in0_done));
   if (!in0_done) {
     const int C0 = ce[0], row = (2 * K + 2) * C0;
@@ -1050,7 +977,7 @@ int lgn_encoder_bwd_f64(const lgn_net_desc* d, const double* params, double* gra
   }
   LGN_CHECK_ARG(dq.off <= dq.cap, "encoder_bwd: partial-row workspace overflow (%zu > %zu)", dq.off, dq.cap);
   // (measured at cfg2, captured module step: the one-launch form is 3 us SLOWER for the encoder alone -- 0.5966 against 0.5937 ms)
-  LGN_TRY(finish_reductions(dq, fin, grads, n_params, nullptr, st));
+  LGN_TRY(finish_reductions(dq, fin, grads, n_params, nullptr, d->flags, st));
   return 0;
 }
 
@@ -1174,8 +1101,7 @@ long long lgn_step_workspace_doubles(const lgn_net_desc* d) {
 // deferred reductions, the radial finalisation, L1 + Adam and the loss assembly are ONE launch (step_tail.hip) instead of three
 static int step_fwd_bwd(const lgn_net_desc* d, const double* params, double* grads, long long n_params, const int64_t* enc_off,
                         const int64_t* dec_off, const double* p4, const double* target, const uint8_t* mask, double* workspace,
-                        long long workspace_doubles, double* recon, double* loss_part, void* stream, void* side_stream,
-                        const StepTailArgs* tail, bool fuse_tail) {
+                        long long workspace_doubles, double* recon, double* loss_part, void* stream, const StepTailArgs* tail) {
   if (int rc = check_desc(d)) return rc;
   LGN_CHECK_ARG(params && grads && enc_off && dec_off && p4 && target && mask && workspace && recon && loss_part && n_params > 0,
                 "step_fwd_bwd: null pointer");
@@ -1184,7 +1110,7 @@ static int step_fwd_bwd(const lgn_net_desc* d, const double* params, double* gra
   hipStream_t st = (hipStream_t)stream;
   if (is_generic(*d, false) || is_generic(*d, true)) {
     LGN_TRY(gen_step_fwd_bwd(*d, params, grads, n_params, enc_off, dec_off, p4, target, mask, workspace, workspace_doubles, recon,
-                             loss_part, st, side_stream));
+                             loss_part, st));
     if (tail)        // (the table-driven step unpacks gradients after its reductions: it keeps the separate launches)
       LGN_TRY(finalize_step(tail->w, tail->g, tail->n, tail->loss_part, tail->nB, tail->lambda, tail->m, tail->v, tail->step_dev, tail->lr,
                             tail->beta1, tail->beta2, tail->eps, tail->do_adam, tail->loss_out, st));
@@ -1218,7 +1144,6 @@ static int step_fwd_bwd(const lgn_net_desc* d, const double* params, double* gra
   Deferred dq;
   dq.parts = w.parts;
   dq.cap = w.parts_size;
-  LGN_TRY(attach_side(dq, side_stream));
   RadFinJob fin{};
 
   // ---------------- forward ----------------
@@ -1242,8 +1167,7 @@ static int step_fwd_bwd(const lgn_net_desc* d, const double* params, double* gra
   }
 
   // ---------------- backward ----------------
-  LGN_TRY(levels_bwd(*d, true, cd, params, grads, dec_off, w.dec, w.pdec, nullptr, w, dq, fin, cur, /*has_s_grad=*/false, st,
-                     /*fork_last=*/true));
+  LGN_TRY(levels_bwd(*d, true, cd, params, grads, dec_off, w.dec, w.pdec, nullptr, w, dq, fin, cur, /*has_s_grad=*/false, st));
   {
     const int C0 = cd[0], Tin = pool_blocks(d->latent_pool) * Tv, row = 4 * C0 + 2 * N * Tin;
     const int CL = ce[L], KL = pool_mix_in(d->latent_pool, N, CL), rowe = 2 * (Ts + Tv) * KL;
@@ -1264,8 +1188,7 @@ static int step_fwd_bwd(const lgn_net_desc* d, const double* params, double* gra
   }
   double* const in0_grads[2] = {grads + enc_off[0], grads + enc_off[1]};
   bool in0_done = false;
-  LGN_TRY(levels_bwd(*d, false, ce, params, grads, enc_off, w.enc, p4, mask, w, dq, fin, cur, /*has_s_grad=*/false, st, false, in0_grads,
-                     &in0_done));
+  LGN_TRY(levels_bwd(*d, false, ce, params, grads, enc_off, w.enc, p4, mask, w, dq, fin, cur, /*has_s_grad=*/false, st, in0_grads, &in0_done));
   if (!in0_done) {      // (three-kernel level backward: N > 40, LGN_AMD_LEVEL_V2)
     const int C0 = ce[0];
     DQ_NEW(part, (size_t)B * 4 * C0);
@@ -1274,13 +1197,13 @@ static int step_fwd_bwd(const lgn_net_desc* d, const double* params, double* gra
     dq.add(part, B, 4 * C0, 2 * C0, 2 * C0, grads + enc_off[1]);
   }
   LGN_CHECK_ARG(dq.off <= dq.cap, "step: partial-row workspace overflow (%zu > %zu)", dq.off, dq.cap);
-  if (tail && fuse_tail && !dq.forked) {
+  if (tail && !(d->flags & LGN_NET_SPLIT_TAIL)) {
     const int rc = step_tail(dq.segs, fin, *tail, st);
     if (rc == 0) return 0;
     if (rc != -2) return rc;                   // -2: does not fit the fused form -> the separate launches below
   }
   // (data-parallel step: the all-reduce follows -- reductions + radial finalisation as one launch where that fits)
-  LGN_TRY(finish_reductions(dq, fin, grads, n_params, tail ? nullptr : w.tail_cnt, st));
+  LGN_TRY(finish_reductions(dq, fin, grads, n_params, tail ? nullptr : w.tail_cnt, d->flags, st));
   if (tail)
     LGN_TRY(finalize_step(tail->w, tail->g, tail->n, tail->loss_part, tail->nB, tail->lambda, tail->m, tail->v, tail->step_dev, tail->lr,
                           tail->beta1, tail->beta2, tail->eps, tail->do_adam, tail->loss_out, st));
@@ -1290,9 +1213,9 @@ extern "C" {
 
 int lgn_step_fwd_bwd_f64(const lgn_net_desc* d, const double* params, double* grads, long long n_params, const int64_t* enc_off,
                          const int64_t* dec_off, const double* p4, const double* target, const uint8_t* mask, double* workspace,
-                         long long workspace_doubles, double* recon, double* loss_part, void* stream, void* side_stream) {
+                         long long workspace_doubles, double* recon, double* loss_part, void* stream) {
   return step_fwd_bwd(d, params, grads, n_params, enc_off, dec_off, p4, target, mask, workspace, workspace_doubles, recon, loss_part,
-                      stream, side_stream, nullptr, false);
+                      stream, nullptr);
 }
 
 int lgn_step_train_f64(const lgn_net_desc* d, double* params, double* grads, long long n_params, const int64_t* enc_off,
@@ -1304,10 +1227,10 @@ int lgn_step_train_f64(const lgn_net_desc* d, double* params, double* grads, lon
   LGN_CHECK_ARG(!do_adam || (adam_m && adam_v && step_dev), "step_train: Adam state missing");
   const StepTailArgs tail{params, grads, (long)n_params, adam_m, adam_v, reinterpret_cast<long*>(step_dev), l1_lambda, lr, beta1, beta2,
                           eps, do_adam, loss_part, n_loss, loss_out, 0, nullptr};
-  // LGN_AMD_SPLIT_TAIL=1: the three separate launches (reduce_segments, rad_finalize_batch, l1_adam) -- the A/B switch of the fused tail
-  const char* split = getenv("LGN_AMD_SPLIT_TAIL");
+  // LGN_NET_SPLIT_TAIL (frozen into the descriptor): the three separate launches (reduce_segments, rad_finalize_batch, l1_adam) -- the
+  // A/B switch of the fused tail
   return step_fwd_bwd(d, params, grads, n_params, enc_off, dec_off, p4, target, mask, workspace, workspace_doubles, recon, loss_part,
-                      stream, nullptr, &tail, !(split && split[0] == '1'));
+                      stream, &tail);
 }
 
 int lgn_step_finalize_f64(double* params, double* grads, long long n_params, const double* loss_part, int n_loss, double l1_lambda,

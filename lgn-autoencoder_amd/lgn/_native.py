@@ -15,7 +15,7 @@ import torch  # imported before the .so so that the process-wide libamdhip64 is 
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LGN_AMD_LIB") or os.path.join(_HERE, "_lib", "liblgn_amd.so")   # LGN_AMD_LIB: debug builds (tools/)
-ABI_VERSION = 15
+ABI_VERSION = 16
 FINALIZE_SCRATCH = 2048      # include/lgn_amd.h: LGN_FINALIZE_SCRATCH
 
 _lib: Optional[C.CDLL] = None
@@ -125,7 +125,7 @@ class NetDesc(C.Structure):
 NET_NO_STATIC = 1
 # kernel-selecting cross-check switches -> LGN_NET_* bits of include/lgn_amd.h
 _NET_FLAG_ENV = {"LGN_AMD_NO_STATIC": 1, "LGN_AMD_DEC_PAIRWISE": 2, "LGN_AMD_LEVEL_V2": 4, "LGN_AMD_MLP_V1": 8,
-                 "LGN_AMD_MOMENTS_V1": 16, "LGN_AMD_BWD_ORDERED": 64}
+                 "LGN_AMD_MOMENTS_V1": 16, "LGN_AMD_BWD_ORDERED": 64, "LGN_AMD_SPLIT_TAIL": 128}
 # LGN_ACT_* of include/lgn_amd.h: the names get_activation_fn accepts (lgn/nn/generic_levels.py:119-135)
 ACTIVATIONS = {"leakyrelu": 0, "relu": 1, "elu": 2, "sigmoid": 3, "logsigmoid": 4, "atan": 5}
 
@@ -155,7 +155,7 @@ _SIGNATURES.update({
     "lgn_local_bwd_static_f64": [_i] * 4 + [_vp] * 3 + [_ip] + [_vp] * 8,
     "lgn_local_bwd_f64": [_i] * 5 + [_tp] + [_vp] * 8,
     "lgn_step_param_slots": [_dp, _i],
-    "lgn_step_fwd_bwd_f64": [_dp, _vp, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _vp, _vp, _vp],
+    "lgn_step_fwd_bwd_f64": [_dp, _vp, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _vp, _vp],
     "lgn_encoder_fwd_f64": [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _vp, _vp],
     "lgn_encoder_bwd_f64": [_dp, _vp, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _vp, _vp, _ll, _vp],
     "lgn_decoder_fwd_f64": [_dp, _vp, _vp, _vp, _vp, _ll, _vp, _vp],

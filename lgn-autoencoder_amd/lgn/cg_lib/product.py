@@ -58,7 +58,7 @@ class _PairProduct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, tab, mode, x1, x2):
         row_ptr, col, coef, DO, nnz, _ = tab
-        x1, x2 = N.f64(x1), N.f64(x2)
+        x1, x2 = N.f64(x1), N.f64(x2)                       # fp64 only (the reference's precision): any other dtype raises, nothing is cast
         node = x2 if mode == 1 else x1                       # the node-like operand fixes rows and channels
         C_, D1, D2 = node.shape[-2], x1.shape[-1], x2.shape[-1]
         R = node[0].numel() // (C_ * node.shape[-1])
@@ -75,9 +75,14 @@ class _PairProduct(torch.autograd.Function):
         x1, x2 = ctx.saved_tensors
         row_ptr, col, coef, DO, nnz, _ = ctx.tab
         R, n, C_, D1, D2 = ctx.dims
-        g1, g2 = torch.zeros_like(x1), torch.zeros_like(x2)
+        # only the gradients autograd asks for (a null pointer tells the library to skip that operand: lgn_cg_product_bwd_f64)
+        g1 = torch.zeros_like(x1) if ctx.needs_input_grad[2] else None
+        g2 = torch.zeros_like(x2) if ctx.needs_input_grad[3] else None
+        if g1 is None and g2 is None:
+            return None, None, None, None
         N._check(N.lib().lgn_cg_product_bwd_f64(R, n, C_, D1, D2, DO, ctx.mode, nnz, N.ptr(row_ptr), N.ptr(col), N.ptr(coef), N.ptr(x1), N.ptr(x2),
-                                                N.ptr(N.f64(g_out)), N.ptr(g1), N.ptr(g2), N.stream_ptr()), "lgn_cg_product_bwd_f64")
+                                                N.ptr(N.f64(g_out)), N.ptr(g1) if g1 is not None else None,
+                                                N.ptr(g2) if g2 is not None else None, N.stream_ptr()), "lgn_cg_product_bwd_f64")
         return None, None, g1, g2
 
 

@@ -321,11 +321,6 @@ class NativeTrainStep:
         self.mask = torch.empty(d.B, d.N, device=dev, dtype=torch.uint8)
         self.use_graph = use_graph
         self._g1 = self._g2 = None
-        # second stream for the forked gradient reductions (include/lgn_amd.h: side_stream).  OFF by default: measured on
-        # MI355X / ROCm 7.2, every fork + join inside a replayed HIP graph costs 20-40 us (0.599 ms per cfg2 step without,
-        # 0.637 / 0.661 / 0.677 ms with 1 / 2 / 3 forks) -- far more than the ~25 us of reductions it takes off the critical
-        # path.  LGN_AMD_FORK=1 enables it (eager launches on two streams do overlap).
-        self._side = torch.cuda.Stream(device=dev) if _os.environ.get("LGN_AMD_FORK") == "1" else None
 
     # -- raw native calls on the current stream
     def _fwd_bwd(self):
@@ -334,7 +329,7 @@ class NativeTrainStep:
         rc = N.lib().lgn_step_fwd_bwd_f64(C.byref(self.desc), N.ptr(self.flat.flat), N.ptr(self.flat.grad), self.flat.flat.numel(),
                                           self.enc_off, self.dec_off, N.ptr(self.p4), N.ptr(self.target), N.ptr(self.mask),
                                           N.ptr(self.workspace), self.workspace.numel(), N.ptr(self.recon), N.ptr(self.loss_part),
-                                          N.stream_ptr(), self._side.cuda_stream if self._side is not None else None)
+                                          N.stream_ptr())
         N._check(rc, "lgn_step_fwd_bwd_f64")
 
     def _finalize(self, do_adam: bool):
@@ -348,11 +343,7 @@ class NativeTrainStep:
     def _train(self, do_adam: bool):
         """Single process: the whole step in ONE native call (lgn_step_train_f64) -- with no all-reduce between the gradients and the
         optimiser, the reductions, the radial finalisation, L1 + Adam and the loss assembly are one launch (csrc/step_tail.hip)
-        instead of three; same results bit for bit (LGN_AMD_SPLIT_TAIL=1 or LGN_AMD_FORK=1: the separate calls)."""
-        if self._side is not None:
-            self._fwd_bwd()
-            self._finalize(do_adam)
-            return
+        instead of three; same results bit for bit (LGN_AMD_SPLIT_TAIL=1 when the step is built: the separate launches)."""
         import ctypes as C
         N = self.N
         rc = N.lib().lgn_step_train_f64(C.byref(self.desc), N.ptr(self.flat.flat), N.ptr(self.flat.grad), self.flat.flat.numel(),
