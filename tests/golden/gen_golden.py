@@ -26,6 +26,8 @@ Fixtures
                       plus one extra input scalar per node through data['scalars']
   g11_e2e_mlpdepth4.npz / g11_e2e_mlpdepth3_maxdim3.npz  end-to-end with --mlp-depth 4 (maxdim 2, B=3 N=12 ch 2344/4432) and 3 (maxdim 3,
                       B=2 N=10 ch 246/642): CGMLPs of 5 / 4 Linear layers (round 5)
+  g14_e2e_mlpwidth{4,5,7}.npz / g14_e2e_mlpwidth5_maxdim3.npz  end-to-end with --mlp-width 4 / 5 / 7 (maxdim 2, B=3 N=12 ch 2344/4432) and 5
+                                     (maxdim 3, B=2 N=10 ch 246/642): CGMLP hidden widths other than 6 x 2C
   g13_e2e_basis5.npz / g13_e2e_basis5_maxdim3.npz  end-to-end with --num-basis-fn 5 (10 bells), maxdim 2 (B=3 N=12) and 3 (B=2 N=10)
   g12_e2e_n150_maxdim3.npz  end-to-end, B=1 N=150 maxdim=3 ch 4466/6644 (round 5: jets beyond the LDS-resident kernels)
   g8_harness.npz      the reference's own equivariance harness (lgn/models/autotest/lgn_tests.py:292-423) run on the g1 weights
@@ -38,6 +40,8 @@ import json
 import os
 import sys
 import types
+
+sys.dont_write_bytecode = True      # the reference tree is read-only by contract: no __pycache__ beside its sources, however this is run
 
 import numpy as np
 import torch
@@ -85,10 +89,10 @@ def jets(B, N, seed, pad_rows=()):
 
 
 def build(N, maxdim, ch_enc, ch_dec, seed, map_to_latent="min&max", activation="leakyrelu", jet_features=False, tau_input_scalars=1,
-          mlp_depth=6, num_basis_fn=10):
+          mlp_depth=6, num_basis_fn=10, mlp_width=6):
     torch.manual_seed(seed)
     common = dict(maxdim=[maxdim], max_zf=[1], weight_init="randn", level_gain=[1.0], num_basis_fn=num_basis_fn,
-                  activation=activation, mlp=True, mlp_depth=mlp_depth, mlp_width=6, device=CPU, dtype=F64)
+                  activation=activation, mlp=True, mlp_depth=mlp_depth, mlp_width=mlp_width, device=CPU, dtype=F64)
     enc = LGNEncoder(num_input_particles=N, tau_input_scalars=tau_input_scalars, tau_input_vectors=1, map_to_latent=map_to_latent,
                      tau_latent_scalars=1, tau_latent_vectors=8, num_channels=list(ch_enc), scale=1.0,
                      jet_features=jet_features, **common)
@@ -99,8 +103,9 @@ def build(N, maxdim, ch_enc, ch_dec, seed, map_to_latent="min&max", activation="
 
 
 def e2e(name, B, N, maxdim, ch_enc, ch_dec, seed, pad_rows=(), map_to_latent="min&max", activation="leakyrelu", jet_features=False,
-        extra_scalars=0, mlp_depth=6, num_basis_fn=10):
-    enc, dec = build(N, maxdim, ch_enc, ch_dec, seed, map_to_latent, activation, jet_features, 1 + extra_scalars, mlp_depth, num_basis_fn)
+        extra_scalars=0, mlp_depth=6, num_basis_fn=10, mlp_width=6):
+    enc, dec = build(N, maxdim, ch_enc, ch_dec, seed, map_to_latent, activation, jet_features, 1 + extra_scalars, mlp_depth, num_basis_fn,
+                     mlp_width)
     p4, labels = jets(B, N, seed + 100, pad_rows)
     meta = dict(B=B, N=N, maxdim=maxdim, ch_enc=list(ch_enc), ch_dec=list(ch_dec), seed=seed, l1_lambda=1e-8, map_to_latent=map_to_latent)
     if activation != "leakyrelu":
@@ -111,6 +116,8 @@ def e2e(name, B, N, maxdim, ch_enc, ch_dec, seed, pad_rows=(), map_to_latent="mi
         meta["mlp_depth"] = mlp_depth
     if num_basis_fn != 10:
         meta["num_basis_fn"] = num_basis_fn
+    if mlp_width != 6:
+        meta["mlp_width"] = mlp_width
     store = {"p4": npy(p4), "labels": npy(labels), "meta": np.array(json.dumps(meta))}
     for k, v in enc.state_dict().items():
         store["enc." + k] = npy(v)
@@ -347,6 +354,13 @@ if __name__ == "__main__":
     if want("g13"):       # --num-basis-fn 5 (lgn/nn/position_levels.py:44-64): 10 Lorentzian bells instead of 20, maxdim 2 and maxdim 3
         e2e("g13_e2e_basis5.npz", 3, 12, 2, (2, 3, 4, 4), (4, 3, 3, 2), seed=10, pad_rows=((2, 9),), num_basis_fn=5)
         e2e("g13_e2e_basis5_maxdim3.npz", 2, 10, 3, (2, 3, 4), (4, 3, 2), seed=11, pad_rows=((1, 6),), num_basis_fn=5)
+    if want("g14"):       # --mlp-width other than the default 6 (lgn/models/lgn_levels.py:124-189): hidden width = mlp_width * 2C -- 16 / 24 /
+        # 32 (width 4), 20 / 30 / 40 (width 5: not multiples of the 4-deep matrix instruction), 28 / 42 / 56 (width 7: C = 4 leaves the
+        # H <= 48 kernels), and 20 / 40 / 60 at maxdim 3
+        e2e("g14_e2e_mlpwidth4.npz", 3, 12, 2, (2, 3, 4, 4), (4, 4, 3, 2), seed=12, pad_rows=((1, 8),), mlp_width=4)
+        e2e("g14_e2e_mlpwidth5.npz", 3, 12, 2, (2, 3, 4, 4), (4, 4, 3, 2), seed=13, pad_rows=((0, 10),), mlp_width=5)
+        e2e("g14_e2e_mlpwidth7.npz", 3, 12, 2, (2, 3, 4, 4), (4, 4, 3, 2), seed=14, pad_rows=((2, 7),), mlp_width=7)
+        e2e("g14_e2e_mlpwidth5_maxdim3.npz", 2, 10, 3, (2, 4, 6), (6, 4, 2), seed=15, pad_rows=((1, 6),), mlp_width=5)
     if want("g12"):       # 150 particles at maxdim 3 (the product of two BASELINE axes; the jet's packed features exceed a CU's LDS)
         e2e("g12_e2e_n150_maxdim3.npz", 1, 150, 3, (4, 4, 6, 6), (6, 6, 4, 4), seed=9, pad_rows=((0, 137),))
     if want("g10"):

@@ -593,7 +593,7 @@ def _build(meta, dev):
     enc, dec = G._models(meta["N"], meta["ch_enc"], meta["ch_dec"], dev, seed=meta["seed"], maxdim=meta["maxdim"],
                          map_to_latent=meta.get("map_to_latent", "min&max"), activation=meta.get("activation", "leakyrelu"),
                          jet_features=meta.get("jet_features", False), tau_input_scalars=1 + meta.get("extra_scalars", 0),
-                         mlp_depth=meta.get("mlp_depth", 6), num_basis_fn=meta.get("num_basis_fn", 10))
+                         mlp_depth=meta.get("mlp_depth", 6), num_basis_fn=meta.get("num_basis_fn", 10), mlp_width=meta.get("mlp_width", 6))
     return enc, dec
 
 
@@ -686,7 +686,8 @@ def _generic_level_case(dev, O, decoder, maxdim, full, C, CO, N, B):
 @pytest.mark.parametrize("name", ["g1_e2e_maxdim2.npz", "g3_e2e_n150.npz", "g2_e2e_maxdim3.npz", "g6_e2e_mix.npz",
                                   "g7_e2e_meanmax.npz", "g9_e2e_elu.npz", "g10_e2e_jetfeat.npz", "g11_e2e_mlpdepth4.npz",
                                   "g11_e2e_mlpdepth3_maxdim3.npz", "g12_e2e_n150_maxdim3.npz", "g13_e2e_basis5.npz",
-                                  "g13_e2e_basis5_maxdim3.npz"])
+                                  "g13_e2e_basis5_maxdim3.npz", "g14_e2e_mlpwidth4.npz", "g14_e2e_mlpwidth5.npz", "g14_e2e_mlpwidth7.npz",
+                                  "g14_e2e_mlpwidth5_maxdim3.npz"])
 @pytest.mark.parametrize("fused", [True, False])
 def test_end_to_end_vs_reference_golden(dev, O, name, fused):
     """Full encoder -> decoder -> Chamfer forward/backward against vectors captured from the reference, through the

@@ -40,14 +40,15 @@ def _golden_setup(name="g1_e2e_maxdim2.npz"):
     m = U.meta(z)
     enc, dec = G._models(m["N"], m["ch_enc"], m["ch_dec"], dev, seed=m["seed"], maxdim=m.get("maxdim", 2),
                          activation=m.get("activation", "leakyrelu"), map_to_latent=m.get("map_to_latent", "min&max"),
-                         mlp_depth=m.get("mlp_depth", 6), num_basis_fn=m.get("num_basis_fn", 10))
+                         mlp_depth=m.get("mlp_depth", 6), num_basis_fn=m.get("num_basis_fn", 10), mlp_width=m.get("mlp_width", 6))
     batch = {"p4": torch.from_numpy(z["p4"]).to(dev), "labels": torch.from_numpy(z["labels"]).to(dev)}
     return z, m, enc, dec, batch
 
 
 @pytest.mark.parametrize("name", ["g1_e2e_maxdim2.npz", "g3_e2e_n150.npz", "g2_e2e_maxdim3.npz", "g9_e2e_elu.npz", "g7_e2e_meanmax.npz", "g6_e2e_mix.npz",
                                   "g11_e2e_mlpdepth4.npz", "g11_e2e_mlpdepth3_maxdim3.npz", "g12_e2e_n150_maxdim3.npz", "g13_e2e_basis5.npz",
-                                  "g13_e2e_basis5_maxdim3.npz"])
+                                  "g13_e2e_basis5_maxdim3.npz", "g14_e2e_mlpwidth4.npz", "g14_e2e_mlpwidth5.npz", "g14_e2e_mlpwidth7.npz",
+                                  "g14_e2e_mlpwidth5_maxdim3.npz"])
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_native_step_matches_reference_golden(name, use_graph):
     """lgn_step_fwd_bwd_f64 + lgn_step_finalize_f64 (one native call each, optionally replayed from a HIP graph)

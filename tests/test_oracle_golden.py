@@ -11,7 +11,7 @@ TOL = 1e-12
 
 def _cfgs(m):
     common = dict(num_particles=m["N"], maxdim=m["maxdim"], map_to_latent=m.get("map_to_latent", "min&max"),
-                  activation=m.get("activation", "leakyrelu"), mlp_depth=m.get("mlp_depth", 6), num_basis_fn=m.get("num_basis_fn", 10))
+                  activation=m.get("activation", "leakyrelu"), mlp_depth=m.get("mlp_depth", 6), num_basis_fn=m.get("num_basis_fn", 10), mlp_width=m.get("mlp_width", 6))
     return (O.NetConfig(num_channels=tuple(m["ch_enc"]), jet_features=m.get("jet_features", False),
                         tau_input_scalars=1 + m.get("extra_scalars", 0), **common),
             O.NetConfig(num_channels=tuple(m["ch_dec"]), **common))
@@ -20,7 +20,8 @@ def _cfgs(m):
 @pytest.mark.parametrize("name", ["g1_e2e_maxdim2.npz", "g2_e2e_maxdim3.npz", "g3_e2e_n150.npz", "g6_e2e_mix.npz",
                                   "g7_e2e_meanmax.npz", "g9_e2e_elu.npz", "g10_e2e_jetfeat.npz", "g11_e2e_mlpdepth4.npz",
                                   "g11_e2e_mlpdepth3_maxdim3.npz", "g12_e2e_n150_maxdim3.npz", "g13_e2e_basis5.npz",
-                                  "g13_e2e_basis5_maxdim3.npz"])
+                                  "g13_e2e_basis5_maxdim3.npz", "g14_e2e_mlpwidth4.npz", "g14_e2e_mlpwidth5.npz", "g14_e2e_mlpwidth7.npz",
+                                  "g14_e2e_mlpwidth5_maxdim3.npz"])
 def test_end_to_end_forward_backward(name):
     z = U.load(name)
     m = U.meta(z)
