@@ -488,6 +488,76 @@ def _time_steps(trainer, batch, steps, warmup, world):
     return elapsed
 
 
+def small_batch_legs(dev, cfg, G, NativeTrainStep):
+    """cfg2's network at 256 / 128 / 64 jets -- the per-GPU shares of BASELINE's cfg3 (512 jets over 2 / 4 / 8 GPUs) -- 20 timed steps
+    each, as ``configs.b256 / b128 / b64``: the single-process step (lgn_step_train_f64, one graph launch) and, where an `nccl` group
+    of ONE rank can be set up on this GPU, the data-parallel branch a rank of an N-GPU job runs ([fwd + bwd | all-reduce | L1 + Adam]
+    in one graph; the all-reduce of a single rank moves no data: its launch is in the figure, the exchange is not)."""
+    import socket
+    legs = {}
+    own_group = False
+    if dist.is_available() and not dist.is_initialized():
+        try:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+            own_group = True
+        except Exception as exc:      # noqa: BLE001  (a secondary figure: reported, never fatal)
+            legs["dp_branch_error"] = f"{type(exc).__name__}: {exc}"[:300]
+    try:
+        for jets in (256, 128, 64):
+            name = f"b{jets}"
+            try:
+                p4, labels = synthetic_jets(jets, cfg["N"], seed=0)
+                b = {"p4": p4.to(dev), "labels": labels.to(dev)}
+                e2, d2 = G._models(cfg["N"], cfg["ch_enc"], cfg["ch_dec"], dev, seed=0, maxdim=cfg["maxdim"])
+                t2 = NativeTrainStep(e2, d2, batch_size=jets, lr=5e-4, l1_lambda=1e-8, use_graph=True)
+                el = _time_steps(t2, b, 20, 5, 1)
+                legs[name] = {"value": jets * 20 / el, "unit": "jets/s", "ms_per_step": 1e3 * el / 20, "steps": 20, "warmup": 5,
+                              "workload": f"cfg2's networks, {jets} jets of 30 particles on one GPU (cfg3's share on {cfg['B'] // jets} GPUs)"}
+                del t2, e2, d2
+                if own_group:
+                    e2, d2 = G._models(cfg["N"], cfg["ch_enc"], cfg["ch_dec"], dev, seed=0, maxdim=cfg["maxdim"])
+                    t2 = NativeTrainStep(e2, d2, batch_size=jets, lr=5e-4, l1_lambda=1e-8, use_graph=True, force_collective=True)
+                    el = _time_steps(t2, b, 20, 5, 1)
+                    legs[name]["dp_branch"] = {"ms_per_step": 1e3 * el / 20, "graph_launches_per_step": t2.launches_per_step,
+                                               "note": "lgn_step_fwd_bwd_f64 | RCCL all-reduce (world size 1) | lgn_step_finalize_f64"}
+                    del t2, e2, d2
+            except RuntimeError as exc:
+                legs[name] = {"value": None, "error": f"{type(exc).__name__}: {exc}"[:300]}
+    finally:
+        if own_group:
+            dist.destroy_process_group()
+    return legs
+
+
+# all-reduce(SUM) of the flat gradient buffer (63.5 k parameters + the per-jet loss terms = 512 KB) over xGMI: latency-bound at
+# this size; NOT measured here (one GPU per box) -- an assumption, stated in the line
+ASSUMED_ALLREDUCE_US = 25.0
+
+
+def predict_strong_scaling(global_batch, one_gpu_rate, configs):
+    """BASELINE's cfg3 (cfg2's 512 jets split over N GPUs) PREDICTED from the one-GPU small-batch steps: a rank's step is the
+    data-parallel branch at 512 / N jets (configs.bNNN.dp_branch, else the single-process step) plus an all-reduce of 512 KB.
+    The driver's SCALE run is the measurement; this object says what the builder expects it to read and why."""
+    pred = {"global_batch": global_batch, "assumed_allreduce_us": ASSUMED_ALLREDUCE_US, "one_gpu_jets_per_s": one_gpu_rate,
+            "note": "prediction, not a measurement: per-rank step time measured on ONE GPU at the per-GPU share of the batch + an assumed "
+                    "latency-bound all-reduce; a 64-jet step is 25 dependent launches at their one-workgroup latency, so strong scaling of "
+                    "a 512-jet batch is bounded by it (>= 6x at 8 GPUs would need <= 87 us per 64-jet step incl. the all-reduce)"}
+    for n in (2, 4, 8):
+        leg = configs.get(f"b{global_batch // n}") or {}
+        ms = (leg.get("dp_branch") or {}).get("ms_per_step") or leg.get("ms_per_step")
+        if not ms:
+            pred[f"gpus_{n}"] = None
+            continue
+        t = ms + ASSUMED_ALLREDUCE_US * 1e-3
+        pred[f"gpus_{n}"] = {"jets_per_gpu": global_batch // n, "ms_per_step": t, "value": global_batch / (t * 1e-3),
+                             "speedup_vs_one_gpu": global_batch / (t * 1e-3) / one_gpu_rate}
+    return pred
+
+
 def _spawn_ranks(n, argv):
     """``python bench.py --gpus N`` without a launcher: start N fresh rank processes of this script (RANK / LOCAL_RANK /
     WORLD_SIZE / MASTER_ADDR / MASTER_PORT as torch.distributed.run would set them), rank 0 inherits stdout and prints the
@@ -577,6 +647,11 @@ def main():
         raise SystemExit("--batch, --global-batch and --weak are exclusive")
     if os.environ.get("LGN_BENCH_DRY") == "1":
         return _dry_run(args, world, rank)
+    # ONE line on stdout, whatever the libraries underneath print there (RCCL writes a version banner to fd 1 when a communicator is
+    # created): fd 1 points at stderr for the whole run, the JSON line goes to the saved descriptor
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -781,9 +856,12 @@ def main():
                     del t2, e2, d2
                 except RuntimeError as exc:
                     out["configs"][name] = {"value": None, "error": f"{type(exc).__name__}: {exc}"[:300]}
+        if world == 1 and not args.no_extras and args.config == "cfg2" and harness == "native" and per_gpu == cfg["B"]:
+            out["configs"].update(small_batch_legs(dev, cfg, G, NativeTrainStep))
+            out["predicted_strong_scaling"] = predict_strong_scaling(cfg["B"], out["value"], out["configs"])
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=real_stdout, flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

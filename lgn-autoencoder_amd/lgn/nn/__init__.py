@@ -81,6 +81,10 @@ class CGMLP(nn.Module):
         self.act_id = _native.activation_id(activation)      # get_activation_fn's names (lgn/nn/generic_levels.py:119-135)
         ns = 2 * num_channels
         width = layer_width_mul * ns
+        if num_hidden > 0 and not ns <= width <= self.KERNEL_MAX_WIDTH:
+            # (the reference takes any width, lgn/models/lgn_levels.py:124-189; the kernels hold a layer's weight image in LDS)
+            raise NotImplementedError(f"the native CGMLP kernels take hidden widths 2C .. {self.KERNEL_MAX_WIDTH} (mlp_width x 2C); got "
+                                      f"mlp_width={layer_width_mul} x {ns} scalars = {width}")
         self.num_scalars, self.width, self.num_hidden = ns, width, num_hidden
         self.linear = nn.ModuleList()
         self.linear.append(nn.Linear(ns, width))
@@ -88,6 +92,8 @@ class CGMLP(nn.Module):
             self.linear.append(nn.Linear(width, width))
         self.linear.append(nn.Linear(width, ns) if num_hidden > 0 else nn.Linear(ns, ns))
         self.to(device=device, dtype=dtype)
+
+    KERNEL_MAX_WIDTH = 96      # csrc/mlp.hip: mlp_dispatch -- 2C <= H <= 96 (mlp_mfma.hip up to 48, mlp_mfma_wide.hip beyond)
 
     def flat_params(self):
         out = []

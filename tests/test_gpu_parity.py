@@ -452,6 +452,49 @@ def test_cgmlp(dev, O, C, B, N, act):
         U.assert_close(flat[2 * i + 1].grad, P[f"lgn_cg.mlp_levels.0.linear.{i}.bias"].grad, GRAD_TOL, f"g_b{i}")
 
 
+@pytest.mark.parametrize("C,B,N,width,depth", [
+    # mlp_width other than 6 (lgn/models/lgn_levels.py:124-189: hidden width = mlp_width x 2C).  Few rows: the 16-row workgroups
+    (3, 2, 30, 4, 6), (3, 2, 30, 5, 6), (4, 3, 30, 4, 6), (4, 3, 30, 5, 6), (4, 3, 30, 7, 6), (2, 1, 5, 1, 6), (1, 2, 30, 9, 6),
+    (4, 2, 30, 12, 6), (8, 1, 30, 3, 6), (6, 2, 30, 5, 6), (3, 2, 30, 8, 6), (5, 1, 33, 9, 6), (7, 2, 20, 2, 6), (3, 2, 30, 16, 6),
+    # >= 8 192 rows: 64-row workgroups -- H = 24 / 30 / 32 / 40 (C = 3, 4: the widths VERDICT r5 names), H = 48 at C != 4 (the
+    # unrolled-k 12-wave kernel, NOT the chain kernel, which is built for H = 6 x 2C), H = 56 / 60 / 80 / 96 (wide kernels)
+    (3, 275, 30, 4, 6), (3, 275, 30, 5, 6), (4, 275, 30, 4, 6), (4, 275, 30, 5, 6), (4, 280, 30, 7, 6), (3, 275, 30, 8, 6),
+    (6, 275, 30, 4, 6), (2, 280, 30, 12, 6), (6, 275, 30, 5, 6), (8, 275, 30, 5, 6), (4, 275, 30, 12, 6), (1, 300, 30, 7, 6),
+    (2, 275, 30, 6, 6), (1, 275, 30, 6, 6),
+    # ... and together with mlp_depth 3 .. 5
+    (3, 275, 30, 5, 3), (4, 275, 30, 4, 4), (4, 3, 30, 7, 5), (3, 2, 30, 5, 4)])
+def test_cgmlp_widths(dev, O, C, B, N, width, depth):
+    """CGMLP forward + all gradients against the oracle at hidden widths that are NOT 6 x 2C (every BASELINE config and every
+    other test uses mlp_width = 6): tile-padding paths of mlp_mfma.hip / mlp_mfma_wide.hip (H not a multiple of 16 or of 4)."""
+    from lgn import ops, _native as Nn
+    g = torch.Generator().manual_seed(C * 7 + N + width)
+    cfg = O.NetConfig(num_channels=(C, C), mlp_width=width, mlp_depth=depth)
+    P = {}
+    torch.manual_seed(C + width)
+    plans = O.build_level_plans(cfg, {(0, 0): C, (1, 1): C})
+    O._init_levels(P, cfg, plans)
+    P = {k: v.requires_grad_(True) for k, v in P.items() if "mlp" in k}
+    nlin = depth + 1
+    assert tuple(P["lgn_cg.mlp_levels.0.linear.0.weight"].shape) == (width * 2 * C, 2 * C)
+    s = torch.randn(2, B, N, C, 1, dtype=torch.float64, generator=g).requires_grad_(True)
+    node = {(1, 1): torch.zeros(2, B, N, C, 4, dtype=torch.float64), (0, 0): s}
+    out = O.cg_mlp(P, cfg, 0, node)[(0, 0)]
+    cot = torch.randn(out.shape, dtype=torch.float64, generator=g)
+    (out * cot).sum().backward()
+    sd = s.detach().squeeze(-1).to(dev).requires_grad_(True)
+    flat = []
+    for i in range(nlin):
+        flat += [P[f"lgn_cg.mlp_levels.0.linear.{i}.weight"].detach().to(dev).requires_grad_(True),
+                 P[f"lgn_cg.mlp_levels.0.linear.{i}.bias"].detach().to(dev).requires_grad_(True)]
+    y = ops.CGMLPFn.apply(Nn.activation_id("leakyrelu"), sd, *flat)
+    U.assert_close(y.unsqueeze(-1), out, FWD_TOL, "mlp out")
+    (y.unsqueeze(-1) * cot.to(dev)).sum().backward()
+    U.assert_close(sd.grad.unsqueeze(-1), s.grad, GRAD_TOL, "mlp g_in")
+    for i in range(nlin):
+        U.assert_close(flat[2 * i].grad, P[f"lgn_cg.mlp_levels.0.linear.{i}.weight"].grad, GRAD_TOL, f"g_w{i}")
+        U.assert_close(flat[2 * i + 1].grad, P[f"lgn_cg.mlp_levels.0.linear.{i}.bias"].grad, GRAD_TOL, f"g_b{i}")
+
+
 @pytest.mark.parametrize("tag,maxdim", [("cg2_2", 2), ("cg3_5", 3), ("cg3_2", 3)])
 def test_cg_product_vs_reference_golden(dev, O, tag, maxdim):
     """lgn.cg_lib.cg_product / CGProduct (lgn_cg_product_fwd/bwd_f64, csrc/cg_product.hip) against the reference's own vectors (g4:

@@ -204,6 +204,34 @@ def test_native_step_batch_regimes(B, monkeypatch):
         U.assert_close(a.flat.grad, c.flat.grad, 1e-10, "flat gradient, chain vs 12-wave CGMLP kernels")
 
 
+@pytest.mark.parametrize("width,maxdim,B", [(4, 2, 280), (5, 2, 280), (7, 2, 280), (5, 2, 64), (4, 3, 280), (5, 3, 140)])
+def test_native_step_mlp_widths(width, maxdim, B):
+    """mlp_width other than 6 through the whole-step call at batch sizes that take the 64-row CGMLP workgroups (>= 8 192 rows; the
+    g14 fixtures have 36 rows): the graph-replayed native step against the module / autograd path on the same weights, whose
+    operators are held to the oracle one by one (test_cgmlp_widths, the level tests)."""
+    import __graft_entry__ as G
+    from lgn.step import NativeTrainStep, TrainStep
+    from oracle import lgn_oracle as O
+    dev = torch.device("cuda:0")
+    N = 30
+    che, chd = ((3, 3, 4, 4), (4, 4, 3, 3)) if maxdim == 2 else ((3, 4, 4), (4, 4, 3))
+    enc, dec = G._models(N, che, chd, dev, seed=5, maxdim=maxdim, mlp_width=width)
+    enc2, dec2 = G._models(N, che, chd, dev, seed=5, maxdim=maxdim, mlp_width=width)
+    for m in (enc2, dec2):
+        m.use_fused = False                   # one native call per operator
+    p4, labels = O.synthetic_jets(B, N, seed=B + width, pad=True)
+    batch = {"p4": p4.to(dev), "labels": labels.to(dev)}
+    a = NativeTrainStep(enc, dec, batch_size=B, optimizer=False, use_graph=True)
+    b = TrainStep(enc2, dec2, optimizer=False)
+    la, ra = a.step(batch)
+    la, ra = a.step(batch)                  # (the replay)
+    lb, rb = b.forward_backward(batch)
+    U.assert_close(la, lb, 1e-12, "loss")
+    U.assert_close(ra, rb, 1e-12, "recon")
+    U.assert_close(a.flat.grad, b.flat.grad, 1e-9, "flat gradient")
+    assert torch.isfinite(a.flat.grad).all()
+
+
 @pytest.mark.parametrize("B,N,use_graph", [(512, 30, True), (64, 30, True), (7, 30, False), (5, 70, True), (3, 150, False)])
 def test_native_step_fused_tail_is_bit_identical_to_the_three_launches(B, N, use_graph, monkeypatch):
     """lgn_step_train_f64 (csrc/step_tail.hip: deferred reductions + radial finalisation + L1 + Adam + loss assembly in ONE launch)

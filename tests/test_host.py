@@ -239,6 +239,10 @@ def test_native_step_refuses_configurations_it_does_not_implement():
     assert all(float(t[..., 10:].abs().max()) == 0 for t in (kp[0], kp[1], kp[2], kp[3], kp[5]))
     kp[3].sum().backward()                                              # the padding is differentiable: gradients reach the 10 real columns
     assert tuple(r5.linear[0].weight.grad.shape) == (6, 10)
+    from lgn.nn import CGMLP
+    with pytest.raises(NotImplementedError, match="mlp_width"):         # hidden width 7 x 16 = 112 > 96: refused at construction
+        CGMLP(8, num_hidden=6, layer_width_mul=7)
+    assert CGMLP(8, num_hidden=6, layer_width_mul=6).width == 96 and CGMLP(3, num_hidden=6, layer_width_mul=5).width == 30
     enc.mlp_depth = 2                                                   # the native CGMLP kernels are built for mlp_depth 3 .. 6
     enc.__dict__.pop("_native_kind", None)
     with pytest.raises(NotImplementedError, match="mlp_depth"):
