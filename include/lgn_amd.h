@@ -264,6 +264,9 @@ typedef struct lgn_net_desc {
 #define LGN_NET_MOMENTS_V1 16    /* LGN_AMD_MOMENTS_V1=1: component-chunked moments kernels (with LGN_NET_NO_STATIC) */
 #define LGN_NET_BWD_ORDERED 64   /* LGN_AMD_BWD_ORDERED=1: the encoder level backward runs its radial-gradient GEMM per ordered pair tile
                                     (the form before round 4's symmetric sweep; cross-check) */
+#define LGN_NET_DEC_UNFUSED 256  /* LGN_AMD_DEC_UNFUSED=1: table-driven decoder levels as moments tensor + per-node kernels (the round-5
+                                    sequence) instead of the fused separable form of csrc/generic_local_sep.hip; cross-check.  Changes
+                                    the activation / scratch layouts: fixed in the descriptor like the others */
 #define LGN_NET_SPLIT_TAIL 128   /* LGN_AMD_SPLIT_TAIL=1: the tail of a step (deferred reductions, radial finalisation, L1 + Adam) as the
                                     three separate launches instead of csrc/step_tail.hip's one (cross-check; bit-identical) */
 

@@ -80,6 +80,55 @@ __global__ __launch_bounds__(512) void dec_sep_fwd_tb_kernel(GenArgs a) {
   }
 }
 
+// Round 6: the jet-level sums as a TABLE instead of the moments tensor -- what local_fwd_sep / local_bwd_sep (generic_local_sep.hip)
+// form U from.  Entry (jet b, channel c, component q) = SEP_TBL_STRIDE doubles (layout: local_static_dev.hpp), plus the centred
+// canonical momenta of every node, pc [B N][8].  Same sums, same butterfly as dec_sep_fwd_tb_kernel; 5 MB written instead of 147.
+template <int Q>
+__global__ __launch_bounds__(512) void dec_sep_tab_kernel(GenArgs a, double* __restrict__ tbl, double* __restrict__ pc) {
+  __shared__ double sraw[8 * Q * 12];                          // [c][q]: SX | SXP[0..3] | pad
+  const int b = blockIdx.x, c = threadIdx.x >> 6, lane = threadIdx.x & 63, C = a.C;
+  const Jet J = load_jet(a, b, lane);
+  if (c == 0 && J.ok) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      pc[(size_t)J.n * 8 + 2 * m] = J.P[m].r;
+      pc[(size_t)J.n * 8 + 2 * m + 1] = J.P[m].i;
+    }
+  }
+  const double* __restrict__ xc = a.X + ((size_t)(J.n >> 6) * C + c) * Q * 128 + (J.n & 63);
+#pragma unroll 2
+  for (int q = 0; q < Q; ++q) {
+    const cx<double> x = J.ok ? cx<double>{xc[q * 128], xc[q * 128 + 64]} : cx<double>{0, 0};
+    double v[12];
+    v[0] = x.r; v[1] = x.i;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const cx<double> xp = cmul(x, J.P[m]);
+      v[2 + 2 * m] = xp.r; v[3 + 2 * m] = xp.i;
+    }
+    v[10] = 0.0; v[11] = 0.0;
+    wave_sum_store<12>(v, sraw + (c * Q + q) * 12, lane);
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < C * Q; e += blockDim.x) {
+    const int cc = e / Q;
+    const double* s = sraw + e * 12;
+    const double b0 = a.b0[cc], b1 = a.b1[cc];
+    const cx<double> e0 = {0.0, 2.0 * b0}, R1 = {b1, b1}, SX = {s[0], s[1]};
+    double* __restrict__ t = tbl + ((size_t)b * C * Q + e) * SEP_TBL_STRIDE;
+    const cx<double> E = cmul(e0, SX), A = cmul(R1, SX);
+    t[0] = E.r; t[1] = E.i; t[2] = A.r; t[3] = A.i;
+    t[12] = SX.r; t[13] = SX.i;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const cx<double> sxp = {s[2 + 2 * m], s[3 + 2 * m]}, Bm = cmul(R1, sxp);
+      t[4 + 2 * m] = Bm.r; t[5 + 2 * m] = Bm.i;
+      t[14 + 2 * m] = sxp.r; t[15 + 2 * m] = sxp.i;
+    }
+    t[22] = 0.0; t[23] = 0.0;
+  }
+}
+
 template <int Q>
 __global__ __launch_bounds__(512) void dec_sep_bwd_tb_kernel(GenArgs a) {
   const int b = blockIdx.x, c = threadIdx.x >> 6, lane = threadIdx.x & 63, C = a.C, N = a.N;
@@ -171,6 +220,16 @@ __global__ __launch_bounds__(512) void dec_sep_bwd_tb_kernel(GenArgs a) {
 }
 
 }  // namespace
+
+// jet table + centred momenta of a decoder level in the tile-blocked layout (tbl: B C Q SEP_TBL_STRIDE doubles, pc: B N 8)
+int dec_sep_tab(const GenArgs& a, double* tbl, double* pc, hipStream_t st) {
+  LGN_CHECK_ARG(a.tb && a.N <= 64 && a.C <= 8 && (a.Q == 5 || a.Q == 20) && tbl && pc, "dec_sep_tab: unsupported shape (N=%d C=%d Q=%d)", a.N, a.C, a.Q);
+  const dim3 grid(a.B), block(64 * a.C);
+  if (a.Q == 5) hipLaunchKernelGGL(dec_sep_tab_kernel<5>, grid, block, 0, st, a, tbl, pc);
+  else hipLaunchKernelGGL(dec_sep_tab_kernel<20>, grid, block, 0, st, a, tbl, pc);
+  LGN_CHECK_LAUNCH();
+  return 0;
+}
 
 // which: 0 forward, 1 backward.  Returns -2 when the shape is outside these kernels (the caller falls back to generic_moments2.hip).
 int moments_dec_sep_tb_dispatch(const GenArgs& a, int which, hipStream_t st) {

@@ -198,6 +198,16 @@ int local_fwd_static(int kind, int M, int C, int CO, const double* XT, const dou
                      double* outT, double* s_copy, int q_s, hipStream_t st, bool packed = false);
 // packed = true: wp already holds the level's packed weight image.  Batched (un)packing, one launch for up to 8 levels:
 // pack: dst = packed image of the CatMix weights src;  unpack: dst (CatMix parameter layout) += unpacked packed gradients src
+// decoder levels with the separable moments kept on chip (generic_local_sep.hip, generic_moments_sep.hip: dec_sep_tab; round 6)
+constexpr int SEP_TBL_STRIDE = 24;        // doubles per (jet, channel, component) of the jet table
+int dec_sep_tab(const GenArgs& a, double* tbl, double* pc, hipStream_t st);
+int local_sep_part_rows(int B);
+int local_fwd_sep(int kind, int B, int N, int C, int CO, const double* XT, const double* tbl, const double* pc, const double* wp,
+                  double* outT, double* s_copy, int q_s, hipStream_t st);
+int local_bwd_sep(int kind, int B, int N, int C, int CO, const double* XT, const double* tbl, const double* pc, const double* b0,
+                  const double* b1, const double* wp, const double* goT, double* gXT, double* part, double* gpb, double* part_rad,
+                  hipStream_t st);
+int local_sep_gp_reduce(const double* const* gpb, const int* C, int n, int M, double* g_p, hipStream_t st);
 struct StaticPackJob { int kind, C, CO; int w0[5]; const double* src; double* dst; };
 int local_static_pack_batch(const StaticPackJob* jobs, int n, bool unpack, hipStream_t st);
 // packed X [2][nodes][C][Q] <-> s [2][nodes][C] (component q_s) + v [2][nodes][C][4] (components q_v..q_v+3); pack zero-fills the rest

@@ -402,6 +402,11 @@ inline bool is_static(const lgn_net_desc& d, bool dec) {
     if (!g.tab[l] || g.tab[l]->static_kind == 0) return false;
   return !(d.flags & LGN_NET_NO_STATIC);                // run-time-table kernels (cross-check): fixed at descriptor creation
 }
+// decoder levels on the static kernels keep their separable moments on chip (generic_local_sep.hip, round 6): no U / dU tensors,
+// one launch per level backward.  LGN_NET_DEC_UNFUSED: the round-5 sequence (dec_sep_fwd/bwd_tb + local_fwd/bwd_static), cross-check
+inline bool is_sep_fused(const lgn_net_desc& d, bool dec) {
+  return dec && is_static(d, dec) && !(d.flags & (LGN_NET_DEC_PAIRWISE | LGN_NET_DEC_UNFUSED));
+}
 inline size_t tb_doubles(const lgn_net_desc& d, int C, int Qx) { return (size_t)(((size_t)d.B * d.N + 63) / 64) * C * Qx * 128; }
 
 int check_generic(const lgn_net_desc& d, bool dec) {
@@ -421,6 +426,8 @@ struct GenAct {                     // written by the forward, read by the backw
   double *s0, *v0;                  // input-kernel outputs [2][BN][C0], [2][BN][C0][4]
   double *X[5], *U[4], *smix[4];
   double* wp[4];                    // static path: packed CatMix weights of each level (written by the forward, reused by the backward)
+  double* tbl[4];                   // fused decoder levels: jet table of each level (dec_sep_tab), instead of U
+  double* pc;                       // ... and the nodes' centred momenta [B N][8]
   double *sL, *vL;                  // (0,0) / (1,1) of the last level, unpacked for the end kernels
   double* pdec;
   int* idx;
@@ -435,9 +442,12 @@ GenAct carve_gen_act(const lgn_net_desc& d, bool dec, double* base) {
   a.s0 = b.take(2 * BN * g.ch[0]);
   a.v0 = b.take(8 * BN * g.ch[0]);
   const bool tb = is_static(d, dec);                  // whole tiles of 64 nodes
+  const bool sep = is_sep_fused(d, dec);
   for (int l = 0; l <= L; ++l) a.X[l] = b.take(tb ? tb_doubles(d, g.ch[l], g.Q[l]) : 2 * BN * g.ch[l] * g.Q[l]);
+  a.pc = sep ? b.take(8 * BN) : nullptr;
   for (int l = 0; l < L; ++l) {
-    a.U[l] = b.take(tb ? tb_doubles(d, g.ch[l], 5 * g.Q[l]) : 10 * BN * g.ch[l] * g.Q[l]);
+    a.U[l] = sep ? nullptr : b.take(tb ? tb_doubles(d, g.ch[l], 5 * g.Q[l]) : 10 * BN * g.ch[l] * g.Q[l]);
+    a.tbl[l] = sep ? b.take((size_t)d.B * g.ch[l] * g.Q[l] * SEP_TBL_STRIDE) : nullptr;
     a.smix[l] = b.take(2 * BN * g.ch[l + 1]);
     a.wp[l] = tb ? b.take(local_static_packed_doubles(g.tab[l]->static_kind, g.ch[l], g.ch[l + 1])) : nullptr;
   }
@@ -456,6 +466,7 @@ struct GenScratch {
   double *gX[2], *gU;
   double* gbuf;                     // encoder: pair-gradient scratch of the channel-outermost radial backward (generic_moments2.hip)
   double* gpk[4];                   // static path: reduced packed CatMix weight gradients per level
+  double* gpb[4];                   // fused decoder levels: per-channel d p of each level [C_l][B N][8]
   double* tot[4];
   double* parts;
   size_t parts_size, total;
@@ -480,18 +491,20 @@ GenScratch carve_gen_scratch(const lgn_net_desc& d, bool dec, double* base) {
   }
   s.gs = b.take(2 * BN * cmax);
   s.gv = b.take(8 * BN * cmax);
-  const bool tb = is_static(d, dec);
+  const bool tb = is_static(d, dec), sep = is_sep_fused(d, dec);
   const size_t tiles = (BN + 63) / 64;
   s.gX[0] = b.take(tb ? tiles * cq * 128 : 2 * BN * cq);
   s.gX[1] = b.take(tb ? tiles * cq * 128 : 2 * BN * cq);
-  s.gU = b.take(tb ? tiles * cq * 640 : 10 * BN * cq);
-  for (int l = 0; l < L; ++l)
+  s.gU = sep ? nullptr : b.take(tb ? tiles * cq * 640 : 10 * BN * cq);
+  for (int l = 0; l < L; ++l) {
     s.gpk[l] = tb ? b.take(local_static_packed_doubles(g.tab[l]->static_kind, g.ch[l], g.ch[l + 1])) : nullptr;
+    s.gpb[l] = sep ? b.take((size_t)g.ch[l] * BN * 8) : nullptr;
+  }
   s.gbuf = (!dec && d.N <= 32) ? b.take(moments2_gbuf_doubles(d.B, d.N, (int)cmax)) : nullptr;
   size_t psum = 0;
   for (int l = 0; l < L; ++l) {
     const size_t nrad = rad_partial_size(g.ch[l], dec);
-    const size_t lrows = tb ? tiles * local_static_packed_doubles(g.tab[l]->static_kind, g.ch[l], g.ch[l + 1])
+    const size_t lrows = tb ? (sep ? (size_t)local_sep_part_rows(d.B) : tiles) * local_static_packed_doubles(g.tab[l]->static_kind, g.ch[l], g.ch[l + 1])
                             : (size_t)local_partial_rows((int)BN) * 2 * g.tab[l]->n_w;
     psum += ((lrows + 15) & ~size_t(15)) + (((size_t)d.B * nrad + 15) & ~size_t(15));
     psum += ((size_t)mlp_partial_rows((int)BN, d.mlp_hidden_mul * 2 * g.ch[l + 1]) * mlp_psize(g.ch[l + 1], d.mlp_hidden_mul * 2 * g.ch[l + 1], d.mlp_nlin) + 15) & ~size_t(15);
@@ -533,17 +546,23 @@ int gen_levels_fwd(const lgn_net_desc& d, bool dec, const double* P, const int64
     }
     LGN_TRY(local_static_pack_batch(jobs, d.n_levels, false, st));
   }
+  const bool sep = is_sep_fused(d, dec);
   for (int l = 0; l < d.n_levels; ++l) {
     GenArgs m = gen_level_args(d, dec, l, P, off, a.X[l], pos, mask);
     m.U = a.U[l];
     m.tb = tb;
-    LGN_TRY(moments_dispatch(m, dec, 0, st));
-    if (tb) {
+    if (sep) {      // jet table instead of the moments tensor; the per-node kernel forms U where a term reads it
+      LGN_TRY(dec_sep_tab(m, a.tbl[l], a.pc, st));
+      LGN_TRY(local_fwd_sep(g.tab[l]->static_kind, d.B, d.N, g.ch[l], g.ch[l + 1], a.X[l], a.tbl[l], a.pc, a.wp[l], a.X[l + 1], a.smix[l],
+                            g.qs[l + 1], st));
+    } else if (tb) {
+      LGN_TRY(moments_dispatch(m, dec, 0, st));
       int w0[8];
       for (int k = 0; k < 5; ++k) w0[k] = g.tab[l]->h_out_w0[k];
       LGN_TRY(local_fwd_static(g.tab[l]->static_kind, BN, g.ch[l], g.ch[l + 1], a.X[l], a.U[l], P + off[S.mix(dec, l, 0)], w0, a.wp[l],
                                a.X[l + 1], a.smix[l], g.qs[l + 1], st, /*packed=*/true));
     } else {
+      LGN_TRY(moments_dispatch(m, dec, 0, st));
       LocalArgs la{};
       LGN_TRY(local_args(la, BN, g.ch[l], g.ch[l + 1], g.Q[l], g.Q[l + 1], g.tab[l]));
       la.X = a.X[l]; la.U = a.U[l]; la.wcat = P + off[S.mix(dec, l, 0)]; la.out = a.X[l + 1];
@@ -591,6 +610,23 @@ int gen_levels_bwd(const lgn_net_desc& d, bool dec, const double* P, double* G, 
       dq.add(m.part, mlp_partial_rows(BN, m.H), m.psize, 0, m.psize, G + off[S.mlp(dec, l, 0)]);
     }
     const int nxt = cur ^ 1;
+    if (is_sep_fused(d, dec)) {      // per-node part + separable moments of the level in ONE launch; d p per channel, reduced after the stack
+      int w0[8];
+      for (int k = 0; k < 5; ++k) w0[k] = g.tab[l]->h_out_w0[k];
+      const int kind = g.tab[l]->static_kind, np = (int)local_static_packed_doubles(kind, C, CO), rows = local_sep_part_rows(d.B);
+      const int nrad = rad_partial_size(C, true);
+      DQ_NEW(part, (size_t)rows * np);
+      DQ_NEW(part_rad, (size_t)d.B * nrad);
+      LGN_TRY(local_bwd_sep(kind, d.B, d.N, C, CO, a.X[l], a.tbl[l], a.pc, P + off[S.rad(dec, l, 4)], P + off[S.rad(dec, l, 6)], a.wp[l],
+                            sc.gX[cur], sc.gX[nxt], part, sc.gpb[l], part_rad, st));
+      dq.add(part, rows, np, 0, np, sc.gpk[l]);
+      post.push_back(UnpackJob{kind, C, CO, {w0[0], w0[1], w0[2], w0[3], w0[4]}, sc.gpk[l], G + off[S.mix(dec, l, 0)]});
+      dq.add(part_rad, d.B, nrad, 0, C, G + off[S.rad(dec, l, 4)]);
+      dq.add(part_rad, d.B, nrad, C, C, G + off[S.rad(dec, l, 6)]);
+      cur = nxt;
+      has_s_grad = true;
+      continue;
+    }
     if (tb) {       // compile-time-table kernel; its packed partial rows are reduced with everything else, then unpacked (post)
       int w0[8];
       for (int k = 0; k < 5; ++k) w0[k] = g.tab[l]->h_out_w0[k];
@@ -717,6 +753,12 @@ int gen_decoder_bwd(const lgn_net_desc& d, const double* P, double* G, const int
   int cur = 0;
   LGN_TRY(net_pack(d, true, L, sc.zero0, sc.gv, sc.gX[cur], st));
   LGN_TRY(gen_levels_bwd(d, true, P, G, off, a, a.pdec, nullptr, sc, dq, fin, post, cur, /*has_s_grad=*/false, st));
+  if (is_sep_fused(d, true)) {     // d p of the levels: per-channel parts -> sc.g_p (zero on entry), in level and channel order
+    const double* gpb[4];
+    int cl[4];
+    for (int l = 0; l < L; ++l) { gpb[l] = sc.gpb[L - 1 - l]; cl[l] = g.ch[L - 1 - l]; }      // (the order the levels ran in)
+    LGN_TRY(local_sep_gp_reduce(gpb, cl, L, B * N, sc.g_p, st));
+  }
   const int C0 = g.ch[0], row = 4 * C0 + 2 * N * Tin;
   LGN_TRY(net_unpack(d, true, 0, sc.gX[cur], sc.gs, sc.gv, st));
   DQ_NEW(part, (size_t)B * row);
