@@ -23,6 +23,13 @@
 namespace lgn {
 namespace {
 using namespace lsd;
+LGN_STAMP_DECL
+#ifdef LGN_STAMPS
+// (first workgroup of the Q = 20 levels: the heavy ones; wave 0 stamps 0.., wave 1 stamps 16..)
+#define PSTAMP(i) do { if (T::Q == 20 && (threadIdx.x & 63) == 0 && blockIdx.x == 0 && blockIdx.y == 0) g_stamps[i] = clock64(); } while (0)
+#else
+#define PSTAMP(i) do { } while (0)
+#endif
 
 // sums of 8 per-lane values over each 32-lane half of the wave (wave_sum.hpp's butterfly without its cross-half stage): the total of
 // value half_sum8_k(lane) comes back in every lane of a quad
@@ -242,58 +249,71 @@ __device__ __forceinline__ void irrep_bwd_sep(const StaticBwdArgs& a, int c, con
   }
 }
 
-// ---- after the walk: the jet sums of component QI from the parked block totals (compile-time gather) -----------------------------
-template <class T, int QI, int P>
-__device__ __forceinline__ void sep_gather_rec(const double* sr, cx<double> (&S)[5], cx<double> (&SP)[4]) {
-  constexpr int NENT = T::BLK_UPTR[sep_nblocks<T>()];
-  if constexpr (P < NENT) {
-    constexpr int e = T::BLK_UELEM[P];
-    if constexpr (e / 5 == QI) {
-      constexpr int at = sep_at<T>(P), k = e % 5;
-      S[k].r += sr[at];
-      S[k].i += sr[at + 1];
-      if constexpr (k != 0) {
-        SP[k - 1].r += sr[at + 2];
-        SP[k - 1].i += sr[at + 3];
-      }
-    }
-    sep_gather_rec<T, QI, P + 1>(sr, S, SP);
+// ---- after the walk: the parked block totals are added up into the jet sums, cmp [half][q][18] = S_0..4 (re, im) | SP_0..3 (re, im).
+// Which parked slots feed which sum is a compile-time table (CSR: sums in walk order, i.e. a fixed summation order); the threads of
+// the workgroup share the 36 Q sums of the two jets.
+template <class T>
+struct SepMap {
+  static constexpr int NOUT = T::Q * 18, NENT = T::BLK_UPTR[sep_nblocks<T>()], ZERO = sep_vtotal<T>();      // ZERO: a slot that holds 0.0
+  struct Tab { short src[NOUT][4]; };       // the parked slots of a sum, in walk order, padded with ZERO (no element feeds more than 4 blocks)
+  static constexpr int out_of(int e, int part, int comp) {         // part 0: S_k, part 1: SP_m
+    return (e / 5) * 18 + (part ? 10 + 2 * (e % 5 - 1) : 2 * (e % 5)) + comp;
   }
-}
-template <class T, int QI>
-__device__ __forceinline__ void sep_gather(const double* sr, cx<double> (&S)[5], cx<double> (&SP)[4]) {
-#pragma unroll
-  for (int k = 0; k < 5; ++k) S[k] = {0, 0};
-#pragma unroll
-  for (int m = 0; m < 4; ++m) SP[m] = {0, 0};
-  sep_gather_rec<T, QI, 0>(sr, S, SP);
-}
+  static constexpr Tab make() {
+    Tab t{};
+    int fill[NOUT] = {};
+    for (int o = 0; o < NOUT; ++o)
+      for (int i = 0; i < 4; ++i) t.src[o][i] = (short)ZERO;
+    for (int p = 0; p < NENT; ++p) {
+      const int e = T::BLK_UELEM[p];
+      for (int part = 0; part < (e % 5 ? 2 : 1); ++part)
+        for (int comp = 0; comp < 2; ++comp) {
+          const int o = out_of(e, part, comp);
+          t.src[o][fill[o] < 4 ? fill[o] : 3] = (short)(sep_at<T>(p) + 2 * part + comp);
+          ++fill[o];
+        }
+    }
+    return t;
+  }
+  static constexpr bool fits() {
+    int cnt[NOUT] = {};
+    for (int p = 0; p < NENT; ++p) {
+      const int e = T::BLK_UELEM[p];
+      ++cnt[out_of(e, 0, 0)];
+    }
+    for (int o = 0; o < NOUT; ++o)
+      if (cnt[o] > 4) return false;
+    return true;
+  }
+  static constexpr Tab tab = make();
+};
 
 struct SepTail {
   cx<double> e0, R1;
   cx<double> gp2[4], A0, A1;
 };
-// component QI .. QEND - 1 of the lane's node: aggregate part of d X (written with the two waves' own parts), second part of d p,
-// bias-gradient terms
-template <class T, int QI, int QEND>
-__device__ __forceinline__ void sep_tail(const double* sr, const SepLane& sl, const double* xl, const double* gx0, const double* gx1,
-                                         double* __restrict__ gxo, bool valid, SepTail& t) {
-  if constexpr (QI < QEND) {
+// components q0 .. q1 - 1 of the lane's node: aggregate part of d X (written with the two waves' own parts), second part of d p,
+// bias-gradient terms.  cm: the compact sums of the lane's jet
+__device__ __forceinline__ void sep_tail(int q0, int q1, const double* cm, const double* raw, const cx<double> (&P)[4], const double* xl,
+                                         const double* gx0, const double* gx1, double* __restrict__ gxo, bool valid, SepTail& t) {
+  for (int q = q0; q < q1; ++q) {
+    const double* c18 = cm + q * 18;
     cx<double> S[5], SP[4];
-    sep_gather<T, QI>(sr, S, SP);
-    const sep_d2* tr = reinterpret_cast<const sep_d2*>(sl.tbc + QI * TBL_STRIDE);
-    const sep_d2 sx2 = tr[6];
-    const cx<double> SX = {sx2.x, sx2.y}, x = {xl[QI * 128], xl[QI * 128 + 1]};
+#pragma unroll
+    for (int k = 0; k < 5; ++k) S[k] = lds_cx(c18 + 2 * k);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) SP[m] = lds_cx(c18 + 10 + 2 * m);
+    const double* r10 = raw + q * 10;          // the jet's SX | SXP_0..3 (LDS)
+    const cx<double> SX = lds_cx(r10), x = {xl[q * 128], xl[q * 128 + 1]};
     cx<double> u = {0, 0};
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-      const cx<double> ps = cmulc(S[1 + m], sl.P[m]);
+      const cx<double> ps = cmulc(S[1 + m], P[m]);
       u.r += SP[m].r - ps.r;
       u.i += SP[m].i - ps.i;
       cfmac(t.gp2[m], S[1 + m], x);
       cfmac(t.A1, SP[m], SX);
-      const sep_d2 q2 = tr[7 + m];
-      const cx<double> u2 = cmulc(S[1 + m], cx<double>{q2.x, q2.y});
+      const cx<double> u2 = cmulc(S[1 + m], lds_cx(r10 + 2 + 2 * m));
       t.A1.r -= u2.r;
       t.A1.i -= u2.i;
     }
@@ -301,30 +321,33 @@ __device__ __forceinline__ void sep_tail(const double* sr, const SepLane& sl, co
     cx<double> gx = cmulc(S[0], t.e0);
     cfmac(gx, u, t.R1);
     if (valid) {
-      gxo[QI * 128] = (gx0[QI * 128] + gx1[QI * 128]) + gx.r;
-      gxo[QI * 128 + 64] = (gx0[QI * 128 + 1] + gx1[QI * 128 + 1]) + gx.i;
+      gxo[q * 128] = (gx0[q * 128] + gx1[q * 128]) + gx.r;
+      gxo[q * 128 + 64] = (gx0[q * 128 + 1] + gx1[q * 128 + 1]) + gx.i;
     }
-    sep_tail<T, QI + 1, QEND>(sr, sl, xl, gx0, gx1, gxo, valid, t);
   }
 }
 
 // Workgroup = (jets 2 t and 2 t + 1, input channel c), two waves that split the blocks as in local_bwd_static_kernel (wave 0 alone
 // touches the moments).  LDS (76.4 KB at Q = 20: two workgroups per CU): the channel's features xs [Q][64][2], the two waves' d X
 // images, the table rows of the two jets, the lanes' momenta and d p, and the parked sums (whose space the tail's exchange reuses).
-template <class T> constexpr int sep_un_doubles() { return 2 * sep_vtotal<T>() > 64 * 8 + 16 ? 2 * sep_vtotal<T>() : 64 * 8 + 16; }
+template <class T> constexpr int sep_un_doubles() { return 2 * (sep_vtotal<T>() + 2) > 64 * 8 + 16 ? 2 * (sep_vtotal<T>() + 2) : 64 * 8 + 16; }
 template <class T> constexpr size_t sep_lds_bytes() { return sizeof(double) * (size_t)(3 * T::Q * 128 + 2 * T::Q * 12 + 2 * 64 * 8 + sep_un_doubles<T>()); }
 
+// Wave assignment (balanced on in-kernel stamps of the 6 -> 4 level of cfg5, tools/sep_stamps.py: walk 100 k / 96 k cycles, sums +
+// tail 15 k):  wave 0: the moment / feature blocks of every irrep, all of irrep 4, irrep 1 but its last block, the first product block
+// of irrep 3;  wave 1: the product blocks of irreps 0, 2, 3 (but the first) and the last block of irrep 1.
 template <class T, int COT>
 __global__ __launch_bounds__(128) void local_bwd_sep_kernel(StaticBwdArgs a) {
-  static_assert(T::N_OUT == 5 && T::NUBLK[1] < T::NBLK[1], "wave assignment");
-  constexpr int Q = T::Q, QO = T::QOUT, VT = sep_vtotal<T>();
+  static_assert(T::N_OUT == 5 && T::NUBLK[1] < T::NBLK[1] && T::NUBLK[3] < T::NBLK[3], "wave assignment");
+  constexpr int Q = T::Q, QO = T::QOUT, VT = sep_vtotal<T>() + 2;      // (+ the slot that holds 0.0: SepMap::ZERO)
+  static_assert(SepMap<T>::fits(), "a jet sum with more than 4 parked slots");
   extern __shared__ double lds[];
   double* xs = lds;                       // [Q][64][2]
   double* gxs = xs + Q * 128;             // [2 waves][Q][64][2]
   double* tab = gxs + 2 * Q * 128;        // [2 halves][Q][12]: E | A | B_0..3
   double* pl = tab + 2 * Q * 12;          // [64 lanes][8]
   double* gpl = pl + 64 * 8;              // [64 lanes][8]
-  double* sraw = gpl + 64 * 8;            // [2 halves][VT]; after the walk: wave 1's tail sums [64][8] + [2 halves][4]
+  double* sraw = gpl + 64 * 8;            // [2 halves][VT]; after the walk: the jet sums, then wave 1's tail sums [64][8] + [2 halves][4]
   const int c = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, C = a.C, CO = a.CO, N = a.N;
   const int half = lane >> 5, j = lane & 31, jet = 2 * blockIdx.x + half;
   const bool valid = jet < a.B && j < N;
@@ -352,6 +375,7 @@ __global__ __launch_bounds__(128) void local_bwd_sep_kernel(StaticBwdArgs a) {
         gpl[lane * 8 + r] = 0.0;
       }
     }
+    if (threadIdx.x < 2) sraw[threadIdx.x * VT + SepMap<T>::ZERO] = 0.0;
   }
   SepWalk w{tab + half * Q * 12, pl + lane * 8, gpl + lane * 8, sraw + half * VT + half_sum8_k(lane), (lane & 3) == 0};
   __syncthreads();
@@ -361,36 +385,80 @@ __global__ __launch_bounds__(128) void local_bwd_sep_kernel(StaticBwdArgs a) {
     const double* __restrict__ got = a.goT + tile * CO * QO * 128 + l64;
     double* __restrict__ part0 = a.part + (size_t)blockIdx.x * a.n_packed;
     if (wave == 0) {
-      irrep_bwd_sep<T, 0, 0, T::NBLK[0], COT>(a, c, got, part0, w, xl, gxl, lane, valid);
+      PSTAMP(0);
+      irrep_bwd_sep<T, 0, 0, T::NUBLK[0], COT>(a, c, got, part0, w, xl, gxl, lane, valid);
+      PSTAMP(1);
       irrep_bwd_sep<T, 1, 0, T::NBLK[1] - 1, COT>(a, c, got, part0, w, xl, gxl, lane, valid);
+      PSTAMP(2);
       irrep_bwd_sep<T, 2, 0, T::NUBLK[2], COT>(a, c, got, part0, w, xl, gxl, lane, valid);
-      irrep_bwd_sep<T, 3, 0, T::NUBLK[3], COT>(a, c, got, part0, w, xl, gxl, lane, valid);
-      irrep_bwd_sep<T, 4, 0, T::NUBLK[4], COT>(a, c, got, part0, w, xl, gxl, lane, valid);
+      PSTAMP(3);
+      irrep_bwd_sep<T, 3, 0, T::NUBLK[3] + 1, COT>(a, c, got, part0, w, xl, gxl, lane, valid);
+      PSTAMP(4);
+      irrep_bwd_sep<T, 4, 0, T::NBLK[4], COT>(a, c, got, part0, w, xl, gxl, lane, valid);
+      PSTAMP(5);
     } else {
+      PSTAMP(16);
       irrep_bwd_sep<T, 2, T::NUBLK[2], T::NBLK[2], COT>(a, c, got, part0, w, xl, gxl, lane, valid);
-      irrep_bwd_sep<T, 3, T::NUBLK[3], T::NBLK[3], COT>(a, c, got, part0, w, xl, gxl, lane, valid);
-      irrep_bwd_sep<T, 4, T::NUBLK[4], T::NBLK[4], COT>(a, c, got, part0, w, xl, gxl, lane, valid);
+      PSTAMP(17);
+      irrep_bwd_sep<T, 3, T::NUBLK[3] + 1, T::NBLK[3], COT>(a, c, got, part0, w, xl, gxl, lane, valid);
+      PSTAMP(18);
+      PSTAMP(19);
       irrep_bwd_sep<T, 1, T::NBLK[1] - 1, T::NBLK[1], COT>(a, c, got, part0, w, xl, gxl, lane, valid);
+      irrep_bwd_sep<T, 0, T::NUBLK[0], T::NBLK[0], COT>(a, c, got, part0, w, xl, gxl, lane, valid);
+      PSTAMP(20);
     }
   }
   __syncthreads();
+  if (wave == 0) PSTAMP(6);
+  // ---- jet sums: parked totals -> cmp [half][Q][18], in place (every thread holds its sums before anybody overwrites a slot); the
+  // jets' raw sums SX | SXP (tail: bias gradients) come in from the table meanwhile and take the place of the walk's table rows ----
+  double* raw = tab;                     // [2 halves][Q][10]
+  {
+    constexpr int NOUT = SepMap<T>::NOUT, PER = (2 * NOUT + 127) / 128, PERR = (2 * Q * 10 + 127) / 128;
+    static_assert(NOUT <= VT, "the compact sums take the place of the parked ones");
+    double rawv[PERR];
+#pragma unroll
+    for (int r = 0; r < PERR; ++r) {
+      const int e = threadIdx.x + 128 * r, ee = e < 2 * Q * 10 ? e : 0, h = ee / (Q * 10), x = ee - h * Q * 10;
+      const int jh = 2 * blockIdx.x + h < a.B ? 2 * blockIdx.x + h : a.B - 1;
+      rawv[r] = a.tbl[(((size_t)jh * C + c) * Q + x / 10) * TBL_STRIDE + 12 + x % 10];
+    }
+    double mine[PER];
+#pragma unroll
+    for (int r = 0; r < PER; ++r) {
+      const int o = threadIdx.x + 128 * r, oc = o < 2 * NOUT ? o : 0, h = oc >= NOUT ? 1 : 0, oo = oc - h * NOUT;
+      const short* sp = SepMap<T>::tab.src[oo];
+      const double* sh = sraw + h * VT;
+      mine[r] = ((sh[sp[0]] + sh[sp[1]]) + sh[sp[2]]) + sh[sp[3]];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < PER; ++r) {
+      const int o = threadIdx.x + 128 * r, h = o >= NOUT ? 1 : 0;
+      if (o < 2 * NOUT) sraw[h * VT + (o - h * NOUT)] = mine[r];
+    }
+#pragma unroll
+    for (int r = 0; r < PERR; ++r)
+      if (threadIdx.x + 128 * r < 2 * Q * 10) raw[threadIdx.x + 128 * r] = rawv[r];
+    __syncthreads();
+  }
+  if (wave == 0) PSTAMP(9);
   // ---- tail: both waves, half of the components each ----
   SepTail t{};
   const double b0 = a.b0[c], b1 = a.b1[c];
   t.e0 = {0.0, 2.0 * b0};
   t.R1 = {b1, b1};
   {
-    SepLane sl{};
-    sl.tbc = a.tbl + ((size_t)(jet < a.B ? jet : a.B - 1) * C + c) * Q * TBL_STRIDE;
+    cx<double> P[4];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) sl.P[m] = lds_cx(pl + lane * 8 + 2 * m);
+    for (int m = 0; m < 4; ++m) P[m] = lds_cx(pl + lane * 8 + 2 * m);
     double* __restrict__ gxo = a.gXT + (tile * C + c) * Q * 128 + l64;
-    const double* sr = sraw + half * VT;
     constexpr int QH = (Q + 1) / 2;
-    if (wave == 0) sep_tail<T, 0, QH>(sr, sl, xl, gxs + 2 * lane, gxs + Q * 128 + 2 * lane, gxo, valid, t);
-    else sep_tail<T, QH, Q>(sr, sl, xl, gxs + 2 * lane, gxs + Q * 128 + 2 * lane, gxo, valid, t);
+    sep_tail(wave == 0 ? 0 : QH, wave == 0 ? QH : Q, sraw + half * VT, raw + half * Q * 10, P, xl, gxs + 2 * lane, gxs + Q * 128 + 2 * lane,
+             gxo, valid, t);
   }
-  __syncthreads();                       // every read of the parked sums is done: their space takes wave 1's share of the tail
+  if (wave == 0) PSTAMP(7); else PSTAMP(21);
+  __syncthreads();                       // every read of the sums is done: their space takes wave 1's share of the tail
   double* xch = sraw;
   if (wave == 1) {
 #pragma unroll
@@ -421,6 +489,7 @@ __global__ __launch_bounds__(128) void local_bwd_sep_kernel(StaticBwdArgs a) {
       pr[c] = 2.0 * (t.A0.i + a1[1]);                                    // dB0[c] = 2 Im A0
       pr[C + c] = (t.A1.r + a1[2]) + (t.A1.i + a1[3]);                   // dB1[c] = Re A1 + Im A1
     }
+    PSTAMP(8);
   }
 }
 
@@ -459,6 +528,7 @@ __global__ __launch_bounds__(BLOCK) void gp_reduce_kernel(GpJob job, int M, doub
 }
 
 }  // namespace
+LGN_STAMP_READER(lgn_debug_stamps_local_sep)
 
 // rows of the packed CatMix partial gradients the separable backward writes (one per pair of jets)
 int local_sep_part_rows(int B) { return (B + 1) / 2; }

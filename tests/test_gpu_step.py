@@ -108,11 +108,12 @@ def test_native_step_maxdim2_alternative_kernels(flags, use_graph, monkeypatch):
             U.assert_close(g, ref, 1e-9, f"grad {pre}.{k}")
 
 
-@pytest.mark.parametrize("flag", ["LGN_AMD_NO_STATIC", "LGN_AMD_DEC_PAIRWISE", "LGN_AMD_MOMENTS_V1"])
+@pytest.mark.parametrize("flag", ["LGN_AMD_NO_STATIC", "LGN_AMD_DEC_PAIRWISE", "LGN_AMD_MOMENTS_V1", "LGN_AMD_DEC_UNFUSED"])
 def test_native_step_maxdim3_alternative_kernels(flag, monkeypatch):
     """The table-driven (maxdim 3) native step through its cross-check kernels: run-time-table local kernels instead of the
     compile-time-table ones (LGN_AMD_NO_STATIC), decoder moments as pair sweeps instead of the separable jet sums
-    (LGN_AMD_DEC_PAIRWISE), component-chunked moments kernels (LGN_AMD_MOMENTS_V1).  Same golden vectors, same tolerances;
+    (LGN_AMD_DEC_PAIRWISE), component-chunked moments kernels (LGN_AMD_MOMENTS_V1), the decoder's moments as a tensor between two
+    kernels per level instead of the fused separable form of round 6 (LGN_AMD_DEC_UNFUSED).  Same golden vectors, same tolerances;
     the switches are read per call, so the step object is built after setting them (the workspace is sized per form)."""
     from lgn.step import NativeTrainStep
     monkeypatch.setenv(flag, "1")
@@ -129,6 +130,37 @@ def test_native_step_maxdim3_alternative_kernels(flag, monkeypatch):
         for k, g in mod.named_grads():
             ref = torch.from_numpy(z[f"grad.{pre}.{k}"]) + lam * torch.sign(sd[k])
             U.assert_close(g, ref, 1e-9, f"grad {pre}.{k}")
+
+
+@pytest.mark.parametrize("B,N,che,chd", [(5, 30, (4, 4, 6, 6), (6, 6, 4, 4)), (64, 30, (4, 4, 6, 6), (6, 6, 4, 4)), (33, 21, (3, 4, 4), (4, 4, 3)),
+                                         (6, 32, (2, 3, 8), (8, 3, 2)), (9, 13, (3, 4, 4), (4, 4, 3)), (3, 7, (2, 5), (5, 2)), (1, 30, (3, 4), (4, 3))])
+def test_native_step_maxdim3_fused_decoder_matches_the_two_kernel_form(B, N, che, chd, monkeypatch):
+    """Decoder levels of the table-driven step with the separable moments kept on chip (csrc/generic_local_sep.hip: jet table instead
+    of the moments tensor, one backward kernel per level on pairs of jets) against the round-5 sequence (LGN_AMD_DEC_UNFUSED=1:
+    dec_sep_fwd/bwd_tb + local_fwd/bwd_static) on the same weights: odd jet counts (the last pair half empty), one jet, jets of
+    7 .. 32 particles (idle lanes in every half wave), 2 .. 8 channels (every compile-time channel bound)."""
+    import __graft_entry__ as G
+    from lgn.step import NativeTrainStep
+    from oracle import lgn_oracle as O
+    dev = torch.device("cuda:0")
+    p4, labels = O.synthetic_jets(B, N, seed=B + N, pad=True)
+    batch = {"p4": p4.to(dev), "labels": labels.to(dev)}
+    runs = []
+    for unfused in (False, True):
+        enc, dec = G._models(N, che, chd, dev, seed=3, maxdim=3)
+        if unfused:
+            monkeypatch.setenv("LGN_AMD_DEC_UNFUSED", "1")
+        st = NativeTrainStep(enc, dec, batch_size=B, optimizer=False, use_graph=True)
+        if unfused:
+            monkeypatch.delenv("LGN_AMD_DEC_UNFUSED")
+        st.step(batch)
+        loss, recon = st.step(batch)          # (the replay)
+        runs.append((loss.clone(), recon.clone(), st.flat.grad.clone()))
+    U.assert_close(runs[0][0], runs[1][0], 1e-13, "loss")
+    U.assert_close(runs[0][1], runs[1][1], 1e-12, "recon")
+    # gradients: every named tensor against its own scale (the two forms add the same terms in a different order)
+    U.assert_close(runs[0][2], runs[1][2], 1e-11, "flat gradient")
+    assert torch.isfinite(runs[0][2]).all()
 
 
 def test_native_adam_matches_torch_adam_and_modular_path():
