@@ -735,33 +735,42 @@ __global__ __launch_bounds__(BLOCK) void moments_rad_reduce2_kernel(GenArgs a, c
     j = r;
     i = uu - r * (r + 1) / 2;
   };
-  auto fetch = [&](int i, int j, bool ok, double (&av)[NG]) {
+  auto fetch = [&](int i, int j, bool ok, double (&av)[2 * NG]) {        // (the two halves are added where they are used: no wait here)
     const double* g1 = Gbuf + ((size_t)b * npairs + (size_t)i * N + j) * C * 4;
     const double* g2 = Gbuf + ((size_t)b * npairs + (size_t)j * N + i) * C * 4;
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       const int rr = lane & 15, quant = rr >> 2, ch = 4 * g + (rr & 3);
       const bool live = ok && ch < C;
-      const double x1 = live ? g1[ch * 4 + quant] : 0.0;
-      const double x2 = (live && i != j) ? g2[ch * 4 + quant] : 0.0;
-      av[g] = x1 + x2;
+      av[2 * g] = live ? g1[ch * 4 + quant] : 0.0;
+      av[2 * g + 1] = (live && i != j) ? g2[ch * 4 + quant] : 0.0;
     }
   };
-  int ci, cj;
-  bool cok;
-  double cav[NG];
-  decode(wave * 4 + kq, ci, cj, cok);
-  fetch(ci, cj, cok, cav);
+  // operands of the next PF steps in flight (one step ahead left the loop a chain of ~30 global round trips per wave: 34 - 46 us for
+  // 60 - 90 MB of pair gradients)
+  constexpr int PF = 3;
+  int ci[PF], cj[PF];
+  bool cok[PF];
+  double cav[PF][2 * NG];
+#pragma unroll
+  for (int d = 0; d < PF; ++d) {
+    decode(wave * 4 + 16 * d + kq, ci[d], cj[d], cok[d]);
+    fetch(ci[d], cj[d], cok[d], cav[d]);
+  }
   for (int u0 = wave * 4; u0 < nuno; u0 += 16) {               // 4 pairs per MFMA step, waves interleaved
-    const int i = ci, j = cj;
-    const bool ok = cok;
+    const int i = ci[0], j = cj[0];
+    const bool ok = cok[0];
     double av[NG];
 #pragma unroll
-    for (int g = 0; g < NG; ++g) av[g] = cav[g];
-    if (u0 + 16 < nuno) {                                      // next step's operands
-      decode(u0 + 16 + kq, ci, cj, cok);
-      fetch(ci, cj, cok, cav);
+    for (int g = 0; g < NG; ++g) av[g] = cav[0][2 * g] + cav[0][2 * g + 1];
+#pragma unroll
+    for (int d = 0; d + 1 < PF; ++d) {
+      ci[d] = ci[d + 1]; cj[d] = cj[d + 1]; cok[d] = cok[d + 1];
+#pragma unroll
+      for (int g = 0; g < 2 * NG; ++g) cav[d][g] = cav[d + 1][g];
     }
+    decode(u0 + 16 * PF + kq, ci[PF - 1], cj[PF - 1], cok[PF - 1]);      // (beyond the last pair: ok = false, the loads are of pair 0)
+    fetch(ci[PF - 1], cj[PF - 1], cok[PF - 1], cav[PF - 1]);
     const double* pi = pj + i * 4;
     const double* pq = pj + j * 4;
     const double d0 = pi[0] - pq[0], d1 = pi[1] - pq[1], d2 = pi[2] - pq[2], d3 = pi[3] - pq[3];

@@ -83,33 +83,59 @@ class CGModule(nn.Module):
         named = list(self.named_parameters())            # registration order == the reference's state_dict order
         self._p_names = [n for n, _ in named]
         self._p_shapes = [tuple(p.shape) for _, p in named]
-        self._p_sizes = [p.numel() for _, p in named]
+        self._p_slots = []
+        # STORAGE shape of every parameter: the reference's shape, except where a sub-module asks for a wider last axis
+        # (``_kernel_pad = {attr: width}``, lgn/nn: RadPolyTrig with num_basis_fn < 10 -- the kernels read 20 bells per radial
+        # network in place).  The padding columns are zeros and stay zeros: a bell with a = b = c = 0 and zero Linear weights feeds
+        # nothing and receives an exactly zero gradient, which Adam and the L1 term leave at zero.  Everything the reference can see
+        # -- names, shapes, state_dict entries, named_grads -- is the narrow view [..., :n] of the stored block.
+        self._p_store = []
+        for name, p in named:
+            path, _, attr = name.rpartition(".")
+            owner = self.get_submodule(path) if path else self
+            self._p_slots.append((owner, attr))
+            width = getattr(owner, "_kernel_pad", {}).get(attr)
+            shape = tuple(p.shape)
+            self._p_store.append(shape[:-1] + (width,) if width and shape and shape[-1] < width else shape)
+        self._p_sizes = [int(torch.Size(s).numel()) for s in self._p_store]
         self._p_offsets = [0]
         for n in self._p_sizes:
             self._p_offsets.append(self._p_offsets[-1] + n)
-        flat = torch.cat([p.detach().reshape(-1) for _, p in named]).contiguous()
-        self._p_slots = []
-        for name, _ in named:
-            path, _, attr = name.rpartition(".")
-            owner = self.get_submodule(path) if path else self
+        pieces = []
+        for (_, p), store in zip(named, self._p_store):
+            t = p.detach()
+            if store != tuple(p.shape):
+                t = torch.nn.functional.pad(t, (0, store[-1] - p.shape[-1]))
+            pieces.append(t.reshape(-1))
+        flat = torch.cat(pieces).contiguous()
+        for owner, attr in self._p_slots:
             del owner._parameters[attr]
-            self._p_slots.append((owner, attr))
         self.flat_params = FlatParameter(flat)
         self._rebind_views()
+
+    @staticmethod
+    def _narrow(stored, shape):
+        return stored if tuple(stored.shape) == tuple(shape) else stored[..., :shape[-1]]
 
     def _rebind_views(self):
         """(Re)create the plain views the sub-modules and the native calls read; called whenever ``flat_params``
         moved (``.to()``, a trainer re-homing it into a joint buffer, deepcopy)."""
         base = self.flat_params.detach()
-        self._p_views = [base[o:o + n].view(s) for o, n, s in zip(self._p_offsets, self._p_sizes, self._p_shapes)]
+        self._p_stores = [base[o:o + n].view(s) for o, n, s in zip(self._p_offsets, self._p_sizes, self._p_store)]
+        self._p_views = [self._narrow(t, s) for t, s in zip(self._p_stores, self._p_shapes)]
         self._views_ptr = base.data_ptr()
         self._device = base.device
-        self._bind(self._p_views)
+        self._bind(self._p_stores)
         self.__dict__.pop("_native_cache", None)
 
-    def _bind(self, tensors):
-        for (owner, attr), t in zip(self._p_slots, tensors):
-            owner.__dict__[attr] = t
+    def _bind(self, stores):
+        """``owner.attr`` = the reference-shaped tensor (the narrow view of its stored block); where the storage is wider,
+        ``owner.attr_store`` = the stored block itself (what the kernels read).  stores: plain views (_p_stores) or the
+        autograd-tracked ones (_tracked_views)."""
+        for (owner, attr), t, shape in zip(self._p_slots, stores, self._p_shapes):
+            owner.__dict__[attr] = self._narrow(t, shape)
+            if tuple(t.shape) != tuple(shape):
+                owner.__dict__[attr + "_store"] = t
 
     def _check_views(self):
         if self._views_ptr != self.flat_params.data_ptr():
@@ -119,7 +145,7 @@ class CGModule(nn.Module):
         """Views of ``flat_params`` that autograd follows (module/autograd path): ONE split node + metadata-only views,
         so the backward assembles the flat gradient with a single concatenation."""
         parts = torch.split_with_sizes(self.flat_params, self._p_sizes)
-        return [p.view(s) for p, s in zip(parts, self._p_shapes)]
+        return [p.view(s) for p, s in zip(parts, self._p_store)]
 
     def _apply(self, fn, *args, **kwargs):
         out = super()._apply(fn, *args, **kwargs)
@@ -135,7 +161,7 @@ class CGModule(nn.Module):
         for k, v in self.__dict__.items():
             # derived, rebuilt on demand: device-side tables and descriptors hold ctypes pointers (not copyable), and the
             # parameter views must point into the COPY's flat block
-            if k in ("_native_cache", "_level_tables", "_p_views", "_views_ptr"):
+            if k in ("_native_cache", "_level_tables", "_p_views", "_p_stores", "_views_ptr"):
                 continue
             new.__dict__[k] = copy.deepcopy(v, memo)
         if "flat_params" in new._parameters:
@@ -152,7 +178,8 @@ class CGModule(nn.Module):
         g = self.flat_params.grad
         if g is None:
             return [(n, None) for n in self._p_names]
-        return [(n, g[o:o + k].view(s)) for n, o, k, s in zip(self._p_names, self._p_offsets, self._p_sizes, self._p_shapes)]
+        return [(n, self._narrow(g[o:o + k].view(st), s))
+                for n, o, k, st, s in zip(self._p_names, self._p_offsets, self._p_sizes, self._p_store, self._p_shapes)]
 
     def state_dict(self, *args, destination=None, prefix="", keep_vars=False):
         from collections import OrderedDict

@@ -80,7 +80,7 @@ class LGNDecoder(CGModule, LevelTablesMixin):
         try:
             return self._forward_modular(lat_v, covariance_test, nodes_all)
         finally:
-            self._bind(self._p_views)
+            self._bind(self._p_stores)
 
     def _fused_ok(self) -> bool:
         """True when a whole-network native implementation covers this configuration (lgn/ops.py: native_kind)."""

@@ -92,7 +92,7 @@ class LGNEncoder(CGModule, LevelTablesMixin):
         try:
             return self._forward_modular(node_ps, node_mask, covariance_test, scalars)
         finally:
-            self._bind(self._p_views)
+            self._bind(self._p_stores)
 
     def _fused_ok(self) -> bool:
         """True when a whole-network native implementation covers this configuration (lgn/ops.py: native_kind)."""

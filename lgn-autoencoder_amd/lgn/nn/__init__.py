@@ -143,6 +143,12 @@ class RadPolyTrig(nn.Module):
         out = num_channels if input_basis == "canonical" else 2 * num_channels
         self.linear = nn.ModuleList([nn.Linear(nb, out).to(device=device, dtype=dtype) for _ in range(max_zf + 1)])
         self.radial_types = (num_channels,) * max_zf
+        if nb < self.KERNEL_BELLS:
+            # fewer bells than the kernels read: a network's flat parameter block STORES these tensors KERNEL_BELLS wide, zero padded
+            # (lgn/models/common.py: CGModule._flatten_parameters), so that every native call -- whole step included -- reads them in place
+            self._kernel_pad = {"a": self.KERNEL_BELLS, "b": self.KERNEL_BELLS, "c": self.KERNEL_BELLS}
+            for lin in self.linear:
+                lin._kernel_pad = {"weight": self.KERNEL_BELLS}
 
     KERNEL_BELLS = 20          # csrc/common.hpp: NB -- the width the level / moments kernels read (2 * num_basis_fn of the default 10)
 
@@ -151,12 +157,15 @@ class RadPolyTrig(nn.Module):
 
     def kernel_params(self):
         """flat_params() in the width the kernels read.  Fewer than 20 bells (num_basis_fn < 10, lgn/nn/position_levels.py:44-64) are
-        embedded by zero padding: a bell with a = b = c = 0 and zero Linear weights evaluates to 0 and feeds nothing, its gradient
-        slots are sliced away by autograd (the padding is a differentiable op).  The whole-network calls read the parameters in
-        place and keep requiring num_basis_fn = 10 (lgn/ops.py: native_kind); the per-operator path takes these."""
-        pad = self.KERNEL_BELLS - 2 * self.num_basis_fn
-        if pad == 0:
+        embedded by zero padding: a bell with a = b = c = 0 and zero Linear weights evaluates to 0 and feeds nothing.  Inside a network
+        the padded blocks are the parameters' STORAGE (``a_store`` ...: views of the flat block, autograd-tracked on the per-operator
+        path); a stand-alone module pads on the fly (a differentiable op: the padding's gradient slots are sliced away)."""
+        if 2 * self.num_basis_fn == self.KERNEL_BELLS:
             return self.flat_params()
+        if "a_store" in self.__dict__:
+            return [self.a_store, self.b_store, self.c_store, self.linear[0].weight_store, self.linear[0].bias,
+                    self.linear[1].weight_store, self.linear[1].bias]
+        pad = self.KERNEL_BELLS - 2 * self.num_basis_fn
         a, b, c, w0, b0, w1, b1 = self.flat_params()
         P = torch.nn.functional.pad
         return [P(a, (0, pad)), P(b, (0, pad)), P(c, (0, pad)), P(w0, (0, pad)), b0, P(w1, (0, pad)), b1]

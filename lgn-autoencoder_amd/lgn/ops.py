@@ -244,7 +244,7 @@ def native_kind(net):
     kind = net.__dict__.get("_native_kind", 0)
     if kind == 0:
         from .plan import check_maxdim2_layout
-        ok = (bool(net.mlp) and 3 <= net.mlp_depth <= 6 and net.num_basis_fn == 10 and 1 <= net.num_cg_levels <= 4
+        ok = (bool(net.mlp) and 3 <= net.mlp_depth <= 6 and 1 <= net.num_basis_fn <= 10 and 1 <= net.num_cg_levels <= 4
               and all(1 <= c <= 8 for c in net.num_channels) and net.mlp_width * 2 * max(net.num_channels[1:]) <= 96
               and (not hasattr(net, "map_to_latent") or N.pool_code(net.map_to_latent) is not None))
         kind = None

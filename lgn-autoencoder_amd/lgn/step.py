@@ -235,7 +235,7 @@ class NativeTrainStep:
             # layout -> refuse instead of computing garbage.
             raise NotImplementedError(
                 "the native step implements maxdim=2 / maxdim=3 networks (the same kind for encoder and decoder) with "
-                "map_to_latent = min / max / mean joined by '&' or '+', CGMLP levels (mlp_depth 3 .. 6), num_basis_fn=10 and <= 8 channels; got encoder "
+                "map_to_latent = min / max / mean joined by '&' or '+', CGMLP levels (mlp_depth 3 .. 6), num_basis_fn <= 10 and <= 8 channels; got encoder "
                 f"maxdim={encoder.level_maxdim} map_to_latent={encoder.map_to_latent!r} mlp={encoder.mlp} mlp_depth="
                 f"{encoder.mlp_depth}, decoder maxdim={decoder.level_maxdim} mlp={decoder.mlp}")
         if getattr(encoder, "tau_input_scalars", 1) != 1:
@@ -297,8 +297,9 @@ class NativeTrainStep:
             for l in range(L):                   # sizes the kernels assume for the per-level slots
                 mix0 = ts[(2 if dec else 0) + 2 + 7 * L + 2 * l]
                 assert not fused or mix0.numel() == 2 * ch[l + 1] * 5 * ch[l], "CatMix weight is not [2][CO][5C]: not a maxdim=2 level"
-                ra = ts[(2 if dec else 0) + 2 + 7 * l]
-                assert ra.numel() == 20, "radial network must have 2 * num_basis_fn = 20 basis functions"
+                rf = net.rad_funcs.rad_funcs[l]      # (num_basis_fn < 10: stored 20 wide, zero padded -- lgn/nn: RadPolyTrig._kernel_pad)
+                assert rf.kernel_params()[0].numel() == 20 and rf.kernel_params()[0].data_ptr() == ts[(2 if dec else 0) + 2 + 7 * l].data_ptr(), \
+                    "the radial parameters must be stored 20 bells wide"
             offs = [(t.data_ptr() - base) // 8 for t in ts]
             assert all(0 <= o < self.flat.flat.numel() for o in offs)
             return (C.c_int64 * len(offs))(*offs)

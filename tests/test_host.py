@@ -301,3 +301,40 @@ def test_generated_static_tables_are_up_to_date_and_match_the_runtime_matcher():
     from lgn.plan import canonical_static_tables, static_kind
     for kind, tab in canonical_static_tables().items():
         assert static_kind(tab) == kind
+
+
+def test_fewer_radial_bells_are_stored_padded_and_seen_unpadded():
+    """num_basis_fn < 10 (lgn/nn/position_levels.py:44-64): the flat parameter block STORES a, b, c and the radial Linear weights 20
+    bells wide (what every kernel reads), zero padded; names, shapes, state_dict, load_state_dict, the parameter count and deepcopy see
+    the reference's tensors (narrow views of the stored blocks)."""
+    import copy
+    import __graft_entry__ as G
+    enc, dec = G._models(12, (2, 3, 4), (4, 3, 2), torch.device("cpu"), seed=3, num_basis_fn=5)
+    ref, _ = G._models(12, (2, 3, 4), (4, 3, 2), torch.device("cpu"), seed=3, num_basis_fn=10)
+    sd = enc.state_dict()
+    assert tuple(sd["rad_funcs.rad_funcs.0.a"].shape) == (1, 1, 1, 10)
+    assert tuple(sd["rad_funcs.rad_funcs.1.linear.0.weight"].shape) == (6, 10) and tuple(sd["rad_funcs.rad_funcs.1.linear.0.bias"].shape) == (6,)
+    assert list(sd) == [k for k in ref.state_dict()], "same keys, same order as with the default 10"
+    true_count = sum(v.numel() for v in sd.values())
+    assert enc.num_learnable_parameters == true_count
+    nrad = 2 * (3 * 10 + 4 * 10 + 6 * 10 + 3 * 10 + 2 * 2 * 10)       # padding columns: per level 3 x 10 (a, b, c) + 2 x 2C x 10 (weights)
+    assert enc.flat_params.numel() == true_count + (3 * 10 * 2 + 2 * (4 + 6) * 10), (enc.flat_params.numel(), true_count, nrad)
+    rf = enc.rad_funcs.rad_funcs[0]
+    kp = rf.kernel_params()
+    assert [tuple(t.shape) for t in kp] == [(1, 1, 1, 20)] * 3 + [(4, 20), (4,), (4, 20), (4,)]
+    assert all(float(t[..., 10:].abs().max()) == 0 for t in (kp[0], kp[1], kp[2], kp[3], kp[5]))
+    assert kp[0].data_ptr() == rf.a.data_ptr() and torch.equal(kp[3][:, :10], rf.linear[0].weight)
+    # a round trip through state_dict leaves the padding at zero and restores the values
+    enc2 = copy.deepcopy(enc)
+    with torch.no_grad():
+        enc2.flat_params.add_(1.0)                      # (dirties the padding too)
+    enc2.load_state_dict(sd)
+    for (k, v), (_, w) in zip(enc2.state_dict().items(), sd.items()):
+        assert torch.equal(v, w), k
+    assert enc2.flat_params.data_ptr() != enc.flat_params.data_ptr()
+    # gradients: named_grads are the narrow views of the flat gradient
+    enc.flat_params.grad = torch.arange(enc.flat_params.numel(), dtype=torch.float64)
+    g = dict(enc.named_grads())
+    assert tuple(g["rad_funcs.rad_funcs.0.a"].shape) == (1, 1, 1, 10) and tuple(g["rad_funcs.rad_funcs.0.linear.1.weight"].shape) == (4, 10)
+    from lgn.ops import native_kind
+    assert native_kind(enc) == "fused" and native_kind(dec) == "fused"
