@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LGN_AMD_ABI_VERSION 16   /* bump on ANY struct or signature change (lgn/_native.py: ABI_VERSION) */
+#define LGN_AMD_ABI_VERSION 17   /* bump on ANY struct or signature change (lgn/_native.py: ABI_VERSION) */
 
 int lgn_abi_version(void);
 const char* lgn_last_error(void);
@@ -233,12 +233,16 @@ typedef struct lgn_net_desc {
   int activation;          /* LGN_ACT_* of every CGMLP of both networks (the reference builds them from one --activation) */
   int n_in_scalars;        /* encoder: input scalars per node, K (0 or 1: the mass alone).  K > 1 -- jet_features and / or
                               data['scalars'], lgn/models/lgn_encoder.py:372-411: the mass, then K - 1 values per node the caller
-                              passes as in_scalars -- is served by lgn_encoder_fwd/bwd_f64; the whole-step call refuses it (its two
-                              networks share one particle count, jet_features gives the encoder one node more) */
+                              passes as in_scalars [B][N][K - 1] -- to the per-network calls and (ABI 17, maxdim = 2 networks) the
+                              whole-step calls */
   int latent_pool;         /* encoder: how the latent channels are pooled over the particles (aggregate(), lgn/models/
                               lgn_encoder.py:419-496): 0 = 'min&max' (the reference default), else LGN_POOL(...).  With P output
                               blocks (one per pooling under '&', one in all under '+') the latent space is lat_s [2][B][P tau_s],
                               lat_v [2][B][P tau_v][4], and the decoder of a whole step takes Tin = P tau_v vectors */
+  int dec_N;               /* whole-step call only: particles the decoder reconstructs when that differs from the encoder's node count N
+                              (jet_features: the encoder works on N = particles + 1 nodes, lgn_encoder.py:372-411); 0 = N.  With
+                              dec_N != N or n_in_scalars > 1 the step runs its four end stages as launches of their own (maxdim = 2
+                              networks; table-driven networks refuse) */
 } lgn_net_desc;
 /* latent pooling code: n = 1..4 poolings o0..o3 (LGN_POOL_MIN / MAX / MEAN), avg = 0: concatenated ('a&b'), 1: averaged ('a+b').
  * min / max pick ONE particle per (plane, channel) -- by the value itself (min) / its square (max) for scalars, by the Minkowski
@@ -282,15 +286,16 @@ long long lgn_junction_lds_bytes(int N, int CL, int Ts, int Tv, int pool, int C0
 
 int lgn_step_param_slots(const lgn_net_desc* d, int decoder);
 long long lgn_step_workspace_doubles(const lgn_net_desc* d);
-/* p4 [B][N][4] real Cartesian encoder input (already multiplied by the encoder's `scale`, lgn_encoder.py:376);
- * target [B][N][4] the UNscaled batch the reconstruction is compared with (utils/train.py:285-292; may alias p4 when
- * scale == 1); mask [B][N]; recon [2][B][N][4]; loss_part [B].  workspace_doubles = capacity of `workspace`: the call
+/* p4 [B][N][4] real Cartesian encoder input (already multiplied by the encoder's `scale`, lgn_encoder.py:376; with jet_features its
+ * last node is the jet); target [B][Nd][4] the UNscaled batch the reconstruction is compared with (utils/train.py:285-292; may alias
+ * p4 when scale == 1 and Nd == N), Nd = d->dec_N or N; mask [B][N]; in_scalars [B][N][K - 1] or NULL (d->n_in_scalars <= 1);
+ * recon [2][B][Nd][4]; loss_part [B].  workspace_doubles = capacity of `workspace`: the call
  * fails before enqueuing anything if the current configuration needs more (lgn_step_workspace_doubles).
  * (ABI 16: the side_stream argument of the forked gradient reductions is gone with that path -- measured slower in every regime.) */
 int lgn_step_fwd_bwd_f64(const lgn_net_desc* d, const double* params, double* grads, long long n_params,
                          const int64_t* enc_off, const int64_t* dec_off, const double* p4, const double* target,
-                         const uint8_t* mask, double* workspace, long long workspace_doubles, double* recon,
-                         double* loss_part, void* stream);
+                         const uint8_t* mask, const double* in_scalars, double* workspace, long long workspace_doubles,
+                         double* recon, double* loss_part, void* stream);
 /* grads += l1_lambda*sign(params) (utils/train.py:484-487); loss_out[0..2] = total, chamfer, sum|w|; optional Adam
  * (torch.optim.Adam defaults; the step counter lives on the device so that graph replays stay correct).
  * loss_out must hold 3 + LGN_FINALIZE_SCRATCH doubles: the results, then scratch -- the per-workgroup |w| partials, the cached
@@ -314,8 +319,8 @@ int lgn_step_finalize_f64(double* params, double* grads, long long n_params, con
  * scratch slots -11 .. -8 of the block are the per-level counters of the fused launch (zero between calls, like the last slot).
  * Data-parallel training keeps the two calls above: the gradient all-reduce sits between them. */
 int lgn_step_train_f64(const lgn_net_desc* d, double* params, double* grads, long long n_params, const int64_t* enc_off,
-                       const int64_t* dec_off, const double* p4, const double* target, const uint8_t* mask, double* workspace,
-                       long long workspace_doubles, double* recon, double* loss_part, int n_loss, double l1_lambda,
+                       const int64_t* dec_off, const double* p4, const double* target, const uint8_t* mask, const double* in_scalars,
+                       double* workspace, long long workspace_doubles, double* recon, double* loss_part, int n_loss, double l1_lambda,
                        double* adam_m, double* adam_v, long long* step_dev, double lr, double beta1, double beta2, double eps,
                        int do_adam, double* loss_out, void* stream);
 

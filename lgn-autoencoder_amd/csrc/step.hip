@@ -96,7 +96,7 @@ int finish_reductions(Deferred& dq, const RadFinJob& fin, double* grads, long lo
 // partial rows of level l's CGMLP weight gradients
 size_t mlp_part_rows(const lgn_net_desc& d, bool dec, int l) {
   const int* ch = dec ? d.dec_channels : d.enc_channels;
-  return (size_t)mlp_partial_rows(d.B * d.N, d.mlp_hidden_mul * 2 * ch[l + 1]);
+  return (size_t)mlp_partial_rows(d.B * (dec && d.dec_N > 0 ? d.dec_N : d.N), d.mlp_hidden_mul * 2 * ch[l + 1]);
 }
 
 inline int in_K(const lgn_net_desc& d) { return d.n_in_scalars > 1 ? d.n_in_scalars : 1; }      // encoder input scalars per node
@@ -106,14 +106,22 @@ int mlp_psize(int C, int H, int nlin) {
   return nlin == 1 ? D * D + D : (H * D + H) + (nlin - 2) * (H * H + H) + (D * H + D);
 }
 
+// decoder node count of a whole step: its own (jet_features gives the encoder one node more than the decoder reconstructs), or N
+inline int dec_nodes(const lgn_net_desc& d) { return d.dec_N > 0 ? d.dec_N : d.N; }
+// the step takes the two-kernel junction and the riding input stage only when both networks work on the same nodes and the mass is
+// the only input scalar; otherwise the four end stages are launches of their own
+inline bool step_is_split(const lgn_net_desc& d) { return dec_nodes(d) != d.N || d.n_in_scalars > 1; }
+
 Work carve(const lgn_net_desc& d, double* base) {
   Work w{};
   Bump b{base};
-  const size_t BN = (size_t)d.B * d.N;
+  const int Nd = dec_nodes(d), Nmax = d.N > Nd ? d.N : Nd;
+  const size_t BNe = (size_t)d.B * d.N, BNd = (size_t)d.B * Nd, BN = (size_t)d.B * Nmax;
   const int L = d.n_levels;
   int cmax = 0;
   for (int l = 0; l <= L; ++l) cmax = cmax > d.enc_channels[l] ? cmax : d.enc_channels[l], cmax = cmax > d.dec_channels[l] ? cmax : d.dec_channels[l];
   auto net = [&](NetBuf& n, const int* ch, bool dec) {
+    const size_t BN = dec ? BNd : BNe;
     for (int l = 0; l <= L; ++l) {
       n.s[l] = b.take(2 * BN * ch[l]);
       n.v[l] = b.take(8 * BN * ch[l]);
@@ -157,14 +165,15 @@ Work carve(const lgn_net_desc& d, double* base) {
     const int* ch = dec ? d.dec_channels : d.enc_channels;
     for (int l = 0; l < L; ++l) {
       int rm, rr;
-      level_bwd_partial_rows(d.B, d.N, dec, d.flags, &rm, &rr);
+      level_bwd_partial_rows(d.B, dec ? Nd : d.N, dec, d.flags, &rm, &rr);
       const size_t nmix = (size_t)4 * ch[l + 1] * 5 * ch[l], nrad = rad_partial_size(ch[l], dec != 0);
       psum += ((rm * nmix + 15) & ~size_t(15)) + ((rr * nrad + 15) & ~size_t(15));
       psum += (mlp_part_rows(d, dec, l) * mlp_psize(ch[l + 1], d.mlp_hidden_mul * 2 * ch[l + 1], d.mlp_nlin) + 15) & ~size_t(15);
       w.tot[dec][l] = b.take(nrad + 16);
     }
   }
-  psum += 4 * (((size_t)d.B * (4 * cmax + 2 * (size_t)d.N * PB * Tv + 2 * (size_t)(Ts + Tv) * pool_mix_in(d.latent_pool, d.N, cmax)) + 15) & ~size_t(15));
+  psum += 4 * (((size_t)d.B * (4 * cmax + 2 * (size_t)Nmax * PB * Tv + 2 * (size_t)(Ts + Tv) * pool_mix_in(d.latent_pool, Nmax, cmax)) + 15) & ~size_t(15));
+  psum += ((size_t)d.B * (2 * in_K(d) + 2) * cmax + 15) & ~size_t(15);                  // input stage with K scalars (split step)
   w.parts = b.take(psum);
   w.parts_size = psum;
   w.total = b.off;
@@ -1139,18 +1148,98 @@ long long lgn_step_workspace_doubles(const lgn_net_desc* d) {
 }
 
 }  // extern "C"
+// The step of networks that do not share their nodes or take more input scalars than the mass (jet_features: the encoder works on
+// N + 1 nodes, lgn/models/lgn_encoder.py:372-411; data['scalars']): the same level stacks, the four end stages as launches of their
+// own (no junction kernels, no riding input stage) -- every one of them takes its network's node count.
+static int step_fwd_bwd_split(const lgn_net_desc& d, Work& w, const double* params, double* grads, long long n_params, const int64_t* enc_off,
+                              const int64_t* dec_off, const double* p4, const double* target, const uint8_t* mask, const double* in_scalars,
+                              double* recon, double* loss_part, hipStream_t st, const StepTailArgs* tail) {
+  if (int rc = check_mlp_contiguous(d, false, enc_off)) return rc;
+  if (int rc = check_mlp_contiguous(d, true, dec_off)) return rc;
+  lgn_net_desc de = d, dd = d;                   // per-network views of the descriptor: the level sequencers read B, N, flags, MLP shape
+  dd.N = dec_nodes(d);
+  const Slots S{d.n_levels, d.mlp_nlin};
+  const int L = d.n_levels, B = d.B, Ne = d.N, Nd = dd.N, Ts = d.tau_s, Tv = d.tau_v, K = in_K(d);
+  const int* ce = d.enc_channels;
+  const int* cd = d.dec_channels;
+  const int Tin = pool_blocks(d.latent_pool) * Tv;
+  LGN_CHECK_ARG(d.tau_v_in == 0 || d.tau_v_in == Tin, "step: the decoder must consume the encoder's %d pooled latent vectors", Tin);
+  Deferred dq;
+  dq.parts = w.parts;
+  dq.cap = w.parts_size;
+  RadFinJob fin{};
+  LGN_TRY(zero_ranges(grads, (size_t)n_params, w.zero0(), w.zero_doubles, nullptr, 0, st));
+  // ---------------- forward ----------------
+  LGN_TRY(enc_input_fwd(B, Ne, ce[0], K, p4, in_scalars, params + enc_off[0], params + enc_off[1], w.enc.s[0], w.enc.v[0], st));
+  LGN_TRY(levels_fwd(de, false, ce, params, enc_off, w.enc, p4, mask, st));
+  LGN_TRY(enc_latent_fwd(B, Ne, ce[L], Ts, Tv, d.latent_pool, w.enc.s[L], w.enc.v[L], params + enc_off[S.out0(false)],
+                         params + enc_off[S.out0(false) + 1], w.lat_s, w.lat_v, w.idx, st));
+  LGN_TRY(dec_input_fwd(B, Nd, cd[0], Tin, w.lat_v, params + dec_off[1], params + dec_off[2], params + dec_off[3], w.pdec, w.dec.s[0],
+                        w.dec.v[0], st));
+  int cur = 0;
+  {
+    DQ_NEW(part, (size_t)B * 2 * cd[L]);
+    const LossStage ls{params + dec_off[S.out0(true) + 1], target, 1.0, recon, loss_part, w.gv[cur], part};
+    const bool rides = level_fwd_carries_loss(Nd, d.flags);
+    LGN_TRY(levels_fwd(dd, true, cd, params, dec_off, w.dec, w.pdec, nullptr, st, nullptr, rides ? &ls : nullptr));
+    if (!rides) LGN_TRY(dec_output_loss(B, Nd, cd[L], w.dec.v[L], ls.wo1, target, 1.0, recon, loss_part, w.gv[cur], part, st));
+    dq.add(part, B, 2 * cd[L], 0, 2 * cd[L], grads + dec_off[S.out0(true) + 1]);
+  }
+  // ---------------- backward ----------------
+  LGN_TRY(levels_bwd(dd, true, cd, params, grads, dec_off, w.dec, w.pdec, nullptr, w, dq, fin, cur, /*has_s_grad=*/false, st));
+  {
+    const int C0 = cd[0], row = 4 * C0 + 2 * Nd * Tin;
+    const int CL = ce[L], KL = pool_mix_in(d.latent_pool, Ne, CL), rowe = 2 * (Ts + Tv) * KL;
+    DQ_NEW(part, (size_t)B * row);
+    DQ_NEW(parte, (size_t)B * rowe);
+    const int rd = cur, wr = cur ^ 1;
+    cur = wr;
+    LGN_TRY(dec_input_bwd(B, Nd, C0, Tin, w.lat_v, params + dec_off[1], params + dec_off[3], w.pdec, w.g_p, w.gs[rd], w.gv[rd], w.g_lat_v,
+                          part, st));
+    // the decoder never reads the latent scalars: their gradient is the zero block's g_lat_s
+    LGN_TRY(enc_latent_bwd(B, Ne, CL, Ts, Tv, d.latent_pool, w.enc.s[L], w.enc.v[L], params + enc_off[S.out0(false)],
+                           params + enc_off[S.out0(false) + 1], w.g_lat_s, w.g_lat_v, w.idx, w.gs[wr], w.gv[wr], parte, st));
+    dq.add(part, B, row, 0, 2 * C0, grads + dec_off[2]);
+    dq.add(part, B, row, 2 * C0, 2 * C0, grads + dec_off[3]);
+    dq.add(part, B, row, 4 * C0, 2 * Nd * Tin, grads + dec_off[1]);
+    dq.add(parte, B, rowe, 0, 2 * Ts * KL, grads + enc_off[S.out0(false)]);
+    dq.add(parte, B, rowe, 2 * Ts * KL, 2 * Tv * KL, grads + enc_off[S.out0(false) + 1]);
+  }
+  LGN_TRY(levels_bwd(de, false, ce, params, grads, enc_off, w.enc, p4, mask, w, dq, fin, cur, /*has_s_grad=*/false, st));
+  {
+    const int C0 = ce[0], row = (2 * K + 2) * C0;
+    DQ_NEW(part, (size_t)B * row);
+    LGN_TRY(enc_input_bwd(B, Ne, C0, K, p4, in_scalars, w.gs[cur], w.gv[cur], part, st));
+    dq.add(part, B, row, 0, 2 * C0 * K, grads + enc_off[0]);
+    dq.add(part, B, row, 2 * C0 * K, 2 * C0, grads + enc_off[1]);
+  }
+  LGN_CHECK_ARG(dq.off <= dq.cap, "step: partial-row workspace overflow (%zu > %zu)", dq.off, dq.cap);
+  if (tail && !(d.flags & LGN_NET_SPLIT_TAIL)) {
+    const int rc = step_tail(dq.segs, fin, *tail, st);
+    if (rc == 0) return 0;
+    if (rc != -2) return rc;
+  }
+  LGN_TRY(finish_reductions(dq, fin, grads, n_params, tail ? nullptr : w.tail_cnt, d.flags, st));
+  if (tail)
+    LGN_TRY(finalize_step(tail->w, tail->g, tail->n, tail->loss_part, tail->nB, tail->lambda, tail->m, tail->v, tail->step_dev, tail->lr,
+                          tail->beta1, tail->beta2, tail->eps, tail->do_adam, tail->loss_out, st));
+  return 0;
+}
+
 // forward + backward of a training step; with `tail` (single process: nothing sits between the gradients and the optimiser) the
 // deferred reductions, the radial finalisation, L1 + Adam and the loss assembly are ONE launch (step_tail.hip) instead of three
 static int step_fwd_bwd(const lgn_net_desc* d, const double* params, double* grads, long long n_params, const int64_t* enc_off,
-                        const int64_t* dec_off, const double* p4, const double* target, const uint8_t* mask, double* workspace,
-                        long long workspace_doubles, double* recon, double* loss_part, void* stream, const StepTailArgs* tail) {
+                        const int64_t* dec_off, const double* p4, const double* target, const uint8_t* mask, const double* in_scalars,
+                        double* workspace, long long workspace_doubles, double* recon, double* loss_part, void* stream,
+                        const StepTailArgs* tail) {
   if (int rc = check_desc(d)) return rc;
   LGN_CHECK_ARG(params && grads && enc_off && dec_off && p4 && target && mask && workspace && recon && loss_part && n_params > 0,
                 "step_fwd_bwd: null pointer");
-  LGN_CHECK_ARG(d->n_in_scalars <= 1, "step_fwd_bwd: the whole-step call takes the mass as the only input scalar (n_in_scalars=%d): "
-                "use the per-network calls", d->n_in_scalars);
+  LGN_CHECK_ARG(d->n_in_scalars <= 1 || in_scalars, "step_fwd_bwd: %d input scalars per node, but in_scalars is NULL", d->n_in_scalars);
   hipStream_t st = (hipStream_t)stream;
   if (is_generic(*d, false) || is_generic(*d, true)) {
+    LGN_CHECK_ARG(!step_is_split(*d), "step_fwd_bwd: table-driven networks take the mass as the only input scalar and one node count "
+                  "for both networks (n_in_scalars=%d, N=%d, dec_N=%d): use the per-network calls", d->n_in_scalars, d->N, d->dec_N);
     LGN_TRY(gen_step_fwd_bwd(*d, params, grads, n_params, enc_off, dec_off, p4, target, mask, workspace, workspace_doubles, recon,
                              loss_part, st));
     if (tail)        // (the table-driven step unpacks gradients after its reductions: it keeps the separate launches)
@@ -1167,6 +1256,8 @@ static int step_fwd_bwd(const lgn_net_desc* d, const double* params, double* gra
   const int L = d->n_levels, B = d->B, N = d->N, Ts = d->tau_s, Tv = d->tau_v;
   const int* ce = d->enc_channels;
   const int* cd = d->dec_channels;
+  if (step_is_split(*d))
+    return step_fwd_bwd_split(*d, w, params, grads, n_params, enc_off, dec_off, p4, target, mask, in_scalars, recon, loss_part, st, tail);
   // MLP parameter blocks must be contiguous (W_0, b_0, W_1, b_1, ...) for the single-reduce path
   for (int dec = 0; dec < 2; ++dec) {
     const int64_t* off = dec ? dec_off : enc_off;
@@ -1254,15 +1345,15 @@ static int step_fwd_bwd(const lgn_net_desc* d, const double* params, double* gra
 extern "C" {
 
 int lgn_step_fwd_bwd_f64(const lgn_net_desc* d, const double* params, double* grads, long long n_params, const int64_t* enc_off,
-                         const int64_t* dec_off, const double* p4, const double* target, const uint8_t* mask, double* workspace,
-                         long long workspace_doubles, double* recon, double* loss_part, void* stream) {
-  return step_fwd_bwd(d, params, grads, n_params, enc_off, dec_off, p4, target, mask, workspace, workspace_doubles, recon, loss_part,
-                      stream, nullptr);
+                         const int64_t* dec_off, const double* p4, const double* target, const uint8_t* mask, const double* in_scalars,
+                         double* workspace, long long workspace_doubles, double* recon, double* loss_part, void* stream) {
+  return step_fwd_bwd(d, params, grads, n_params, enc_off, dec_off, p4, target, mask, in_scalars, workspace, workspace_doubles, recon,
+                      loss_part, stream, nullptr);
 }
 
 int lgn_step_train_f64(const lgn_net_desc* d, double* params, double* grads, long long n_params, const int64_t* enc_off,
-                       const int64_t* dec_off, const double* p4, const double* target, const uint8_t* mask, double* workspace,
-                       long long workspace_doubles, double* recon, double* loss_part, int n_loss, double l1_lambda, double* adam_m,
+                       const int64_t* dec_off, const double* p4, const double* target, const uint8_t* mask, const double* in_scalars,
+                       double* workspace, long long workspace_doubles, double* recon, double* loss_part, int n_loss, double l1_lambda, double* adam_m,
                        double* adam_v, long long* step_dev, double lr, double beta1, double beta2, double eps, int do_adam,
                        double* loss_out, void* stream) {
   LGN_CHECK_ARG(loss_out && n_loss > 0, "step_train: null pointer");
@@ -1271,8 +1362,8 @@ int lgn_step_train_f64(const lgn_net_desc* d, double* params, double* grads, lon
                           eps, do_adam, loss_part, n_loss, loss_out, 0, nullptr};
   // LGN_NET_SPLIT_TAIL (frozen into the descriptor): the three separate launches (reduce_segments, rad_finalize_batch, l1_adam) -- the
   // A/B switch of the fused tail
-  return step_fwd_bwd(d, params, grads, n_params, enc_off, dec_off, p4, target, mask, workspace, workspace_doubles, recon, loss_part,
-                      stream, &tail);
+  return step_fwd_bwd(d, params, grads, n_params, enc_off, dec_off, p4, target, mask, in_scalars, workspace, workspace_doubles, recon,
+                      loss_part, stream, &tail);
 }
 
 int lgn_step_finalize_f64(double* params, double* grads, long long n_params, const double* loss_part, int n_loss, double l1_lambda,

@@ -15,7 +15,7 @@ import torch  # imported before the .so so that the process-wide libamdhip64 is 
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LGN_AMD_LIB") or os.path.join(_HERE, "_lib", "liblgn_amd.so")   # LGN_AMD_LIB: debug builds (tools/)
-ABI_VERSION = 16
+ABI_VERSION = 17
 FINALIZE_SCRATCH = 2048      # include/lgn_amd.h: LGN_FINALIZE_SCRATCH
 
 _lib: Optional[C.CDLL] = None
@@ -88,7 +88,7 @@ def end_stages_fit(encoder=None, decoder=None, junction: bool = False) -> bool:
         code = pool_code(encoder.map_to_latent)
         if code is None:
             return False
-        n = encoder.num_input_particles + int(bool(getattr(encoder, "jet_features", False)))
+        n = encoder.num_input_particles           # (counts the jet node of jet_features: lgn/models/encoder.py)
         ch = encoder.num_channels
         ts, tv = encoder.tau_latent[(0, 0)], encoder.tau_latent[(1, 1)]
         need = max(need, L.lgn_encoder_end_lds_bytes(n, ch[0], max(1, encoder.tau_input_scalars), ch[-1], ts, tv, code))
@@ -115,7 +115,7 @@ class NetDesc(C.Structure):
                 ("enc_tables", _tp * 4), ("dec_tables", _tp * 4),
                 ("enc_Q", C.c_int * 5), ("enc_qs", C.c_int * 5), ("enc_qv", C.c_int * 5),
                 ("dec_Q", C.c_int * 5), ("dec_qs", C.c_int * 5), ("dec_qv", C.c_int * 5), ("flags", C.c_int),
-                ("activation", C.c_int), ("n_in_scalars", C.c_int), ("latent_pool", C.c_int)]
+                ("activation", C.c_int), ("n_in_scalars", C.c_int), ("latent_pool", C.c_int), ("dec_N", C.c_int)]
 
     def __init__(self, *a, **kw):
         super().__init__(*a, **kw)
@@ -155,14 +155,14 @@ _SIGNATURES.update({
     "lgn_local_bwd_static_f64": [_i] * 4 + [_vp] * 3 + [_ip] + [_vp] * 8,
     "lgn_local_bwd_f64": [_i] * 5 + [_tp] + [_vp] * 8,
     "lgn_step_param_slots": [_dp, _i],
-    "lgn_step_fwd_bwd_f64": [_dp, _vp, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _vp, _vp],
+    "lgn_step_fwd_bwd_f64": [_dp, _vp, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _vp, _vp],
     "lgn_encoder_fwd_f64": [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _vp, _vp],
     "lgn_encoder_bwd_f64": [_dp, _vp, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _vp, _vp, _ll, _vp],
     "lgn_decoder_fwd_f64": [_dp, _vp, _vp, _vp, _vp, _ll, _vp, _vp],
     "lgn_decoder_bwd_f64": [_dp, _vp, _vp, _ll, _vp, _vp, _vp, _ll, _vp, _vp, _vp, _ll, _vp],
     "lgn_step_finalize_f64": [_vp, _vp, _ll, _vp, _i, _d, _vp, _vp, _vp, _d, _d, _d, _d, _i, _vp, _vp],
-    "lgn_step_train_f64": [_dp, _vp, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _vp, _i, _d, _vp, _vp, _vp, _d, _d, _d, _d, _i, _vp,
-                           _vp],
+    "lgn_step_train_f64": [_dp, _vp, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _vp, _i, _d, _vp, _vp, _vp, _d, _d, _d, _d, _i,
+                           _vp, _vp],
 })
 _LL_SIGNATURES = {          # entry points that return a long long
     "lgn_step_workspace_doubles": [_dp],

@@ -238,12 +238,16 @@ class NativeTrainStep:
                 "map_to_latent = min / max / mean joined by '&' or '+', CGMLP levels (mlp_depth 3 .. 6), num_basis_fn <= 10 and <= 8 channels; got encoder "
                 f"maxdim={encoder.level_maxdim} map_to_latent={encoder.map_to_latent!r} mlp={encoder.mlp} mlp_depth="
                 f"{encoder.mlp_depth}, decoder maxdim={decoder.level_maxdim} mlp={decoder.mlp}")
-        if getattr(encoder, "tau_input_scalars", 1) != 1:
-            raise NotImplementedError("the native step takes the particle masses as the only input scalars: jet_features / extra "
-                                      "input scalars run through the module API (CapturedModuleStep / native_train_step capture that "
-                                      "step into one graph)")
+        # jet_features (the encoder works on one node more than the decoder reconstructs) and data['scalars']: the whole-step call
+        # takes them for maxdim = 2 networks (lgn_net_desc.dec_N / n_in_scalars, ABI 17), its four end stages then run as launches
+        # of their own; table-driven networks keep the module route
+        self.split = getattr(encoder, "tau_input_scalars", 1) != 1 or bool(getattr(encoder, "jet_features", False))
+        if self.split and (_kind(encoder) != "fused" or encoder.tau_input_scalars > 8):
+            raise NotImplementedError("the native step of table-driven (maxdim 3) networks takes the particle masses as the only input "
+                                      "scalars: jet_features / extra input scalars run through the module API there (CapturedModuleStep "
+                                      "/ native_train_step capture that step into one graph)")
         encoder._require_gpu()
-        if not N.end_stages_fit(encoder, decoder, junction=True):
+        if not N.end_stages_fit(encoder, decoder, junction=not self.split):
             # a jet's latent / junction stage is ONE workgroup: refused here, at plan time, so that native_train_step (and any caller
             # catching NotImplementedError) takes the module route instead of failing at the first launch
             raise NotImplementedError(
@@ -272,7 +276,7 @@ class NativeTrainStep:
         L = encoder.num_cg_levels
         d = N.NetDesc()
         from .ops import describe_network, native_kind
-        d.B, d.N, d.n_levels = batch_size, encoder.num_input_particles, L
+        d.B, d.N, d.n_levels = batch_size, encoder.num_input_particles, L       # (num_input_particles counts the jet node of jet_features)
         self._keep = describe_network(d, encoder, False) + describe_network(d, decoder, True)    # (after FlatParams re-homed the blocks)
         d.mlp_hidden_mul, d.mlp_nlin = encoder.mlp_width, encoder.mlp_depth + 1
         if N.activation_id(encoder.activation) != N.activation_id(decoder.activation):
@@ -280,7 +284,9 @@ class NativeTrainStep:
                                       f"got {encoder.activation} / {decoder.activation}")
         d.activation = N.activation_id(encoder.activation)
         fused = native_kind(encoder) == "fused"
-        if decoder.tau_latent_vectors != N.pool_blocks(d.latent_pool) * d.tau_v or decoder.num_output_particles != d.N:
+        d.dec_N = decoder.num_output_particles if self.split else 0
+        if decoder.tau_latent_vectors != N.pool_blocks(d.latent_pool) * d.tau_v or \
+                decoder.num_output_particles != encoder.num_input_particles - int(bool(getattr(encoder, "jet_features", False))):
             raise ValueError(f"decoder latent size / particle count does not match the encoder (map_to_latent={encoder.map_to_latent!r} "
                              f"gives {N.pool_blocks(d.latent_pool)} x {d.tau_v} latent vectors, the decoder takes {decoder.tau_latent_vectors})")
         self.desc = d
@@ -309,17 +315,20 @@ class NativeTrainStep:
         if nws < 0:
             raise RuntimeError(N.last_error())
         self.workspace = torch.empty(nws, device=dev, dtype=dt)
-        self.recon = torch.empty(2, d.B, d.N, 4, device=dev, dtype=dt)
+        Nd = decoder.num_output_particles
+        self.recon = torch.empty(2, d.B, Nd, 4, device=dev, dtype=dt)
         self.loss_part = self.flat.tail
         self._loss_buf = torch.zeros(3 + N.FINALIZE_SCRATCH, device=dev, dtype=dt)   # results | scratch
         self.loss_out = self._loss_buf[:3]
         self.adam_m = torch.zeros_like(self.flat.flat)
         self.adam_v = torch.zeros_like(self.flat.flat)
         self.step_dev = torch.zeros(1, device=dev, dtype=torch.int64)
-        self.p4 = torch.empty(d.B, d.N, 4, device=dev, dtype=dt)           # encoder input (p4 * scale)
-        # Chamfer target = the UNscaled batch (utils/train.py:285-292); aliases the input when scale == 1
-        self.target = self.p4 if encoder.scale == 1.0 else torch.empty_like(self.p4)
+        self.p4 = torch.empty(d.B, d.N, 4, device=dev, dtype=dt)           # encoder input (p4 * scale; with jet_features + the jet node)
+        # Chamfer target = the UNscaled batch (utils/train.py:285-292); aliases the input when scale == 1 and the nodes are the same
+        self.target = self.p4 if encoder.scale == 1.0 and not self.split else torch.empty(d.B, Nd, 4, device=dev, dtype=dt)
         self.mask = torch.empty(d.B, d.N, device=dev, dtype=torch.uint8)
+        K = max(1, encoder.tau_input_scalars)
+        self.in_scalars = torch.empty(d.B, d.N, K - 1, device=dev, dtype=dt) if K > 1 else None     # jet mass term, data['scalars']
         self.use_graph = use_graph
         self._g1 = self._g2 = None
 
@@ -329,6 +338,7 @@ class NativeTrainStep:
         N = self.N
         rc = N.lib().lgn_step_fwd_bwd_f64(C.byref(self.desc), N.ptr(self.flat.flat), N.ptr(self.flat.grad), self.flat.flat.numel(),
                                           self.enc_off, self.dec_off, N.ptr(self.p4), N.ptr(self.target), N.ptr(self.mask),
+                                          N.ptr(self.in_scalars) if self.in_scalars is not None else None,
                                           N.ptr(self.workspace), self.workspace.numel(), N.ptr(self.recon), N.ptr(self.loss_part),
                                           N.stream_ptr())
         N._check(rc, "lgn_step_fwd_bwd_f64")
@@ -349,6 +359,7 @@ class NativeTrainStep:
         N = self.N
         rc = N.lib().lgn_step_train_f64(C.byref(self.desc), N.ptr(self.flat.flat), N.ptr(self.flat.grad), self.flat.flat.numel(),
                                         self.enc_off, self.dec_off, N.ptr(self.p4), N.ptr(self.target), N.ptr(self.mask),
+                                        N.ptr(self.in_scalars) if self.in_scalars is not None else None,
                                         N.ptr(self.workspace), self.workspace.numel(), N.ptr(self.recon), N.ptr(self.loss_part),
                                         self.loss_part.numel(), float(self.l1_lambda), N.ptr(self.adam_m), N.ptr(self.adam_v),
                                         N.ptr(self.step_dev), float(self.lr), float(self.betas[0]), float(self.betas[1]),
@@ -417,9 +428,18 @@ class NativeTrainStep:
         """Stage a batch into the static input buffers (device-to-device copy; labels/masks as in
         LGNEncoder._prepare_input, lgn/models/lgn_encoder.py:386-398)."""
         p4 = batch["p4"]
-        if tuple(p4.shape) != tuple(self.p4.shape):
-            raise ValueError(f"NativeTrainStep was built for batches of shape {tuple(self.p4.shape)}, got {tuple(p4.shape)} "
+        if tuple(p4.shape) != tuple(self.target.shape):
+            raise ValueError(f"NativeTrainStep was built for batches of shape {tuple(self.target.shape)}, got {tuple(p4.shape)} "
                              "(static buffers / captured graph: pad or drop the last short batch)")
+        if self.split:
+            # jet node, jet-mass scalar, data['scalars']: the encoder's own input preparation (lgn_encoder.py:372-411), on the device
+            ps, mask, scalars = self.encoder._prepare_input(batch)
+            self.p4.copy_(ps)
+            self.mask.copy_(mask)
+            if self.in_scalars is not None:
+                self.in_scalars.copy_(scalars)
+            self.target.copy_(p4)
+            return
         if self.target is not self.p4:
             self.target.copy_(p4)
             torch.mul(self.target, self.encoder.scale, out=self.p4)
@@ -587,7 +607,8 @@ def native_train_step(encoder, decoder, batch_size: int, **kw):
     def only(cls):
         return {k: v for k, v in kw.items() if k in takes[cls]}
 
-    needs_modules = bool(kw.get("chamfer_jet_features") or kw.get("extra_scalars") or kw.get("get_real_method", "sum") != "sum")
+    # (extra_scalars: sizes CapturedModuleStep's buffers; NativeTrainStep reads the count off the encoder -- it does not force the module route)
+    needs_modules = bool(kw.get("chamfer_jet_features") or kw.get("get_real_method", "sum") != "sum")
     if not needs_modules:
         try:
             return NativeTrainStep(encoder, decoder, batch_size, **only(NativeTrainStep))

@@ -437,11 +437,13 @@ def test_reference_loop_step_matches_native_step(native_loss):
     U.assert_close(torch.cat([enc.flat_params.detach(), dec.flat_params.detach()]), ref.flat.flat, 1e-9, "parameters after 3 steps")
 
 
+@pytest.mark.parametrize("route", ["native", "captured"])
 @pytest.mark.parametrize("use_graph", [False, True])
-def test_captured_module_step_jet_features_matches_reference_golden(use_graph):
-    """CapturedModuleStep -- enc(batch) -> dec -> ChamferLoss -> backward() -> native L1 + Adam, captured into one HIP graph -- on the
-    configuration the whole-step call refuses (g10: jet_features, one more encoder node, two extra input scalars): the reference's
-    loss, reconstruction and gradients, eager and replayed."""
+def test_jet_features_step_matches_reference_golden(use_graph, route):
+    """g10 -- jet_features (one more encoder node than the decoder reconstructs) + an extra input scalar per node: the reference's
+    loss, reconstruction and gradients through the whole-step native call (round 6: lgn_net_desc.dec_N / in_scalars; what the chooser
+    takes) and through CapturedModuleStep (enc(batch) -> dec -> ChamferLoss -> backward() -> native L1 + Adam in one graph: the route
+    of round 5, still what --chamfer-jet-features and maxdim 3 with jet features get), eager and replayed."""
     import __graft_entry__ as G
     from lgn.step import CapturedModuleStep, NativeTrainStep, native_train_step
     dev = torch.device("cuda:0")
@@ -450,14 +452,16 @@ def test_captured_module_step_jet_features_matches_reference_golden(use_graph):
     enc, dec = G._models(m["N"], m["ch_enc"], m["ch_dec"], dev, seed=m["seed"], maxdim=m.get("maxdim", 2), jet_features=True,
                          tau_input_scalars=1 + m.get("extra_scalars", 0))
     enc.load_state_dict(U.params_from(z, "enc")); dec.load_state_dict(U.params_from(z, "dec"))
-    with pytest.raises(NotImplementedError, match="jet_features"):
-        NativeTrainStep(enc, dec, batch_size=m["B"])
     batch = {"p4": torch.from_numpy(z["p4"]).to(dev), "labels": torch.from_numpy(z["labels"]).to(dev)}
     if "scalars" in z.files:
         batch["scalars"] = torch.from_numpy(z["scalars"]).to(dev)
-    step = native_train_step(enc, dec, m["B"], l1_lambda=m["l1_lambda"], optimizer=False, use_graph=use_graph,
-                             extra_scalars=m.get("extra_scalars", 0))
-    assert isinstance(step, CapturedModuleStep)
+    if route == "native":
+        step = native_train_step(enc, dec, m["B"], l1_lambda=m["l1_lambda"], optimizer=False, use_graph=use_graph,
+                                 extra_scalars=m.get("extra_scalars", 0))
+        assert isinstance(step, NativeTrainStep) and step.split
+    else:
+        step = CapturedModuleStep(enc, dec, m["B"], l1_lambda=m["l1_lambda"], optimizer=False, use_graph=use_graph,
+                                  extra_scalars=m.get("extra_scalars", 0))
     for _ in range(3):
         total, recon = step.step(batch)
     U.assert_close(total, z["loss_total"], 1e-11, "total loss")
@@ -469,6 +473,36 @@ def test_captured_module_step_jet_features_matches_reference_golden(use_graph):
         for k, g in mod.named_grads():
             U.assert_close(g, torch.from_numpy(z[f"grad.{pre}.{k}"]) + lam * torch.sign(sd[k]), 1e-9, f"grad {pre}.{k}")
     assert step.launches_per_step == (1 if use_graph else None)
+
+
+@pytest.mark.parametrize("B,N,K,jet", [(64, 30, 2, True), (300, 30, 1, True), (7, 30, 3, False), (5, 70, 2, True)])
+def test_native_step_with_input_scalars_matches_module_path(B, N, K, jet):
+    """The split form of the whole-step call (jet_features and / or K - 1 extra input scalars) at the batch sizes that change the
+    launch geometry and at a jet size that takes the large-jet level kernels, against the module / autograd path on the same weights
+    (per-network native calls; the operators themselves are held to the oracle elsewhere)."""
+    import __graft_entry__ as G
+    from lgn.step import NativeTrainStep, TrainStep
+    from oracle import lgn_oracle as O
+    dev = torch.device("cuda:0")
+    che, chd = (3, 3, 4, 4), (4, 4, 3, 3)
+    # tau_input_scalars = mass + (K - 1) extra scalars; jet_features adds the jet-mass term (and the jet node) by itself
+    enc, dec = G._models(N, che, chd, dev, seed=5, jet_features=jet, tau_input_scalars=K)
+    enc2, dec2 = G._models(N, che, chd, dev, seed=5, jet_features=jet, tau_input_scalars=K)
+    p4, labels = O.synthetic_jets(B, N, seed=B, pad=True)
+    batch = {"p4": p4.to(dev), "labels": labels.to(dev)}
+    if K > 1:
+        g = torch.Generator().manual_seed(B + K)
+        batch["scalars"] = torch.randn(B, N + int(jet), K - 1, dtype=torch.float64, generator=g).to(dev)
+    a = NativeTrainStep(enc, dec, batch_size=B, optimizer=False, use_graph=True)
+    assert a.split
+    b = TrainStep(enc2, dec2, optimizer=False)
+    la, ra = a.step(batch)
+    la, ra = a.step(batch)                  # (the replay)
+    lb, rb = b.forward_backward(batch)
+    U.assert_close(la, lb, 1e-12, "loss")
+    U.assert_close(ra, rb, 1e-12, "recon")
+    U.assert_close(a.flat.grad, b.flat.grad, 1e-9, "flat gradient")
+    assert torch.isfinite(a.flat.grad).all()
 
 
 @pytest.mark.parametrize("case", ["sum", "mixed_maxdim"])

@@ -265,11 +265,13 @@ def test_native_step_refuses_configurations_it_does_not_implement():
         assert not enc._fused_ok()
         with pytest.raises(NotImplementedError, match="map_to_latent"):
             NativeTrainStep(enc, dec, batch_size=4)
-    # jet features / extra input scalars: the per-network native calls take them (lgn_net_desc.n_in_scalars, round 4), the whole-step
-    # call does not (its two networks share one particle count; the encoder has one node more here)
+    # jet features / extra input scalars: the per-network native calls take them (lgn_net_desc.n_in_scalars, round 4) and, for
+    # maxdim = 2 networks, the whole-step call (round 6: lgn_net_desc.dec_N -- the encoder has one node more here); table-driven
+    # networks with jet features are refused at plan time (-> CapturedModuleStep)
     enc, dec = G._models(12, (3, 3, 4, 4), (4, 4, 3, 3), torch.device("cpu"), seed=0, jet_features=True)
     assert enc.num_input_particles == 13 and enc.tau_input_scalars == 2 and enc._fused_ok()
     assert tuple(enc.input_func_node.weight((0, 0)).shape) == (2, 3, 2)
+    enc, dec = G._models(12, (3, 3, 4, 4), (4, 4, 3, 3), torch.device("cpu"), seed=0, jet_features=True, maxdim=3)
     with pytest.raises(NotImplementedError, match="jet_features"):
         NativeTrainStep(enc, dec, batch_size=4)
 
