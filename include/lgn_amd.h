@@ -271,6 +271,8 @@ typedef struct lgn_net_desc {
 #define LGN_NET_DEC_UNFUSED 256  /* LGN_AMD_DEC_UNFUSED=1: table-driven decoder levels as moments tensor + per-node kernels (the round-5
                                     sequence) instead of the fused separable form of csrc/generic_local_sep.hip; cross-check.  Changes
                                     the activation / scratch layouts: fixed in the descriptor like the others */
+#define LGN_NET_MOMENTS_SPLIT 512 /* LGN_AMD_MOMENTS_SPLIT=1: the encoder's table-driven level backward runs its two pair sweeps as two
+                                    kernels (moments_bwd_nodes2 + moments_bwd_G2: the round-5 form) instead of the merged one; cross-check */
 #define LGN_NET_SPLIT_TAIL 128   /* LGN_AMD_SPLIT_TAIL=1: the tail of a step (deferred reductions, radial finalisation, L1 + Adam) as the
                                     three separate launches instead of csrc/step_tail.hip's one (cross-check; bit-identical) */
 

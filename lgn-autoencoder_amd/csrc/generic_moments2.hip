@@ -145,6 +145,44 @@ __device__ __forceinline__ void fill_R(const GenArgs& a, int c, const Jet& J, in
   }
 }
 
+// Encoder: the radial functions see a pair through |p_i - p_j|^2 and the two masks only, R(i, j) = R(j, i): the table for i <= j at
+// tri_index(i, j), one thread per UNORDERED pair -- half the radial evaluations (a third of the forward kernel's instructions) and
+// half the LDS of fill_R.  Same arithmetic per pair ((p_i - p_j)^2 is the same number either way round).
+__device__ __forceinline__ int tri_index(int i, int j) {
+  const int lo = i < j ? i : j, hi = i < j ? j : i;
+  return hi * (hi + 1) / 2 + lo;
+}
+__device__ __forceinline__ void fill_R_sym(const GenArgs& a, const Jet& J) {
+  const int N = a.N, NU = N * (N + 1) / 2;
+  for (int u = threadIdx.x; u < NU; u += BLOCK) {
+    int hi = (int)((sqrt(8.0 * (double)u + 1.0) - 1.0) * 0.5);
+    while ((hi + 1) * (hi + 2) / 2 <= u) ++hi;
+    while (hi * (hi + 1) / 2 > u) --hi;
+    const int lo = u - hi * (hi + 1) / 2;
+    const double* pi = J.pj + lo * 4;
+    const double* pq = J.pj + hi * 4;
+    const double d0 = pi[0] - pq[0], d1 = pi[1] - pq[1], d2 = pi[2] - pq[2], d3 = pi[3] - pq[3];
+    const double q0 = d0 * d0, q1 = d1 * d1, q2 = d2 * d2, q3 = d3 * d3;
+    const double nsq = (2.0 * q0 - (((q0 + q1) + q2) + q3)) + 1e-16;
+    const double an = fabs(nsq);
+    const bool on = J.mk[lo] != 0 && J.mk[hi] != 0 && nsq != 0.0;
+    double r0 = J.wl[NB * 8 + 0], r1 = J.wl[NB * 8 + 1], r2 = J.wl[NB * 8 + 2], r3 = J.wl[NB * 8 + 3];
+    if (on) {
+#pragma unroll 4
+      for (int k = 0; k < NB; ++k) {
+        const double* w = J.wl + k * 8;
+        const double beta = __builtin_fma(w[1], fast_rcp((1.0 + w[2] * an) + 1e-16), w[0]);
+        r0 = __builtin_fma(w[4], beta, r0);
+        r1 = __builtin_fma(w[5], beta, r1);
+        r2 = __builtin_fma(w[6], beta, r2);
+        r3 = __builtin_fma(w[7], beta, r3);
+      }
+    }
+    double* r = J.Rl + (size_t)u * 4;
+    r[0] = r0; r[1] = r1; r[2] = r2; r[3] = r3;
+  }
+}
+
 // canonical components of p_i - p_j (encoder: real Cartesian input; decoder: complex canonical input)
 template <bool DEC>
 __device__ __forceinline__ void rel_q(const double* pi, const double* pq, cx<double> (&q)[4]) {
@@ -177,8 +215,8 @@ __global__ __launch_bounds__(BLOCK) void moments_fwd2_kernel(GenArgs a) {
   const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   extern __shared__ __align__(16) unsigned char smem_raw[];
   Jet J;
-  J.Rl = reinterpret_cast<double*>(smem_raw);                  // N * RP * 4
-  double* xs = J.Rl + (size_t)N * RP * 4;                      // [N][Q][2] of the current channel
+  J.Rl = reinterpret_cast<double*>(smem_raw);                  // decoder: N * RP * 4; encoder: the pairs i <= j only (fill_R_sym)
+  double* xs = J.Rl + (DEC ? (size_t)N * RP * 4 : (size_t)(N * (N + 1) / 2) * 4);      // [N][Q][2] of the current channel
   J.pj = xs + (size_t)N * Q * 2;
   J.wl = J.pj + (size_t)N * PS;
   J.mk = reinterpret_cast<uint8_t*>(J.wl + NB * 8 + 4);
@@ -201,7 +239,8 @@ __global__ __launch_bounds__(BLOCK) void moments_fwd2_kernel(GenArgs a) {
       }
     }
     __syncthreads();
-    fill_R<DEC>(a, c, J, RP);
+    if (DEC) fill_R<DEC>(a, c, J, RP);
+    else fill_R_sym(a, J);
     __syncthreads();
     for (int q0 = wave * QPT; q0 < Q; q0 += 4 * QPT) {         // wave-uniform
       cx<double> acc[QPT][5];
@@ -215,7 +254,7 @@ __global__ __launch_bounds__(BLOCK) void moments_fwd2_kernel(GenArgs a) {
       for (int j = jb; j < je; ++j) {
         cx<double> q[4], e[5];
         rel_q<DEC>(pi, J.pj + j * PS, q);
-        edge_from_R(J.Rl + ((size_t)ii * RP + j) * 4, q, e);
+        edge_from_R(J.Rl + (DEC ? ((size_t)ii * RP + j) : (size_t)tri_index(ii, j)) * 4, q, e);
         const double* xj = xs + ((size_t)j * Q + q0) * 2;
 #pragma unroll
         for (int x = 0; x < QPT; ++x) {
@@ -473,6 +512,133 @@ __global__ __launch_bounds__(BLOCK) void moments_bwd_G2_kernel(GenArgs a, double
   }
 }
 
+
+// =========================================================================================================
+// encoder backward, both sweeps in ONE kernel (round 6).  moments_bwd_nodes2 and moments_bwd_G2 each staged the same 48 KB slice of
+// dU (147 MB per level at cfg5) and ran one sweep over it; side by side their LDS images do not fit two workgroups per CU (the
+// pair table alone is 29 KB).  The radial functions depend on the pair through |p_i - p_j|^2 and the two masks only: R(i, j) =
+// R(j, i) -- the table is kept for i <= j (15 KB, half the radial evaluations), and one staging of dU and X serves
+//   sweep 1 (j-centric):  dX[j][q] += sum_i sum_k dU[i][q][k] conj(e_k(i, j))
+//   sweep 2 (i-centric):  G_k(i, j) = sum_q dU[i][q][k] conj(X_j[q])  ->  Gbuf (moments_rad_reduce2_kernel)
+// with the arithmetic of the two kernels above, term for term.
+// =========================================================================================================
+template <int QPT>
+__global__ __launch_bounds__(BLOCK) void moments_bwd_enc2_kernel(GenArgs a, double* Gbuf) {
+  const int N = a.N, B = a.B, Q = a.Q, C = a.C;
+  const int b = blockIdx.x, c = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int GS = g2_row_pitch(Q), NU = N * (N + 1) / 2;
+  Jet J;
+  J.Rl = reinterpret_cast<double*>(smem_raw);                  // [NU][4]: R(i, j) for i <= j at tri_index(i, j)
+  double* gu = J.Rl + (size_t)NU * 4;                          // [N][GS]: (q, k, plane) of row n
+  double* xs = gu + (size_t)N * GS;                            // [N][Q][2]
+  J.pj = xs + (size_t)N * Q * 2;
+  J.wl = J.pj + (size_t)N * 4;
+  J.mk = reinterpret_cast<uint8_t*>(J.wl + NB * 8 + 4);
+  load_jet<false>(a, b, J);
+  load_channel_consts(a, c, J.wl);
+  const size_t plane = (size_t)B * N * C * Q;
+  if (a.tb) {
+    stage_tb(a.gU, 5 * Q, C, c, b, N, gu, GS);
+    stage_tb(a.X, Q, C, c, b, N, xs, 2 * Q);
+  } else {
+    for (int e = tid; e < N * Q * 10; e += BLOCK) {
+      const int n = e / (Q * 10), r = e - n * Q * 10;
+      gu[(size_t)n * GS + r] = a.gU[(((size_t)b * N + n) * C + c) * Q * 10 + r];
+    }
+    for (int e = tid; e < N * Q; e += BLOCK) {
+      const int q = e % Q, n = e / Q;
+      xs[2 * (n * Q + q)] = a.X[feat_index(false, plane, C, Q, b * N + n, c, q, 0)];
+      xs[2 * (n * Q + q) + 1] = a.X[feat_index(false, plane, C, Q, b * N + n, c, q, 1)];
+    }
+  }
+  __syncthreads();
+  fill_R_sym(a, J);
+  __syncthreads();
+  // ---- sweep 1, j-centric: lane = (node j, half of the source range), wave = group of QPT components ----
+  {
+    const int half = lane & 1, j = lane >> 1;
+    const bool jok = j < N;
+    const int jj = jok ? j : N - 1;
+    const int imid = (N + 1) >> 1, ib = half ? imid : 0, ie = half ? N : imid;
+    double pme[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) pme[m] = J.pj[jj * 4 + m];
+    for (int q0 = wave * QPT; q0 < Q; q0 += 4 * QPT) {
+      cx<double> acc[QPT];
+#pragma unroll
+      for (int x = 0; x < QPT; ++x) acc[x] = {0, 0};
+      for (int i = ib; i < ie; ++i) {
+        cx<double> q[4], e[5];
+        rel_q<false>(J.pj + i * 4, pme, q);
+        edge_from_R(J.Rl + (size_t)tri_index(i, jj) * 4, q, e);
+        const double* gi = gu + (size_t)i * GS + q0 * 10;
+#pragma unroll
+        for (int x = 0; x < QPT; ++x) {
+          if (q0 + x < Q) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+              const cx<double> gv = {gi[(x * 5 + k) * 2], gi[(x * 5 + k) * 2 + 1]};
+              cfmac(acc[x], gv, e[k]);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int x = 0; x < QPT; ++x) {
+        const double sr = pair_sum(acc[x].r), si = pair_sum(acc[x].i);
+        if (half == 0 && jok && q0 + x < Q) {
+          a.gX[feat_index(a.tb, plane, C, Q, b * N + j, c, q0 + x, 0)] += sr;
+          a.gX[feat_index(a.tb, plane, C, Q, b * N + j, c, q0 + x, 1)] += si;
+        }
+      }
+    }
+  }
+  // ---- sweep 2, i-centric: lane = (row i, partner group), the gradient of the pair's radial values ----
+  {
+    const int grp = wave * 2 + (lane & 1), i = lane >> 1;        // 8 partner groups
+    const bool iok = i < N;
+    const int ii = iok ? i : N - 1;
+    const int per = (N + 7) >> 3, jb = grp * per, je = min(N, jb + per);
+    double pi[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) pi[m] = J.pj[ii * 4 + m];
+    const double* gi = gu + (size_t)ii * GS;
+    constexpr int JP = (MAXN + 7) / 8;
+    cx<double> ge[JP][5];
+#pragma unroll
+    for (int t = 0; t < JP; ++t)
+#pragma unroll
+      for (int k = 0; k < 5; ++k) ge[t][k] = {0, 0};
+    for (int x = 0; x < Q; ++x) {
+      cx<double> gv[5];
+#pragma unroll
+      for (int k = 0; k < 5; ++k) gv[k] = {gi[x * 10 + 2 * k], gi[x * 10 + 2 * k + 1]};
+#pragma unroll
+      for (int t = 0; t < JP; ++t) {
+        const int j = min(jb + t, N - 1);
+        const cx<double> xv = {xs[((size_t)j * Q + x) * 2], xs[((size_t)j * Q + x) * 2 + 1]};
+#pragma unroll
+        for (int k = 0; k < 5; ++k) cfmac(ge[t][k], gv[k], xv);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < JP; ++t) {
+      const int j = jb + t;
+      if (j >= je || !iok) continue;
+      cx<double> q[4];
+      rel_q<false>(pi, J.pj + j * 4, q);
+      cx<double> gR1 = {0, 0};
+#pragma unroll
+      for (int m = 0; m < 4; ++m) cfmac(gR1, ge[t][1 + m], q[m]);
+      double* g = Gbuf + (((size_t)b * N * N + (size_t)i * N + j) * C + c) * 4;
+      g[0] = ge[t][0].r + ge[t][0].i;             // e0 = R0 (1 + i)  ->  G_R0 = G_e0 conj(1 + i)
+      g[1] = ge[t][0].i - ge[t][0].r;
+      g[2] = gR1.r;
+      g[3] = gR1.i;
+    }
+  }
+}
 
 // =========================================================================================================
 // decoder in separable form (SURVEY a-14; the same algebraic change as the SEP instantiations of level_fwd2 / level_bwd3 at
@@ -856,7 +1022,8 @@ static int launch(const GenArgs& a, int which, double* Gbuf, hipStream_t st) {
   const dim3 grid(a.B, DEC ? 1 : a.C);
   int rc;
   if (which == 0) {
-    const size_t smem = base_smem(a, DEC, row_pitch(a.N)) + xs;
+    // (encoder: the symmetric pair table, N (N + 1) / 2 entries instead of N x pitch)
+    const size_t smem = base_smem(a, DEC, row_pitch(a.N)) + xs - (DEC ? 0 : sizeof(double) * 4 * ((size_t)a.N * row_pitch(a.N) - (size_t)(a.N * (a.N + 1) / 2)));
     if (a.Q <= 8) {
       auto k = moments_fwd2_kernel<DEC, 2>;
       if ((rc = set_smem(k, smem, "moments_fwd2"))) return rc;
@@ -881,6 +1048,28 @@ static int launch(const GenArgs& a, int which, double* Gbuf, hipStream_t st) {
     const size_t smem = base_smem(a, DEC, 0) + sizeof(double) * (size_t)a.N * g2_row_pitch(a.Q) + xs + (DEC ? sizeof(double) * (8 * a.N * 8 + 8 * 2 * 8) : 0);
     auto k = moments_bwd_G2_kernel<DEC>;
     if ((rc = set_smem(k, smem, "moments_bwd_G2"))) return rc;
+    hipLaunchKernelGGL(k, grid, dim3(BLOCK), smem, st, a, Gbuf);
+  }
+  LGN_CHECK_LAUNCH();
+  return 0;
+}
+
+// encoder backward, both sweeps (moments_bwd_enc2_kernel): LDS = symmetric pair table + padded dU rows + X + jet data
+static size_t enc2_smem(const GenArgs& a) {
+  return sizeof(double) * ((size_t)(a.N * (a.N + 1) / 2) * 4 + (size_t)a.N * g2_row_pitch(a.Q) + (size_t)a.N * a.Q * 2 + (size_t)a.N * 4 + NB * 8 + 4) +
+         a.N + 16;
+}
+static int launch_enc2(const GenArgs& a, double* Gbuf, hipStream_t st) {
+  const size_t smem = enc2_smem(a);
+  const dim3 grid(a.B, a.C);
+  int rc;
+  if (a.Q <= 8) {
+    auto k = moments_bwd_enc2_kernel<2>;
+    if ((rc = set_smem(k, smem, "moments_bwd_enc2"))) return rc;
+    hipLaunchKernelGGL(k, grid, dim3(BLOCK), smem, st, a, Gbuf);
+  } else {
+    auto k = moments_bwd_enc2_kernel<5>;
+    if ((rc = set_smem(k, smem, "moments_bwd_enc2"))) return rc;
     hipLaunchKernelGGL(k, grid, dim3(BLOCK), smem, st, a, Gbuf);
   }
   LGN_CHECK_LAUNCH();
@@ -933,9 +1122,14 @@ int moments2_dispatch(const GenArgs& a, int decoder, int which, double* Gbuf, hi
     LGN_CHECK_LAUNCH();
     return 0;
   }
-  if (which != 2) return m2::launch<false>(a, which, nullptr, st);
+  // encoder backward: ONE kernel for both sweeps (which = 1; which = 2 is then the radial-parameter reduction alone) unless the
+  // caller asks for the two-kernel form (LVL_MOMENTS_SPLIT: cross-check) or has no pair-gradient scratch for pass 1
+  const bool merged = Gbuf && !(a.flags & LVL_MOMENTS_SPLIT);
+  if (which == 0) return m2::launch<false>(a, 0, nullptr, st);
+  if (which == 1) return merged ? m2::launch_enc2(a, Gbuf, st) : m2::launch<false>(a, 1, nullptr, st);
   LGN_CHECK_ARG(Gbuf, "moments: the encoder's radial backward needs the pair-gradient scratch buffer");
-  if (int rc = m2::launch<false>(a, 2, Gbuf, st)) return rc;
+  if (!merged)
+    if (int rc = m2::launch<false>(a, 2, Gbuf, st)) return rc;
 #define LGN_CASE(CC) case CC: return m2::launch_reduce<CC>(a, Gbuf, st);
   switch (a.C) {
     LGN_CASE(1) LGN_CASE(2) LGN_CASE(3) LGN_CASE(4) LGN_CASE(5) LGN_CASE(6) LGN_CASE(7) LGN_CASE(8)

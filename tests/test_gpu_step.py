@@ -110,12 +110,13 @@ def test_native_step_maxdim2_alternative_kernels(flags, use_graph, monkeypatch):
             U.assert_close(g, ref, 1e-9, f"grad {pre}.{k}")
 
 
-@pytest.mark.parametrize("flag", ["LGN_AMD_NO_STATIC", "LGN_AMD_DEC_PAIRWISE", "LGN_AMD_MOMENTS_V1", "LGN_AMD_DEC_UNFUSED"])
+@pytest.mark.parametrize("flag", ["LGN_AMD_NO_STATIC", "LGN_AMD_DEC_PAIRWISE", "LGN_AMD_MOMENTS_V1", "LGN_AMD_DEC_UNFUSED", "LGN_AMD_MOMENTS_SPLIT"])
 def test_native_step_maxdim3_alternative_kernels(flag, monkeypatch):
     """The table-driven (maxdim 3) native step through its cross-check kernels: run-time-table local kernels instead of the
     compile-time-table ones (LGN_AMD_NO_STATIC), decoder moments as pair sweeps instead of the separable jet sums
     (LGN_AMD_DEC_PAIRWISE), component-chunked moments kernels (LGN_AMD_MOMENTS_V1), the decoder's moments as a tensor between two
-    kernels per level instead of the fused separable form of round 6 (LGN_AMD_DEC_UNFUSED).  Same golden vectors, same tolerances;
+    kernels per level instead of the fused separable form of round 6 (LGN_AMD_DEC_UNFUSED), the encoder's two backward pair sweeps as
+    two kernels instead of the merged one (LGN_AMD_MOMENTS_SPLIT).  Same golden vectors, same tolerances;
     the switches are read per call, so the step object is built after setting them (the workspace is sized per form)."""
     from lgn.step import NativeTrainStep
     monkeypatch.setenv(flag, "1")
