@@ -162,9 +162,13 @@ __global__ __launch_bounds__(128) void local_bwd_static_kernel(StaticBwdArgs a) 
   __syncthreads();
   const double* xl = xs + 2 * lane;
   double* gxl = gxs[wave] + 2 * lane;
+  // (round 6, in-kernel stamps of the 6 -> 6 level: wave 0 141 k cycles, wave 1 113 k -- the last four product blocks of irrep 0, 13 k,
+  // moved to wave 1 for the later levels; the first level keeps the round-3 split)
+  constexpr int B0 = T::Q == 20 ? T::NBLK[0] - 4 : T::NBLK[0];
+  static_assert(B0 >= T::NUBLK[0], "wave 1 takes product blocks only");
   if (wave == 0) {
     SSTAMP(0);
-    irrep_bwd<T, 0, 0, T::NBLK[0], COT>(a, tile, lane, c, xl, gxl);
+    irrep_bwd<T, 0, 0, B0, COT>(a, tile, lane, c, xl, gxl);
     SSTAMP(1);
     irrep_bwd<T, 1, 0, T::NBLK[1] - 1, COT>(a, tile, lane, c, xl, gxl);
     SSTAMP(2);
@@ -182,6 +186,7 @@ __global__ __launch_bounds__(128) void local_bwd_static_kernel(StaticBwdArgs a) 
     SSTAMP(12);
     irrep_bwd<T, 4, T::NUBLK[4], T::NBLK[4], COT>(a, tile, lane, c, xl, gxl);
     irrep_bwd<T, 1, T::NBLK[1] - 1, T::NBLK[1], COT>(a, tile, lane, c, xl, gxl);
+    irrep_bwd<T, 0, B0, T::NBLK[0], COT>(a, tile, lane, c, xl, gxl);
     SSTAMP(13);
   }
   __syncthreads();
