@@ -26,7 +26,7 @@ using namespace lsd;
 LGN_STAMP_DECL
 #ifdef LGN_STAMPS
 // (first workgroup of the Q = 20 levels: the heavy ones; wave 0 stamps 0.., wave 1 stamps 16..)
-#define PSTAMP(i) do { if (T::Q == 20 && (threadIdx.x & 63) == 0 && blockIdx.x == 0 && blockIdx.y == 0) g_stamps[i] = clock64(); } while (0)
+#define PSTAMP(i) do { if (T::Q == 20 && (threadIdx.x & 63) == 0 && blockIdx.x == 0) g_stamps[i] = clock64(); } while (0)
 #else
 #define PSTAMP(i) do { } while (0)
 #endif
@@ -348,8 +348,10 @@ __global__ __launch_bounds__(128) void local_bwd_sep_kernel(StaticBwdArgs a) {
   double* pl = tab + 2 * Q * 12;          // [64 lanes][8]
   double* gpl = pl + 64 * 8;              // [64 lanes][8]
   double* sraw = gpl + 64 * 8;            // [2 halves][VT]; after the walk: the jet sums, then wave 1's tail sums [64][8] + [2 halves][4]
-  const int c = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, C = a.C, CO = a.CO, N = a.N;
-  const int half = lane >> 5, j = lane & 31, jet = 2 * blockIdx.x + half;
+  int pair, c;
+  if (!xcd_index((a.B + 1) >> 1, a.C, pair, c)) return;            // (workgroup-uniform: before any barrier)
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, C = a.C, CO = a.CO, N = a.N;
+  const int half = lane >> 5, j = lane & 31, jet = 2 * pair + half;
   const bool valid = jet < a.B && j < N;
   const int node = valid ? jet * N + j : (jet < a.B ? jet * N : a.M - 1);      // (an idle lane points at a valid node; it never stores)
   const size_t tile = (size_t)(node >> 6), l64 = (size_t)(node & 63);
@@ -365,7 +367,7 @@ __global__ __launch_bounds__(128) void local_bwd_sep_kernel(StaticBwdArgs a) {
       gxw[q * 128 + 2 * lane + 1] = 0.0;
     }
     for (int e = threadIdx.x; e < 2 * Q * 12; e += 128) {
-      const int h = e / (Q * 12), r = e - h * Q * 12, jh = 2 * blockIdx.x + h < a.B ? 2 * blockIdx.x + h : a.B - 1;
+      const int h = e / (Q * 12), r = e - h * Q * 12, jh = 2 * pair + h < a.B ? 2 * pair + h : a.B - 1;
       tab[e] = a.tbl[(((size_t)jh * C + c) * Q + r / 12) * TBL_STRIDE + r % 12];
     }
     if (wave == 0) {
@@ -383,7 +385,7 @@ __global__ __launch_bounds__(128) void local_bwd_sep_kernel(StaticBwdArgs a) {
   {
     double* gxl = gxs + wave * Q * 128 + 2 * lane;
     const double* __restrict__ got = a.goT + tile * CO * QO * 128 + l64;
-    double* __restrict__ part0 = a.part + (size_t)blockIdx.x * a.n_packed;
+    double* __restrict__ part0 = a.part + (size_t)pair * a.n_packed;
     if (wave == 0) {
       PSTAMP(0);
       irrep_bwd_sep<T, 0, 0, T::NUBLK[0], COT>(a, c, got, part0, w, xl, gxl, lane, valid);
@@ -420,7 +422,7 @@ __global__ __launch_bounds__(128) void local_bwd_sep_kernel(StaticBwdArgs a) {
 #pragma unroll
     for (int r = 0; r < PERR; ++r) {
       const int e = threadIdx.x + 128 * r, ee = e < 2 * Q * 10 ? e : 0, h = ee / (Q * 10), x = ee - h * Q * 10;
-      const int jh = 2 * blockIdx.x + h < a.B ? 2 * blockIdx.x + h : a.B - 1;
+      const int jh = 2 * pair + h < a.B ? 2 * pair + h : a.B - 1;
       rawv[r] = a.tbl[(((size_t)jh * C + c) * Q + x / 10) * TBL_STRIDE + 12 + x % 10];
     }
     double mine[PER];
@@ -569,7 +571,7 @@ int local_bwd_sep(int kind, int B, int N, int C, int CO, const double* XT, const
   a.n_packed = (int)local_static_packed_doubles(kind, C, CO);
   a.tbl = tbl; a.pc = pc; a.b0 = b0; a.b1 = b1; a.gpb = gpb; a.part_rad = part_rad; a.B = B; a.N = N;
   for (int l = 0; l < 5; ++l) a.wp0[l] = p.wp0[l];
-  dim3 grid(local_sep_part_rows(B), C);
+  dim3 grid(xcd_grid(local_sep_part_rows(B), C));
 #define LGN_LAUNCH(KIND, COT)                                                                                                   \
   do {                                                                                                                          \
     const size_t smem = sep_lds_bytes<cgs::KIND>();                                                                             \

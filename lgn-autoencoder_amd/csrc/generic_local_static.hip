@@ -24,7 +24,7 @@ namespace {
 using namespace lsd;
 LGN_STAMP_DECL
 #ifdef LGN_STAMPS
-#define SSTAMP(i) do { if ((threadIdx.x & 63) == 0 && blockIdx.x == 0 && blockIdx.y == 0) g_stamps[i] = clock64(); } while (0)
+#define SSTAMP(i) do { if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) g_stamps[i] = clock64(); } while (0)
 #else
 #define SSTAMP(i) do { } while (0)
 #endif
@@ -146,7 +146,9 @@ __global__ __launch_bounds__(128) void local_bwd_static_kernel(StaticBwdArgs a) 
   constexpr int Q = T::Q;
   __shared__ double xs[Q * 128];                       // this channel's features, lane-private columns [q][lane][2]
   __shared__ double gxs[2][Q * 128];                   // d X per wave, same layout
-  const int tile = blockIdx.x, c = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, C = a.C;
+  int tile, c;
+  if (!xcd_index((a.M + 63) >> 6, a.C, tile, c)) return;           // (workgroup-uniform: before any barrier)
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, C = a.C;
   {
     const double* __restrict__ xc = a.XT + ((size_t)tile * C + c) * Q * 128;
     for (int e = threadIdx.x; e < Q * 128; e += 128) {
@@ -242,6 +244,8 @@ __global__ __launch_bounds__(BLOCK) void pack_batch_kernel(PackBatch b, int unpa
   }
 }
 
+// (the forward's twelve items of a tile re-read its features and moments as well, but giving THEM neighbouring ids was measured slower
+// -- 49 / 79 -> 53 / 86 us at cfg5: a CU then holds workgroups of several items, i.e. several straight-line code images)
 // items of a level kind: every output irrep in chunks of <= 2 rows (few accumulators: two waves per SIMD); both kinds have output dims 4,3,3,9,1
 constexpr int N_ITEMS = 12;
 template <class T, int COT>
@@ -315,7 +319,7 @@ int local_bwd_static(int kind, int M, int C, int CO, const double* XT, const dou
   }
   StaticBwdArgs a{M, C, CO, XT, UT, wp, {0, 0, 0, 0, 0, 0, 0, 0}, goT, gUT, gXT, part, (int)local_static_packed_doubles(kind, C, CO)};
   for (int l = 0; l < 5; ++l) a.wp0[l] = p.wp0[l];
-  dim3 grid(cdiv(M, 64), C);
+  dim3 grid(xcd_grid(cdiv(M, 64), C));
 #define LGN_LAUNCH(KIND, COT) hipLaunchKernelGGL((local_bwd_static_kernel<cgs::KIND, COT>), grid, dim3(128), 0, st, a)
   if (kind == 1) { if (CO <= 4) LGN_LAUNCH(Kind1, 4); else if (CO <= 6) LGN_LAUNCH(Kind1, 6); else LGN_LAUNCH(Kind1, 8); }
   else { if (CO <= 4) LGN_LAUNCH(Kind2, 4); else if (CO <= 6) LGN_LAUNCH(Kind2, 6); else LGN_LAUNCH(Kind2, 8); }

@@ -11,6 +11,19 @@ namespace lsd {
 
 constexpr int COMAX = 8;
 
+// XCD-aware workgroup index.  A tile's ny workgroups (its input channels in the backward kernels) all read the tile's upstream
+// gradient; dealt as grid (tiles, ny) they are ny x tiles ids apart: the re-reads come from HBM (PMC: 118 of the 147 MB a decoder
+// backward launch fetched at cfg5).  Consecutive linear ids go round-robin to the 8 XCDs, each with its own L2, so the ny workgroups
+// of a tile get ids that are congruent mod 8 and at most 8 ny apart: id = (x / 8) 8 ny + y 8 + x % 8.  Grid: 1-D, xcd_grid(nx, ny)
+// workgroups; xcd_index returns false for the padding ids of the last group of 8.
+__host__ __device__ inline int xcd_grid(int nx, int ny) { return ((nx + 7) / 8) * 8 * ny; }
+__device__ __forceinline__ bool xcd_index(int nx, int ny, int& x, int& y) {
+  const int id = blockIdx.x, grp = id / (8 * ny), r = id - grp * 8 * ny;
+  y = r >> 3;
+  x = grp * 8 + (r & 7);
+  return x < nx;
+}
+
 // Separable decoder moments (round 6): instead of the moments tensor U, a table of jet-level sums written by dec_sep_tab
 // (generic_moments_sep.hip): entry (jet b, channel c, component q) = TBL_STRIDE doubles
 //   [0,1] E = e0 SX    [2,3] A = R1 SX    [4 + 2m, 5 + 2m] B_m = R1 SXP_m    [12,13] SX    [14 + 2m, 15 + 2m] SXP_m      (m = 0..3)
