@@ -181,7 +181,7 @@ __device__ __forceinline__ void sep_reduce(const SepWalk& w, const cx<double> (&
 template <class T, int L, int BLK, int BEND, int COT>
 __device__ __forceinline__ void blocks_bwd_sep(const cx<double> (&go)[COT][T::DIM[L]], cx<double> (&wn)[COT],
                                                const double __attribute__((address_space(4))) * wc, const SepWalk& w,
-                                               const double* xl, double* gxl, double* __restrict__ part, int lane, bool valid) {
+                                               const double* xl, double* gxl, const DwOut& part, int lane, bool valid) {
   constexpr int D = T::DIM[L], ROWB = T::ROW0[L] + BLK * D;
   if constexpr (BLK < BEND) {
     constexpr int A0 = blk_lo<T>(ROWB, D, 0), A1 = blk_hi<T>(ROWB, D, 0), B0 = blk_lo<T>(ROWB, D, 1), B1 = blk_hi<T>(ROWB, D, 1);
@@ -212,7 +212,7 @@ __device__ __forceinline__ void blocks_bwd_sep(const cx<double> (&go)[COT][T::DI
     rows_bwd<T, ROWB, 0, D, COT, A0, NA, B0, NB, NU1>(go, wv, UvLds{w}, gu, xa, ga, xb, gb, dw);
     if constexpr (A1 > A0) gx_flush<NA>(gxl, A0, ga);
     if constexpr (B1 > B0) gx_flush<NB>(gxl, B0, gb);
-    wave_sum_store<2 * COT>(dw, part + BLK * COT * 2, lane);
+    dw_store<2 * COT>(dw, part, BLK, lane);
     __builtin_amdgcn_sched_barrier(0);
     sep_reduce<T, L, BLK, NU1>(w, gu, lane);
     __builtin_amdgcn_sched_barrier(0);
@@ -230,7 +230,7 @@ __device__ __forceinline__ void irrep_bwd_sep(const StaticBwdArgs& a, int c, con
     const int CO = a.CO;
     typedef const double __attribute__((address_space(4))) * cptr;
     cptr wc = (cptr)(a.wp + a.wp0[L]) + (size_t)c * NB * COT * 2;
-    double* __restrict__ part = part0 + a.wp0[L] + (size_t)c * NB * COT * 2;
+    const DwOut part = dw_out<COT>(a, part0, L, NB, c, lane);
     cx<double> go[COT][D];
 #pragma unroll
     for (int o = 0; o < COT; ++o) {
@@ -558,8 +558,8 @@ int local_fwd_sep(int kind, int B, int N, int C, int CO, const double* XT, const
 // backward of a decoder level: per-node part AND separable moments in one launch.  part: local_sep_part_rows(B) rows of packed
 // CatMix partial gradients; gpb [C][B N][8] and part_rad [B][2 C]: every entry written; gXT: written for every node
 int local_bwd_sep(int kind, int B, int N, int C, int CO, const double* XT, const double* tbl, const double* pc, const double* b0,
-                  const double* b1, const double* wp, const double* goT, double* gXT, double* part, double* gpb, double* part_rad,
-                  hipStream_t st) {
+                  const double* b1, const double* wp, const int* w0p, const double* goT, double* gXT, double* part, double* gpb,
+                  double* part_rad, hipStream_t st) {
   LGN_CHECK_ARG(kind == 1 || kind == 2, "local_bwd_sep: unknown level kind %d", kind);
   LGN_CHECK_ARG(B > 0 && N > 0 && N <= 32 && C >= 1 && C <= 8 && CO >= 1 && CO <= COMAX,
                 "local_bwd_sep: unsupported shape (B=%d N=%d C=%d CO=%d)", B, N, C, CO);
@@ -570,7 +570,8 @@ int local_bwd_sep(int kind, int B, int N, int C, int CO, const double* XT, const
   a.M = B * N; a.C = C; a.CO = CO; a.XT = XT; a.wp = wp; a.goT = goT; a.gXT = gXT; a.part = part;
   a.n_packed = (int)local_static_packed_doubles(kind, C, CO);
   a.tbl = tbl; a.pc = pc; a.b0 = b0; a.b1 = b1; a.gpb = gpb; a.part_rad = part_rad; a.B = B; a.N = N;
-  for (int l = 0; l < 5; ++l) a.wp0[l] = p.wp0[l];
+  for (int l = 0; l < 5; ++l) { a.wp0[l] = p.wp0[l]; a.w0[l] = w0p ? w0p[l] : 0; }
+  a.param_layout = w0p ? 1 : 0;          // (w0p: the irreps' offsets in the CatMix parameter block -> partial rows in parameter layout)
   dim3 grid(xcd_grid(local_sep_part_rows(B), C));
 #define LGN_LAUNCH(KIND, COT)                                                                                                   \
   do {                                                                                                                          \

@@ -52,7 +52,7 @@ __device__ __forceinline__ void blocks_bwd(const cx<double> (&go)[COT][T::DIM[L]
                                            const double __attribute__((address_space(4))) * wc, const double* __restrict__ uc,
                                            double* guc, const cx<double> (&uv)[blk_nu1<T>(L, BLK)],
                                            const cx<double> (&gold)[blk_nu1<T>(L, BLK)], const double* xl, double* gxl,
-                                           double* __restrict__ part, int lane, bool valid) {
+                                           const DwOut& part, int lane, bool valid) {
   constexpr int D = T::DIM[L], ROWB = T::ROW0[L] + BLK * D;
   if constexpr (BLK < BEND) {
     constexpr int A0 = blk_lo<T>(ROWB, D, 0), A1 = blk_hi<T>(ROWB, D, 0), B0 = blk_lo<T>(ROWB, D, 1), B1 = blk_hi<T>(ROWB, D, 1);
@@ -94,7 +94,7 @@ __device__ __forceinline__ void blocks_bwd(const cx<double> (&go)[COT][T::DIM[L]
       guc[e * 128] = gu[k].r;
       guc[e * 128 + 64] = gu[k].i;
     }
-    wave_sum_store<2 * COT>(dw, part + BLK * COT * 2, lane);
+    dw_store<2 * COT>(dw, part, BLK, lane);
     __builtin_amdgcn_sched_barrier(0);
     blocks_bwd<T, L, BLK + 1, BEND, COT>(go, wn, wc, uc, guc, uvn, goldn, xl, gxl, part, lane, valid);
   }
@@ -114,7 +114,7 @@ __device__ __forceinline__ void irrep_bwd(const StaticBwdArgs& a, int tile, int 
     const double* __restrict__ uc = a.UT + ((size_t)tile * C + c) * Q * 640 + lane;
     double* guc = a.gUT + ((size_t)tile * C + c) * Q * 640 + lane;
     const double* __restrict__ got = a.goT + (size_t)tile * CO * QO * 128 + lane;
-    double* __restrict__ part = a.part + (size_t)tile * a.n_packed + a.wp0[L] + (size_t)c * NB * COT * 2;
+    const DwOut part = dw_out<COT>(a, a.part + (size_t)tile * a.n_packed, L, NB, c, lane);
     cx<double> go[COT][D];
 #pragma unroll
     for (int o = 0; o < COT; ++o) {
@@ -308,7 +308,7 @@ int local_fwd_static(int kind, int M, int C, int CO, const double* XT, const dou
 // (every entry written); gpacked: packed doubles (the caller reduces `part` over the tiles into it, then calls
 // local_static_unpack_grads).  goT / gUT / gXT: see StaticBwdArgs.
 int local_bwd_static(int kind, int M, int C, int CO, const double* XT, const double* UT, const double* w, const int* w0, double* wp,
-                     const double* goT, double* gUT, double* gXT, double* part, hipStream_t st, bool packed) {
+                     const double* goT, double* gUT, double* gXT, double* part, hipStream_t st, bool packed, bool param_layout) {
   LGN_CHECK_ARG(kind == 1 || kind == 2, "local_bwd_static: unknown level kind %d", kind);
   LGN_CHECK_ARG(M > 0 && C >= 1 && C <= 8 && CO >= 1 && CO <= COMAX, "local_bwd_static: unsupported shape (M=%d C=%d CO=%d)", M, C, CO);
   PackArgs p{};
@@ -318,7 +318,8 @@ int local_bwd_static(int kind, int M, int C, int CO, const double* XT, const dou
     LGN_CHECK_LAUNCH();
   }
   StaticBwdArgs a{M, C, CO, XT, UT, wp, {0, 0, 0, 0, 0, 0, 0, 0}, goT, gUT, gXT, part, (int)local_static_packed_doubles(kind, C, CO)};
-  for (int l = 0; l < 5; ++l) a.wp0[l] = p.wp0[l];
+  for (int l = 0; l < 5; ++l) { a.wp0[l] = p.wp0[l]; a.w0[l] = w0[l]; }
+  a.param_layout = param_layout ? 1 : 0;
   dim3 grid(xcd_grid(cdiv(M, 64), C));
 #define LGN_LAUNCH(KIND, COT) hipLaunchKernelGGL((local_bwd_static_kernel<cgs::KIND, COT>), grid, dim3(128), 0, st, a)
   if (kind == 1) { if (CO <= 4) LGN_LAUNCH(Kind1, 4); else if (CO <= 6) LGN_LAUNCH(Kind1, 6); else LGN_LAUNCH(Kind1, 8); }

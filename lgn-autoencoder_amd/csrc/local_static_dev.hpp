@@ -181,8 +181,12 @@ struct StaticBwdArgs {
   const double* __restrict__ goT;     // upstream gradient [tile][CO][Qout][2][64]
   double* __restrict__ gUT;           // [tile][C][5 Q][2][64]   (every entry written)
   double* __restrict__ gXT;           // [tile][C][Q][2][64]     (overwritten; the N^2 backward adds the aggregate part)
-  double* __restrict__ part;          // [tiles][n_packed]  partial CatMix weight gradients, packed layout
-  int n_packed;
+  double* __restrict__ part;          // [tiles][n_packed]  partial CatMix weight gradients: packed layout, or (param_w0) the layout
+  int n_packed;                       //                    of the CatMix parameters themselves, rows n_packed apart all the same
+  // param_layout: the partial rows are written where the PARAMETERS sit relative to the level's CatMix base (irrep l at w0[l]:
+  // [2][CO][nblk_l C]) -- the batch reduction then writes the gradient itself, nothing to unpack (whole-network / whole-step calls)
+  int param_layout;
+  int w0[8];
   // separable decoder form (generic_local_sep.hip): workgroup = (pair of jets, channel)
   const double* __restrict__ tbl;     // jet table (see TBL_STRIDE)
   const double* __restrict__ pc;      // centred momenta [M][8]
@@ -280,6 +284,28 @@ __device__ __forceinline__ void rows_bwd(const cx<double> (&go)[COT][D], const c
     if constexpr (MM % 3 == 2) __builtin_amdgcn_sched_barrier(0);      // three rows at a time
     rows_bwd<T, ROWB, MM + 1, D, COT, A0, NA, B0, NB, NU>(go, w, us, gu, xa, ga, xb, gb, dw);
   }
+}
+
+// where a block's weight-gradient lane sums go: the total of value v = 2 o + plane (wave_sum_slot) of block BLK at p[BLK * stride]
+struct DwOut {
+  double* p;
+  int stride;
+  bool on;
+};
+template <int NV>
+__device__ __forceinline__ void dw_store(const double (&dw)[NV], const DwOut& out, int blk, int lane) {
+  const double w = wave_sum_core<NV>(dw, lane);
+  if (out.on) out.p[blk * out.stride] = w;
+}
+// irrep L (nb blocks) of channel c of partial row `row`
+template <int COT>
+__device__ __forceinline__ DwOut dw_out(const StaticBwdArgs& a, double* row, int L, int nb, int c, int lane) {
+  const int v = wave_sum_slot<2 * COT>(lane);
+  if (a.param_layout) {
+    const int K = nb * a.C, o = v >> 1;
+    return DwOut{row + a.w0[L] + (size_t)(v & 1) * a.CO * K + (size_t)o * K + c, a.C, v >= 0 && o < a.CO};
+  }
+  return DwOut{row + a.wp0[L] + (size_t)c * nb * COT * 2 + (v >= 0 ? v : 0), COT * 2, v >= 0};
 }
 
 // d X accumulator of the wave in LDS, lane-private columns gxl[q * 128 + {0, 1}] (pointer already offset by the lane): plain

@@ -192,7 +192,8 @@ int local_partial_rows(int nodes);
 // compile-time-table kernels for the two maxdim = 3 level kinds (generic_local_static.hip), node-innermost layouts
 size_t local_static_packed_doubles(int kind, int C, int CO);
 int local_bwd_static(int kind, int M, int C, int CO, const double* XT, const double* UT, const double* w, const int* w0, double* wp,
-                     const double* goT, double* gUT, double* gXT, double* part, hipStream_t st, bool packed = false);
+                     const double* goT, double* gUT, double* gXT, double* part, hipStream_t st, bool packed = false,
+                     bool param_layout = false);
 int local_static_unpack_grads(int kind, int C, int CO, const int* w0, const double* gpacked, double* gw, hipStream_t st);
 int local_fwd_static(int kind, int M, int C, int CO, const double* XT, const double* UT, const double* w, const int* w0, double* wp,
                      double* outT, double* s_copy, int q_s, hipStream_t st, bool packed = false);
@@ -205,8 +206,8 @@ int local_sep_part_rows(int B);
 int local_fwd_sep(int kind, int B, int N, int C, int CO, const double* XT, const double* tbl, const double* pc, const double* wp,
                   double* outT, double* s_copy, int q_s, hipStream_t st);
 int local_bwd_sep(int kind, int B, int N, int C, int CO, const double* XT, const double* tbl, const double* pc, const double* b0,
-                  const double* b1, const double* wp, const double* goT, double* gXT, double* part, double* gpb, double* part_rad,
-                  hipStream_t st);
+                  const double* b1, const double* wp, const int* w0p, const double* goT, double* gXT, double* part, double* gpb,
+                  double* part_rad, hipStream_t st);
 int local_sep_gp_reduce(const double* const* gpb, const int* C, int n, int M, double* g_p, hipStream_t st);
 struct StaticPackJob { int kind, C, CO; int w0[5]; const double* src; double* dst; };
 int local_static_pack_batch(const StaticPackJob* jobs, int n, bool unpack, hipStream_t st);

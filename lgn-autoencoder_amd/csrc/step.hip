@@ -626,10 +626,10 @@ int gen_levels_bwd(const lgn_net_desc& d, bool dec, const double* P, double* G, 
       const int nrad = rad_partial_size(C, true);
       DQ_NEW(part, (size_t)rows * np);
       DQ_NEW(part_rad, (size_t)d.B * nrad);
-      LGN_TRY(local_bwd_sep(kind, d.B, d.N, C, CO, a.X[l], a.tbl[l], a.pc, P + off[S.rad(dec, l, 4)], P + off[S.rad(dec, l, 6)], a.wp[l],
+      // (partial rows in the layout of the CatMix parameters themselves, np apart: the reduction writes the gradient, nothing to unpack)
+      LGN_TRY(local_bwd_sep(kind, d.B, d.N, C, CO, a.X[l], a.tbl[l], a.pc, P + off[S.rad(dec, l, 4)], P + off[S.rad(dec, l, 6)], a.wp[l], w0,
                             sc.gX[cur], sc.gX[nxt], part, sc.gpb[l], part_rad, st));
-      dq.add(part, rows, np, 0, np, sc.gpk[l]);
-      post.push_back(UnpackJob{kind, C, CO, {w0[0], w0[1], w0[2], w0[3], w0[4]}, sc.gpk[l], G + off[S.mix(dec, l, 0)]});
+      dq.add(part, rows, np, 0, 2 * g.tab[l]->n_w, G + off[S.mix(dec, l, 0)]);
       dq.add(part_rad, d.B, nrad, 0, C, G + off[S.rad(dec, l, 4)]);
       dq.add(part_rad, d.B, nrad, C, C, G + off[S.rad(dec, l, 6)]);
       cur = nxt;
@@ -642,9 +642,8 @@ int gen_levels_bwd(const lgn_net_desc& d, bool dec, const double* P, double* G, 
       const int kind = g.tab[l]->static_kind, np = (int)local_static_packed_doubles(kind, C, CO), tiles = (BN + 63) / 64;
       DQ_NEW(part, (size_t)tiles * np);
       LGN_TRY(local_bwd_static(kind, BN, C, CO, a.X[l], a.U[l], P + off[S.mix(dec, l, 0)], w0, a.wp[l], sc.gX[cur], sc.gU, sc.gX[nxt], part, st,
-                               /*packed=*/true));
-      dq.add(part, tiles, np, 0, np, sc.gpk[l]);
-      post.push_back(UnpackJob{kind, C, CO, {w0[0], w0[1], w0[2], w0[3], w0[4]}, sc.gpk[l], G + off[S.mix(dec, l, 0)]});
+                               /*packed=*/true, /*param_layout=*/true));
+      dq.add(part, tiles, np, 0, 2 * g.tab[l]->n_w, G + off[S.mix(dec, l, 0)]);
     } else {
       LocalArgs la{};
       LGN_TRY(local_args(la, BN, C, CO, g.Q[l], g.Q[l + 1], g.tab[l]));
@@ -704,9 +703,10 @@ int gen_encoder_fwd(const lgn_net_desc& d, const double* P, const int64_t* off, 
 }
 
 // the caller has zero-filled G and sc's zero block
+// hand_dq / hand_fin (whole step): the pending reductions and radial finalisations are handed to the caller instead of being run here
 int gen_encoder_bwd(const lgn_net_desc& d, const double* P, double* G, const int64_t* off, const double* p4, const uint8_t* mask,
                     const GenAct& a, const double* g_lat_s, const double* g_lat_v, GenScratch& sc, hipStream_t st,
-                    const double* xs = nullptr) {
+                    const double* xs = nullptr, Deferred* hand_dq = nullptr, RadFinJob* hand_fin = nullptr) {
   const Slots S{d.n_levels, d.mlp_nlin};
   const GenGeom g = geom(d, false);
   const int L = d.n_levels, B = d.B, N = d.N, Ts = d.tau_s, Tv = d.tau_v;
@@ -736,6 +736,12 @@ int gen_encoder_bwd(const lgn_net_desc& d, const double* P, double* G, const int
     dq.add(part, B, row, 2 * C0 * K, 2 * C0, G + off[1]);
   }
   LGN_CHECK_ARG(dq.off <= dq.cap, "encoder_bwd: partial-row workspace overflow (%zu > %zu)", dq.off, dq.cap);
+  if (hand_dq) {
+    LGN_CHECK_ARG(post.empty() && hand_fin && hand_fin->n + fin.n <= (int)(sizeof(fin.it) / sizeof(fin.it[0])), "encoder_bwd: hand-over");
+    hand_dq->segs.insert(hand_dq->segs.end(), dq.segs.begin(), dq.segs.end());
+    for (int i = 0; i < fin.n; ++i) hand_fin->it[hand_fin->n++] = fin.it[i];
+    return 0;
+  }
   LGN_TRY(dq.flush(st));
   LGN_TRY(run_unpack_jobs(post, st));
   LGN_TRY(rad_finalize_batch(fin, st));
@@ -803,7 +809,7 @@ GenStep carve_gen_step(const lgn_net_desc& d, double* base) {
 
 int gen_step_fwd_bwd(const lgn_net_desc& d, const double* params, double* grads, long long n_params, const int64_t* enc_off,
                      const int64_t* dec_off, const double* p4, const double* target, const uint8_t* mask, double* workspace,
-                     long long workspace_doubles, double* recon, double* loss_part, hipStream_t st) {
+                     long long workspace_doubles, double* recon, double* loss_part, hipStream_t st, const StepTailArgs* tail) {
   LGN_CHECK_ARG(is_generic(d, false) && is_generic(d, true), "step: encoder and decoder must both be table-driven (or both fused)");
   if (int rc = check_generic(d, false)) return rc;
   if (int rc = check_generic(d, true)) return rc;
@@ -831,10 +837,31 @@ int gen_step_fwd_bwd(const lgn_net_desc& d, const double* params, double* grads,
   std::vector<UnpackJob> post;
   LGN_TRY(gen_decoder_bwd(d, params, grads, dec_off, g.lat_v, g.da, g.g_lat_v, g.ds, dq, fin, post, st));
   LGN_CHECK_ARG(dq.off <= dq.cap, "step: partial-row workspace overflow (%zu > %zu)", dq.off, dq.cap);
+  // Round 6: the static levels leave their CatMix partial rows in PARAMETER layout (nothing to unpack after the reduction), so the
+  // two networks' reductions wait for ONE launch at the end of the step -- with `tail` (single process) the fused tail of the
+  // maxdim-2 step (step_tail.hip: reductions + radial finalisation + L1 + Adam + loss), else reduce_segments + rad_finalize_batch.
+  // Run-time-table levels (LGN_NET_NO_STATIC) keep packed rows and the round-5 sequence.
+  if (!post.empty() || !is_static(d, false) || !is_static(d, true)) {
+    LGN_TRY(dq.flush(st));
+    LGN_TRY(run_unpack_jobs(post, st));
+    // the decoder never reads the latent scalars: no gradient on them
+    LGN_TRY(gen_encoder_bwd(d, params, grads, enc_off, p4, mask, g.ea, nullptr, g.g_lat_v, g.es, st));
+    if (tail)
+      LGN_TRY(finalize_step(tail->w, tail->g, tail->n, tail->loss_part, tail->nB, tail->lambda, tail->m, tail->v, tail->step_dev, tail->lr,
+                            tail->beta1, tail->beta2, tail->eps, tail->do_adam, tail->loss_out, st));
+    return 0;
+  }
+  LGN_TRY(gen_encoder_bwd(d, params, grads, enc_off, p4, mask, g.ea, nullptr, g.g_lat_v, g.es, st, nullptr, &dq, &fin));
+  if (tail && !(d.flags & LGN_NET_SPLIT_TAIL)) {
+    const int rc = step_tail(dq.segs, fin, *tail, st);
+    if (rc == 0) return 0;
+    if (rc != -2) return rc;
+  }
   LGN_TRY(dq.flush(st));
-  LGN_TRY(run_unpack_jobs(post, st));
-  // the decoder never reads the latent scalars: no gradient on them
-  LGN_TRY(gen_encoder_bwd(d, params, grads, enc_off, p4, mask, g.ea, nullptr, g.g_lat_v, g.es, st));
+  LGN_TRY(rad_finalize_batch(fin, st));
+  if (tail)
+    LGN_TRY(finalize_step(tail->w, tail->g, tail->n, tail->loss_part, tail->nB, tail->lambda, tail->m, tail->v, tail->step_dev, tail->lr,
+                          tail->beta1, tail->beta2, tail->eps, tail->do_adam, tail->loss_out, st));
   return 0;
 }
 
@@ -1240,12 +1267,8 @@ static int step_fwd_bwd(const lgn_net_desc* d, const double* params, double* gra
   if (is_generic(*d, false) || is_generic(*d, true)) {
     LGN_CHECK_ARG(!step_is_split(*d), "step_fwd_bwd: table-driven networks take the mass as the only input scalar and one node count "
                   "for both networks (n_in_scalars=%d, N=%d, dec_N=%d): use the per-network calls", d->n_in_scalars, d->N, d->dec_N);
-    LGN_TRY(gen_step_fwd_bwd(*d, params, grads, n_params, enc_off, dec_off, p4, target, mask, workspace, workspace_doubles, recon,
-                             loss_part, st));
-    if (tail)        // (the table-driven step unpacks gradients after its reductions: it keeps the separate launches)
-      LGN_TRY(finalize_step(tail->w, tail->g, tail->n, tail->loss_part, tail->nB, tail->lambda, tail->m, tail->v, tail->step_dev, tail->lr,
-                            tail->beta1, tail->beta2, tail->eps, tail->do_adam, tail->loss_out, st));
-    return 0;
+    return gen_step_fwd_bwd(*d, params, grads, n_params, enc_off, dec_off, p4, target, mask, workspace, workspace_doubles, recon,
+                            loss_part, st, tail);
   }
   Work w = carve(*d, workspace);
   // the layout depends on run-time switches (LGN_AMD_DEC_PAIRWISE / LGN_AMD_LEVEL_V2 change the partial-row counts):

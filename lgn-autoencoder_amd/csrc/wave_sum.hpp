@@ -75,6 +75,17 @@ __device__ __forceinline__ void wave_sum_store(const double (&v)[NV], double* __
   const bool owner = (i & 3) == 0 && (N3 == 2 || (i & 4) == 0) && (!single || i < 8);
   if (owner) dst[4 * q + 2 * (rho & 1) + (rho >> 1)] = w;
 }
+// the value whose total this lane is the FIRST holder of after wave_sum_core<NV> (wave_sum_store's owner rule), or -1
+template <int NV>
+__device__ __forceinline__ int wave_sum_slot(int lane) {
+  constexpr int N2 = NV / 4, N3 = (N2 + 1) / 2;
+  const int i = lane & 15, rho = lane >> 4;
+  const int jsel = N3 == 2 ? (i >> 2) & 1 : 0;
+  const bool single = (N2 & 1) && jsel == N3 - 1;
+  const int q = single ? N2 - 1 : 2 * jsel + (i >> 3);
+  const bool owner = (i & 3) == 0 && (N3 == 2 || (i & 4) == 0) && (!single || i < 8);
+  return owner ? 4 * q + 2 * (rho & 1) + (rho >> 1) : -1;
+}
 template <int NV>
 __device__ __forceinline__ void wave_allsum(const double (&v)[NV], double (&s)[NV], int lane) {
   const double w = wave_sum_core<NV>(v, lane);

@@ -747,6 +747,36 @@ def test_deepcopy_of_a_network_that_has_run():
         assert torch.equal(r0, r1)
 
 
+@pytest.mark.parametrize("B,N,che,chd", [(40, 30, (4, 4, 6, 6), (6, 6, 4, 4)), (5, 13, (2, 3, 4), (4, 3, 2))])
+def test_native_step_maxdim3_fused_tail_is_bit_identical_to_the_separate_launches(B, N, che, chd, monkeypatch):
+    """Round 6: the table-driven step leaves its CatMix partial rows in parameter layout, so its tail is the fused launch of the
+    maxdim-2 step as well (csrc/step_tail.hip) -- against LGN_AMD_SPLIT_TAIL=1 (reduce_segments, rad_finalize_batch, l1_adam): three
+    Adam steps, weights / moments / gradients / step counter bit for bit, the loss value to rounding."""
+    import __graft_entry__ as G
+    from lgn.step import NativeTrainStep
+    from oracle import lgn_oracle as O
+    dev = torch.device("cuda:0")
+    p4, labels = O.synthetic_jets(B, N, seed=B + N, pad=True)
+    batch = {"p4": p4.to(dev), "labels": labels.to(dev)}
+    runs = []
+    for split in (False, True):
+        enc, dec = G._models(N, che, chd, dev, seed=21, maxdim=3)
+        if split:
+            monkeypatch.setenv("LGN_AMD_SPLIT_TAIL", "1")
+        st = NativeTrainStep(enc, dec, batch_size=B, lr=1e-3, l1_lambda=1e-6, use_graph=True)
+        losses = [st.step(batch)[0].clone() for _ in range(3)]
+        if split:
+            monkeypatch.delenv("LGN_AMD_SPLIT_TAIL")
+        torch.cuda.synchronize()
+        runs.append((torch.stack(losses), st.flat.grad.clone(), st.adam_m.clone(), st.adam_v.clone(), st.flat.flat.clone(), st.step_dev.clone(),
+                     st._loss_buf[3:].clone()))
+    U.assert_close(runs[0][0], runs[1][0], 1e-13, "losses of the three steps")
+    for what, x, y in zip(("gradients (with the L1 term)", "Adam m", "Adam v", "weights", "step counter"), runs[0][1:6], runs[1][1:6]):
+        assert torch.equal(x, y), f"{what}: fused tail != separate launches (max diff {(x.double() - y.double()).abs().max().item():.3e})"
+    assert int(runs[0][5].item()) == 3
+    assert float(runs[0][6][:-12].abs().sum()) == 0.0 and float(runs[0][6][-1]) == 0.0, "the fused launch left slots / counters behind"
+
+
 @pytest.mark.parametrize("B", [512, 9])
 def test_native_step_split_and_fused_tail_share_one_scratch_block(B):
     """lgn_step_finalize_f64 (l1_adam: positive |w| partials in the scratch slots) followed by lgn_step_train_f64 (step_tail: reads
