@@ -687,9 +687,17 @@ int net_unpack(const lgn_net_desc& d, bool dec, int l, const double* X, double* 
   return gen_unpack((size_t)d.B * d.N * g.ch[l], g.Q[l], g.qs[l], g.qv[l], X, s, v, st);
 }
 
+// decoder-side operands of junction_bwd (whole step)
+struct JunctionBwd {
+  int C0, Tin;
+  const double *lat_v, *wg1, *w1, *pdec, *g_p, *g_s0, *g_v0;
+  double* part_dec;
+};
+
 // ---- one table-driven network, forward / backward (shared by the per-network API and the whole step) ----------------
+// with_latent = false (whole step): the latent stage runs in the junction kernel together with the decoder's input stage
 int gen_encoder_fwd(const lgn_net_desc& d, const double* P, const int64_t* off, const double* p4, const uint8_t* mask, GenAct& a,
-                    double* lat_s, double* lat_v, hipStream_t st, const double* xs = nullptr) {
+                    double* lat_s, double* lat_v, hipStream_t st, const double* xs = nullptr, bool with_latent = true) {
   const Slots S{d.n_levels, d.mlp_nlin};
   const GenGeom g = geom(d, false);
   const int L = d.n_levels;
@@ -697,8 +705,9 @@ int gen_encoder_fwd(const lgn_net_desc& d, const double* P, const int64_t* off, 
   LGN_TRY(net_pack(d, false, 0, a.s0, a.v0, a.X[0], st));
   LGN_TRY(gen_levels_fwd(d, false, P, off, a, p4, mask, st));
   LGN_TRY(net_unpack(d, false, L, a.X[L], a.sL, a.vL, st));
-  LGN_TRY(enc_latent_fwd(d.B, d.N, g.ch[L], d.tau_s, d.tau_v, d.latent_pool, a.sL, a.vL, P + off[S.out0(false)], P + off[S.out0(false) + 1], lat_s,
-                         lat_v, a.idx, st));
+  if (with_latent)
+    LGN_TRY(enc_latent_fwd(d.B, d.N, g.ch[L], d.tau_s, d.tau_v, d.latent_pool, a.sL, a.vL, P + off[S.out0(false)], P + off[S.out0(false) + 1],
+                           lat_s, lat_v, a.idx, st));
   return 0;
 }
 
@@ -706,7 +715,7 @@ int gen_encoder_fwd(const lgn_net_desc& d, const double* P, const int64_t* off, 
 // hand_dq / hand_fin (whole step): the pending reductions and radial finalisations are handed to the caller instead of being run here
 int gen_encoder_bwd(const lgn_net_desc& d, const double* P, double* G, const int64_t* off, const double* p4, const uint8_t* mask,
                     const GenAct& a, const double* g_lat_s, const double* g_lat_v, GenScratch& sc, hipStream_t st,
-                    const double* xs = nullptr, Deferred* hand_dq = nullptr, RadFinJob* hand_fin = nullptr) {
+                    const double* xs = nullptr, Deferred* hand_dq = nullptr, RadFinJob* hand_fin = nullptr, const JunctionBwd* jb = nullptr) {
   const Slots S{d.n_levels, d.mlp_nlin};
   const GenGeom g = geom(d, false);
   const int L = d.n_levels, B = d.B, N = d.N, Ts = d.tau_s, Tv = d.tau_v;
@@ -718,8 +727,13 @@ int gen_encoder_bwd(const lgn_net_desc& d, const double* P, double* G, const int
   {
     const int CL = g.ch[L], KL = pool_mix_in(d.latent_pool, N, CL), rowe = 2 * (Ts + Tv) * KL;
     DQ_NEW(parte, (size_t)B * rowe);
-    LGN_TRY(enc_latent_bwd(B, N, CL, Ts, Tv, d.latent_pool, a.sL, a.vL, P + off[S.out0(false)], P + off[S.out0(false) + 1],
-                           g_lat_s ? g_lat_s : sc.g_lat_s, g_lat_v, a.idx, sc.gs, sc.gv, parte, st));
+    if (jb)       // whole step: the decoder's input stage backward and this latent stage backward of a jet in one launch
+      LGN_TRY(junction_bwd(B, N, jb->C0, jb->Tin, jb->lat_v, jb->wg1, jb->w1, jb->pdec, jb->g_p, jb->g_s0, jb->g_v0, const_cast<double*>(g_lat_v),
+                           jb->part_dec, CL, Ts, Tv, d.latent_pool, a.sL, a.vL, P + off[S.out0(false)], P + off[S.out0(false) + 1],
+                           g_lat_s ? g_lat_s : sc.g_lat_s, a.idx, sc.gs, sc.gv, parte, st));
+    else
+      LGN_TRY(enc_latent_bwd(B, N, CL, Ts, Tv, d.latent_pool, a.sL, a.vL, P + off[S.out0(false)], P + off[S.out0(false) + 1],
+                             g_lat_s ? g_lat_s : sc.g_lat_s, g_lat_v, a.idx, sc.gs, sc.gv, parte, st));
     dq.add(parte, B, rowe, 0, 2 * Ts * KL, G + off[S.out0(false)]);
     dq.add(parte, B, rowe, 2 * Ts * KL, 2 * Tv * KL, G + off[S.out0(false) + 1]);
     LGN_TRY(net_pack(d, false, L, g_lat_s ? sc.gs : sc.zero0, sc.gv, sc.gX[cur], st));
@@ -749,10 +763,11 @@ int gen_encoder_bwd(const lgn_net_desc& d, const double* P, double* G, const int
 }
 
 // forward up to the unpacked last-level features (the caller applies dec_output_fwd or the fused output + loss kernel)
-int gen_decoder_fwd(const lgn_net_desc& d, const double* P, const int64_t* off, const double* lat_v, GenAct& a, hipStream_t st) {
+int gen_decoder_fwd(const lgn_net_desc& d, const double* P, const int64_t* off, const double* lat_v, GenAct& a, hipStream_t st,
+                    bool with_input = true) {
   const GenGeom g = geom(d, true);
   const int L = d.n_levels, Tin = d.tau_v_in > 0 ? d.tau_v_in : pool_blocks(d.latent_pool) * d.tau_v;
-  LGN_TRY(dec_input_fwd(d.B, d.N, g.ch[0], Tin, lat_v, P + off[1], P + off[2], P + off[3], a.pdec, a.s0, a.v0, st));
+  if (with_input) LGN_TRY(dec_input_fwd(d.B, d.N, g.ch[0], Tin, lat_v, P + off[1], P + off[2], P + off[3], a.pdec, a.s0, a.v0, st));
   LGN_TRY(net_pack(d, true, 0, a.s0, a.v0, a.X[0], st));
   LGN_TRY(gen_levels_fwd(d, true, P, off, a, a.pdec, nullptr, st));
   LGN_TRY(net_unpack(d, true, L, a.X[L], a.sL, a.vL, st));
@@ -761,8 +776,11 @@ int gen_decoder_fwd(const lgn_net_desc& d, const double* P, const int64_t* off, 
 
 // sc.gv holds the gradient w.r.t. the last level's (1,1) features (from dec_output_bwd / dec_output_loss); dq carries the
 // caller's pending reductions and is flushed by the caller
+// part_in (whole step): the input stage's backward is the caller's (junction kernel) -- its partial rows are allocated and their
+// reductions registered here, *part_in tells the caller where they go
 int gen_decoder_bwd(const lgn_net_desc& d, const double* P, double* G, const int64_t* off, const double* lat_v, const GenAct& a,
-                    double* g_lat_v, GenScratch& sc, Deferred& dq, RadFinJob& fin, std::vector<UnpackJob>& post, hipStream_t st) {
+                    double* g_lat_v, GenScratch& sc, Deferred& dq, RadFinJob& fin, std::vector<UnpackJob>& post, hipStream_t st,
+                    double** part_in = nullptr) {
   const GenGeom g = geom(d, true);
   const int L = d.n_levels, B = d.B, N = d.N, Tin = d.tau_v_in > 0 ? d.tau_v_in : pool_blocks(d.latent_pool) * d.tau_v;
   int cur = 0;
@@ -777,7 +795,8 @@ int gen_decoder_bwd(const lgn_net_desc& d, const double* P, double* G, const int
   const int C0 = g.ch[0], row = 4 * C0 + 2 * N * Tin;
   LGN_TRY(net_unpack(d, true, 0, sc.gX[cur], sc.gs, sc.gv, st));
   DQ_NEW(part, (size_t)B * row);
-  LGN_TRY(dec_input_bwd(B, N, C0, Tin, lat_v, P + off[1], P + off[3], a.pdec, sc.g_p, sc.gs, sc.gv, g_lat_v, part, st));
+  if (part_in) *part_in = part;
+  else LGN_TRY(dec_input_bwd(B, N, C0, Tin, lat_v, P + off[1], P + off[3], a.pdec, sc.g_p, sc.gs, sc.gv, g_lat_v, part, st));
   dq.add(part, B, row, 0, 2 * C0, G + off[2]);
   dq.add(part, B, row, 2 * C0, 2 * C0, G + off[3]);
   dq.add(part, B, row, 4 * C0, 2 * N * Tin, G + off[1]);
@@ -823,8 +842,13 @@ int gen_step_fwd_bwd(const lgn_net_desc& d, const double* params, double* grads,
   const Slots S{d.n_levels, d.mlp_nlin};
   const int L = d.n_levels, B = d.B, N = d.N, CL = d.dec_channels[L];
   LGN_TRY(zero_ranges(grads, (size_t)n_params, g.es.zero0, g.es.zero_doubles, g.ds.zero0, g.ds.zero_doubles, st));
-  LGN_TRY(gen_encoder_fwd(d, params, enc_off, p4, mask, g.ea, g.lat_s, g.lat_v, st));
-  LGN_TRY(gen_decoder_fwd(d, params, dec_off, g.lat_v, g.da, st));
+  // encoder latent stage + decoder input stage of a jet: ONE launch (the junction kernels of the maxdim-2 step), forward and backward
+  const int Tin = pool_blocks(d.latent_pool) * d.tau_v, CLe = d.enc_channels[d.n_levels], C0d = d.dec_channels[0];
+  LGN_TRY(gen_encoder_fwd(d, params, enc_off, p4, mask, g.ea, g.lat_s, g.lat_v, st, nullptr, /*with_latent=*/false));
+  LGN_TRY(junction_fwd(B, N, CLe, d.tau_s, d.tau_v, d.latent_pool, g.ea.sL, g.ea.vL, params + enc_off[S.out0(false)],
+                       params + enc_off[S.out0(false) + 1], g.lat_s, g.lat_v, g.ea.idx, C0d, params + dec_off[1], params + dec_off[2],
+                       params + dec_off[3], g.da.pdec, g.da.s0, g.da.v0, st));
+  LGN_TRY(gen_decoder_fwd(d, params, dec_off, g.lat_v, g.da, st, /*with_input=*/false));
   Deferred dq;
   dq.parts = g.ds.parts;
   dq.cap = g.ds.parts_size;
@@ -835,13 +859,18 @@ int gen_step_fwd_bwd(const lgn_net_desc& d, const double* params, double* grads,
     dq.add(part, B, 2 * CL, 0, 2 * CL, grads + dec_off[S.out0(true) + 1]);
   }
   std::vector<UnpackJob> post;
-  LGN_TRY(gen_decoder_bwd(d, params, grads, dec_off, g.lat_v, g.da, g.g_lat_v, g.ds, dq, fin, post, st));
+  double* part_in = nullptr;
+  LGN_TRY(gen_decoder_bwd(d, params, grads, dec_off, g.lat_v, g.da, g.g_lat_v, g.ds, dq, fin, post, st, &part_in));
   LGN_CHECK_ARG(dq.off <= dq.cap, "step: partial-row workspace overflow (%zu > %zu)", dq.off, dq.cap);
+  const JunctionBwd jb{C0d, Tin, g.lat_v, params + dec_off[1], params + dec_off[3], g.da.pdec, g.ds.g_p, g.ds.gs, g.ds.gv, part_in};
   // Round 6: the static levels leave their CatMix partial rows in PARAMETER layout (nothing to unpack after the reduction), so the
   // two networks' reductions wait for ONE launch at the end of the step -- with `tail` (single process) the fused tail of the
   // maxdim-2 step (step_tail.hip: reductions + radial finalisation + L1 + Adam + loss), else reduce_segments + rad_finalize_batch.
   // Run-time-table levels (LGN_NET_NO_STATIC) keep packed rows and the round-5 sequence.
   if (!post.empty() || !is_static(d, false) || !is_static(d, true)) {
+    // (the decoder's reductions run now: its input stage's backward must have written its partial rows -- no junction kernel here)
+    LGN_TRY(dec_input_bwd(B, N, C0d, Tin, g.lat_v, params + dec_off[1], params + dec_off[3], g.da.pdec, g.ds.g_p, g.ds.gs, g.ds.gv, g.g_lat_v,
+                          part_in, st));
     LGN_TRY(dq.flush(st));
     LGN_TRY(run_unpack_jobs(post, st));
     // the decoder never reads the latent scalars: no gradient on them
@@ -851,7 +880,7 @@ int gen_step_fwd_bwd(const lgn_net_desc& d, const double* params, double* grads,
                             tail->beta1, tail->beta2, tail->eps, tail->do_adam, tail->loss_out, st));
     return 0;
   }
-  LGN_TRY(gen_encoder_bwd(d, params, grads, enc_off, p4, mask, g.ea, nullptr, g.g_lat_v, g.es, st, nullptr, &dq, &fin));
+  LGN_TRY(gen_encoder_bwd(d, params, grads, enc_off, p4, mask, g.ea, nullptr, g.g_lat_v, g.es, st, nullptr, &dq, &fin, &jb));
   if (tail && !(d.flags & LGN_NET_SPLIT_TAIL)) {
     const int rc = step_tail(dq.segs, fin, *tail, st);
     if (rc == 0) return 0;
