@@ -61,7 +61,7 @@ FP64_VECTOR_PEAK_TFLOPS = 78.6     # MI355X fp64 vector == fp64 matrix peak (MI3
 # algorithmic flops per jet of one training step (forward + backward = 3 x forward), decoder levels as pair sweeps
 WHOLE_STEP_FLOPS_PER_JET = {"cfg1": 31.2e6, "cfg2": 31.2e6, "cfg4": 533.7e6, "cfg5": 109.9e6}
 SETTLE_STEPS = 40                  # untimed steps before the caller's warm-up: the GPU's clocks settle (see _time_steps)
-PROFILE_ROUND = "r05"              # profiles/<round>_pmc_<cfg>.json: the PMC passes the `traffic` figures come from
+PROFILE_ROUND = "r06"              # profiles/<round>_pmc_<cfg>.json: the PMC passes the `traffic` figures come from
 
 
 def synthetic_jets(B, N, seed):
@@ -791,10 +791,10 @@ def main():
                 out["roofline"] = {"bound": "mfma", "pipe": "fp64 vector datapath (no matrix instructions in this kernel; schema has hbm|mfma only)",
                                    "kernel": dom["kernel"], "achieved": ach, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                                    "frac": ach / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic,
-                                   "traffic_note": "2 x FETCH_SIZE + WRITE_SIZE of the rocprofv3 --pmc passes in profiles/r05_pmc_cfg5.json",
+                                   "traffic_note": f"2 x FETCH_SIZE + WRITE_SIZE of the rocprofv3 --pmc passes in profiles/{PROFILE_ROUND}_pmc_cfg5.json",
                                    "us_per_launch": dom["us"], "algorithmic_flops_per_launch": dom["flops"],
                                    "note": "us_per_launch is the C-ABI call (kernel + weight packing + partial-row reduction + unpacking); "
-                                           "the kernel alone: profiles/r05_cfg5_kernel_stats.csv",
+                                           f"the kernel alone: profiles/{PROFILE_ROUND}_cfg5_kernel_stats.csv",
                                    "whole_step": {"achieved": ach_step, "frac": ach_step / FP64_VECTOR_PEAK_TFLOPS,
                                                   "algorithmic_flops_per_jet": flops_per_jet,
                                                   "note": "SURVEY 8(d) algorithmic flops per jet x measured jets/s"}}

@@ -38,6 +38,17 @@ bash tools/ab.sh "$OUT/ab_tail64" LGN_AMD_SPLIT_TAIL=1 - -- --config cfg2 --batc
   echo "== data-parallel branch on one rank (tools/dp_bench.py 64 300): one-launch reductions, then LGN_AMD_SPLIT_TAIL=1";
   python3 tools/dp_bench.py 64 300 2>&1 | grep jets; LGN_AMD_SPLIT_TAIL=1 python3 tools/dp_bench.py 64 300 2>&1 | grep jets; } > "$OUT/step_tail.txt"
 
+# cfg5, round 6: the decoder's moments as a tensor between two kernels per level (LGN_AMD_DEC_UNFUSED=1: round 5) | the encoder's
+# backward sweeps as two kernels (LGN_AMD_MOMENTS_SPLIT=1) | separate tail launches (LGN_AMD_SPLIT_TAIL=1) | default
+echo "[evidence] A/B of the cfg5 step"
+bash tools/ab.sh "$OUT/ab_cfg5" LGN_AMD_DEC_UNFUSED=1 LGN_AMD_MOMENTS_SPLIT=1 LGN_AMD_SPLIT_TAIL=1 - -- --config cfg5 --no-extras > /dev/null 2>&1
+cp "$OUT/ab_cfg5/ab.txt" "$OUT/cfg5_ab.txt"
+echo "[evidence] kernel sequences"
+bash tools/kseq.sh cfg5 -- python3 bench.py --config cfg5 --no-cpu-baseline --no-extras --steps 3 --warmup 1 > "$OUT/kernel_sequence_cfg5.txt" 2>&1
+bash tools/kseq.sh cfg2 -- python3 bench.py --config cfg2 --no-cpu-baseline --no-extras --steps 3 --warmup 1 > "$OUT/kernel_sequence_cfg2.txt" 2>&1
+rm -f "$ROOT"/gpurun_out/ks_cfg5.log "$ROOT"/gpurun_out/ks_cfg2.log
+echo "[evidence] in-kernel stamps of the fused decoder backward and of the static encoder backward"
+{ python3 tools/sep_stamps.py 2>&1 | tail -2; python3 tools/local_bench.py stamps 2>&1 | grep -v amdgpu.ids; } > "$OUT/local_stamps.txt"
 for cfg in cfg2 cfg5; do
   echo "[evidence] pmc passes $cfg"
   bash tools/pmc_passes.sh $cfg "$OUT/pmc_$cfg" > "$OUT/pmc_$cfg.log" 2>&1

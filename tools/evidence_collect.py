@@ -22,6 +22,12 @@ for cfg in ("cfg2", "cfg5"):
         subprocess.check_call([sys.executable, os.path.join(root, "tools", "pmc_summary.py"), d, os.path.join(prof, f"{tag}_pmc_{cfg}.json")])
     else:
         print("missing", d)
+for name in ("cfg5_ab.txt", "kernel_sequence_cfg5.txt", "kernel_sequence_cfg2.txt", "local_stamps.txt"):
+    f = os.path.join(src, name)
+    if os.path.exists(f):
+        shutil.copy(f, os.path.join(prof, f"{tag}_{name}"))
+    else:
+        print("missing", f)
 f = os.path.join(src, "step_tail.txt")
 if os.path.exists(f):
     shutil.copy(f, os.path.join(prof, f"{tag}_step_tail.txt"))
