@@ -88,7 +88,9 @@ struct Bwd3 {
 //   stage 1   per (node, channel): the node's terms of S, VS, SP, VP (forward) and of the sums of g_ag (backward)
 //   stage 2   per (channel, term): sum over the nodes in node order
 //   outputs   node gradient, position gradient and bias gradients from O(N C) closed forms.
-// (amdgpu_waves_per_eu(2): two workgroups per CU is what the 77 KB of LDS are sized for)
+// (amdgpu_waves_per_eu(2): two workgroups per CU is what the 77 KB of LDS are sized for.  Round 6: the encoder instantiations with
+// C >= 5 spilled 70 - 76 registers into the pair loop at that budget -- they get one wave per SIMD and ~312 registers instead:
+// 142 - 159 us -> ~115 - 135 us per launch at 512 jets, tools/wide_levels.py, profiles/r06_c5to8_levels.txt)
 // SYM (encoder, whole jet in one workgroup): the radial network sees a pair only through |p_i - p_j|^2 and the masks, so R(i, j) =
 // R(j, i) and the gradient w.r.t. the pair's radial values is the SUM of what the two directed edges i <- j and j <- i send back.
 // The wave that owns the source group J therefore adds, on its tiles with receiver group I < J, the reverse edge's share (receiver
@@ -97,7 +99,7 @@ struct Bwd3 {
 // 36 instead of 64 radial GEMM tiles per 30-particle jet; waves own the groups in pairs (p, G - 1 - p) so that each gets the same
 // number of them.  Node gradients flow exactly as before (every ordered tile still evaluates R and its edge).
 template <int C, bool DEC, bool SEP, int NWV, bool SYM = false>
-__global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2))) void level_bwd3_kernel(LevelBwdArgs<double> a) {
+__global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(C <= 4 || DEC ? 2 : 1, C <= 4 || DEC ? 2 : 1))) void level_bwd3_kernel(LevelBwdArgs<double> a) {
   static_assert(!SYM || !DEC, "the symmetric sweep is the encoder's");
   using F = Bwd3<C, DEC, NWV>;
   constexpr int BLK = F::BLK;
