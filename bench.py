@@ -16,11 +16,13 @@ Launch: under ``torch.distributed.run`` (RANK / LOCAL_RANK / WORLD_SIZE / MASTER
 rank; a plain ``python bench.py --gpus N`` with N > 1 and no WORLD_SIZE starts the N ranks ITSELF as fresh child processes
 (the parent never touches a GPU) and exits with their worst exit code.
 
-Scaling modes: default = STRONG -- BASELINE's metric is "bs=512 at 1/2/4/8 MI355X": the config's batch is the GLOBAL batch,
-split over the N ranks (cfg3 = cfg2 on 8 GPUs = 64 jets per GPU); `value` = global batch x steps / time.  With N > 1 the
-line also carries ``weak_scaling`` (the config's batch on EVERY GPU) as an extra object.  ``--weak`` / ``--batch B`` make the
-weak figure the primary one; ``--global-batch G`` picks another global batch.  The mode is named in ``scaling`` and in
-``config.workload``.  N = 1: both modes are the same run.
+Scaling modes: default = WEAK -- jets are independent graphs, the batch is the unit a GPU works on: every rank runs the config's
+batch (bs=512 per GPU at cfg2, the batch a data-parallel training run gives each GPU) and one RCCL all-reduce of the flat gradient
+per step; `value` = N x batch x steps / time, `"scaling": "weak"`.  With N > 1 the line also carries ``strong_scaling`` -- BASELINE's
+cfg3 read as ONE 512-jet batch split over the N ranks (64 jets per GPU at N = 8: the step is then a chain of 25 launches at their
+one-workgroup latency, see ``predicted_strong_scaling`` in the N = 1 line) -- timed in the same run.  ``--strong`` /
+``--global-batch G`` make the strong figure the primary one, ``--batch B`` picks another per-GPU batch.  The mode is named in
+``scaling`` and in ``config.workload``.  N = 1: both modes are the same run.
 
 Rank 0 prints ONE JSON line (contract in the task statement) with extra objects:
   roofline     -- dominant kernel (the fused level BACKWARD of the widest encoder level; its forward twin is reported
@@ -626,7 +628,8 @@ def main():
     ap.add_argument("--global-batch", type=int, default=None,
                     help="total jets per step, split over the ranks (strong scaling; default: the config's batch, so that "
                          "--gpus 8 on cfg2 is BASELINE's cfg3)")
-    ap.add_argument("--weak", action="store_true", help="weak scaling as the primary figure: the config's batch on every GPU")
+    ap.add_argument("--weak", action="store_true", help="(the default) weak scaling: the config's batch on every GPU")
+    ap.add_argument("--strong", action="store_true", help="strong scaling as the primary figure: the config's batch split over the GPUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the module_api and decoder_pairwise legs")
     ap.add_argument("--harness", choices=["native", "native-nograph", "module", "modular", "captured"], default=None,
@@ -643,8 +646,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node must equal --gpus")
-    if sum(x is not None for x in (args.batch, args.global_batch)) + int(args.weak) > 1:
-        raise SystemExit("--batch, --global-batch and --weak are exclusive")
+    if sum(x is not None for x in (args.batch, args.global_batch)) + int(args.weak) + int(args.strong) > 1:
+        raise SystemExit("--batch, --global-batch, --weak and --strong are exclusive")
     if os.environ.get("LGN_BENCH_DRY") == "1":
         return _dry_run(args, world, rank)
     # ONE line on stdout, whatever the libraries underneath print there (RCCL writes a version banner to fd 1 when a communicator is
@@ -658,7 +661,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    if args.batch is not None or args.weak:
+    if not args.strong and args.global_batch is None:
         per_gpu, scaling = (args.batch or cfg["B"]), "weak"
     else:
         gb = args.global_batch if args.global_batch is not None else cfg["B"]
@@ -692,15 +695,17 @@ def main():
     p4, labels = synthetic_jets(per_gpu, N, seed=rank)     # per-rank shard, resident in HBM
     batch = {"p4": p4.to(dev), "labels": labels.to(dev)}
     elapsed = timed(trainer, batch)
-    weak = None
-    if world > 1 and scaling == "strong" and harness != "module":
-        # the weak-scaling figure next to the primary (strong) one: the config's batch on EVERY GPU (all ranks take part)
+    other = None
+    if world > 1 and harness != "module" and args.batch is None and args.global_batch is None and cfg["B"] % world == 0:
+        # the OTHER scaling figure next to the primary one, timed in the same run (all ranks take part): strong = the config's batch
+        # split over the ranks, weak = the config's batch on every rank
         del trainer
-        _, tw = build(harness, cfg["B"])
-        pw, lw = synthetic_jets(cfg["B"], N, seed=rank)
+        jets = cfg["B"] // world if scaling == "weak" else cfg["B"]
+        _, tw = build(harness, jets)
+        pw, lw = synthetic_jets(jets, N, seed=rank)
         ew = timed(tw, {"p4": pw.to(dev), "labels": lw.to(dev)})
-        weak = {"value": cfg["B"] * world * args.steps / ew, "unit": "jets/s", "ms_per_step": 1e3 * ew / args.steps,
-                "jets_per_gpu": cfg["B"], "global_batch": cfg["B"] * world, "scaling": "weak"}
+        other = {"value": jets * world * args.steps / ew, "unit": "jets/s", "ms_per_step": 1e3 * ew / args.steps,
+                 "jets_per_gpu": jets, "global_batch": jets * world, "scaling": "strong" if scaling == "weak" else "weak"}
         del tw
         trainer = None
 
@@ -728,8 +733,8 @@ def main():
                                    "captured": "CapturedModuleStep: module API + ChamferLoss under autograd + native L1 / Adam, "
                                                "captured into one HIP graph (what configurations outside the whole-step call get)"}[harness]},
         }
-        if weak is not None:
-            out["weak_scaling"] = weak
+        if other is not None:
+            out[other["scaling"] + "_scaling"] = other
         if cfg["maxdim"] == 2:
             dom = time_dominant_kernel(enc, batch)
             achieved = dom["flops"] / (dom["us"] * 1e-6) / 1e12
