@@ -25,8 +25,11 @@ namespace {
 using namespace lsd;
 LGN_STAMP_DECL
 #ifdef LGN_STAMPS
-// (first workgroup of the Q = 20 levels: the heavy ones; wave 0 stamps 0.., wave 1 stamps 16..)
-#define PSTAMP(i) do { if (T::Q == 20 && (threadIdx.x & 63) == 0 && blockIdx.x == 0) g_stamps[i] = clock64(); } while (0)
+// (first workgroup of the Q = 20 levels: the heavy ones -- -DLGN_PSTAMP_Q=5: the first level; wave 0 stamps 0.., wave 1 stamps 16..)
+#ifndef LGN_PSTAMP_Q
+#define LGN_PSTAMP_Q 20
+#endif
+#define PSTAMP(i) do { if (T::Q == LGN_PSTAMP_Q && (threadIdx.x & 63) == 0 && blockIdx.x == 0) g_stamps[i] = clock64(); } while (0)
 #else
 #define PSTAMP(i) do { } while (0)
 #endif
@@ -331,7 +334,11 @@ __device__ __forceinline__ void sep_tail(int q0, int q1, const double* cm, const
 // touches the moments).  LDS (76.4 KB at Q = 20: two workgroups per CU): the channel's features xs [Q][64][2], the two waves' d X
 // images, the table rows of the two jets, the lanes' momenta and d p, and the parked sums (whose space the tail's exchange reuses).
 template <class T> constexpr int sep_un_doubles() { return 2 * (sep_vtotal<T>() + 2) > 64 * 8 + 16 ? 2 * (sep_vtotal<T>() + 2) : 64 * 8 + 16; }
-template <class T> constexpr size_t sep_lds_bytes() { return sizeof(double) * (size_t)(3 * T::Q * 128 + 2 * T::Q * 12 + 2 * 64 * 8 + sep_un_doubles<T>()); }
+// (the first level kind -- Q = 5, a small walk -- lets wave 1 take moment blocks too: it then has d p accumulators of its own)
+template <class T> constexpr int sep_gpl_waves() { return T::Q == 5 ? 2 : 1; }
+template <class T> constexpr size_t sep_lds_bytes() {
+  return sizeof(double) * (size_t)(3 * T::Q * 128 + 2 * T::Q * 12 + (1 + sep_gpl_waves<T>()) * 64 * 8 + sep_un_doubles<T>());
+}
 
 // Wave assignment (balanced on in-kernel stamps of the 6 -> 4 level of cfg5, tools/sep_stamps.py: walk 100 k / 96 k cycles, sums +
 // tail 15 k):  wave 0: the moment / feature blocks of every irrep, all of irrep 4, irrep 1 but its last block, the first product block
@@ -346,8 +353,8 @@ __global__ __launch_bounds__(128) void local_bwd_sep_kernel(StaticBwdArgs a) {
   double* gxs = xs + Q * 128;             // [2 waves][Q][64][2]
   double* tab = gxs + 2 * Q * 128;        // [2 halves][Q][12]: E | A | B_0..3
   double* pl = tab + 2 * Q * 12;          // [64 lanes][8]
-  double* gpl = pl + 64 * 8;              // [64 lanes][8]
-  double* sraw = gpl + 64 * 8;            // [2 halves][VT]; after the walk: the jet sums, then wave 1's tail sums [64][8] + [2 halves][4]
+  double* gpl = pl + 64 * 8;              // [1 or 2 waves][64 lanes][8]
+  double* sraw = gpl + sep_gpl_waves<T>() * 64 * 8;      // [2 halves][VT]; after the walk: the jet sums, then wave 1's tail sums [64][8] + [2 halves][4]
   int pair, c;
   if (!xcd_index((a.B + 1) >> 1, a.C, pair, c)) return;            // (workgroup-uniform: before any barrier)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, C = a.C, CO = a.CO, N = a.N;
@@ -372,21 +379,48 @@ __global__ __launch_bounds__(128) void local_bwd_sep_kernel(StaticBwdArgs a) {
     }
     if (wave == 0) {
 #pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        pl[lane * 8 + r] = valid ? a.pc[(size_t)node * 8 + r] : 0.0;
-        gpl[lane * 8 + r] = 0.0;
-      }
+      for (int r = 0; r < 8; ++r) pl[lane * 8 + r] = valid ? a.pc[(size_t)node * 8 + r] : 0.0;
+    }
+    if (wave < sep_gpl_waves<T>()) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) gpl[(wave * 64 + lane) * 8 + r] = 0.0;
     }
     if (threadIdx.x < 2) sraw[threadIdx.x * VT + SepMap<T>::ZERO] = 0.0;
   }
-  SepWalk w{tab + half * Q * 12, pl + lane * 8, gpl + lane * 8, sraw + half * VT + half_sum8_k(lane), (lane & 3) == 0};
+  SepWalk w{tab + half * Q * 12, pl + lane * 8, gpl + ((sep_gpl_waves<T>() == 2 ? wave : 0) * 64 + lane) * 8,
+            sraw + half * VT + half_sum8_k(lane), (lane & 3) == 0};
   __syncthreads();
   const double* xl = xs + 2 * lane;
   {
     double* gxl = gxs + wave * Q * 128 + 2 * lane;
     const double* __restrict__ got = a.goT + tile * CO * QO * 128 + l64;
     double* __restrict__ part0 = a.part + (size_t)pair * a.n_packed;
-    if (wave == 0) {
+    if constexpr (T::Q == 5) {
+      // first level (stamps, -DLGN_PSTAMP_Q=5: the round-3 split left wave 1 idle for 44 k of 68 k cycles): wave 0 the moment blocks of
+      // irreps 0, 1, 3, 4; wave 1 irrep 2 whole -- its moment block included -- and every product block
+      if (wave == 0) {
+        PSTAMP(0);
+        irrep_bwd_sep<T, 0, 0, T::NUBLK[0], COT>(a, c, got, part0, w, xl, gxl, lane, valid);
+        PSTAMP(1);
+        irrep_bwd_sep<T, 1, 0, T::NUBLK[1], COT>(a, c, got, part0, w, xl, gxl, lane, valid);
+        PSTAMP(2);
+        irrep_bwd_sep<T, 3, 0, T::NUBLK[3], COT>(a, c, got, part0, w, xl, gxl, lane, valid);
+        PSTAMP(4);
+        irrep_bwd_sep<T, 4, 0, T::NUBLK[4], COT>(a, c, got, part0, w, xl, gxl, lane, valid);
+        PSTAMP(5);
+      } else {
+        PSTAMP(16);
+        irrep_bwd_sep<T, 2, 0, T::NBLK[2], COT>(a, c, got, part0, w, xl, gxl, lane, valid);
+        PSTAMP(17);
+        irrep_bwd_sep<T, 3, T::NUBLK[3], T::NBLK[3], COT>(a, c, got, part0, w, xl, gxl, lane, valid);
+        PSTAMP(18);
+        irrep_bwd_sep<T, 4, T::NUBLK[4], T::NBLK[4], COT>(a, c, got, part0, w, xl, gxl, lane, valid);
+        PSTAMP(19);
+        irrep_bwd_sep<T, 1, T::NUBLK[1], T::NBLK[1], COT>(a, c, got, part0, w, xl, gxl, lane, valid);
+        irrep_bwd_sep<T, 0, T::NUBLK[0], T::NBLK[0], COT>(a, c, got, part0, w, xl, gxl, lane, valid);
+        PSTAMP(20);
+      }
+    } else if (wave == 0) {
       PSTAMP(0);
       irrep_bwd_sep<T, 0, 0, T::NUBLK[0], COT>(a, c, got, part0, w, xl, gxl, lane, valid);
       PSTAMP(1);
@@ -481,8 +515,10 @@ __global__ __launch_bounds__(128) void local_bwd_sep_kernel(StaticBwdArgs a) {
       for (int m = 0; m < 4; ++m) {
         const cx<double> g2 = {t.gp2[m].r + xch[lane * 8 + m], t.gp2[m].i + xch[lane * 8 + 4 + m]};
         const cx<double> r = cmulc(g2, t.R1);              // g2 conj(R1)
-        gp[m] = gpl[lane * 8 + 2 * m] - r.r;
-        gp[4 + m] = gpl[lane * 8 + 2 * m + 1] - r.i;
+        double g1r = gpl[lane * 8 + 2 * m], g1i = gpl[lane * 8 + 2 * m + 1];
+        if constexpr (sep_gpl_waves<T>() == 2) { g1r += gpl[(64 + lane) * 8 + 2 * m]; g1i += gpl[(64 + lane) * 8 + 2 * m + 1]; }
+        gp[m] = g1r - r.r;
+        gp[4 + m] = g1i - r.i;
       }
     }
     if (j == 0 && jet < a.B) {
