@@ -165,8 +165,10 @@ __global__ __launch_bounds__(128) void local_bwd_static_kernel(StaticBwdArgs a) 
   const double* xl = xs + 2 * lane;
   double* gxl = gxs[wave] + 2 * lane;
   // (round 6, in-kernel stamps of the 6 -> 6 level: wave 0 141 k cycles, wave 1 113 k -- the last four product blocks of irrep 0, 13 k,
-  // moved to wave 1 for the later levels; the first level keeps the round-3 split)
-  constexpr int B0 = T::Q == 20 ? T::NBLK[0] - 4 : T::NBLK[0];
+  // moved to wave 1 for the later levels)
+  // (first level, stamps of the encoder's level 0: wave 0 38 k cycles, wave 1 18 k -- its product blocks of irrep 0 go to wave 1 as
+  // well; the moment blocks, two thirds of wave 0's time, cannot: dU is read-modify-written by one wave only)
+  constexpr int B0 = T::Q == 20 ? T::NBLK[0] - 4 : T::NUBLK[0];
   static_assert(B0 >= T::NUBLK[0], "wave 1 takes product blocks only");
   if (wave == 0) {
     SSTAMP(0);

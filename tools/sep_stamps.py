@@ -25,6 +25,12 @@ for _ in range(3):
     st.step()
 torch.cuda.synchronize()
 out = (C.c_longlong * 256)()
+if len(sys.argv) > 1 and sys.argv[1] == "static":      # the LAST local_bwd_static launch of the step: the encoder's first level (Kind1)
+    Nn.lib().lgn_debug_stamps_local_static(out)
+    s = list(out)
+    print("local_bwd_static, encoder level 0: wave 0 stamps 0..6:", [s[i] - s[0] for i in range(0, 7)], " wave 1 stamps 10..13:",
+          [s[i] - s[0] for i in range(10, 14)])
+    sys.exit(0)
 Nn.lib().lgn_debug_stamps_local_sep(out)
 s = list(out)
 w0 = [s[i] - s[0] for i in range(0, 10)]
