@@ -208,8 +208,10 @@ __device__ __forceinline__ void edge_from_R(const double* r, const cx<double> (&
 // =========================================================================================================
 // forward
 // =========================================================================================================
+// (round 6: the QPT = 5 instantiation took 196 registers -- two waves per SIMD, PMC 1.6 resident, 42 % of a wave's life waiting; at
+// three waves per SIMD (168 registers, 16 spilled outside the pair loop) 72.7 / 106.8 -> 69.3 / 94.8 us; four: 94 spilled, 2.4 x slower)
 template <bool DEC, int QPT>
-__global__ __launch_bounds__(BLOCK) void moments_fwd2_kernel(GenArgs a) {
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(QPT >= 5 ? 3 : 1, QPT >= 5 ? 3 : 8))) void moments_fwd2_kernel(GenArgs a) {
   constexpr int PS = DEC ? 8 : 4;
   const int N = a.N, B = a.B, Q = a.Q, C = a.C, RP = row_pitch(N);
   const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -913,14 +915,28 @@ __global__ __launch_bounds__(BLOCK) void moments_rad_reduce2_kernel(GenArgs a, c
     }
   };
   // operands of the next PF steps in flight (one step ahead left the loop a chain of ~30 global round trips per wave: 34 - 46 us for
-  // 60 - 90 MB of pair gradients)
-  constexpr int PF = 3;
+  // 60 - 90 MB of pair gradients; three ahead: 30 - 40 us)
+  constexpr int PF = 6;
   int ci[PF], cj[PF];
   bool cok[PF];
   double cav[PF][2 * NG];
+  // this lane's pairs are u = 4 wave + kq + 16 t: decoded once (the square root), then walked -- i += 16, rows j hold j + 1 pairs
+  int wi, wj, wu = wave * 4 + kq;
+  {
+    bool ok0;
+    decode(wu, wi, wj, ok0);
+  }
+  auto next_pair = [&](int& i, int& j, bool& ok) {
+    ok = wu < nuno;
+    i = ok ? wi : 0;
+    j = ok ? wj : 0;
+    wu += 16;
+    wi += 16;
+    while (wi > wj) { wi -= wj + 1; ++wj; }
+  };
 #pragma unroll
   for (int d = 0; d < PF; ++d) {
-    decode(wave * 4 + 16 * d + kq, ci[d], cj[d], cok[d]);
+    next_pair(ci[d], cj[d], cok[d]);
     fetch(ci[d], cj[d], cok[d], cav[d]);
   }
   for (int u0 = wave * 4; u0 < nuno; u0 += 16) {               // 4 pairs per MFMA step, waves interleaved
@@ -935,7 +951,7 @@ __global__ __launch_bounds__(BLOCK) void moments_rad_reduce2_kernel(GenArgs a, c
 #pragma unroll
       for (int g = 0; g < 2 * NG; ++g) cav[d][g] = cav[d + 1][g];
     }
-    decode(u0 + 16 * PF + kq, ci[PF - 1], cj[PF - 1], cok[PF - 1]);      // (beyond the last pair: ok = false, the loads are of pair 0)
+    next_pair(ci[PF - 1], cj[PF - 1], cok[PF - 1]);                      // (beyond the last pair: ok = false, the loads are of pair (0, 0))
     fetch(ci[PF - 1], cj[PF - 1], cok[PF - 1], cav[PF - 1]);
     const double* pi = pj + i * 4;
     const double* pq = pj + j * 4;
