@@ -51,6 +51,7 @@ __host__ __device__ inline int row_pitch(int N) { return (N | 1) + ((((N | 1) & 
 // One channel of a tile-blocked tensor ([tile][C][Qx][2][64], node n = 64 tile + lane) -> LDS rows dst[node * pitch + 2 r + plane],
 // r = 0 .. Qx - 1.  lane = particle of the jet (a jet's particles are consecutive lanes of one or two tiles: every load is a
 // coalesced run), waves take rows r round robin; no index arithmetic per element, the loads of an unrolled group in flight together.
+template <int NW = 4>      // waves of the workgroup
 __device__ __forceinline__ void stage_tb(const double* __restrict__ src, int Qx, int C, int c, int b, int N, double* dst, int pitch) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (lane >= N) return;
@@ -58,14 +59,14 @@ __device__ __forceinline__ void stage_tb(const double* __restrict__ src, int Qx,
   const double* __restrict__ s = src + ((size_t)(n >> 6) * C + c) * Qx * 128 + (n & 63);
   double* d = dst + (size_t)lane * pitch;
   int r = wave;
-  for (; r + 12 < Qx; r += 16) {
+  for (; r + 3 * NW < Qx; r += 4 * NW) {
     double v[4][2];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { v[u][0] = s[(r + 4 * u) * 128]; v[u][1] = s[(r + 4 * u) * 128 + 64]; }
+    for (int u = 0; u < 4; ++u) { v[u][0] = s[(r + NW * u) * 128]; v[u][1] = s[(r + NW * u) * 128 + 64]; }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { d[2 * (r + 4 * u)] = v[u][0]; d[2 * (r + 4 * u) + 1] = v[u][1]; }
+    for (int u = 0; u < 4; ++u) { d[2 * (r + NW * u)] = v[u][0]; d[2 * (r + NW * u) + 1] = v[u][1]; }
   }
-  for (; r < Qx; r += 4) { d[2 * r] = s[r * 128]; d[2 * r + 1] = s[r * 128 + 64]; }
+  for (; r < Qx; r += NW) { d[2 * r] = s[r * 128]; d[2 * r + 1] = s[r * 128 + 64]; }
 }
 
 template <bool DEC>
@@ -152,9 +153,9 @@ __device__ __forceinline__ int tri_index(int i, int j) {
   const int lo = i < j ? i : j, hi = i < j ? j : i;
   return hi * (hi + 1) / 2 + lo;
 }
-__device__ __forceinline__ void fill_R_sym(const GenArgs& a, const Jet& J) {
+__device__ __forceinline__ void fill_R_sym(const GenArgs& a, const Jet& J, int nthreads = BLOCK) {
   const int N = a.N, NU = N * (N + 1) / 2;
-  for (int u = threadIdx.x; u < NU; u += BLOCK) {
+  for (int u = threadIdx.x; u < NU; u += nthreads) {
     int hi = (int)((sqrt(8.0 * (double)u + 1.0) - 1.0) * 0.5);
     while ((hi + 1) * (hi + 2) / 2 <= u) ++hi;
     while (hi * (hi + 1) / 2 > u) --hi;
@@ -524,52 +525,72 @@ __global__ __launch_bounds__(BLOCK) void moments_bwd_G2_kernel(GenArgs a, double
 //   sweep 2 (i-centric):  G_k(i, j) = sum_q dU[i][q][k] conj(X_j[q])  ->  Gbuf (moments_rad_reduce2_kernel)
 // with the arithmetic of the two kernels above, term for term.
 // =========================================================================================================
-template <int QPT>
-__global__ __launch_bounds__(BLOCK) void moments_bwd_enc2_kernel(GenArgs a, double* Gbuf) {
+// EIGHT waves per workgroup (round 6, second step): the LDS image allows two workgroups per CU, which at four waves each left two
+// waves per SIMD and 58 % of a wave's life waiting (PMC) -- with eight, four.  Sweep 1: wave = (component group, half of the source
+// range), the two halves of a (j, component) sum meet through LDS (in the pair table's place: sweep 2 does not need it); sweep 2:
+// sixteen partner groups.
+// (measured: 252.7 / 160.9 -> 238.4 / 156.0 us at Q = 20; the first level, Q = 5, has three component groups for four and LOSES with
+// eight waves -- 58.2 -> 68.8 us -- and keeps four)
+// doubles at the head of the LDS image: the symmetric pair table, or sweep 1's exchange block where that is larger (small jets)
+__host__ __device__ inline size_t enc2_head_doubles(int N, int qpt) {
+  const size_t tab = (size_t)(N * (N + 1) / 2) * 4, xch = (size_t)4 * N * qpt * 2;
+  return tab > xch ? tab : xch;
+}
+template <int QPT, int ENC2_NW>
+__global__ __launch_bounds__(64 * ENC2_NW) void moments_bwd_enc2_kernel(GenArgs a, double* Gbuf) {
+  static_assert(ENC2_NW == 4 || ENC2_NW == 8, "four component groups x one or two halves of the source range");
+  constexpr int NT = 64 * ENC2_NW, NPART = ENC2_NW / 2;          // source-range parts: lane halves x wave halves
   const int N = a.N, B = a.B, Q = a.Q, C = a.C;
   const int b = blockIdx.x, c = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   extern __shared__ __align__(16) unsigned char smem_raw[];
-  const int GS = g2_row_pitch(Q), NU = N * (N + 1) / 2;
+  const int GS = g2_row_pitch(Q);
   Jet J;
-  J.Rl = reinterpret_cast<double*>(smem_raw);                  // [NU][4]: R(i, j) for i <= j at tri_index(i, j)
-  double* gu = J.Rl + (size_t)NU * 4;                          // [N][GS]: (q, k, plane) of row n
+  J.Rl = reinterpret_cast<double*>(smem_raw);                  // [N (N + 1) / 2][4]: R(i, j) for i <= j at tri_index(i, j); then sweep 1's exchange
+  double* gu = J.Rl + enc2_head_doubles(N, QPT);               // [N][GS]: (q, k, plane) of row n
   double* xs = gu + (size_t)N * GS;                            // [N][Q][2]
   J.pj = xs + (size_t)N * Q * 2;
   J.wl = J.pj + (size_t)N * 4;
   J.mk = reinterpret_cast<uint8_t*>(J.wl + NB * 8 + 4);
-  load_jet<false>(a, b, J);
-  load_channel_consts(a, c, J.wl);
+  {
+    const double* p0 = a.p + (size_t)b * N * 4;
+    for (int e = tid; e < N * 4; e += NT) J.pj[e] = p0[e];
+    for (int e = tid; e < N; e += NT) J.mk[e] = a.mask[(size_t)b * N + e];
+  }
+  if (tid < BLOCK) load_channel_consts(a, c, J.wl);
   const size_t plane = (size_t)B * N * C * Q;
   if (a.tb) {
-    stage_tb(a.gU, 5 * Q, C, c, b, N, gu, GS);
-    stage_tb(a.X, Q, C, c, b, N, xs, 2 * Q);
+    stage_tb<ENC2_NW>(a.gU, 5 * Q, C, c, b, N, gu, GS);
+    stage_tb<ENC2_NW>(a.X, Q, C, c, b, N, xs, 2 * Q);
   } else {
-    for (int e = tid; e < N * Q * 10; e += BLOCK) {
+    for (int e = tid; e < N * Q * 10; e += NT) {
       const int n = e / (Q * 10), r = e - n * Q * 10;
       gu[(size_t)n * GS + r] = a.gU[(((size_t)b * N + n) * C + c) * Q * 10 + r];
     }
-    for (int e = tid; e < N * Q; e += BLOCK) {
+    for (int e = tid; e < N * Q; e += NT) {
       const int q = e % Q, n = e / Q;
       xs[2 * (n * Q + q)] = a.X[feat_index(false, plane, C, Q, b * N + n, c, q, 0)];
       xs[2 * (n * Q + q) + 1] = a.X[feat_index(false, plane, C, Q, b * N + n, c, q, 1)];
     }
   }
   __syncthreads();
-  fill_R_sym(a, J);
+  fill_R_sym(a, J, NT);
   __syncthreads();
-  // ---- sweep 1, j-centric: lane = (node j, half of the source range), wave = group of QPT components ----
+  // ---- sweep 1, j-centric: lane = (node j, half), wave = (group of QPT components, half of the source range) ----
+  const int half = lane & 1, j = lane >> 1;
+  const bool jok = j < N;
+  const int jj = jok ? j : N - 1;
+  const int qg = wave & 3, ipart = wave >> 2, part = 2 * ipart + half;
+  const int iper = (N + NPART - 1) / NPART, ib = part * iper, ie = min(N, ib + iper);
+  constexpr int NQG = 1;        // component groups a wave runs through: Q <= 4 QPT for both instantiations (Q = 20 / QPT = 5, Q = 5 / QPT = 2)
+  cx<double> acc[QPT];
+  const int q0 = qg * QPT;
   {
-    const int half = lane & 1, j = lane >> 1;
-    const bool jok = j < N;
-    const int jj = jok ? j : N - 1;
-    const int imid = (N + 1) >> 1, ib = half ? imid : 0, ie = half ? N : imid;
     double pme[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) pme[m] = J.pj[jj * 4 + m];
-    for (int q0 = wave * QPT; q0 < Q; q0 += 4 * QPT) {
-      cx<double> acc[QPT];
 #pragma unroll
-      for (int x = 0; x < QPT; ++x) acc[x] = {0, 0};
+    for (int x = 0; x < QPT; ++x) acc[x] = {0, 0};
+    if (q0 < Q) {
       for (int i = ib; i < ie; ++i) {
         cx<double> q[4], e[5];
         rel_q<false>(J.pj + i * 4, pme, q);
@@ -586,27 +607,48 @@ __global__ __launch_bounds__(BLOCK) void moments_bwd_enc2_kernel(GenArgs a, doub
           }
         }
       }
+    }
+#pragma unroll
+    for (int x = 0; x < QPT; ++x) {
+      acc[x].r = pair_sum(acc[x].r);
+      acc[x].i = pair_sum(acc[x].i);
+    }
+  }
+  (void)NQG;
+  double* xch = J.Rl;                                          // [4 groups][N nodes][QPT][2]
+  if constexpr (ENC2_NW == 8) {
+    __syncthreads();                                           // every wave is done with the pair table
+    if (ipart == 1 && half == 0 && jok) {
 #pragma unroll
       for (int x = 0; x < QPT; ++x) {
-        const double sr = pair_sum(acc[x].r), si = pair_sum(acc[x].i);
-        if (half == 0 && jok && q0 + x < Q) {
-          a.gX[feat_index(a.tb, plane, C, Q, b * N + j, c, q0 + x, 0)] += sr;
-          a.gX[feat_index(a.tb, plane, C, Q, b * N + j, c, q0 + x, 1)] += si;
-        }
+        xch[((qg * N + j) * QPT + x) * 2] = acc[x].r;
+        xch[((qg * N + j) * QPT + x) * 2 + 1] = acc[x].i;
+      }
+    }
+    __syncthreads();
+  }
+  if (ipart == 0 && half == 0 && jok) {
+#pragma unroll
+    for (int x = 0; x < QPT; ++x) {
+      if (q0 + x < Q) {
+        const double or_ = ENC2_NW == 8 ? xch[((qg * N + j) * QPT + x) * 2] : 0.0, oi = ENC2_NW == 8 ? xch[((qg * N + j) * QPT + x) * 2 + 1] : 0.0;
+        a.gX[feat_index(a.tb, plane, C, Q, b * N + j, c, q0 + x, 0)] += acc[x].r + or_;
+        a.gX[feat_index(a.tb, plane, C, Q, b * N + j, c, q0 + x, 1)] += acc[x].i + oi;
       }
     }
   }
   // ---- sweep 2, i-centric: lane = (row i, partner group), the gradient of the pair's radial values ----
   {
-    const int grp = wave * 2 + (lane & 1), i = lane >> 1;        // 8 partner groups
+    constexpr int NGRP = 2 * ENC2_NW;
+    const int grp = wave * 2 + (lane & 1), i = lane >> 1;        // 8 or 16 partner groups
     const bool iok = i < N;
     const int ii = iok ? i : N - 1;
-    const int per = (N + 7) >> 3, jb = grp * per, je = min(N, jb + per);
+    const int per = (N + NGRP - 1) / NGRP, jb = grp * per, je = min(N, jb + per);
     double pi[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) pi[m] = J.pj[ii * 4 + m];
     const double* gi = gu + (size_t)ii * GS;
-    constexpr int JP = (MAXN + 7) / 8;
+    constexpr int JP = (MAXN + NGRP - 1) / NGRP;
     cx<double> ge[JP][5];
 #pragma unroll
     for (int t = 0; t < JP; ++t)
@@ -618,22 +660,22 @@ __global__ __launch_bounds__(BLOCK) void moments_bwd_enc2_kernel(GenArgs a, doub
       for (int k = 0; k < 5; ++k) gv[k] = {gi[x * 10 + 2 * k], gi[x * 10 + 2 * k + 1]};
 #pragma unroll
       for (int t = 0; t < JP; ++t) {
-        const int j = min(jb + t, N - 1);
-        const cx<double> xv = {xs[((size_t)j * Q + x) * 2], xs[((size_t)j * Q + x) * 2 + 1]};
+        const int jx = min(jb + t, N - 1);
+        const cx<double> xv = {xs[((size_t)jx * Q + x) * 2], xs[((size_t)jx * Q + x) * 2 + 1]};
 #pragma unroll
         for (int k = 0; k < 5; ++k) cfmac(ge[t][k], gv[k], xv);
       }
     }
 #pragma unroll
     for (int t = 0; t < JP; ++t) {
-      const int j = jb + t;
-      if (j >= je || !iok) continue;
+      const int jx = jb + t;
+      if (jx >= je || !iok) continue;
       cx<double> q[4];
-      rel_q<false>(pi, J.pj + j * 4, q);
+      rel_q<false>(pi, J.pj + jx * 4, q);
       cx<double> gR1 = {0, 0};
 #pragma unroll
       for (int m = 0; m < 4; ++m) cfmac(gR1, ge[t][1 + m], q[m]);
-      double* g = Gbuf + (((size_t)b * N * N + (size_t)i * N + j) * C + c) * 4;
+      double* g = Gbuf + (((size_t)b * N * N + (size_t)i * N + jx) * C + c) * 4;
       g[0] = ge[t][0].r + ge[t][0].i;             // e0 = R0 (1 + i)  ->  G_R0 = G_e0 conj(1 + i)
       g[1] = ge[t][0].i - ge[t][0].r;
       g[2] = gR1.r;
@@ -1072,7 +1114,7 @@ static int launch(const GenArgs& a, int which, double* Gbuf, hipStream_t st) {
 
 // encoder backward, both sweeps (moments_bwd_enc2_kernel): LDS = symmetric pair table + padded dU rows + X + jet data
 static size_t enc2_smem(const GenArgs& a) {
-  return sizeof(double) * ((size_t)(a.N * (a.N + 1) / 2) * 4 + (size_t)a.N * g2_row_pitch(a.Q) + (size_t)a.N * a.Q * 2 + (size_t)a.N * 4 + NB * 8 + 4) +
+  return sizeof(double) * (enc2_head_doubles(a.N, a.Q <= 8 ? 2 : 5) + (size_t)a.N * g2_row_pitch(a.Q) + (size_t)a.N * a.Q * 2 + (size_t)a.N * 4 + NB * 8 + 4) +
          a.N + 16;
 }
 static int launch_enc2(const GenArgs& a, double* Gbuf, hipStream_t st) {
@@ -1080,13 +1122,13 @@ static int launch_enc2(const GenArgs& a, double* Gbuf, hipStream_t st) {
   const dim3 grid(a.B, a.C);
   int rc;
   if (a.Q <= 8) {
-    auto k = moments_bwd_enc2_kernel<2>;
+    auto k = moments_bwd_enc2_kernel<2, 4>;
     if ((rc = set_smem(k, smem, "moments_bwd_enc2"))) return rc;
-    hipLaunchKernelGGL(k, grid, dim3(BLOCK), smem, st, a, Gbuf);
+    hipLaunchKernelGGL(k, grid, dim3(256), smem, st, a, Gbuf);
   } else {
-    auto k = moments_bwd_enc2_kernel<5>;
+    auto k = moments_bwd_enc2_kernel<5, 8>;
     if ((rc = set_smem(k, smem, "moments_bwd_enc2"))) return rc;
-    hipLaunchKernelGGL(k, grid, dim3(BLOCK), smem, st, a, Gbuf);
+    hipLaunchKernelGGL(k, grid, dim3(512), smem, st, a, Gbuf);
   }
   LGN_CHECK_LAUNCH();
   return 0;
@@ -1140,7 +1182,7 @@ int moments2_dispatch(const GenArgs& a, int decoder, int which, double* Gbuf, hi
   }
   // encoder backward: ONE kernel for both sweeps (which = 1; which = 2 is then the radial-parameter reduction alone) unless the
   // caller asks for the two-kernel form (LVL_MOMENTS_SPLIT: cross-check) or has no pair-gradient scratch for pass 1
-  const bool merged = Gbuf && !(a.flags & LVL_MOMENTS_SPLIT);
+  const bool merged = Gbuf && !(a.flags & LVL_MOMENTS_SPLIT) && a.Q <= 20;       // (a wave of the merged kernel owns ONE group of <= 5 components)
   if (which == 0) return m2::launch<false>(a, 0, nullptr, st);
   if (which == 1) return merged ? m2::launch_enc2(a, Gbuf, st) : m2::launch<false>(a, 1, nullptr, st);
   LGN_CHECK_ARG(Gbuf, "moments: the encoder's radial backward needs the pair-gradient scratch buffer");
