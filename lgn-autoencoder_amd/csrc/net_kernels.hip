@@ -692,10 +692,11 @@ __global__ __launch_bounds__(BLOCK) void dec_input_fwd_kernel(int B, int N, int 
 
 // backward.  g_p holds the gradient w.r.t. pdec accumulated by the levels.  part row per jet:
 //   dW00 [2][C] | dW11 [2][C] | dWg1 [2][N][Tin]
-// LDS: gcan [N][8] | gcart [N][8] | tmp [N*C][4] | wgl [2][N][Tin] | latl [Tin][8] | gp_l [N][8] | pd_l [N][8] | gs_l [N*C][2] |
-//      gv_l [N*C][8] | w1l [2C]
+// LDS: gcan [N][8] | gcart [N][8] | wgl [2][N][Tin] | latl [Tin][8] | gp_l [N][8] | pd_l [N][8] | gs_l [N*C][2] | gv_l [N*C][8] | w1l [2C]
+// (round 6: the input-mixing terms tmp [N*C][4] take the first half of each gv_l row once the momenta gradient has read it -- one
+//  barrier more, 29 KB less at N = 150, C = 6: that shape's decoder input stage now fits a CU's LDS, 150 of 160 KB)
 __host__ __device__ inline size_t dec_in_bwd_doubles(int N, int C, int Tin) {
-  return (size_t)N * 16 + (size_t)N * C * 4 + 2 * (size_t)N * Tin + (size_t)Tin * 8 + (size_t)N * 16 + (size_t)N * C * 10 + 2 * (size_t)C;
+  return (size_t)N * 16 + 2 * (size_t)N * Tin + (size_t)Tin * 8 + (size_t)N * 16 + (size_t)N * C * 10 + 2 * (size_t)C;
 }
 struct DecInBwdStage {
   StageRegs<4> gvr, gvi, wg;
@@ -715,7 +716,7 @@ struct DecInBwdStage {
     gsr.issue(gs0, N * C); gsi.issue(gs1, N * C); lr.issue(l0, Tin * 4); li.issue(l1, Tin * 4); a1.issue(w1, 2 * C);
   }
   __device__ __forceinline__ void commit(double* lds) const {
-    double* wgl = lds + N * 16 + N * C * 4;
+    double* wgl = lds + N * 16;
     double* latl = wgl + 2 * N * Tin;
     double* gp_l = latl + Tin * 8;
     double* pd_l = gp_l + N * 8;
@@ -741,13 +742,12 @@ template <bool TO_LDS>
 __device__ __forceinline__ void dec_input_bwd_body(int B, int N, int C, int Tin, double* g_lat_v, double* part, double* lds, double* g_lat_l) {
   double* gcan = lds;                                    // [N][8] gradient w.r.t. the canonical momenta
   double* gcart = gcan + N * 8;                          // [N][8] gradient w.r.t. the complex Cartesian momenta
-  double* tmp = gcart + N * 8;                           // [N*C][4] input-mixing terms
-  const double* wgl = tmp + N * C * 4;                   // [2][N][Tin]
+  const double* wgl = gcart + N * 8;                     // [2][N][Tin]
   const double* latl = wgl + 2 * N * Tin;                // [Tin][8]
   const double* gp_l = latl + Tin * 8;
   const double* pd_l = gp_l + N * 8;
   const double* gs_l = pd_l + N * 8;
-  const double* gv_l = gs_l + N * C * 2;
+  double* gv_l = const_cast<double*>(gs_l) + N * C * 2;  // [N*C][8]; then tmp: the input-mixing terms in [i][0..3]
   const double* w1l = gv_l + N * C * 8;
   const int b = blockIdx.x;
   double* row = part + (size_t)b * (4 * C + 2 * N * Tin);
@@ -761,6 +761,7 @@ __device__ __forceinline__ void dec_input_bwd_body(int B, int N, int C, int Tin,
     gcan[n * 8 + m] = g.r;
     gcan[n * 8 + 4 + m] = g.i;
   }
+  __syncthreads();                                       // every read of gv_l by ANOTHER thread is done: row i now belongs to thread i
   for (int i = threadIdx.x; i < N * C; i += BLOCK) {     // (n, c): terms of dW00, dW11
     const int n = i / C;
     cx<double> d0 = {0, 0}, d1 = {0, 0};
@@ -768,7 +769,7 @@ __device__ __forceinline__ void dec_input_bwd_body(int B, int N, int C, int Tin,
 #pragma unroll
     for (int m = 0; m < 4; ++m)
       cfmac(d1, cx<double>{gv_l[i * 8 + m], gv_l[i * 8 + 4 + m]}, cx<double>{pd_l[n * 8 + m], pd_l[n * 8 + 4 + m]});
-    tmp[i * 4 + 0] = d0.r;  tmp[i * 4 + 1] = d0.i;  tmp[i * 4 + 2] = d1.r;  tmp[i * 4 + 3] = d1.i;
+    gv_l[i * 8 + 0] = d0.r;  gv_l[i * 8 + 1] = d0.i;  gv_l[i * 8 + 2] = d1.r;  gv_l[i * 8 + 3] = d1.i;
   }
   __syncthreads();
   STAMP(12);
@@ -781,7 +782,7 @@ __device__ __forceinline__ void dec_input_bwd_body(int B, int N, int C, int Tin,
     const int k = (threadIdx.x - (BLOCK - 64)) / C, c = (threadIdx.x - (BLOCK - 64)) - k * C;
     double acc = 0.0;
 #pragma unroll 6
-    for (int n = 0; n < N; ++n) acc += tmp[(n * C + c) * 4 + k];
+    for (int n = 0; n < N; ++n) acc += gv_l[(n * C + c) * 8 + k];
     row[k * C + c] = acc;
   }
   __syncthreads();

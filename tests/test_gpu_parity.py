@@ -760,11 +760,9 @@ def test_end_to_end_vs_reference_golden(dev, O, name, fused):
     if fused:
         # every fixture's configuration IS covered by the whole-network native calls (since round 4: g10 jet features + extra input
         # scalars, g7 mean+max pooling, g6 the learned 'mix' latent map) -- the training forward below must take them
-        # -- except g12's decoder: the input stage of 150 particles x 6 channels does not fit a CU's LDS, the plan-time query
-        # (lgn_decoder_end_lds_bytes) sends that network down the per-operator path while the encoder keeps its one call
-        # (g13, num_basis_fn = 5: since round 6 the flat parameter block stores the radial tensors 20 bells wide, zero padded -- the
-        # whole-network calls read them in place)
-        assert enc._fused_ok() and dec._fused_ok() == (not name.startswith("g12")), "expected the one-call-per-network native path"
+        # (g12, 150 particles x 6 channels at maxdim 3: the decoder's input stage fits a CU's LDS since round 6 -- its input-mixing terms
+        # share the vector-gradient rows; g13, num_basis_fn = 5: the flat parameter block stores the radial tensors 20 bells wide)
+        assert enc._fused_ok() and dec._fused_ok(), "expected the one-call-per-network native path"
     rec = dec(enc(batch))
     U.assert_close(rec, z["recon"], FWD_TOL, "recon")
     loss = O.chamfer_loss(rec[0] + rec[1], p4.to(dev))

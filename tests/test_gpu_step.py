@@ -55,18 +55,10 @@ def test_native_step_matches_reference_golden(name, use_graph):
     against the reference's loss / reconstruction / gradients."""
     from lgn.step import CapturedModuleStep, NativeTrainStep, native_train_step
     z, m, enc, dec, batch = _golden_setup(name)
-    if name.startswith("g12"):
-        # g12, 150 particles at maxdim 3: the decoder's per-jet input stage (6 channels) does not fit a CU's LDS -- the whole-step class
-        # says so at plan time and the chooser captures the module-API step (encoder: one call; decoder: one call per operator) instead.
-        with pytest.raises(NotImplementedError, match="LDS"):
-            NativeTrainStep(enc, dec, batch_size=m["B"])
-        step = native_train_step(enc, dec, m["B"], l1_lambda=m["l1_lambda"], optimizer=False, use_graph=use_graph)
-        assert isinstance(step, CapturedModuleStep)
-    else:
-        # (g13, num_basis_fn = 5, included since round 6: the radial parameters are STORED 20 bells wide in the flat block, zero
-        # padded, and the whole-step call reads them in place -- lgn/nn: RadPolyTrig._kernel_pad)
-        step = native_train_step(enc, dec, m["B"], l1_lambda=m["l1_lambda"], optimizer=False, use_graph=use_graph)
-        assert isinstance(step, NativeTrainStep), "the chooser must take the whole-step call for this configuration"
+    # (g12, 150 particles at maxdim 3, and g13, num_basis_fn = 5, included since round 6: the decoder's input stage of 150 x 6 fits a CU's
+    # LDS now, the radial parameters are STORED 20 bells wide -- the chooser must take the whole-step call for every fixture)
+    step = native_train_step(enc, dec, m["B"], l1_lambda=m["l1_lambda"], optimizer=False, use_graph=use_graph)
+    assert isinstance(step, NativeTrainStep), "the chooser must take the whole-step call for this configuration"
     for _ in range(2):                      # second iteration = graph replay on the same buffers
         total, recon = step.step(batch)
     U.assert_close(total, z["loss_total"], 1e-11, "total loss")
@@ -597,30 +589,33 @@ def test_latent_poolings_native_calls_match_per_op_path(latent, maxdim):
 def test_latent_poolings_other_jet_sizes(latent, N, B):
     """The same at jet sizes where the particle loops of the pooling kernels run partial rounds (7, 30) and where the junction's
     two stages share their LDS (150: with 'mix' the latent weights alone are 86 KB)."""
-    if latent == "mean&min&max" and N == 150:
-        # three pooled blocks of 8 latent vectors for 150 particles: the decoder's input stage would need 165 KB of LDS.  Decided at
-        # PLAN time (lgn_*_lds_bytes, lgn/_native.py: end_stages_fit): the whole-step class refuses with NotImplementedError, the chooser
-        # falls back to the captured module step, the modules take the per-operator path -- nothing fails at a launch.
-        import __graft_entry__ as G
-        from lgn.step import CapturedModuleStep, NativeTrainStep, TrainStep, native_train_step
-        from oracle import lgn_oracle as O
-        dev = torch.device("cuda:0")
-        enc, dec = G._models(N, (2, 3, 3, 4), (4, 3, 3, 2), dev, seed=7, map_to_latent=latent)
-        enc2, dec2 = G._models(N, (2, 3, 3, 4), (4, 3, 3, 2), dev, seed=7, map_to_latent=latent)
-        p4, labels = O.synthetic_jets(B, N, seed=11, pad=True)
-        batch = {"p4": p4.to(dev), "labels": labels.to(dev)}
-        assert enc._fused_ok() and not dec._fused_ok()          # (the encoder's latent stage fits, the decoder's input stage does not)
-        with pytest.raises(NotImplementedError, match="LDS"):
-            NativeTrainStep(enc, dec, batch_size=B, optimizer=False, use_graph=False)
-        a = native_train_step(enc, dec, B, optimizer=False, use_graph=False)
-        assert isinstance(a, CapturedModuleStep)
-        la, ra = a.step(batch)
-        enc2.use_fused = dec2.use_fused = False                 # every operator on its own native call
-        lb, rb = TrainStep(enc2, dec2, optimizer=False).forward_backward(batch)
-        U.assert_close(la, lb, 1e-11, "loss")
-        U.assert_close(ra, rb, 1e-11, "recon")
-        return
     _latent_case(latent, 2, N, B)
+
+
+def test_latent_stage_beyond_lds_is_refused_at_plan_time():
+    """Four pooled blocks of 8 latent vectors for 150 particles: the decoder's input stage would need 165 KB of LDS (three blocks fit
+    since round 6: 150 KB).  Decided at PLAN time (lgn_*_lds_bytes, lgn/_native.py: end_stages_fit): the whole-step class refuses with
+    NotImplementedError, the chooser falls back to the captured module step, the decoder takes the per-operator path -- nothing fails
+    at a launch."""
+    import __graft_entry__ as G
+    from lgn.step import CapturedModuleStep, NativeTrainStep, TrainStep, native_train_step
+    from oracle import lgn_oracle as O
+    dev = torch.device("cuda:0")
+    N, B, latent = 150, 2, "mean&max&min&mean"
+    enc, dec = G._models(N, (2, 3, 3, 4), (4, 3, 3, 2), dev, seed=7, map_to_latent=latent)
+    enc2, dec2 = G._models(N, (2, 3, 3, 4), (4, 3, 3, 2), dev, seed=7, map_to_latent=latent)
+    p4, labels = O.synthetic_jets(B, N, seed=11, pad=True)
+    batch = {"p4": p4.to(dev), "labels": labels.to(dev)}
+    assert not dec._fused_ok()          # (the decoder's input stage does not fit)
+    with pytest.raises(NotImplementedError, match="LDS"):
+        NativeTrainStep(enc, dec, batch_size=B, optimizer=False, use_graph=False)
+    a = native_train_step(enc, dec, B, optimizer=False, use_graph=False)
+    assert isinstance(a, CapturedModuleStep)
+    la, ra = a.step(batch)
+    enc2.use_fused = dec2.use_fused = False                 # every operator on its own native call
+    lb, rb = TrainStep(enc2, dec2, optimizer=False).forward_backward(batch)
+    U.assert_close(la, lb, 1e-11, "loss")
+    U.assert_close(ra, rb, 1e-11, "recon")
 
 
 def _latent_case(latent, maxdim, N, B):
