@@ -86,13 +86,19 @@ __device__ __forceinline__ cx<double> lds_cx(const double* p) {
   const sep_d2 v = *reinterpret_cast<const sep_d2*>(p);
   return {v.x, v.y};
 }
+__device__ __forceinline__ void lds_cx_add(double* p, const cx<double>& g) {
+  sep_d2 v = *reinterpret_cast<sep_d2*>(p);
+  v.x += g.r;
+  v.y += g.i;
+  *reinterpret_cast<sep_d2*>(p) = v;
+}
 // moment e = 5 q + k of the lane's node from the LDS copies
 __device__ __forceinline__ cx<double> sepw_u(const SepWalk& w, int e) {
   const int q = e / 5, k = e % 5;
   if (k == 0) return lds_cx(w.tab + q * 12);
   const cx<double> A = lds_cx(w.tab + q * 12 + 2), Bm = lds_cx(w.tab + q * 12 + 2 + 2 * k);
   cx<double> r = {-Bm.r, -Bm.i};
-  cfma(r, lds_cx(w.pl + 2 * (k - 1)), A);
+  cfma(r, lds_cx(w.pl + 128 * (k - 1)), A);
   return r;
 }
 
@@ -136,7 +142,7 @@ __device__ __forceinline__ double sep_val(const SepWalk& w, const cx<double> (&g
     if constexpr (comp == 0) return gu[K].r;
     else if constexpr (comp == 1) return gu[K].i;
     else {
-      const cx<double> sp = cmulc(gu[K], lds_cx(w.pl + 2 * (e % 5 - 1)));
+      const cx<double> sp = cmulc(gu[K], lds_cx(w.pl + 128 * (e % 5 - 1)));
       return comp == 2 ? sp.r : sp.i;
     }
   }
@@ -172,10 +178,10 @@ __device__ __forceinline__ void sep_reduce(const SepWalk& w, const cx<double> (&
     cx<double> gpb[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
     sep_gp<T, L, BLK, 0, NU1>(w, gu, gpb);
     // the lane's d p: plain read-modify-write of lane-private slots, once per block
-    if constexpr (sep_blk_has_m<T>(L, BLK, 0)) { w.gpl[0] += gpb[0].r; w.gpl[1] += gpb[0].i; }
-    if constexpr (sep_blk_has_m<T>(L, BLK, 1)) { w.gpl[2] += gpb[1].r; w.gpl[3] += gpb[1].i; }
-    if constexpr (sep_blk_has_m<T>(L, BLK, 2)) { w.gpl[4] += gpb[2].r; w.gpl[5] += gpb[2].i; }
-    if constexpr (sep_blk_has_m<T>(L, BLK, 3)) { w.gpl[6] += gpb[3].r; w.gpl[7] += gpb[3].i; }
+    if constexpr (sep_blk_has_m<T>(L, BLK, 0)) lds_cx_add(w.gpl + 0, gpb[0]);
+    if constexpr (sep_blk_has_m<T>(L, BLK, 1)) lds_cx_add(w.gpl + 128, gpb[1]);
+    if constexpr (sep_blk_has_m<T>(L, BLK, 2)) lds_cx_add(w.gpl + 256, gpb[2]);
+    if constexpr (sep_blk_has_m<T>(L, BLK, 3)) lds_cx_add(w.gpl + 384, gpb[3]);
     __builtin_amdgcn_sched_barrier(0);
     sep_batches<T, L, BLK, 0, NB8, NU1>(w, gu, lane);
   }
@@ -348,12 +354,12 @@ __global__ __launch_bounds__(128) void local_bwd_sep_kernel(StaticBwdArgs a) {
   static_assert(T::N_OUT == 5 && T::NUBLK[1] < T::NBLK[1] && T::NUBLK[3] < T::NBLK[3], "wave assignment");
   constexpr int Q = T::Q, QO = T::QOUT, VT = sep_vtotal<T>() + 2;      // (+ the slot that holds 0.0: SepMap::ZERO)
   static_assert(SepMap<T>::fits(), "a jet sum with more than 4 parked slots");
-  extern __shared__ double lds[];
+  extern __shared__ __align__(16) double lds[];      // (16 bytes: the (re, im) pairs travel as ds_read_b128 / ds_write_b128, not as two b64 halves)
   double* xs = lds;                       // [Q][64][2]
   double* gxs = xs + Q * 128;             // [2 waves][Q][64][2]
   double* tab = gxs + 2 * Q * 128;        // [2 halves][Q][12]: E | A | B_0..3
-  double* pl = tab + 2 * Q * 12;          // [64 lanes][8]
-  double* gpl = pl + 64 * 8;              // [1 or 2 waves][64 lanes][8]
+  double* pl = tab + 2 * Q * 12;          // [4 m][64 lanes][2]: a lane's pairs 16 bytes apart (stride 64 bytes: 4-way bank conflicts on every read)
+  double* gpl = pl + 64 * 8;              // [1 or 2 waves][4 m][64 lanes][2]
   double* sraw = gpl + sep_gpl_waves<T>() * 64 * 8;      // [2 halves][VT]; after the walk: the jet sums, then wave 1's tail sums [64][8] + [2 halves][4]
   int pair, c;
   if (!xcd_index((a.B + 1) >> 1, a.C, pair, c)) return;            // (workgroup-uniform: before any barrier)
@@ -379,15 +385,15 @@ __global__ __launch_bounds__(128) void local_bwd_sep_kernel(StaticBwdArgs a) {
     }
     if (wave == 0) {
 #pragma unroll
-      for (int r = 0; r < 8; ++r) pl[lane * 8 + r] = valid ? a.pc[(size_t)node * 8 + r] : 0.0;
+      for (int r = 0; r < 8; ++r) pl[(r >> 1) * 128 + 2 * lane + (r & 1)] = valid ? a.pc[(size_t)node * 8 + r] : 0.0;
     }
     if (wave < sep_gpl_waves<T>()) {
 #pragma unroll
-      for (int r = 0; r < 8; ++r) gpl[(wave * 64 + lane) * 8 + r] = 0.0;
+      for (int r = 0; r < 8; ++r) gpl[wave * 512 + (r >> 1) * 128 + 2 * lane + (r & 1)] = 0.0;
     }
     if (threadIdx.x < 2) sraw[threadIdx.x * VT + SepMap<T>::ZERO] = 0.0;
   }
-  SepWalk w{tab + half * Q * 12, pl + lane * 8, gpl + ((sep_gpl_waves<T>() == 2 ? wave : 0) * 64 + lane) * 8,
+  SepWalk w{tab + half * Q * 12, pl + 2 * lane, gpl + (sep_gpl_waves<T>() == 2 ? wave : 0) * 512 + 2 * lane,
             sraw + half * VT + half_sum8_k(lane), (lane & 3) == 0};
   __syncthreads();
   const double* xl = xs + 2 * lane;
@@ -487,7 +493,7 @@ __global__ __launch_bounds__(128) void local_bwd_sep_kernel(StaticBwdArgs a) {
   {
     cx<double> P[4];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) P[m] = lds_cx(pl + lane * 8 + 2 * m);
+    for (int m = 0; m < 4; ++m) P[m] = lds_cx(pl + 128 * m + 2 * lane);
     double* __restrict__ gxo = a.gXT + (tile * C + c) * Q * 128 + l64;
     constexpr int QH = (Q + 1) / 2;
     sep_tail(wave == 0 ? 0 : QH, wave == 0 ? QH : Q, sraw + half * VT, raw + half * Q * 10, P, xl, gxs + 2 * lane, gxs + Q * 128 + 2 * lane,
@@ -499,8 +505,8 @@ __global__ __launch_bounds__(128) void local_bwd_sep_kernel(StaticBwdArgs a) {
   if (wave == 1) {
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-      xch[lane * 8 + m] = t.gp2[m].r;
-      xch[lane * 8 + 4 + m] = t.gp2[m].i;
+      xch[m * 64 + lane] = t.gp2[m].r;
+      xch[(4 + m) * 64 + lane] = t.gp2[m].i;
     }
     if (j == 0) {
       double* ax = xch + 64 * 8 + half * 4;
@@ -513,10 +519,10 @@ __global__ __launch_bounds__(128) void local_bwd_sep_kernel(StaticBwdArgs a) {
       double* __restrict__ gp = a.gpb + ((size_t)c * a.M + node) * 8;
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
-        const cx<double> g2 = {t.gp2[m].r + xch[lane * 8 + m], t.gp2[m].i + xch[lane * 8 + 4 + m]};
+        const cx<double> g2 = {t.gp2[m].r + xch[m * 64 + lane], t.gp2[m].i + xch[(4 + m) * 64 + lane]};
         const cx<double> r = cmulc(g2, t.R1);              // g2 conj(R1)
-        double g1r = gpl[lane * 8 + 2 * m], g1i = gpl[lane * 8 + 2 * m + 1];
-        if constexpr (sep_gpl_waves<T>() == 2) { g1r += gpl[(64 + lane) * 8 + 2 * m]; g1i += gpl[(64 + lane) * 8 + 2 * m + 1]; }
+        double g1r = gpl[128 * m + 2 * lane], g1i = gpl[128 * m + 2 * lane + 1];
+        if constexpr (sep_gpl_waves<T>() == 2) { g1r += gpl[512 + 128 * m + 2 * lane]; g1i += gpl[512 + 128 * m + 2 * lane + 1]; }
         gp[m] = g1r - r.r;
         gp[4 + m] = g1i - r.i;
       }
