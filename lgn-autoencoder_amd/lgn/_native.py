@@ -402,9 +402,9 @@ class DeviceTables:
         self.struct = st
 
 
-def moments_fwd(decoder, X, p, mask, rad):
+def moments_fwd(decoder, X, p, mask, rad, out=None):
     _, B, N, Cc, Q = X.shape
-    U = torch.empty(B, N, Cc, Q, 5, 2, device=X.device, dtype=X.dtype)
+    U = torch.empty(B, N, Cc, Q, 5, 2, device=X.device, dtype=X.dtype) if out is None else out.view(B, N, Cc, Q, 5, 2)
     a, b, c, w0, b0, w1, b1 = rad
     _check(lib().lgn_moments_fwd_f64(B, N, Cc, Q, int(decoder), ptr(X), ptr(p), ptr(mask), ptr(a), ptr(b), ptr(c), ptr(w0),
                                      ptr(b0), ptr(w1), ptr(b1), ptr(U), stream_ptr()), "lgn_moments_fwd_f64")

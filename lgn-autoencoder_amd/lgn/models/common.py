@@ -280,8 +280,11 @@ def run_levels(module, decoder: bool, feats, p, mask):
     out = [feats]
     for lvl, plan in enumerate(plans):
         mix = lgn_cg.node_levels[lvl].cat_mix.mix_reps
-        radp = rad_funcs.rad_funcs[lvl].kernel_params()       # (zero-padded to the kernels' 20 bells when num_basis_fn < 10)
-        if _is_fused_layout(plan, module.level_maxdim[lvl]):
+        radp = rad_funcs.rad_funcs[lvl].kernel_params()       # (whole groups of the kernels' 20 bells, zero padded)
+        # (more than one group -- num_basis_fn > 10 -- runs the table-driven kernels at any maxdim: their moments are summed over the
+        # groups, ops.GenericLevelFn; the closed-form kernels evaluate their one group inside the pair sweep.  The decoder's
+        # edges carry the Linear bias alone -- no bells, no groups)
+        if _is_fused_layout(plan, module.level_maxdim[lvl]) and (decoder or radp[0].shape[-1] == ops.BELLS):
             s, v = ops.LevelFn.apply(decoder, feats[(0, 0)].squeeze(-1), feats[(1, 1)], p, mask, *radp,
                                      mix.weight((0, 0)), mix.weight((1, 1)))
             new = {(0, 0): s.unsqueeze(-1), (1, 1): v}

@@ -131,9 +131,8 @@ class RadPolyTrig(nn.Module):
             raise ValueError("Input basis can only be 'cartesian' or 'canonical'!")
         if not (mix is True or mix == "cplx"):
             raise NotImplementedError("the native radial network implements mix='cplx' (the only mode the autoencoder uses)")
-        if not 1 <= num_basis_fn <= self.KERNEL_BELLS // 2:
-            raise NotImplementedError(f"the native radial network evaluates up to {self.KERNEL_BELLS} Lorentzian bells (num_basis_fn <= "
-                                      f"{self.KERNEL_BELLS // 2}); got num_basis_fn={num_basis_fn}")
+        if num_basis_fn < 1:
+            raise ValueError(f"num_basis_fn must be at least 1; got {num_basis_fn}")
         self.max_zf, self.num_basis_fn, self.num_channels, self.input_basis = max_zf, num_basis_fn, num_channels, input_basis
         nb = 2 * num_basis_fn
         # drawn in the default dtype on the CPU, then cast/moved, like the reference (position_levels.py:67-73)
@@ -143,12 +142,16 @@ class RadPolyTrig(nn.Module):
         out = num_channels if input_basis == "canonical" else 2 * num_channels
         self.linear = nn.ModuleList([nn.Linear(nb, out).to(device=device, dtype=dtype) for _ in range(max_zf + 1)])
         self.radial_types = (num_channels,) * max_zf
-        if nb < self.KERNEL_BELLS:
-            # fewer bells than the kernels read: a network's flat parameter block STORES these tensors KERNEL_BELLS wide, zero padded
-            # (lgn/models/common.py: CGModule._flatten_parameters), so that every native call -- whole step included -- reads them in place
-            self._kernel_pad = {"a": self.KERNEL_BELLS, "b": self.KERNEL_BELLS, "c": self.KERNEL_BELLS}
+        # The kernels read KERNEL_BELLS bells per radial network.  Fewer (num_basis_fn < 10): a network's flat parameter block STORES
+        # these tensors KERNEL_BELLS wide, zero padded (lgn/models/common.py: CGModule._flatten_parameters), so that every native call --
+        # whole step included -- reads them in place.  More (num_basis_fn > 10, round 6): stored as whole groups of KERNEL_BELLS; the
+        # Linear layer is a sum over bells, so a level's moments are the sum of the moments of its groups (the bias in the first
+        # one) -- lgn/ops.py: GenericLevelFn runs the moments kernels once per group, on the per-operator path.
+        self.kernel_width = -(-nb // self.KERNEL_BELLS) * self.KERNEL_BELLS
+        if nb != self.kernel_width:
+            self._kernel_pad = {"a": self.kernel_width, "b": self.kernel_width, "c": self.kernel_width}
             for lin in self.linear:
-                lin._kernel_pad = {"weight": self.KERNEL_BELLS}
+                lin._kernel_pad = {"weight": self.kernel_width}
 
     KERNEL_BELLS = 20          # csrc/common.hpp: NB -- the width the level / moments kernels read (2 * num_basis_fn of the default 10)
 
@@ -156,16 +159,16 @@ class RadPolyTrig(nn.Module):
         return [self.a, self.b, self.c, self.linear[0].weight, self.linear[0].bias, self.linear[1].weight, self.linear[1].bias]
 
     def kernel_params(self):
-        """flat_params() in the width the kernels read.  Fewer than 20 bells (num_basis_fn < 10, lgn/nn/position_levels.py:44-64) are
-        embedded by zero padding: a bell with a = b = c = 0 and zero Linear weights evaluates to 0 and feeds nothing.  Inside a network
+        """flat_params() in the width the kernels read: whole groups of 20 bells (``kernel_width``).  Other counts (num_basis_fn not a
+        multiple of 10, lgn/nn/position_levels.py:44-64) are embedded by zero padding: a bell with a = b = c = 0 and zero Linear weights evaluates to 0 and feeds nothing.  Inside a network
         the padded blocks are the parameters' STORAGE (``a_store`` ...: views of the flat block, autograd-tracked on the per-operator
         path); a stand-alone module pads on the fly (a differentiable op: the padding's gradient slots are sliced away)."""
-        if 2 * self.num_basis_fn == self.KERNEL_BELLS:
+        if 2 * self.num_basis_fn == self.kernel_width:
             return self.flat_params()
         if "a_store" in self.__dict__:
             return [self.a_store, self.b_store, self.c_store, self.linear[0].weight_store, self.linear[0].bias,
                     self.linear[1].weight_store, self.linear[1].bias]
-        pad = self.KERNEL_BELLS - 2 * self.num_basis_fn
+        pad = self.kernel_width - 2 * self.num_basis_fn
         a, b, c, w0, b0, w1, b1 = self.flat_params()
         P = torch.nn.functional.pad
         return [P(a, (0, pad)), P(b, (0, pad)), P(c, (0, pad)), P(w0, (0, pad)), b0, P(w1, (0, pad)), b1]

@@ -189,42 +189,80 @@ def aggregate_latent(method, lat):
     raise NotImplementedError(f"{method} is not implemented.")
 
 
+BELLS = 20      # bells per radial network the kernels read (csrc/common.hpp: NB; lgn/nn: RadPolyTrig.KERNEL_BELLS)
+
+
+def _bell_groups(rad):
+    """The radial parameters (a, b, c, w0, b0, w1, b1), stored in whole groups of BELLS bells (RadPolyTrig.kernel_params), as one
+    tuple per group.  The Linear layer over the bells (lgn/nn/position_levels.py:144-170) is a sum, so radial functions, edges and
+    neighbour moments of the level are the sums over the groups; the Linear bias rides with the first group, the others get zeros
+    (a masked pair then contributes the bias once, as in the reference)."""
+    a, b, c, w0, b0, w1, b1 = rad
+    n = a.shape[-1] // BELLS
+    if n == 1:
+        return [rad]
+    z0, z1 = torch.zeros_like(b0), torch.zeros_like(b1)
+    out = []
+    for k in range(n):
+        cut = lambda t: t[..., k * BELLS:(k + 1) * BELLS].contiguous()      # noqa: E731
+        out.append((cut(a), cut(b), cut(c), cut(w0), b0 if k == 0 else z0, cut(w1), b1 if k == 0 else z1))
+    return out
+
+
 class GenericLevelFn(torch.autograd.Function):
     """LGNNodeLevel + edge network for arbitrary irreps (csrc/generic_moments.hip, csrc/generic_local.hip).
     args: decoder, tables (N.DeviceTables), CO, X packed (2,B,N,C,Q), p, mask, 7 radial params, then the CatMix
-    weights of the output irreps in ``tables.meta['out_irreps']`` order.  Returns the packed output (2,B,N,CO,Qout)."""
+    weights of the output irreps in ``tables.meta['out_irreps']`` order.  Returns the packed output (2,B,N,CO,Qout).
+    More than 20 bells (num_basis_fn > 10): the moments kernels run once per group of 20 (see _bell_groups), the groups' moments
+    are summed by the native row reduction, and the backward hands the ONE moment gradient to every group."""
 
     @staticmethod
     def forward(ctx, decoder, tables, CO, X, p, mask, ra, rb, rc, w0, b0, w1, b1, *wmix):
         X, p = N.f64(X), N.f64(p)
         rad = tuple(N.f64(t.detach()) for t in (ra, rb, rc, w0, b0, w1, b1))
-        if decoder:
-            rad = (None, None, None, None, rad[4], None, rad[6])
+        if decoder:       # (the decoder's edge mask is identically zero: only the Linear biases reach the output, whatever the bell count)
+            groups = [(None, None, None, None, rad[4], None, rad[6])]
+        else:
+            groups = _bell_groups(rad)
         wcat = torch.cat([N.f64(w.detach()).reshape(-1) for w in wmix])
-        U = N.moments_fwd(decoder, X, p, mask, rad)
+        if len(groups) == 1:
+            U = N.moments_fwd(decoder, X, p, mask, groups[0])
+        else:
+            _, B, Nn, Cc, Q = X.shape
+            Ug = torch.empty(len(groups), B * Nn * Cc * Q * 10, device=X.device, dtype=X.dtype)
+            for k, g in enumerate(groups):
+                N.moments_fwd(decoder, X, p, mask, g, out=Ug[k])
+            U = torch.empty(B, Nn, Cc, Q, 5, 2, device=X.device, dtype=X.dtype)
+            N.reduce_partials(Ug, U.view(-1))
         out = N.local_fwd(tables, CO, X, U, wcat)
         ctx.decoder, ctx.tables, ctx.CO, ctx.mask = decoder, tables, CO, mask
         ctx.rad_full = (ra, rb, rc, w0, b0, w1, b1)
         ctx.wshapes = [w.shape for w in wmix]
-        ctx.save_for_backward(X, p, U, wcat, *[t for t in rad if t is not None])
+        ctx.n_groups = len(groups)
+        ctx.save_for_backward(X, p, U, wcat, *([groups[0][4], groups[0][6]] if decoder else rad))
         return out
 
     @staticmethod
     def backward(ctx, g_out):
         X, p, U, wcat, *radl = ctx.saved_tensors
         decoder = ctx.decoder
-        if decoder:
-            rad = (None, None, None, None, radl[0], None, radl[1])
-            g_p = torch.zeros_like(p)
-        else:
-            rad, g_p = tuple(radl), None
         gU, gX, g_w = N.local_bwd(ctx.tables, ctx.CO, X, U, wcat, N.f64(g_out))
-        rg = N.moments_bwd(decoder, X, p, ctx.mask, rad, gU, gX, g_p)
         ra, rb, rc, w0, b0, w1, b1 = ctx.rad_full
         if decoder:
+            g_p = torch.zeros_like(p)
+            rg = N.moments_bwd(decoder, X, p, ctx.mask, (None, None, None, None, radl[0], None, radl[1]), gU, gX, g_p)
             g_rad = (torch.zeros_like(ra), torch.zeros_like(rb), torch.zeros_like(rc), torch.zeros_like(w0),
                      rg[0].view_as(b0), torch.zeros_like(w1), rg[1].view_as(b1))
         else:
+            g_p = None
+            # every group's call adds its share of d X (d X = sum over pairs of dU conj(edge), linear in the radial functions) and
+            # returns the gradients of its own bells; the bias gradients do not depend on the bells: the first group's are kept
+            per = [N.moments_bwd(decoder, X, p, ctx.mask, g, gU, gX, g_p) for g in _bell_groups(tuple(radl))]
+            if len(per) == 1:
+                rg = per[0]
+            else:
+                cat = lambda i: torch.cat([r[i] for r in per], dim=-1)      # noqa: E731
+                rg = (cat(0), cat(1), cat(2), cat(3), per[0][4], cat(5), per[0][6])
             g_rad = (rg[0].view_as(ra), rg[1].view_as(rb), rg[2].view_as(rc), rg[3], rg[4], rg[5], rg[6])
         g_ws, off = [], 0
         for shp in ctx.wshapes:

@@ -29,6 +29,8 @@ Fixtures
   g14_e2e_mlpwidth{4,5,7}.npz / g14_e2e_mlpwidth5_maxdim3.npz  end-to-end with --mlp-width 4 / 5 / 7 (maxdim 2, B=3 N=12 ch 2344/4432) and 5
                                      (maxdim 3, B=2 N=10 ch 246/642): CGMLP hidden widths other than 6 x 2C
   g13_e2e_basis5.npz / g13_e2e_basis5_maxdim3.npz  end-to-end with --num-basis-fn 5 (10 bells), maxdim 2 (B=3 N=12) and 3 (B=2 N=10)
+  g15_e2e_basis12.npz / g15_e2e_basis20_maxdim3.npz  end-to-end with --num-basis-fn 12 (24 bells, maxdim 2, B=3 N=12) and 20 (40 bells,
+                      maxdim 3, B=2 N=10): more bells than one group of the kernels' 20 (round 6)
   g12_e2e_n150_maxdim3.npz  end-to-end, B=1 N=150 maxdim=3 ch 4466/6644 (round 5: jets beyond the LDS-resident kernels)
   g8_harness.npz      the reference's own equivariance harness (lgn/models/autotest/lgn_tests.py:292-423) run on the g1 weights
                       (maxdim 2) and the g2 weights (maxdim 3): gamma / theta grids, output and internal-feature deviation
@@ -354,6 +356,10 @@ if __name__ == "__main__":
     if want("g13"):       # --num-basis-fn 5 (lgn/nn/position_levels.py:44-64): 10 Lorentzian bells instead of 20, maxdim 2 and maxdim 3
         e2e("g13_e2e_basis5.npz", 3, 12, 2, (2, 3, 4, 4), (4, 3, 3, 2), seed=10, pad_rows=((2, 9),), num_basis_fn=5)
         e2e("g13_e2e_basis5_maxdim3.npz", 2, 10, 3, (2, 3, 4), (4, 3, 2), seed=11, pad_rows=((1, 6),), num_basis_fn=5)
+    if want("g15"):       # --num-basis-fn beyond the default 10: 24 bells (12: one whole group of the kernels' 20 + a padded one) at maxdim 2,
+        # 40 bells (20: two whole groups) at maxdim 3
+        e2e("g15_e2e_basis12.npz", 3, 12, 2, (2, 3, 4, 4), (4, 3, 3, 2), seed=16, pad_rows=((1, 9),), num_basis_fn=12)
+        e2e("g15_e2e_basis20_maxdim3.npz", 2, 10, 3, (2, 3, 4), (4, 3, 2), seed=17, pad_rows=((0, 6),), num_basis_fn=20)
     if want("g14"):       # --mlp-width other than the default 6 (lgn/models/lgn_levels.py:124-189): hidden width = mlp_width * 2C -- 16 / 24 /
         # 32 (width 4), 20 / 30 / 40 (width 5: not multiples of the 4-deep matrix instruction), 28 / 42 / 56 (width 7: C = 4 leaves the
         # H <= 48 kernels), and 20 / 40 / 60 at maxdim 3

@@ -730,7 +730,7 @@ def _generic_level_case(dev, O, decoder, maxdim, full, C, CO, N, B):
                                   "g7_e2e_meanmax.npz", "g9_e2e_elu.npz", "g10_e2e_jetfeat.npz", "g11_e2e_mlpdepth4.npz",
                                   "g11_e2e_mlpdepth3_maxdim3.npz", "g12_e2e_n150_maxdim3.npz", "g13_e2e_basis5.npz",
                                   "g13_e2e_basis5_maxdim3.npz", "g14_e2e_mlpwidth4.npz", "g14_e2e_mlpwidth5.npz", "g14_e2e_mlpwidth7.npz",
-                                  "g14_e2e_mlpwidth5_maxdim3.npz"])
+                                  "g14_e2e_mlpwidth5_maxdim3.npz", "g15_e2e_basis12.npz", "g15_e2e_basis20_maxdim3.npz"])
 @pytest.mark.parametrize("fused", [True, False])
 def test_end_to_end_vs_reference_golden(dev, O, name, fused):
     """Full encoder -> decoder -> Chamfer forward/backward against vectors captured from the reference, through the
@@ -757,8 +757,12 @@ def test_end_to_end_vs_reference_golden(dev, O, name, fused):
     for i, rep in enumerate(nodes_all[n_enc:]):
         U.assert_rep_close(dict(rep.items()), U.rep_from(z, f"dec_nodes.{i}"), FWD_TOL, f"dec_nodes[{i}]")
 
-    if fused:
-        # every fixture's configuration IS covered by the whole-network native calls (since round 4: g10 jet features + extra input
+    if fused and name.startswith("g15"):
+        # num_basis_fn 12 / 20 (24 / 40 bells): more than the one group of 20 the whole-network calls read -- the per-operator path sums
+        # the table-driven moments over the groups (lgn/ops.py: GenericLevelFn), at maxdim 2 as well
+        assert not enc._fused_ok() and not dec._fused_ok(), "more than 20 bells must take the per-operator path"
+    elif fused:
+        # every OTHER fixture's configuration IS covered by the whole-network native calls (since round 4: g10 jet features + extra input
         # scalars, g7 mean+max pooling, g6 the learned 'mix' latent map) -- the training forward below must take them
         # (g12, 150 particles x 6 channels at maxdim 3: the decoder's input stage fits a CU's LDS since round 6 -- its input-mixing terms
         # share the vector-gradient rows; g13, num_basis_fn = 5: the flat parameter block stores the radial tensors 20 bells wide)

@@ -75,6 +75,29 @@ def test_native_step_matches_reference_golden(name, use_graph):
                 assert torch.equal(g.cpu(), lam * torch.sign(sd[k])), f"{pre}.{k}: dead parameter must get exactly the L1 term"
 
 
+@pytest.mark.parametrize("name", ["g15_e2e_basis12.npz", "g15_e2e_basis20_maxdim3.npz"])
+def test_more_than_twenty_bells_train_through_the_captured_module_step(name):
+    """num_basis_fn > 10 (lgn/nn/position_levels.py:60-97 takes any value): the whole-step call reads ONE group of 20 bells and must
+    refuse; the chooser then captures the module-API step (per-operator calls, moments summed over the groups of bells) into one
+    graph.  Loss, reconstruction and every gradient against the reference's vectors."""
+    from lgn.step import CapturedModuleStep, NativeTrainStep, native_train_step
+    z, m, enc, dec, batch = _golden_setup(name)
+    with pytest.raises(NotImplementedError):
+        NativeTrainStep(enc, dec, batch_size=m["B"], l1_lambda=m["l1_lambda"], optimizer=False)
+    step = native_train_step(enc, dec, m["B"], l1_lambda=m["l1_lambda"], optimizer=False)
+    assert isinstance(step, CapturedModuleStep)
+    for _ in range(2):
+        total, recon = step.step(batch)
+    U.assert_close(total, z["loss_total"], 1e-11, "total loss")
+    U.assert_close(recon, z["recon"], 1e-11, "recon")
+    lam = m["l1_lambda"]
+    for pre, mod in (("enc", enc), ("dec", dec)):
+        sd = U.params_from(z, pre)
+        for k, g in mod.named_grads():
+            ref = torch.from_numpy(z[f"grad.{pre}.{k}"]) + lam * torch.sign(sd[k])
+            U.assert_close(g, ref, 1e-9, f"grad {pre}.{k}")
+
+
 @pytest.mark.parametrize("flags", [("LGN_AMD_LEVEL_V2",), ("LGN_AMD_DEC_PAIRWISE",), ("LGN_AMD_BWD_ORDERED",), ("LGN_AMD_MLP_V1",),
                                    ("LGN_AMD_LEVEL_V2", "LGN_AMD_DEC_PAIRWISE")])
 @pytest.mark.parametrize("use_graph", [False, True])

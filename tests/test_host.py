@@ -231,8 +231,13 @@ def test_native_step_refuses_configurations_it_does_not_implement():
         NativeTrainStep(enc, dec, batch_size=4)
     enc, dec = G._models(30, (3, 3, 4, 4), (4, 4, 3, 3), torch.device("cpu"), seed=0)
     from lgn.nn import RadPolyTrig
-    with pytest.raises(NotImplementedError, match="num_basis_fn"):      # more Lorentzian bells than the kernels evaluate
-        RadPolyTrig(1, 11, 3)
+    r11 = RadPolyTrig(1, 11, 3)                                         # more bells than one group of the kernels' 20: whole groups, zero padded
+    kp = r11.kernel_params()
+    assert r11.kernel_width == 40 and [tuple(t.shape) for t in kp] == [(1, 1, 1, 40)] * 3 + [(6, 40), (6,), (6, 40), (6,)]
+    assert all(float(t[..., 22:].abs().max()) == 0 for t in (kp[0], kp[1], kp[2], kp[3], kp[5])) and torch.equal(kp[0][..., :22], r11.a)
+    assert RadPolyTrig(1, 20, 3).kernel_params()[0].shape[-1] == 40 and RadPolyTrig(1, 10, 3).kernel_width == 20
+    with pytest.raises(ValueError, match="num_basis_fn"):
+        RadPolyTrig(1, 0, 3)
     r5 = RadPolyTrig(1, 5, 3)                                           # fewer: zero-padded to the kernels' 20 on the per-operator path
     kp = r5.kernel_params()
     assert [tuple(t.shape) for t in kp] == [(1, 1, 1, 20)] * 3 + [(6, 20), (6,), (6, 20), (6,)]
@@ -340,3 +345,14 @@ def test_fewer_radial_bells_are_stored_padded_and_seen_unpadded():
     assert tuple(g["rad_funcs.rad_funcs.0.a"].shape) == (1, 1, 1, 10) and tuple(g["rad_funcs.rad_funcs.0.linear.1.weight"].shape) == (4, 10)
     from lgn.ops import native_kind
     assert native_kind(enc) == "fused" and native_kind(dec) == "fused"
+    # more than 20 bells (num_basis_fn 12): stored as two groups of 20, seen 24 wide; only the per-operator path sums over groups
+    big, bigd = G._models(12, (2, 3, 4), (4, 3, 2), torch.device("cpu"), seed=3, num_basis_fn=12)
+    sdb = big.state_dict()
+    assert tuple(sdb["rad_funcs.rad_funcs.0.a"].shape) == (1, 1, 1, 24) and tuple(sdb["rad_funcs.rad_funcs.1.linear.1.weight"].shape) == (6, 24)
+    assert big.num_learnable_parameters == sum(v.numel() for v in sdb.values())
+    assert big.rad_funcs.rad_funcs[1].kernel_params()[3].shape == (6, 40) and big.rad_funcs.rad_funcs[1].kernel_params()[3].data_ptr() == \
+        big.rad_funcs.rad_funcs[1].linear[0].weight.data_ptr()
+    assert native_kind(big) is None and native_kind(bigd) is None
+    from lgn.step import NativeTrainStep
+    with pytest.raises(NotImplementedError, match="num_basis_fn"):
+        NativeTrainStep(big, bigd, batch_size=2)

@@ -21,7 +21,7 @@ def _cfgs(m):
                                   "g7_e2e_meanmax.npz", "g9_e2e_elu.npz", "g10_e2e_jetfeat.npz", "g11_e2e_mlpdepth4.npz",
                                   "g11_e2e_mlpdepth3_maxdim3.npz", "g12_e2e_n150_maxdim3.npz", "g13_e2e_basis5.npz",
                                   "g13_e2e_basis5_maxdim3.npz", "g14_e2e_mlpwidth4.npz", "g14_e2e_mlpwidth5.npz", "g14_e2e_mlpwidth7.npz",
-                                  "g14_e2e_mlpwidth5_maxdim3.npz"])
+                                  "g14_e2e_mlpwidth5_maxdim3.npz", "g15_e2e_basis12.npz", "g15_e2e_basis20_maxdim3.npz"])
 def test_end_to_end_forward_backward(name):
     z = U.load(name)
     m = U.meta(z)
