@@ -44,6 +44,9 @@ for p in (ROOT, os.path.join(ROOT, "lgn-autoencoder_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+# (multi-process GPU work on this pool needs dmabuf IPC: the image exports this already; kept here for launchers that scrub the environment)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
