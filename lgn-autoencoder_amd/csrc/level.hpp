@@ -30,6 +30,7 @@ constexpr int LVL_LEVEL_V2 = 4;        // three-kernel level backward also for N
 constexpr int LVL_MLP_V1 = 8;          // CGMLP: the 12-wave kernels of mlp_mfma.hip also where the chain kernels (mlp_chain.hip) apply
 // (8 and 32 were round 4's switches of the CGMLP riding on the level kernels: built, measured slower in every regime, removed in round 5)
 constexpr int LVL_MOMENTS_V1 = 16;     // table-driven levels: component-chunked moments kernels
+constexpr int LVL_MLP_BWD1 = 1024;      // CGMLP chain backward: the one-role kernel (four waves: chain + weight gradients + staging) instead of the two-role one
 constexpr int LVL_MOMENTS_SPLIT = 512; // table-driven encoder levels: the backward's two pair sweeps as two kernels (cross-check of the merged one)
 constexpr int LVL_BWD_ORDERED = 64;    // encoder level backward (N <= 40): radial-gradient GEMM per ORDERED pair tile (cross-check of the symmetric sweep)
 int level_flags_from_env();

@@ -571,6 +571,142 @@ __global__ __launch_bounds__(256) void mlp_chain_bwd_kernel(MlpArgs<double> a) {
   STAMP(26);
 }
 
+// ---- backward, two roles per workgroup (round 6) ---------------------------------------------------------------------------------
+// The kernel above runs ONE wave per SIMD: whatever a wave waits for -- an LDS fragment, the barrier, the datapath's turn-around
+// after an fp64 vector instruction -- leaves the matrix pipe idle (0.40 busy at cfg2).  Here a workgroup is EIGHT waves over the same
+// 64 rows: waves 0 - 3 carry the chain (recompute, g_in = W^T g_pre, tile publication) and nothing else; waves 4 - 7 take what the
+// chain waves did on the side -- the weight gradients dW_l from the published tiles (one step behind the chain, as before) and the
+// staging of the weight images.  Every SIMD then holds two waves with independent instruction streams and the pipe takes whichever is
+// ready.  Same arithmetic, same summation order, same barriers (one per step, over all eight waves); 256 registers per wave.
+template <int H, int D, bool GEN>
+__global__ __launch_bounds__(512) void mlp_chain_bwd2_kernel(MlpArgs<double> a) {
+  using G = Geo<H, D>;
+  constexpr int NT = G::NT, NH = G::NH;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int w4 = wave & 3;                                   // chain waves: the 16-row tile; dW waves: the owner index of dw_layer
+  const int c = lane & 15, g = lane >> 4;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  double* Wl = reinterpret_cast<double*>(smem_raw);          // 2 weight images
+  double* Gt = Wl + 2 * G::WSIZE;                            // 2 g_pre tiles [neuron][64 rows]
+  double* Xt = Gt + 2 * G::TSIZE;                            // 2 layer-input tiles
+  STAMP(10);
+  if (wave >= 4) {
+    // ================= weight gradients + image staging =================
+    const int tid = (int)threadIdx.x - 256;
+    double* part = a.part + (size_t)blockIdx.x * a.psize;
+    WRegs<G> wrA, wrB;
+    stage_prologue<G, true>(a, Wl, wrA, wrB, tid);
+    lds_barrier();
+#define LGN_STAGE_ALL(Q)                                                                                             \
+  _Pragma("unroll") for (int j = 0; j < stage_pieces<G>(); ++j) stage_piece<G, true, Q>(a, Wl, wrA, wrB, tid, j);
+#define LGN_STAGE_STEP(Q) LGN_STAGE_ALL(Q) lds_barrier();
+    LGN_STAGE_STEP(0) LGN_STAGE_STEP(1) LGN_STAGE_STEP(2) LGN_STAGE_STEP(3) LGN_STAGE_STEP(4) LGN_STAGE_STEP(5)
+    LGN_STAGE_STEP(6)                                        // the output layer's step: nothing published yet
+    // step q = 2 NH - L: weight gradient of Linear L + 1 from the tiles of parity (L + 1) & 1, staging dealt under its matrix stream
+#define LGN_DW_STEP(L)                                                                                               \
+  {                                                                                                                  \
+    constexpr int q_ = 2 * NH - (L), NS = stage_pieces<G>();                                                         \
+    constexpr int NI = ((L) + 1 == NH || (L) + 1 == 0) ? 16 : 16 * NT;                                               \
+    auto side = [&](int i) { deal<NI, NS>(i, [&](int j) { stage_piece<G, true, q_>(a, Wl, wrA, wrB, tid, j); }); };  \
+    if (!dw_layer<G, (L) + 1>(Gt + (((L) + 1) & 1) * G::TSIZE, Xt + (((L) + 1) & 1) * G::TSIZE, part, w4, c, g, side)) { \
+      LGN_STAGE_ALL(q_)                                                                                              \
+    }                                                                                                                \
+    lds_barrier();                                                                                                   \
+  }
+    LGN_DW_STEP(5) LGN_DW_STEP(4) LGN_DW_STEP(3) LGN_DW_STEP(2) LGN_DW_STEP(1) LGN_DW_STEP(0)
+#undef LGN_DW_STEP
+#undef LGN_STAGE_STEP
+#undef LGN_STAGE_ALL
+    dw_layer<G, 0>(Gt, Xt, part, w4, c, g, [&](int) {});
+    return;
+  }
+  // ================= the chain =================
+  const int row = blockIdx.x * 64 + wave * 16 + c;
+  v4d xb[1];
+  load_x<G>(a, row, g, xb);
+  v4d gout[1];                                               // upstream gradient, D layout of the output tile (o = 4r + g, row c)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int o = 4 * r + g;
+    const bool ok = o < D && row < a.M;
+    const double x = a.g_out[ok ? mlp_out_index(a, o & 1, row, o >> 1) : 0];
+    gout[0][r] = ok ? x : 0.0;
+  }
+  v4d h[NH][NT];
+  lds_barrier();
+  STAMP(11);
+#define LGN_CHAIN_STEP(Q, HIN, KS, NTI)                                                                              \
+  layer_fwd<G, KS, NTI, GEN>(Wl + (Q & 1) * G::WSIZE, HIN, h[Q], c, g, a.act, [&](int) {});                          \
+  lds_barrier();                                                                                                     \
+  STAMP(12 + Q);
+  LGN_CHAIN_STEP(0, xb, G::KS0, 1)
+  LGN_CHAIN_STEP(1, h[0], G::KSH, NT)
+  LGN_CHAIN_STEP(2, h[1], G::KSH, NT)
+  LGN_CHAIN_STEP(3, h[2], G::KSH, NT)
+  LGN_CHAIN_STEP(4, h[3], G::KSH, NT)
+  LGN_CHAIN_STEP(5, h[4], G::KSH, NT)
+#undef LGN_CHAIN_STEP
+  v4d gpA[NT], gpB[NT], gin[NT];
+  {  // q = 6, l = 6: the output layer
+    constexpr int NI = G::KS0 * NT, NPC = 4 + 4 * NT;
+    auto fin = [&](int u, int r) {
+      double y = gin[u][r] * act_slope_t<GEN>(h[NH - 1][u][r], a.act);
+      pin(y);
+      gpA[u][r] = y;
+    };
+    layer_bwd<G, G::KS0, NT, 1>(Wl + 0 * G::WSIZE, gout, gin, c, g, fin, [&](int i) {
+      deal<NI, NPC>(i, [&](int j) {
+        if (j < 4) publish_piece<G, 1>(Gt, gout, wave, c, g, j);
+        else publish_piece<G, NT>(Xt, h[NH - 1], wave, c, g, j - 4);
+      });
+    });
+#pragma unroll
+    for (int r = 0; r < 4; ++r) fin(NT - 1, r);
+    lds_barrier();
+    STAMP(18);
+  }
+#define LGN_CHAIN_BSTEP(L, GP, GN)                                                                                   \
+  {                                                                                                                  \
+    constexpr int q_ = 2 * NH - (L), NI = G::KSH * NT, NPC = 8 * NT;                                                 \
+    auto fin = [&](int u, int r) {                                                                                   \
+      double y = gin[u][r] * act_slope_t<GEN>(h[(L) - 1][u][r], a.act);                                              \
+      pin(y);                                                                                                        \
+      GN[u][r] = y;                                                                                                  \
+    };                                                                                                               \
+    layer_bwd<G, G::KSH, NT, NT>(Wl + (q_ & 1) * G::WSIZE, GP, gin, c, g, fin, [&](int i) {                          \
+      deal<NI, NPC>(i, [&](int j) {                                                                                  \
+        if (j < 4 * NT) publish_piece<G, NT>(Gt + ((L) & 1) * G::TSIZE, GP, wave, c, g, j);                          \
+        else publish_piece<G, NT>(Xt + ((L) & 1) * G::TSIZE, h[(L) - 1], wave, c, g, j - 4 * NT);                    \
+      });                                                                                                            \
+    });                                                                                                              \
+    _Pragma("unroll") for (int r = 0; r < 4; ++r) fin(NT - 1, r);                                                    \
+    lds_barrier();                                                                                                   \
+    STAMP(12 + q_);                                                                                                  \
+  }
+  LGN_CHAIN_BSTEP(5, gpA, gpB)
+  LGN_CHAIN_BSTEP(4, gpB, gpA)
+  LGN_CHAIN_BSTEP(3, gpA, gpB)
+  LGN_CHAIN_BSTEP(2, gpB, gpA)
+  LGN_CHAIN_BSTEP(1, gpA, gpB)
+#undef LGN_CHAIN_BSTEP
+  {  // q = 12, l = 0: the first layer; its input tile holds the MLP's input rows (k-steps beyond KS0 never stored or read)
+    v4d gx[1];
+    layer_bwd<G, G::KSH, 1, NT>(Wl + 0 * G::WSIZE, gpB, gx, c, g, [&](int, int) {}, [&](int i) {
+      deal<G::KSH, 4 * NT + 4>(i, [&](int j) {
+        if (j < 4 * NT) publish_piece<G, NT>(Gt, gpB, wave, c, g, j);
+        else publish_piece<G, 1>(Xt, xb, wave, c, g, j - 4 * NT);
+      });
+    });
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {                            // D layout of the input tile: feature f = 4r + g, row c
+      const int f = 4 * r + g;
+      if (f < D && row < a.M) a.g_in[mlp_out_index(a, f & 1, row, f >> 1)] = gx[0][r];
+    }
+    lds_barrier();
+    STAMP(25);
+  }
+}
+
 // 48 < H <= 96 (C = 5 .. 8): the FORWARD chain only -- its two weight images (up to 150 KB) and ping-ponged activations fit; the
 // backward's tiles and six kept activations do not (LDS 274 KB, > 512 registers), it stays with mlp_mfma_wide.hip
 template <int H, int D>
@@ -593,6 +729,13 @@ static int launch(const MlpArgs<double>& a, bool backward, hipStream_t stream) {
   if (backward) LGN_CHECK_ARG(a.psize == G::psize(), "cgmlp: psize %d, expected %d", a.psize, G::psize());
   LGN_CHECK_ARG(!a.h_saved || a.h_rows >= nblk * 64, "cgmlp: the saved-activation buffer has %d rows per layer, %d rows need %d",
                 a.h_rows, a.M, nblk * 64);
+  if (backward && !a.h_saved && !(a.flags & LVL_MLP_BWD1)) {      // (kept activations: the one-role kernel reads them)
+    auto k2 = a.act == 0 ? mlp_chain_bwd2_kernel<H, D, false> : mlp_chain_bwd2_kernel<H, D, true>;
+    if (smem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL(k2, dim3(nblk), dim3(512), smem, stream, a);
+    LGN_CHECK_LAUNCH();
+    return 0;
+  }
   auto kern = a.h_saved ? (a.act == 0 ? (backward ? mlp_chain_bwd_kernel<H, D, false, true> : mlp_chain_fwd_kernel<H, D, false, true>)
                                       : (backward ? mlp_chain_bwd_kernel<H, D, true, true> : mlp_chain_fwd_kernel<H, D, true, true>))
                         : (a.act == 0 ? (backward ? mlp_chain_bwd_kernel<H, D, false, false> : mlp_chain_fwd_kernel<H, D, false, false>)

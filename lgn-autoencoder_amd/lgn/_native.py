@@ -125,7 +125,8 @@ class NetDesc(C.Structure):
 NET_NO_STATIC = 1
 # kernel-selecting cross-check switches -> LGN_NET_* bits of include/lgn_amd.h
 _NET_FLAG_ENV = {"LGN_AMD_NO_STATIC": 1, "LGN_AMD_DEC_PAIRWISE": 2, "LGN_AMD_LEVEL_V2": 4, "LGN_AMD_MLP_V1": 8,
-                 "LGN_AMD_MOMENTS_V1": 16, "LGN_AMD_BWD_ORDERED": 64, "LGN_AMD_SPLIT_TAIL": 128, "LGN_AMD_DEC_UNFUSED": 256, "LGN_AMD_MOMENTS_SPLIT": 512}
+                 "LGN_AMD_MOMENTS_V1": 16, "LGN_AMD_BWD_ORDERED": 64, "LGN_AMD_SPLIT_TAIL": 128, "LGN_AMD_DEC_UNFUSED": 256, "LGN_AMD_MOMENTS_SPLIT": 512,
+                 "LGN_AMD_MLP_BWD1": 1024}
 # LGN_ACT_* of include/lgn_amd.h: the names get_activation_fn accepts (lgn/nn/generic_levels.py:119-135)
 ACTIVATIONS = {"leakyrelu": 0, "relu": 1, "elu": 2, "sigmoid": 3, "logsigmoid": 4, "atan": 5}
 

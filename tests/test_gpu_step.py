@@ -98,7 +98,7 @@ def test_more_than_twenty_bells_train_through_the_captured_module_step(name):
             U.assert_close(g, ref, 1e-9, f"grad {pre}.{k}")
 
 
-@pytest.mark.parametrize("flags", [("LGN_AMD_LEVEL_V2",), ("LGN_AMD_DEC_PAIRWISE",), ("LGN_AMD_BWD_ORDERED",), ("LGN_AMD_MLP_V1",),
+@pytest.mark.parametrize("flags", [("LGN_AMD_LEVEL_V2",), ("LGN_AMD_DEC_PAIRWISE",), ("LGN_AMD_BWD_ORDERED",), ("LGN_AMD_MLP_V1",), ("LGN_AMD_MLP_BWD1",),
                                    ("LGN_AMD_LEVEL_V2", "LGN_AMD_DEC_PAIRWISE")])
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_native_step_maxdim2_alternative_kernels(flags, use_graph, monkeypatch):
@@ -226,7 +226,7 @@ def test_native_step_batch_regimes(B, monkeypatch):
     (level.hpp: level_jet_split: 64 / 65 .. 128 / 129 .. 256 / more jets), the CGMLP runs 16-row workgroups with kept activations
     (<= 4 096 rows), without them, or the chain kernels of mlp_chain.hip (>= 8 129 rows: 300 and 512 jets).  The graph-replayed
     native step against the module / autograd path on the same weights, and at the chain-kernel sizes also against the same step
-    on the 12-wave CGMLP kernels (LGN_AMD_MLP_V1=1)."""
+    on the 12-wave CGMLP kernels (LGN_AMD_MLP_V1=1) and on the one-role chain backward (LGN_AMD_MLP_BWD1=1)."""
     import __graft_entry__ as G
     from lgn.step import NativeTrainStep, TrainStep
     from oracle import lgn_oracle as O
@@ -252,6 +252,14 @@ def test_native_step_batch_regimes(B, monkeypatch):
         lc, rc = c.step(batch)
         U.assert_close(la, lc, 1e-13, "loss, chain vs 12-wave CGMLP kernels")
         U.assert_close(a.flat.grad, c.flat.grad, 1e-10, "flat gradient, chain vs 12-wave CGMLP kernels")
+        # the chain backward as one role per wave (round 5's kernel; the default splits chain and weight gradients over two sets of
+        # waves): the same products in the same order -- bit for bit
+        enc4, dec4 = G._models(N, che, chd, dev, seed=5)
+        monkeypatch.setenv("LGN_AMD_MLP_BWD1", "1")
+        d = NativeTrainStep(enc4, dec4, batch_size=B, optimizer=False, use_graph=True)
+        monkeypatch.delenv("LGN_AMD_MLP_BWD1")
+        ld, _ = d.step(batch)
+        assert torch.equal(a.flat.grad, d.flat.grad) and torch.equal(la, ld), "two-role vs one-role chain backward"
 
 
 @pytest.mark.parametrize("width,maxdim,B", [(4, 2, 280), (5, 2, 280), (7, 2, 280), (5, 2, 64), (4, 3, 280), (5, 3, 140)])
