@@ -313,8 +313,10 @@ __device__ __forceinline__ void load_x(const MlpArgs<double>& a, int row, int g,
   }
 }
 
-template <int H, int D, bool GEN, bool SAVE>
-__global__ __launch_bounds__(256) void mlp_chain_fwd_kernel(MlpArgs<double> a) {
+// TWO: eight waves per workgroup -- waves 4 - 7 stage the weight images (global -> registers -> LDS, two steps ahead) and nothing else,
+// waves 0 - 3 carry the chain without the staging pieces in their matrix streams (round 6; see mlp_chain_bwd2_kernel)
+template <int H, int D, bool GEN, bool SAVE, bool TWO = false>
+__global__ __launch_bounds__(TWO ? 512 : 256) void mlp_chain_fwd_kernel(MlpArgs<double> a) {
   using G = Geo<H, D>;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 15, g = lane >> 4;
@@ -324,9 +326,22 @@ __global__ __launch_bounds__(256) void mlp_chain_fwd_kernel(MlpArgs<double> a) {
   WRegs<G> wrA, wrB;
   STAMP(0);
   STAMP_LIFE_BEGIN();
+  if constexpr (TWO) {
+    if (wave >= 4) {
+      const int st = tid - 256;
+      stage_prologue<G, false>(a, Wl, wrA, wrB, st);
+      lds_barrier();
+#define LGN_STAGE_STEP(Q)                                                                                            \
+  _Pragma("unroll") for (int j = 0; j < stage_pieces<G>(); ++j) stage_piece<G, false, Q>(a, Wl, wrA, wrB, st, j);    \
+  lds_barrier();
+      LGN_STAGE_STEP(0) LGN_STAGE_STEP(1) LGN_STAGE_STEP(2) LGN_STAGE_STEP(3) LGN_STAGE_STEP(4) LGN_STAGE_STEP(5)
+#undef LGN_STAGE_STEP
+      return;
+    }
+  }
   v4d xb[1];
   load_x<G>(a, row, g, xb);
-  stage_prologue<G, false>(a, Wl, wrA, wrB, tid);
+  if constexpr (!TWO) stage_prologue<G, false>(a, Wl, wrA, wrB, tid);
   lds_barrier();
   STAMP(1);
   v4d h0[G::NT], h1[G::NT];
@@ -335,7 +350,7 @@ __global__ __launch_bounds__(256) void mlp_chain_fwd_kernel(MlpArgs<double> a) {
   // (SAVE: the activations of layer q - 1 are stored under layer q's matrix instructions)
 #define LGN_CHAIN_STEP(Q, HIN, HOUT, KS, NTI)                                                                        \
   layer_fwd<G, KS, NTI, GEN, (Q == 3)>(Wl + (Q & 1) * G::WSIZE, HIN, HOUT, c, g, a.act, [&](int i) {               \
-    if (!LGN_DBG_NOSTAGE) deal<KS * G::NT, stage_pieces<G>()>(i, [&](int j) { stage_piece<G, false, Q>(a, Wl, wrA, wrB, tid, j); });      \
+    if (!TWO && !LGN_DBG_NOSTAGE) deal<KS * G::NT, stage_pieces<G>()>(i, [&](int j) { stage_piece<G, false, Q>(a, Wl, wrA, wrB, tid, j); });      \
     if (SAVE && Q > 0) deal<KS * G::NT, 2 * NTI>(i, [&](int j) { save_piece<G>(hs, Q - 1, HIN, j); });              \
   });                                                                                                                \
   lds_barrier();                                                                                                     \
@@ -713,9 +728,11 @@ template <int H, int D>
 static int launch_fwd(const MlpArgs<double>& a, hipStream_t stream) {
   using G = Geo<H, D>;
   static_assert(G::fwd_bytes() <= 160 * 1024, "LDS budget");
-  auto kern = a.act == 0 ? mlp_chain_fwd_kernel<H, D, false, false> : mlp_chain_fwd_kernel<H, D, true, false>;
+  const bool two = !(a.flags & LVL_MLP_BWD1);
+  auto kern = two ? (a.act == 0 ? mlp_chain_fwd_kernel<H, D, false, false, true> : mlp_chain_fwd_kernel<H, D, true, false, true>)
+                  : (a.act == 0 ? mlp_chain_fwd_kernel<H, D, false, false> : mlp_chain_fwd_kernel<H, D, true, false>);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::fwd_bytes());
-  hipLaunchKernelGGL(kern, dim3(cdiv(a.M, 64)), dim3(256), G::fwd_bytes(), stream, a);
+  hipLaunchKernelGGL(kern, dim3(cdiv(a.M, 64)), dim3(two ? 512 : 256), G::fwd_bytes(), stream, a);
   LGN_CHECK_LAUNCH();
   return 0;
 }
@@ -731,6 +748,13 @@ static int launch(const MlpArgs<double>& a, bool backward, hipStream_t stream) {
                 a.h_rows, a.M, nblk * 64);
   if (backward && !a.h_saved && !(a.flags & LVL_MLP_BWD1)) {      // (kept activations: the one-role kernel reads them)
     auto k2 = a.act == 0 ? mlp_chain_bwd2_kernel<H, D, false> : mlp_chain_bwd2_kernel<H, D, true>;
+    if (smem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL(k2, dim3(nblk), dim3(512), smem, stream, a);
+    LGN_CHECK_LAUNCH();
+    return 0;
+  }
+  if (!backward && !a.h_saved && !(a.flags & LVL_MLP_BWD1)) {
+    auto k2 = a.act == 0 ? mlp_chain_fwd_kernel<H, D, false, false, true> : mlp_chain_fwd_kernel<H, D, true, false, true>;
     if (smem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     hipLaunchKernelGGL(k2, dim3(nblk), dim3(512), smem, stream, a);
     LGN_CHECK_LAUNCH();
