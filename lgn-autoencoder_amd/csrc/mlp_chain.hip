@@ -103,7 +103,7 @@ struct Geo {
   static constexpr int NREG = (HP * 2 * KSH + 255) / 256;   // staging registers (PAIRS of doubles) per thread for a hidden image
   static_assert(H % 4 == 0 && D <= 16 && D <= H && H <= 96, "chain kernels: H = 12 .. 96 (multiple of 4; the backward: H <= 48), 2C <= 16");
   static constexpr size_t fwd_bytes() { return sizeof(double) * 2 * WSIZE; }
-  static constexpr size_t bwd_bytes() { return sizeof(double) * (2 * WSIZE + 4 * TSIZE); }
+  static constexpr size_t bwd_bytes() { return sizeof(double) * (2 * WSIZE + 4 * TSIZE + 2 * 1024); }      // (+ the quarter sums of the two-role kernel)
   // offsets of (W_l, b_l) in a partial row / parameter block: concat_l (W_l, b_l)
   static constexpr int off_w(int l) { return l == 0 ? 0 : (H * D + H) + (l - 1) * (H * H + H); }
   static constexpr int hout(int l) { return l == NH ? D : H; }
@@ -586,6 +586,74 @@ __global__ __launch_bounds__(256) void mlp_chain_bwd_kernel(MlpArgs<double> a) {
   STAMP(26);
 }
 
+// Weight gradient of a HIDDEN Linear L (NT = 3: nine 16 x 16 tiles over the workgroup's 64 rows = 144 matrix instructions) dealt evenly
+// to the four dW waves of the two-role kernel: wave w takes tiles 2w and 2w + 1 (row-major) whole and k-steps 4w .. 4w + 3 of the
+// ninth tile (2, 2) -- 36 instructions each, where whole tile rows gave 48 / 48 / 48 / 0.  The four quarter sums of the ninth tile
+// meet through LDS (qs: [wave][register][lane]); dw_quarter_sum adds them in a fixed order one step later.
+template <class G, int L, class SideF>
+__device__ __forceinline__ void dw_hidden3(const double* Gt, const double* Xt, double* part, double* qs, int w, int lane, int c, int g, SideF side) {
+  static_assert(G::NT == 3 && L >= 1 && L < G::NH, "hidden layers of three tiles");
+  constexpr int SR = G::SR, H = G::H, N = 36, P = 6;
+  const int i0 = 2 * w, i1 = 2 * w + 1;
+  const int t0 = i0 / 3, u0 = i0 - 3 * t0, t1 = i1 / 3, u1 = i1 - 3 * t1;
+  const double* ga0 = Gt + (16 * t0 + c) * SR + g;
+  const double* xb0 = Xt + (16 * u0 + c) * SR + g;
+  const double* ga1 = Gt + (16 * t1 + c) * SR + g;
+  const double* xb1 = Xt + (16 * u1 + c) * SR + g;
+  const double* ga2 = Gt + (32 + c) * SR + g + 16 * w;
+  const double* xb2 = Xt + (32 + c) * SR + g + 16 * w;
+  double* pW = part + G::off_w(L);
+  v4d acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
+  double qa[N], qx[N];
+  auto load = [&](int i) {
+    if (i < 16) { qa[i] = ga0[4 * i]; qx[i] = xb0[4 * i]; }
+    else if (i < 32) { qa[i] = ga1[4 * (i - 16)]; qx[i] = xb1[4 * (i - 16)]; }
+    else { qa[i] = ga2[4 * (i - 32)]; qx[i] = xb2[4 * (i - 32)]; }
+  };
+  auto store = [&](const v4d& acc, int t, int u, int r) {
+    const int o = 16 * t + 4 * r + g, k = 16 * u + c;
+    if (o < H && k < H) __builtin_nontemporal_store(acc[r], &pW[o * H + k]);
+  };
+#pragma unroll
+  for (int i = 0; i < P; ++i) load(i);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    if (i + P < N) load(i + P);
+    if (i < 16) acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[i], qx[i], acc0, 0, 0, 0);
+    else if (i < 32) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[i], qx[i], acc1, 0, 0, 0);
+    else acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[i], qx[i], acc2, 0, 0, 0);
+    if (i >= 17 && i <= 20) store(acc0, t0, u0, i - 17);
+    if (i >= 33) store(acc1, t1, u1, i - 33);
+    side(i);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  store(acc1, t1, u1, 3);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) qs[(w * 4 + r) * 64 + lane] = acc2[r];
+  if (w != 1) {      // bias gradient of tile row t0 (rows 0, 1, 2 for waves 0, 2, 3): the sum of the sixteen A fragments of the first tile
+    double d4[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int sk = 0; sk < 16; ++sk) d4[sk & 3] += qa[sk];
+    double dbs = (d4[0] + d4[1]) + (d4[2] + d4[3]);
+    dbs += shfl_xor(dbs, 16);
+    dbs += shfl_xor(dbs, 32);
+    if (g == 0 && 16 * t0 + c < H) __builtin_nontemporal_store(dbs, &part[G::off_b(L) + 16 * t0 + c]);
+  }
+}
+// the ninth tile of hidden Linear L from the four quarter sums (one wave; the quarters were written before the last barrier)
+template <class G, int L>
+__device__ __forceinline__ void dw_quarter_sum(const double* qs, double* part, int lane, int c, int g) {
+  constexpr int H = G::H;
+  double* pW = part + G::off_w(L);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const double v = (qs[(0 * 4 + r) * 64 + lane] + qs[(1 * 4 + r) * 64 + lane]) + (qs[(2 * 4 + r) * 64 + lane] + qs[(3 * 4 + r) * 64 + lane]);
+    const int o = 32 + 4 * r + g, k = 32 + c;
+    if (o < H && k < H) __builtin_nontemporal_store(v, &pW[o * H + k]);
+  }
+}
+
 // ---- backward, two roles per workgroup (round 6) ---------------------------------------------------------------------------------
 // The kernel above runs ONE wave per SIMD: whatever a wave waits for -- an LDS fragment, the barrier, the datapath's turn-around
 // after an fp64 vector instruction -- leaves the matrix pipe idle (0.40 busy at cfg2).  Here a workgroup is EIGHT waves over the same
@@ -618,12 +686,22 @@ __global__ __launch_bounds__(512) void mlp_chain_bwd2_kernel(MlpArgs<double> a) 
     LGN_STAGE_STEP(0) LGN_STAGE_STEP(1) LGN_STAGE_STEP(2) LGN_STAGE_STEP(3) LGN_STAGE_STEP(4) LGN_STAGE_STEP(5)
     LGN_STAGE_STEP(6)                                        // the output layer's step: nothing published yet
     // step q = 2 NH - L: weight gradient of Linear L + 1 from the tiles of parity (L + 1) & 1, staging dealt under its matrix stream
+    // (NT = 3: the hidden layers' nine tiles dealt evenly, dw_hidden3; the ninth tile's quarter sums of Linear L + 2 are added up by
+    // wave 1 at the head of the step that follows their barrier)
+    constexpr bool EVEN = NT == 3;
+    double* qs = Xt + 2 * G::TSIZE;                          // [2 parities][4 waves][4 registers][64 lanes]
 #define LGN_DW_STEP(L)                                                                                               \
   {                                                                                                                  \
-    constexpr int q_ = 2 * NH - (L), NS = stage_pieces<G>();                                                         \
-    constexpr int NI = ((L) + 1 == NH || (L) + 1 == 0) ? 16 : 16 * NT;                                               \
+    constexpr int q_ = 2 * NH - (L), NS = stage_pieces<G>(), L1 = (L) + 1;                                           \
+    constexpr bool HID = EVEN && L1 >= 1 && L1 < NH;                                                                 \
+    constexpr int NI = HID ? 36 : (L1 == NH || L1 == 0) ? 16 : 16 * NT;                                              \
     auto side = [&](int i) { deal<NI, NS>(i, [&](int j) { stage_piece<G, true, q_>(a, Wl, wrA, wrB, tid, j); }); };  \
-    if (!dw_layer<G, (L) + 1>(Gt + (((L) + 1) & 1) * G::TSIZE, Xt + (((L) + 1) & 1) * G::TSIZE, part, w4, c, g, side)) { \
+    if constexpr (EVEN && L1 + 1 >= 1 && L1 + 1 < NH) {                                                              \
+      if (w4 == 1) dw_quarter_sum<G, (L1 + 1 < NH ? L1 + 1 : 1)>(qs + ((L1 + 1) & 1) * 1024, part, lane, c, g);     \
+    }                                                                                                                \
+    if constexpr (HID) {                                                                                             \
+      dw_hidden3<G, (HID ? L1 : 1)>(Gt + (L1 & 1) * G::TSIZE, Xt + (L1 & 1) * G::TSIZE, part, qs + (L1 & 1) * 1024, w4, lane, c, g, side); \
+    } else if (!dw_layer<G, L1>(Gt + (L1 & 1) * G::TSIZE, Xt + (L1 & 1) * G::TSIZE, part, w4, c, g, side)) {         \
       LGN_STAGE_ALL(q_)                                                                                              \
     }                                                                                                                \
     lds_barrier();                                                                                                   \
@@ -632,6 +710,9 @@ __global__ __launch_bounds__(512) void mlp_chain_bwd2_kernel(MlpArgs<double> a) 
 #undef LGN_DW_STEP
 #undef LGN_STAGE_STEP
 #undef LGN_STAGE_ALL
+    if constexpr (EVEN && NH >= 2) {
+      if (w4 == 1) dw_quarter_sum<G, 1>(qs + 1024, part, lane, c, g);      // (Linear 1: its quarters were written in the last step)
+    }
     dw_layer<G, 0>(Gt, Xt, part, w4, c, g, [&](int) {});
     return;
   }

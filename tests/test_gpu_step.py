@@ -253,13 +253,14 @@ def test_native_step_batch_regimes(B, monkeypatch):
         U.assert_close(la, lc, 1e-13, "loss, chain vs 12-wave CGMLP kernels")
         U.assert_close(a.flat.grad, c.flat.grad, 1e-10, "flat gradient, chain vs 12-wave CGMLP kernels")
         # the chain backward as one role per wave (round 5's kernel; the default splits chain and weight gradients over two sets of
-        # waves): the same products in the same order -- bit for bit
+        # waves): the same products; one 16 x 16 tile of every hidden layer's weight gradient is summed in four quarters
         enc4, dec4 = G._models(N, che, chd, dev, seed=5)
         monkeypatch.setenv("LGN_AMD_MLP_BWD1", "1")
         d = NativeTrainStep(enc4, dec4, batch_size=B, optimizer=False, use_graph=True)
         monkeypatch.delenv("LGN_AMD_MLP_BWD1")
         ld, _ = d.step(batch)
-        assert torch.equal(a.flat.grad, d.flat.grad) and torch.equal(la, ld), "two-role vs one-role chain backward"
+        assert torch.equal(la, ld), "two-role vs one-role chain backward: loss"
+        U.assert_close(a.flat.grad, d.flat.grad, 1e-13, "flat gradient, two-role vs one-role chain backward")
 
 
 @pytest.mark.parametrize("width,maxdim,B", [(4, 2, 280), (5, 2, 280), (7, 2, 280), (5, 2, 64), (4, 3, 280), (5, 3, 140)])
