@@ -90,20 +90,21 @@ __device__ __forceinline__ double act_t(double x, int act) {
   if constexpr (GEN) return act_apply(x, act);
   else return fmax(x, 0.01 * x);     // (probes/mfma_issue_probe: 165 cycles per 36-instruction layer; multiply + compare + select: 250 - 300)
 }
-template <int H_, int D_>
+template <int H_, int D_, int NST_ = 256>
 struct Geo {
   static constexpr int H = H_, D = D_, NH = 6;
+  static constexpr int NST = NST_;                          // threads that stage the weight images (256: a 64-row workgroup; 128: the 16-row kernels)
   static constexpr int NT = (H + 15) / 16, HP = 16 * NT;   // hidden tiles
   static constexpr int KSH = H / 4;                         // k-steps over a hidden layer's inputs
   static constexpr int KS0 = (D + 3) / 4;                   // k-steps over the MLP's inputs (2C features, zero padded to 4 KS0)
   static constexpr int S = stride2mod4(HP + 1);             // row stride of a weight image; column HP holds the bias
   static constexpr int WSIZE = HP * S;
-  static constexpr int SR = 66;                             // row stride of the [neuron][64 rows] tiles of the backward
+  static constexpr int SR = NST == 256 ? 66 : 18;           // row stride of the [neuron][64 (16) rows] tiles of the backward (== 2 mod 4: conflict-free fragment reads)
   static constexpr int TSIZE = HP * SR;
-  static constexpr int NREG = (HP * 2 * KSH + 255) / 256;   // staging registers (PAIRS of doubles) per thread for a hidden image
+  static constexpr int NREG = (HP * 2 * KSH + NST - 1) / NST;   // staging registers (PAIRS of doubles) per thread for a hidden image
   static_assert(H % 4 == 0 && D <= 16 && D <= H && H <= 96, "chain kernels: H = 12 .. 96 (multiple of 4; the backward: H <= 48), 2C <= 16");
   static constexpr size_t fwd_bytes() { return sizeof(double) * 2 * WSIZE; }
-  static constexpr size_t bwd_bytes() { return sizeof(double) * (2 * WSIZE + 4 * TSIZE + 2 * 1024); }      // (+ the quarter sums of the two-role kernel)
+  static constexpr size_t bwd_bytes() { return sizeof(double) * (2 * WSIZE + 4 * TSIZE + (NST == 256 ? 2 * 1024 : 0)); }      // (+ the quarter sums of the two-role kernel)
   // offsets of (W_l, b_l) in a partial row / parameter block: concat_l (W_l, b_l)
   static constexpr int off_w(int l) { return l == 0 ? 0 : (H * D + H) + (l - 1) * (H * H + H); }
   static constexpr int hout(int l) { return l == NH ? D : H; }
@@ -121,7 +122,7 @@ struct Img {
   static constexpr int RP = L == G::NH ? 16 : G::HP;                       // rows read: a full tile of outputs
   static constexpr int CP = L == 0 ? 4 * G::KS0 : 4 * G::KSH;              // columns read by the k-steps
   static constexpr int CP2 = CP / 2;                                       // ... in pairs: the images travel 16 bytes per lane
-  static constexpr int NP = (RP * CP2 + 255) / 256;                        // (a lone wave pays ~40 cycles of issue per global load)
+  static constexpr int NP = (RP * CP2 + G::NST - 1) / G::NST;              // (a lone wave pays ~40 cycles of issue per global load)
   static_assert(NP <= G::NREG && HI % 2 == 0, "staging registers; rows of an even number of doubles");
 };
 typedef double v2d __attribute__((ext_vector_type(2)));
@@ -137,7 +138,7 @@ template <class G, int L>
 __device__ __forceinline__ void issue_piece(const MlpArgs<double>& a, WRegs<G>& wr, int tid, int j) {
   using I = Img<G, L>;
   if (j < I::NP) {
-    const int e = tid + 256 * j, o = e / I::CP2, k = 2 * (e - o * I::CP2);
+    const int e = tid + G::NST * j, o = e / I::CP2, k = 2 * (e - o * I::CP2);
     const bool ok = o < I::HO && k < I::HI;
     const v2d x = *reinterpret_cast<const v2d*>(a.w[L] + (ok ? o * I::HI + k : 0));   // clamped address + select: no branch around the load
     wr.v[j] = ok ? x : v2d{0.0, 0.0};
@@ -150,8 +151,8 @@ template <class G, int L>
 __device__ __forceinline__ void commit_piece(double* Wl, const WRegs<G>& wr, int tid, int j) {
   using I = Img<G, L>;
   if (j < I::NP) {
-    const int e = tid + 256 * j, o = e / I::CP2, k = 2 * (e - o * I::CP2);
-    if (I::RP * I::CP2 % 256 == 0 || e < I::RP * I::CP2) *reinterpret_cast<v2d*>(Wl + o * G::S + k) = wr.v[j];
+    const int e = tid + G::NST * j, o = e / I::CP2, k = 2 * (e - o * I::CP2);
+    if (I::RP * I::CP2 % G::NST == 0 || e < I::RP * I::CP2) *reinterpret_cast<v2d*>(Wl + o * G::S + k) = wr.v[j];
   } else if (j == I::NP) {
     if (tid < I::RP) Wl[tid * G::S + G::HP] = wr.b;
   }
@@ -803,6 +804,269 @@ __global__ __launch_bounds__(512) void mlp_chain_bwd2_kernel(MlpArgs<double> a) 
   }
 }
 
+// ---- small batches: 16-row workgroups (round 6) ---------------------------------------------------------------------------------
+// Below 128 workgroups of 64 rows the CGMLP ran the 12-wave kernels of mlp_mfma.hip on 16-row workgroups: every layer split over
+// three waves, activations exchanged through LDS, two barriers per layer -- 9 / 21 us per forward / backward at 64 jets for
+// 0.05 GFLOP.  The chain form with roles needs no exchange: a workgroup is ONE chain wave (16 rows through all layers out of
+// registers), one wave for the weight gradients (K = 16 rows: four k-steps per tile, 36 matrix instructions per hidden layer: what
+// the chain wave computes meanwhile) and two waves staging the weight images -- each alone on its SIMD.  The forward keeps the
+// activations for the backward where the step asks for it (MlpArgs::h_saved, <= 4 096 rows; same register image as the 64-row
+// kernels, one block per workgroup).
+template <class G>
+__device__ __forceinline__ double* saved_ptr16(const MlpArgs<double>& a, int lane) {
+  return a.h_saved + (size_t)blockIdx.x * (G::NH * G::NT * 256) + lane * 4;
+}
+template <int H, int D, bool GEN, bool SAVE>
+__global__ __launch_bounds__(192) void mlp_chain_fwd16_kernel(MlpArgs<double> a) {
+  using G = Geo<H, D, 128>;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, g = lane >> 4;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  double* Wl = reinterpret_cast<double*>(smem_raw);          // 2 weight images
+  if (wave >= 1) {
+    const int st = tid - 64;
+    WRegs<G> wrA, wrB;
+    stage_prologue<G, false>(a, Wl, wrA, wrB, st);
+    lds_barrier();
+#define LGN_STAGE_STEP(Q)                                                                                            \
+  _Pragma("unroll") for (int j = 0; j < stage_pieces<G>(); ++j) stage_piece<G, false, Q>(a, Wl, wrA, wrB, st, j);    \
+  lds_barrier();
+    LGN_STAGE_STEP(0) LGN_STAGE_STEP(1) LGN_STAGE_STEP(2) LGN_STAGE_STEP(3) LGN_STAGE_STEP(4) LGN_STAGE_STEP(5)
+#undef LGN_STAGE_STEP
+    return;
+  }
+  const int row = blockIdx.x * 16 + c;
+  v4d xb[1];
+  load_x<G>(a, row, g, xb);
+  lds_barrier();
+  v4d h0[G::NT], h1[G::NT];
+  double* hs = SAVE ? saved_ptr16<G>(a, lane) : nullptr;
+#define LGN_CHAIN_STEP(Q, HIN, HOUT, KS, NTI)                                                                        \
+  layer_fwd<G, KS, NTI, GEN>(Wl + (Q & 1) * G::WSIZE, HIN, HOUT, c, g, a.act, [&](int i) {                          \
+    if (SAVE && Q > 0) deal<KS * G::NT, 2 * NTI>(i, [&](int j) { save_piece<G>(hs, Q - 1, HIN, j); });              \
+  });                                                                                                                \
+  lds_barrier();
+  LGN_CHAIN_STEP(0, xb, h0, G::KS0, 1)
+  LGN_CHAIN_STEP(1, h0, h1, G::KSH, G::NT)
+  LGN_CHAIN_STEP(2, h1, h0, G::KSH, G::NT)
+  LGN_CHAIN_STEP(3, h0, h1, G::KSH, G::NT)
+  LGN_CHAIN_STEP(4, h1, h0, G::KSH, G::NT)
+  LGN_CHAIN_STEP(5, h0, h1, G::KSH, G::NT)
+#undef LGN_CHAIN_STEP
+  if (SAVE) {
+#pragma unroll
+    for (int j = 0; j < saved_pieces<G>(); ++j) save_piece<G>(hs, G::NH - 1, h1, j);
+  }
+  const v4d y = layer_out<G>(Wl + (G::NH & 1) * G::WSIZE, h1, c, g);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int o = 4 * r + g;
+    if (o < D && row < a.M) a.s_out[mlp_out_index(a, o & 1, row, o >> 1)] = y[r];
+  }
+}
+
+// weight gradient of Linear L over the workgroup's 16 rows (columns 0 .. 15 of the published tiles): every tile, four k-steps each
+template <class G, int L>
+__device__ __forceinline__ void dw16(const double* Gt, const double* Xt, double* part, int c, int g) {
+  constexpr int SR = G::SR, HO = G::hout(L), HI = G::hin(L);
+  constexpr int NTO = L == G::NH ? 1 : G::NT, NTI = L == 0 ? 1 : G::NT, NTL = NTO * NTI;
+  double* pW = part + G::off_w(L);
+  double qa[NTO][4], qx[NTI][4];
+#pragma unroll
+  for (int t = 0; t < NTO; ++t)
+#pragma unroll
+    for (int sk = 0; sk < 4; ++sk) qa[t][sk] = Gt[(16 * t + c) * SR + g + 4 * sk];
+#pragma unroll
+  for (int u = 0; u < NTI; ++u)
+#pragma unroll
+    for (int sk = 0; sk < 4; ++sk) qx[u][sk] = Xt[(16 * u + c) * SR + g + 4 * sk];
+  __builtin_amdgcn_sched_barrier(0);
+  v4d acc[NTL];
+  auto store = [&](int tile, int r) {
+    const int t = tile / NTI, u = tile - t * NTI, o = 16 * t + 4 * r + g, k = 16 * u + c;
+    if (o < HO && k < HI) __builtin_nontemporal_store(acc[tile][r], &pW[o * HI + k]);
+  };
+#pragma unroll
+  for (int i = 0; i < 4 * NTL; ++i) {
+    const int tile = i >> 2, sk = i & 3, t = tile / NTI, u = tile - t * NTI;
+    if (sk == 0) acc[tile] = v4d{0, 0, 0, 0};
+    acc[tile] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[t][sk], qx[u][sk], acc[tile], 0, 0, 0);
+    if (tile > 0) store(tile > 0 ? tile - 1 : 0, sk);       // the previous tile has left the pipe
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) store(NTL - 1, r);
+#pragma unroll
+  for (int t = 0; t < NTO; ++t) {                            // bias gradient: row sums of g_pre^T over the 16 rows
+    double dbs = (qa[t][0] + qa[t][1]) + (qa[t][2] + qa[t][3]);
+    dbs += shfl_xor(dbs, 16);
+    dbs += shfl_xor(dbs, 32);
+    if (g == 0 && 16 * t + c < HO) __builtin_nontemporal_store(dbs, &part[G::off_b(L) + 16 * t + c]);
+  }
+}
+
+template <int H, int D, bool GEN, bool SAVE>
+__global__ __launch_bounds__(256) void mlp_chain_bwd16_kernel(MlpArgs<double> a) {
+  using G = Geo<H, D, 128>;
+  constexpr int NT = G::NT, NH = G::NH;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int c = lane & 15, g = lane >> 4;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  double* Wl = reinterpret_cast<double*>(smem_raw);          // 2 weight images
+  double* Gt = Wl + 2 * G::WSIZE;                            // 2 g_pre tiles [neuron][rows] (columns 0 .. 15 in use)
+  double* Xt = Gt + 2 * G::TSIZE;                            // 2 layer-input tiles
+  if (wave >= 2) {
+    // ================= image staging =================
+    const int st = (int)threadIdx.x - 128;
+    WRegs<G> wrA, wrB;
+#define LGN_STAGE_STEP(Q)                                                                                            \
+  _Pragma("unroll") for (int j = 0; j < stage_pieces<G>(); ++j) stage_piece<G, true, Q>(a, Wl, wrA, wrB, st, j);     \
+  lds_barrier();
+    if constexpr (SAVE) {      // the images start at the output layer (steps NH, NH + 1, ...: the same buffers and register sets)
+      issue_image<G, NH>(a, wrA, st);
+      issue_image<G, NH - 1>(a, wrB, st);
+      commit_image<G, NH>(Wl, wrA, st);
+      issue_image<G, NH - 2>(a, wrA, st);
+      lds_barrier();
+    } else {
+      stage_prologue<G, true>(a, Wl, wrA, wrB, st);
+      lds_barrier();
+      LGN_STAGE_STEP(0) LGN_STAGE_STEP(1) LGN_STAGE_STEP(2) LGN_STAGE_STEP(3) LGN_STAGE_STEP(4) LGN_STAGE_STEP(5)
+    }
+    LGN_STAGE_STEP(6) LGN_STAGE_STEP(7) LGN_STAGE_STEP(8) LGN_STAGE_STEP(9) LGN_STAGE_STEP(10) LGN_STAGE_STEP(11) LGN_STAGE_STEP(12)
+#undef LGN_STAGE_STEP
+    return;
+  }
+  if (wave == 1) {
+    // ================= weight gradients, one step behind the chain =================
+    double* part = a.part + (size_t)blockIdx.x * a.psize;
+    lds_barrier();
+    if constexpr (!SAVE) {
+#pragma unroll
+      for (int q = 0; q < 6; ++q) lds_barrier();
+    }
+    lds_barrier();                                           // q = 6: nothing published yet
+    dw16<G, 6>(Gt + 0 * G::TSIZE, Xt + 0 * G::TSIZE, part, c, g);  lds_barrier();
+    dw16<G, 5>(Gt + 1 * G::TSIZE, Xt + 1 * G::TSIZE, part, c, g);  lds_barrier();
+    dw16<G, 4>(Gt + 0 * G::TSIZE, Xt + 0 * G::TSIZE, part, c, g);  lds_barrier();
+    dw16<G, 3>(Gt + 1 * G::TSIZE, Xt + 1 * G::TSIZE, part, c, g);  lds_barrier();
+    dw16<G, 2>(Gt + 0 * G::TSIZE, Xt + 0 * G::TSIZE, part, c, g);  lds_barrier();
+    dw16<G, 1>(Gt + 1 * G::TSIZE, Xt + 1 * G::TSIZE, part, c, g);  lds_barrier();
+    dw16<G, 0>(Gt, Xt, part, c, g);
+    return;
+  }
+  // ================= the chain =================
+  const int row = blockIdx.x * 16 + c;
+  v4d xb[1];
+  load_x<G>(a, row, g, xb);
+  v4d gout[1];                                               // upstream gradient, D layout of the output tile (o = 4r + g, row c)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int o = 4 * r + g;
+    const bool ok = o < D && row < a.M;
+    const double x = a.g_out[ok ? mlp_out_index(a, o & 1, row, o >> 1) : 0];
+    gout[0][r] = ok ? x : 0.0;
+  }
+  v4d h[NH][NT];
+  const double* hs = SAVE ? saved_ptr16<G>(a, lane) : nullptr;
+  if constexpr (SAVE) {
+#pragma unroll
+    for (int j = 0; j < saved_pieces<G>(); ++j) load_piece<G>(hs, NH - 1, h[NH - 1], j);      // needed by the first two steps; the
+#pragma unroll
+    for (int j = 0; j < saved_pieces<G>(); ++j) load_piece<G>(hs, NH - 2, h[NH - 2], j);      // others follow two steps ahead of their use
+    lds_barrier();
+  } else {
+    lds_barrier();
+#define LGN_CHAIN_STEP(Q, HIN, KS, NTI)                                                                              \
+  layer_fwd<G, KS, NTI, GEN>(Wl + (Q & 1) * G::WSIZE, HIN, h[Q], c, g, a.act, [&](int) {});                          \
+  lds_barrier();
+    LGN_CHAIN_STEP(0, xb, G::KS0, 1)
+    LGN_CHAIN_STEP(1, h[0], G::KSH, NT)
+    LGN_CHAIN_STEP(2, h[1], G::KSH, NT)
+    LGN_CHAIN_STEP(3, h[2], G::KSH, NT)
+    LGN_CHAIN_STEP(4, h[3], G::KSH, NT)
+    LGN_CHAIN_STEP(5, h[4], G::KSH, NT)
+#undef LGN_CHAIN_STEP
+  }
+  v4d gpA[NT], gpB[NT], gin[NT];
+  {  // q = 6, l = 6: the output layer
+    constexpr int NI = G::KS0 * NT, NSV = SAVE && NH >= 3 ? saved_pieces<G>() : 0, NPC = 4 + 4 * NT + NSV;
+    auto fin = [&](int u, int r) {
+      double y = gin[u][r] * act_slope_t<GEN>(h[NH - 1][u][r], a.act);
+      pin(y);
+      gpA[u][r] = y;
+    };
+    layer_bwd<G, G::KS0, NT, 1>(Wl + 0 * G::WSIZE, gout, gin, c, g, fin, [&](int i) {
+      deal<NI, NPC>(i, [&](int j) {
+        if (j < 4) publish_piece<G, 1>(Gt, gout, 0, c, g, j);
+        else if (j < 4 + 4 * NT) publish_piece<G, NT>(Xt, h[NH - 1], 0, c, g, j - 4);
+        else if constexpr (NSV > 0) load_piece<G>(hs, NH - 3, h[NH >= 3 ? NH - 3 : 0], j - 4 - 4 * NT);
+      });
+    });
+#pragma unroll
+    for (int r = 0; r < 4; ++r) fin(NT - 1, r);
+    lds_barrier();
+  }
+#define LGN_CHAIN_BSTEP(L, GP, GN)                                                                                   \
+  {                                                                                                                  \
+    constexpr int q_ = 2 * NH - (L), NI = G::KSH * NT, NSV = SAVE && (L) >= 3 ? saved_pieces<G>() : 0, NPC = 8 * NT + NSV; \
+    auto fin = [&](int u, int r) {                                                                                   \
+      double y = gin[u][r] * act_slope_t<GEN>(h[(L) - 1][u][r], a.act);                                              \
+      pin(y);                                                                                                        \
+      GN[u][r] = y;                                                                                                  \
+    };                                                                                                               \
+    layer_bwd<G, G::KSH, NT, NT>(Wl + (q_ & 1) * G::WSIZE, GP, gin, c, g, fin, [&](int i) {                          \
+      deal<NI, NPC>(i, [&](int j) {                                                                                  \
+        if (j < 4 * NT) publish_piece<G, NT>(Gt + ((L) & 1) * G::TSIZE, GP, 0, c, g, j);                             \
+        else if (j < 8 * NT) publish_piece<G, NT>(Xt + ((L) & 1) * G::TSIZE, h[(L) - 1], 0, c, g, j - 4 * NT);       \
+        else if constexpr (NSV > 0) load_piece<G>(hs, (L) - 3, h[(L) >= 3 ? (L) - 3 : 0], j - 8 * NT);               \
+      });                                                                                                            \
+    });                                                                                                              \
+    _Pragma("unroll") for (int r = 0; r < 4; ++r) fin(NT - 1, r);                                                    \
+    lds_barrier();                                                                                                   \
+  }
+  LGN_CHAIN_BSTEP(5, gpA, gpB)
+  LGN_CHAIN_BSTEP(4, gpB, gpA)
+  LGN_CHAIN_BSTEP(3, gpA, gpB)
+  LGN_CHAIN_BSTEP(2, gpB, gpA)
+  LGN_CHAIN_BSTEP(1, gpA, gpB)
+#undef LGN_CHAIN_BSTEP
+  {  // q = 12, l = 0: the first layer
+    v4d gx[1];
+    layer_bwd<G, G::KSH, 1, NT>(Wl + 0 * G::WSIZE, gpB, gx, c, g, [&](int, int) {}, [&](int i) {
+      deal<G::KSH, 4 * NT + 4>(i, [&](int j) {
+        if (j < 4 * NT) publish_piece<G, NT>(Gt, gpB, 0, c, g, j);
+        else publish_piece<G, 1>(Xt, xb, 0, c, g, j - 4 * NT);
+      });
+    });
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int f = 4 * r + g;
+      if (f < D && row < a.M) a.g_in[mlp_out_index(a, f & 1, row, f >> 1)] = gx[0][r];
+    }
+    lds_barrier();
+  }
+}
+
+template <int H, int D>
+static int launch16(const MlpArgs<double>& a, bool backward, hipStream_t stream) {
+  using G = Geo<H, D, 128>;
+  const int nblk = cdiv(a.M, 16);
+  const size_t smem = backward ? G::bwd_bytes() : G::fwd_bytes();
+  if (backward) LGN_CHECK_ARG(a.psize == G::psize(), "cgmlp: psize %d, expected %d", a.psize, G::psize());
+  LGN_CHECK_ARG(!a.h_saved || a.h_rows >= nblk * 16, "cgmlp: the saved-activation buffer has %d rows per layer, %d rows need %d",
+                a.h_rows, a.M, nblk * 16);
+  void (*kern)(MlpArgs<double>);
+  if (backward) kern = a.h_saved ? (a.act == 0 ? mlp_chain_bwd16_kernel<H, D, false, true> : mlp_chain_bwd16_kernel<H, D, true, true>)
+                                 : (a.act == 0 ? mlp_chain_bwd16_kernel<H, D, false, false> : mlp_chain_bwd16_kernel<H, D, true, false>);
+  else kern = a.h_saved ? (a.act == 0 ? mlp_chain_fwd16_kernel<H, D, false, true> : mlp_chain_fwd16_kernel<H, D, true, true>)
+                        : (a.act == 0 ? mlp_chain_fwd16_kernel<H, D, false, false> : mlp_chain_fwd16_kernel<H, D, true, false>);
+  if (smem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipLaunchKernelGGL(kern, dim3(nblk), dim3(backward ? 256 : 192), smem, stream, a);
+  LGN_CHECK_LAUNCH();
+  return 0;
+}
+
 // 48 < H <= 96 (C = 5 .. 8): the FORWARD chain only -- its two weight images (up to 150 KB) and ping-ponged activations fit; the
 // backward's tiles and six kept activations do not (LDS 274 KB, > 512 registers), it stays with mlp_mfma_wide.hip
 template <int H, int D>
@@ -853,9 +1117,16 @@ static int launch(const MlpArgs<double>& a, bool backward, hipStream_t stream) {
 
 }  // namespace chain
 
-// The reference widths H = 6 * 2C (C = 1 .. 4) at batches that run 64-row workgroups, activations recomputed; -2 = not this kernel's shape.
+// The reference widths H = 6 * 2C (C = 1 .. 4): 64-row workgroups (large batches, activations recomputed) or 16-row ones (small batches); -2 = not this kernel's shape.
 int mlp_chain_dispatch(const MlpArgs<double>& a, bool backward, hipStream_t stream) {
-  if ((a.flags & LVL_MLP_V1) || a.nlin != 7 || mlp_rows_per_workgroup(a.M, a.H) != 64) return -2;
+  if ((a.flags & LVL_MLP_V1) || a.nlin != 7) return -2;
+  if (mlp_rows_per_workgroup(a.M, a.H) != 64) {             // small batches: 16-row workgroups (one chain wave + helpers)
+    if (a.H == 48 && a.C == 4) return chain::launch16<48, 8>(a, backward, stream);
+    if (a.H == 36 && a.C == 3) return chain::launch16<36, 6>(a, backward, stream);
+    if (a.H == 24 && a.C == 2) return chain::launch16<24, 4>(a, backward, stream);
+    if (a.H == 12 && a.C == 1) return chain::launch16<12, 2>(a, backward, stream);
+    return -2;
+  }
   if (a.H == 48 && a.C == 4) return chain::launch<48, 8>(a, backward, stream);
   if (a.H == 36 && a.C == 3) return chain::launch<36, 6>(a, backward, stream);
   if (a.H == 24 && a.C == 2) return chain::launch<24, 4>(a, backward, stream);

@@ -224,7 +224,7 @@ def test_native_step_full_size_properties(name, B, N, maxdim, che, chd):
 def test_native_step_batch_regimes(B, monkeypatch):
     """cfg2 shapes at the batch sizes that change the launch geometry: the level kernels split a jet over 8 / 4 / 2 / 1 workgroups
     (level.hpp: level_jet_split: 64 / 65 .. 128 / 129 .. 256 / more jets), the CGMLP runs 16-row workgroups with kept activations
-    (<= 4 096 rows), without them, or the chain kernels of mlp_chain.hip (>= 8 129 rows: 300 and 512 jets).  The graph-replayed
+    (<= 4 096 rows) or without them (chain kernels with one chain wave per workgroup), or 64-row workgroups (>= 8 129 rows: 300 and 512 jets).  The graph-replayed
     native step against the module / autograd path on the same weights, and at the chain-kernel sizes also against the same step
     on the 12-wave CGMLP kernels (LGN_AMD_MLP_V1=1) and on the one-role chain backward (LGN_AMD_MLP_BWD1=1)."""
     import __graft_entry__ as G
@@ -244,14 +244,15 @@ def test_native_step_batch_regimes(B, monkeypatch):
     U.assert_close(la, lb, 1e-12, "loss")
     U.assert_close(ra, rb, 1e-12, "recon")
     U.assert_close(a.flat.grad, b.flat.grad, 1e-9, "flat gradient")
+    # every size runs chain CGMLP kernels (16-row workgroups below 8 129 rows, since round 6): against the 12-wave kernels
+    enc3, dec3 = G._models(N, che, chd, dev, seed=5)
+    monkeypatch.setenv("LGN_AMD_MLP_V1", "1")
+    c = NativeTrainStep(enc3, dec3, batch_size=B, optimizer=False, use_graph=True)
+    monkeypatch.delenv("LGN_AMD_MLP_V1")
+    lc, rc = c.step(batch)
+    U.assert_close(la, lc, 1e-13, "loss, chain vs 12-wave CGMLP kernels")
+    U.assert_close(a.flat.grad, c.flat.grad, 1e-10, "flat gradient, chain vs 12-wave CGMLP kernels")
     if B * N >= 8129:
-        enc3, dec3 = G._models(N, che, chd, dev, seed=5)
-        monkeypatch.setenv("LGN_AMD_MLP_V1", "1")
-        c = NativeTrainStep(enc3, dec3, batch_size=B, optimizer=False, use_graph=True)
-        monkeypatch.delenv("LGN_AMD_MLP_V1")
-        lc, rc = c.step(batch)
-        U.assert_close(la, lc, 1e-13, "loss, chain vs 12-wave CGMLP kernels")
-        U.assert_close(a.flat.grad, c.flat.grad, 1e-10, "flat gradient, chain vs 12-wave CGMLP kernels")
         # the chain backward as one role per wave (round 5's kernel; the default splits chain and weight gradients over two sets of
         # waves): the same products; one 16 x 16 tile of every hidden layer's weight gradient is summed in four quarters
         enc4, dec4 = G._models(N, che, chd, dev, seed=5)
