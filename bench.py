@@ -246,8 +246,11 @@ def _time_cgmlp(net, lvl, M, reps=20):
         Nn._check(L.lgn_cgmlp_bwd_f64(M, C, H, len(ws), 0, wp, bp, P(s_in), P(g_out), P(g_in), P(part), psize, Nn.stream_ptr()), "lgn_cgmlp_bwd_f64")
 
     us_f, us_b = _events_us(fwd, reps), _events_us(bwd, reps)
-    chain = M >= 8129 and H in (12, 24, 36, 48) and H == 12 * C and os.environ.get("LGN_AMD_MLP_V1") != "1"
-    name = ("mlp_chain_{}_kernel<%d, %d, false, false>" % (H, 2 * C)) if chain else ("mlp_{}_mfma_kernel (H = %d)" % H)
+    chain = H in (12, 24, 36, 48) and H == 12 * C and os.environ.get("LGN_AMD_MLP_V1") != "1"
+    one_role = os.environ.get("LGN_AMD_MLP_BWD1") == "1"
+    # (csrc/mlp_chain.hip: 64-row workgroups from 8 129 rows on -- eight waves in two roles unless LGN_AMD_MLP_BWD1 --, 16-row ones below)
+    name = (("mlp_chain_{}_kernel<%d, %d, ...> (one role per wave)" if one_role else "mlp_chain_{}_kernel<%d, %d, ...> / mlp_chain_bwd2_kernel (two roles)")
+            if M >= 8129 else "mlp_chain_{}16_kernel<%d, %d, ...>") % (H, 2 * C) if chain else ("mlp_{}_mfma_kernel (H = %d)" % H)
     return C, H, us_f, us_b, name
 
 
