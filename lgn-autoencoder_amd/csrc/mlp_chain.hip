@@ -1048,6 +1048,310 @@ __global__ __launch_bounds__(256) void mlp_chain_bwd16_kernel(MlpArgs<double> a)
   }
 }
 
+// ---- 16-row workgroups, every layer split over THREE chain waves (NT = 3; kept activations) ---------------------------------------
+// At small batches a CU holds one workgroup and most SIMDs idle: a layer's three output tiles go to three waves (12 matrix
+// instructions each instead of 36 in a row).  Wave t keeps its own tile of the previous layer in registers (it multiplies those
+// k-steps first) and reads the other two from the [neuron][16 rows] tile the waves publish into before the layer's barrier -- in the
+// backward those are the tiles the weight gradients are computed from anyway.  One barrier per layer; weight images by two staging
+// waves; the backward's weight gradients by two more, concurrent with the chain step of the SAME layer.
+// B operand of k-step ks (neuron 4 ks + g = tile ks >> 2, register ks & 3) for wave t in ROTATED order i -> ks = (4 t + i) mod KS
+template <class G, int KS>
+__device__ __forceinline__ void split_operands(const double* T, const double (&own)[4], int t, int c, int g, double (&hb)[KS]) {
+  const int nown = KS - 4 * t < 4 ? KS - 4 * t : 4;          // (H = 36: the last tile has one k-step)
+#pragma unroll
+  for (int i = 0; i < KS; ++i) {
+    int ks = 4 * t + i;
+    if (ks >= KS) ks -= KS;
+    const double v = T[(4 * ks + g) * G::SR + c];
+    hb[i] = (i < 4 && i < nown) ? own[i < 4 ? i : 0] : v;
+  }
+}
+template <int H, int D, bool GEN, bool SAVE>
+__global__ __launch_bounds__(320) void mlp_chain_fwd16s_kernel(MlpArgs<double> a) {
+  using G = Geo<H, D, 128>;
+  static_assert(G::NT == 3, "three chain waves");
+  constexpr int S = G::S, SR = G::SR, NH = G::NH, KSH = G::KSH, KS0 = G::KS0, HP = G::HP;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, g = lane >> 4;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  double* Wl = reinterpret_cast<double*>(smem_raw);          // 2 weight images
+  double* At = Wl + 2 * G::WSIZE;                            // 2 activation tiles [neuron][16 rows]
+  if (wave >= 3) {
+    const int st = tid - 192;
+    WRegs<G> wrA, wrB;
+    stage_prologue<G, false>(a, Wl, wrA, wrB, st);
+    lds_barrier();
+#define LGN_STAGE_STEP(Q)                                                                                            \
+  _Pragma("unroll") for (int j = 0; j < stage_pieces<G>(); ++j) stage_piece<G, false, Q>(a, Wl, wrA, wrB, st, j);    \
+  lds_barrier();
+    LGN_STAGE_STEP(0) LGN_STAGE_STEP(1) LGN_STAGE_STEP(2) LGN_STAGE_STEP(3) LGN_STAGE_STEP(4) LGN_STAGE_STEP(5)
+#undef LGN_STAGE_STEP
+    return;
+  }
+  const int t = wave, row = blockIdx.x * 16 + c;
+  v4d xb[1];
+  load_x<G>(a, row, g, xb);
+  double* hs = SAVE ? saved_ptr16<G>(a, lane) + t * 256 : nullptr;
+  lds_barrier();
+  double own[4];
+  auto finish = [&](int q, v4d& acc) {                      // activation, publication (and the backward's copy) of this wave's tile of layer q
+    double* T = At + (q & 1) * G::TSIZE;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      own[r] = act_t<GEN>(acc[r], a.act);
+      T[(16 * t + 4 * r + g) * SR + c] = own[r];
+    }
+    if (SAVE) {
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf)
+        *reinterpret_cast<v2d*>(hs + q * G::NT * 256 + 2 * hf) = v2d{own[2 * hf], own[2 * hf + 1]};      // (plain store: a small batch's copy -- 4.4 MB
+                                                                                                        // at 64 jets -- is read back from the same XCD's L2)
+    }
+  };
+  {  // layer 0: inputs from registers
+    const double* Wc = Wl;
+    const double* wa = Wc + (16 * t + c) * S + g;
+    v4d acc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = Wc[(16 * t + 4 * r + g) * S + HP];
+    mfma_stream<KS0, LOOKAHEAD>([&](int i) { return wa[4 * i]; },
+                                [&](int i, double av) { acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, xb[0][i], acc, 0, 0, 0); }, [&](int) {});
+    finish(0, acc);
+    lds_barrier();
+  }
+#pragma unroll
+  for (int q = 1; q < NH; ++q) {
+    const double* Wc = Wl + (q & 1) * G::WSIZE;
+    const double* wa = Wc + (16 * t + c) * S + g;
+    double hb[KSH];
+    split_operands<G, KSH>(At + ((q - 1) & 1) * G::TSIZE, own, t, c, g, hb);
+    v4d acc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = Wc[(16 * t + 4 * r + g) * S + HP];
+    mfma_stream<KSH, LOOKAHEAD>([&](int i) { int ks = 4 * t + i; if (ks >= KSH) ks -= KSH; return wa[4 * ks]; },
+                                [&](int i, double av) { acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, hb[i], acc, 0, 0, 0); }, [&](int) {});
+    finish(q, acc);
+    lds_barrier();
+  }
+  if (t != 0) return;
+  {  // output layer: one tile, wave 0
+    const double* Wc = Wl + (NH & 1) * G::WSIZE;
+    const double* wa = Wc + c * S + g;
+    double hb[KSH];
+    split_operands<G, KSH>(At + ((NH - 1) & 1) * G::TSIZE, own, 0, c, g, hb);
+    v4d y;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) y[r] = Wc[(4 * r + g) * S + HP];
+    mfma_stream<KSH, LOOKAHEAD>([&](int i) { return wa[4 * i]; },
+                                [&](int i, double av) { y = __builtin_amdgcn_mfma_f64_16x16x4f64(av, hb[i], y, 0, 0, 0); }, [&](int) {});
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int o = 4 * r + g;
+      if (o < D && row < a.M) a.s_out[mlp_out_index(a, o & 1, row, o >> 1)] = y[r];
+    }
+  }
+}
+
+// weight gradient of Linear L over 16 rows, tiles w, w + NW, ... (NW dW waves); wave 0 also the bias gradient
+template <class G, int L, int NW = 4>
+__device__ __forceinline__ void dw16_half(const double* Gt, const double* Xt, double* part, int w, int c, int g) {
+  constexpr int SR = G::SR, HO = G::hout(L), HI = G::hin(L);
+  constexpr int NTO = L == G::NH ? 1 : G::NT, NTI = L == 0 ? 1 : G::NT, NTL = NTO * NTI;
+  double* pW = part + G::off_w(L);
+  double qa[NTO][4], qx[NTI][4];
+#pragma unroll
+  for (int t = 0; t < NTO; ++t)
+#pragma unroll
+    for (int sk = 0; sk < 4; ++sk) qa[t][sk] = Gt[(16 * t + c) * SR + g + 4 * sk];
+#pragma unroll
+  for (int u = 0; u < NTI; ++u)
+#pragma unroll
+    for (int sk = 0; sk < 4; ++sk) qx[u][sk] = Xt[(16 * u + c) * SR + g + 4 * sk];
+  __builtin_amdgcn_sched_barrier(0);
+  v4d acc[NTL];
+  auto store = [&](int tile) {
+    const int t = tile / NTI, u = tile - t * NTI;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int o = 16 * t + 4 * r + g, k = 16 * u + c;
+      if (o < HO && k < HI) __builtin_nontemporal_store(acc[tile][r], &pW[o * HI + k]);
+    }
+  };
+  // a wave's tiles are w, w + NW, ...: the stores of one run under the matrix instructions of the next
+#pragma unroll
+  for (int tile = 0; tile < NTL; ++tile) {
+    if (tile % NW == w) {
+      const int t = tile / NTI, u = tile - t * NTI;
+      acc[tile] = v4d{0, 0, 0, 0};
+#pragma unroll
+      for (int sk = 0; sk < 4; ++sk) acc[tile] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[t][sk], qx[u][sk], acc[tile], 0, 0, 0);
+      if (tile >= NW) store(tile >= NW ? tile - NW : 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#pragma unroll
+  for (int tile = (NTL > NW ? NTL - NW : 0); tile < NTL; ++tile)      // each wave's last tile
+    if (tile % NW == w) store(tile);
+  if (w == 0) {
+#pragma unroll
+    for (int t = 0; t < NTO; ++t) {
+      double dbs = (qa[t][0] + qa[t][1]) + (qa[t][2] + qa[t][3]);
+      dbs += shfl_xor(dbs, 16);
+      dbs += shfl_xor(dbs, 32);
+      if (g == 0 && 16 * t + c < HO) __builtin_nontemporal_store(dbs, &part[G::off_b(L) + 16 * t + c]);
+    }
+  }
+}
+
+// backward with kept activations (the forward above, SAVE): 3 chain waves | 4 weight-gradient waves | 2 staging waves
+template <int H, int D, bool GEN>
+__global__ __launch_bounds__(576) void mlp_chain_bwd16s_kernel(MlpArgs<double> a) {
+  using G = Geo<H, D, 128>;
+  static_assert(G::NT == 3, "three chain waves");
+  constexpr int S = G::S, SR = G::SR, NT = G::NT, NH = G::NH, KSH = G::KSH, KS0 = G::KS0;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int c = lane & 15, g = lane >> 4;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  double* Wl = reinterpret_cast<double*>(smem_raw);          // 2 weight images
+  double* Gt = Wl + 2 * G::WSIZE;                            // 2 g_pre tiles [neuron][16 rows]
+  double* Xt = Gt + 2 * G::TSIZE;                            // 2 layer-input tiles
+  if (wave >= 7) {
+    // ================= image staging: the images start at the output layer =================
+    const int st = (int)threadIdx.x - 448;
+    WRegs<G> wrA, wrB;
+    issue_image<G, NH>(a, wrA, st);
+    issue_image<G, NH - 1>(a, wrB, st);
+    commit_image<G, NH>(Wl, wrA, st);
+    issue_image<G, NH - 2>(a, wrA, st);
+    lds_barrier();
+#define LGN_STAGE_STEP(Q)                                                                                            \
+  _Pragma("unroll") for (int j = 0; j < stage_pieces<G>(); ++j) stage_piece<G, true, Q>(a, Wl, wrA, wrB, st, j);     \
+  lds_barrier();
+    LGN_STAGE_STEP(6) LGN_STAGE_STEP(7) LGN_STAGE_STEP(8) LGN_STAGE_STEP(9) LGN_STAGE_STEP(10) LGN_STAGE_STEP(11)
+#undef LGN_STAGE_STEP
+    return;
+  }
+  if (wave >= 3) {
+    // ================= weight gradients of Linear L during the chain's step for Linear L =================
+    const int w = wave - 3;
+    double* part = a.part + (size_t)blockIdx.x * a.psize;
+    lds_barrier();
+    dw16_half<G, 6>(Gt + 0 * G::TSIZE, Xt + 0 * G::TSIZE, part, w, c, g);  lds_barrier();
+    dw16_half<G, 5>(Gt + 1 * G::TSIZE, Xt + 1 * G::TSIZE, part, w, c, g);  lds_barrier();
+    dw16_half<G, 4>(Gt + 0 * G::TSIZE, Xt + 0 * G::TSIZE, part, w, c, g);  lds_barrier();
+    dw16_half<G, 3>(Gt + 1 * G::TSIZE, Xt + 1 * G::TSIZE, part, w, c, g);  lds_barrier();
+    dw16_half<G, 2>(Gt + 0 * G::TSIZE, Xt + 0 * G::TSIZE, part, w, c, g);  lds_barrier();
+    dw16_half<G, 1>(Gt + 1 * G::TSIZE, Xt + 1 * G::TSIZE, part, w, c, g);  lds_barrier();
+    dw16_half<G, 0>(Gt, Xt, part, w, c, g);
+    return;
+  }
+  // ================= the chain: wave u owns tile u of every layer =================
+  const int u = wave, row = blockIdx.x * 16 + c;
+  STAMP(10);
+  const double* hs = saved_ptr16<G>(a, lane) + u * 256;
+  double hown[NH][4];                                        // this wave's tile of the six hidden activations
+#pragma unroll
+  for (int l = 0; l < NH; ++l)
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      const v2d v = *reinterpret_cast<const v2d*>(hs + l * NT * 256 + 2 * hf);
+      hown[l][2 * hf] = v[0];
+      hown[l][2 * hf + 1] = v[1];
+    }
+  v4d xb[1], gout[1];
+  load_x<G>(a, row, g, xb);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int o = 4 * r + g;
+    const bool ok = o < D && row < a.M;
+    const double x = a.g_out[ok ? mlp_out_index(a, o & 1, row, o >> 1) : 0];
+    gout[0][r] = ok ? x : 0.0;
+  }
+  // publication of this wave's tile (rows 16 u + 4 r + g) / of a single-tile operand (rows 4 r + g, wave 0)
+  auto publish = [&](double* T, const double (&v)[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) T[(16 * u + 4 * r + g) * SR + c] = v[r];
+  };
+  auto publish1 = [&](double* T, const v4d& v) {
+    if (u == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) T[(4 * r + g) * SR + c] = v[r];
+    }
+  };
+  STAMP(27);
+  publish1(Gt, gout[0]);                                     // dW of the output layer: g_out and h_5
+  publish(Xt, hown[NH - 1]);
+  lds_barrier();
+  STAMP(11);
+  double gp[4];                                              // this wave's tile of g_pre of the layer below
+  {  // l = 6: the output layer -- K = its 2C outputs, from registers
+    const double* Wc = Wl;
+    const double* wa = Wc + g * S + 16 * u + c;
+    v4d gin = {0, 0, 0, 0};
+    mfma_stream<KS0, LOOKAHEAD>([&](int i) { return wa[4 * i * S]; },
+                                [&](int i, double av) { gin = __builtin_amdgcn_mfma_f64_16x16x4f64(av, gout[0][i], gin, 0, 0, 0); }, [&](int) {});
+#pragma unroll
+    for (int r = 0; r < 4; ++r) gp[r] = gin[r] * act_slope_t<GEN>(hown[NH - 1][r], a.act);
+    publish(Gt + G::TSIZE, gp);                              // g_pre of Linear 5 (parity 1) and its input h_4
+    publish(Xt + G::TSIZE, hown[NH - 2]);
+    lds_barrier();
+    STAMP(12);
+  }
+#pragma unroll
+  for (int L = NH - 1; L >= 1; --L) {
+    // Linear L: g_in = W_L^T g_pre_L (this wave's tile of the inputs), image in buffer (2 NH - L) & 1 = L & 1
+    const double* Wc = Wl + (L & 1) * G::WSIZE;
+    const double* wa = Wc + g * S + 16 * u + c;
+    double hb[KSH];
+    split_operands<G, KSH>(Gt + (L & 1) * G::TSIZE, gp, u, c, g, hb);
+    v4d gin = {0, 0, 0, 0};
+    mfma_stream<KSH, LOOKAHEAD>([&](int i) { int ks = 4 * u + i; if (ks >= KSH) ks -= KSH; return wa[4 * ks * S]; },
+                                [&](int i, double av) { gin = __builtin_amdgcn_mfma_f64_16x16x4f64(av, hb[i], gin, 0, 0, 0); }, [&](int) {});
+#pragma unroll
+    for (int r = 0; r < 4; ++r) gp[r] = gin[r] * act_slope_t<GEN>(hown[L - 1][r], a.act);
+    publish(Gt + ((L - 1) & 1) * G::TSIZE, gp);              // g_pre of Linear L - 1 and its input (h_{L-2}, or the MLP's input rows)
+    if (L >= 2) publish(Xt + ((L - 1) & 1) * G::TSIZE, hown[L >= 2 ? L - 2 : 0]);
+    else publish1(Xt, xb[0]);
+    STAMP(20 + L);
+    lds_barrier();
+    STAMP(12 + NH - L);
+  }
+  if (u != 0) return;
+  {  // Linear 0: the gradient of the MLP's input rows (one tile), wave 0
+    const double* Wc = Wl;
+    const double* wa = Wc + g * S + c;
+    double hb[KSH];
+    split_operands<G, KSH>(Gt, gp, 0, c, g, hb);
+    v4d gx = {0, 0, 0, 0};
+    mfma_stream<KSH, LOOKAHEAD>([&](int i) { return wa[4 * i * S]; },
+                                [&](int i, double av) { gx = __builtin_amdgcn_mfma_f64_16x16x4f64(av, hb[i], gx, 0, 0, 0); }, [&](int) {});
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int f = 4 * r + g;
+      if (f < D && row < a.M) a.g_in[mlp_out_index(a, f & 1, row, f >> 1)] = gx[r];
+    }
+    STAMP(19);
+  }
+}
+
+template <int H, int D>
+static int launch16s(const MlpArgs<double>& a, bool backward, hipStream_t stream) {
+  using G = Geo<H, D, 128>;
+  const int nblk = cdiv(a.M, 16);
+  const size_t smem = sizeof(double) * (2 * G::WSIZE + (backward ? 4 : 2) * G::TSIZE);
+  if (backward) LGN_CHECK_ARG(a.psize == G::psize(), "cgmlp: psize %d, expected %d", a.psize, G::psize());
+  LGN_CHECK_ARG(!a.h_saved || a.h_rows >= nblk * 16, "cgmlp: the saved-activation buffer has %d rows per layer, %d rows need %d",
+                a.h_rows, a.M, nblk * 16);
+  void (*kern)(MlpArgs<double>);
+  if (backward) kern = a.act == 0 ? mlp_chain_bwd16s_kernel<H, D, false> : mlp_chain_bwd16s_kernel<H, D, true>;
+  else kern = a.h_saved ? (a.act == 0 ? mlp_chain_fwd16s_kernel<H, D, false, true> : mlp_chain_fwd16s_kernel<H, D, true, true>)
+                        : (a.act == 0 ? mlp_chain_fwd16s_kernel<H, D, false, false> : mlp_chain_fwd16s_kernel<H, D, true, false>);
+  if (smem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipLaunchKernelGGL(kern, dim3(nblk), dim3(backward ? 576 : 320), smem, stream, a);
+  LGN_CHECK_LAUNCH();
+  return 0;
+}
+
 template <int H, int D>
 static int launch16(const MlpArgs<double>& a, bool backward, hipStream_t stream) {
   using G = Geo<H, D, 128>;
@@ -1121,6 +1425,12 @@ static int launch(const MlpArgs<double>& a, bool backward, hipStream_t stream) {
 int mlp_chain_dispatch(const MlpArgs<double>& a, bool backward, hipStream_t stream) {
   if ((a.flags & LVL_MLP_V1) || a.nlin != 7) return -2;
   if (mlp_rows_per_workgroup(a.M, a.H) != 64) {             // small batches: 16-row workgroups (one chain wave + helpers)
+    // three chain waves per 16 rows: the forward always, the backward where the forward kept its activations (LGN_AMD_MLP_BWD1: the
+    // one-chain-wave kernels everywhere)
+    if (!(a.flags & LVL_MLP_BWD1) && (!backward || a.h_saved)) {
+      if (a.H == 48 && a.C == 4) return chain::launch16s<48, 8>(a, backward, stream);
+      if (a.H == 36 && a.C == 3) return chain::launch16s<36, 6>(a, backward, stream);
+    }
     if (a.H == 48 && a.C == 4) return chain::launch16<48, 8>(a, backward, stream);
     if (a.H == 36 && a.C == 3) return chain::launch16<36, 6>(a, backward, stream);
     if (a.H == 24 && a.C == 2) return chain::launch16<24, 4>(a, backward, stream);

@@ -252,6 +252,8 @@ def test_native_step_batch_regimes(B, monkeypatch):
     lc, rc = c.step(batch)
     U.assert_close(la, lc, 1e-13, "loss, chain vs 12-wave CGMLP kernels")
     U.assert_close(a.flat.grad, c.flat.grad, 1e-10, "flat gradient, chain vs 12-wave CGMLP kernels")
+    # LGN_AMD_MLP_BWD1: below 8 129 rows the 16-row kernels with ONE chain wave (the default splits every layer over three),
+    # from there on the 64-row kernels with one role per wave
     if B * N >= 8129:
         # the chain backward as one role per wave (round 5's kernel; the default splits chain and weight gradients over two sets of
         # waves): the same products; one 16 x 16 tile of every hidden layer's weight gradient is summed in four quarters
@@ -262,6 +264,14 @@ def test_native_step_batch_regimes(B, monkeypatch):
         ld, _ = d.step(batch)
         assert torch.equal(la, ld), "two-role vs one-role chain backward: loss"
         U.assert_close(a.flat.grad, d.flat.grad, 1e-13, "flat gradient, two-role vs one-role chain backward")
+    else:
+        enc4, dec4 = G._models(N, che, chd, dev, seed=5)
+        monkeypatch.setenv("LGN_AMD_MLP_BWD1", "1")
+        d = NativeTrainStep(enc4, dec4, batch_size=B, optimizer=False, use_graph=True)
+        monkeypatch.delenv("LGN_AMD_MLP_BWD1")
+        ld, _ = d.step(batch)
+        U.assert_close(la, ld, 1e-13, "loss, three chain waves vs one per 16 rows")
+        U.assert_close(a.flat.grad, d.flat.grad, 1e-11, "flat gradient, three chain waves vs one per 16 rows")
 
 
 @pytest.mark.parametrize("width,maxdim,B", [(4, 2, 280), (5, 2, 280), (7, 2, 280), (5, 2, 64), (4, 3, 280), (5, 3, 140)])
