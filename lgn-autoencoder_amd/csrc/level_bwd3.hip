@@ -585,6 +585,13 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(C <= 4
   // the other -- 36 against 46 us at 512 jets, whatever the jets hold -- which then finishes alone.  s_setprio does move the
   // advantage (priority 3 on the younger one swaps the two times exactly), but alternating it per tile only brought the two to
   // 40.5 / 46.5 us and the kernel from 50.2 to 49.4 - 50.1 us: the makespan is the CU's total work, not the order.  Not kept.)
+  // Small batches (level_jet_split: a workgroup owns 1 or 2 source groups of the jet): the waves that would idle take a share of the
+  // RECEIVER tiles of a group instead -- rs = 4 or 2 waves per group, each sweeps ntiles / rs of them; the partial node gradients meet
+  // in LDS below (round 6: at 64 jets the sweep was one wave running eight tiles in a row, 25 k of the workgroup's 43 k cycles).
+  const int gcount = ghi - glo;
+  const int rs = (!SYM && !DEC && NWV == 4 && gcount >= 1 && gcount <= 2) ? NWV / gcount : 1;      // (workgroup-uniform)
+  const int rpart = rs > 1 ? wave % rs : 0;
+  const int ntl = (N + 3) >> 2, i0lo = rs > 1 ? 4 * (rpart * ntl / rs) : 0, i0hi = rs > 1 ? min(N, 4 * ((rpart + 1) * ntl / rs)) : N;
   for (int u = 0;; ++u) {
     int rg;
     if constexpr (SYM) {                                   // groups in pairs (p, G - 1 - p): u = 2 k -> p, 2 k + 1 -> its partner
@@ -592,6 +599,9 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(C <= 4
       if (p >= (ngroups + 1) >> 1) break;
       rg = (u & 1) ? ngroups - 1 - p : p;
       if ((u & 1) && rg == p) continue;
+    } else if (rs > 1) {
+      if (u > 0) break;
+      rg = glo + wave / rs;
     } else {
       rg = glo + wave + NWV * u;
       if (rg >= ghi) break;
@@ -623,7 +633,7 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(C <= 4
 #pragma unroll
     for (int m = 0; m < 4; ++m) Gq[m] = {0, 0};
 
-    for (int i0 = 0; i0 < N; i0 += 4) {
+    for (int i0 = i0lo; i0 < i0hi; i0 += 4) {
       if (rg == glo && i0 < 32) STAMP(16 + (i0 >> 2) * 4);
       // SYM: 2 = receiver group below the source group (this tile also carries the reverse edges' radial gradient), 1 = diagonal
       // tile (both directions are lanes of the tile), 0 = above (radial gradient left to the owner of the other group)
@@ -826,11 +836,38 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(C <= 4
     }
 
     if (rg == glo) STAMP(6);
+    if (rs > 1) {
+      // receiver parts of one source group: parts 1 .. rs - 1 leave their quad sums in their own transpose tile (free after the
+      // sweep), part 0 adds them in part order and finishes the group alone (the final sums of a lane sit where Gs / Gv were)
+      double* mine = trw + lane;
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        Gs[g].r = quad_sum(Gs[g].r);  Gs[g].i = quad_sum(Gs[g].i);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) { Gv[g][m].r = quad_sum(Gv[g][m].r);  Gv[g][m].i = quad_sum(Gv[g][m].i); }
+        if (rpart != 0) {
+          mine[(g * 10 + 0) * 64] = Gs[g].r;  mine[(g * 10 + 1) * 64] = Gs[g].i;
+#pragma unroll
+          for (int m = 0; m < 4; ++m) { mine[(g * 10 + 2 + m) * 64] = Gv[g][m].r;  mine[(g * 10 + 6 + m) * 64] = Gv[g][m].i; }
+        }
+      }
+      __syncthreads();                                       // (rs > 1 is workgroup-uniform and every wave runs this iteration)
+      if (rpart != 0) break;
+      for (int pp = 1; pp < rs; ++pp) {
+        const double* oth = trw + pp * (NG + 3) * 16 * TS + lane;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          Gs[g].r += oth[(g * 10 + 0) * 64];  Gs[g].i += oth[(g * 10 + 1) * 64];
+#pragma unroll
+          for (int m = 0; m < 4; ++m) { Gv[g][m].r += oth[(g * 10 + 2 + m) * 64];  Gv[g][m].i += oth[(g * 10 + 6 + m) * 64]; }
+        }
+      }
+    }
     // node gradient of the wave's 4 particles: neighbour part (quad sum over the i slots) + direct part, written once
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       const int ch = 4 * g + cg;
-      const double sr = quad_sum(Gs[g].r), si = quad_sum(Gs[g].i);
+      const double sr = rs > 1 ? Gs[g].r : quad_sum(Gs[g].r), si = rs > 1 ? Gs[g].i : quad_sum(Gs[g].i);
       const bool wr = jok && ti == 0 && ch < C;
       const size_t e = ((size_t)b * N + jj) * C + (ch < C ? ch : 0);
       const double* gdn = gd + (jj * C + (ch < C ? ch : 0)) * 10;
@@ -842,7 +879,7 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(C <= 4
       cx<double> gvn[4];
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
-        const double vr = quad_sum(Gv[g][m].r), vi = quad_sum(Gv[g][m].i);
+        const double vr = rs > 1 ? Gv[g][m].r : quad_sum(Gv[g][m].r), vi = rs > 1 ? Gv[g][m].i : quad_sum(Gv[g][m].i);
         gvn[m] = {gdn[2 + m] + vr, gdn[6 + m] + vi};
         if (wr) {
           a.g_v_in[e * 4 + m] = gvn[m].r;
