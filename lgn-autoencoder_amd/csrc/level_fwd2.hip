@@ -344,8 +344,15 @@ __global__ __launch_bounds__(2 * BLOCK) void level_fwd2_kernel(LevelArgs<double>
         st[F::A2 + (c * 4 + m) * 2] = a2.r;  st[F::A2 + (c * 4 + m) * 2 + 1] = a2.i;
       }
     }
-  } else
-  for (int rg = (c0 >> 2) + wave; rg * 4 < c1; rg += nw) {
+  } else {
+  // Small batches (level_jet_split: this workgroup has 1 or 2 row groups): the waves that would idle take a share of a row group's
+  // PARTNER tiles -- rs = 4 or 2 waves per group; their partial aggregates land in slabs of the staging rows and are added up below
+  const int ngr = (c1 - c0 + 3) >> 2;
+  const int rs = (!DEC && nw == 4 && ngr >= 1 && ngr <= 2 && chunk >= 16) ? 4 / ngr : 1;      // (workgroup-uniform)
+  const int rpart = rs > 1 ? wave % rs : 0, ntl = (N + 3) >> 2;
+  const int jlo = rs > 1 ? 4 * (rpart * ntl / rs) : 0, jhi = rs > 1 ? min(N, 4 * ((rpart + 1) * ntl / rs)) : N;
+  for (int rg = (c0 >> 2) + (rs > 1 ? wave / rs : wave); rg * 4 < c1; rg += (rs > 1 ? nw : nw)) {
+    if (rs > 1 && rg != (c0 >> 2) + wave / rs) break;
     const int i0 = rg * 4;
     const int i = i0 + ti;
     const bool iok = i < N;
@@ -457,19 +464,19 @@ __global__ __launch_bounds__(2 * BLOCK) void level_fwd2_kernel(LevelArgs<double>
         }
       }
     };
-    {
+    if (jlo < jhi) {
       Tile ta, tb;
-      prep(0, ta);
-      int j0 = 0;
+      prep(jlo, ta);
+      int j0 = jlo;
       while (true) {
-        if (j0 + 4 < N) prep(j0 + 4, tb);
+        if (j0 + 4 < jhi) prep(j0 + 4, tb);
         agg(ta);
         j0 += 4;
-        if (j0 >= N) break;
-        if (j0 + 4 < N) prep(j0 + 4, ta);
+        if (j0 >= jhi) break;
+        if (j0 + 4 < jhi) prep(j0 + 4, ta);
         agg(tb);
         j0 += 4;
-        if (j0 >= N) break;
+        if (j0 >= jhi) break;
       }
     }
 
@@ -486,7 +493,7 @@ __global__ __launch_bounds__(2 * BLOCK) void level_fwd2_kernel(LevelArgs<double>
       }
     }
     if (tj == 0) {
-      double* st = agl + (i0 + ti - c0) * F::AGS;        // rows >= N of the last group land in the padding
+      double* st = agl + (rpart * 4 * ngr + i0 + ti - c0) * F::AGS;        // rows >= N of the last group land in the padding
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
         const int ch = 4 * g + cg;
@@ -502,6 +509,16 @@ __global__ __launch_bounds__(2 * BLOCK) void level_fwd2_kernel(LevelArgs<double>
       }
     }
     STAMP(4 + ((rg >> 2) & 3) * 4);
+  }
+  if (rs > 1) {                                             // the partner parts of a row: slabs 1 .. rs - 1 added to slab 0, in part order
+    __syncthreads();
+    const int tot = 4 * ngr * F::AGS;
+    for (int e = tid; e < tot; e += nthr) {
+      double v = agl[e];
+      for (int pp = 1; pp < rs; ++pp) v += agl[pp * tot + e];
+      agl[e] = v;
+    }
+  }
   }
   __syncthreads();
   STAMP(20);
