@@ -94,7 +94,9 @@ inline size_t mlp_saved_doubles(int M, int H, int nlin) {
 // backward drops from 24 to 17 us.  The step keeps the copy when the batch has at most this many rows.
 // (Round 5, chain kernels at 512 x 30 rows, the copy moved 16 bytes per lane and re-read two steps ahead of its use: backward
 // 33.5 -> 27.7 us, forward 11.5 -> 19.2 us -- a 12 us forward cannot absorb 35 MB of stores.  Recomputation stays.)
-constexpr int MLP_SAVE_MAX_ROWS = 4096;
+// (Round 6, 16-row chain kernels with the layers split over three waves: the copy pays up to the last batch size that runs them --
+// 256 jets x 30 rows: 0.439 -> 0.422 ms per step, 200 jets 0.431 -> 0.408 -- so the threshold is the 16-row regime itself.)
+constexpr int MLP_SAVE_MAX_ROWS = 8128;
 inline size_t mlp_save_max_rows() {          // LGN_AMD_MLP_SAVE_ROWS overrides the threshold (tuning; read once)
   static const long v = [] { const char* e = getenv("LGN_AMD_MLP_SAVE_ROWS"); return e ? atol(e) : (long)MLP_SAVE_MAX_ROWS; }();
   return (size_t)(v < 0 ? 0 : v);

@@ -47,7 +47,10 @@ def test_equivariance_harness_native_vs_reference_tables(tag):
     # deviation is rounding noise that grows like eps * gamma^2 and scatters by an order of magnitude from one gamma to the
     # next, so a point passes if it is within 20x of the reference's value at the same point OR under the smooth envelope.
     irreps = [(0, 0), (1, 1)]
-    floor = 1e-13 if maxdim == 2 else 1e-10      # (maxdim 3: the reference's own rotation table scatters between 1e-12 and 6e-10)
+    # (maxdim 2: the native metric scatters between 3e-14 and 3e-12 below gamma = 10 -- |mean(a - b) / mean(b)| of rounding noise --
+    # and WHICH boost gets the large value moves with the summation order of the pair sweep: round 6's partner split at small
+    # batches moved the maximum from gamma = 5.6 (1.9e-12) to gamma = 3.8 (3.1e-12); the floor was 1e-13 until then)
+    floor = 2e-13 if maxdim == 2 else 1e-10      # (maxdim 3: the reference's own rotation table scatters between 1e-12 and 6e-10)
     for kind, xs in (("rot", np.ones(26)), ("boost", gam)):
         ref = h[f"{tag}.{kind}_dev_output"]
         for row, (a, gm) in enumerate(zip(res[f"{kind}_dev_output"], xs)):
