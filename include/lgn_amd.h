@@ -275,7 +275,8 @@ typedef struct lgn_net_desc {
                                     kernels (moments_bwd_nodes2 + moments_bwd_G2: the round-5 form) instead of the merged one; cross-check */
 #define LGN_NET_MLP_BWD1 1024    /* LGN_AMD_MLP_BWD1=1: the chain CGMLP backward as ONE role per wave (four waves per workgroup: chain, weight
                                     gradients and image staging on the same wave -- the round-5 kernel) instead of the two-role kernel
-                                    (eight waves: four carry the chain, four the weight gradients and the staging); cross-check */
+                                    (eight waves: four carry the chain, four the weight gradients and the staging); below 8 129 rows: one chain
+                                    wave per 16-row workgroup instead of a layer split over three; cross-check */
 #define LGN_NET_SPLIT_TAIL 128   /* LGN_AMD_SPLIT_TAIL=1: the tail of a step (deferred reductions, radial finalisation, L1 + Adam) as the
                                     three separate launches instead of csrc/step_tail.hip's one (cross-check; bit-identical) */
 

@@ -350,9 +350,9 @@ __global__ __launch_bounds__(2 * BLOCK) void level_fwd2_kernel(LevelArgs<double>
   const int ngr = (c1 - c0 + 3) >> 2;
   const int rs = (!DEC && nw == 4 && ngr >= 1 && ngr <= 2 && chunk >= 16) ? 4 / ngr : 1;      // (workgroup-uniform)
   const int rpart = rs > 1 ? wave % rs : 0, ntl = (N + 3) >> 2;
-  const int jlo = rs > 1 ? 4 * (rpart * ntl / rs) : 0, jhi = rs > 1 ? min(N, 4 * ((rpart + 1) * ntl / rs)) : N;
-  for (int rg = (c0 >> 2) + (rs > 1 ? wave / rs : wave); rg * 4 < c1; rg += (rs > 1 ? nw : nw)) {
-    if (rs > 1 && rg != (c0 >> 2) + wave / rs) break;
+  // (the row group's sweep as a lambda called from two places: the whole-jet form keeps its compile-time-simple bounds -- with
+  // run-time partner bounds in the one loop the cfg2 launches were 0.8 us slower)
+  auto row_group = [&](const int rg, const int jlo, const int jhi, const int slab) __attribute__((always_inline)) {
     const int i0 = rg * 4;
     const int i = i0 + ti;
     const bool iok = i < N;
@@ -493,7 +493,7 @@ __global__ __launch_bounds__(2 * BLOCK) void level_fwd2_kernel(LevelArgs<double>
       }
     }
     if (tj == 0) {
-      double* st = agl + (rpart * 4 * ngr + i0 + ti - c0) * F::AGS;        // rows >= N of the last group land in the padding
+      double* st = agl + (slab + i0 + ti - c0) * F::AGS;        // rows >= N of the last group land in the padding
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
         const int ch = 4 * g + cg;
@@ -509,6 +509,12 @@ __global__ __launch_bounds__(2 * BLOCK) void level_fwd2_kernel(LevelArgs<double>
       }
     }
     STAMP(4 + ((rg >> 2) & 3) * 4);
+  };
+  if (rs > 1) {
+    const int rg = (c0 >> 2) + wave / rs;
+    if (rg * 4 < c1) row_group(rg, 4 * (rpart * ntl / rs), min(N, 4 * ((rpart + 1) * ntl / rs)), rpart * 4 * ngr);
+  } else {
+    for (int rg = (c0 >> 2) + wave; rg * 4 < c1; rg += nw) row_group(rg, 0, N, 0);
   }
   if (rs > 1) {                                             // the partner parts of a row: slabs 1 .. rs - 1 added to slab 0, in part order
     __syncthreads();
