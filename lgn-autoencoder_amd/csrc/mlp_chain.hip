@@ -810,7 +810,7 @@ __global__ __launch_bounds__(512) void mlp_chain_bwd2_kernel(MlpArgs<double> a) 
 // 0.05 GFLOP.  The chain form with roles needs no exchange: a workgroup is ONE chain wave (16 rows through all layers out of
 // registers), one wave for the weight gradients (K = 16 rows: four k-steps per tile, 36 matrix instructions per hidden layer: what
 // the chain wave computes meanwhile) and two waves staging the weight images -- each alone on its SIMD.  The forward keeps the
-// activations for the backward where the step asks for it (MlpArgs::h_saved, <= 4 096 rows; same register image as the 64-row
+// activations for the backward where the step asks for it (MlpArgs::h_saved, <= 8 128 rows since the split kernels below; same register image as the 64-row
 // kernels, one block per workgroup).
 template <class G>
 __device__ __forceinline__ double* saved_ptr16(const MlpArgs<double>& a, int lane) {

@@ -224,7 +224,7 @@ def test_native_step_full_size_properties(name, B, N, maxdim, che, chd):
 def test_native_step_batch_regimes(B, monkeypatch):
     """cfg2 shapes at the batch sizes that change the launch geometry: the level kernels split a jet over 8 / 4 / 2 / 1 workgroups
     (level.hpp: level_jet_split: 64 / 65 .. 128 / 129 .. 256 / more jets), the CGMLP runs 16-row workgroups with kept activations
-    (<= 4 096 rows) or without them (chain kernels with one chain wave per workgroup), or 64-row workgroups (>= 8 129 rows: 300 and 512 jets).  The graph-replayed
+    (<= 8 128 rows: chain kernels with every layer split over three waves), or 64-row workgroups (>= 8 129 rows: 300 and 512 jets).  The graph-replayed
     native step against the module / autograd path on the same weights, and at the chain-kernel sizes also against the same step
     on the 12-wave CGMLP kernels (LGN_AMD_MLP_V1=1) and on the one-role chain backward (LGN_AMD_MLP_BWD1=1)."""
     import __graft_entry__ as G
