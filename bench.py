@@ -249,7 +249,7 @@ def _time_cgmlp(net, lvl, M, reps=20):
     chain = H in (12, 24, 36, 48) and H == 12 * C and os.environ.get("LGN_AMD_MLP_V1") != "1"
     one_role = os.environ.get("LGN_AMD_MLP_BWD1") == "1"
     # (csrc/mlp_chain.hip: 64-row workgroups from 8 129 rows on -- eight waves in two roles unless LGN_AMD_MLP_BWD1 --, 16-row ones below)
-    name = (("mlp_chain_{}_kernel<%d, %d, ...> (one role per wave)" if one_role else "mlp_chain_{}_kernel<%d, %d, ...> / mlp_chain_bwd2_kernel (two roles)")
+    name = (("mlp_chain_{}_kernel<%d, %d, ...> (one role per wave)" if one_role else "mlp_chain_{}_kernel<%d, %d, ...> (two roles per workgroup: mlp_chain_bwd2_kernel / mlp_chain_fwd_kernel<..., TWO>)")
             if M >= 8129 else "mlp_chain_{}16_kernel<%d, %d, ...>") % (H, 2 * C) if chain else ("mlp_{}_mfma_kernel (H = %d)" % H)
     return C, H, us_f, us_b, name
 
