@@ -43,10 +43,18 @@ bash tools/ab.sh "$OUT/ab_tail64" LGN_AMD_SPLIT_TAIL=1 - -- --config cfg2 --batc
 echo "[evidence] A/B of the cfg5 step"
 bash tools/ab.sh "$OUT/ab_cfg5" LGN_AMD_DEC_UNFUSED=1 LGN_AMD_MOMENTS_SPLIT=1 LGN_AMD_SPLIT_TAIL=1 - -- --config cfg5 --no-extras > /dev/null 2>&1
 cp "$OUT/ab_cfg5/ab.txt" "$OUT/cfg5_ab.txt"
+# CGMLP chain kernels, round 6: the 12-wave kernels (LGN_AMD_MLP_V1=1) | one role per wave / one chain wave per 16 rows
+# (LGN_AMD_MLP_BWD1=1: round 5's chain kernels at 512 jets) | default (roles; three chain waves per 16 rows), at 512, 64 and 32 jets
+echo "[evidence] A/B of the CGMLP kernels"
+for b in 512 64 32; do
+  bash tools/ab.sh "$OUT/ab_mlp$b" LGN_AMD_MLP_V1=1 LGN_AMD_MLP_BWD1=1 - -- --config cfg2 --batch $b --no-extras > /dev/null 2>&1
+  { echo "== $b jets"; cat "$OUT/ab_mlp$b/ab.txt"; } >> "$OUT/mlp_roles_ab.txt"
+done
 echo "[evidence] kernel sequences"
 bash tools/kseq.sh cfg5 -- python3 bench.py --config cfg5 --no-cpu-baseline --no-extras --steps 3 --warmup 1 > "$OUT/kernel_sequence_cfg5.txt" 2>&1
 bash tools/kseq.sh cfg2 -- python3 bench.py --config cfg2 --no-cpu-baseline --no-extras --steps 3 --warmup 1 > "$OUT/kernel_sequence_cfg2.txt" 2>&1
-rm -f "$ROOT"/gpurun_out/ks_cfg5.log "$ROOT"/gpurun_out/ks_cfg2.log
+bash tools/kseq.sh b64 -- python3 bench.py --config cfg2 --batch 64 --no-cpu-baseline --no-extras --steps 3 --warmup 1 > "$OUT/kernel_sequence_b64.txt" 2>&1
+rm -f "$ROOT"/gpurun_out/ks_cfg5.log "$ROOT"/gpurun_out/ks_cfg2.log "$ROOT"/gpurun_out/ks_b64.log
 echo "[evidence] in-kernel stamps of the fused decoder backward and of the static encoder backward"
 { python3 tools/sep_stamps.py 2>&1 | tail -2; python3 tools/local_bench.py stamps 2>&1 | grep -v amdgpu.ids; } > "$OUT/local_stamps.txt"
 for cfg in cfg2 cfg5; do

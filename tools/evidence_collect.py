@@ -22,7 +22,7 @@ for cfg in ("cfg2", "cfg5"):
         subprocess.check_call([sys.executable, os.path.join(root, "tools", "pmc_summary.py"), d, os.path.join(prof, f"{tag}_pmc_{cfg}.json")])
     else:
         print("missing", d)
-for name in ("cfg5_ab.txt", "kernel_sequence_cfg5.txt", "kernel_sequence_cfg2.txt", "local_stamps.txt"):
+for name in ("cfg5_ab.txt", "kernel_sequence_cfg5.txt", "kernel_sequence_cfg2.txt", "kernel_sequence_b64.txt", "local_stamps.txt", "mlp_roles_ab.txt"):
     f = os.path.join(src, name)
     if os.path.exists(f):
         shutil.copy(f, os.path.join(prof, f"{tag}_{name}"))
