@@ -30,6 +30,11 @@ namespace lgn {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 namespace { LGN_STAMP_DECL }
+#ifdef LGN_STAMPS
+#define DSTAMP(i) do { if (threadIdx.x == 256 && blockIdx.x == 0) g_stamps[i] = clock64(); } while (0)
+#else
+#define DSTAMP(i) do { } while (0)
+#endif
 LGN_STAMP_READER(lgn_debug_stamps_mlp_chain)
 
 namespace chain {
@@ -676,6 +681,10 @@ __global__ __launch_bounds__(512) void mlp_chain_bwd2_kernel(MlpArgs<double> a) 
   STAMP(10);
   if (wave >= 4) {
     // ================= weight gradients + image staging =================
+    // (the SIMD arbiter serves the OLDER wave first: the chain wave of the SIMD ran its 36 matrix instructions in ~4 100 cycles and the dW
+    // wave finished alone 2 000 later; with the dW waves at a higher priority both end within ~700 cycles of each other and a
+    // backward step is 150 - 450 cycles shorter -- stamps 44.., 50.., 56.. of the debug build)
+    __builtin_amdgcn_s_setprio(2);
     const int tid = (int)threadIdx.x - 256;
     double* part = a.part + (size_t)blockIdx.x * a.psize;
     WRegs<G> wrA, wrB;
@@ -705,6 +714,7 @@ __global__ __launch_bounds__(512) void mlp_chain_bwd2_kernel(MlpArgs<double> a) 
     } else if (!dw_layer<G, L1>(Gt + (L1 & 1) * G::TSIZE, Xt + (L1 & 1) * G::TSIZE, part, w4, c, g, side)) {         \
       LGN_STAGE_ALL(q_)                                                                                              \
     }                                                                                                                \
+    DSTAMP(44 + (L));                                                                                                \
     lds_barrier();                                                                                                   \
   }
     LGN_DW_STEP(5) LGN_DW_STEP(4) LGN_DW_STEP(3) LGN_DW_STEP(2) LGN_DW_STEP(1) LGN_DW_STEP(0)
@@ -776,7 +786,9 @@ __global__ __launch_bounds__(512) void mlp_chain_bwd2_kernel(MlpArgs<double> a) 
         else publish_piece<G, NT>(Xt + ((L) & 1) * G::TSIZE, h[(L) - 1], wave, c, g, j - 4 * NT);                    \
       });                                                                                                            \
     });                                                                                                              \
+    STAMP(56 + (L));                                                                                                 \
     _Pragma("unroll") for (int r = 0; r < 4; ++r) fin(NT - 1, r);                                                    \
+    STAMP(50 + (L));                                                                                                 \
     lds_barrier();                                                                                                   \
     STAMP(12 + q_);                                                                                                  \
   }
