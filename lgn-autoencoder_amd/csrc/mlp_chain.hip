@@ -1166,7 +1166,7 @@ __global__ __launch_bounds__(320) void mlp_chain_fwd16s_kernel(MlpArgs<double> a
 
 // weight gradient of Linear L over 16 rows, tiles w, w + NW, ... (NW dW waves); wave 0 also the bias gradient
 template <class G, int L, int NW = 4>
-__device__ __forceinline__ void dw16_half(const double* Gt, const double* Xt, double* part, int w, int c, int g) {
+__device__ __forceinline__ void dw16_part(const double* Gt, const double* Xt, double* part, int w, int c, int g) {
   constexpr int SR = G::SR, HO = G::hout(L), HI = G::hin(L);
   constexpr int NTO = L == G::NH ? 1 : G::NT, NTI = L == 0 ? 1 : G::NT, NTL = NTO * NTI;
   double* pW = part + G::off_w(L);
@@ -1248,13 +1248,13 @@ __global__ __launch_bounds__(576) void mlp_chain_bwd16s_kernel(MlpArgs<double> a
     const int w = wave - 3;
     double* part = a.part + (size_t)blockIdx.x * a.psize;
     lds_barrier();
-    dw16_half<G, 6>(Gt + 0 * G::TSIZE, Xt + 0 * G::TSIZE, part, w, c, g);  lds_barrier();
-    dw16_half<G, 5>(Gt + 1 * G::TSIZE, Xt + 1 * G::TSIZE, part, w, c, g);  lds_barrier();
-    dw16_half<G, 4>(Gt + 0 * G::TSIZE, Xt + 0 * G::TSIZE, part, w, c, g);  lds_barrier();
-    dw16_half<G, 3>(Gt + 1 * G::TSIZE, Xt + 1 * G::TSIZE, part, w, c, g);  lds_barrier();
-    dw16_half<G, 2>(Gt + 0 * G::TSIZE, Xt + 0 * G::TSIZE, part, w, c, g);  lds_barrier();
-    dw16_half<G, 1>(Gt + 1 * G::TSIZE, Xt + 1 * G::TSIZE, part, w, c, g);  lds_barrier();
-    dw16_half<G, 0>(Gt, Xt, part, w, c, g);
+    dw16_part<G, 6>(Gt + 0 * G::TSIZE, Xt + 0 * G::TSIZE, part, w, c, g);  lds_barrier();
+    dw16_part<G, 5>(Gt + 1 * G::TSIZE, Xt + 1 * G::TSIZE, part, w, c, g);  lds_barrier();
+    dw16_part<G, 4>(Gt + 0 * G::TSIZE, Xt + 0 * G::TSIZE, part, w, c, g);  lds_barrier();
+    dw16_part<G, 3>(Gt + 1 * G::TSIZE, Xt + 1 * G::TSIZE, part, w, c, g);  lds_barrier();
+    dw16_part<G, 2>(Gt + 0 * G::TSIZE, Xt + 0 * G::TSIZE, part, w, c, g);  lds_barrier();
+    dw16_part<G, 1>(Gt + 1 * G::TSIZE, Xt + 1 * G::TSIZE, part, w, c, g);  lds_barrier();
+    dw16_part<G, 0>(Gt, Xt, part, w, c, g);
     return;
   }
   // ================= the chain: wave u owns tile u of every layer =================
